@@ -1,0 +1,406 @@
+"""ctypes loader for the CPU parity oracle (oracle/*.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.  Nothing under ``relearn_amd/`` may import this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+CONTINUE, TERMINATE, INTERRUPT = 0, 1, 2
+LIMIT_NONE, LIMIT_LATENT, LIMIT_VISIBLE = 0, 1, 2
+OPT_OK, OPT_LOSS_NOT_IMPROVING, OPT_CONSTRAINT_VIOLATED, OPT_NAN_LOSS, OPT_NAN_CONSTRAINT = range(5)
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class Prng(C.Structure):
+    _fields_ = [("key", C.c_uint32 * 8), ("counter", C.c_uint64), ("stream", C.c_uint64),
+                ("buf", C.c_uint32 * 64), ("index", C.c_uint32)]
+
+
+class CartPole(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "gravity", "mass_cart", "mass_pole", "length_half_pole", "friction_cart", "friction_pole", "time_step",
+        "action_force", "max_pos", "max_angle", "discount_factor",
+        "total_weight", "inv_total_mass", "mass_length_pole")] + [("use_libm", C.c_int)]
+
+
+class CartPoleState(C.Structure):
+    _fields_ = [("x", C.c_double), ("xdot", C.c_double), ("th", C.c_double), ("thdot", C.c_double),
+                ("nv_pos", C.c_int32)]
+
+
+class Chain(C.Structure):
+    _fields_ = [("size", C.c_uint64), ("discount_factor", C.c_double)]
+
+
+class Bound(C.Structure):
+    _fields_ = [("min_steps", C.c_uint64), ("slack_steps", C.c_uint64)]
+
+
+class MlpShape(C.Structure):
+    _fields_ = [("in_dim", C.c_uint32), ("hidden", C.c_uint32), ("out_dim", C.c_uint32)]
+
+
+class TrpoCfg(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("max_backtracks", C.c_uint64), ("backtrack_ratio", C.c_double),
+                ("hpv_reg_coeff", C.c_double), ("max_kl", C.c_double), ("accept_violation", C.c_int)]
+
+
+class TrpoStats(C.Structure):
+    _fields_ = [("entropy", C.c_double), ("step_size", C.c_double), ("loss_initial", C.c_double),
+                ("loss_final", C.c_double), ("constraint_val_final", C.c_double), ("step_scale", C.c_double),
+                ("num_backtracks", C.c_int64), ("status", C.c_int32), ("cg_iterations", C.c_int32)]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double)]
+
+
+class AdamState(C.Structure):
+    _fields_ = [("step", C.c_uint64), ("m", C.POINTER(C.c_float)), ("v", C.POINTER(C.c_float)), ("n", C.c_uint64)]
+
+
+class VecBuffer(C.Structure):
+    _fields_ = [("obs_dim", C.c_uint32), ("len", C.c_uint64), ("cap", C.c_uint64),
+                ("obs", C.POINTER(C.c_float)), ("next_obs", C.POINTER(C.c_float)),
+                ("action", C.POINTER(C.c_int32)), ("reward", C.POINTER(C.c_double)),
+                ("next", C.POINTER(C.c_uint8)), ("n_episode_ends", C.c_uint64), ("cap_episode_ends", C.c_uint64),
+                ("episode_ends", C.POINTER(C.c_uint64))]
+
+
+class Features(C.Structure):
+    _fields_ = [("obs_dim", C.c_uint32), ("n_steps", C.c_uint64), ("n_episodes", C.c_uint64), ("n_ext", C.c_uint64),
+                ("n_batches", C.c_uint64), ("n_ext_batches", C.c_uint64),
+                ("batch_sizes", C.POINTER(C.c_uint64)), ("ext_batch_sizes", C.POINTER(C.c_uint64)),
+                ("obs", C.POINTER(C.c_float)), ("ext_obs", C.POINTER(C.c_float)),
+                ("is_invalid", C.POINTER(C.c_uint8)), ("actions", C.POINTER(C.c_int64)),
+                ("rewards", C.POINTER(C.c_float)), ("src_index", C.POINTER(C.c_uint64))]
+
+
+class Lanes(C.Structure):
+    _fields_ = [("env", CartPole), ("limit_kind", C.c_int), ("max_steps", C.c_uint64), ("seed_env", C.c_uint64),
+                ("seed_actor", C.c_uint64), ("n_lanes", C.c_uint64), ("lane_offset", C.c_uint64),
+                ("state", C.POINTER(CartPoleState)), ("steps_remaining", C.POINTER(C.c_uint64)),
+                ("reset_count", C.POINTER(C.c_uint64)), ("t_global", C.c_uint64)]
+
+
+class PeriodStats(C.Structure):
+    _fields_ = [("rollout_seconds", C.c_double), ("update_seconds", C.c_double), ("steps", C.c_uint64),
+                ("episodes", C.c_uint64), ("mean_episode_length", C.c_double), ("trpo", TrpoStats),
+                ("critic_loss_first", C.c_float), ("critic_loss_last", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def f32p(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return _p(a, C.c_float)
+
+
+def f64p(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return _p(a, C.c_double)
+
+
+def u8p(a):
+    assert a.dtype == np.uint8 and a.flags.c_contiguous
+    return _p(a, C.c_uint8)
+
+
+def i32p(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return _p(a, C.c_int32)
+
+
+def i64p(a):
+    assert a.dtype == np.int64 and a.flags.c_contiguous
+    return _p(a, C.c_int64)
+
+
+def u64p(a):
+    assert a.dtype == np.uint64 and a.flags.c_contiguous
+    return _p(a, C.c_uint64)
+
+
+def _declare(L):
+    P = C.POINTER
+    L.oracle_prng_seed_from_u64.argtypes = [P(Prng), C.c_uint64]
+    L.oracle_prng_from_rng.argtypes = [P(Prng), P(Prng)]
+    L.oracle_prng_set_stream.argtypes = [P(Prng), C.c_uint64]
+    L.oracle_prng_set_word_pos.argtypes = [P(Prng), C.c_uint64]
+    L.oracle_prng_next_u32.argtypes = [P(Prng)]
+    L.oracle_prng_next_u32.restype = C.c_uint32
+    L.oracle_prng_next_u64.argtypes = [P(Prng)]
+    L.oracle_prng_next_u64.restype = C.c_uint64
+    L.oracle_prng_gen_f32.argtypes = [P(Prng)]
+    L.oracle_prng_gen_f32.restype = C.c_float
+    L.oracle_prng_gen_f64.argtypes = [P(Prng)]
+    L.oracle_prng_gen_f64.restype = C.c_double
+    L.oracle_prng_gen_range_u64.argtypes = [P(Prng), C.c_uint64, C.c_uint64]
+    L.oracle_prng_gen_range_u64.restype = C.c_uint64
+    L.oracle_prng_gen_bool.argtypes = [P(Prng), C.c_double]
+    L.oracle_prng_gen_bool.restype = C.c_int
+    L.oracle_prng_uniform_f64_inclusive.argtypes = [P(Prng), C.c_double, C.c_double]
+    L.oracle_prng_uniform_f64_inclusive.restype = C.c_double
+
+    L.oracle_cartpole_default.argtypes = [P(CartPole)]
+    L.oracle_cartpole_finish.argtypes = [P(CartPole)]
+    L.oracle_cartpole_initial_state.argtypes = [P(CartPole), P(Prng), P(CartPoleState)]
+    L.oracle_cartpole_next_state.argtypes = [P(CartPole), P(CartPoleState), C.c_double, P(CartPoleState)]
+    L.oracle_cartpole_step.argtypes = [P(CartPole), P(CartPoleState), C.c_int, P(C.c_double)]
+    L.oracle_cartpole_step.restype = C.c_int
+    L.oracle_chain_default.argtypes = [P(Chain)]
+    L.oracle_chain_step.argtypes = [P(Chain), P(C.c_uint64), C.c_int, P(Prng), P(C.c_double)]
+    L.oracle_chain_step.restype = C.c_int
+    L.oracle_step_limit_apply.argtypes = [C.c_int, P(C.c_uint64)]
+    L.oracle_step_limit_apply.restype = C.c_int
+    L.oracle_step_limit_remaining.argtypes = [C.c_uint64, C.c_uint64]
+    L.oracle_step_limit_remaining.restype = C.c_double
+    L.oracle_cartpole_features.argtypes = [P(CartPoleState), C.c_int, C.c_uint64, C.c_uint64, P(C.c_float)]
+    L.oracle_index_features.argtypes = [C.c_uint64, C.c_uint64, P(C.c_float)]
+
+    L.oracle_bound_divide.argtypes = [Bound, C.c_uint64]
+    L.oracle_bound_divide.restype = Bound
+    L.oracle_bound_max.argtypes = [Bound, Bound]
+    L.oracle_bound_max.restype = Bound
+    L.oracle_bound_with_default_slack.argtypes = [C.c_uint64]
+    L.oracle_bound_with_default_slack.restype = Bound
+    L.oracle_take_aligned_count.argtypes = [P(C.c_uint8), C.c_uint64, C.c_uint64, C.c_uint64]
+    L.oracle_take_aligned_count.restype = C.c_uint64
+
+    L.oracle_vecbuffer_new.argtypes = [C.c_uint32]
+    L.oracle_vecbuffer_new.restype = P(VecBuffer)
+    L.oracle_vecbuffer_free.argtypes = [P(VecBuffer)]
+    L.oracle_vecbuffer_clear.argtypes = [P(VecBuffer)]
+    L.oracle_vecbuffer_write_step.argtypes = [P(VecBuffer), P(C.c_float), C.c_int32, C.c_double, C.c_int,
+                                              P(C.c_float)]
+    L.oracle_vecbuffer_end_experience.argtypes = [P(VecBuffer)]
+
+    L.oracle_replay_new.argtypes = [C.c_uint64]
+    L.oracle_replay_new.restype = C.c_void_p
+    L.oracle_replay_free.argtypes = [C.c_void_p]
+    L.oracle_replay_write_step.argtypes = [C.c_void_p, C.c_int32, C.c_int]
+    L.oracle_replay_write_step.restype = C.c_int
+    L.oracle_replay_end_experience.argtypes = [C.c_void_p]
+    for n in ("num_steps", "num_episodes", "total_step_count"):
+        f = getattr(L, "oracle_replay_" + n)
+        f.argtypes = [C.c_void_p]
+        f.restype = C.c_uint64
+    L.oracle_replay_dump.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_uint64)]
+
+    L.oracle_packed_batch_sizes.argtypes = [P(C.c_uint64), C.c_uint64, P(C.c_uint64), C.c_uint64]
+    L.oracle_packed_batch_sizes.restype = C.c_int64
+    L.oracle_packed_order.argtypes = [P(C.c_uint64), C.c_uint64, P(C.c_uint64), P(C.c_uint64)]
+    L.oracle_discounted_cumsum_from_end_f32.argtypes = [P(C.c_float), C.c_uint64, C.c_float, P(C.c_uint64),
+                                                        C.c_uint64]
+    L.oracle_packed_trim_batch_sizes.argtypes = [P(C.c_uint64), C.c_uint64, C.c_uint64, P(C.c_uint64)]
+    L.oracle_packed_trim_batch_sizes.restype = C.c_uint64
+    L.oracle_packed_trim_end_f32.argtypes = [P(C.c_float), P(C.c_uint64), C.c_uint64, C.c_uint64, P(C.c_float)]
+
+    L.oracle_features_from_buffers.argtypes = [P(P(VecBuffer)), C.c_uint64]
+    L.oracle_features_from_buffers.restype = P(Features)
+    L.oracle_features_free.argtypes = [P(Features)]
+
+    L.oracle_mlp_num_params.argtypes = [MlpShape]
+    L.oracle_mlp_num_params.restype = C.c_uint64
+    L.oracle_mlp_init.argtypes = [MlpShape, C.c_uint64, P(C.c_float)]
+    L.oracle_mlp_forward_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_float)]
+    L.oracle_mlp_forward_batch_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
+
+    L.oracle_log_softmax_f32.argtypes = [P(C.c_float), C.c_uint32, P(C.c_float), C.c_int]
+    L.oracle_categorical_sample_u.argtypes = [P(C.c_float), C.c_uint32, C.c_float, C.c_int]
+    L.oracle_categorical_sample_u.restype = C.c_int
+    L.oracle_categorical_entropy_f32.argtypes = [P(C.c_float), C.c_uint32, C.c_int]
+    L.oracle_categorical_entropy_f32.restype = C.c_float
+    L.oracle_categorical_kl_f32.argtypes = [P(C.c_float), P(C.c_float), C.c_uint32, C.c_int]
+    L.oracle_categorical_kl_f32.restype = C.c_float
+
+    L.oracle_gae_packed.argtypes = [MlpShape, P(C.c_float), P(Features), C.c_float, C.c_float, P(C.c_float),
+                                    P(C.c_float)]
+    L.oracle_reward_to_go_packed.argtypes = [P(Features), C.c_float, P(C.c_float)]
+
+    L.oracle_trpo_cfg_default.argtypes = [P(TrpoCfg)]
+    L.oracle_policy_grad_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), P(C.c_float),
+                                         C.c_uint64, P(C.c_float), P(C.c_float)]
+    L.oracle_policy_fvp_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float), C.c_float,
+                                        P(C.c_float)]
+    L.oracle_policy_loss_kl_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_int64),
+                                            P(C.c_float), C.c_uint64, P(C.c_float), P(C.c_float)]
+    L.oracle_trpo_update_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), P(C.c_float),
+                                         C.c_uint64, P(TrpoCfg), P(TrpoStats), P(C.c_float)]
+    L.oracle_policy_grad_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), P(C.c_double),
+                                         C.c_uint64, P(C.c_double), P(C.c_double)]
+    L.oracle_policy_fvp_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), C.c_uint64, P(C.c_double),
+                                        C.c_double, P(C.c_double)]
+    L.oracle_cg_dense_f32.argtypes = [P(C.c_float), P(C.c_float), C.c_uint32, C.c_uint64, C.c_double, P(C.c_float)]
+
+    L.oracle_adam_cfg_default.argtypes = [P(AdamCfg)]
+    L.oracle_adam_new.argtypes = [C.c_uint64]
+    L.oracle_adam_new.restype = P(AdamState)
+    L.oracle_adam_free.argtypes = [P(AdamState)]
+    L.oracle_adam_step_f32.argtypes = [P(AdamState), P(AdamCfg), P(C.c_float), P(C.c_float)]
+    L.oracle_critic_grad_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_float), C.c_uint64,
+                                         P(C.c_float), P(C.c_float)]
+    L.oracle_critic_update_f32.argtypes = [MlpShape, P(C.c_float), P(AdamState), P(AdamCfg), P(C.c_float),
+                                           P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float)]
+
+    L.oracle_tabular_q_new.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double]
+    L.oracle_tabular_q_new.restype = C.c_void_p
+    L.oracle_tabular_q_free.argtypes = [C.c_void_p]
+    L.oracle_tabular_q_step_update.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_uint64]
+    L.oracle_chain_tabular_q_train.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_double),
+                                               P(C.c_uint64), P(C.c_uint64)]
+    L.oracle_chain_tabular_q_eval.argtypes = [P(C.c_double), C.c_uint64, C.c_uint64, P(C.c_int32)]
+    L.oracle_chain_tabular_q_eval.restype = C.c_double
+
+    L.oracle_lanes_new.argtypes = [P(CartPole), C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.oracle_lanes_new.restype = P(Lanes)
+    L.oracle_lanes_free.argtypes = [P(Lanes)]
+    L.oracle_lanes_reset.argtypes = [P(Lanes)]
+    L.oracle_lanes_get_state.argtypes = [P(Lanes), P(C.c_double), P(C.c_int32), P(C.c_uint64), P(C.c_uint64)]
+    L.oracle_lanes_set_state.argtypes = [P(Lanes), P(C.c_double), P(C.c_int32), P(C.c_uint64), P(C.c_uint64)]
+    L.oracle_lanes_step.argtypes = [P(Lanes), P(C.c_uint8), P(C.c_float), P(C.c_uint8), P(C.c_float), P(C.c_float)]
+    L.oracle_lanes_observe.argtypes = [P(Lanes), P(C.c_float)]
+    L.oracle_lanes_rollout.argtypes = [P(Lanes), MlpShape, P(C.c_float), C.c_uint64, P(C.c_float), P(C.c_uint8),
+                                       P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int]
+    L.oracle_lanes_gae.argtypes = [MlpShape, P(C.c_float), C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_float),
+                                   P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_float, C.c_float, P(C.c_float),
+                                   P(C.c_float), P(C.c_float)]
+    L.oracle_lanes_to_vecbuffer.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_uint8),
+                                            P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int, P(C.c_uint64)]
+    L.oracle_lanes_to_vecbuffer.restype = P(VecBuffer)
+    L.oracle_cartpole_trpo_period.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
+                                              C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_float), P(AdamState),
+                                              C.c_uint64, P(PeriodStats)]
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy-level conveniences used by the tests
+
+
+def cartpole_default(use_libm=False):
+    env = CartPole()
+    lib().oracle_cartpole_default(C.byref(env))
+    env.use_libm = 1 if use_libm else 0
+    return env
+
+
+def mlp_init(shape, seed):
+    p = np.zeros(int(lib().oracle_mlp_num_params(shape)), dtype=np.float32)
+    lib().oracle_mlp_init(shape, seed, f32p(p))
+    return p
+
+
+def mlp_forward_batch(shape, params, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((x.shape[0], shape.out_dim), dtype=np.float32)
+    lib().oracle_mlp_forward_batch_f32(shape, f32p(params), f32p(x), x.shape[0], f32p(out))
+    return out
+
+
+class LaneSim:
+    """numpy view of oracle_lanes: the engine's vectorised env restated with the scalar pieces."""
+
+    def __init__(self, n_lanes, max_steps=500, limit=LIMIT_VISIBLE, lane_offset=0, seed_env=0, seed_actor=1,
+                 env=None):
+        self.env = env if env is not None else cartpole_default()
+        self.ptr = lib().oracle_lanes_new(C.byref(self.env), limit, max_steps, n_lanes, lane_offset, seed_env,
+                                          seed_actor)
+        self.n = n_lanes
+        self.D = 5 if limit == LIMIT_VISIBLE else 4
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().oracle_lanes_free(self.ptr)
+            self.ptr = None
+
+    def reset(self):
+        lib().oracle_lanes_reset(self.ptr)
+
+    def get_state(self):
+        st = np.zeros((4, self.n), dtype=np.float64)
+        nv = np.zeros(self.n, dtype=np.int32)
+        rem = np.zeros(self.n, dtype=np.uint64)
+        rc = np.zeros(self.n, dtype=np.uint64)
+        lib().oracle_lanes_get_state(self.ptr, f64p(st), i32p(nv), u64p(rem), u64p(rc))
+        return st, nv, rem, rc
+
+    def set_state(self, st, nv, rem, rc):
+        lib().oracle_lanes_set_state(self.ptr, f64p(np.ascontiguousarray(st, dtype=np.float64)),
+                                     i32p(np.ascontiguousarray(nv, dtype=np.int32)),
+                                     u64p(np.ascontiguousarray(rem, dtype=np.uint64)),
+                                     u64p(np.ascontiguousarray(rc, dtype=np.uint64)))
+
+    def observe(self):
+        obs = np.zeros((self.D, self.n), dtype=np.float32)
+        lib().oracle_lanes_observe(self.ptr, f32p(obs))
+        return obs
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        reward = np.zeros(self.n, dtype=np.float32)
+        flag = np.zeros(self.n, dtype=np.uint8)
+        obs = np.zeros((self.D, self.n), dtype=np.float32)
+        term = np.zeros((self.D, self.n), dtype=np.float32)
+        lib().oracle_lanes_step(self.ptr, u8p(actions), f32p(reward), u8p(flag), f32p(obs), f32p(term))
+        return reward, flag, obs, term
+
+    def rollout(self, pshape, pparams, T, threads=8):
+        n, D = self.n, self.D
+        obs = np.zeros((D, T + 1, n), dtype=np.float32)
+        action = np.zeros((T, n), dtype=np.uint8)
+        reward = np.zeros((T, n), dtype=np.float32)
+        flag = np.zeros((T, n), dtype=np.uint8)
+        term = np.zeros((D, T, n), dtype=np.float32)
+        lib().oracle_lanes_rollout(self.ptr, pshape, f32p(pparams), T, f32p(obs), u8p(action), f32p(reward),
+                                   u8p(flag), f32p(term), threads)
+        return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
+
+
+def lanes_gae(cshape, cparams, traj, gamma, lam):
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    values = np.zeros((T + 1, n), dtype=np.float32)
+    adv = np.zeros((T, n), dtype=np.float32)
+    rtg = np.zeros((T, n), dtype=np.float32)
+    lib().oracle_lanes_gae(cshape, f32p(cparams), n, T, D, f32p(obs), f32p(traj["reward"]), u8p(traj["flag"]),
+                           f32p(traj["term_obs"]), gamma, lam, f32p(values), f32p(adv), f32p(rtg))
+    return values, adv, rtg
+
+
+def flat_samples(traj):
+    """[D][T+1][n] trajectory -> (obs [B][D], actions [B] i64) in the engine's flat sample order b = t*n + lane."""
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    x = np.ascontiguousarray(obs[:, :T, :].reshape(D, T * n).T, dtype=np.float32)
+    a = np.ascontiguousarray(traj["action"].reshape(T * n).astype(np.int64))
+    return x, a

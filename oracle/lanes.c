@@ -1,0 +1,353 @@
+/* lanes.c — the engine's vectorised rollout semantics restated with the scalar reference pieces,
+ * and the train_parallel-structured CPU baseline.  TEST INFRASTRUCTURE (see oracle.h).
+ *
+ * Lane model (documented in DESIGN.md §Data layout): lane g (global id) is one
+ * `Steps` iterator (src/simulation/steps.rs:113-167) over CartPole wrapped in a step limit, with
+ *   env stream   = ChaCha8Rng::seed_from_u64(seed_env),  set_stream(g); the k-th reset of the lane
+ *                  reads its 4 initial-state draws at word position 8k;
+ *   actor stream = ChaCha8Rng::seed_from_u64(seed_actor), set_stream(g); the action of global step t
+ *                  uses the single `gen::<f32>()` at word position t.
+ * A lane that ends an episode starts the next one immediately (Steps::step does the same on its next call).
+ */
+#include "oracle.h"
+#include "../include/rl_detmath.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+oracle_lanes *oracle_lanes_new(const oracle_cartpole *env, int limit_kind, uint64_t max_steps, uint64_t n_lanes,
+                               uint64_t lane_offset, uint64_t seed_env, uint64_t seed_actor) {
+  oracle_lanes *l = (oracle_lanes *)calloc(1, sizeof(*l));
+  l->env = *env;
+  l->limit_kind = limit_kind;
+  l->max_steps = max_steps;
+  l->seed_env = seed_env;
+  l->seed_actor = seed_actor;
+  l->n_lanes = n_lanes;
+  l->lane_offset = lane_offset;
+  l->state = (oracle_cartpole_state *)calloc(n_lanes, sizeof(oracle_cartpole_state));
+  l->steps_remaining = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->reset_count = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  oracle_lanes_reset(l);
+  return l;
+}
+
+void oracle_lanes_free(oracle_lanes *l) {
+  if (!l) return;
+  free(l->state);
+  free(l->steps_remaining);
+  free(l->reset_count);
+  free(l);
+}
+
+static void lane_reset(oracle_lanes *l, uint64_t i, oracle_prng *env_rng) {
+  oracle_prng_set_word_pos(env_rng, 8 * l->reset_count[i]);
+  oracle_cartpole_initial_state(&l->env, env_rng, &l->state[i]);
+  l->steps_remaining[i] = l->max_steps; /* Wrapped::initial_state (step_limit.rs:57-62, 187-192) */
+  l->reset_count[i] += 1;
+}
+
+static void lane_env_rng(const oracle_lanes *l, uint64_t i, oracle_prng *r) {
+  oracle_prng_seed_from_u64(r, l->seed_env);
+  oracle_prng_set_stream(r, l->lane_offset + i);
+}
+
+void oracle_lanes_reset(oracle_lanes *l) {
+  for (uint64_t i = 0; i < l->n_lanes; ++i) {
+    oracle_prng r;
+    lane_env_rng(l, i, &r);
+    lane_reset(l, i, &r);
+  }
+}
+
+void oracle_lanes_get_state(const oracle_lanes *l, double *state4, int32_t *nv_pos, uint64_t *steps_remaining,
+                            uint64_t *reset_count) {
+  for (uint64_t i = 0; i < l->n_lanes; ++i) {
+    state4[0 * l->n_lanes + i] = l->state[i].x;
+    state4[1 * l->n_lanes + i] = l->state[i].xdot;
+    state4[2 * l->n_lanes + i] = l->state[i].th;
+    state4[3 * l->n_lanes + i] = l->state[i].thdot;
+    nv_pos[i] = l->state[i].nv_pos;
+    steps_remaining[i] = l->steps_remaining[i];
+    reset_count[i] = l->reset_count[i];
+  }
+}
+
+void oracle_lanes_set_state(oracle_lanes *l, const double *state4, const int32_t *nv_pos,
+                            const uint64_t *steps_remaining, const uint64_t *reset_count) {
+  for (uint64_t i = 0; i < l->n_lanes; ++i) {
+    l->state[i].x = state4[0 * l->n_lanes + i];
+    l->state[i].xdot = state4[1 * l->n_lanes + i];
+    l->state[i].th = state4[2 * l->n_lanes + i];
+    l->state[i].thdot = state4[3 * l->n_lanes + i];
+    l->state[i].nv_pos = nv_pos[i];
+    l->steps_remaining[i] = steps_remaining[i];
+    l->reset_count[i] = reset_count[i];
+  }
+}
+
+static uint32_t lanes_obs_dim(const oracle_lanes *l) { return l->limit_kind == ORACLE_LIMIT_VISIBLE ? 5 : 4; }
+
+void oracle_lanes_observe(const oracle_lanes *l, float *obs_soa) {
+  uint32_t D = lanes_obs_dim(l);
+  float f[5];
+  for (uint64_t i = 0; i < l->n_lanes; ++i) {
+    oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
+    for (uint32_t d = 0; d < D; ++d) obs_soa[d * l->n_lanes + i] = f[d];
+  }
+}
+
+/* env.step of the wrapped env for one lane + auto-reset; returns the successor code */
+static int lane_step(oracle_lanes *l, uint64_t i, int action, oracle_prng *env_rng, float *reward, float *term_f) {
+  double r;
+  int succ = oracle_cartpole_step(&l->env, &l->state[i], action, &r);
+  if (l->limit_kind != ORACLE_LIMIT_NONE) succ = oracle_step_limit_apply(succ, &l->steps_remaining[i]);
+  *reward = (float)r; /* f64 reward -> f32 tensor element (features.rs:202) */
+  if (succ == ORACLE_INTERRUPT && term_f)
+    oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, term_f);
+  if (succ != ORACLE_CONTINUE) lane_reset(l, i, env_rng);
+  return succ;
+}
+
+void oracle_lanes_step(oracle_lanes *l, const uint8_t *actions, float *reward, uint8_t *flag, float *obs_next_soa,
+                       float *term_obs_soa) {
+  uint32_t D = lanes_obs_dim(l);
+  for (uint64_t i = 0; i < l->n_lanes; ++i) {
+    oracle_prng r;
+    lane_env_rng(l, i, &r);
+    float tf[5], f[5];
+    int succ = lane_step(l, i, actions[i], &r, &reward[i], tf);
+    flag[i] = (uint8_t)succ;
+    if (succ == ORACLE_INTERRUPT && term_obs_soa)
+      for (uint32_t d = 0; d < D; ++d) term_obs_soa[d * l->n_lanes + i] = tf[d];
+    if (obs_next_soa) {
+      oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
+      for (uint32_t d = 0; d < D; ++d) obs_next_soa[d * l->n_lanes + i] = f[d];
+    }
+  }
+  l->t_global += 1;
+}
+
+/* PolicyActor::act (torch/agents/policies/actor.rs:42-55): features -> Mlp::step -> Categorical -> sample */
+static int policy_act(oracle_mlp_shape ps, const float *params, const float *feat, float u) {
+  float z[16], lp[16];
+  oracle_mlp_forward_f32(ps, params, feat, z);
+  oracle_log_softmax_f32(z, ps.out_dim, lp, 0);
+  return oracle_categorical_sample_u(lp, ps.out_dim, u, 0);
+}
+
+void oracle_lanes_rollout(oracle_lanes *l, oracle_mlp_shape ps, const float *policy_params, uint64_t T, float *obs,
+                          uint8_t *action, float *reward, uint8_t *flag, float *term_obs, int n_threads) {
+  uint32_t D = lanes_obs_dim(l);
+  uint64_t n = l->n_lanes;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads > 0 ? n_threads : 1) schedule(static)
+#endif
+  for (uint64_t i = 0; i < n; ++i) {
+    oracle_prng env_rng, act_rng;
+    lane_env_rng(l, i, &env_rng);
+    oracle_prng_seed_from_u64(&act_rng, l->seed_actor);
+    oracle_prng_set_stream(&act_rng, l->lane_offset + i);
+    oracle_prng_set_word_pos(&act_rng, l->t_global);
+    float f[5], tf[5];
+    for (uint64_t t = 0; t < T; ++t) {
+      oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
+      for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + t) * n + i] = f[d];
+      float u = oracle_prng_gen_f32(&act_rng);
+      int a = policy_act(ps, policy_params, f, u);
+      float r;
+      int succ = lane_step(l, i, a, &env_rng, &r, tf);
+      action[t * n + i] = (uint8_t)a;
+      reward[t * n + i] = r;
+      flag[t * n + i] = (uint8_t)succ;
+      if (succ == ORACLE_INTERRUPT && term_obs)
+        for (uint32_t d = 0; d < D; ++d) term_obs[(d * T + t) * n + i] = tf[d];
+    }
+    oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
+    for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + T) * n + i] = f[d];
+  }
+  l->t_global += T;
+}
+
+/* Lane-major GAE and reward-to-go.  Same arithmetic as critics/mod.rs:158-199 + packed.rs:312-342
+ * (delta = (r + gamma*V') - V with each op rounded; a = a + (b * discount)), applied along each lane;
+ * an episode cut by the horizon is an Interrupt whose successor observation is obs[T]. */
+void oracle_lanes_gae(oracle_mlp_shape cs, const float *critic_params, uint64_t n, uint64_t T, uint32_t D,
+                      const float *obs, const float *reward, const uint8_t *flag, const float *term_obs, float gamma,
+                      float lambda, float *values_out, float *adv_out, float *rtg_out) {
+  float disc = lambda * gamma;
+  for (uint64_t i = 0; i < n; ++i) {
+    float x[8], v;
+    for (uint64_t t = 0; t <= T; ++t) {
+      for (uint32_t d = 0; d < D; ++d) x[d] = obs[(d * (T + 1) + t) * n + i];
+      oracle_mlp_forward_f32(cs, critic_params, x, &v);
+      values_out[t * n + i] = v;
+    }
+    float adv_next = 0.0f, rtg_next = 0.0f;
+    for (uint64_t t = T; t-- > 0;) {
+      uint8_t f = flag[t * n + i];
+      float vnext;
+      int ends;
+      if (f == ORACLE_TERMINATE) {
+        vnext = 0.0f;
+        ends = 1;
+      } else if (f == ORACLE_INTERRUPT) {
+        for (uint32_t d = 0; d < D; ++d) x[d] = term_obs[(d * T + t) * n + i];
+        oracle_mlp_forward_f32(cs, critic_params, x, &vnext);
+        ends = 1;
+      } else {
+        vnext = values_out[(t + 1) * n + i];
+        ends = (t == T - 1);
+      }
+      float r = reward[t * n + i];
+      float dn = gamma * vnext;
+      float tmp = r + dn;
+      float delta = tmp - values_out[t * n + i];
+      float a, g;
+      if (ends) {
+        a = delta;
+        g = r;
+      } else {
+        float pa = adv_next * disc;
+        a = delta + pa;
+        float pg = rtg_next * gamma;
+        g = r + pg;
+      }
+      adv_out[t * n + i] = a;
+      rtg_out[t * n + i] = g;
+      adv_next = a;
+      rtg_next = g;
+    }
+  }
+}
+
+oracle_vecbuffer *oracle_lanes_to_vecbuffer(uint64_t n, uint64_t T, uint32_t D, const float *obs,
+                                            const uint8_t *action, const float *reward, const uint8_t *flag,
+                                            const float *term_obs, int keep_last, uint64_t *lane_t_index_out) {
+  oracle_vecbuffer *b = oracle_vecbuffer_new(D);
+  float x[8], nx[8];
+  for (uint64_t i = 0; i < n; ++i) {
+    for (uint64_t t = 0; t < T; ++t) {
+      for (uint32_t d = 0; d < D; ++d) x[d] = obs[(d * (T + 1) + t) * n + i];
+      int f = flag[t * n + i];
+      const float *np = NULL;
+      if (f == ORACLE_INTERRUPT) {
+        for (uint32_t d = 0; d < D; ++d) nx[d] = term_obs[(d * T + t) * n + i];
+        np = nx;
+      } else if (f == ORACLE_CONTINUE && t == T - 1 && keep_last) {
+        for (uint32_t d = 0; d < D; ++d) nx[d] = obs[(d * (T + 1) + T) * n + i];
+        np = nx;
+        f = ORACLE_INTERRUPT;
+      }
+      if (lane_t_index_out) lane_t_index_out[b->len] = i * T + t;
+      oracle_vecbuffer_write_step(b, x, action[t * n + i], (double)reward[t * n + i], f, np);
+    }
+    oracle_vecbuffer_end_experience(b); /* each lane is one thread of experience */
+  }
+  return b;
+}
+
+/* ------------------------------------------------------------------ CPU baseline */
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
+                                 uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
+                                 float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
+                                 oracle_period_stats *stats) {
+  oracle_cartpole env;
+  oracle_cartpole_default(&env);
+  oracle_mlp_shape ps = {5, hidden, 2}, cs = {5, hidden, 1};
+  memset(stats, 0, sizeof(*stats));
+  oracle_vecbuffer **buffers = (oracle_vecbuffer **)malloc(n_threads * sizeof(*buffers));
+  oracle_prng *t_env = (oracle_prng *)malloc(n_threads * sizeof(oracle_prng));
+  oracle_prng *t_agent = (oracle_prng *)malloc(n_threads * sizeof(oracle_prng));
+  /* per-thread generators forked with from_rng (train.rs:99-106); re-derived per period from
+   * (seed, period) because this harness keeps no state between calls */
+  oracle_prng root, rng_env;
+  oracle_prng_seed_from_u64(&root, seed + 0x9e3779b97f4a7c15ULL * period_index);
+  oracle_prng_from_rng(&rng_env, &root);
+  for (uint32_t i = 0; i < n_threads; ++i) {
+    oracle_prng_from_rng(&t_env[i], &rng_env);
+    oracle_prng_from_rng(&t_agent[i], &root);
+    buffers[i] = oracle_vecbuffer_new(5);
+  }
+  double t0 = now_s();
+  uint64_t n_take_max = steps_per_thread + slack_steps;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+#endif
+  for (uint32_t i = 0; i < n_threads; ++i) {
+    /* TakeAlignedSteps over Steps::step (take_steps.rs:80-93; steps.rs:113-167) */
+    uint64_t n = steps_per_thread == 0 ? 0 : n_take_max;
+    int have_state = 0;
+    oracle_cartpole_state s;
+    uint64_t remaining = 0;
+    float f[5], nf[5];
+    while (n != 0) {
+      if (!have_state) {
+        oracle_cartpole_initial_state(&env, &t_env[i], &s);
+        remaining = max_steps;
+        have_state = 1;
+      }
+      oracle_cartpole_features(&s, ORACLE_LIMIT_VISIBLE, remaining, max_steps, f);
+      float u = oracle_prng_gen_f32(&t_agent[i]);
+      int a = policy_act(ps, policy_params, f, u);
+      double r;
+      int succ = oracle_cartpole_step(&env, &s, a, &r);
+      succ = oracle_step_limit_apply(succ, &remaining);
+      const float *np = NULL;
+      if (succ == ORACLE_INTERRUPT) {
+        oracle_cartpole_features(&s, ORACLE_LIMIT_VISIBLE, remaining, max_steps, nf);
+        np = nf;
+      }
+      if (succ != ORACLE_CONTINUE) have_state = 0;
+      oracle_vecbuffer_write_step(buffers[i], f, a, r, succ, np);
+      n -= 1;
+      if (succ != ORACLE_CONTINUE && n <= slack_steps) n = 0;
+    }
+    oracle_vecbuffer_end_experience(buffers[i]);
+  }
+  double t1 = now_s();
+  stats->rollout_seconds = t1 - t0;
+  /* ActorCriticAgent::batch_update_slice (torch/agents/actor_critic.rs:176-211), single thread */
+  oracle_features *feat = oracle_features_from_buffers(buffers, n_threads);
+  stats->steps = feat->n_steps;
+  stats->episodes = feat->n_episodes;
+  stats->mean_episode_length = feat->n_episodes ? (double)feat->n_steps / (double)feat->n_episodes : 0.0;
+  float gamma = (float)fmin(0.99, env.discount_factor); /* critics/opt.rs:73 */
+  float *adv = (float *)malloc(sizeof(float) * (feat->n_steps ? feat->n_steps : 1));
+  float *rtg = (float *)malloc(sizeof(float) * (feat->n_steps ? feat->n_steps : 1));
+  oracle_gae_packed(cs, critic_params, feat, gamma, 0.95f, adv, NULL);
+  oracle_trpo_cfg cfg;
+  oracle_trpo_cfg_default(&cfg);
+  oracle_trpo_update_f32(ps, policy_params, feat->obs, feat->actions, adv, feat->n_steps, &cfg, &stats->trpo, NULL);
+  oracle_reward_to_go_packed(feat, gamma, rtg);
+  oracle_adam_cfg acfg;
+  oracle_adam_cfg_default(&acfg);
+  float *losses = (float *)malloc(sizeof(float) * (critic_steps ? critic_steps : 1));
+  oracle_critic_update_f32(cs, critic_params, critic_opt, &acfg, feat->obs, rtg, feat->n_steps, critic_steps, losses);
+  if (critic_steps) {
+    stats->critic_loss_first = losses[0];
+    stats->critic_loss_last = losses[critic_steps - 1];
+  }
+  stats->update_seconds = now_s() - t1;
+  free(losses);
+  free(adv);
+  free(rtg);
+  oracle_features_free(feat);
+  for (uint32_t i = 0; i < n_threads; ++i) oracle_vecbuffer_free(buffers[i]);
+  free(buffers);
+  free(t_env);
+  free(t_agent);
+}

@@ -1,0 +1,377 @@
+/* nn.c — oracle restatement of the MLP, Categorical, GAE, TRPO (conjugate-gradient trust region),
+ * Adam and the ValuesOpt critic update.  TEST INFRASTRUCTURE (see oracle.h).
+ */
+#include "oracle.h"
+#include "../include/rl_chacha.h"
+#include "../include/rl_detmath.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+uint64_t oracle_mlp_num_params(oracle_mlp_shape s) {
+  return (uint64_t)s.hidden * s.in_dim + s.hidden + (uint64_t)s.out_dim * s.hidden + s.out_dim;
+}
+
+/* ---- instantiate the shared update math for f32 (engine transcendental contract) and f64 (libm) */
+#define REAL float
+#define SUF _f32
+#define RFMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define REXP(x) rl_expf(x)
+#define RLOG(x) rl_logf(x)
+#define RMIN (-FLT_MAX)
+#include "nn_impl.inc"
+#undef REAL
+#undef SUF
+#undef RFMA
+#undef REXP
+#undef RLOG
+#undef RMIN
+
+#define REAL double
+#define SUF _f64
+#define RFMA(a, b, c) __builtin_fma((a), (b), (c))
+#define REXP(x) exp(x)
+#define RLOG(x) log(x)
+#define RMIN (-DBL_MAX)
+#include "nn_impl.inc"
+#undef REAL
+#undef SUF
+#undef RFMA
+#undef REXP
+#undef RLOG
+#undef RMIN
+
+/* ------------------------------------------------------------------ init
+ * Linear::new (ff/linear.rs:54-68): fan_in = in_dim + 1 for kernel AND bias; Initializer default
+ * Uniform(FanAvg) => lim = sqrt(3 * 2 / (fan_in + fan_out)) (initializers.rs:31-38, 78-108, 159-163);
+ * kernel fan_out = out_dim (shape [out, in]); bias shape [out] => fan_out = out (calculate_fan_in_and_fan_out
+ * with a 1-D shape: shape[0]).  libtorch's RNG is never seeded by the reference, so the draw
+ * stream is engine-defined: ChaCha8(seed), stream 0, one `gen::<f32>()` per element in flat order,
+ * value = (2u - 1) * lim computed in f32. */
+void oracle_mlp_init(oracle_mlp_shape s, uint64_t seed, float *params) {
+  oracle_prng r;
+  oracle_prng_seed_from_u64(&r, seed);
+  uint32_t dims[2][2] = {{s.in_dim, s.hidden}, {s.hidden, s.out_dim}};
+  float *p = params;
+  for (int l = 0; l < 2; ++l) {
+    uint32_t in = dims[l][0], out = dims[l][1];
+    float lim = (float)sqrt(3.0 * (2.0 / ((double)(in + 1) + (double)out)));
+    uint64_t n = (uint64_t)in * out + out;
+    for (uint64_t i = 0; i < n; ++i) {
+      float u = oracle_prng_gen_f32(&r);
+      *p++ = (2.0f * u - 1.0f) * lim;
+    }
+  }
+}
+
+void oracle_mlp_forward_f32(oracle_mlp_shape s, const float *params, const float *x, float *out) {
+  mlp_view_f32 m = view_f32(s, params);
+  float *pre = (float *)malloc(sizeof(float) * 2 * m.H);
+  mlp_fwd_f32(&m, x, pre, pre + m.H, out);
+  free(pre);
+}
+
+void oracle_mlp_forward_batch_f32(oracle_mlp_shape s, const float *params, const float *x, uint64_t n, float *out) {
+  mlp_view_f32 m = view_f32(s, params);
+  float *pre = (float *)malloc(sizeof(float) * 2 * m.H);
+  for (uint64_t i = 0; i < n; ++i) mlp_fwd_f32(&m, x + i * m.D, pre, pre + m.H, out + i * m.A);
+  free(pre);
+}
+
+/* ------------------------------------------------------------------ Categorical
+ * src/torch/distributions/categorical.rs:29-77 */
+static float expf_sel(float x, int use_libm) { return use_libm ? expf(x) : rl_expf(x); }
+static float logf_sel(float x, int use_libm) { return use_libm ? logf(x) : rl_logf(x); }
+
+void oracle_log_softmax_f32(const float *z, uint32_t n, float *lp, int use_libm) {
+  float m = z[0];
+  for (uint32_t a = 1; a < n; ++a)
+    if (z[a] > m) m = z[a];
+  float s = 0.0f;
+  for (uint32_t a = 0; a < n; ++a) s += expf_sel(z[a] - m, use_libm);
+  float ls = logf_sel(s, use_libm);
+  for (uint32_t a = 0; a < n; ++a) lp[a] = (z[a] - m) - ls;
+}
+
+/* `log_probs.exp().multinomial(1, true)` (categorical.rs:53) with an explicit uniform: inverse CDF over
+ * p_a = exp(lp_a) accumulated in index order; the last index absorbs rounding. */
+int oracle_categorical_sample_u(const float *lp, uint32_t n, float u, int use_libm) {
+  float cum = 0.0f;
+  for (uint32_t a = 0; a + 1 < n; ++a) {
+    cum += expf_sel(lp[a], use_libm);
+    if (u < cum) return (int)a;
+  }
+  return (int)(n - 1);
+}
+
+float oracle_categorical_entropy_f32(const float *lp, uint32_t n, int use_libm) {
+  float s = 0.0f;
+  for (uint32_t a = 0; a < n; ++a) {
+    float c = lp[a] < -FLT_MAX ? -FLT_MAX : lp[a];
+    s += c * expf_sel(lp[a], use_libm);
+  }
+  return -s;
+}
+
+float oracle_categorical_kl_f32(const float *lp_self, const float *lp_other, uint32_t n, int use_libm) {
+  float s = 0.0f;
+  for (uint32_t a = 0; a < n; ++a) {
+    float rel = lp_self[a] - lp_other[a];
+    if (rel < -FLT_MAX) rel = -FLT_MAX;
+    s += rel * expf_sel(lp_self[a], use_libm);
+  }
+  return s;
+}
+
+/* ------------------------------------------------------------------ GAE on packed features
+ * eval_extended_state_values / temporal_differences / gae (critics/mod.rs:116-131, 158-199) */
+void oracle_gae_packed(oracle_mlp_shape cs, const float *critic_params, const oracle_features *f, float gamma,
+                       float lambda, float *adv_out, float *ext_values_out) {
+  float *ext = (float *)malloc(sizeof(float) * (f->n_ext ? f->n_ext : 1));
+  oracle_mlp_forward_batch_f32(cs, critic_params, f->ext_obs, f->n_ext, ext); /* out_dim == 1 => squeeze */
+  for (uint64_t i = 0; i < f->n_ext; ++i)
+    if (f->is_invalid[i]) ext[i] = 0.0f; /* masked_fill_ */
+  if (ext_values_out) memcpy(ext_values_out, ext, sizeof(float) * f->n_ext);
+  float *v = (float *)malloc(sizeof(float) * (f->n_steps ? f->n_steps : 1));
+  oracle_packed_trim_end_f32(ext, f->ext_batch_sizes, f->n_ext_batches, 1, v);
+  const float *vnext = ext + f->n_episodes; /* view_trim_start(1): skip the first time slice */
+  for (uint64_t i = 0; i < f->n_steps; ++i) {
+    float dn = gamma * vnext[i];
+    float t = f->rewards[i] + dn;
+    adv_out[i] = t - v[i];
+  }
+  float disc = lambda * gamma; /* f32 product (critics/mod.rs:198) */
+  oracle_discounted_cumsum_from_end_f32(adv_out, f->n_steps, disc, f->batch_sizes, f->n_batches);
+  free(v);
+  free(ext);
+}
+
+/* reward_to_go (critics/mod.rs:101-105) */
+void oracle_reward_to_go_packed(const oracle_features *f, float gamma, float *out) {
+  memcpy(out, f->rewards, sizeof(float) * f->n_steps);
+  oracle_discounted_cumsum_from_end_f32(out, f->n_steps, gamma, f->batch_sizes, f->n_batches);
+}
+
+/* ------------------------------------------------------------------ conjugate gradient + TRPO step */
+void oracle_trpo_cfg_default(oracle_trpo_cfg *c) {
+  /* ConjugateGradientOptimizerConfig::default (conjugate_gradient.rs:55-65); TrpoConfig (trpo.rs:38) */
+  c->iterations = 10;
+  c->max_backtracks = 15;
+  c->backtrack_ratio = 0.8;
+  c->hpv_reg_coeff = 1e-5;
+  c->accept_violation = 0;
+  c->max_kl = 0.01;
+}
+
+static float dot_f32(const float *a, const float *b, uint64_t n) {
+  double s = 0.0;
+  for (uint64_t i = 0; i < n; ++i) s += (double)(a[i] * b[i]);
+  return (float)s;
+}
+
+typedef void (*matvec_fn)(void *ctx, const float *v, float *out);
+
+/* solve_conjugate_gradient (conjugate_gradient.rs:371-403) */
+static int solve_cg(matvec_fn f_Ax, void *ctx, const float *b, uint64_t n, uint64_t iterations, double tol, float *x) {
+  float *r = (float *)malloc(sizeof(float) * 3 * n), *p = r + n, *z = p + n;
+  memset(x, 0, sizeof(float) * n);
+  memcpy(r, b, sizeof(float) * n);
+  memcpy(p, b, sizeof(float) * n);
+  float rr = dot_f32(r, r, n);
+  int iters = 0;
+  for (uint64_t it = 0; it < iterations; ++it) {
+    f_Ax(ctx, p, z);
+    iters += 1;
+    float alpha = rr / dot_f32(p, z, n);
+    for (uint64_t i = 0; i < n; ++i) x[i] = x[i] + alpha * p[i];
+    float nalpha = -alpha;
+    for (uint64_t i = 0; i < n; ++i) r[i] = r[i] + nalpha * z[i];
+    float new_rr = dot_f32(r, r, n);
+    if ((double)new_rr < tol) break;
+    float mu = new_rr / rr;
+    for (uint64_t i = 0; i < n; ++i) p[i] = p[i] * mu;
+    for (uint64_t i = 0; i < n; ++i) p[i] = p[i] + r[i];
+    rr = new_rr;
+  }
+  free(r);
+  return iters;
+}
+
+typedef struct { const float *A; uint32_t n; } dense_ctx;
+static void dense_mv(void *c, const float *v, float *out) {
+  dense_ctx *d = (dense_ctx *)c;
+  for (uint32_t i = 0; i < d->n; ++i) out[i] = dot_f32(d->A + (size_t)i * d->n, v, d->n);
+}
+void oracle_cg_dense_f32(const float *A, const float *b, uint32_t n, uint64_t iterations, double tol, float *x) {
+  dense_ctx c = {A, n};
+  solve_cg(dense_mv, &c, b, n, iterations, tol, x);
+}
+
+typedef struct {
+  oracle_mlp_shape s;
+  const float *params, *obs;
+  uint64_t n;
+  float reg;
+} fvp_ctx;
+static void fvp_mv(void *c, const float *v, float *out) {
+  fvp_ctx *f = (fvp_ctx *)c;
+  oracle_policy_fvp_f32(f->s, f->params, f->obs, f->n, v, f->reg, out);
+}
+
+/* Trpo::update -> ConjugateGradientOptimizer::trust_region_backward_step + backtracking_line_search
+ * (policies/trpo.rs:97-164; optimizers/conjugate_gradient.rs:115-255) */
+void oracle_trpo_update_f32(oracle_mlp_shape s, float *params, const float *obs, const int64_t *actions,
+                            const float *adv, uint64_t n, const oracle_trpo_cfg *cfg, oracle_trpo_stats *st,
+                            float *step_dir_out) {
+  uint64_t P = oracle_mlp_num_params(s);
+  float *g = (float *)malloc(sizeof(float) * 4 * P), *x = g + P, *hx = x + P, *prev = hx + P;
+  memset(st, 0, sizeof(*st));
+  /* entropy of the initial distribution (trpo.rs:112-122) */
+  {
+    mlp_view_f32 m = view_f32(s, params);
+    float *pre = (float *)malloc(sizeof(float) * (2 * m.H + 2 * m.A));
+    float *h = pre + m.H, *z = h + m.H, *lp = z + m.A;
+    double e = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+      mlp_fwd_f32(&m, obs + i * m.D, pre, h, z);
+      log_softmax_f32(z, m.A, lp);
+      e += (double)oracle_categorical_entropy_f32(lp, m.A, 0);
+    }
+    st->entropy = (double)(float)(e / (double)n);
+    free(pre);
+  }
+  float loss0;
+  oracle_policy_grad_f32(s, params, obs, actions, adv, n, g, &loss0);
+  fvp_ctx ctx = {s, params, obs, n, (float)cfg->hpv_reg_coeff};
+  st->cg_iterations = solve_cg(fvp_mv, &ctx, g, P, cfg->iterations, 1e-10, x);
+  for (uint64_t i = 0; i < P; ++i) { /* nan_to_num_(0.0, None, None) */
+    if (x[i] != x[i]) x[i] = 0.0f;
+    else if (isinf(x[i])) x[i] = x[i] > 0 ? FLT_MAX : -FLT_MAX;
+  }
+  if (step_dir_out) memcpy(step_dir_out, x, sizeof(float) * P);
+  fvp_mv(&ctx, x, hx);
+  double xhx = (double)dot_f32(x, hx, P);
+  double step_size = sqrt(1.0 / (xhx + 1e-8) * cfg->max_kl * 2.0);
+  if (step_size != step_size) step_size = 1.0;
+  st->step_size = step_size;
+  /* descent_step = step_size * step_dir : f32 tensor times a double scalar => f32 multiply */
+  float ss = (float)step_size;
+  for (uint64_t i = 0; i < P; ++i) x[i] = ss * x[i];
+  double initial_loss = (double)loss0;
+  st->loss_initial = initial_loss;
+  memcpy(prev, params, sizeof(float) * P);
+  double loss = initial_loss, cval = INFINITY;
+  st->num_backtracks = -1;
+  for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
+    double ratio = 1.0;
+    for (uint64_t k = 0; k < i; ++k) ratio *= cfg->backtrack_ratio; /* powi */
+    float rf = (float)ratio;
+    for (uint64_t k = 0; k < P; ++k) params[k] = prev[k] - rf * x[k];
+    float lf, kf;
+    oracle_policy_loss_kl_f32(s, params, prev, obs, actions, adv, n, &lf, &kf);
+    loss = (double)lf;
+    cval = (double)kf;
+    if (loss < initial_loss && cval <= cfg->max_kl) {
+      st->num_backtracks = (int64_t)i;
+      st->step_scale = ratio;
+      break;
+    }
+  }
+  st->loss_final = loss;
+  st->constraint_val_final = cval;
+  if (loss != loss) st->status = ORACLE_OPT_NAN_LOSS;
+  else if (cval != cval) st->status = ORACLE_OPT_NAN_CONSTRAINT;
+  else if (loss >= initial_loss) st->status = ORACLE_OPT_LOSS_NOT_IMPROVING;
+  else if (cval >= cfg->max_kl && !cfg->accept_violation) st->status = ORACLE_OPT_CONSTRAINT_VIOLATED;
+  else st->status = ORACLE_OPT_OK;
+  if (st->status != ORACLE_OPT_OK) memcpy(params, prev, sizeof(float) * P);
+  free(g);
+}
+
+/* ------------------------------------------------------------------ Adam
+ * COptimizer::adam (optimizers/coptimizer.rs:158-167) -> torch::optim::Adam of libtorch 1.12 (third party,
+ * not under /root/reference): amsgrad off, eps 1e-8 default. */
+void oracle_adam_cfg_default(oracle_adam_cfg *c) {
+  c->lr = 1e-3;
+  c->beta1 = 0.9;
+  c->beta2 = 0.999;
+  c->eps = 1e-8;
+  c->weight_decay = 0.0;
+}
+
+oracle_adam_state *oracle_adam_new(uint64_t n) {
+  oracle_adam_state *st = (oracle_adam_state *)calloc(1, sizeof(*st));
+  st->n = n;
+  st->m = (float *)calloc(n, sizeof(float));
+  st->v = (float *)calloc(n, sizeof(float));
+  return st;
+}
+
+void oracle_adam_free(oracle_adam_state *st) {
+  if (!st) return;
+  free(st->m);
+  free(st->v);
+  free(st);
+}
+
+void oracle_adam_step_f32(oracle_adam_state *st, const oracle_adam_cfg *cfg, float *params, const float *grad) {
+  st->step += 1;
+  double bc1 = 1.0 - pow(cfg->beta1, (double)st->step);
+  double bc2 = 1.0 - pow(cfg->beta2, (double)st->step);
+  float b1 = (float)cfg->beta1, b2 = (float)cfg->beta2;
+  float omb1 = (float)(1.0 - cfg->beta1), omb2 = (float)(1.0 - cfg->beta2);
+  float sqrt_bc2 = (float)sqrt(bc2);
+  float step_size = (float)(cfg->lr / bc1);
+  float eps = (float)cfg->eps;
+  for (uint64_t i = 0; i < st->n; ++i) {
+    float gi = grad[i];
+    if (cfg->weight_decay != 0.0) gi = gi + (float)cfg->weight_decay * params[i];
+    st->m[i] = st->m[i] * b1 + omb1 * gi;
+    st->v[i] = st->v[i] * b2 + omb2 * gi * gi;
+    float denom = sqrtf(st->v[i]) / sqrt_bc2 + eps;
+    params[i] = params[i] + ((-step_size) * st->m[i]) / denom; /* addcdiv_(exp_avg, denom, -step_size) */
+  }
+}
+
+/* ------------------------------------------------------------------ ValuesOpt critic
+ * loss = mse_loss(critic(obs).squeeze(-1), targets, Mean) (critics/opt.rs:109-115) */
+void oracle_critic_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const float *targets,
+                            uint64_t n, float *grad_out, float *loss_out) {
+  mlp_view_f32 m = view_f32(s, params);
+  uint64_t P = oracle_mlp_num_params(s);
+  double *g = (double *)calloc(P, sizeof(double));
+  float *pre = (float *)malloc(sizeof(float) * (2 * m.H + 2));
+  float *h = pre + m.H, *z = h + m.H, *dz = z + 1;
+  double loss = 0.0;
+  float two_over_n = 2.0f / (float)n;
+  for (uint64_t i = 0; i < n; ++i) {
+    const float *x = obs + i * m.D;
+    mlp_fwd_f32(&m, x, pre, h, z);
+    float d = z[0] - targets[i];
+    loss += (double)(d * d);
+    dz[0] = d * two_over_n;
+    mlp_bwd_acc_f32(&m, x, pre, h, dz, g);
+  }
+  for (uint64_t i = 0; i < P; ++i) grad_out[i] = (float)g[i];
+  if (loss_out) *loss_out = (float)(loss / (double)n);
+  free(pre);
+  free(g);
+}
+
+/* ValuesOpt::update via n_backward_steps (critics/opt.rs:100-126; torch/agents/mod.rs:35-72;
+ * COptimizer::backward_step coptimizer.rs:14-26) */
+void oracle_critic_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,
+                              const float *obs, const float *targets, uint64_t n, uint64_t n_steps,
+                              float *losses_out) {
+  uint64_t P = oracle_mlp_num_params(s);
+  float *g = (float *)malloc(sizeof(float) * P);
+  for (uint64_t k = 0; k < n_steps; ++k) {
+    float loss;
+    oracle_critic_grad_f32(s, params, obs, targets, n, g, &loss);
+    if (losses_out) losses_out[k] = loss;
+    oracle_adam_step_f32(st, cfg, params, g);
+  }
+  free(g);
+}

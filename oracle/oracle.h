@@ -1,0 +1,324 @@
+/* oracle.h — CPU restatement of the reference (edlanglois/relearn v0.3.1) hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under relearn_amd/ links, loads or calls this library.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and there
+ * only as the checker / the reported CPU baseline — never as the thing measured or shipped.
+ *
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - ChaCha block function: pinned by RFC 7539 (20 rounds) and eSTREAM ChaCha8 zero-key vectors.
+ *   - packed / cumsum / features / buffers / take-aligned / step-limit / categorical / CG:
+ *     pinned by the reference's own unit-test fixtures (tests/golden/reference_fixtures.json).
+ *   - MLP backward, TRPO step, Adam, GAE numerics: pinned by vectors generated with PyTorch CPU
+ *     autograd in the build container (tests/golden/make_torch_golden.py).
+ *   - rand 0.8.5 sampling conventions (seed_from_u64, Uniform, gen_range, gen_bool) and
+ *     CartPole numerics have no concrete values in the reference's tests: PARITY UNPINNED for
+ *     "same seed as the Rust binary"; they are restated from the pinned crate versions' published
+ *     algorithms.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- Prng (src/lib.rs:68) */
+typedef struct {
+  uint32_t key[8];
+  uint64_t counter; /* block counter of the NEXT buffer refill */
+  uint64_t stream;
+  uint32_t buf[64]; /* rand_chacha generates 4 blocks per refill */
+  uint32_t index;   /* next unread word; 64 = empty */
+} oracle_prng;
+
+void oracle_prng_seed_from_u64(oracle_prng *r, uint64_t seed);
+void oracle_prng_from_seed(oracle_prng *r, const uint32_t key[8]);
+void oracle_prng_from_rng(oracle_prng *out, oracle_prng *src);
+void oracle_prng_set_stream(oracle_prng *r, uint64_t stream);
+void oracle_prng_set_word_pos(oracle_prng *r, uint64_t word_pos);
+uint32_t oracle_prng_next_u32(oracle_prng *r);
+uint64_t oracle_prng_next_u64(oracle_prng *r);
+float oracle_prng_gen_f32(oracle_prng *r);
+double oracle_prng_gen_f64(oracle_prng *r);
+uint64_t oracle_prng_gen_range_u64(oracle_prng *r, uint64_t low, uint64_t high);
+int oracle_prng_gen_bool(oracle_prng *r, double p);
+double oracle_prng_uniform_f64_inclusive(oracle_prng *r, double low, double high);
+
+/* ---------------------------------------------------------------- Successor (src/envs/mod.rs:257) */
+enum { ORACLE_CONTINUE = 0, ORACLE_TERMINATE = 1, ORACLE_INTERRUPT = 2 };
+
+/* ---------------------------------------------------------------- CartPole (src/envs/cartpole.rs) */
+typedef struct {
+  double gravity, mass_cart, mass_pole, length_half_pole, friction_cart, friction_pole, time_step;
+  double action_force, max_pos, max_angle, discount_factor;
+  /* InternalPhysicalConstants (cartpole.rs:238-251) */
+  double total_weight, inv_total_mass, mass_length_pole;
+  int use_libm; /* 0: rl_detmath sincos (engine contract); 1: platform libm like the reference */
+} oracle_cartpole;
+
+typedef struct {
+  double x, xdot, th, thdot;
+  int32_t nv_pos; /* cached_normal_velocity_is_positive */
+} oracle_cartpole_state;
+
+void oracle_cartpole_default(oracle_cartpole *env);
+void oracle_cartpole_finish(oracle_cartpole *env); /* recompute derived constants */
+void oracle_cartpole_initial_state(const oracle_cartpole *env, oracle_prng *rng, oracle_cartpole_state *s);
+void oracle_cartpole_next_state(const oracle_cartpole *env, const oracle_cartpole_state *s, double force,
+                                oracle_cartpole_state *out);
+/* returns successor code; *s is overwritten with the next state unless Terminate */
+int oracle_cartpole_step(const oracle_cartpole *env, oracle_cartpole_state *s, int action, double *reward);
+
+/* ---------------------------------------------------------------- Chain (src/envs/chain.rs) */
+typedef struct { uint64_t size; double discount_factor; } oracle_chain;
+void oracle_chain_default(oracle_chain *env);
+int oracle_chain_step(const oracle_chain *env, uint64_t *state, int action, oracle_prng *rng, double *reward);
+
+/* ---------------------------------------------------------------- step limits (src/envs/wrappers/step_limit.rs) */
+enum { ORACLE_LIMIT_NONE = 0, ORACLE_LIMIT_LATENT = 1, ORACLE_LIMIT_VISIBLE = 2 };
+/* apply the wrapper's post-step rule: decrement, Continue -> Interrupt at 0 (step_limit.rs:216-222) */
+int oracle_step_limit_apply(int inner_successor, uint64_t *steps_remaining);
+double oracle_step_limit_remaining(uint64_t steps_remaining, uint64_t max_steps);
+
+/* observation features, f32 (spaces/interval.rs:108-116, index.rs:104-116, derive space.rs:504-513) */
+void oracle_cartpole_features(const oracle_cartpole_state *s, int limit_kind, uint64_t steps_remaining,
+                              uint64_t max_steps, float *out);
+void oracle_index_features(uint64_t index, uint64_t size, float *out);
+
+/* ---------------------------------------------------------------- HistoryDataBound / TakeAlignedSteps */
+typedef struct { uint64_t min_steps, slack_steps; } oracle_bound;
+oracle_bound oracle_bound_divide(oracle_bound b, uint64_t n);
+oracle_bound oracle_bound_max(oracle_bound a, oracle_bound b);
+oracle_bound oracle_bound_with_default_slack(uint64_t min_steps);
+/* how many steps TakeAlignedSteps yields given the episode_done flag of each offered step */
+uint64_t oracle_take_aligned_count(const uint8_t *episode_done, uint64_t n_available, uint64_t min_steps,
+                                   uint64_t slack_steps);
+
+/* ---------------------------------------------------------------- history buffers (generic steps) */
+/* A step with an observation vector of obs_dim floats (features are what the torch path needs;
+ * index envs use obs_dim = 1 with the index stored as a float for buffer tests). */
+typedef struct {
+  uint32_t obs_dim;
+  uint64_t len, cap;
+  float *obs;       /* [len][obs_dim] */
+  float *next_obs;  /* [len][obs_dim], meaningful where next == INTERRUPT */
+  int32_t *action;  /* [len] */
+  double *reward;   /* [len] */
+  uint8_t *next;    /* [len] successor code */
+  uint64_t n_episode_ends, cap_episode_ends;
+  uint64_t *episode_ends; /* one past the end index of each episode */
+} oracle_vecbuffer;
+
+oracle_vecbuffer *oracle_vecbuffer_new(uint32_t obs_dim);
+void oracle_vecbuffer_free(oracle_vecbuffer *b);
+void oracle_vecbuffer_clear(oracle_vecbuffer *b);
+void oracle_vecbuffer_write_step(oracle_vecbuffer *b, const float *obs, int32_t action, double reward, int next,
+                                 const float *next_obs);
+void oracle_vecbuffer_end_experience(oracle_vecbuffer *b);
+uint64_t oracle_vecbuffer_num_steps(const oracle_vecbuffer *b);
+uint64_t oracle_vecbuffer_num_episodes(const oracle_vecbuffer *b);
+/* copy-out helpers for tests */
+void oracle_vecbuffer_episode_ends(const oracle_vecbuffer *b, uint64_t *out);
+void oracle_vecbuffer_steps(const oracle_vecbuffer *b, float *obs, int32_t *action, double *reward, uint8_t *next,
+                            float *next_obs);
+
+/* replay buffer eviction rule (src/agents/buffers/replay.rs:89-115) on episode lengths only */
+typedef struct oracle_replay oracle_replay;
+oracle_replay *oracle_replay_new(uint64_t capacity);
+void oracle_replay_free(oracle_replay *r);
+int oracle_replay_write_step(oracle_replay *r, int32_t tag, int episode_done);
+void oracle_replay_end_experience(oracle_replay *r);
+uint64_t oracle_replay_num_steps(const oracle_replay *r);
+uint64_t oracle_replay_num_episodes(const oracle_replay *r);
+uint64_t oracle_replay_total_step_count(const oracle_replay *r);
+void oracle_replay_dump(const oracle_replay *r, int32_t *tags, uint64_t *episode_lens);
+
+/* ---------------------------------------------------------------- packed sequences (src/torch/packed.rs) */
+/* batch sizes from monotonically non-increasing sequence lengths; returns count or -1 on error */
+int64_t oracle_packed_batch_sizes(const uint64_t *sorted_lengths, uint64_t n_seq, uint64_t *batch_sizes_out,
+                                  uint64_t cap);
+/* packed index -> (sequence, offset) pairs in packing order */
+void oracle_packed_order(const uint64_t *sorted_lengths, uint64_t n_seq, uint64_t *seq_out, uint64_t *off_out);
+void oracle_discounted_cumsum_from_end_f32(float *data, uint64_t n, float discount, const uint64_t *batch_sizes,
+                                           uint64_t n_batches);
+/* trim helpers on batch-size vectors (packed.rs:195-267 Ragged semantics) */
+uint64_t oracle_packed_trim_batch_sizes(const uint64_t *batch_sizes, uint64_t n, uint64_t trim, uint64_t *out);
+void oracle_packed_trim_end_f32(const float *in, const uint64_t *batch_sizes, uint64_t n_batches, uint64_t trim,
+                                float *out);
+
+/* ---------------------------------------------------------------- history features (src/torch/agents/features.rs) */
+typedef struct {
+  uint32_t obs_dim;
+  uint64_t n_steps, n_episodes, n_ext;
+  uint64_t n_batches, n_ext_batches;
+  uint64_t *batch_sizes;     /* [n_batches] structure of obs/actions/rewards */
+  uint64_t *ext_batch_sizes; /* [n_ext_batches] */
+  float *obs;                /* [n_steps][obs_dim] packed */
+  float *ext_obs;            /* [n_ext][obs_dim] packed */
+  uint8_t *is_invalid;       /* [n_ext] */
+  int64_t *actions;          /* [n_steps] */
+  float *rewards;            /* [n_steps] */
+  uint64_t *src_index;       /* [n_steps] packed position -> index of the step in the source buffer order */
+} oracle_features;
+
+oracle_features *oracle_features_from_buffers(oracle_vecbuffer *const *buffers, uint64_t n_buffers);
+void oracle_features_free(oracle_features *f);
+
+/* ---------------------------------------------------------------- MLP (src/torch/modules/ff/{linear,mlp}.rs) */
+typedef struct { uint32_t in_dim, hidden, out_dim; } oracle_mlp_shape;
+uint64_t oracle_mlp_num_params(oracle_mlp_shape s);
+/* Glorot-uniform with fan_in = in+1 for kernel and bias (ff/linear.rs:54-68, initializers.rs:78-108);
+ * draws from the engine's documented init stream (ChaCha8 seed, stream 0, gen f32 per element). */
+void oracle_mlp_init(oracle_mlp_shape s, uint64_t seed, float *params);
+void oracle_mlp_forward_f32(oracle_mlp_shape s, const float *params, const float *x, float *out);
+void oracle_mlp_forward_batch_f32(oracle_mlp_shape s, const float *params, const float *x, uint64_t n, float *out);
+
+/* ---------------------------------------------------------------- Categorical (src/torch/distributions/categorical.rs) */
+void oracle_log_softmax_f32(const float *z, uint32_t n, float *lp, int use_libm);
+int oracle_categorical_sample_u(const float *lp, uint32_t n, float u, int use_libm);
+float oracle_categorical_entropy_f32(const float *lp, uint32_t n, int use_libm);
+float oracle_categorical_kl_f32(const float *lp_self, const float *lp_other, uint32_t n, int use_libm);
+
+/* ---------------------------------------------------------------- critic / GAE (src/torch/agents/critics/mod.rs) */
+/* reference-structured: packed features -> packed advantages / reward-to-go */
+void oracle_gae_packed(oracle_mlp_shape cs, const float *critic_params, const oracle_features *f, float gamma,
+                       float lambda, float *adv_out, float *ext_values_out);
+void oracle_reward_to_go_packed(const oracle_features *f, float gamma, float *out);
+
+/* ---------------------------------------------------------------- update math on flat sample arrays */
+typedef struct {
+  uint64_t iterations, max_backtracks;
+  double backtrack_ratio, hpv_reg_coeff, max_kl;
+  int accept_violation;
+} oracle_trpo_cfg;
+void oracle_trpo_cfg_default(oracle_trpo_cfg *c);
+
+enum { ORACLE_OPT_OK = 0, ORACLE_OPT_LOSS_NOT_IMPROVING = 1, ORACLE_OPT_CONSTRAINT_VIOLATED = 2,
+       ORACLE_OPT_NAN_LOSS = 3, ORACLE_OPT_NAN_CONSTRAINT = 4 };
+
+typedef struct {
+  double entropy, step_size, loss_initial, loss_final, constraint_val_final, step_scale;
+  int64_t num_backtracks; /* -1 when the line search exhausted its budget */
+  int32_t status;
+  int32_t cg_iterations;
+} oracle_trpo_stats;
+
+/* f32 arithmetic ("as reference", Kind::Float) and f64 arithmetic (ground truth for tolerances) */
+void oracle_policy_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const int64_t *actions,
+                            const float *adv, uint64_t n, float *grad_out, float *loss_out);
+void oracle_policy_fvp_f32(oracle_mlp_shape s, const float *params, const float *obs, uint64_t n, const float *v,
+                           float reg, float *out);
+void oracle_policy_loss_kl_f32(oracle_mlp_shape s, const float *params, const float *params0, const float *obs,
+                               const int64_t *actions, const float *adv, uint64_t n, float *loss, float *kl);
+void oracle_trpo_update_f32(oracle_mlp_shape s, float *params, const float *obs, const int64_t *actions,
+                            const float *adv, uint64_t n, const oracle_trpo_cfg *cfg, oracle_trpo_stats *stats,
+                            float *step_dir_out);
+void oracle_policy_grad_f64(oracle_mlp_shape s, const double *params, const double *obs, const int64_t *actions,
+                            const double *adv, uint64_t n, double *grad_out, double *loss_out);
+void oracle_policy_fvp_f64(oracle_mlp_shape s, const double *params, const double *obs, uint64_t n, const double *v,
+                           double reg, double *out);
+
+/* solve_conjugate_gradient on an explicit dense matrix (conjugate_gradient.rs:371-403), f32 */
+void oracle_cg_dense_f32(const float *A, const float *b, uint32_t n, uint64_t iterations, double tol, float *x);
+
+typedef struct { double lr, beta1, beta2, eps, weight_decay; } oracle_adam_cfg;
+void oracle_adam_cfg_default(oracle_adam_cfg *c);
+typedef struct { uint64_t step; float *m, *v; uint64_t n; } oracle_adam_state;
+oracle_adam_state *oracle_adam_new(uint64_t n);
+void oracle_adam_free(oracle_adam_state *st);
+void oracle_adam_step_f32(oracle_adam_state *st, const oracle_adam_cfg *cfg, float *params, const float *grad);
+
+void oracle_critic_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const float *targets,
+                            uint64_t n, float *grad_out, float *loss_out);
+/* n_steps x {mse; backward; adam}; losses_out[n_steps] = loss BEFORE each step (opt.rs:100-126) */
+void oracle_critic_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,
+                              const float *obs, const float *targets, uint64_t n, uint64_t n_steps,
+                              float *losses_out);
+
+/* ---------------------------------------------------------------- tabular Q (src/agents/tabular.rs) */
+typedef struct {
+  uint64_t n_obs, n_act;
+  double discount_factor, exploration_rate;
+  uint64_t *counts; /* [n_obs][n_act] */
+  double *values;   /* [n_obs][n_act] */
+} oracle_tabular_q;
+oracle_tabular_q *oracle_tabular_q_new(uint64_t n_obs, uint64_t n_act, double gamma, double eps);
+void oracle_tabular_q_free(oracle_tabular_q *q);
+int oracle_tabular_q_act(const oracle_tabular_q *q, uint64_t obs, int training, oracle_prng *rng);
+void oracle_tabular_q_step_update(oracle_tabular_q *q, uint64_t obs, uint64_t action, double reward, int next,
+                                  uint64_t next_obs);
+/* examples/chain-tabular-q.rs with `n_threads` workers run sequentially (results are independent of
+ * thread interleaving because workers only share the immutable actor snapshot). */
+void oracle_chain_tabular_q_train(uint64_t seed, uint64_t n_threads, uint64_t n_periods, uint64_t min_worker_steps,
+                                  double *q_values_out, uint64_t *counts_out, uint64_t *total_steps_out);
+/* evaluation run: SimSeed::Root(seed), greedy actor, n steps; returns sum of rewards */
+double oracle_chain_tabular_q_eval(const double *q_values, uint64_t seed, uint64_t n_steps, int32_t *actions_out);
+
+/* ---------------------------------------------------------------- lane engine restatement */
+/* The engine's vectorised semantics expressed with the scalar pieces above: lane `g` (global id)
+ * runs Steps::step (simulation/steps.rs:113-167) against its own env/actor streams. */
+typedef struct {
+  oracle_cartpole env;
+  int limit_kind;
+  uint64_t max_steps;
+  uint64_t seed_env, seed_actor;
+  uint64_t n_lanes, lane_offset;
+  /* per-lane persistent state */
+  oracle_cartpole_state *state;
+  uint64_t *steps_remaining;
+  uint64_t *reset_count;
+  uint64_t t_global; /* steps taken so far (same for every lane) */
+} oracle_lanes;
+
+oracle_lanes *oracle_lanes_new(const oracle_cartpole *env, int limit_kind, uint64_t max_steps, uint64_t n_lanes,
+                               uint64_t lane_offset, uint64_t seed_env, uint64_t seed_actor);
+void oracle_lanes_free(oracle_lanes *l);
+void oracle_lanes_reset(oracle_lanes *l);
+void oracle_lanes_get_state(const oracle_lanes *l, double *state4, int32_t *nv_pos, uint64_t *steps_remaining,
+                            uint64_t *reset_count);
+void oracle_lanes_set_state(oracle_lanes *l, const double *state4, const int32_t *nv_pos,
+                            const uint64_t *steps_remaining, const uint64_t *reset_count);
+/* one vectorised env step with given actions; outputs [n_lanes] (obs_next: [D][n_lanes] SoA) */
+void oracle_lanes_step(oracle_lanes *l, const uint8_t *actions, float *reward, uint8_t *flag, float *obs_next_soa,
+                       float *term_obs_soa);
+void oracle_lanes_observe(const oracle_lanes *l, float *obs_soa);
+/* T-step rollout with the MLP policy; time-major SoA outputs as the engine lays them out:
+ * obs [D][T+1][n], action [T][n], reward [T][n], flag [T][n], term_obs [D][T][n] (written at Interrupt) */
+void oracle_lanes_rollout(oracle_lanes *l, oracle_mlp_shape ps, const float *policy_params, uint64_t T, float *obs,
+                          uint8_t *action, float *reward, uint8_t *flag, float *term_obs, int n_threads);
+/* lane-major GAE / reward-to-go exactly as the engine defines it (horizon cut = Interrupt(obs[T])) */
+void oracle_lanes_gae(oracle_mlp_shape cs, const float *critic_params, uint64_t n, uint64_t T, uint32_t D,
+                      const float *obs, const float *reward, const uint8_t *flag, const float *term_obs, float gamma,
+                      float lambda, float *values_out, float *adv_out, float *rtg_out);
+/* convert a lane trajectory into reference-style episodes in a VecBuffer (one buffer, lanes in order);
+ * horizon cut handled with keep_last (engine rule) or the reference's drop rule (buffers/mod.rs:237-261) */
+oracle_vecbuffer *oracle_lanes_to_vecbuffer(uint64_t n, uint64_t T, uint32_t D, const float *obs,
+                                            const uint8_t *action, const float *reward, const uint8_t *flag,
+                                            const float *term_obs, int keep_last, uint64_t *lane_t_index_out);
+
+/* ---------------------------------------------------------------- CPU baseline (simulation/train.rs:68-186) */
+typedef struct {
+  double rollout_seconds, update_seconds;
+  uint64_t steps, episodes;
+  double mean_episode_length;
+  oracle_trpo_stats trpo;
+  float critic_loss_first, critic_loss_last;
+} oracle_period_stats;
+
+/* One train_parallel period of CartPole+VisibleStepLimit MLP-TRPO: `n_threads` OS threads each run the
+ * scalar Steps::step loop for `steps_per_thread` steps (TakeAlignedSteps with slack), then the calling
+ * thread does GAE -> TRPO -> critic update on the packed batch. */
+void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
+                                 uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
+                                 float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
+                                 oracle_period_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
