@@ -1,0 +1,259 @@
+/* relearn_hip.h — C ABI of the MI355X-native batched rollout-and-update engine.
+ *
+ * This is the drop-in boundary for ONE hot path of edlanglois/relearn (v0.3.1):
+ *   vectorised env step -> MLP policy/critic forward -> GAE/return scan -> TRPO + critic update.
+ * The reference has no FFI of its own (it is 100 % Rust over tch/libtorch); the boundary it offers
+ * is its trait surface.  Every entry point below names the reference interface it stands in for
+ * (paths relative to the reference tree), and INTEGRATION.md shows the `extern "C"` block a Rust
+ * maintainer adds to bind them behind `Environment` / `Actor` / `Agent` / `BatchUpdate`.
+ *
+ * Conventions
+ *   - every function returns int32_t: 0 = RL_OK, otherwise an rl_status code; no exception or abort
+ *     crosses the boundary; `rl_last_error(engine)` returns a static-lifetime-until-next-call message;
+ *   - handles are opaque, created/destroyed by the library; device memory is library-owned;
+ *   - host buffers are caller-owned and only borrowed for the duration of a call;
+ *   - a handle is NOT thread-safe: one engine per GPU, driven by one host thread;
+ *   - calls enqueue work on the engine's HIP stream; functions that return data to the host
+ *     synchronise that stream, the others may return before the GPU has finished
+ *     (`rl_engine_sync` waits);
+ *   - there is NO CPU fallback: without a visible gfx950 device `rl_engine_create` fails with
+ *     RL_ERR_NO_DEVICE.
+ *
+ * Data layout in HBM: one env per lane, struct-of-arrays, time-major trajectories
+ *   obs[d][t][lane] f32, action[t][lane] u8, reward[t][lane] f32, flag[t][lane] u8 (successor code).
+ * The flat sample index used by the update kernels is b = t * n_lanes + lane.
+ */
+#ifndef RELEARN_HIP_H
+#define RELEARN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL_ABI_VERSION 1
+
+/* ---------------------------------------------------------------------------------------------
+ * Status codes.  The non-generic ones mirror the reference's error enums:
+ *   BuildAgentError              src/agents/mod.rs:219-226
+ *   BuildEnvError                src/envs/builders.rs:62-66
+ *   WriteExperienceError::Full   src/agents/buffers/mod.rs:225-228
+ *   PackingError                 src/torch/packed.rs:18-23
+ *   OptimizerStepError           src/torch/optimizers/mod.rs:80-94 (reported in *_stats.status;
+ *                                NaN variants additionally make the call return RL_ERR_OPT_NAN because
+ *                                the reference panics on them, src/torch/agents/policies/trpo.rs:154-162)
+ */
+typedef enum {
+  RL_OK = 0,
+  RL_ERR_INVALID_ARGUMENT = 1,
+  RL_ERR_HIP = 2,
+  RL_ERR_NO_DEVICE = 3,
+  RL_ERR_BUILD_AGENT = 4,
+  RL_ERR_BUILD_ENV = 5,
+  RL_ERR_BUFFER_FULL = 6,
+  RL_ERR_PACKING = 7,
+  RL_ERR_COMM = 8,
+  RL_ERR_OPT_NAN = 9,
+  RL_ERR_UNSUPPORTED = 10
+} rl_status;
+
+/* Successor codes stored in `flag` (src/envs/mod.rs:257-269) */
+enum { RL_SUCC_CONTINUE = 0, RL_SUCC_TERMINATE = 1, RL_SUCC_INTERRUPT = 2 };
+/* OptimizerStepError as an integer (src/torch/optimizers/mod.rs:80-94) */
+enum { RL_OPT_OK = 0, RL_OPT_LOSS_NOT_IMPROVING = 1, RL_OPT_CONSTRAINT_VIOLATED = 2, RL_OPT_NAN_LOSS = 3,
+       RL_OPT_NAN_CONSTRAINT = 4 };
+/* env kinds / step-limit wrappers (src/envs/cartpole.rs, chain.rs, wrappers/step_limit.rs:13,97) */
+enum { RL_ENV_CARTPOLE = 0, RL_ENV_CHAIN = 1 };
+enum { RL_LIMIT_NONE = 0, RL_LIMIT_LATENT = 1, RL_LIMIT_VISIBLE = 2 };
+
+typedef struct rl_engine rl_engine;
+typedef struct rl_env rl_env;
+typedef struct rl_mlp rl_mlp;
+typedef struct rl_traj rl_traj;
+typedef struct rl_adam rl_adam;
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine (one per GPU).  Stands in for `Device::cuda_if_available()` + the libtorch runtime the
+ * reference configures in ActorCriticConfig.device (src/torch/agents/actor_critic.rs:20-45). */
+int32_t rl_abi_version(void);
+int32_t rl_device_count(int32_t *count);
+int32_t rl_engine_create(int32_t device_ordinal, rl_engine **out);
+int32_t rl_engine_destroy(rl_engine *engine);
+int32_t rl_engine_sync(rl_engine *engine);
+const char *rl_last_error(const rl_engine *engine);
+/* name of the device, gcnArchName (must start with "gfx950"), CU count */
+int32_t rl_engine_info(const rl_engine *engine, char *name_out, size_t name_cap, char *arch_out, size_t arch_cap,
+                       int32_t *compute_units);
+/* HIP-event timing of everything enqueued between begin and end on the engine stream (milliseconds) */
+int32_t rl_timer_begin(rl_engine *engine);
+int32_t rl_timer_end(rl_engine *engine, float *elapsed_ms);
+/* Per-kernel-class accumulated device time since the last reset, measured with HIP events around each
+ * launch when profiling is on (off by default: events add host overhead).  classes: see rl_kernel_class. */
+typedef enum {
+  RL_K_ENV_STEP = 0, RL_K_ROLLOUT = 1, RL_K_VALUES = 2, RL_K_GAE = 3, RL_K_POLICY_PASS = 4, RL_K_BACKWARD = 5,
+  RL_K_REDUCE = 6, RL_K_SMALL = 7, RL_K_CRITIC_FWD = 8, RL_K_ALLREDUCE = 9, RL_K_CLASS_COUNT = 10
+} rl_kernel_class;
+int32_t rl_profile_enable(rl_engine *engine, int32_t on);
+int32_t rl_profile_read(rl_engine *engine, double *total_ms_out /*[RL_K_CLASS_COUNT]*/,
+                        uint64_t *launches_out /*[RL_K_CLASS_COUNT]*/, int32_t reset);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: env lanes are sharded over ranks; the only exchange is an RCCL all-reduce (sum, f32)
+ * of the <= 4 KiB reduced gradient / Hessian-vector / scalar vectors.  The reference has no
+ * collective at all (threads + shared memory, src/simulation/train.rs:98-180); this replaces the
+ * `Vec<buffer>` hand-off of train.rs:180.  `unique_id` is the 128-byte ncclUniqueId produced on
+ * rank 0 and distributed by the caller (bench.py uses torch.distributed for that). */
+int32_t rl_comm_unique_id(uint8_t id_out[128]);
+int32_t rl_comm_init(rl_engine *engine, int32_t rank, int32_t n_ranks, const uint8_t unique_id[128]);
+int32_t rl_comm_destroy(rl_engine *engine);
+
+/* ---------------------------------------------------------------------------------------------
+ * Environments.  Mirrors `Environment::{initial_state, observe, step}` (src/envs/mod.rs:76-127) for N
+ * lanes at once; state is explicit and owned by the handle. */
+typedef struct {
+  /* PhysicalConstants (src/envs/cartpole.rs:157-191) */
+  double gravity, mass_cart, mass_pole, length_half_pole, friction_cart, friction_pole, time_step;
+  /* EnvironmentParams (src/envs/cartpole.rs:194-216) */
+  double action_force, max_pos, max_angle, discount_factor;
+} rl_cartpole_params;
+/* CartPole::default() */
+int32_t rl_cartpole_params_default(rl_cartpole_params *p);
+
+typedef struct {
+  int32_t kind;          /* RL_ENV_CARTPOLE */
+  int32_t limit_kind;    /* RL_LIMIT_* : `env.wrap(VisibleStepLimit::new(max_steps))` */
+  uint64_t max_steps;    /* max_steps_per_episode (< 2^32) */
+  uint64_t n_lanes;      /* lanes resident on THIS engine */
+  uint64_t lane_offset;  /* global id of lane 0 (random streams are keyed by global lane id) */
+  uint64_t seed_env;     /* env stream seed   (the `rng_env` of Steps, src/simulation/steps.rs:15-28) */
+  uint64_t seed_actor;   /* actor stream seed (the `rng_actor` of Steps) */
+  rl_cartpole_params cartpole;
+} rl_env_config;
+
+int32_t rl_env_create(rl_engine *engine, const rl_env_config *cfg, rl_env **out);
+int32_t rl_env_destroy(rl_env *env);
+/* number of observation features (CartPole 4, +1 `remaining` under VisibleStepLimit) and actions */
+int32_t rl_env_dims(const rl_env *env, uint32_t *obs_dim, uint32_t *n_actions);
+/* Environment::initial_state for every lane (a new episode in every lane) */
+int32_t rl_env_reset(rl_env *env);
+/* Environment::observe -> feature vectors, SoA [obs_dim][n_lanes] f32 (host buffer) */
+int32_t rl_env_observe(rl_env *env, float *obs_out);
+/* Environment::step for every lane with host-side actions (u8 indices); lanes whose episode ends start
+ * a new one.  Outputs (host, may be NULL): reward[n] f32, flag[n] u8, next observation features
+ * [obs_dim][n] (of the NEW episode when the lane was reset), interrupt successor features [obs_dim][n]
+ * (valid where flag == RL_SUCC_INTERRUPT). */
+int32_t rl_env_step(rl_env *env, const uint8_t *actions, float *reward_out, uint8_t *flag_out, float *obs_out,
+                    float *term_obs_out);
+/* Same step with everything device-resident (no PCIe): actions from / results to the env's own HBM
+ * staging buffers.  `rl_env_upload_actions` fills the action buffer once; used by bench.py. */
+int32_t rl_env_upload_actions(rl_env *env, const uint8_t *actions);
+int32_t rl_env_step_resident(rl_env *env);
+/* raw lane state for parity tests: state4 [4][n] f64 (x, xdot, theta, thetadot), nv_pos[n] i32 (cached sign),
+ * steps_remaining[n] u64, reset_count[n] u64 */
+int32_t rl_env_get_state(rl_env *env, double *state4, int32_t *nv_pos, uint64_t *steps_remaining,
+                         uint64_t *reset_count);
+int32_t rl_env_set_state(rl_env *env, const double *state4, const int32_t *nv_pos, const uint64_t *steps_remaining,
+                         const uint64_t *reset_count);
+
+/* ---------------------------------------------------------------------------------------------
+ * Modules.  `MlpConfig::build_module` with one hidden layer, ReLU, identity output
+ * (src/torch/modules/ff/mlp.rs:25-69); parameters are exchanged in the reference's flat order
+ * (kernel [out][in] then bias per layer: ff/linear.rs:108-110, torch/utils.rs:10-22). */
+int32_t rl_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t hidden, uint32_t out_dim, rl_mlp **out);
+int32_t rl_mlp_destroy(rl_mlp *mlp);
+int32_t rl_mlp_num_params(const rl_mlp *mlp, uint64_t *n);
+/* Linear::new Glorot-uniform init (ff/linear.rs:54-68) from the engine-defined stream ChaCha8(seed) */
+int32_t rl_mlp_init(rl_mlp *mlp, uint64_t seed);
+int32_t rl_params_get(rl_mlp *mlp, float *host, uint64_t n);
+int32_t rl_params_set(rl_mlp *mlp, const float *host, uint64_t n);
+/* Forward::forward on host rows [n_rows][in_dim] -> [n_rows][out_dim] (test/utility path) */
+int32_t rl_mlp_forward(rl_mlp *mlp, const float *rows, uint64_t n_rows, float *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Trajectory store (replaces VecBuffer + LazyHistoryFeatures: src/agents/buffers/vec.rs:15-143,
+ * src/torch/agents/features.rs:48-213 — trajectories are born in HBM, no H2D per update). */
+typedef enum {
+  RL_TRAJ_OBS = 0,       /* f32 [obs_dim][T+1][n] (slot T = observation after the last step) */
+  RL_TRAJ_ACTION = 1,    /* u8  [T][n] */
+  RL_TRAJ_REWARD = 2,    /* f32 [T][n] */
+  RL_TRAJ_FLAG = 3,      /* u8  [T][n] successor code */
+  RL_TRAJ_TERM_OBS = 4,  /* f32 [obs_dim][T][n], valid where flag == INTERRUPT */
+  RL_TRAJ_VALUES = 5,    /* f32 [T+1][n] critic values of OBS (after rl_gae) */
+  RL_TRAJ_ADVANTAGES = 6,/* f32 [T][n] */
+  RL_TRAJ_RETURNS = 7    /* f32 [T][n] discounted reward-to-go */
+} rl_traj_field;
+
+int32_t rl_traj_create(rl_engine *engine, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, rl_traj **out);
+int32_t rl_traj_destroy(rl_traj *traj);
+int32_t rl_traj_field_bytes(const rl_traj *traj, int32_t field, uint64_t *bytes);
+int32_t rl_traj_read(rl_traj *traj, int32_t field, void *host, uint64_t bytes);
+/* upload (tests: feed oracle-generated trajectories / advantages to the update kernels) */
+int32_t rl_traj_write(rl_traj *traj, int32_t field, const void *host, uint64_t bytes);
+
+/* HOT LOOP A: `horizon` calls of Steps::step per lane (src/simulation/steps.rs:113-167) with
+ * PolicyActor::act (src/torch/agents/policies/actor.rs:42-55) fused in: one persistent kernel. */
+int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj);
+
+/* critic.advantages + reward_to_go (src/torch/agents/critics/mod.rs:101-199; opt.rs:95-104).
+ * gamma = min(max_discount_factor, env discount) as f32 (opt.rs:73), lambda f32 (critics/mod.rs:78). */
+int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);
+
+/* ---------------------------------------------------------------------------------------------
+ * TRPO policy update: Trpo::update (src/torch/agents/policies/trpo.rs:97-164) =
+ * ConjugateGradientOptimizer::trust_region_backward_step + backtracking_line_search
+ * (src/torch/optimizers/conjugate_gradient.rs:115-255). */
+typedef struct {
+  uint64_t iterations;      /* 10 */
+  uint64_t max_backtracks;  /* 15 */
+  double backtrack_ratio;   /* 0.8 */
+  double hpv_reg_coeff;     /* 1e-5 */
+  double max_policy_step_kl;/* 0.01 (TrpoConfig, trpo.rs:38) */
+  int32_t accept_violation; /* false */
+} rl_trpo_config;
+int32_t rl_trpo_config_default(rl_trpo_config *cfg);
+
+/* logged scalars, named as the reference logs them under `policy/` (conjugate_gradient.rs:164,200,219-226;
+ * trpo.rs:119) */
+typedef struct {
+  double entropy, step_size, loss_initial, loss_final, constraint_val_final, step_scale;
+  int64_t num_backtracks; /* -1: line search exhausted */
+  int32_t status;         /* RL_OPT_* */
+  int32_t cg_iterations;
+} rl_trpo_stats;
+
+int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats);
+/* pieces of the update exposed for parity tests (host vectors in flat parameter order) */
+int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float *loss_out, float *entropy_out);
+int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, float *out);
+int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, float *loss_out, float *kl_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Critic update: ValuesOpt::update (src/torch/agents/critics/opt.rs:100-126) = n_backward_steps
+ * (src/torch/agents/mod.rs:35-72) of full-batch MSE with COptimizer Adam (optimizers/coptimizer.rs:13-26,
+ * 136-167; libtorch default eps 1e-8, amsgrad off). */
+typedef struct {
+  double learning_rate, beta1, beta2, weight_decay; /* AdamConfig (coptimizer.rs:136-156) */
+  double eps;                                       /* libtorch default 1e-8 (not a field in the reference) */
+} rl_adam_config;
+int32_t rl_adam_config_default(rl_adam_config *cfg);
+int32_t rl_adam_create(rl_mlp *module, const rl_adam_config *cfg, rl_adam **out);
+int32_t rl_adam_destroy(rl_adam *opt);
+/* one optimizer step from a host gradient (parity tests) */
+int32_t rl_adam_step_host(rl_adam *opt, const float *grad);
+
+typedef struct {
+  double loss_first, loss_last; /* loss before the first / last optimisation step */
+  uint64_t steps;
+} rl_critic_stats;
+/* targets = RL_TRAJ_RETURNS (StepValueTarget::RewardToGo, critics/mod.rs:203-229); `losses_out` (host,
+ * may be NULL) receives the loss before each of the opt_steps steps */
+int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
+                         float *losses_out);
+int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELEARN_HIP_H */

@@ -260,6 +260,12 @@ def _declare(L):
     L.oracle_policy_fvp_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), C.c_uint64, P(C.c_double),
                                         C.c_double, P(C.c_double)]
     L.oracle_cg_dense_f32.argtypes = [P(C.c_float), P(C.c_float), C.c_uint32, C.c_uint64, C.c_double, P(C.c_float)]
+    L.oracle_cg_dense_f64.argtypes = [P(C.c_double), P(C.c_double), C.c_uint32, C.c_uint64, C.c_double,
+                                      P(C.c_double)]
+    L.oracle_trpo_update_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), P(C.c_double),
+                                         C.c_uint64, P(TrpoCfg), P(TrpoStats), P(C.c_double)]
+    L.oracle_policy_loss_kl_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_int64),
+                                            P(C.c_double), C.c_uint64, P(C.c_double), P(C.c_double)]
 
     L.oracle_adam_cfg_default.argtypes = [P(AdamCfg)]
     L.oracle_adam_new.argtypes = [C.c_uint64]
@@ -382,6 +388,26 @@ class LaneSim:
         lib().oracle_lanes_rollout(self.ptr, pshape, f32p(pparams), T, f32p(obs), u8p(action), f32p(reward),
                                    u8p(flag), f32p(term), threads)
         return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
+
+
+def trpo_update(pshape, params, x, a, adv, cfg=None, f64=False):
+    """Run the oracle TRPO step; returns (new_params, stats, step_dir)."""
+    if cfg is None:
+        cfg = TrpoCfg()
+        lib().oracle_trpo_cfg_default(C.byref(cfg))
+    st = TrpoStats()
+    if f64:
+        p = np.ascontiguousarray(params, dtype=np.float64).copy()
+        sd = np.zeros_like(p)
+        lib().oracle_trpo_update_f64(pshape, f64p(p), f64p(np.ascontiguousarray(x, dtype=np.float64)), i64p(a),
+                                     f64p(np.ascontiguousarray(adv, dtype=np.float64)), len(a), C.byref(cfg),
+                                     C.byref(st), f64p(sd))
+    else:
+        p = np.ascontiguousarray(params, dtype=np.float32).copy()
+        sd = np.zeros_like(p)
+        lib().oracle_trpo_update_f32(pshape, f32p(p), f32p(x), i64p(a), f32p(adv), len(a), C.byref(cfg), C.byref(st),
+                                     f32p(sd))
+    return p, st, sd
 
 
 def lanes_gae(cshape, cparams, traj, gamma, lam):

@@ -21,6 +21,7 @@ uint64_t oracle_mlp_num_params(oracle_mlp_shape s) {
 #define REXP(x) rl_expf(x)
 #define RLOG(x) rl_logf(x)
 #define RMIN (-FLT_MAX)
+#define RMAXV FLT_MAX
 #include "nn_impl.inc"
 #undef REAL
 #undef SUF
@@ -28,6 +29,7 @@ uint64_t oracle_mlp_num_params(oracle_mlp_shape s) {
 #undef REXP
 #undef RLOG
 #undef RMIN
+#undef RMAXV
 
 #define REAL double
 #define SUF _f64
@@ -35,6 +37,7 @@ uint64_t oracle_mlp_num_params(oracle_mlp_shape s) {
 #define REXP(x) exp(x)
 #define RLOG(x) log(x)
 #define RMIN (-DBL_MAX)
+#define RMAXV DBL_MAX
 #include "nn_impl.inc"
 #undef REAL
 #undef SUF
@@ -42,6 +45,7 @@ uint64_t oracle_mlp_num_params(oracle_mlp_shape s) {
 #undef REXP
 #undef RLOG
 #undef RMIN
+#undef RMAXV
 
 /* ------------------------------------------------------------------ init
  * Linear::new (ff/linear.rs:54-68): fan_in = in_dim + 1 for kernel AND bias; Initializer default
@@ -165,130 +169,7 @@ void oracle_trpo_cfg_default(oracle_trpo_cfg *c) {
   c->max_kl = 0.01;
 }
 
-static float dot_f32(const float *a, const float *b, uint64_t n) {
-  double s = 0.0;
-  for (uint64_t i = 0; i < n; ++i) s += (double)(a[i] * b[i]);
-  return (float)s;
-}
-
-typedef void (*matvec_fn)(void *ctx, const float *v, float *out);
-
-/* solve_conjugate_gradient (conjugate_gradient.rs:371-403) */
-static int solve_cg(matvec_fn f_Ax, void *ctx, const float *b, uint64_t n, uint64_t iterations, double tol, float *x) {
-  float *r = (float *)malloc(sizeof(float) * 3 * n), *p = r + n, *z = p + n;
-  memset(x, 0, sizeof(float) * n);
-  memcpy(r, b, sizeof(float) * n);
-  memcpy(p, b, sizeof(float) * n);
-  float rr = dot_f32(r, r, n);
-  int iters = 0;
-  for (uint64_t it = 0; it < iterations; ++it) {
-    f_Ax(ctx, p, z);
-    iters += 1;
-    float alpha = rr / dot_f32(p, z, n);
-    for (uint64_t i = 0; i < n; ++i) x[i] = x[i] + alpha * p[i];
-    float nalpha = -alpha;
-    for (uint64_t i = 0; i < n; ++i) r[i] = r[i] + nalpha * z[i];
-    float new_rr = dot_f32(r, r, n);
-    if ((double)new_rr < tol) break;
-    float mu = new_rr / rr;
-    for (uint64_t i = 0; i < n; ++i) p[i] = p[i] * mu;
-    for (uint64_t i = 0; i < n; ++i) p[i] = p[i] + r[i];
-    rr = new_rr;
-  }
-  free(r);
-  return iters;
-}
-
-typedef struct { const float *A; uint32_t n; } dense_ctx;
-static void dense_mv(void *c, const float *v, float *out) {
-  dense_ctx *d = (dense_ctx *)c;
-  for (uint32_t i = 0; i < d->n; ++i) out[i] = dot_f32(d->A + (size_t)i * d->n, v, d->n);
-}
-void oracle_cg_dense_f32(const float *A, const float *b, uint32_t n, uint64_t iterations, double tol, float *x) {
-  dense_ctx c = {A, n};
-  solve_cg(dense_mv, &c, b, n, iterations, tol, x);
-}
-
-typedef struct {
-  oracle_mlp_shape s;
-  const float *params, *obs;
-  uint64_t n;
-  float reg;
-} fvp_ctx;
-static void fvp_mv(void *c, const float *v, float *out) {
-  fvp_ctx *f = (fvp_ctx *)c;
-  oracle_policy_fvp_f32(f->s, f->params, f->obs, f->n, v, f->reg, out);
-}
-
-/* Trpo::update -> ConjugateGradientOptimizer::trust_region_backward_step + backtracking_line_search
- * (policies/trpo.rs:97-164; optimizers/conjugate_gradient.rs:115-255) */
-void oracle_trpo_update_f32(oracle_mlp_shape s, float *params, const float *obs, const int64_t *actions,
-                            const float *adv, uint64_t n, const oracle_trpo_cfg *cfg, oracle_trpo_stats *st,
-                            float *step_dir_out) {
-  uint64_t P = oracle_mlp_num_params(s);
-  float *g = (float *)malloc(sizeof(float) * 4 * P), *x = g + P, *hx = x + P, *prev = hx + P;
-  memset(st, 0, sizeof(*st));
-  /* entropy of the initial distribution (trpo.rs:112-122) */
-  {
-    mlp_view_f32 m = view_f32(s, params);
-    float *pre = (float *)malloc(sizeof(float) * (2 * m.H + 2 * m.A));
-    float *h = pre + m.H, *z = h + m.H, *lp = z + m.A;
-    double e = 0.0;
-    for (uint64_t i = 0; i < n; ++i) {
-      mlp_fwd_f32(&m, obs + i * m.D, pre, h, z);
-      log_softmax_f32(z, m.A, lp);
-      e += (double)oracle_categorical_entropy_f32(lp, m.A, 0);
-    }
-    st->entropy = (double)(float)(e / (double)n);
-    free(pre);
-  }
-  float loss0;
-  oracle_policy_grad_f32(s, params, obs, actions, adv, n, g, &loss0);
-  fvp_ctx ctx = {s, params, obs, n, (float)cfg->hpv_reg_coeff};
-  st->cg_iterations = solve_cg(fvp_mv, &ctx, g, P, cfg->iterations, 1e-10, x);
-  for (uint64_t i = 0; i < P; ++i) { /* nan_to_num_(0.0, None, None) */
-    if (x[i] != x[i]) x[i] = 0.0f;
-    else if (isinf(x[i])) x[i] = x[i] > 0 ? FLT_MAX : -FLT_MAX;
-  }
-  if (step_dir_out) memcpy(step_dir_out, x, sizeof(float) * P);
-  fvp_mv(&ctx, x, hx);
-  double xhx = (double)dot_f32(x, hx, P);
-  double step_size = sqrt(1.0 / (xhx + 1e-8) * cfg->max_kl * 2.0);
-  if (step_size != step_size) step_size = 1.0;
-  st->step_size = step_size;
-  /* descent_step = step_size * step_dir : f32 tensor times a double scalar => f32 multiply */
-  float ss = (float)step_size;
-  for (uint64_t i = 0; i < P; ++i) x[i] = ss * x[i];
-  double initial_loss = (double)loss0;
-  st->loss_initial = initial_loss;
-  memcpy(prev, params, sizeof(float) * P);
-  double loss = initial_loss, cval = INFINITY;
-  st->num_backtracks = -1;
-  for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
-    double ratio = 1.0;
-    for (uint64_t k = 0; k < i; ++k) ratio *= cfg->backtrack_ratio; /* powi */
-    float rf = (float)ratio;
-    for (uint64_t k = 0; k < P; ++k) params[k] = prev[k] - rf * x[k];
-    float lf, kf;
-    oracle_policy_loss_kl_f32(s, params, prev, obs, actions, adv, n, &lf, &kf);
-    loss = (double)lf;
-    cval = (double)kf;
-    if (loss < initial_loss && cval <= cfg->max_kl) {
-      st->num_backtracks = (int64_t)i;
-      st->step_scale = ratio;
-      break;
-    }
-  }
-  st->loss_final = loss;
-  st->constraint_val_final = cval;
-  if (loss != loss) st->status = ORACLE_OPT_NAN_LOSS;
-  else if (cval != cval) st->status = ORACLE_OPT_NAN_CONSTRAINT;
-  else if (loss >= initial_loss) st->status = ORACLE_OPT_LOSS_NOT_IMPROVING;
-  else if (cval >= cfg->max_kl && !cfg->accept_violation) st->status = ORACLE_OPT_CONSTRAINT_VIOLATED;
-  else st->status = ORACLE_OPT_OK;
-  if (st->status != ORACLE_OPT_OK) memcpy(params, prev, sizeof(float) * P);
-  free(g);
-}
+/* dot / solve_cg / oracle_cg_dense / oracle_trpo_update are instantiated from nn_impl.inc (f32 and f64) */
 
 /* ------------------------------------------------------------------ Adam
  * COptimizer::adam (optimizers/coptimizer.rs:158-167) -> torch::optim::Adam of libtorch 1.12 (third party,

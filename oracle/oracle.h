@@ -222,6 +222,12 @@ void oracle_policy_grad_f64(oracle_mlp_shape s, const double *params, const doub
                             const double *adv, uint64_t n, double *grad_out, double *loss_out);
 void oracle_policy_fvp_f64(oracle_mlp_shape s, const double *params, const double *obs, uint64_t n, const double *v,
                            double reg, double *out);
+void oracle_policy_loss_kl_f64(oracle_mlp_shape s, const double *params, const double *params0, const double *obs,
+                               const int64_t *actions, const double *adv, uint64_t n, double *loss, double *kl);
+void oracle_trpo_update_f64(oracle_mlp_shape s, double *params, const double *obs, const int64_t *actions,
+                            const double *adv, uint64_t n, const oracle_trpo_cfg *cfg, oracle_trpo_stats *stats,
+                            double *step_dir_out);
+void oracle_cg_dense_f64(const double *A, const double *b, uint32_t n, uint64_t iterations, double tol, double *x);
 
 /* solve_conjugate_gradient on an explicit dense matrix (conjugate_gradient.rs:371-403), f32 */
 void oracle_cg_dense_f32(const float *A, const float *b, uint32_t n, uint64_t iterations, double tol, float *x);

@@ -1,0 +1,451 @@
+"""relearn_amd — thin ctypes binding over the C ABI of ``librelearn_hip.so`` (include/relearn_hip.h).
+
+The product is the HIP library; this module is plumbing for tests and bench.py.  There is no CPU
+fallback: importing works anywhere (so the symbol table can be checked without a GPU), but creating an
+``Engine`` raises unless a gfx950 device is visible, and a missing/unbuilt library raises at import of
+``lib()``.
+"""
+import atexit
+import ctypes as C
+import os
+import subprocess
+import sys
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librelearn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# status codes (include/relearn_hip.h)
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_BUILD_AGENT, ERR_BUILD_ENV = 1, 2, 3, 4, 5
+ERR_BUFFER_FULL, ERR_PACKING, ERR_COMM, ERR_OPT_NAN, ERR_UNSUPPORTED = 6, 7, 8, 9, 10
+SUCC_CONTINUE, SUCC_TERMINATE, SUCC_INTERRUPT = 0, 1, 2
+OPT_OK, OPT_LOSS_NOT_IMPROVING, OPT_CONSTRAINT_VIOLATED, OPT_NAN_LOSS, OPT_NAN_CONSTRAINT = range(5)
+ENV_CARTPOLE, ENV_CHAIN = 0, 1
+LIMIT_NONE, LIMIT_LATENT, LIMIT_VISIBLE = 0, 1, 2
+(TRAJ_OBS, TRAJ_ACTION, TRAJ_REWARD, TRAJ_FLAG, TRAJ_TERM_OBS, TRAJ_VALUES, TRAJ_ADVANTAGES,
+ TRAJ_RETURNS) = range(8)
+KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backward", "reduce", "small",
+                  "critic_fwd", "allreduce"]
+
+# every symbol include/relearn_hip.h declares (checked by tests/test_abi_symbols.py against the header)
+ABI_SYMBOLS = [
+    "rl_abi_version", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
+    "rl_last_error", "rl_engine_info", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
+    "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy",
+    "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
+    "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
+    "rl_env_set_state",
+    "rl_mlp_create", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_params_get", "rl_params_set",
+    "rl_mlp_forward",
+    "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
+    "rl_rollout", "rl_gae",
+    "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
+    "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
+    "rl_critic_update", "rl_critic_gradient",
+]
+
+
+class RelearnError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rl status %d: %s" % (code, message))
+        self.code = code
+
+
+class CartPoleParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "gravity", "mass_cart", "mass_pole", "length_half_pole", "friction_cart", "friction_pole", "time_step",
+        "action_force", "max_pos", "max_angle", "discount_factor")]
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("limit_kind", C.c_int32), ("max_steps", C.c_uint64), ("n_lanes", C.c_uint64),
+                ("lane_offset", C.c_uint64), ("seed_env", C.c_uint64), ("seed_actor", C.c_uint64),
+                ("cartpole", CartPoleParams)]
+
+
+class TrpoConfig(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("max_backtracks", C.c_uint64), ("backtrack_ratio", C.c_double),
+                ("hpv_reg_coeff", C.c_double), ("max_policy_step_kl", C.c_double), ("accept_violation", C.c_int32)]
+
+
+class TrpoStats(C.Structure):
+    _fields_ = [("entropy", C.c_double), ("step_size", C.c_double), ("loss_initial", C.c_double),
+                ("loss_final", C.c_double), ("constraint_val_final", C.c_double), ("step_scale", C.c_double),
+                ("num_backtracks", C.c_int64), ("status", C.c_int32), ("cg_iterations", C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class AdamConfig(C.Structure):
+    _fields_ = [("learning_rate", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("weight_decay", C.c_double), ("eps", C.c_double)]
+
+
+class CriticStats(C.Structure):
+    _fields_ = [("loss_first", C.c_double), ("loss_last", C.c_double), ("steps", C.c_uint64)]
+
+
+def build(force=False):
+    """Compile librelearn_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("librelearn_hip.so is not built: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.rl_last_error.restype = C.c_char_p
+        L.rl_last_error.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(code, eng=None):
+    if code != OK:
+        msg = lib().rl_last_error(eng)
+        raise RelearnError(code, msg.decode() if msg else "")
+
+
+def _ptr(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+# Handles are released before the interpreter (and with it the HIP runtime) shuts down: children first, then
+# engines.  A __del__ that runs during finalisation must not call into a runtime that is already gone.
+_live = weakref.WeakSet()
+
+
+def _register(obj):
+    _live.add(obj)
+
+
+@atexit.register
+def _close_all():
+    objs = list(_live)
+    for o in objs:
+        if not isinstance(o, Engine):
+            o.close()
+    for o in objs:
+        if isinstance(o, Engine):
+            o.close()
+
+
+class _Handle:
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine(_Handle):
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(lib().rl_engine_create(C.c_int32(device), C.byref(self.h)))
+        _register(self)
+
+    def close(self):
+        if self.h:
+            lib().rl_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def sync(self):
+        _check(lib().rl_engine_sync(self.h), self.h)
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        arch = C.create_string_buffer(256)
+        cus = C.c_int32()
+        _check(lib().rl_engine_info(self.h, name, C.c_size_t(256), arch, C.c_size_t(256), C.byref(cus)), self.h)
+        return name.value.decode(), arch.value.decode(), cus.value
+
+    def timer_begin(self):
+        _check(lib().rl_timer_begin(self.h), self.h)
+
+    def timer_end(self):
+        ms = C.c_float()
+        _check(lib().rl_timer_end(self.h, C.byref(ms)), self.h)
+        return ms.value
+
+    def profile_enable(self, on=True):
+        _check(lib().rl_profile_enable(self.h, C.c_int32(1 if on else 0)), self.h)
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * len(KERNEL_CLASSES))()
+        cnt = (C.c_uint64 * len(KERNEL_CLASSES))()
+        _check(lib().rl_profile_read(self.h, ms, cnt, C.c_int32(1 if reset else 0)), self.h)
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+    def comm_init(self, rank, n_ranks, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().rl_comm_init(self.h, C.c_int32(rank), C.c_int32(n_ranks), buf), self.h)
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * 128)()
+    _check(lib().rl_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def cartpole_params_default():
+    p = CartPoleParams()
+    _check(lib().rl_cartpole_params_default(C.byref(p)))
+    return p
+
+
+class CartPoleEnv(_Handle):
+    """N CartPole lanes wrapped in a step limit — `CartPole::default().wrap(VisibleStepLimit::new(500))`."""
+
+    def __init__(self, engine, n_lanes, max_steps=500, limit=LIMIT_VISIBLE, lane_offset=0, seed_env=0,
+                 seed_actor=1, params=None):
+        self.eng = engine
+        cfg = EnvConfig()
+        cfg.kind = ENV_CARTPOLE
+        cfg.limit_kind = limit
+        cfg.max_steps = max_steps
+        cfg.n_lanes = n_lanes
+        cfg.lane_offset = lane_offset
+        cfg.seed_env = seed_env
+        cfg.seed_actor = seed_actor
+        cfg.cartpole = params if params is not None else cartpole_params_default()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _check(lib().rl_env_create(engine.h, C.byref(cfg), C.byref(self.h)), engine.h)
+        _register(self)
+        self.n = n_lanes
+        d, a = C.c_uint32(), C.c_uint32()
+        _check(lib().rl_env_dims(self.h, C.byref(d), C.byref(a)), engine.h)
+        self.D, self.A = d.value, a.value
+
+    def close(self):
+        if self.h:
+            lib().rl_env_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def reset(self):
+        _check(lib().rl_env_reset(self.h), self.eng.h)
+
+    def observe(self):
+        obs = np.zeros((self.D, self.n), dtype=np.float32)
+        _check(lib().rl_env_observe(self.h, obs.ctypes.data_as(C.c_void_p)), self.eng.h)
+        return obs
+
+    def step(self, actions):
+        a, ap = _ptr(actions, np.uint8)
+        assert a.shape == (self.n,)
+        reward = np.zeros(self.n, dtype=np.float32)
+        flag = np.zeros(self.n, dtype=np.uint8)
+        obs = np.zeros((self.D, self.n), dtype=np.float32)
+        term = np.zeros((self.D, self.n), dtype=np.float32)
+        _check(lib().rl_env_step(self.h, ap, reward.ctypes.data_as(C.c_void_p), flag.ctypes.data_as(C.c_void_p),
+                                 obs.ctypes.data_as(C.c_void_p), term.ctypes.data_as(C.c_void_p)), self.eng.h)
+        return reward, flag, obs, term
+
+    def upload_actions(self, actions):
+        a, ap = _ptr(actions, np.uint8)
+        _check(lib().rl_env_upload_actions(self.h, ap), self.eng.h)
+
+    def step_resident(self):
+        _check(lib().rl_env_step_resident(self.h), self.eng.h)
+
+    def get_state(self):
+        st = np.zeros((4, self.n), dtype=np.float64)
+        nv = np.zeros(self.n, dtype=np.int32)
+        rem = np.zeros(self.n, dtype=np.uint64)
+        rc = np.zeros(self.n, dtype=np.uint64)
+        _check(lib().rl_env_get_state(self.h, st.ctypes.data_as(C.c_void_p), nv.ctypes.data_as(C.c_void_p),
+                                      rem.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p)), self.eng.h)
+        return st, nv, rem, rc
+
+    def set_state(self, st, nv, rem, rc):
+        st, sp = _ptr(st, np.float64)
+        nv, np_ = _ptr(nv, np.int32)
+        rem, rp = _ptr(rem, np.uint64)
+        rc, cp = _ptr(rc, np.uint64)
+        _check(lib().rl_env_set_state(self.h, sp, np_, rp, cp), self.eng.h)
+
+
+class Mlp(_Handle):
+    """`MlpConfig{hidden_sizes:[H], activation: Relu}.build_module(in, out)`; flat params in reference order."""
+
+    def __init__(self, engine, in_dim, hidden, out_dim):
+        self.eng = engine
+        self.h = C.c_void_p()
+        _check(lib().rl_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(hidden), C.c_uint32(out_dim),
+                                   C.byref(self.h)), engine.h)
+        _register(self)
+        n = C.c_uint64()
+        _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)
+        self.P = n.value
+        self.in_dim, self.hidden, self.out_dim = in_dim, hidden, out_dim
+
+    def close(self):
+        if self.h:
+            lib().rl_mlp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def init(self, seed):
+        _check(lib().rl_mlp_init(self.h, C.c_uint64(seed)), self.eng.h)
+
+    def get_params(self):
+        p = np.zeros(self.P, dtype=np.float32)
+        _check(lib().rl_params_get(self.h, p.ctypes.data_as(C.c_void_p), C.c_uint64(self.P)), self.eng.h)
+        return p
+
+    def set_params(self, p):
+        p, pp = _ptr(p, np.float32)
+        _check(lib().rl_params_set(self.h, pp, C.c_uint64(p.size)), self.eng.h)
+
+    def forward(self, rows):
+        rows, rp = _ptr(rows, np.float32)
+        out = np.zeros((rows.shape[0], self.out_dim), dtype=np.float32)
+        _check(lib().rl_mlp_forward(self.h, rp, C.c_uint64(rows.shape[0]), out.ctypes.data_as(C.c_void_p)),
+               self.eng.h)
+        return out
+
+
+_TRAJ_DTYPES = {TRAJ_OBS: np.float32, TRAJ_ACTION: np.uint8, TRAJ_REWARD: np.float32, TRAJ_FLAG: np.uint8,
+                TRAJ_TERM_OBS: np.float32, TRAJ_VALUES: np.float32, TRAJ_ADVANTAGES: np.float32,
+                TRAJ_RETURNS: np.float32}
+
+
+class Trajectory(_Handle):
+    def __init__(self, engine, n_lanes, horizon, obs_dim):
+        self.eng = engine
+        self.h = C.c_void_p()
+        _check(lib().rl_traj_create(engine.h, C.c_uint64(n_lanes), C.c_uint64(horizon), C.c_uint32(obs_dim),
+                                    C.byref(self.h)), engine.h)
+        _register(self)
+        self.n, self.T, self.D = n_lanes, horizon, obs_dim
+
+    def close(self):
+        if self.h:
+            lib().rl_traj_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def shape(self, field):
+        n, T, D = self.n, self.T, self.D
+        return {TRAJ_OBS: (D, T + 1, n), TRAJ_ACTION: (T, n), TRAJ_REWARD: (T, n), TRAJ_FLAG: (T, n),
+                TRAJ_TERM_OBS: (D, T, n), TRAJ_VALUES: (T + 1, n), TRAJ_ADVANTAGES: (T, n),
+                TRAJ_RETURNS: (T, n)}[field]
+
+    def read(self, field):
+        out = np.zeros(self.shape(field), dtype=_TRAJ_DTYPES[field])
+        _check(lib().rl_traj_read(self.h, C.c_int32(field), out.ctypes.data_as(C.c_void_p),
+                                  C.c_uint64(out.nbytes)), self.eng.h)
+        return out
+
+    def write(self, field, arr):
+        arr, ap = _ptr(arr, _TRAJ_DTYPES[field])
+        assert arr.shape == self.shape(field), (arr.shape, self.shape(field))
+        _check(lib().rl_traj_write(self.h, C.c_int32(field), ap, C.c_uint64(arr.nbytes)), self.eng.h)
+
+    def read_all(self):
+        return dict(obs=self.read(TRAJ_OBS), action=self.read(TRAJ_ACTION), reward=self.read(TRAJ_REWARD),
+                    flag=self.read(TRAJ_FLAG), term_obs=self.read(TRAJ_TERM_OBS))
+
+    def write_all(self, traj):
+        self.write(TRAJ_OBS, traj["obs"])
+        self.write(TRAJ_ACTION, traj["action"])
+        self.write(TRAJ_REWARD, traj["reward"])
+        self.write(TRAJ_FLAG, traj["flag"])
+        self.write(TRAJ_TERM_OBS, traj["term_obs"])
+
+
+def rollout(env, policy, traj):
+    _check(lib().rl_rollout(env.h, policy.h, traj.h), env.eng.h)
+
+
+def gae(traj, critic, gamma, lam):
+    _check(lib().rl_gae(traj.h, critic.h, C.c_float(gamma), C.c_float(lam)), traj.eng.h)
+
+
+def trpo_config_default():
+    c = TrpoConfig()
+    _check(lib().rl_trpo_config_default(C.byref(c)))
+    return c
+
+
+def trpo_update(policy, traj, cfg=None):
+    cfg = cfg if cfg is not None else trpo_config_default()
+    st = TrpoStats()
+    _check(lib().rl_trpo_update(policy.h, traj.h, C.byref(cfg), C.byref(st)), traj.eng.h)
+    return st
+
+
+def policy_gradient(policy, traj):
+    g = np.zeros(policy.P, dtype=np.float32)
+    loss, ent = C.c_float(), C.c_float()
+    _check(lib().rl_policy_gradient(policy.h, traj.h, g.ctypes.data_as(C.c_void_p), C.byref(loss), C.byref(ent)),
+           traj.eng.h)
+    return g, loss.value, ent.value
+
+
+def policy_fvp(policy, traj, v, reg):
+    v, vp = _ptr(v, np.float32)
+    out = np.zeros(policy.P, dtype=np.float32)
+    _check(lib().rl_policy_fvp(policy.h, traj.h, vp, C.c_float(reg), out.ctypes.data_as(C.c_void_p)), traj.eng.h)
+    return out
+
+
+def policy_loss_kl(policy, traj, params0):
+    p0, pp = _ptr(params0, np.float32)
+    loss, kl = C.c_float(), C.c_float()
+    _check(lib().rl_policy_loss_kl(policy.h, traj.h, pp, C.byref(loss), C.byref(kl)), traj.eng.h)
+    return loss.value, kl.value
+
+
+def adam_config_default():
+    c = AdamConfig()
+    _check(lib().rl_adam_config_default(C.byref(c)))
+    return c
+
+
+class Adam(_Handle):
+    def __init__(self, module, cfg=None):
+        self.mod = module
+        self.cfg = cfg if cfg is not None else adam_config_default()
+        self.h = C.c_void_p()
+        _check(lib().rl_adam_create(module.h, C.byref(self.cfg), C.byref(self.h)), module.eng.h)
+        _register(self)
+
+    def close(self):
+        if self.h:
+            lib().rl_adam_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def step_host(self, grad):
+        g, gp = _ptr(grad, np.float32)
+        _check(lib().rl_adam_step_host(self.h, gp), self.mod.eng.h)
+
+
+def critic_update(critic, opt, traj, opt_steps=80, want_losses=False):
+    st = CriticStats()
+    losses = np.zeros(max(opt_steps, 1), dtype=np.float32)
+    _check(lib().rl_critic_update(critic.h, opt.h, traj.h, C.c_uint64(opt_steps), C.byref(st),
+                                  losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
+    return (st, losses[:opt_steps]) if want_losses else st
+
+
+def critic_gradient(critic, traj):
+    g = np.zeros(critic.P, dtype=np.float32)
+    loss = C.c_float()
+    _check(lib().rl_critic_gradient(critic.h, traj.h, g.ctypes.data_as(C.c_void_p), C.byref(loss)), traj.eng.h)
+    return g, loss.value

@@ -1,0 +1,1026 @@
+// abi.hip — extern "C" entry points of include/relearn_hip.h (host side only; kernels live in kernels_*.hip).
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "../../include/rl_chacha.h"
+#include "engine.hpp"
+#include "kernels.hpp"
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local std::string g_last_error_no_engine;
+
+template <typename F>
+static int32_t guarded(rl_engine *eng, F &&f) {
+  try {
+    f();
+    return RL_OK;
+  } catch (const RlError &e) {
+    (eng ? eng->last_error : g_last_error_no_engine) = e.what();
+    return e.code;
+  } catch (const std::exception &e) {
+    (eng ? eng->last_error : g_last_error_no_engine) = e.what();
+    return RL_ERR_INVALID_ARGUMENT;
+  } catch (...) {
+    (eng ? eng->last_error : g_last_error_no_engine) = "unknown error";
+    return RL_ERR_INVALID_ARGUMENT;
+  }
+}
+
+template <typename T>
+static T *dalloc(size_t count) {
+  void *p = nullptr;
+  RL_HIP_CHECK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+  return (T *)p;
+}
+
+static void dfree(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------- profiling scope
+ProfScope::ProfScope(rl_engine *eng, int c) : e(eng), cls(c) {
+  if (!e->profiling) return;
+  auto get = [&]() {
+    hipEvent_t ev;
+    if (!e->prof_event_pool.empty()) {
+      ev = e->prof_event_pool.back();
+      e->prof_event_pool.pop_back();
+    } else if (hipEventCreate(&ev) != hipSuccess) {
+      ev = nullptr;
+    }
+    return ev;
+  };
+  a = get();
+  b = get();
+  if (a) (void)hipEventRecord(a, e->stream);
+}
+
+ProfScope::~ProfScope() {
+  if (!e->profiling || !a || !b) return;
+  (void)hipEventRecord(b, e->stream);
+  e->prof_pending.push_back({cls, {a, b}});
+}
+
+static void prof_drain(rl_engine *e) {
+  for (auto &it : e->prof_pending) {
+    float ms = 0.0f;
+    (void)hipEventSynchronize(it.second.second);
+    if (hipEventElapsedTime(&ms, it.second.first, it.second.second) == hipSuccess) {
+      e->prof_ms[it.first] += (double)ms;
+      e->prof_launches[it.first] += 1;
+    }
+    e->prof_event_pool.push_back(it.second.first);
+    e->prof_event_pool.push_back(it.second.second);
+  }
+  e->prof_pending.clear();
+}
+
+// ---------------------------------------------------------------- RCCL through dlopen
+// The library must load (and export every symbol) on machines without a GPU or without RCCL, and must not
+// clash with an RCCL copy a host program (e.g. PyTorch) already mapped; so RCCL is bound at rl_comm_init.
+namespace {
+struct Rccl {
+  void *handle = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, const void * /*ncclUniqueId by value: 128 bytes*/, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+struct UniqueId { char bytes[128]; };
+typedef int (*comm_init_rank_t)(void **, int, UniqueId, int);
+
+void rccl_load() {
+  if (g_rccl.handle) return;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (g_rccl.handle) break;
+  }
+  if (!g_rccl.handle) throw RlError(RL_ERR_COMM, std::string("cannot dlopen librccl: ") + dlerror());
+  g_rccl.GetUniqueId = (int (*)(void *))dlsym(g_rccl.handle, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void **, int, const void *, int))dlsym(g_rccl.handle, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void *))dlsym(g_rccl.handle, "ncclCommDestroy");
+  g_rccl.AllReduce =
+      (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(g_rccl.handle, "ncclAllReduce");
+  g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.handle, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
+    throw RlError(RL_ERR_COMM, "librccl is missing expected symbols");
+}
+
+void rccl_check(int rc, const char *what) {
+  if (rc != 0)
+    throw RlError(RL_ERR_COMM, std::string(what) + ": " +
+                                   (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : std::to_string(rc).c_str()));
+}
+}  // namespace
+
+void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
+  if (e->n_ranks <= 1 || !e->comm) return;
+  ProfScope ps(e, RL_K_ALLREDUCE);
+  // ncclFloat32 = 7, ncclSum = 0
+  rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 7, 0, e->comm, e->stream), "ncclAllReduce");
+}
+
+// ---------------------------------------------------------------- helpers
+static uint64_t b_total(const rl_traj *t) { return t->B * (uint64_t)t->eng->n_ranks; }
+
+static void sync(rl_engine *e) { RL_HIP_CHECK(hipStreamSynchronize(e->stream)); }
+
+static void h2d(rl_engine *e, void *d, const void *h, size_t bytes) {
+  RL_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
+  sync(e);
+}
+
+static void d2h(rl_engine *e, void *h, const void *d, size_t bytes) {
+  RL_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+}
+
+extern "C" {
+
+int32_t rl_abi_version(void) { return RL_ABI_VERSION; }
+
+int32_t rl_device_count(int32_t *count) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(count, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+  });
+}
+
+int32_t rl_engine_create(int32_t device_ordinal, rl_engine **out) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+      throw RlError(RL_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
+    RL_REQUIRE(device_ordinal >= 0 && device_ordinal < n, "device ordinal out of range");
+    std::unique_ptr<rl_engine> e(new rl_engine());
+    e->device = device_ordinal;
+    RL_HIP_CHECK(hipSetDevice(device_ordinal));
+    RL_HIP_CHECK(hipGetDeviceProperties(&e->prop, device_ordinal));
+    if (std::strncmp(e->prop.gcnArchName, "gfx950", 6) != 0)
+      throw RlError(RL_ERR_NO_DEVICE,
+                    std::string("device is ") + e->prop.gcnArchName + ", this library is built for gfx950 only");
+    RL_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    RL_HIP_CHECK(hipEventCreate(&e->ev_begin));
+    RL_HIP_CHECK(hipEventCreate(&e->ev_end));
+    e->pinned_bytes = 1 << 16;
+    RL_HIP_CHECK(hipHostMalloc(&e->pinned, e->pinned_bytes, hipHostMallocDefault));
+    *out = e.release();
+  });
+}
+
+static void engine_teardown(rl_engine *e);
+
+int32_t rl_engine_destroy(rl_engine *e) {
+  if (!e) return RL_OK;
+  if (e->live_handles > 0) {
+    e->zombie = true;  // torn down when the last child handle goes away
+    return RL_OK;
+  }
+  engine_teardown(e);
+  return RL_OK;
+}
+
+static void engine_release_child(rl_engine *e) {
+  e->live_handles -= 1;
+  if (e->zombie && e->live_handles <= 0) engine_teardown(e);
+}
+
+static void engine_teardown(rl_engine *e) {
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+  prof_drain(e);
+  for (auto ev : e->prof_event_pool) (void)hipEventDestroy(ev);
+  if (e->pinned) (void)hipHostFree(e->pinned);
+  (void)hipEventDestroy(e->ev_begin);
+  (void)hipEventDestroy(e->ev_end);
+  (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int32_t rl_engine_sync(rl_engine *e) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    sync(e);
+  });
+}
+
+const char *rl_last_error(const rl_engine *e) { return e ? e->last_error.c_str() : g_last_error_no_engine.c_str(); }
+
+int32_t rl_engine_info(const rl_engine *e, char *name_out, size_t name_cap, char *arch_out, size_t arch_cap,
+                       int32_t *compute_units) {
+  return guarded(const_cast<rl_engine *>(e), [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    if (name_out && name_cap) std::snprintf(name_out, name_cap, "%s", e->prop.name);
+    if (arch_out && arch_cap) std::snprintf(arch_out, arch_cap, "%s", e->prop.gcnArchName);
+    if (compute_units) *compute_units = e->prop.multiProcessorCount;
+  });
+}
+
+int32_t rl_timer_begin(rl_engine *e) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    RL_HIP_CHECK(hipEventRecord(e->ev_begin, e->stream));
+  });
+}
+
+int32_t rl_timer_end(rl_engine *e, float *elapsed_ms) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && elapsed_ms, "NULL argument");
+    RL_HIP_CHECK(hipEventRecord(e->ev_end, e->stream));
+    RL_HIP_CHECK(hipEventSynchronize(e->ev_end));
+    RL_HIP_CHECK(hipEventElapsedTime(elapsed_ms, e->ev_begin, e->ev_end));
+  });
+}
+
+int32_t rl_profile_enable(rl_engine *e, int32_t on) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    sync(e);
+    prof_drain(e);
+    e->profiling = on != 0;
+  });
+}
+
+int32_t rl_profile_read(rl_engine *e, double *total_ms_out, uint64_t *launches_out, int32_t reset) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    sync(e);
+    prof_drain(e);
+    for (int i = 0; i < RL_K_CLASS_COUNT; ++i) {
+      if (total_ms_out) total_ms_out[i] = e->prof_ms[i];
+      if (launches_out) launches_out[i] = e->prof_launches[i];
+      if (reset) {
+        e->prof_ms[i] = 0.0;
+        e->prof_launches[i] = 0;
+      }
+    }
+  });
+}
+
+// ---------------------------------------------------------------- comm
+int32_t rl_comm_unique_id(uint8_t id_out[128]) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(id_out, "id_out is NULL");
+    rccl_load();
+    rccl_check(g_rccl.GetUniqueId(id_out), "ncclGetUniqueId");
+  });
+}
+
+int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t unique_id[128]) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && unique_id, "NULL argument");
+    RL_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
+    RL_REQUIRE(!e->comm, "communicator already initialised");
+    e->rank = rank;
+    e->n_ranks = n_ranks;
+    if (n_ranks == 1) return;
+    rccl_load();
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    UniqueId id;
+    std::memcpy(id.bytes, unique_id, 128);
+    comm_init_rank_t init = (comm_init_rank_t)(void *)g_rccl.CommInitRank;
+    rccl_check(init(&e->comm, n_ranks, id, rank), "ncclCommInitRank");
+  });
+}
+
+int32_t rl_comm_destroy(rl_engine *e) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    if (e->comm) {
+      sync(e);
+      rccl_check(g_rccl.CommDestroy(e->comm), "ncclCommDestroy");
+      e->comm = nullptr;
+    }
+    e->rank = 0;
+    e->n_ranks = 1;
+  });
+}
+
+// ---------------------------------------------------------------- env
+int32_t rl_cartpole_params_default(rl_cartpole_params *p) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(p, "params is NULL");
+    // PhysicalConstants::default / EnvironmentParams::default (reference src/envs/cartpole.rs:178-216)
+    p->gravity = 9.8;
+    p->mass_cart = 1.0;
+    p->mass_pole = 0.1;
+    p->length_half_pole = 0.5;
+    p->friction_cart = 0.01;
+    p->friction_pole = 0.01;
+    p->time_step = 0.02;
+    p->action_force = 10.0;
+    p->max_pos = 2.4;
+    p->max_angle = 12.0 * (3.14159265358979323846 / 180.0);  // 12.0f64.to_radians()
+    p->discount_factor = 0.99;
+  });
+}
+
+int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && cfg && out, "NULL argument");
+    *out = nullptr;
+    if (cfg->kind != RL_ENV_CARTPOLE)
+      throw RlError(RL_ERR_BUILD_ENV, "only RL_ENV_CARTPOLE has a device implementation in this build");
+    if (cfg->limit_kind != RL_LIMIT_NONE && (cfg->max_steps == 0 || cfg->max_steps >= (1ull << 32)))
+      throw RlError(RL_ERR_BUILD_ENV, "step limit must be positive and < 2^32");  // StepLimit::new asserts > 0
+    if (cfg->n_lanes == 0 || cfg->n_lanes >= (1ull << 31)) throw RlError(RL_ERR_BUILD_ENV, "bad n_lanes");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_env> env(new rl_env());
+    env->eng = e;
+    env->cfg = *cfg;
+    env->D = cfg->limit_kind == RL_LIMIT_VISIBLE ? 5 : 4;
+    env->A = 2;
+    const rl_cartpole_params &p = cfg->cartpole;
+    CartPoleDev &d = env->dev;
+    d.gravity = p.gravity;
+    d.mass_pole = p.mass_pole;
+    d.length_half_pole = p.length_half_pole;
+    d.friction_cart = p.friction_cart;
+    d.friction_pole = p.friction_pole;
+    d.time_step = p.time_step;
+    d.action_force = p.action_force;
+    d.max_pos = p.max_pos;
+    d.max_angle = p.max_angle;
+    // From<PhysicalConstants> for InternalPhysicalConstants (cartpole.rs:238-251)
+    double total_mass = p.mass_cart + p.mass_pole;
+    d.total_weight = p.gravity * total_mass;
+    d.inv_total_mass = 1.0 / total_mass;
+    d.mass_length_pole = p.mass_pole * p.length_half_pole;
+    d.init_low = -0.05;
+    d.init_scale = rl_uniform_f64_inclusive_scale(-0.05, 0.05);
+    rl_seed_from_u64(cfg->seed_env, d.key_env);
+    rl_seed_from_u64(cfg->seed_actor, d.key_actor);
+    d.lane_offset = cfg->lane_offset;
+    d.max_steps = cfg->max_steps < (1ull << 32) ? (uint32_t)cfg->max_steps : 0u;
+    d.limit_kind = cfg->limit_kind;
+    size_t n = cfg->n_lanes;
+    env->st.x = dalloc<double>(n);
+    env->st.xdot = dalloc<double>(n);
+    env->st.th = dalloc<double>(n);
+    env->st.thdot = dalloc<double>(n);
+    env->st.nv_pos = dalloc<uint8_t>(n);
+    env->st.steps_remaining = dalloc<uint32_t>(n);
+    env->st.reset_count = dalloc<uint32_t>(n);
+    env->d_actions = dalloc<uint8_t>(n);
+    env->d_flag = dalloc<uint8_t>(n);
+    env->d_reward = dalloc<float>(n);
+    env->d_obs = dalloc<float>(n * env->D);
+    env->d_term_obs = dalloc<float>(n * env->D);
+    RL_HIP_CHECK(hipMemsetAsync(env->st.reset_count, 0, n * sizeof(uint32_t), e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(env->d_actions, 0, n, e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(env->d_term_obs, 0, n * env->D * sizeof(float), e->stream));
+    launch_env_reset(env.get());
+    sync(e);
+    e->live_handles += 1;
+    *out = env.release();
+  });
+}
+
+int32_t rl_env_destroy(rl_env *env) {
+  if (!env) return RL_OK;
+  (void)hipSetDevice(env->eng->device);
+  (void)hipStreamSynchronize(env->eng->stream);
+  dfree(env->st.x);
+  dfree(env->st.xdot);
+  dfree(env->st.th);
+  dfree(env->st.thdot);
+  dfree(env->st.nv_pos);
+  dfree(env->st.steps_remaining);
+  dfree(env->st.reset_count);
+  dfree(env->d_actions);
+  dfree(env->d_flag);
+  dfree(env->d_reward);
+  dfree(env->d_obs);
+  dfree(env->d_term_obs);
+  rl_engine *eng = env->eng;
+  delete env;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_env_dims(const rl_env *env, uint32_t *obs_dim, uint32_t *n_actions) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env, "env is NULL");
+    if (obs_dim) *obs_dim = env->D;
+    if (n_actions) *n_actions = env->A;
+  });
+}
+
+int32_t rl_env_reset(rl_env *env) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env, "env is NULL");
+    launch_env_reset(env);
+  });
+}
+
+int32_t rl_env_observe(rl_env *env, float *obs_out) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && obs_out, "NULL argument");
+    launch_env_observe(env, env->d_obs);
+    d2h(env->eng, obs_out, env->d_obs, env->cfg.n_lanes * env->D * sizeof(float));
+  });
+}
+
+int32_t rl_env_upload_actions(rl_env *env, const uint8_t *actions) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && actions, "NULL argument");
+    h2d(env->eng, env->d_actions, actions, env->cfg.n_lanes);
+  });
+}
+
+int32_t rl_env_step_resident(rl_env *env) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env, "env is NULL");
+    launch_env_step(env);
+    env->t_global += 1;
+  });
+}
+
+int32_t rl_env_step(rl_env *env, const uint8_t *actions, float *reward_out, uint8_t *flag_out, float *obs_out,
+                    float *term_obs_out) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && actions, "NULL argument");
+    rl_engine *e = env->eng;
+    size_t n = env->cfg.n_lanes;
+    RL_HIP_CHECK(hipMemcpyAsync(env->d_actions, actions, n, hipMemcpyHostToDevice, e->stream));
+    launch_env_step(env);
+    env->t_global += 1;
+    if (reward_out)
+      RL_HIP_CHECK(hipMemcpyAsync(reward_out, env->d_reward, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (flag_out) RL_HIP_CHECK(hipMemcpyAsync(flag_out, env->d_flag, n, hipMemcpyDeviceToHost, e->stream));
+    if (obs_out)
+      RL_HIP_CHECK(
+          hipMemcpyAsync(obs_out, env->d_obs, n * env->D * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (term_obs_out)
+      RL_HIP_CHECK(hipMemcpyAsync(term_obs_out, env->d_term_obs, n * env->D * sizeof(float), hipMemcpyDeviceToHost,
+                                  e->stream));
+    sync(e);
+  });
+}
+
+int32_t rl_env_get_state(rl_env *env, double *state4, int32_t *nv_pos, uint64_t *steps_remaining,
+                         uint64_t *reset_count) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && state4 && nv_pos && steps_remaining && reset_count, "NULL argument");
+    rl_engine *e = env->eng;
+    size_t n = env->cfg.n_lanes;
+    d2h(e, state4 + 0 * n, env->st.x, n * sizeof(double));
+    d2h(e, state4 + 1 * n, env->st.xdot, n * sizeof(double));
+    d2h(e, state4 + 2 * n, env->st.th, n * sizeof(double));
+    d2h(e, state4 + 3 * n, env->st.thdot, n * sizeof(double));
+    std::vector<uint8_t> nv(n);
+    std::vector<uint32_t> a(n), b(n);
+    d2h(e, nv.data(), env->st.nv_pos, n);
+    d2h(e, a.data(), env->st.steps_remaining, n * sizeof(uint32_t));
+    d2h(e, b.data(), env->st.reset_count, n * sizeof(uint32_t));
+    for (size_t i = 0; i < n; ++i) {
+      nv_pos[i] = nv[i];
+      steps_remaining[i] = a[i];
+      reset_count[i] = b[i];
+    }
+  });
+}
+
+int32_t rl_env_set_state(rl_env *env, const double *state4, const int32_t *nv_pos, const uint64_t *steps_remaining,
+                         const uint64_t *reset_count) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && state4 && nv_pos && steps_remaining && reset_count, "NULL argument");
+    rl_engine *e = env->eng;
+    size_t n = env->cfg.n_lanes;
+    std::vector<uint8_t> nv(n);
+    std::vector<uint32_t> a(n), b(n);
+    for (size_t i = 0; i < n; ++i) {
+      nv[i] = nv_pos[i] ? 1 : 0;
+      RL_REQUIRE(steps_remaining[i] < (1ull << 32) && reset_count[i] < (1ull << 32), "state value out of range");
+      a[i] = (uint32_t)steps_remaining[i];
+      b[i] = (uint32_t)reset_count[i];
+    }
+    h2d(e, env->st.x, state4 + 0 * n, n * sizeof(double));
+    h2d(e, env->st.xdot, state4 + 1 * n, n * sizeof(double));
+    h2d(e, env->st.th, state4 + 2 * n, n * sizeof(double));
+    h2d(e, env->st.thdot, state4 + 3 * n, n * sizeof(double));
+    h2d(e, env->st.nv_pos, nv.data(), n);
+    h2d(e, env->st.steps_remaining, a.data(), n * sizeof(uint32_t));
+    h2d(e, env->st.reset_count, b.data(), n * sizeof(uint32_t));
+  });
+}
+
+// ---------------------------------------------------------------- mlp
+int32_t rl_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t hidden, uint32_t out_dim, rl_mlp **out) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && out, "NULL argument");
+    *out = nullptr;
+    if (!(in_dim == 4 || in_dim == 5) || !(out_dim == 1 || out_dim == 2) || hidden == 0 || hidden > 128)
+      throw RlError(RL_ERR_BUILD_AGENT, "supported MLP shapes: in_dim in {4,5}, 1 <= hidden <= 128, out_dim in {1,2}");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_mlp> m(new rl_mlp());
+    m->eng = e;
+    m->in_dim = in_dim;
+    m->hidden = hidden;
+    m->out_dim = out_dim;
+    m->P = (uint64_t)hidden * in_dim + hidden + (uint64_t)out_dim * hidden + out_dim;
+    m->d_params = dalloc<float>(m->P);
+    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+    sync(e);
+    e->live_handles += 1;
+    *out = m.release();
+  });
+}
+
+int32_t rl_mlp_destroy(rl_mlp *m) {
+  if (!m) return RL_OK;
+  (void)hipSetDevice(m->eng->device);
+  (void)hipStreamSynchronize(m->eng->stream);
+  dfree(m->d_params);
+  rl_engine *eng = m->eng;
+  delete m;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_mlp_num_params(const rl_mlp *m, uint64_t *n) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m && n, "NULL argument");
+    *n = m->P;
+  });
+}
+
+int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m, "mlp is NULL");
+    // Linear::new (reference src/torch/modules/ff/linear.rs:54-68; initializers.rs:31-38,78-108,159-163):
+    // Uniform(+-sqrt(3 * 2 / (fan_in + fan_out))) with fan_in = in_dim + 1 for kernel and bias.
+    // Stream (engine-defined, libtorch's RNG is unseeded in the reference): ChaCha8(seed), stream 0,
+    // one Standard f32 per element in flat parameter order; value = (2u - 1) * lim in f32.
+    std::vector<float> h(m->P);
+    uint32_t key[8];
+    rl_seed_from_u64(seed, key);
+    uint32_t words[16];
+    uint64_t widx = 0;
+    auto next_f32 = [&]() {
+      if ((widx & 15) == 0) rl_chacha_block(key, widx >> 4, 0, 4, words);
+      float u = rl_u32_to_unit_f32(words[widx & 15]);
+      widx += 1;
+      return u;
+    };
+    uint32_t dims[2][2] = {{m->in_dim, m->hidden}, {m->hidden, m->out_dim}};
+    size_t k = 0;
+    for (int l = 0; l < 2; ++l) {
+      uint32_t in = dims[l][0], out = dims[l][1];
+      float lim = (float)std::sqrt(3.0 * (2.0 / ((double)(in + 1) + (double)out)));
+      size_t cnt = (size_t)in * out + out;
+      for (size_t i = 0; i < cnt; ++i) {
+        float u = next_f32();
+        float t = 2.0f * u;
+        t = t - 1.0f;
+        h[k++] = t * lim;
+      }
+    }
+    h2d(m->eng, m->d_params, h.data(), m->P * sizeof(float));
+  });
+}
+
+int32_t rl_params_get(rl_mlp *m, float *host, uint64_t n) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m && host, "NULL argument");
+    RL_REQUIRE(n == m->P, "parameter count mismatch");
+    d2h(m->eng, host, m->d_params, n * sizeof(float));
+  });
+}
+
+int32_t rl_params_set(rl_mlp *m, const float *host, uint64_t n) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m && host, "NULL argument");
+    RL_REQUIRE(n == m->P, "parameter count mismatch");
+    h2d(m->eng, m->d_params, host, n * sizeof(float));
+  });
+}
+
+int32_t rl_mlp_forward(rl_mlp *m, const float *rows, uint64_t n_rows, float *out) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m && rows && out, "NULL argument");
+    if (n_rows == 0) return;
+    rl_engine *e = m->eng;
+    std::vector<float> soa((size_t)n_rows * m->in_dim), res((size_t)n_rows * m->out_dim);
+    for (uint64_t r = 0; r < n_rows; ++r)
+      for (uint32_t d = 0; d < m->in_dim; ++d) soa[(size_t)d * n_rows + r] = rows[r * m->in_dim + d];
+    float *d_in = dalloc<float>(soa.size()), *d_out = dalloc<float>(res.size());
+    try {
+      h2d(e, d_in, soa.data(), soa.size() * sizeof(float));
+      launch_mlp_forward_host_rows(m, d_in, n_rows, d_out);
+      d2h(e, res.data(), d_out, res.size() * sizeof(float));
+    } catch (...) {
+      dfree(d_in);
+      dfree(d_out);
+      throw;
+    }
+    dfree(d_in);
+    dfree(d_out);
+    for (uint64_t r = 0; r < n_rows; ++r)
+      for (uint32_t a = 0; a < m->out_dim; ++a) out[r * m->out_dim + a] = res[(size_t)a * n_rows + r];
+  });
+}
+
+// ---------------------------------------------------------------- trajectory
+static void traj_field(const rl_traj *t, int32_t field, void **ptr, uint64_t *bytes) {
+  uint64_t n = t->d.n, T = t->d.T, D = t->d.D;
+  switch (field) {
+    case RL_TRAJ_OBS: *ptr = t->d.obs; *bytes = D * (T + 1) * n * 4; break;
+    case RL_TRAJ_ACTION: *ptr = t->d.action; *bytes = T * n; break;
+    case RL_TRAJ_REWARD: *ptr = t->d.reward; *bytes = T * n * 4; break;
+    case RL_TRAJ_FLAG: *ptr = t->d.flag; *bytes = T * n; break;
+    case RL_TRAJ_TERM_OBS: *ptr = t->d.term_obs; *bytes = D * T * n * 4; break;
+    case RL_TRAJ_VALUES: *ptr = t->d.values; *bytes = (T + 1) * n * 4; break;
+    case RL_TRAJ_ADVANTAGES: *ptr = t->d.adv; *bytes = T * n * 4; break;
+    case RL_TRAJ_RETURNS: *ptr = t->d.rtg; *bytes = T * n * 4; break;
+    default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown trajectory field");
+  }
+}
+
+int32_t rl_traj_create(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, rl_traj **out) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && out, "NULL argument");
+    *out = nullptr;
+    RL_REQUIRE(n_lanes > 0 && n_lanes < (1ull << 31), "bad n_lanes");
+    RL_REQUIRE(horizon > 0 && horizon < (1ull << 20), "bad horizon");
+    RL_REQUIRE(obs_dim == 4 || obs_dim == 5, "obs_dim must be 4 or 5");
+    RL_REQUIRE(n_lanes * horizon < (1ull << 32), "T * n must fit 32 bits");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_traj> t(new rl_traj());
+    t->eng = e;
+    t->d.n = (uint32_t)n_lanes;
+    t->d.T = (uint32_t)horizon;
+    t->d.D = obs_dim;
+    uint64_t n = n_lanes, T = horizon, D = obs_dim;
+    t->B = n * T;
+    t->d.obs = dalloc<float>(D * (T + 1) * n);
+    t->d.action = dalloc<uint8_t>(T * n);
+    t->d.reward = dalloc<float>(T * n);
+    t->d.flag = dalloc<uint8_t>(T * n);
+    t->d.term_obs = dalloc<float>(D * T * n);
+    t->d.values = dalloc<float>((T + 1) * n);
+    t->d.adv = dalloc<float>(T * n);
+    t->d.rtg = dalloc<float>(T * n);
+    t->lp0 = dalloc<float>(2 * t->B);
+    t->dz = dalloc<float>(2 * t->B);
+    t->Pmax = 128 * 5 + 128 + 2 * 128 + 2;
+    // backward: <= 1024 workgroups of 128 threads, chunk a multiple of 8 samples
+    uint64_t chunk = (t->B + 1023) / 1024;
+    chunk = ((chunk + 7) / 8) * 8;
+    if (chunk < 64) chunk = 64;
+    t->bwd_chunk = (uint32_t)chunk;
+    t->nbA = (uint32_t)((t->B + chunk - 1) / chunk);
+    uint64_t nbB = (t->B + 255) / 256;
+    if (nbB > 2048) nbB = 2048;
+    t->nbB = (uint32_t)nbB;
+    t->slabA = dalloc<double>((size_t)t->nbA * t->Pmax);
+    t->slabB = dalloc<double>((size_t)t->nbB * 4);
+    t->vec = dalloc<float>(t->Pmax + 4);
+    t->cg_x = dalloc<float>(t->Pmax);
+    t->cg_r = dalloc<float>(t->Pmax);
+    t->cg_p = dalloc<float>(t->Pmax);
+    t->prev_params = dalloc<float>(t->Pmax);
+    t->descent = dalloc<float>(t->Pmax);
+    t->max_losses = 4096;
+    t->losses = dalloc<float>(t->max_losses);
+    t->trpo = dalloc<TrpoStateDev>(1);
+    RL_HIP_CHECK(hipMemsetAsync(t->d.term_obs, 0, D * T * n * 4, e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(t->d.values, 0, (T + 1) * n * 4, e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(t->d.adv, 0, T * n * 4, e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(t->d.rtg, 0, T * n * 4, e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(t->trpo, 0, sizeof(TrpoStateDev), e->stream));
+    sync(e);
+    e->live_handles += 1;
+    *out = t.release();
+  });
+}
+
+int32_t rl_traj_destroy(rl_traj *t) {
+  if (!t) return RL_OK;
+  (void)hipSetDevice(t->eng->device);
+  (void)hipStreamSynchronize(t->eng->stream);
+  void *ptrs[] = {t->d.obs, t->d.action, t->d.reward, t->d.flag, t->d.term_obs, t->d.values, t->d.adv, t->d.rtg,
+                  t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
+                  t->losses, t->trpo};
+  for (void *p : ptrs) dfree(p);
+  rl_engine *eng = t->eng;
+  delete t;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_traj_field_bytes(const rl_traj *t, int32_t field, uint64_t *bytes) {
+  return guarded(t ? t->eng : nullptr, [&] {
+    RL_REQUIRE(t && bytes, "NULL argument");
+    void *p;
+    traj_field(t, field, &p, bytes);
+  });
+}
+
+int32_t rl_traj_read(rl_traj *t, int32_t field, void *host, uint64_t bytes) {
+  return guarded(t ? t->eng : nullptr, [&] {
+    RL_REQUIRE(t && host, "NULL argument");
+    void *p;
+    uint64_t need;
+    traj_field(t, field, &p, &need);
+    RL_REQUIRE(bytes == need, "byte count mismatch for trajectory field");
+    d2h(t->eng, host, p, bytes);
+  });
+}
+
+int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t bytes) {
+  return guarded(t ? t->eng : nullptr, [&] {
+    RL_REQUIRE(t && host, "NULL argument");
+    void *p;
+    uint64_t need;
+    traj_field(t, field, &p, &need);
+    RL_REQUIRE(bytes == need, "byte count mismatch for trajectory field");
+    h2d(t->eng, p, host, bytes);
+  });
+}
+
+// ---------------------------------------------------------------- rollout + GAE
+int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && policy && traj, "NULL argument");
+    RL_REQUIRE(env->eng == traj->eng && env->eng == policy->eng, "handles belong to different engines");
+    RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
+    RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
+    launch_rollout(env, policy, traj);
+    env->t_global += traj->d.T;
+  });
+}
+
+int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    RL_REQUIRE(traj && critic, "NULL argument");
+    RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
+    launch_values(traj, critic);
+    launch_gae(traj, critic, gamma, lambda);
+  });
+}
+
+// ---------------------------------------------------------------- TRPO
+int32_t rl_trpo_config_default(rl_trpo_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    // ConjugateGradientOptimizerConfig::default (conjugate_gradient.rs:55-65), TrpoConfig::default (trpo.rs:29-41)
+    c->iterations = 10;
+    c->max_backtracks = 15;
+    c->backtrack_ratio = 0.8;
+    c->hpv_reg_coeff = 1e-5;
+    c->max_policy_step_kl = 0.01;
+    c->accept_violation = 0;
+  });
+}
+
+static void check_policy(const rl_mlp *policy, const rl_traj *traj) {
+  RL_REQUIRE(policy && traj, "NULL argument");
+  RL_REQUIRE(policy->eng == traj->eng, "handles belong to different engines");
+  RL_REQUIRE(policy->in_dim == traj->d.D && policy->out_dim == 2, "policy shape does not match the trajectory");
+}
+
+// gradient pass: PASS_INIT -> backward -> reduce(A+B) -> allreduce
+static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
+  uint32_t P = (uint32_t)policy->P;
+  launch_policy_pass(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr);
+  launch_mlp_backward(traj, policy, nullptr);
+  launch_reduce(traj, P, true, true);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+// Fisher/Hessian-vector product pass with tangent d_v: PASS_JVP -> backward -> reduce(A) -> allreduce
+static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
+  uint32_t P = (uint32_t)policy->P;
+  launch_policy_pass(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip);
+  launch_mlp_backward(traj, policy, d_skip);
+  launch_reduce(traj, P, true, false);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P);
+}
+
+int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(cfg && stats, "NULL argument");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj);
+    float reg = (float)cfg->hpv_reg_coeff;
+    // loss gradient at theta0 and CG prologue
+    run_policy_gradient(policy, traj);
+    launch_trpo_begin(traj, policy, Bt);
+    // x = A^-1 g by `iterations` CG steps (early exit handled on the device)
+    for (uint64_t it = 0; it < cfg->iterations; ++it) {
+      run_policy_fvp(policy, traj, traj->cg_p, &traj->trpo->cg_done);
+      launch_cg_step(traj, P, reg, 1e-10f);
+    }
+    launch_cg_finish(traj, P);
+    // step size from x^T A x
+    run_policy_fvp(policy, traj, traj->cg_x, nullptr);
+    launch_step_size(traj, policy, reg, cfg->max_policy_step_kl);
+    // backtracking line search
+    double ratio = 1.0;
+    for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
+      if (i > 0) ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
+      launch_ls_set_params(traj, policy, ratio);
+      launch_policy_pass(traj, policy, PASS_EVAL, nullptr, Bt, &traj->trpo->ls_accepted);
+      launch_reduce(traj, P, false, true);
+      rl_allreduce_sum_f32(e, traj->vec + P, 4);
+      launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
+    }
+    launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
+    TrpoStateDev h;
+    d2h(e, &h, traj->trpo, sizeof(h));
+    stats->entropy = (double)h.entropy;
+    stats->step_size = h.step_size;
+    stats->loss_initial = (double)h.loss0;
+    stats->loss_final = (double)h.ls_loss;
+    stats->constraint_val_final = (double)h.ls_kl;
+    stats->step_scale = h.ls_accepted ? h.ls_ratio : 0.0;
+    stats->num_backtracks = h.ls_accepted ? (int64_t)h.ls_index : -1;
+    stats->status = h.status;
+    stats->cg_iterations = h.cg_iters;
+    if (h.status == RL_OPT_NAN_LOSS || h.status == RL_OPT_NAN_CONSTRAINT)
+      throw RlError(RL_ERR_OPT_NAN, h.status == RL_OPT_NAN_LOSS ? "NaN loss in policy optimization"
+                                                                : "NaN constraint in policy optimization");
+  });
+}
+
+int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float *loss_out, float *entropy_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(grad_out, "grad_out is NULL");
+    uint32_t P = (uint32_t)policy->P;
+    run_policy_gradient(policy, traj);
+    std::vector<float> h(P + 4);
+    d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
+    std::memcpy(grad_out, h.data(), P * sizeof(float));
+    double inv_B = 1.0 / (double)b_total(traj);
+    if (loss_out) *loss_out = (float)(-((double)h[P] * inv_B));
+    if (entropy_out) *entropy_out = (float)((double)h[P + 1] * inv_B);
+  });
+}
+
+int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, float *out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(v && out, "NULL argument");
+    uint32_t P = (uint32_t)policy->P;
+    h2d(traj->eng, traj->cg_x, v, P * sizeof(float));
+    run_policy_fvp(policy, traj, traj->cg_x, nullptr);
+    std::vector<float> h(P);
+    d2h(traj->eng, h.data(), traj->vec, P * sizeof(float));
+    for (uint32_t i = 0; i < P; ++i) out[i] = h[i] + reg * v[i];
+  });
+}
+
+int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, float *loss_out, float *kl_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(params0 && loss_out && kl_out, "NULL argument");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj);
+    // lp0 under params0, then evaluate the current parameters against it
+    std::vector<float> cur(P);
+    d2h(e, cur.data(), policy->d_params, P * sizeof(float));
+    h2d(e, policy->d_params, params0, P * sizeof(float));
+    launch_policy_pass(traj, policy, PASS_INIT, nullptr, Bt, nullptr);
+    h2d(e, policy->d_params, cur.data(), P * sizeof(float));
+    launch_policy_pass(traj, policy, PASS_EVAL, nullptr, Bt, nullptr);
+    launch_reduce(traj, P, false, true);
+    rl_allreduce_sum_f32(e, traj->vec + P, 4);
+    float h[4];
+    d2h(e, h, traj->vec + P, sizeof(h));
+    double inv_B = 1.0 / (double)Bt;
+    *loss_out = (float)(-((double)h[0] * inv_B));
+    *kl_out = (float)((double)h[1] * inv_B);
+  });
+}
+
+// ---------------------------------------------------------------- critic
+int32_t rl_adam_config_default(rl_adam_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    c->learning_rate = 1e-3;  // AdamConfig::default (coptimizer.rs:147-156)
+    c->beta1 = 0.9;
+    c->beta2 = 0.999;
+    c->weight_decay = 0.0;
+    c->eps = 1e-8;  // libtorch AdamOptions default
+  });
+}
+
+int32_t rl_adam_create(rl_mlp *module, const rl_adam_config *cfg, rl_adam **out) {
+  return guarded(module ? module->eng : nullptr, [&] {
+    RL_REQUIRE(module && cfg && out, "NULL argument");
+    *out = nullptr;
+    rl_engine *e = module->eng;
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_adam> o(new rl_adam());
+    o->mod = module;
+    o->cfg = *cfg;
+    o->d_m = dalloc<float>(module->P);
+    o->d_v = dalloc<float>(module->P);
+    o->d_step = dalloc<uint64_t>(1);
+    RL_HIP_CHECK(hipMemsetAsync(o->d_m, 0, module->P * sizeof(float), e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(o->d_v, 0, module->P * sizeof(float), e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(o->d_step, 0, sizeof(uint64_t), e->stream));
+    sync(e);
+    e->live_handles += 1;
+    *out = o.release();
+  });
+}
+
+int32_t rl_adam_destroy(rl_adam *o) {
+  if (!o) return RL_OK;
+  (void)hipSetDevice(o->mod->eng->device);
+  (void)hipStreamSynchronize(o->mod->eng->stream);
+  dfree(o->d_m);
+  dfree(o->d_v);
+  dfree(o->d_step);
+  rl_engine *eng = o->mod->eng;
+  delete o;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_adam_step_host(rl_adam *o, const float *grad) {
+  return guarded(o ? o->mod->eng : nullptr, [&] {
+    RL_REQUIRE(o && grad, "NULL argument");
+    rl_engine *e = o->mod->eng;
+    float *d_g = dalloc<float>(o->mod->P);
+    try {
+      h2d(e, d_g, grad, o->mod->P * sizeof(float));
+      launch_adam_step_vec(o, d_g);
+      sync(e);
+    } catch (...) {
+      dfree(d_g);
+      throw;
+    }
+    dfree(d_g);
+  });
+}
+
+static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
+  RL_REQUIRE(critic && traj, "NULL argument");
+  RL_REQUIRE(critic->eng == traj->eng, "handles belong to different engines");
+  RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
+}
+
+static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
+  uint32_t P = (uint32_t)critic->P;
+  launch_critic_fwd(traj, critic, b_total(traj));
+  launch_mlp_backward(traj, critic, nullptr);
+  launch_reduce(traj, P, true, true);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
+                         float *losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_critic(critic, traj);
+    RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
+    RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
+    uint64_t Bt = b_total(traj);
+    for (uint64_t k = 0; k < opt_steps; ++k) {
+      run_critic_gradient(critic, traj);
+      launch_adam_step(traj, opt, (int)k, Bt);
+    }
+    if (stats || losses_out) {
+      std::vector<float> h(opt_steps ? opt_steps : 1);
+      if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
+      if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
+      if (stats) {
+        stats->steps = opt_steps;
+        stats->loss_first = opt_steps ? (double)h[0] : 0.0;
+        stats->loss_last = opt_steps ? (double)h[opt_steps - 1] : 0.0;
+      }
+    }
+  });
+}
+
+int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_critic(critic, traj);
+    RL_REQUIRE(grad_out, "grad_out is NULL");
+    uint32_t P = (uint32_t)critic->P;
+    run_critic_gradient(critic, traj);
+    std::vector<float> h(P + 4);
+    d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
+    std::memcpy(grad_out, h.data(), P * sizeof(float));
+    if (loss_out) *loss_out = (float)((double)h[P] / (double)b_total(traj));
+  });
+}
+
+}  // extern "C"

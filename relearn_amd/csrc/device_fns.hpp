@@ -1,0 +1,197 @@
+// device_fns.hpp — per-lane device functions shared by the kernels.
+//
+// Arithmetic contract: this library is compiled with -ffp-contract=off.  Every fused multiply-add is
+// written explicitly (__builtin_fmaf / __builtin_fma); every other a*b+c is two roundings, exactly like
+// the reference's Rust and like the oracle (gcc -ffp-contract=off).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/rl_chacha.h"
+#include "../../include/rl_detmath.h"
+#include "engine.hpp"
+
+// ---------------------------------------------------------------- CartPole physics
+// InternalPhysicalConstants::{next_state, angular_acceleration, normal_force}
+// (reference src/envs/cartpole.rs:306-446).  f64 throughout, operation order preserved.
+__device__ __forceinline__ double cp_angular_acceleration(const CartPoleDev &c, double thdot, double applied_force,
+                                                          double signed_cart_friction, double w2, double sin_a,
+                                                          double cos_a) {
+  double alpha =
+      (-applied_force - c.mass_length_pole * w2 * (sin_a + signed_cart_friction * cos_a)) * c.inv_total_mass;
+  double beta = c.friction_pole * thdot / c.mass_length_pole;
+  double numerator = c.gravity * sin_a + cos_a * (alpha + c.gravity * signed_cart_friction) - beta;
+  double denominator =
+      c.length_half_pole * (4.0 / 3.0 - c.mass_pole * cos_a * c.inv_total_mass * (cos_a - signed_cart_friction));
+  return numerator / denominator;
+}
+
+__device__ __forceinline__ double cp_normal_force(const CartPoleDev &c, double acc, double w2, double sin_a,
+                                                  double cos_a) {
+  return c.total_weight - c.mass_length_pole * (acc * sin_a + w2 * cos_a);
+}
+
+struct LaneState {
+  double x, xdot, th, thdot;
+  uint32_t nv_pos;
+  uint32_t steps_remaining;
+  uint32_t reset_count;
+};
+
+// CartPole::step (cartpole.rs:128-154) + Wrapped<_, StepLimit>::step tail (wrappers/step_limit.rs:216-222).
+// Returns the successor code; on Continue/Interrupt `s` holds the next state.
+__device__ __forceinline__ int cp_step(const CartPoleDev &c, LaneState &s, int action) {
+  double applied_force = action == 0 ? -c.action_force : c.action_force;
+  double signed_cart_friction = s.nv_pos ? c.friction_cart : -c.friction_cart;
+  double sin_a, cos_a;
+  rl_sincos(s.th, &sin_a, &cos_a);
+  double w2 = s.thdot * s.thdot;
+  double acc = cp_angular_acceleration(c, s.thdot, applied_force, signed_cart_friction, w2, sin_a, cos_a);
+  double nf = cp_normal_force(c, acc, w2, sin_a, cos_a);
+  uint32_t nv_pos = (rl_f64_bits(nf * s.xdot) >> 63) ? 0u : 1u;  // is_sign_positive
+  if (nv_pos != s.nv_pos) {
+    signed_cart_friction = -signed_cart_friction;
+    acc = cp_angular_acceleration(c, s.thdot, applied_force, signed_cart_friction, w2, sin_a, cos_a);
+    nf = cp_normal_force(c, acc, w2, sin_a, cos_a);
+  }
+  double force_pole = c.mass_length_pole * (w2 * sin_a + acc * cos_a);
+  double force_friction = -signed_cart_friction * nf;
+  double net_force = applied_force + force_pole + force_friction;
+  double cart_acc = net_force * c.inv_total_mass;
+  double xdot = s.xdot + c.time_step * cart_acc;
+  double x = s.x + c.time_step * xdot;
+  double thdot = s.thdot + c.time_step * acc;
+  double th = s.th + c.time_step * s.thdot;
+  bool terminal = __builtin_fabs(x) > c.max_pos || __builtin_fabs(th) > c.max_angle;
+  if (terminal) return RL_SUCC_TERMINATE;
+  s.x = x;
+  s.xdot = xdot;
+  s.th = th;
+  s.thdot = thdot;
+  s.nv_pos = nv_pos;
+  if (c.limit_kind != RL_LIMIT_NONE) {
+    s.steps_remaining -= 1;
+    if (s.steps_remaining == 0) return RL_SUCC_INTERRUPT;
+  }
+  return RL_SUCC_CONTINUE;
+}
+
+// features_out of StepLimitObsSpace<CartPolePhysicalStateSpace> (spaces/interval.rs:108-116,
+// wrappers/step_limit.rs:127-140,194-200): each field `as f32`, `remaining` last.
+template <int D>
+__device__ __forceinline__ void cp_features(const CartPoleDev &c, const LaneState &s, float (&f)[D]) {
+  f[0] = (float)s.x;
+  f[1] = (float)s.xdot;
+  f[2] = (float)s.th;
+  f[3] = (float)s.thdot;
+  if (D == 5) f[4] = (float)((double)s.steps_remaining / (double)c.max_steps);
+}
+
+// CartPole::initial_state (cartpole.rs:103-115) from the lane's env stream: reset k reads words [8k, 8k+8).
+__device__ __forceinline__ void cp_reset(const CartPoleDev &c, LaneState &s, uint64_t global_lane) {
+  uint32_t w[16];
+  uint32_t k = s.reset_count;
+  rl_chacha_block(c.key_env, (uint64_t)(k >> 1), global_lane, 4, w);
+  bool hi = (k & 1u) != 0;
+  uint32_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = hi ? w[8 + i] : w[i];
+  s.x = rl_uniform_f64_from_u64(((uint64_t)v[1] << 32) | v[0], c.init_low, c.init_scale);
+  s.xdot = rl_uniform_f64_from_u64(((uint64_t)v[3] << 32) | v[2], c.init_low, c.init_scale);
+  s.th = rl_uniform_f64_from_u64(((uint64_t)v[5] << 32) | v[4], c.init_low, c.init_scale);
+  s.thdot = rl_uniform_f64_from_u64(((uint64_t)v[7] << 32) | v[6], c.init_low, c.init_scale);
+  s.nv_pos = 1;
+  s.steps_remaining = c.max_steps;
+  s.reset_count = k + 1;
+}
+
+__device__ __forceinline__ void lane_load(const EnvStateDev &st, uint32_t i, LaneState &s) {
+  s.x = st.x[i];
+  s.xdot = st.xdot[i];
+  s.th = st.th[i];
+  s.thdot = st.thdot[i];
+  s.nv_pos = st.nv_pos[i];
+  s.steps_remaining = st.steps_remaining[i];
+  s.reset_count = st.reset_count[i];
+}
+
+__device__ __forceinline__ void lane_store(const EnvStateDev &st, uint32_t i, const LaneState &s) {
+  st.x[i] = s.x;
+  st.xdot[i] = s.xdot;
+  st.th[i] = s.th;
+  st.thdot[i] = s.thdot;
+  st.nv_pos[i] = (uint8_t)s.nv_pos;
+  st.steps_remaining[i] = s.steps_remaining;
+  st.reset_count[i] = s.reset_count;
+}
+
+// ---------------------------------------------------------------- MLP forward, one row per lane
+// Mlp::forward (torch/modules/ff/mlp.rs:139-151): relu(x W1^T + b1) W2^T + b2, weights wave-uniform
+// (scalar loads), chain order: acc = bias; acc = fma(x_k, w_k, acc) with k ascending.
+template <int D, int A>
+__device__ __forceinline__ void mlp_forward_lane(const float *__restrict__ params, int H, const float (&x)[D],
+                                                 float (&z)[A]) {
+  const float *__restrict__ W1 = params;
+  const float *__restrict__ b1 = W1 + H * D;
+  const float *__restrict__ W2 = b1 + H;
+  const float *__restrict__ b2 = W2 + A * H;
+#pragma unroll
+  for (int a = 0; a < A; ++a) z[a] = b2[a];
+  for (int j = 0; j < H; ++j) {
+    float acc = b1[j];
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(x[k], W1[j * D + k], acc);
+    float h = acc > 0.0f ? acc : 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) z[a] = __builtin_fmaf(h, W2[a * H + j], z[a]);
+  }
+}
+
+// Categorical::new: log_softmax (torch/distributions/categorical.rs:29-33)
+template <int A>
+__device__ __forceinline__ void log_softmax_lane(const float (&z)[A], float (&lp)[A]) {
+  float m = z[0];
+#pragma unroll
+  for (int a = 1; a < A; ++a)
+    if (z[a] > m) m = z[a];
+  float s = 0.0f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) s += rl_expf(z[a] - m);
+  float ls = rl_logf(s);
+#pragma unroll
+  for (int a = 0; a < A; ++a) lp[a] = (z[a] - m) - ls;
+}
+
+// `log_probs.exp().multinomial(1, true)` (categorical.rs:53) with an explicit uniform draw
+template <int A>
+__device__ __forceinline__ int categorical_sample_lane(const float (&lp)[A], float u) {
+  float cum = 0.0f;
+  int act = A - 1;
+  bool found = false;
+#pragma unroll
+  for (int a = 0; a + 1 < A; ++a) {
+    cum += rl_expf(lp[a]);
+    if (!found && u < cum) {
+      act = a;
+      found = true;
+    }
+  }
+  return act;
+}
+
+// ---------------------------------------------------------------- block reductions (deterministic)
+// Sum over a block with a fixed tree order; result valid in thread 0.
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_sum(T v, T *smem) {
+  int tid = threadIdx.x;
+  smem[tid] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if (tid < s) smem[tid] = smem[tid] + smem[tid + s];
+    __syncthreads();
+  }
+  T r = smem[0];
+  __syncthreads();
+  return r;
+}

@@ -1,0 +1,158 @@
+// engine.hpp — internal structures behind the opaque handles of include/relearn_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/relearn_hip.h"
+
+struct RlError : std::runtime_error {
+  int32_t code;
+  RlError(int32_t c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define RL_HIP_CHECK(expr)                                                                          \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      throw RlError(RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                                    std::to_string(__LINE__) + ")");                                \
+  } while (0)
+
+#define RL_REQUIRE(cond, msg)                                        \
+  do {                                                               \
+    if (!(cond)) throw RlError(RL_ERR_INVALID_ARGUMENT, (msg));      \
+  } while (0)
+
+// ---- device-side plain structs passed by value to kernels ---------------------------------------
+struct CartPoleDev {
+  double gravity, mass_pole, length_half_pole, friction_cart, friction_pole, time_step;
+  double action_force, max_pos, max_angle;
+  double total_weight, inv_total_mass, mass_length_pole;
+  double init_low, init_scale;  // Uniform::new_inclusive(-0.05, 0.05)
+  uint32_t key_env[8], key_actor[8];
+  uint64_t lane_offset;
+  uint32_t max_steps;
+  int32_t limit_kind;
+};
+
+struct EnvStateDev {
+  double *x, *xdot, *th, *thdot;  // [n]
+  uint8_t *nv_pos;                // [n] cached_normal_velocity_is_positive
+  uint32_t *steps_remaining;      // [n]
+  uint32_t *reset_count;          // [n]
+};
+
+struct TrajDev {
+  float *obs;       // [D][T+1][n]
+  uint8_t *action;  // [T][n]
+  float *reward;    // [T][n]
+  uint8_t *flag;    // [T][n]
+  float *term_obs;  // [D][T][n]
+  float *values;    // [T+1][n]
+  float *adv;       // [T][n]
+  float *rtg;       // [T][n]
+  uint32_t n, T, D;
+};
+
+// scalar state of one TRPO update, lives in HBM so that the whole update needs no host round trip
+struct TrpoStateDev {
+  float rr;            // CG residual norm squared
+  int32_t cg_done;     // CG converged (residual < tol): later HVP launches become no-ops
+  int32_t cg_iters;
+  float loss0;         // initial loss
+  float entropy;
+  double step_size;
+  int32_t ls_accepted;
+  int32_t ls_index;    // backtrack index that was accepted
+  double ls_ratio;
+  float ls_loss, ls_kl;  // last evaluated
+  int32_t status;
+};
+
+// ---- host-side handle structs ----------------------------------------------------------------------
+struct RcclApi;  // dlopen'ed entry points (comm.cpp)
+
+struct rl_engine {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop{};
+  std::string last_error;
+  // timing
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  bool profiling = false;
+  double prof_ms[RL_K_CLASS_COUNT] = {0};
+  uint64_t prof_launches[RL_K_CLASS_COUNT] = {0};
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+  std::vector<hipEvent_t> prof_event_pool;
+  // comm
+  void *comm = nullptr;  // ncclComm_t
+  int rank = 0, n_ranks = 1;
+  // host pinned scratch for small readbacks
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // child handles keep the engine alive: rl_engine_destroy with live children defers the teardown until the
+  // last child is destroyed (hosts with garbage collectors release handles in arbitrary order)
+  int64_t live_handles = 0;
+  bool zombie = false;
+};
+
+struct rl_env {
+  rl_engine *eng;
+  rl_env_config cfg;
+  CartPoleDev dev;
+  EnvStateDev st;
+  uint32_t D, A;
+  uint64_t t_global = 0;
+  // staging buffers for the standalone step API
+  uint8_t *d_actions = nullptr, *d_flag = nullptr;
+  float *d_reward = nullptr, *d_obs = nullptr, *d_term_obs = nullptr;
+};
+
+struct rl_mlp {
+  rl_engine *eng;
+  uint32_t in_dim, hidden, out_dim;
+  uint64_t P;
+  float *d_params = nullptr;
+};
+
+struct rl_adam {
+  rl_mlp *mod;
+  rl_adam_config cfg;
+  float *d_m = nullptr, *d_v = nullptr;
+  uint64_t *d_step = nullptr;
+};
+
+struct rl_traj {
+  rl_engine *eng;
+  TrajDev d;
+  uint64_t B;  // T * n
+  // update workspace
+  float *lp0 = nullptr;     // [2][B]
+  float *dz = nullptr;      // [2][B]
+  double *slabA = nullptr;  // [nbA][Pmax] per-workgroup partial sums (f64)
+  double *slabB = nullptr;  // [nbB][4]
+  float *vec = nullptr;     // reduced vector [Pmax + 4]
+  float *cg_x = nullptr, *cg_r = nullptr, *cg_p = nullptr, *prev_params = nullptr, *descent = nullptr;
+  float *losses = nullptr;  // [max critic steps]
+  TrpoStateDev *trpo = nullptr;
+  uint32_t nbA = 0, nbB = 0, Pmax = 0, max_losses = 0;
+  uint32_t bwd_chunk = 0;   // samples per backward block
+};
+
+// ---- profiling helper: wraps a launch with events when enabled ---------------------------------------
+struct ProfScope {
+  rl_engine *e;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(rl_engine *eng, int c);
+  ~ProfScope();
+};
+
+// comm.cpp
+void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count);

@@ -1,0 +1,35 @@
+// kernels.hpp — host launchers implemented in the .hip translation units.
+#pragma once
+#include "engine.hpp"
+
+// kernels_rollout.hip
+void launch_env_reset(rl_env *env);
+void launch_env_observe(rl_env *env, float *d_obs);
+void launch_env_step(rl_env *env);
+void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj);
+void launch_values(rl_traj *traj, const rl_mlp *critic);
+void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);
+void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa);
+
+// kernels_update.hip
+enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2 };
+// PASS_INIT : lp0 <- log pi(.|s); dz <- d(-mean(ratio*A))/dz at theta0; slabB <- {sum A, sum entropy}
+// PASS_EVAL : slabB <- {sum ratio*A, sum KL(pi0||pi)}                      (skipped when *skip_flag != 0)
+// PASS_JVP  : dz <- (diag(p) - p p^T) J v / B_total                         (skipped when *skip_flag != 0)
+void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
+                        const int32_t *d_skip_flag);
+void launch_critic_fwd(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
+// J^T dz accumulated per block into slabA (lane = hidden unit, samples broadcast through scalar loads)
+void launch_mlp_backward(rl_traj *traj, const rl_mlp *mlp, const int32_t *d_skip_flag);
+// vec[0..P) <- sum_blocks slabA (if useA), vec[P..P+4) <- sum_blocks slabB; deterministic order
+void launch_reduce(rl_traj *traj, uint32_t P, bool useA, bool useB);
+
+void launch_trpo_begin(rl_traj *traj, rl_mlp *policy, uint64_t B_total);                 // after grad reduce
+void launch_cg_step(rl_traj *traj, uint32_t P, float reg, float tol);                    // after HVP reduce
+void launch_cg_finish(rl_traj *traj, uint32_t P);                                        // nan_to_num, tangent <- x
+void launch_step_size(rl_traj *traj, rl_mlp *policy, float reg, double max_kl);          // after HVP(x) reduce
+void launch_ls_set_params(rl_traj *traj, rl_mlp *policy, double ratio);
+void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, double ratio, double max_kl);
+void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept_violation);
+void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_total);     // after critic reduce
+void launch_adam_step_vec(rl_adam *opt, const float *d_grad);

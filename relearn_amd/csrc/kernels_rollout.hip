@@ -1,0 +1,273 @@
+// kernels_rollout.hip — env step, fused persistent rollout, value forward and GAE scan.
+//
+// Layout: one env per lane, struct-of-arrays state in HBM, time-major trajectory planes so that every
+// global access of a wavefront is one contiguous 256-B (f32) / 64-B (u8) segment.
+#include "device_fns.hpp"
+#include "kernels.hpp"
+
+// ---------------------------------------------------------------- reset / observe / standalone step
+__global__ void k_env_reset(CartPoleDev c, EnvStateDev st, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  LaneState s;
+  s.reset_count = st.reset_count[i];
+  cp_reset(c, s, c.lane_offset + i);
+  lane_store(st, i, s);
+}
+
+template <int D>
+__global__ void k_env_observe(CartPoleDev c, EnvStateDev st, uint32_t n, float *__restrict__ obs) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  LaneState s;
+  lane_load(st, i, s);
+  float f[D];
+  cp_features<D>(c, s, f);
+#pragma unroll
+  for (int d = 0; d < D; ++d) obs[(size_t)d * n + i] = f[d];
+}
+
+// Environment::step for every lane (reference src/envs/cartpole.rs:128-154 through the step-limit wrapper),
+// with auto-reset.  Algorithmic traffic per env-step: read state 32 B + sign 1 B + remaining 4 B
+// + action 1 B; write state 37 B + reward 4 B + flag 1 B + next-obs 4*D B  => 100 B at D = 5.
+template <int D>
+__global__ void __launch_bounds__(256) k_env_step(CartPoleDev c, EnvStateDev st, uint32_t n,
+                                                  const uint8_t *__restrict__ actions, float *__restrict__ reward,
+                                                  uint8_t *__restrict__ flag, float *__restrict__ obs_next,
+                                                  float *__restrict__ term_obs) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  LaneState s;
+  lane_load(st, i, s);
+  int a = actions[i];
+  int succ = cp_step(c, s, a);
+  float f[D];
+  if (succ == RL_SUCC_INTERRUPT) {
+    cp_features<D>(c, s, f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) term_obs[(size_t)d * n + i] = f[d];
+  }
+  if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, c.lane_offset + i);
+  cp_features<D>(c, s, f);
+#pragma unroll
+  for (int d = 0; d < D; ++d) obs_next[(size_t)d * n + i] = f[d];
+  reward[i] = 1.0f;  // Reward(1.0) as f32
+  flag[i] = (uint8_t)succ;
+  lane_store(st, i, s);
+}
+
+// ---------------------------------------------------------------- fused persistent rollout
+// HOT LOOP A of the reference (src/simulation/steps.rs:113-167 + torch/agents/policies/actor.rs:42-55):
+// T env-actor steps per lane in one launch; lane state lives in registers for the whole horizon; the only
+// HBM traffic is the 26 B/step trajectory record (obs 20 + action 1 + reward 4 + flag 1) plus the sparse
+// interrupt successor observations.  The actor's uniform draw for global step t is word t of the lane's
+// ChaCha8 actor stream; a 16-word block is regenerated every 16 steps and parked in an LDS column that is
+// private to the lane (no bank conflicts: lanes are consecutive in the fastest dimension).
+template <int D, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvStateDev st, TrajDev tr,
+                                                            const float *__restrict__ policy, int H,
+                                                            uint64_t t_global) {
+  __shared__ uint32_t actor_words[16 * BLOCK];
+  const uint32_t n = tr.n, T = tr.T;
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;  // no barrier is used below, early exit is safe
+  const uint64_t lane = c.lane_offset + i;
+  LaneState s;
+  lane_load(st, i, s);
+  const size_t plane = (size_t)(T + 1) * n;
+  uint64_t cur_block = ~0ull;
+  for (uint32_t t = 0; t < T; ++t) {
+    float f[D];
+    cp_features<D>(c, s, f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)t * n + i] = f[d];
+    // actor draw
+    uint64_t w = t_global + t;
+    uint64_t blk = w >> 4;
+    if (blk != cur_block) {
+      uint32_t words[16];
+      rl_chacha_block(c.key_actor, blk, lane, 4, words);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) actor_words[k * BLOCK + threadIdx.x] = words[k];
+      cur_block = blk;
+    }
+    float u = rl_u32_to_unit_f32(actor_words[(uint32_t)(w & 15) * BLOCK + threadIdx.x]);
+    float z[2], lp[2];
+    mlp_forward_lane<D, 2>(policy, H, f, z);
+    log_softmax_lane<2>(z, lp);
+    int a = categorical_sample_lane<2>(lp, u);
+    int succ = cp_step(c, s, a);
+    size_t o = (size_t)t * n + i;
+    tr.action[o] = (uint8_t)a;
+    tr.reward[o] = 1.0f;
+    tr.flag[o] = (uint8_t)succ;
+    if (succ == RL_SUCC_INTERRUPT) {
+      cp_features<D>(c, s, f);
+#pragma unroll
+      for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * n + o] = f[d];
+    }
+    if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, lane);
+  }
+  float f[D];
+  cp_features<D>(c, s, f);
+#pragma unroll
+  for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)T * n + i] = f[d];
+  lane_store(st, i, s);
+}
+
+// ---------------------------------------------------------------- value forward over SoA rows
+// eval_extended_state_values (torch/agents/critics/mod.rs:116-131) on the lane layout: V for every
+// obs[.][t][lane], t = 0..T.  One row per lane, A outputs.
+template <int D, int A>
+__global__ void __launch_bounds__(256) k_mlp_forward_rows(const float *__restrict__ params, int H,
+                                                          const float *__restrict__ in, size_t in_plane,
+                                                          size_t rows, float *__restrict__ out, size_t out_plane) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float x[D], z[A];
+#pragma unroll
+  for (int d = 0; d < D; ++d) x[d] = in[d * in_plane + r];
+  mlp_forward_lane<D, A>(params, H, x, z);
+#pragma unroll
+  for (int a = 0; a < A; ++a) out[a * out_plane + r] = z[a];
+}
+
+// ---------------------------------------------------------------- GAE + reward-to-go scan
+// temporal_differences + gae + reward_to_go (critics/mod.rs:101-105,158-199) with the arithmetic of
+// inplace_discounted_cumsum_from_end (torch/packed.rs:312-342): delta = (r + gamma*V') - V, every op
+// rounded; a = a + (b * discount).  Lane-major: each lane walks its own time axis backwards, so
+// trim_end/trim_start (packed.rs:195-267) are index shifts.  Episode ends: Terminate -> V' = 0;
+// Interrupt -> V' = V(term_obs); a lane cut by the horizon is an Interrupt with successor obs[T].
+// Algorithmic traffic: r 4 + V 4 + flag 1 in, adv 4 + rtg 4 out = 17 B/sample.
+template <int D>
+__global__ void __launch_bounds__(256) k_gae_scan(TrajDev tr, const float *__restrict__ critic, int H, float gamma,
+                                                  float lambda) {
+  const uint32_t n = tr.n, T = tr.T;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float disc = lambda * gamma;
+  float adv_next = 0.0f, rtg_next = 0.0f;
+  float v_next = tr.values[(size_t)T * n + i];
+  for (uint32_t t = T; t-- > 0;) {
+    size_t o = (size_t)t * n + i;
+    uint8_t f = tr.flag[o];
+    float r = tr.reward[o];
+    float v = tr.values[o];
+    float vn;
+    bool ends;
+    if (f == RL_SUCC_TERMINATE) {
+      vn = 0.0f;
+      ends = true;
+    } else if (f == RL_SUCC_INTERRUPT) {
+      float x[D], z[1];
+#pragma unroll
+      for (int d = 0; d < D; ++d) x[d] = tr.term_obs[(size_t)d * T * n + o];
+      mlp_forward_lane<D, 1>(critic, H, x, z);
+      vn = z[0];
+      ends = true;
+    } else {
+      vn = v_next;
+      ends = (t == T - 1);
+    }
+    float dn = gamma * vn;
+    float tmp = r + dn;
+    float delta = tmp - v;
+    float a, g;
+    if (ends) {
+      a = delta;
+      g = r;
+    } else {
+      float pa = adv_next * disc;
+      a = delta + pa;
+      float pg = rtg_next * gamma;
+      g = r + pg;
+    }
+    tr.adv[o] = a;
+    tr.rtg[o] = g;
+    adv_next = a;
+    rtg_next = g;
+    v_next = v;
+  }
+}
+
+// ---------------------------------------------------------------- host launchers
+static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_env_reset(rl_env *env) {
+  ProfScope ps(env->eng, RL_K_SMALL);
+  uint32_t n = (uint32_t)env->cfg.n_lanes;
+  hipLaunchKernelGGL(k_env_reset, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n);
+}
+
+void launch_env_observe(rl_env *env, float *d_obs) {
+  ProfScope ps(env->eng, RL_K_SMALL);
+  uint32_t n = (uint32_t)env->cfg.n_lanes;
+  if (env->D == 5)
+    hipLaunchKernelGGL(k_env_observe<5>, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n,
+                       d_obs);
+  else
+    hipLaunchKernelGGL(k_env_observe<4>, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n,
+                       d_obs);
+}
+
+void launch_env_step(rl_env *env) {
+  ProfScope ps(env->eng, RL_K_ENV_STEP);
+  uint32_t n = (uint32_t)env->cfg.n_lanes;
+  if (env->D == 5)
+    hipLaunchKernelGGL(k_env_step<5>, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n,
+                       env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs);
+  else
+    hipLaunchKernelGGL(k_env_step<4>, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n,
+                       env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs);
+}
+
+void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
+  ProfScope ps(env->eng, RL_K_ROLLOUT);
+  uint32_t n = (uint32_t)env->cfg.n_lanes;
+  // 64-lane workgroups: N/64 workgroups spread over all 256 CUs even at N = 4096 (64 WGs) .. 65536 (1024 WGs)
+  constexpr int BLOCK = 64;
+  if (env->D == 5)
+    hipLaunchKernelGGL((k_rollout_cartpole<5, BLOCK>), dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream,
+                       env->dev, env->st, traj->d, policy->d_params, (int)policy->hidden, env->t_global);
+  else
+    hipLaunchKernelGGL((k_rollout_cartpole<4, BLOCK>), dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream,
+                       env->dev, env->st, traj->d, policy->d_params, (int)policy->hidden, env->t_global);
+}
+
+void launch_values(rl_traj *traj, const rl_mlp *critic) {
+  ProfScope ps(traj->eng, RL_K_VALUES);
+  size_t rows = (size_t)(traj->d.T + 1) * traj->d.n;
+  if (traj->d.D == 5)
+    hipLaunchKernelGGL((k_mlp_forward_rows<5, 1>), dim3(cdiv(rows, 256)), dim3(256), 0, traj->eng->stream,
+                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows);
+  else
+    hipLaunchKernelGGL((k_mlp_forward_rows<4, 1>), dim3(cdiv(rows, 256)), dim3(256), 0, traj->eng->stream,
+                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows);
+}
+
+void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
+  ProfScope ps(traj->eng, RL_K_GAE);
+  uint32_t n = traj->d.n;
+  if (traj->d.D == 5)
+    hipLaunchKernelGGL(k_gae_scan<5>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d, critic->d_params,
+                       (int)critic->hidden, gamma, lambda);
+  else
+    hipLaunchKernelGGL(k_gae_scan<4>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d, critic->d_params,
+                       (int)critic->hidden, gamma, lambda);
+}
+
+void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa) {
+  ProfScope ps(mlp->eng, RL_K_VALUES);
+  dim3 g(cdiv(rows, 256)), b(256);
+  hipStream_t s = mlp->eng->stream;
+  int H = (int)mlp->hidden;
+#define FWD(DD, AA)                                                                                              \
+  hipLaunchKernelGGL((k_mlp_forward_rows<DD, AA>), g, b, 0, s, mlp->d_params, H, d_in_soa, rows, rows, d_out_soa, \
+                     rows)
+  if (mlp->in_dim == 5 && mlp->out_dim == 2) FWD(5, 2);
+  else if (mlp->in_dim == 5 && mlp->out_dim == 1) FWD(5, 1);
+  else if (mlp->in_dim == 4 && mlp->out_dim == 2) FWD(4, 2);
+  else if (mlp->in_dim == 4 && mlp->out_dim == 1) FWD(4, 1);
+  else throw RlError(RL_ERR_UNSUPPORTED, "mlp forward: unsupported (in_dim, out_dim)");
+#undef FWD
+}

@@ -1,0 +1,445 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact for discrete action indices, successor flags and everything on
+the rollout path (both sides use include/rl_detmath.h + include/rl_chacha.h and explicit fma order);
+stated fp32 tolerances for returns / advantages / gradients / parameters where the reduction order over
+samples differs (device: blocked f32 partial sums; oracle: f64 accumulation rounded once).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ra = pytest.importorskip("relearn_amd")
+
+H = 128
+PS, CS = O.MlpShape(5, H, 2), O.MlpShape(5, H, 1)
+
+# tolerances for sums over B samples in a different order (relative to the vector's max magnitude)
+GRAD_RTOL = 1e-6
+PARAM_ATOL = 2e-5
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_pair(engine, n, max_steps=500, limit=ra.LIMIT_VISIBLE, lane_offset=0, seed_env=0, seed_actor=1):
+    env = ra.CartPoleEnv(engine, n, max_steps=max_steps, limit=limit, lane_offset=lane_offset, seed_env=seed_env,
+                         seed_actor=seed_actor)
+    sim = O.LaneSim(n, max_steps=max_steps, limit=limit, lane_offset=lane_offset, seed_env=seed_env,
+                    seed_actor=seed_actor)
+    return env, sim
+
+
+def test_engine_is_gfx950(engine):
+    name, arch, cus = engine.info()
+    assert arch.startswith("gfx950")
+    assert cus >= 200
+
+
+def test_param_init_bit_exact(engine):
+    for shape, seed in ((PS, 2), (CS, 3), (O.MlpShape(4, 64, 2), 11)):
+        m = ra.Mlp(engine, shape.in_dim, shape.hidden, shape.out_dim)
+        m.init(seed)
+        assert np.array_equal(m.get_params(), O.mlp_init(shape, seed))
+    # Glorot bound of Linear::new: U(+-sqrt(6 / (in + 1 + out)))
+    p = O.mlp_init(PS, 2)
+    assert np.abs(p[:5 * H + H]).max() <= np.float32(np.sqrt(6.0 / (5 + 1 + H)))
+    assert np.abs(p[5 * H + H:]).max() <= np.float32(np.sqrt(6.0 / (H + 1 + 2)))
+
+
+@pytest.mark.parametrize("limit,max_steps", [(ra.LIMIT_VISIBLE, 500), (ra.LIMIT_VISIBLE, 3), (ra.LIMIT_NONE, 0),
+                                             (ra.LIMIT_LATENT, 7)])
+def test_env_reset_observe_bit_exact(engine, limit, max_steps):
+    env, sim = make_pair(engine, 1000, max_steps=max_steps or 1, limit=limit, lane_offset=12345, seed_env=7)
+    st_d, st_o = env.get_state(), sim.get_state()
+    for a, b in zip(st_d, st_o):
+        assert np.array_equal(a, b)
+    assert np.array_equal(env.observe(), sim.observe())
+    assert np.all(np.abs(st_d[0]) <= 0.05)
+    env.reset()
+    sim.reset()
+    for a, b in zip(env.get_state(), sim.get_state()):
+        assert np.array_equal(a, b)
+
+
+def test_env_step_bit_exact_with_resets(engine):
+    n = 2048
+    env, sim = make_pair(engine, n, max_steps=9, seed_env=3)
+    rng = np.random.default_rng(0)
+    n_term = n_int = 0
+    for t in range(60):
+        actions = rng.integers(0, 2, size=n).astype(np.uint8)
+        if t % 7 == 0:
+            actions[:] = 1  # push one way to force pole falls
+        r_d, f_d, o_d, t_d = env.step(actions)
+        r_o, f_o, o_o, t_o = sim.step(actions)
+        assert np.array_equal(f_d, f_o)
+        assert np.array_equal(r_d, r_o)
+        assert np.array_equal(o_d, o_o)
+        m = f_o == O.INTERRUPT
+        assert np.array_equal(t_d[:, m], t_o[:, m])
+        n_term += int((f_o == O.TERMINATE).sum())
+        n_int += int(m.sum())
+    for a, b in zip(env.get_state(), sim.get_state()):
+        assert np.array_equal(a, b)
+    assert n_int > 0, "the test must exercise step-limit interrupts"
+
+
+def test_env_step_edge_states(engine):
+    """friction-sign flip, both termination edges, -0.0 velocity, and a far-out-of-range angle"""
+    n = 64
+    env, sim = make_pair(engine, n, max_steps=500)
+    st, nv, rem, rc = sim.get_state()
+    st[:] = 0.0
+    st[0, 0], st[1, 0] = 2.399, 3.0          # crosses +max_pos
+    st[0, 1], st[1, 1] = -2.399, -3.0        # crosses -max_pos
+    st[2, 2], st[3, 2] = 0.2094, 1.0         # crosses +12 degrees
+    st[2, 3], st[3, 3] = -0.2094, -1.0
+    st[1, 4] = -0.0                           # is_sign_positive(-0.0 * N) edge
+    st[1, 5], nv[5] = -1.0, 1                 # cached sign inconsistent -> recompute branch
+    st[1, 6], nv[6] = 1.0, 0
+    st[2, 7] = 2.0                            # outside the observation space; dynamics must still agree
+    st[2, 8] = -7.5
+    st[3, 9] = 25.0                           # large angular velocity: normal force can change sign
+    rem[10] = 1                               # interrupt on this very step
+    for i in range(11, n):
+        st[:, i] = np.random.default_rng(i).uniform(-0.2, 0.2, size=4)
+        nv[i] = i % 2
+    env.set_state(st, nv, rem, rc)
+    sim.set_state(st, nv, rem, rc)
+    for actions in (np.zeros(n, np.uint8), np.ones(n, np.uint8)):
+        env.set_state(st, nv, rem, rc)
+        sim.set_state(st, nv, rem, rc)
+        r_d, f_d, o_d, t_d = env.step(actions)
+        r_o, f_o, o_o, t_o = sim.step(actions)
+        assert np.array_equal(f_d, f_o)
+        assert np.array_equal(o_d, o_o)
+        for a, b in zip(env.get_state(), sim.get_state()):
+            assert np.array_equal(a, b)
+        assert f_o[10] == O.INTERRUPT and t_d[4, 10] == 0.0
+    assert f_o[0] == O.TERMINATE and f_o[2] == O.TERMINATE
+
+
+@pytest.mark.parametrize("n,T,max_steps,lane_offset", [(256, 64, 500, 0), (1000, 37, 11, 4096), (64, 130, 40, 7)])
+def test_rollout_bit_exact(engine, n, T, max_steps, lane_offset):
+    env, sim = make_pair(engine, n, max_steps=max_steps, lane_offset=lane_offset, seed_env=5, seed_actor=6)
+    policy = ra.Mlp(engine, 5, H, 2)
+    policy.init(2)
+    pp = policy.get_params()
+    traj = ra.Trajectory(engine, n, T, 5)
+    for period in range(2):  # lanes persist across periods: second period continues the episodes
+        ra.rollout(env, policy, traj)
+        got = traj.read_all()
+        want = sim.rollout(PS, pp, T)
+        assert np.array_equal(got["action"], want["action"])
+        assert np.array_equal(got["flag"], want["flag"])
+        assert np.array_equal(got["reward"], want["reward"])
+        assert np.array_equal(got["obs"], want["obs"])
+        m = want["flag"] == O.INTERRUPT
+        assert np.array_equal(got["term_obs"][:, m], want["term_obs"][:, m])
+        for a, b in zip(env.get_state(), sim.get_state()):
+            assert np.array_equal(a, b)
+    assert 0.2 < want["action"].mean() < 0.8
+
+
+def test_rollout_sharding_invariance(engine):
+    """lanes [k, k+m) of a big engine == an engine created with lane_offset = k (multi-GPU sharding rule)"""
+    n, T = 512, 48
+    policy = ra.Mlp(engine, 5, H, 2)
+    policy.init(2)
+    full_env = ra.CartPoleEnv(engine, n, max_steps=30)
+    full = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(full_env, policy, full)
+    f = full.read_all()
+    half_env = ra.CartPoleEnv(engine, n // 2, max_steps=30, lane_offset=n // 2)
+    half = ra.Trajectory(engine, n // 2, T, 5)
+    ra.rollout(half_env, policy, half)
+    h = half.read_all()
+    for k in ("action", "flag", "obs"):
+        assert np.array_equal(f[k][..., n // 2:], h[k])
+
+
+def _traj_pair(engine, n, T, max_steps, seed=2):
+    env, sim = make_pair(engine, n, max_steps=max_steps)
+    policy = ra.Mlp(engine, 5, H, 2)
+    policy.init(seed)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, policy, traj)
+    want = sim.rollout(PS, policy.get_params(), T)
+    return policy, traj, want
+
+
+def test_values_and_gae_bit_exact(engine):
+    n, T = 384, 96
+    policy, traj, want = _traj_pair(engine, n, T, max_steps=25)
+    critic = ra.Mlp(engine, 5, H, 1)
+    critic.init(3)
+    ra.gae(traj, critic, 0.99, 0.95)
+    v_o, adv_o, rtg_o = O.lanes_gae(CS, critic.get_params(), want, 0.99, 0.95)
+    assert np.array_equal(traj.read(ra.TRAJ_VALUES), v_o)
+    assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), adv_o)
+    assert np.array_equal(traj.read(ra.TRAJ_RETURNS), rtg_o)
+    assert (want["flag"] == O.INTERRUPT).any() and (want["flag"] == O.TERMINATE).any()
+
+
+def test_gae_linearity_and_gamma_one(engine):
+    """size-independent properties: scaling rewards and the critic output by 2 scales advantages exactly by 2;
+    with gamma = 1 and a zero critic the return is the number of steps left in the episode segment"""
+    n, T = 256, 64
+    policy, traj, want = _traj_pair(engine, n, T, max_steps=17)
+    critic = ra.Mlp(engine, 5, H, 1)
+    zero = np.zeros(critic.P, dtype=np.float32)
+    critic.set_params(zero)
+    ra.gae(traj, critic, 1.0, 1.0)
+    rtg = traj.read(ra.TRAJ_RETURNS)
+    flag = want["flag"]
+    expect = np.zeros_like(rtg)
+    run = np.zeros(n)
+    for t in range(T - 1, -1, -1):
+        ends = (flag[t] != 0) | (t == T - 1)
+        run = np.where(ends, 1.0, run + 1.0)
+        expect[t] = run
+    assert np.array_equal(rtg, expect)
+    adv = traj.read(ra.TRAJ_ADVANTAGES)
+    assert np.array_equal(adv, expect)  # V == 0 => delta = r, lambda*gamma = 1
+    cp = O.mlp_init(CS, 3)
+    critic.set_params(cp)
+    ra.gae(traj, critic, 0.99, 0.95)
+    a1 = traj.read(ra.TRAJ_ADVANTAGES)
+    cp2 = cp.copy()
+    cp2[5 * H + H:] *= 2.0  # doubling the output layer doubles V exactly
+    critic.set_params(cp2)
+    traj.write(ra.TRAJ_REWARD, want["reward"] * 2.0)
+    ra.gae(traj, critic, 0.99, 0.95)
+    assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), a1 * 2.0)
+
+
+def _with_advantages(engine, n, T, max_steps=30):
+    policy, traj, want = _traj_pair(engine, n, T, max_steps)
+    critic = ra.Mlp(engine, 5, H, 1)
+    critic.init(3)
+    ra.gae(traj, critic, 0.99, 0.95)
+    adv = traj.read(ra.TRAJ_ADVANTAGES)
+    rtg = traj.read(ra.TRAJ_RETURNS)
+    x, a = O.flat_samples(want)
+    return policy, critic, traj, x, a, np.ascontiguousarray(adv.reshape(-1)), np.ascontiguousarray(rtg.reshape(-1))
+
+
+def test_policy_gradient_matches_oracle(engine):
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, 512, 64)
+    g_d, loss_d, ent_d = ra.policy_gradient(policy, traj)
+    pp = policy.get_params()
+    g_o = np.zeros_like(pp)
+    loss_o = C.c_float()
+    O.lib().oracle_policy_grad_f32(PS, O.f32p(pp), O.f32p(x), O.i64p(a), O.f32p(adv), len(a), O.f32p(g_o),
+                                   C.byref(loss_o))
+    assert rel_err(g_d, g_o) < GRAD_RTOL
+    assert abs(loss_d - loss_o.value) <= 1e-5 * max(1.0, abs(loss_o.value))
+    # f64 ground truth: the f32 device result must be as close to it as the f32 oracle is (x4 slack)
+    g64 = np.zeros(len(pp), dtype=np.float64)
+    l64 = C.c_double()
+    O.lib().oracle_policy_grad_f64(PS, O.f64p(pp.astype(np.float64)), O.f64p(x.astype(np.float64)), O.i64p(a),
+                                   O.f64p(adv.astype(np.float64)), len(a), O.f64p(g64), C.byref(l64))
+    assert rel_err(g_d, g64) < max(4 * rel_err(g_o, g64), 1e-5)
+    assert 0.0 < ent_d <= np.log(2.0) + 1e-6
+
+
+def test_policy_fvp_matches_oracle_and_is_symmetric(engine):
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, 512, 64)
+    pp = policy.get_params()
+    rng = np.random.default_rng(1)
+    u = rng.standard_normal(policy.P).astype(np.float32)
+    v = rng.standard_normal(policy.P).astype(np.float32)
+    hv_d = ra.policy_fvp(policy, traj, v, 1e-5)
+    hv_o = np.zeros_like(pp)
+    O.lib().oracle_policy_fvp_f32(PS, O.f32p(pp), O.f32p(x), len(a), O.f32p(v), 1e-5, O.f32p(hv_o))
+    assert rel_err(hv_d, hv_o) < GRAD_RTOL
+    hu_d = ra.policy_fvp(policy, traj, u, 1e-5)
+    # symmetry u^T H v == v^T H u and positive semi-definiteness v^T H v >= 0
+    lhs, rhs = float(np.dot(u.astype(np.float64), hv_d)), float(np.dot(v.astype(np.float64), hu_d))
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1e-6)
+    assert float(np.dot(v.astype(np.float64), hv_d)) > 0.0
+
+
+def test_policy_loss_kl_matches_oracle(engine):
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, 512, 64)
+    p0 = policy.get_params()
+    rng = np.random.default_rng(2)
+    p1 = (p0 + 0.01 * rng.standard_normal(len(p0))).astype(np.float32)
+    policy.set_params(p1)
+    loss_d, kl_d = ra.policy_loss_kl(policy, traj, p0)
+    lo, ko = C.c_float(), C.c_float()
+    O.lib().oracle_policy_loss_kl_f32(PS, O.f32p(p1), O.f32p(p0), O.f32p(x), O.i64p(a), O.f32p(adv), len(a),
+                                      C.byref(lo), C.byref(ko))
+    assert abs(loss_d - lo.value) <= 1e-5 * max(1.0, abs(lo.value))
+    assert abs(kl_d - ko.value) <= 1e-5 * max(1e-3, abs(ko.value))
+    # KL(theta0 || theta0) == 0 exactly and loss == -mean(A)
+    policy.set_params(p0)
+    loss0, kl0 = ra.policy_loss_kl(policy, traj, p0)
+    assert kl0 == 0.0
+    assert abs(loss0 + adv.astype(np.float64).mean()) < 1e-5 * max(1.0, abs(adv.mean()))
+
+
+def _oracle_cfg(dcfg):
+    cfg = O.TrpoCfg()
+    O.lib().oracle_trpo_cfg_default(C.byref(cfg))
+    cfg.iterations, cfg.max_backtracks = dcfg.iterations, dcfg.max_backtracks
+    cfg.backtrack_ratio, cfg.hpv_reg_coeff = dcfg.backtrack_ratio, dcfg.hpv_reg_coeff
+    cfg.max_kl, cfg.accept_violation = dcfg.max_policy_step_kl, dcfg.accept_violation
+    return cfg
+
+
+@pytest.mark.parametrize("iterations,tol", [(1, 1e-4), (2, 1e-3)])
+def test_trpo_update_few_cg_iterations_tight(engine, iterations, tol):
+    """With 1-2 CG iterations rounding is not amplified: the whole pipeline (gradient, Fisher-vector products,
+    CG bookkeeping, step size, line search, acceptance) must agree with the f32 oracle tightly."""
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, 512, 64, 500)
+    p0 = policy.get_params()
+    dcfg = ra.trpo_config_default()
+    dcfg.iterations = iterations
+    st_d = ra.trpo_update(policy, traj, dcfg)
+    p_d = policy.get_params()
+    p_o, st_o, sd_o = O.trpo_update(PS, p0, x, a, adv, _oracle_cfg(dcfg))
+    assert st_d.status == st_o.status
+    assert st_d.num_backtracks == st_o.num_backtracks
+    assert st_d.cg_iterations == st_o.cg_iterations == iterations
+    assert abs(st_d.entropy - st_o.entropy) < 1e-5
+    assert abs(st_d.loss_initial - st_o.loss_initial) <= 1e-5 * max(1.0, abs(st_o.loss_initial))
+    assert abs(st_d.step_size - st_o.step_size) <= tol * st_o.step_size
+    assert abs(st_d.loss_final - st_o.loss_final) <= 1e-5 * max(1.0, abs(st_o.loss_final))
+    assert abs(st_d.constraint_val_final - st_o.constraint_val_final) <= 10 * tol * st_o.constraint_val_final + 1e-7
+    assert np.abs(p_d - p_o).max() <= tol * np.abs(p_o - p0).max() + 1e-7
+
+
+@pytest.mark.parametrize("n,T,max_steps", [(256, 32, 30), (1024, 128, 500)])
+def test_trpo_update_default_config_vs_f64_truth(engine, n, T, max_steps):
+    """10 CG iterations in f32 on the Fisher matrix of this MLP are ill-conditioned: two correct f32
+    implementations differ from each other by tens of percent in the step direction (the f32 and f64 oracles
+    differ by 20-40 % here).  Stated tolerance: the device result must be no farther from the f64 ground truth
+    than twice the f32 restatement is, and must satisfy the trust-region acceptance rule itself."""
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, n, T, max_steps)
+    p0 = policy.get_params()
+    st_d = ra.trpo_update(policy, traj)
+    p_d = policy.get_params()
+    p32, st32, sd32 = O.trpo_update(PS, p0, x, a, adv)
+    p64, st64, sd64 = O.trpo_update(PS, p0, x, a, adv, f64=True)
+    assert st_d.status == st32.status == st64.status == ra.OPT_OK
+    assert st_d.cg_iterations == st32.cg_iterations == st64.cg_iterations
+    assert abs(st_d.entropy - st64.entropy) < 1e-5
+    assert abs(st_d.loss_initial - st64.loss_initial) <= 1e-5 * max(1.0, abs(st64.loss_initial))
+    err_dev = abs(st_d.step_size - st64.step_size)
+    err_o32 = abs(st32.step_size - st64.step_size)
+    assert err_dev <= 2.0 * err_o32 + 1e-3 * st64.step_size
+    lo = min(st32.num_backtracks, st64.num_backtracks) - 1
+    hi = max(st32.num_backtracks, st64.num_backtracks) + 1
+    assert lo <= st_d.num_backtracks <= hi
+    # the accepted step obeys the trust region and improves the surrogate (conjugate_gradient.rs:218)
+    assert st_d.constraint_val_final <= 0.01 and st_d.loss_final < st_d.loss_initial
+    assert np.abs(p_d - p0).max() > 0
+    # and what was accepted is what the device says: re-evaluate loss / KL of the new parameters independently
+    lo_, ko_ = C.c_float(), C.c_float()
+    O.lib().oracle_policy_loss_kl_f32(PS, O.f32p(p_d), O.f32p(p0), O.f32p(x), O.i64p(a), O.f32p(adv), len(a),
+                                      C.byref(lo_), C.byref(ko_))
+    assert abs(lo_.value - st_d.loss_final) <= 1e-5 * max(1.0, abs(lo_.value))
+    assert abs(ko_.value - st_d.constraint_val_final) <= 1e-4 * ko_.value + 1e-8
+
+
+def test_trpo_rollback_on_failure(engine):
+    """Line-search failures restore the parameters and report the reference's error kinds
+    (conjugate_gradient.rs:228-253); the device must classify exactly like the oracle."""
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, 256, 32)
+    p0 = policy.get_params()
+    # (a) budget too small: this short-episode batch needs ~13 backtracks, allow 3
+    cfg = ra.trpo_config_default()
+    cfg.max_backtracks = 3
+    st = ra.trpo_update(policy, traj, cfg)
+    p_o, st_o, _ = O.trpo_update(PS, p0, x, a, adv, _oracle_cfg(cfg))
+    assert st.status == st_o.status
+    assert st.status in (ra.OPT_CONSTRAINT_VIOLATED, ra.OPT_LOSS_NOT_IMPROVING)
+    assert st.num_backtracks == -1 and st_o.num_backtracks == -1
+    assert np.array_equal(policy.get_params(), p0) and np.array_equal(p_o, p0)
+    # (b) no CG iterations: zero step, loss cannot improve
+    cfg = ra.trpo_config_default()
+    cfg.iterations = 0
+    st = ra.trpo_update(policy, traj, cfg)
+    assert st.status == ra.OPT_LOSS_NOT_IMPROVING and st.cg_iterations == 0
+    assert np.array_equal(policy.get_params(), p0)
+    # (c) zero advantages: g = 0 -> alpha = 0/0 = NaN -> nan_to_num(step_dir) = 0 (conjugate_gradient.rs:152)
+    traj.write(ra.TRAJ_ADVANTAGES, np.zeros((32, 256), np.float32))
+    st = ra.trpo_update(policy, traj)
+    p_o, st_o, _ = O.trpo_update(PS, p0, x, a, np.zeros_like(adv))
+    assert st.status == st_o.status == ra.OPT_LOSS_NOT_IMPROVING
+    assert np.array_equal(policy.get_params(), p0)
+
+
+def test_critic_gradient_and_update_match_oracle(engine):
+    policy, critic, traj, x, a, adv, rtg = _with_advantages(engine, 512, 64)
+    cp = critic.get_params()
+    g_d, loss_d = ra.critic_gradient(critic, traj)
+    g_o = np.zeros_like(cp)
+    lo = C.c_float()
+    O.lib().oracle_critic_grad_f32(CS, O.f32p(cp), O.f32p(x), O.f32p(rtg), len(a), O.f32p(g_o), C.byref(lo))
+    assert rel_err(g_d, g_o) < GRAD_RTOL
+    assert abs(loss_d - lo.value) <= 1e-5 * lo.value
+    steps = 20
+    opt = ra.Adam(critic)
+    st, losses_d = ra.critic_update(critic, opt, traj, steps, want_losses=True)
+    ad = O.lib().oracle_adam_new(len(cp))
+    ac = O.AdamCfg()
+    O.lib().oracle_adam_cfg_default(C.byref(ac))
+    losses_o = np.zeros(steps, dtype=np.float32)
+    c_o = cp.copy()
+    O.lib().oracle_critic_update_f32(CS, O.f32p(c_o), ad, C.byref(ac), O.f32p(x), O.f32p(rtg), len(a), steps,
+                                     O.f32p(losses_o))
+    O.lib().oracle_adam_free(ad)
+    assert np.allclose(losses_d, losses_o, rtol=1e-4)
+    assert np.abs(critic.get_params() - c_o).max() < PARAM_ATOL + 1e-3 * steps * 1e-3
+    assert losses_d[-1] < losses_d[0]
+    assert st.steps == steps
+
+
+def test_adam_step_matches_oracle(engine):
+    m = ra.Mlp(engine, 5, H, 1)
+    m.init(9)
+    p = m.get_params()
+    opt = ra.Adam(m)
+    ad = O.lib().oracle_adam_new(len(p))
+    ac = O.AdamCfg()
+    O.lib().oracle_adam_cfg_default(C.byref(ac))
+    rng = np.random.default_rng(3)
+    p_o = p.copy()
+    for k in range(5):
+        g = (rng.standard_normal(len(p)) * 10.0 ** rng.integers(-6, 2)).astype(np.float32)
+        opt.step_host(g)
+        O.lib().oracle_adam_step_f32(ad, C.byref(ac), O.f32p(p_o), O.f32p(g))
+    O.lib().oracle_adam_free(ad)
+    # identical formulas; only pow()/sqrt() of the f64 bias corrections may differ in the last place
+    assert np.abs(m.get_params() - p_o).max() <= 2e-7
+
+
+def test_error_paths(engine):
+    with pytest.raises(ra.RelearnError) as e:
+        ra.Mlp(engine, 7, 128, 2)
+    assert e.value.code == ra.ERR_BUILD_AGENT
+    with pytest.raises(ra.RelearnError) as e:
+        ra.CartPoleEnv(engine, 16, max_steps=0)
+    assert e.value.code == ra.ERR_BUILD_ENV
+    env = ra.CartPoleEnv(engine, 16)
+    traj = ra.Trajectory(engine, 32, 8, 5)
+    pol = ra.Mlp(engine, 5, 16, 2)
+    with pytest.raises(ra.RelearnError) as e:
+        ra.rollout(env, pol, traj)
+    assert e.value.code == ra.ERR_INVALID_ARGUMENT
+    buf = np.zeros(4, np.uint8)
+    with pytest.raises(ra.RelearnError) as e:
+        ra._check(ra.lib().rl_traj_read(traj.h, C.c_int32(99), buf.ctypes.data_as(C.c_void_p), C.c_uint64(4)),
+                  engine.h)
+    assert e.value.code == ra.ERR_INVALID_ARGUMENT
+    assert b"unknown trajectory field" in ra.lib().rl_last_error(engine.h)
