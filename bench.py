@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of CartPole MLP-TRPO on MI355X (BASELINE.json metric).
+
+One "step" = one training period of the hot path: a T-step fused rollout of every lane, critic values +
+GAE/return scan, the TRPO policy update (gradient, 10 CG iterations with Fisher-vector products, step size,
+backtracking line search) and 80 full-batch Adam steps on the critic — inputs resident in HBM, nothing
+skipped.  The workload at every GPU count is the configuration the metric is quoted on: 65,536 CartPole
+envs (VisibleStepLimit(500)), T = 128, policy 5-128-2, critic 5-128-1; with N GPUs each rank owns 65,536/N
+lanes (strong scaling) and every reduced gradient / Hessian-vector / scalar vector is all-reduced with RCCL.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA peak = f32 vector peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=65536, help="total env lanes over all GPUs")
+    ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--critic-steps", type=int, default=80)
+    ap.add_argument("--max-episode-steps", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true",
+                    help="do not wrap launches in HIP events inside the timed region")
+    ap.add_argument("--cpu-sample-steps", type=int, default=262144,
+                    help="total env-steps of the bounded CPU-baseline sample (split over the host cores)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle's train_parallel-structured CPU path (one worker thread per host core running the scalar
+    Steps::step loop, single-threaded update), timed on this box's host cores on a bounded sample."""
+    import ctypes as C
+
+    import oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    H = args.hidden
+    ps, cs = O.MlpShape(5, H, 2), O.MlpShape(5, H, 1)
+    pp, cp = O.mlp_init(ps, 2), O.mlp_init(cs, 3)
+    opt = O.lib().oracle_adam_new(len(cp))
+    st = O.PeriodStats()
+    t0 = time.time()
+    per_thread = max(64, args.cpu_sample_steps // cores)
+    O.lib().oracle_cartpole_trpo_period(0, 0, cores, per_thread, 100, args.max_episode_steps, H,
+                                        O.f32p(pp), O.f32p(cp), opt, args.critic_steps, C.byref(st))
+    wall = time.time() - t0
+    O.lib().oracle_adam_free(opt)
+    steps = int(st.steps)
+    return {
+        "value": steps / (st.rollout_seconds + st.update_seconds),
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes), then single-threaded "
+                  "GAE + TRPO + %d Adam steps; rollout %.2f s, update %.2f s" % (
+                      cores, per_thread, steps, int(st.episodes), args.critic_steps,
+                      st.rollout_seconds, st.update_seconds),
+        "rollout_only_steps_per_s": steps / max(st.rollout_seconds, 1e-9),
+        "wall_s": wall,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (
+                args.gpus, args.gpus))
+        args.gpus = world
+
+    import relearn_amd as ra
+
+    dist = None
+    if world > 1:
+        # control plane only (unique-id exchange, barrier, max-reduce of the timing); the data-plane
+        # collective is RCCL called from the library on its own HIP stream
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    assert args.envs % world == 0, "envs must divide evenly over GPUs"
+    n_local = args.envs // world
+    T, H = args.horizon, args.hidden
+
+    eng = ra.Engine(local_rank)
+    if world > 1:
+        ids = [ra.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(rank, world, ids[0])
+
+    env = ra.CartPoleEnv(eng, n_local, max_steps=args.max_episode_steps, limit=ra.LIMIT_VISIBLE,
+                         lane_offset=rank * n_local, seed_env=0, seed_actor=1)
+    policy = ra.Mlp(eng, 5, H, 2)
+    critic = ra.Mlp(eng, 5, H, 1)
+    policy.init(2)   # every rank initialises identical replicas from the same stream
+    critic.init(3)
+    opt = ra.Adam(critic)
+    traj = ra.Trajectory(eng, n_local, T, 5)
+    trpo_cfg = ra.trpo_config_default()
+    gamma = min(0.99, 0.99)  # min(max_discount_factor, env discount) (critics/opt.rs:73)
+
+    last = {}
+
+    def period():
+        ra.rollout(env, policy, traj)
+        ra.gae(traj, critic, gamma, 0.95)
+        last["trpo"] = ra.trpo_update(policy, traj, trpo_cfg)
+        last["critic"] = ra.critic_update(critic, opt, traj, args.critic_steps)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        period()
+    barrier()
+    if not args.no_kernel_profile:
+        eng.profile_enable(True)
+        eng.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        period()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read(reset=True) if not args.no_kernel_profile else None
+    eng.profile_enable(False)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_steps = args.envs * T * args.steps
+    value = total_steps / elapsed
+    B_local = n_local * T
+
+    # ---- roofline of the dominant kernel: k_mlp_backward (class "backward") ----------------------------
+    # Algorithmic flops per sample and launch: the backward of the 2-layer MLP is two
+    # forward-equivalents — recompute of layer 1 (2*D*H) + dW1 (2*D*H) + dh (2*A*H) + dW2 (2*A*H):
+    #   critic (A=1): 3072 flop/sample   policy (A=2): 3584 flop/sample.
+    roofline = None
+    phases = None
+    if prof is not None:
+        bw_ms, bw_n = prof["backward"]
+        n_critic = args.critic_steps * args.steps
+        n_policy = bw_n - n_critic
+        flop_c = 2 * (2 * 5 * H) + 2 * (2 * 1 * H)
+        flop_p = 2 * (2 * 5 * H) + 2 * (2 * 2 * H)
+        alg_flops = (n_critic * flop_c + n_policy * flop_p) * B_local
+        achieved = alg_flops / (bw_ms * 1e-3) / 1e12 if bw_ms > 0 else 0.0
+        roofline = {
+            "kernel": "k_mlp_backward", "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS, "traffic": None,
+            "launches": int(bw_n), "avg_launch_us": 1e3 * bw_ms / max(bw_n, 1),
+            "algorithmic_flop_per_sample": {"critic": flop_c, "policy": flop_p},
+            "note": "f32 vector/matrix peak 157.3 TFLOP/s; per-rank figures",
+        }
+        tot = sum(v[0] for v in prof.values())
+        phases = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
+                      "share": (v[0] / tot if tot > 0 else 0.0)} for k, v in prof.items() if v[1]}
+        # fused rollout: 26 B/env-step trajectory record
+        ro_ms, ro_n = prof["rollout"]
+        if ro_n:
+            gbs = 26.0 * B_local * ro_n / (ro_ms * 1e-3) / 1e9
+            phases["rollout"]["hbm_GBps_at_26B_per_step"] = gbs
+            phases["rollout"]["hbm_frac"] = gbs / HBM_PEAK_GBS
+
+    # ---- standalone env-step kernel: 100 B/env-step, HBM roofline --------------------------
+    env_step = None
+    if rank == 0:
+        reps = 200
+        env.upload_actions(np.random.default_rng(0).integers(0, 2, size=n_local).astype(np.uint8))
+        for _ in range(20):
+            env.step_resident()
+        eng.sync()
+        eng.timer_begin()
+        for _ in range(reps):
+            env.step_resident()
+        ms = eng.timer_end()
+        gbs = 100.0 * n_local * reps / (ms * 1e-3) / 1e9
+        env_step = {"kernel": "k_env_step", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * ms / reps,
+                    "env_steps_per_s": n_local * reps / (ms * 1e-3)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        st = last["trpo"]
+        out = {
+            "metric": "env-steps/sec (whole node), 64k-env CartPole TRPO",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "CartPole(VisibleStepLimit %d) MLP-TRPO, %d envs total, T=%d, policy 5-%d-2, critic "
+                            "5-%d-1, CG 10, <=15 backtracks, %d Adam critic steps per period" % (
+                                args.max_episode_steps, args.envs, T, H, H, args.critic_steps),
+                "n_envs_total": args.envs, "n_envs_per_gpu": n_local, "horizon": T, "hidden": H,
+                "critic_steps": args.critic_steps, "parallelism": "env-sharded x%d + RCCL all-reduce" % world,
+            },
+            "roofline": roofline,
+            "roofline_env_step": env_step,
+            "cpu_baseline": cpu,
+            "phases": phases,
+            "last_update": {"trpo_status": st.status, "num_backtracks": st.num_backtracks,
+                            "kl": st.constraint_val_final, "entropy": st.entropy,
+                            "critic_loss_first": last["critic"].loss_first,
+                            "critic_loss_last": last["critic"].loss_last},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
