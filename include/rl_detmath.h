@@ -46,6 +46,8 @@ RL_HD double rl_kernel_sin(double x) {
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double ax = x < 0.0 ? -x : x;
+  if (ax < 1.4901161193847656e-08) return x; /* |x| < 2^-26: sin x == x to the last bit, keeps -0.0 */
   double z = x * x;
   double v = z * x;
   double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/torch_golden.json with PyTorch CPU autograd (run in the build container only).
+
+The reference delegates its tensor math to libtorch 1.12 through `tch`; that source is not under
+/root/reference.  PyTorch 2.10 (CPU) is importable in the build container and implements the same public
+op semantics, so it is used here as an INDEPENDENT cross-check of the oracle's hand-derived math: the
+quantities below are produced by real reverse-mode autograd, the Hessian-vector product by the same
+double-backward construction the reference uses (HessianVectorProduct, conjugate_gradient.rs:262-339),
+the TRPO step by a transcription of trust_region_backward_step / backtracking_line_search
+(conjugate_gradient.rs:115-255) onto torch tensors, and Adam by torch.optim.Adam.
+
+Only numbers are committed (inputs + expected outputs); this script is the generator.
+"""
+import json
+import math
+import os
+
+import torch
+
+torch.manual_seed(1234)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def mlp_forward(params, x, D, H, A):
+    W1 = params[:H * D].reshape(H, D)
+    b1 = params[H * D:H * D + H]
+    W2 = params[H * D + H:H * D + H + A * H].reshape(A, H)
+    b2 = params[H * D + H + A * H:]
+    h = torch.relu(torch.nn.functional.linear(x, W1, b1))
+    return torch.nn.functional.linear(h, W2, b2)
+
+
+def clamp_min_float(x):
+    return x.clamp_min(torch.finfo(x.dtype).min)
+
+
+def categorical_kl(lp_self, lp_other):
+    return (clamp_min_float(lp_self - lp_other) * lp_self.exp()).sum(-1)
+
+
+def categorical_entropy(lp):
+    return -(clamp_min_float(lp) * lp.exp()).sum(-1)
+
+
+def loss_distance(params, x, actions, adv, lp0, lp0_a, dims):
+    lp = torch.log_softmax(mlp_forward(params, x, *dims), -1)
+    lpa = lp.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+    loss = -((lpa - lp0_a).exp() * adv).mean()
+    dist = categorical_kl(lp0, lp).mean()
+    return loss, dist
+
+
+def solve_cg(f_Ax, b, iterations, tol):
+    x = torch.zeros_like(b)
+    r = b.clone()
+    p = b.clone()
+    rr = r.dot(r)
+    iters = 0
+    for _ in range(iterations):
+        z = f_Ax(p)
+        iters += 1
+        alpha = rr / p.dot(z)
+        x = x + alpha * p
+        r = r - alpha * z
+        new_rr = r.dot(r)
+        if float(new_rr) < tol:
+            break
+        mu = new_rr / rr
+        p = p * mu + r
+        rr = new_rr
+    return x, iters
+
+
+def trpo_case(dtype, D=5, H=8, A=2, n=24, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    P = H * D + H + A * H + A
+    params0 = (torch.rand(P, generator=g, dtype=torch.float64) * 0.8 - 0.4).to(dtype)
+    x = (torch.randn(n, D, generator=g, dtype=torch.float64) * 0.5).to(dtype)
+    actions = torch.randint(0, A, (n,), generator=g)
+    adv = torch.randn(n, generator=g, dtype=torch.float64).to(dtype)
+    v = torch.randn(P, generator=g, dtype=torch.float64).to(dtype)
+    dims = (D, H, A)
+    params = params0.clone().requires_grad_(True)
+    with torch.no_grad():
+        lp0 = torch.log_softmax(mlp_forward(params, x, *dims), -1)
+        lp0_a = lp0.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+        entropy = categorical_entropy(lp0).mean()
+    loss, dist = loss_distance(params, x, actions, adv, lp0, lp0_a, dims)
+    (grad,) = torch.autograd.grad(loss, params, retain_graph=True)
+    (dgrad,) = torch.autograd.grad(dist, params, create_graph=True)
+    reg = 1e-5
+
+    def hvp(vec):
+        (hv,) = torch.autograd.grad((dgrad * vec).sum(), params, retain_graph=True)
+        return hv + reg * vec
+
+    hv = hvp(v)
+    step_dir, iters = solve_cg(hvp, grad, 10, 1e-10)
+    step_dir = torch.nan_to_num(step_dir, nan=0.0)
+    max_kl = 0.01
+    step_size = math.sqrt(1.0 / (float(step_dir.dot(hvp(step_dir))) + 1e-8) * max_kl * 2.0)
+    descent = step_size * step_dir
+    initial_loss = float(loss)
+    prev = params0.clone()
+    new_params = prev.clone()
+    num_backtracks = -1
+    final_loss, final_kl = initial_loss, float("inf")
+    for i in range(15):
+        ratio = 0.8 ** i
+        cand = prev - ratio * descent
+        with torch.no_grad():
+            l, d = loss_distance(cand, x, actions, adv, lp0, lp0_a, dims)
+        final_loss, final_kl = float(l), float(d)
+        if final_loss < initial_loss and final_kl <= max_kl:
+            num_backtracks = i
+            new_params = cand
+            break
+    ok = (final_loss < initial_loss) and (final_kl < max_kl)
+    if not ok:
+        new_params = prev
+    # (loss, distance) at a perturbed point for the loss/KL evaluation check
+    pert = (params0.double() + 0.05 * torch.randn(P, generator=g, dtype=torch.float64)).to(dtype)
+    with torch.no_grad():
+        l1, d1 = loss_distance(pert, x, actions, adv, lp0, lp0_a, dims)
+    return {
+        "dims": [D, H, A], "n": n, "dtype": str(dtype).replace("torch.", ""),
+        "params0": params0.double().tolist(), "obs": x.double().tolist(), "actions": actions.tolist(),
+        "adv": adv.double().tolist(), "v": v.double().tolist(), "reg": reg,
+        "entropy": float(entropy), "loss0": initial_loss, "grad": grad.double().tolist(),
+        "hvp_v": hv.detach().double().tolist(), "cg_iterations": iters,
+        "step_dir": step_dir.detach().double().tolist(), "step_size": step_size,
+        "num_backtracks": num_backtracks, "loss_final": final_loss, "kl_final": final_kl, "status_ok": ok,
+        "new_params": new_params.detach().double().tolist(),
+        "params_pert": pert.double().tolist(), "loss_pert": float(l1), "kl_pert": float(d1),
+    }
+
+
+def critic_case(dtype, D=5, H=8, n=24, steps=6, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    P = H * D + H + H + 1
+    params0 = (torch.rand(P, generator=g, dtype=torch.float64) * 0.8 - 0.4).to(dtype)
+    x = (torch.randn(n, D, generator=g, dtype=torch.float64) * 0.5).to(dtype)
+    targets = (torch.randn(n, generator=g, dtype=torch.float64) * 3.0).to(dtype)
+    params = params0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([params], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    losses, grads0 = [], None
+    for k in range(steps):
+        loss = torch.nn.functional.mse_loss(mlp_forward(params, x, D, H, 1).squeeze(-1), targets)
+        opt.zero_grad()
+        loss.backward()
+        if k == 0:
+            grads0 = params.grad.detach().clone()
+        losses.append(float(loss))
+        opt.step()
+    return {
+        "dims": [D, H, 1], "n": n, "dtype": str(dtype).replace("torch.", ""), "steps": steps,
+        "params0": params0.double().tolist(), "obs": x.double().tolist(), "targets": targets.double().tolist(),
+        "grad0": grads0.double().tolist(), "losses": losses, "params_final": params.detach().double().tolist(),
+    }
+
+
+def gae_case(seed=5):
+    """GAE / reward-to-go on the reference's own 4-episode history fixture (features.rs:293-333) with a fixed
+    random critic on the 1-d boolean observation, computed the reference way on padded sequences."""
+    g = torch.Generator().manual_seed(seed)
+    D, H = 1, 4
+    P = H * D + H + H + 1
+    params = (torch.rand(P, generator=g, dtype=torch.float64) * 2 - 1).float()
+    episodes = [  # (obs, reward) per step, terminal kind, interrupt successor obs
+        ([(1.0, 1.0), (1.0, 1.0), (1.0, 1.0), (1.0, 1.0)], "interrupt_dropped", None),
+        ([(0.0, -1.0), (0.0, -1.0), (0.0, 0.0), (0.0, 0.0), (0.0, 1.0), (0.0, 1.0)], "terminate", None),
+        ([(0.0, 2.0), (1.0, 2.0), (0.0, 2.0)], "interrupt", 1.0),
+        ([(1.0, 3.0)], "terminate", None),
+    ]
+    gamma, lam = 0.9, 0.8
+    out = []
+    for steps, kind, succ in episodes:
+        obs = torch.tensor([[s[0]] for s in steps], dtype=torch.float32)
+        r = torch.tensor([s[1] for s in steps], dtype=torch.float32)
+        v = mlp_forward(params, obs, D, H, 1).squeeze(-1)
+        if kind == "interrupt":
+            vlast = mlp_forward(params, torch.tensor([[succ]], dtype=torch.float32), D, H, 1).squeeze(-1)
+        else:
+            vlast = torch.zeros(1)
+        vnext = torch.cat([v[1:], vlast])
+        delta = r + torch.tensor(gamma, dtype=torch.float32) * vnext - v
+        adv = delta.clone()
+        rtg = r.clone()
+        disc = torch.tensor(lam, dtype=torch.float32) * torch.tensor(gamma, dtype=torch.float32)
+        for t in range(len(steps) - 2, -1, -1):
+            adv[t] = adv[t] + adv[t + 1] * disc
+            rtg[t] = rtg[t] + rtg[t + 1] * torch.tensor(gamma, dtype=torch.float32)
+        out.append({"adv": adv.tolist(), "rtg": rtg.tolist(), "values": v.tolist()})
+    return {"critic_params": params.double().tolist(), "dims": [D, H, 1], "gamma": gamma, "lambda": lam,
+            "episodes": out}
+
+
+def main():
+    data = {
+        "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
+        "trpo_f64": trpo_case(torch.float64),
+        "trpo_f32": trpo_case(torch.float32),
+        "critic_f32": critic_case(torch.float32),
+        "critic_f64": critic_case(torch.float64),
+        "gae_f32": gae_case(),
+    }
+    with open(os.path.join(HERE, "torch_golden.json"), "w") as f:
+        json.dump(data, f)
+    print("wrote torch_golden.json")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""The C-ABI library loads without a GPU and exports exactly the entry points include/relearn_hip.h declares;
+compute entry points fail loudly (no CPU fallback).  CPU only."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import relearn_amd as ra
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "relearn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    ra.build()
+    lib = ra.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 45
+    missing = [s for s in decl if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(ra.ABI_SYMBOLS) == decl, set(ra.ABI_SYMBOLS) ^ set(decl)
+    assert lib.rl_abi_version() == 1
+
+
+def test_every_entry_point_cites_the_reference():
+    text = open(os.path.join(ROOT, "include", "relearn_hip.h")).read()
+    assert text.count("src/") >= 20  # file:line citations of the interfaces each entry point replaces
+    for needle in ("src/envs/mod.rs:76-127", "src/torch/agents/policies/trpo.rs:97-164",
+                   "src/torch/agents/critics/opt.rs:100-126", "src/simulation/steps.rs:113-167"):
+        assert needle in text
+
+
+def test_defaults_match_reference_configs():
+    lib = ra.lib()
+    p = ra.cartpole_params_default()
+    assert (p.gravity, p.mass_cart, p.mass_pole, p.length_half_pole) == (9.8, 1.0, 0.1, 0.5)
+    assert (p.friction_cart, p.friction_pole, p.time_step) == (0.01, 0.01, 0.02)
+    assert (p.action_force, p.max_pos, p.discount_factor) == (10.0, 2.4, 0.99)
+    assert abs(p.max_angle - 0.20943951023931956) < 1e-16
+    t = ra.trpo_config_default()
+    assert (t.iterations, t.max_backtracks, t.backtrack_ratio, t.hpv_reg_coeff, t.max_policy_step_kl,
+            t.accept_violation) == (10, 15, 0.8, 1e-5, 0.01, 0)
+    a = ra.adam_config_default()
+    assert (a.learning_rate, a.beta1, a.beta2, a.weight_decay, a.eps) == (1e-3, 0.9, 0.999, 0.0, 1e-8)
+
+
+def test_no_cpu_fallback():
+    n = C.c_int32(-1)
+    assert ra.lib().rl_device_count(C.byref(n)) == ra.OK
+    if n.value > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(ra.RelearnError) as e:
+        ra.Engine(0)
+    assert e.value.code == ra.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must never import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "relearn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                bad = re.findall(r"import\s+oracle|from\s+oracle|#include\s*[<\"][^>\"]*oracle|liboracle|oracle/", src)
+                assert not bad, (os.path.join(dirpath, f), bad)
