@@ -34,7 +34,7 @@ KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backwa
 # every symbol include/relearn_hip.h declares (checked by tests/test_abi_symbols.py against the header)
 ABI_SYMBOLS = [
     "rl_abi_version", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
-    "rl_last_error", "rl_engine_info", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
+    "rl_last_error", "rl_engine_info", "rl_engine_set_kernel_variant", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
     "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy",
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
@@ -175,6 +175,9 @@ class Engine(_Handle):
         cus = C.c_int32()
         _check(lib().rl_engine_info(self.h, name, C.c_size_t(256), arch, C.c_size_t(256), C.byref(cus)), self.h)
         return name.value.decode(), arch.value.decode(), cus.value
+
+    def set_kernel_variant(self, variant):
+        _check(lib().rl_engine_set_kernel_variant(self.h, C.c_int32(variant)), self.h)
 
     def timer_begin(self):
         _check(lib().rl_timer_begin(self.h), self.h)

@@ -243,6 +243,14 @@ int32_t rl_timer_end(rl_engine *e, float *elapsed_ms) {
   });
 }
 
+int32_t rl_engine_set_kernel_variant(rl_engine *e, int32_t variant) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    RL_REQUIRE(variant == 0 || variant == 1, "kernel variant must be 0 (best) or 1 (v1 reference kernels)");
+    e->kernel_variant = variant;
+  });
+}
+
 int32_t rl_profile_enable(rl_engine *e, int32_t on) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
@@ -684,8 +692,14 @@ int32_t rl_traj_create(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_
     uint64_t nbB = (t->B + 255) / 256;
     if (nbB > 2048) nbB = 2048;
     t->nbB = (uint32_t)nbB;
-    t->slabA = dalloc<double>((size_t)t->nbA * t->Pmax);
-    t->slabB = dalloc<double>((size_t)t->nbB * 4);
+    // v2 kernels: persistent grid of 4-wave workgroups, 2 per CU, one 32-sample tile per wave and iteration
+    uint64_t n_tiles = (t->B + 31) / 32;
+    uint64_t nbV2 = (n_tiles + 3) / 4;
+    uint64_t max_v2 = 2ull * (uint64_t)e->prop.multiProcessorCount;
+    if (nbV2 > max_v2) nbV2 = max_v2;
+    t->nbV2 = (uint32_t)nbV2;
+    t->slabA = dalloc<double>((size_t)(t->nbA > t->nbV2 ? t->nbA : t->nbV2) * t->Pmax);
+    t->slabB = dalloc<double>((size_t)(t->nbB > t->nbV2 ? t->nbB : t->nbV2) * 4);
     t->vec = dalloc<float>(t->Pmax + 4);
     t->cg_x = dalloc<float>(t->Pmax);
     t->cg_r = dalloc<float>(t->Pmax);
@@ -794,18 +808,38 @@ static void check_policy(const rl_mlp *policy, const rl_traj *traj) {
 // gradient pass: PASS_INIT -> backward -> reduce(A+B) -> allreduce
 static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
   uint32_t P = (uint32_t)policy->P;
-  launch_policy_pass(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr);
-  launch_mlp_backward(traj, policy, nullptr);
-  launch_reduce(traj, P, true, true);
+  if (traj->eng->kernel_variant == 0 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
+    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr);
+    launch_mlp_backward(traj, policy, nullptr);
+    launch_reduce(traj, P, true, true, traj->nbA, traj->nbB);
+  }
   rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+// (loss, KL) of the current parameters against lp0: PASS_EVAL -> reduce(B) -> allreduce
+static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
+  uint32_t P = (uint32_t)policy->P;
+  if (traj->eng->kernel_variant == 0 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
+    launch_reduce(traj, P, false, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip);
+    launch_reduce(traj, P, false, true, traj->nbA, traj->nbB);
+  }
+  rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
 }
 
 // Fisher/Hessian-vector product pass with tangent d_v: PASS_JVP -> backward -> reduce(A) -> allreduce
 static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
   uint32_t P = (uint32_t)policy->P;
-  launch_policy_pass(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip);
-  launch_mlp_backward(traj, policy, d_skip);
-  launch_reduce(traj, P, true, false);
+  if (traj->eng->kernel_variant == 0 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
+    launch_reduce(traj, P, true, false, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip);
+    launch_mlp_backward(traj, policy, d_skip);
+    launch_reduce(traj, P, true, false, traj->nbA, traj->nbB);
+  }
   rl_allreduce_sum_f32(traj->eng, traj->vec, P);
 }
 
@@ -834,9 +868,7 @@ int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg,
     for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
       if (i > 0) ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
       launch_ls_set_params(traj, policy, ratio);
-      launch_policy_pass(traj, policy, PASS_EVAL, nullptr, Bt, &traj->trpo->ls_accepted);
-      launch_reduce(traj, P, false, true);
-      rl_allreduce_sum_f32(e, traj->vec + P, 4);
+      run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
       launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
     }
     launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
@@ -877,6 +909,7 @@ int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, 
     check_policy(policy, traj);
     RL_REQUIRE(v && out, "NULL argument");
     uint32_t P = (uint32_t)policy->P;
+    run_policy_gradient(policy, traj);  // the product is taken at the current parameters: refresh log pi_0
     h2d(traj->eng, traj->cg_x, v, P * sizeof(float));
     run_policy_fvp(policy, traj, traj->cg_x, nullptr);
     std::vector<float> h(P);
@@ -896,11 +929,9 @@ int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, f
     std::vector<float> cur(P);
     d2h(e, cur.data(), policy->d_params, P * sizeof(float));
     h2d(e, policy->d_params, params0, P * sizeof(float));
-    launch_policy_pass(traj, policy, PASS_INIT, nullptr, Bt, nullptr);
+    run_policy_gradient(policy, traj);  // fills lp0 under params0
     h2d(e, policy->d_params, cur.data(), P * sizeof(float));
-    launch_policy_pass(traj, policy, PASS_EVAL, nullptr, Bt, nullptr);
-    launch_reduce(traj, P, false, true);
-    rl_allreduce_sum_f32(e, traj->vec + P, 4);
+    run_policy_eval(policy, traj, nullptr);
     float h[4];
     d2h(e, h, traj->vec + P, sizeof(h));
     double inv_B = 1.0 / (double)Bt;
@@ -980,9 +1011,13 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
 
 static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
   uint32_t P = (uint32_t)critic->P;
-  launch_critic_fwd(traj, critic, b_total(traj));
-  launch_mlp_backward(traj, critic, nullptr);
-  launch_reduce(traj, P, true, true);
+  if (traj->eng->kernel_variant == 0 && launch_critic_step_v2(traj, critic, b_total(traj))) {
+    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_critic_fwd(traj, critic, b_total(traj));
+    launch_mlp_backward(traj, critic, nullptr);
+    launch_reduce(traj, P, true, true, traj->nbA, traj->nbB);
+  }
   rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
 }
 

@@ -100,6 +100,8 @@ struct rl_engine {
   // last child is destroyed (hosts with garbage collectors release handles in arbitrary order)
   int64_t live_handles = 0;
   bool zombie = false;
+  // 0: best available kernels (MFMA v2 where the shape allows); 1: v1 reference kernels only
+  int kernel_variant = 0;
 };
 
 struct rl_env {
@@ -141,7 +143,7 @@ struct rl_traj {
   float *cg_x = nullptr, *cg_r = nullptr, *cg_p = nullptr, *prev_params = nullptr, *descent = nullptr;
   float *losses = nullptr;  // [max critic steps]
   TrpoStateDev *trpo = nullptr;
-  uint32_t nbA = 0, nbB = 0, Pmax = 0, max_losses = 0;
+  uint32_t nbA = 0, nbB = 0, nbV2 = 0, Pmax = 0, max_losses = 0;
   uint32_t bwd_chunk = 0;   // samples per backward block
 };
 

@@ -22,7 +22,7 @@ void launch_critic_fwd(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
 // J^T dz accumulated per block into slabA (lane = hidden unit, samples broadcast through scalar loads)
 void launch_mlp_backward(rl_traj *traj, const rl_mlp *mlp, const int32_t *d_skip_flag);
 // vec[0..P) <- sum_blocks slabA (if useA), vec[P..P+4) <- sum_blocks slabB; deterministic order
-void launch_reduce(rl_traj *traj, uint32_t P, bool useA, bool useB);
+void launch_reduce(rl_traj *traj, uint32_t P, bool useA, bool useB, uint32_t rowsA, uint32_t rowsB);
 
 void launch_trpo_begin(rl_traj *traj, rl_mlp *policy, uint64_t B_total);                 // after grad reduce
 void launch_cg_step(rl_traj *traj, uint32_t P, float reg, float tol);                    // after HVP reduce
@@ -33,3 +33,9 @@ void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, dou
 void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept_violation);
 void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_total);     // after critic reduce
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad);
+
+// kernels_mfma.hip ("v2": f32-MFMA layer 1, lane = hidden unit backward; H = 128, D = 5 only)
+// returns false when the shape is not supported (caller falls back to the v1 kernels)
+bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
+bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
+                      const int32_t *d_skip_flag);

@@ -1,0 +1,600 @@
+// kernels_mfma.hip — "v2" fused full-batch MLP gradient kernels built around the f32 MFMA.
+//
+// One wavefront owns a tile of 32 samples at a time.  Layer 1 of the MLP (x~ [32 x 6] times W~1^T [6 x 128],
+// bias folded in as the 6th input) is 4 x 3 issues of v_mfma_f32_32x32x2_f32 whose D layout puts
+//     the HIDDEN UNIT on the lane   (col  = lane & 31, one 32-unit tile per accumulator)
+//     the SAMPLE in the registers   (row  = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = 0..15).
+// That orientation is chosen for the BACKWARD pass: every gradient entry of hidden unit j is a sum over
+// samples, i.e. over registers and over time — never over lanes — so lane j keeps dW1[j][:], db1[j], dW2[:][j]
+// in its own registers for the whole launch (exactly one cross-half add at the very end).
+// The only cross-lane step is the forward's sum over hidden units (y_s = sum_j w2_j h_sj): 16 partial sums per
+// lane go through a per-wave LDS transpose (conflict-free, stride 33) and come back as one value per sample;
+// the sample-owning lanes then do the per-sample scalar math (loss, dL/dy) and publish dL/dy * x~ rows that
+// the backward reads as LDS broadcasts.
+//
+// f32 MFMA runs at the f32 vector rate (64 FLOP/clk/SIMD) on its own pipe, so layer 1 (and its recompute)
+// costs no VALU issue slots; the VALU does relu, the 128->A layer, masks and the gradient accumulation.
+// Accumulation is two-level: f32 over 4 tiles (64 samples per accumulator), f64 across tiles/waves/workgroups
+// (see kernels_update.hip for why f32 sums are not accurate enough for TRPO's CG).
+//
+// Reference semantics: ValuesOpt::update (src/torch/agents/critics/opt.rs:100-126): loss = mse_loss(V(obs),
+// targets, Mean); backward; the Adam step itself is k_adam_step (kernels_update.hip).
+#include "device_fns.hpp"
+#include "kernels.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline uint32_t cdiv_u(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wavefront execute in program order; what is needed is that the compiler keeps that
+  // order across lanes it cannot see a dependence between.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int V2_WAVES = 4;        // waves per workgroup
+constexpr int V2_NT = 4;           // 32-unit hidden tiles (H = 128)
+constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 samples per accumulator)
+
+// ---------------------------------------------------------------- critic: forward + loss + backward fused
+// per 32-sample tile and wave:  MFMA 12 issues (768 cycles on the matrix pipe)
+//                               VALU ~128 (relu, y partials) + ~50 (owner math) + 576 (backward) instructions
+// Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2x backward of the 5-128-1 MLP).
+__global__ void __launch_bounds__(V2_WAVES * 64, 2)
+    k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
+                       double *__restrict__ slabB, float two_over_B, uint32_t P) {
+  constexpr int D = 5, H = 128, NT = V2_NT;
+  constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] = sum_s [pre_sj > 0] dy_s x~_sk (slot 6 unused); + db2, loss
+  __shared__ float Ysh[V2_WAVES][32][33];
+  __shared__ float Ush[V2_WAVES][32][8];
+  __shared__ double Acc[V2_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5;
+  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H;
+  const float b2 = W2[H];
+  const size_t B = (size_t)tr.T * tr.n;
+  const size_t plane = (size_t)(tr.T + 1) * tr.n;
+  double *acc64 = Acc[wave];
+  for (int p = lane; p < IMG; p += 64) acc64[p] = 0.0;
+
+  // B operand of the MFMA: W~1^T[k][j], k = hf + 2*step; k == 5 is the bias row
+  float wb[NT][3], w2v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = t * 32 + n;
+    wb[t][0] = W1[j * D + hf];
+    wb[t][1] = W1[j * D + 2 + hf];
+    wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
+    w2v[t] = W2[j];
+  }
+  float m[NT][6];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[t][k] = 0.0f;
+  const float big = 0x1p126f;
+  double loss64 = 0.0, db2_64 = 0.0;
+  wave_lds_fence();
+
+  // f32 -> f64 flush: add the two lane halves (same hidden unit, different samples), then accumulate in LDS
+  auto flush = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = t * 32 + n;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float v = m[t][k] + __shfl_xor(m[t][k], 32, 64);
+        if (hf == 0) acc64[j * 7 + k] += (double)v;
+        m[t][k] = 0.0f;
+      }
+    }
+  };
+
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t wave_id = (size_t)blockIdx.x * V2_WAVES + wave, n_waves = (size_t)gridDim.x * V2_WAVES;
+  int since_flush = 0;
+  // A operand: x~[sample n][k = hf + 2*step]; x~5 = 1 (bias input).
+  struct TileOp {
+    float a0, a1, a2, tgt;
+    bool valid;
+  };
+  auto load_tile = [&](size_t g) {
+    TileOp o;
+    const size_t sidx = g * 32 + n;
+    o.a0 = o.a1 = o.a2 = o.tgt = 0.0f;
+    o.valid = g < n_tiles && sidx < B;
+    if (o.valid) {
+      o.a0 = tr.obs[(size_t)hf * plane + sidx];
+      o.a1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
+      o.a2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
+      o.tgt = tr.rtg[sidx];
+    }
+    return o;
+  };
+  auto layer1 = [&](f32x16(&acc)[NT], const TileOp &o) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0, wb[t][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1, wb[t][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a2, wb[t][2], c, 0, 0, 0);
+      acc[t] = c;
+    }
+  };
+  auto process = [&](f32x16(&acc)[NT], const TileOp &o) {
+    // relu in place + partial y over this lane's 4 hidden units
+    float yp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yp[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // relu on the bit pattern (one v_max_i32, no float canonicalisation of the MFMA output):
+        // negative floats and -0.0 are negative integers -> 0; positive floats are unchanged
+        int hb = __builtin_bit_cast(int, (float)acc[t][r]);
+        hb = hb > 0 ? hb : 0;
+        float h = __builtin_bit_cast(float, hb);
+        acc[t][r] = h;
+        yp[r] = __builtin_fmaf(h, w2v[t], yp[r]);
+      }
+    // transpose through LDS: row = sample, column = source lane
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
+    wave_lds_fence();
+    float part = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part = part + Ysh[wave][n][hf * 16 + c];
+    float other = __shfl_xor(part, 32, 64);
+    float p0 = hf == 0 ? part : other, p1 = hf == 0 ? other : part;
+    float y = (p0 + p1) + b2;
+    float d = y - o.tgt;
+    float dy = o.valid ? d * two_over_B : 0.0f;
+    if (hf == 0 && o.valid) {
+      loss64 += (double)(d * d);
+      db2_64 += (double)dy;
+    }
+    // publish u[sample][k] = dy * x~_k (k = 5: dy itself)
+    Ush[wave][n][hf] = dy * o.a0;
+    Ush[wave][n][2 + hf] = dy * o.a1;
+    Ush[wave][n][4 + hf] = dy * o.a2;
+    wave_lds_fence();
+    // backward: lane = hidden unit, registers = samples
+#pragma unroll
+    for (int rc = 0; rc < 8; ++rc) {
+      float u[2][8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = rc * 2 + q;
+        const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
+        float4 lo = src[0], hi = src[1];
+        u[q][0] = lo.x; u[q][1] = lo.y; u[q][2] = lo.z; u[q][3] = lo.w;
+        u[q][4] = hi.x; u[q][5] = hi.y; u[q][6] = hi.z; u[q][7] = hi.w;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float h = acc[t][rc * 2 + q];
+          // relu'(pre) as one VALU op: clamp(h * 2^126) is 1 for every normal h > 0 and 0 for h == 0
+          float gsel;
+          asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(gsel) : "v"(h), "s"(big));
+#pragma unroll
+          for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[q][k], m[t][k]);
+        }
+    }
+    wave_lds_fence();  // Ysh / Ush are rewritten by the next tile
+    if (++since_flush == V2_FLUSH) {
+      since_flush = 0;
+      flush();
+    }
+  };
+  // global loads run one tile ahead; the two waves of a SIMD desynchronise so that one wave's MFMA phase runs
+  // under the other's VALU phase (an in-wave software pipeline with two accumulator sets spills at 256 VGPRs)
+  f32x16 acc[NT];
+  TileOp op = load_tile(wave_id);
+  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
+    TileOp next = load_tile(g + n_waves);
+    layer1(acc, op);
+    process(acc, op);
+    op = next;
+  }
+  flush();
+  // loss / db2: reduce over the 32 owner lanes of the wave (f64 moved as two 32-bit halves)
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+  double l = hf == 0 ? loss64 : 0.0, bsum = hf == 0 ? db2_64 : 0.0;
+#pragma unroll
+  for (int s = 16; s > 0; s >>= 1) {
+    l = l + xlane(l, s);
+    bsum = bsum + xlane(bsum, s);
+  }
+  if (lane == 0) {
+    acc64[H * 7] = bsum;   // db2
+    acc64[H * 7 + 1] = l;  // loss partial
+  }
+  __syncthreads();
+  // sum the per-wave images in wave order, turn M into gradients and write the workgroup's slab row:
+  //   dL/dW1[j][k] = w2_j * M[j][k],  dL/db1[j] = w2_j * M[j][5],  dL/db2 = sum dy,
+  //   dL/dW2[j] = sum_s dy_s h_sj = sum_s dy_s [pre_sj > 0] (W~1[j] . x~_s) = sum_k W~1[j][k] M[j][k]
+  for (uint32_t p = threadIdx.x; p <= P; p += V2_WAVES * 64) {
+    auto tot = [&](int src) {
+      double s = Acc[0][src];
+#pragma unroll
+      for (int w = 1; w < V2_WAVES; ++w) s = s + Acc[w][src];
+      return s;
+    };
+    double s;
+    if (p < (uint32_t)(H * D)) {
+      int j = p / D, k = p % D;
+      s = tot(j * 7 + k) * (double)W2[j];
+    } else if (p < (uint32_t)(H * D + H)) {
+      int j = p - H * D;
+      s = tot(j * 7 + 5) * (double)W2[j];
+    } else if (p < (uint32_t)(H * D + 2 * H)) {
+      int j = p - H * D - H;
+      s = tot(j * 7 + 5) * (double)b1[j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += tot(j * 7 + k) * (double)W1[j * D + k];
+    } else if (p == (uint32_t)(H * D + 2 * H)) {
+      s = tot(H * 7);
+    } else {
+      s = tot(H * 7 + 1);
+    }
+    if (p < P) slabA[(size_t)blockIdx.x * P + p] = s;
+    else slabB[(size_t)blockIdx.x * 4 + 0] = s;
+  }
+  if (threadIdx.x < 3) slabB[(size_t)blockIdx.x * 4 + 1 + threadIdx.x] = 0.0;
+}
+
+// ================================================================================================
+// Policy kernels (2-action categorical head).  Same tile machinery as the critic kernel; differences:
+//   - two output channels: the forward carries 2 x 16 partial sums and transposes them one after the other
+//     through the same LDS tile;
+//   - the backward accumulates M_a[j][k] = sum_s [pre_sj > 0] dz_sa x~_sk for a = 0, 1 (12 values per hidden
+//     unit); at the end  dW1[j][k] = sum_a W2[a][j] M_a[j][k],  db1[j] = sum_a W2[a][j] M_a[j][5],
+//     dW2[a][j] = sum_k W~1[j][k] M_a[j][k]  (because h_sj = [pre_sj > 0] W~1[j].x~_s),  db2[a] = sum_s dz_sa.
+// Reference semantics: Trpo::update closure + HessianVectorProduct (src/torch/agents/policies/trpo.rs:97-146,
+// src/torch/optimizers/conjugate_gradient.rs:262-339) and Categorical (src/torch/distributions/categorical.rs).
+// ================================================================================================
+constexpr int PIMG = 128 * 12 + 4;  // per-wave f64 image: M_a[j][k] (a*6+k), then db2[0], db2[1], sum0, sum1
+
+struct PolicyTile {
+  float a0, a1, a2;
+  bool valid;
+};
+
+template <int MODE>  // PASS_INIT (gradient), PASS_JVP (Fisher-vector product), PASS_EVAL (loss / KL only)
+__global__ void __launch_bounds__(V2_WAVES * 64, 2)
+    k_policy_mfma(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
+                  float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
+                  uint32_t P, const int32_t *__restrict__ skip) {
+  constexpr int D = 5, H = 128, NT = V2_NT, A = 2;
+  __shared__ float Ysh[V2_WAVES][32][33];
+  __shared__ float Ush[V2_WAVES][32][12];
+  __shared__ double Acc[V2_WAVES][MODE == PASS_EVAL ? 4 : PIMG];
+  if (skip != nullptr && *skip != 0) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5;
+  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H,
+                           *__restrict__ b2 = W2 + A * H;
+  const size_t B = (size_t)tr.T * tr.n;
+  const size_t plane = (size_t)(tr.T + 1) * tr.n;
+  double *acc64 = Acc[wave];
+  if (MODE != PASS_EVAL)
+    for (int p = lane; p < PIMG; p += 64) acc64[p] = 0.0;
+
+  float wb[NT][3], w2v[NT][A];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = t * 32 + n;
+    wb[t][0] = W1[j * D + hf];
+    wb[t][1] = W1[j * D + 2 + hf];
+    wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
+#pragma unroll
+    for (int a = 0; a < A; ++a) w2v[t][a] = W2[a * H + j];
+  }
+  // tangent copies (PASS_JVP only)
+  float tb[NT][3], t2v[NT][A];
+  float tb2[A] = {0.0f, 0.0f};
+  if (MODE == PASS_JVP) {
+    const float *__restrict__ V1 = tangent, *__restrict__ vb1 = V1 + H * D, *__restrict__ V2 = vb1 + H,
+                             *__restrict__ vb2 = V2 + A * H;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = t * 32 + n;
+      tb[t][0] = V1[j * D + hf];
+      tb[t][1] = V1[j * D + 2 + hf];
+      tb[t][2] = hf == 0 ? V1[j * D + 4] : vb1[j];
+#pragma unroll
+      for (int a = 0; a < A; ++a) t2v[t][a] = V2[a * H + j];
+    }
+    tb2[0] = vb2[0];
+    tb2[1] = vb2[1];
+  }
+  const float b2_0 = b2[0], b2_1 = b2[1];
+  float m[NT][A * 6];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int k = 0; k < A * 6; ++k) m[t][k] = 0.0f;
+  const float big = 0x1p126f;
+  double sum0 = 0.0, sum1 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
+  wave_lds_fence();
+
+  auto flush = [&]() {
+    if (MODE == PASS_EVAL) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = t * 32 + n;
+#pragma unroll
+      for (int k = 0; k < A * 6; ++k) {
+        float v = m[t][k] + __shfl_xor(m[t][k], 32, 64);
+        if (hf == 0) acc64[j * 12 + k] += (double)v;
+        m[t][k] = 0.0f;
+      }
+    }
+  };
+  // sum over the 32 source lanes of 16 per-lane partials: LDS transpose, result for sample n in both halves
+  auto lane_sum = [&](const float(&yp)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
+    wave_lds_fence();
+    float part = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part = part + Ysh[wave][n][hf * 16 + c];
+    float other = __shfl_xor(part, 32, 64);
+    wave_lds_fence();
+    return hf == 0 ? part + other : other + part;
+  };
+
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t wave_id = (size_t)blockIdx.x * V2_WAVES + wave, n_waves = (size_t)gridDim.x * V2_WAVES;
+  int since_flush = 0;
+  auto load_tile = [&](size_t g) {
+    PolicyTile o;
+    const size_t sidx = g * 32 + n;
+    o.a0 = o.a1 = o.a2 = 0.0f;
+    o.valid = g < n_tiles && sidx < B;
+    if (o.valid) {
+      o.a0 = tr.obs[(size_t)hf * plane + sidx];
+      o.a1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
+      o.a2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
+    }
+    return o;
+  };
+  PolicyTile op = load_tile(wave_id);
+  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
+    PolicyTile next = load_tile(g + n_waves);
+    const size_t sidx = g * 32 + n;
+    f32x16 acc[NT];
+    float y0[16], y1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      y0[r] = 0.0f;
+      y1[r] = 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0, wb[t][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1, wb[t][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a2, wb[t][2], c, 0, 0, 0);
+      if (MODE == PASS_JVP) {
+        // tangent pre-activation of the same tile, consumed immediately (16 live registers)
+        f32x16 tc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        tc = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0, tb[t][0], tc, 0, 0, 0);
+        tc = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1, tb[t][1], tc, 0, 0, 0);
+        tc = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a2, tb[t][2], tc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int hb = __builtin_bit_cast(int, (float)c[r]);
+          hb = hb > 0 ? hb : 0;
+          float h = __builtin_bit_cast(float, hb);
+          c[r] = h;
+          float gsel;
+          asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(gsel) : "v"(h), "s"(big));
+          float dh = gsel * tc[r];
+          // d z_a = sum_j (W2[a][j] dh_j + V2[a][j] h_j)   (J v through the output layer)
+          y0[r] = __builtin_fmaf(dh, w2v[t][0], y0[r]);
+          y1[r] = __builtin_fmaf(dh, w2v[t][1], y1[r]);
+          y0[r] = __builtin_fmaf(h, t2v[t][0], y0[r]);
+          y1[r] = __builtin_fmaf(h, t2v[t][1], y1[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int hb = __builtin_bit_cast(int, (float)c[r]);
+          hb = hb > 0 ? hb : 0;
+          float h = __builtin_bit_cast(float, hb);
+          c[r] = h;
+          y0[r] = __builtin_fmaf(h, w2v[t][0], y0[r]);
+          y1[r] = __builtin_fmaf(h, w2v[t][1], y1[r]);
+        }
+      }
+      acc[t] = c;
+    }
+    const float s0 = lane_sum(y0), s1 = lane_sum(y1);
+    // ---- per-sample math on the owner lanes (lane n and n+32 both hold sample n)
+    float dz0 = 0.0f, dz1 = 0.0f;
+    if (MODE == PASS_JVP) {
+      float dzt0 = s0 + tb2[0], dzt1 = s1 + tb2[1];
+      float p0 = 0.0f, p1 = 0.0f;
+      if (op.valid) {
+        p0 = rl_expf(lp0[sidx]);
+        p1 = rl_expf(lp0[B + sidx]);
+      }
+      float pdz = __builtin_fmaf(p1, dzt1, __builtin_fmaf(p0, dzt0, 0.0f));
+      dz0 = op.valid ? p0 * (dzt0 - pdz) * inv_B : 0.0f;
+      dz1 = op.valid ? p1 * (dzt1 - pdz) * inv_B : 0.0f;
+    } else {
+      float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
+      log_softmax_lane<2>(z, lp);
+      const float adv = op.valid ? tr.adv[sidx] : 0.0f;
+      const int act = op.valid ? (int)tr.action[sidx] : 0;
+      if (MODE == PASS_INIT) {
+        if (op.valid && hf == 0) {
+          lp0[sidx] = lp[0];
+          lp0[B + sidx] = lp[1];
+        }
+        float lpa = act == 0 ? lp[0] : lp[1];
+        float ratio = rl_expf(lpa - lpa);
+        float c = -(ratio * adv) * inv_B;
+        float pa0 = rl_expf(lp[0]), pa1 = rl_expf(lp[1]);
+        dz0 = op.valid ? c * ((act == 0 ? 1.0f : 0.0f) - pa0) : 0.0f;
+        dz1 = op.valid ? c * ((act == 1 ? 1.0f : 0.0f) - pa1) : 0.0f;
+        float cl0 = lp[0] < -3.402823466e+38f ? -3.402823466e+38f : lp[0];
+        float cl1 = lp[1] < -3.402823466e+38f ? -3.402823466e+38f : lp[1];
+        float ent = cl0 * pa0;
+        ent += cl1 * pa1;
+        if (op.valid && hf == 0) {
+          sum0 += (double)(ratio * adv);
+          sum1 += (double)(-ent);
+        }
+      } else {  // PASS_EVAL
+        float l00 = 0.0f, l01 = 0.0f;
+        if (op.valid) {
+          l00 = lp0[sidx];
+          l01 = lp0[B + sidx];
+        }
+        float lpa = act == 0 ? lp[0] : lp[1];
+        float l0a = act == 0 ? l00 : l01;
+        float ratio = rl_expf(lpa - l0a);
+        float rel0 = l00 - lp[0], rel1 = l01 - lp[1];
+        if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
+        if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
+        float kl = rel0 * rl_expf(l00);
+        kl += rel1 * rl_expf(l01);
+        if (op.valid && hf == 0) {
+          sum0 += (double)(ratio * adv);
+          sum1 += (double)kl;
+        }
+      }
+    }
+    if (MODE != PASS_EVAL) {
+      if (hf == 0) {
+        db2_0 += (double)dz0;
+        db2_1 += (double)dz1;
+      }
+      // publish u[sample][a*6 + k] = dz_a * x~_k
+      Ush[wave][n][hf] = dz0 * op.a0;
+      Ush[wave][n][2 + hf] = dz0 * op.a1;
+      Ush[wave][n][4 + hf] = dz0 * op.a2;
+      Ush[wave][n][6 + hf] = dz1 * op.a0;
+      Ush[wave][n][8 + hf] = dz1 * op.a1;
+      Ush[wave][n][10 + hf] = dz1 * op.a2;
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
+        float4 u0 = src[0], u1 = src[1], u2 = src[2];
+        const float u[12] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float h = acc[t][r];
+          float gsel;
+          asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(gsel) : "v"(h), "s"(big));
+#pragma unroll
+          for (int k = 0; k < 12; ++k) m[t][k] = __builtin_fmaf(gsel, u[k], m[t][k]);
+        }
+      }
+      wave_lds_fence();
+      if (++since_flush == V2_FLUSH) {
+        since_flush = 0;
+        flush();
+      }
+    }
+    op = next;
+  }
+  flush();
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+  double r0 = hf == 0 ? sum0 : 0.0, r1 = hf == 0 ? sum1 : 0.0, r2 = hf == 0 ? db2_0 : 0.0, r3 = hf == 0 ? db2_1 : 0.0;
+#pragma unroll
+  for (int s = 16; s > 0; s >>= 1) {
+    r0 = r0 + xlane(r0, s);
+    r1 = r1 + xlane(r1, s);
+    r2 = r2 + xlane(r2, s);
+    r3 = r3 + xlane(r3, s);
+  }
+  constexpr int TAIL = MODE == PASS_EVAL ? 0 : H * 12;
+  if (lane == 0) {
+    acc64[TAIL + 0] = r2;
+    acc64[TAIL + 1] = r3;
+    acc64[TAIL + 2] = r0;
+    acc64[TAIL + 3] = r1;
+  }
+  __syncthreads();
+  auto tot = [&](int src) {
+    double s = Acc[0][src];
+#pragma unroll
+    for (int w = 1; w < V2_WAVES; ++w) s = s + Acc[w][src];
+    return s;
+  };
+  if (MODE != PASS_EVAL) {
+    for (uint32_t p = threadIdx.x; p < P; p += V2_WAVES * 64) {
+      double s = 0.0;
+      if (p < (uint32_t)(H * D)) {
+        int j = p / D, k = p % D;
+        s = tot(j * 12 + k) * (double)W2[j] + tot(j * 12 + 6 + k) * (double)W2[H + j];
+      } else if (p < (uint32_t)(H * D + H)) {
+        int j = p - H * D;
+        s = tot(j * 12 + 5) * (double)W2[j] + tot(j * 12 + 11) * (double)W2[H + j];
+      } else if (p < (uint32_t)(H * D + H + A * H)) {
+        int q = p - H * D - H, a = q / H, j = q % H;
+        s = tot(j * 12 + a * 6 + 5) * (double)b1[j];
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += tot(j * 12 + a * 6 + k) * (double)W1[j * D + k];
+      } else {
+        s = tot(TAIL + (int)(p - (H * D + H + A * H)));
+      }
+      slabA[(size_t)blockIdx.x * P + p] = s;
+    }
+  }
+  if (threadIdx.x < 4) {
+    double v = 0.0;
+    if (MODE != PASS_JVP && threadIdx.x < 2) v = tot(TAIL + 2 + threadIdx.x);
+    slabB[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+  }
+}
+
+// ---------------------------------------------------------------- launcher
+bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
+  if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
+  ProfScope ps(traj->eng, RL_K_BACKWARD);
+  float two_over_B = 2.0f / (float)B_total;
+  hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbV2), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
+                     critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
+  return true;
+}
+
+// gradient (PASS_INIT), Fisher-vector product (PASS_JVP) or loss/KL evaluation (PASS_EVAL) in one launch
+bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
+                      const int32_t *d_skip) {
+  if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
+  ProfScope ps(traj->eng, mode == PASS_EVAL ? RL_K_POLICY_PASS : RL_K_BACKWARD);
+  float inv_B = 1.0f / (float)B_total;
+  dim3 g(traj->nbV2), b(V2_WAVES * 64);
+  hipStream_t s = traj->eng->stream;
+  uint32_t P = (uint32_t)policy->P;
+#define PLAUNCH(MM)                                                                                              \
+  hipLaunchKernelGGL((k_policy_mfma<MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0, traj->slabA, \
+                     traj->slabB, inv_B, P, d_skip)
+  if (mode == PASS_INIT) PLAUNCH(PASS_INIT);
+  else if (mode == PASS_JVP) PLAUNCH(PASS_JVP);
+  else PLAUNCH(PASS_EVAL);
+#undef PLAUNCH
+  return true;
+}

@@ -551,10 +551,10 @@ void launch_mlp_backward(rl_traj *traj, const rl_mlp *mlp, const int32_t *d_skip
 #undef BWD
 }
 
-void launch_reduce(rl_traj *traj, uint32_t P, bool useA, bool useB) {
+void launch_reduce(rl_traj *traj, uint32_t P, bool useA, bool useB, uint32_t rowsA, uint32_t rowsB) {
   ProfScope ps(traj->eng, RL_K_REDUCE);
-  hipLaunchKernelGGL(k_reduce, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, traj->nbA, P,
-                     traj->slabB, traj->nbB, traj->vec, useA ? 1 : 0, useB ? 1 : 0);
+  hipLaunchKernelGGL(k_reduce, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
+                     traj->slabB, rowsB, traj->vec, useA ? 1 : 0, useB ? 1 : 0);
 }
 
 void launch_trpo_begin(rl_traj *traj, rl_mlp *policy, uint64_t B_total) {
