@@ -246,7 +246,7 @@ int32_t rl_timer_end(rl_engine *e, float *elapsed_ms) {
 int32_t rl_engine_set_kernel_variant(rl_engine *e, int32_t variant) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
-    RL_REQUIRE(variant == 0 || variant == 1, "kernel variant must be 0 (best) or 1 (v1 reference kernels)");
+    RL_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (best), 1 (v1 reference kernels) or 2");
     e->kernel_variant = variant;
   });
 }
@@ -698,8 +698,18 @@ int32_t rl_traj_create(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_
     uint64_t max_v2 = 2ull * (uint64_t)e->prop.multiProcessorCount;
     if (nbV2 > max_v2) nbV2 = max_v2;
     t->nbV2 = (uint32_t)nbV2;
-    t->slabA = dalloc<double>((size_t)(t->nbA > t->nbV2 ? t->nbA : t->nbV2) * t->Pmax);
-    t->slabB = dalloc<double>((size_t)(t->nbB > t->nbV2 ? t->nbB : t->nbV2) * 4);
+    // pair kernels: 2-wave workgroups, 8 per CU (4 waves per SIMD), a contiguous run of tiles per workgroup
+    uint64_t max_pair = 8ull * (uint64_t)e->prop.multiProcessorCount;
+    uint64_t tpb = (n_tiles + max_pair - 1) / max_pair;
+    if (tpb == 0) tpb = 1;
+    t->pair_tiles_per_block = (uint32_t)tpb;
+    t->nbPair = (uint32_t)((n_tiles + tpb - 1) / tpb);
+    uint32_t rows = t->nbA;
+    if (t->nbV2 > rows) rows = t->nbV2;
+    if (t->nbPair > rows) rows = t->nbPair;
+    uint32_t rowsB = t->nbB > rows ? t->nbB : rows;
+    t->slabA = dalloc<double>((size_t)rows * t->Pmax);
+    t->slabB = dalloc<double>((size_t)rowsB * 4);
     t->vec = dalloc<float>(t->Pmax + 4);
     t->cg_x = dalloc<float>(t->Pmax);
     t->cg_r = dalloc<float>(t->Pmax);
@@ -808,7 +818,7 @@ static void check_policy(const rl_mlp *policy, const rl_traj *traj) {
 // gradient pass: PASS_INIT -> backward -> reduce(A+B) -> allreduce
 static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
   uint32_t P = (uint32_t)policy->P;
-  if (traj->eng->kernel_variant == 0 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
+  if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
     launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
   } else {
     launch_policy_pass(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr);
@@ -821,7 +831,7 @@ static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
 // (loss, KL) of the current parameters against lp0: PASS_EVAL -> reduce(B) -> allreduce
 static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
   uint32_t P = (uint32_t)policy->P;
-  if (traj->eng->kernel_variant == 0 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
+  if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
     launch_reduce(traj, P, false, true, traj->nbV2, traj->nbV2);
   } else {
     launch_policy_pass(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip);
@@ -833,7 +843,7 @@ static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip
 // Fisher/Hessian-vector product pass with tangent d_v: PASS_JVP -> backward -> reduce(A) -> allreduce
 static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
   uint32_t P = (uint32_t)policy->P;
-  if (traj->eng->kernel_variant == 0 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
+  if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
     launch_reduce(traj, P, true, false, traj->nbV2, traj->nbV2);
   } else {
     launch_policy_pass(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip);
@@ -1011,8 +1021,9 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
 
 static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
   uint32_t P = (uint32_t)critic->P;
-  if (traj->eng->kernel_variant == 0 && launch_critic_step_v2(traj, critic, b_total(traj))) {
-    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+  if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
+    uint32_t rows = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbV2;
+    launch_reduce(traj, P, true, true, rows, rows);
   } else {
     launch_critic_fwd(traj, critic, b_total(traj));
     launch_mlp_backward(traj, critic, nullptr);

@@ -23,6 +23,7 @@
 #include "kernels.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline uint32_t cdiv_u(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
@@ -36,6 +37,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 constexpr int V2_WAVES = 4;        // waves per workgroup
 constexpr int V2_NT = 4;           // 32-unit hidden tiles (H = 128)
+constexpr int V2_NV = 4;           // hidden tiles whose backward runs on the VALU (the rest: 4x4x1 MFMA)
 constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 samples per accumulator)
 
 // ---------------------------------------------------------------- critic: forward + loss + backward fused
@@ -59,6 +61,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   double *acc64 = Acc[wave];
   for (int p = lane; p < IMG; p += 64) acc64[p] = 0.0;
+  for (int p = lane; p < 32 * 8; p += 64) (&Ush[wave][0][0])[p] = 0.0f;  // columns 6, 7 stay zero
 
   // B operand of the MFMA: W~1^T[k][j], k = hf + 2*step; k == 5 is the bias row
   float wb[NT][3], w2v[NT];
@@ -70,11 +73,22 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
     w2v[t] = W2[j];
   }
+  // Backward accumulators: the gradient GEMM  M[j][k] += [pre_sj > 0] * u_sk  is issued as 16-block 4x4x1 f32
+  // MFMAs (one sample per issue, A = mask of 64 lane-resident hidden units, B = 4 features of u): lane l,
+  // register i of dacc[t][fg] holds M[t*32 + 4*((l&31)>>2) + i][4*fg + (l&3)] for the samples of its lane half.
+  // The VALU is this kernel's busiest pipe (relu, layer 2, masks), the matrix pipe idles 3/4 of the time after
+  // layer 1; so the backward is SPLIT: hidden tiles [0, NV) accumulate with VALU FMAs (lane = hidden unit),
+  // tiles [NV, NT) with the 4x4x1 MFMAs.
+  constexpr int NV = V2_NV;
+  f32x4 dacc[NT][2];
   float m[NT][6];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    dacc[t][0] = (f32x4){0, 0, 0, 0};
+    dacc[t][1] = (f32x4){0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 6; ++k) m[t][k] = 0.0f;
+  }
   const float big = 0x1p126f;
   double loss64 = 0.0, db2_64 = 0.0;
   wave_lds_fence();
@@ -82,7 +96,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   // f32 -> f64 flush: add the two lane halves (same hidden unit, different samples), then accumulate in LDS
   auto flush = [&]() {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NV; ++t) {
       const int j = t * 32 + n;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -91,6 +105,17 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         m[t][k] = 0.0f;
       }
     }
+#pragma unroll
+    for (int t = NV; t < NT; ++t)
+#pragma unroll
+      for (int fg = 0; fg < 2; ++fg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = dacc[t][fg][i] + __shfl_xor(dacc[t][fg][i], 32, 64);
+          const int j = t * 32 + 4 * (n >> 2) + i, k = 4 * fg + (n & 3);
+          if (hf == 0 && k < 6) acc64[j * 7 + k] += (double)v;
+          dacc[t][fg][i] = 0.0f;
+        }
   };
 
   const size_t n_tiles = (B + 31) / 32;
@@ -162,29 +187,38 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     Ush[wave][n][2 + hf] = dy * o.a1;
     Ush[wave][n][4 + hf] = dy * o.a2;
     wave_lds_fence();
-    // backward: lane = hidden unit, registers = samples
+    // backward on the matrix pipe: per sample row r two 4x4x1 issues per hidden tile (features 0-3, 4-7)
 #pragma unroll
     for (int rc = 0; rc < 8; ++rc) {
-      float u[2][8];
+      float ub[2][2], u[2][8];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int r = rc * 2 + q;
-        const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
+        const float *urow = &Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0];
+        ub[q][0] = urow[lane & 3];
+        ub[q][1] = urow[4 + (lane & 3)];
+        const float4 *src = reinterpret_cast<const float4 *>(urow);
         float4 lo = src[0], hi = src[1];
         u[q][0] = lo.x; u[q][1] = lo.y; u[q][2] = lo.z; u[q][3] = lo.w;
         u[q][4] = hi.x; u[q][5] = hi.y; u[q][6] = hi.z; u[q][7] = hi.w;
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int q = 0; q < 2; ++q) {
+        const int r = rc * 2 + q;
+        // relu'(pre) as one VALU op: clamp(h * 2^126) is 1 for every normal h > 0 and 0 for h == 0
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float h = acc[t][rc * 2 + q];
-          // relu'(pre) as one VALU op: clamp(h * 2^126) is 1 for every normal h > 0 and 0 for h == 0
-          float gsel;
-          asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(gsel) : "v"(h), "s"(big));
+        for (int t = NV; t < NT; ++t) {
+          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
+          dacc[t][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub[q][0], dacc[t][0], 0, 0, 0);
+          dacc[t][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub[q][1], dacc[t][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
 #pragma unroll
           for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[q][k], m[t][k]);
         }
+      }
     }
     wave_lds_fence();  // Ysh / Ush are rewritten by the next tile
     if (++since_flush == V2_FLUSH) {
@@ -192,8 +226,8 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
       flush();
     }
   };
-  // global loads run one tile ahead; the two waves of a SIMD desynchronise so that one wave's MFMA phase runs
-  // under the other's VALU phase (an in-wave software pipeline with two accumulator sets spills at 256 VGPRs)
+  // global loads run one tile ahead; the waves of a SIMD desynchronise so that one wave's matrix work runs
+  // under the other's VALU work
   f32x16 acc[NT];
   TileOp op = load_tile(wave_id);
   for (size_t g = wave_id; g < n_tiles; g += n_waves) {
@@ -252,6 +286,207 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     else slabB[(size_t)blockIdx.x * 4 + 0] = s;
   }
   if (threadIdx.x < 3) slabB[(size_t)blockIdx.x * 4 + 1 + threadIdx.x] = 0.0;
+}
+
+// ================================================================================================
+// "pair" variant of the fused critic step: a workgroup of TWO waves owns a 32-sample tile, each wave owning
+// 64 of the 128 hidden units (two 32-unit MFMA tiles).  Measured on MI355X: one wave issues a VALU op only every
+// ~10 cycles, two waves per SIMD reach ~45 % of the VALU rate, four reach ~85 % (scripts/probe/valu_rate.hip) —
+// so the register footprint per wave is what matters: 32 accumulator registers instead of 64 lets four
+// waves share a SIMD.  Costs: two workgroup barriers per tile and the y reduction now spans two waves.
+// ================================================================================================
+constexpr int PAIR_NT = 2;  // hidden tiles per wave
+
+__global__ void __launch_bounds__(128, 4)
+    k_critic_step_pair(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
+                       double *__restrict__ slabB, float two_over_B, uint32_t P, uint32_t tiles_per_block) {
+  constexpr int D = 5, H = 128, NT = PAIR_NT;
+  constexpr int IMG = H * 7 + 2;
+  __shared__ float Ysh[32][65];   // row = sample, column = wave * 32 + source lane
+  __shared__ float Ush[32][8];    // u[sample][k] = dy * x~_k, columns 6, 7 zero
+  __shared__ double Acc[IMG];     // f64 level of the accumulation (each wave owns its hidden units' rows)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hf = lane >> 5;
+  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H;
+  const float b2 = W2[H];
+  const size_t B = (size_t)tr.T * tr.n;
+  const size_t plane = (size_t)(tr.T + 1) * tr.n;
+  for (int p = tid; p < IMG; p += 128) Acc[p] = 0.0;
+  for (int p = tid; p < 32 * 8; p += 128) (&Ush[0][0])[p] = 0.0f;
+
+  float wb[NT][3], w2v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = (wave * NT + t) * 32 + n;
+    wb[t][0] = W1[j * D + hf];
+    wb[t][1] = W1[j * D + 2 + hf];
+    wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
+    w2v[t] = W2[j];
+  }
+  float m[NT][6];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[t][k] = 0.0f;
+  const float big = 0x1p126f;
+  double loss64 = 0.0, db2_64 = 0.0;
+  __syncthreads();
+
+  auto flush = [&]() {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = (wave * NT + t) * 32 + n;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float v = m[t][k] + __shfl_xor(m[t][k], 32, 64);
+        if (hf == 0) Acc[j * 7 + k] += (double)v;
+        m[t][k] = 0.0f;
+      }
+    }
+  };
+
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t g0 = (size_t)blockIdx.x * tiles_per_block;
+  // owner role of this thread: sample `os` (16 samples per wave), quarter `oq` of the 64 partial columns
+  const int os = wave * 16 + (lane & 15), oq = lane >> 4;
+  int since_flush = 0;
+  float na0 = 0.0f, na1 = 0.0f, na2 = 0.0f;
+  auto load_ops = [&](size_t g) {
+    const size_t sidx = g * 32 + n;
+    na0 = na1 = na2 = 0.0f;
+    if (g < n_tiles && sidx < B) {
+      na0 = tr.obs[(size_t)hf * plane + sidx];
+      na1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
+      na2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
+    }
+  };
+  load_ops(g0);
+  for (uint32_t it = 0; it < tiles_per_block; ++it) {  // every wave of the grid runs the same trip count
+    const size_t g = g0 + it;
+    const float a0 = na0, a1 = na1, a2 = na2;
+    load_ops(g + 1 < g0 + tiles_per_block ? g + 1 : n_tiles);
+    // owner-side operands: all 6 inputs of sample `os` (for u = dy * x~) and its target
+    const size_t osidx = g * 32 + os;
+    const bool ovalid = g < n_tiles && osidx < B;
+    float ox[6] = {0, 0, 0, 0, 0, 1.0f}, tgt = 0.0f;
+    if (ovalid && oq == 0) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) ox[k] = tr.obs[(size_t)k * plane + osidx];
+      tgt = tr.rtg[osidx];
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wb[t][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wb[t][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, wb[t][2], c, 0, 0, 0);
+      acc[t] = c;
+    }
+    float yp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yp[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int hb = __builtin_bit_cast(int, (float)acc[t][r]);
+        hb = hb > 0 ? hb : 0;
+        float h = __builtin_bit_cast(float, hb);
+        acc[t][r] = h;
+        yp[r] = __builtin_fmaf(h, w2v[t], yp[r]);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ysh[(r & 3) + 8 * (r >> 2) + 4 * hf][wave * 32 + n] = yp[r];
+    __syncthreads();
+    // y of sample `os`: this lane sums its quarter of the 64 columns, the four quarters meet through shuffles
+    float part = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part = part + Ysh[os][oq * 16 + c];
+    float q1 = part + __shfl_xor(part, 16, 64);
+    float y = (q1 + __shfl_xor(q1, 32, 64)) + b2;
+    if (oq == 0) {
+      float d = y - tgt;
+      float dy = ovalid ? d * two_over_B : 0.0f;
+      if (ovalid) {
+        loss64 += (double)(d * d);
+        db2_64 += (double)dy;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ush[os][k] = dy * ox[k];
+    }
+    __syncthreads();
+    // backward for this wave's hidden units over all 32 samples
+#pragma unroll
+    for (int rc = 0; rc < 8; ++rc) {
+      float u[2][8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = rc * 2 + q;
+        const float4 *src = reinterpret_cast<const float4 *>(&Ush[(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
+        float4 lo = src[0], hi = src[1];
+        u[q][0] = lo.x; u[q][1] = lo.y; u[q][2] = lo.z; u[q][3] = lo.w;
+        u[q][4] = hi.x; u[q][5] = hi.y; u[q][6] = hi.z; u[q][7] = hi.w;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][rc * 2 + q] * big, 0.0f, 1.0f);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[q][k], m[t][k]);
+        }
+    }
+    if (++since_flush == V2_FLUSH) {
+      since_flush = 0;
+      flush();
+    }
+    // no barrier needed here: the next tile's Ysh writes come after this tile's Ysh reads (barrier 2 above), and
+    // its Ush writes come after its own barrier 1, which every wave reaches only after finishing this backward
+  }
+  flush();
+  // loss / db2 live on the oq == 0 lanes (16 per wave)
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+  double l = oq == 0 ? loss64 : 0.0, bsum = oq == 0 ? db2_64 : 0.0;
+#pragma unroll
+  for (int s = 8; s > 0; s >>= 1) {
+    l = l + xlane(l, s);
+    bsum = bsum + xlane(bsum, s);
+  }
+  __shared__ double tail[2][2];
+  if (lane == 0) {
+    tail[wave][0] = bsum;
+    tail[wave][1] = l;
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p <= P; p += 128) {
+    double s;
+    if (p < (uint32_t)(H * D)) {
+      int j = p / D, k = p % D;
+      s = Acc[j * 7 + k] * (double)W2[j];
+    } else if (p < (uint32_t)(H * D + H)) {
+      int j = p - H * D;
+      s = Acc[j * 7 + 5] * (double)W2[j];
+    } else if (p < (uint32_t)(H * D + 2 * H)) {
+      int j = p - H * D - H;
+      s = Acc[j * 7 + 5] * (double)b1[j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += Acc[j * 7 + k] * (double)W1[j * D + k];
+    } else if (p == (uint32_t)(H * D + 2 * H)) {
+      s = tail[0][0] + tail[1][0];
+    } else {
+      s = tail[0][1] + tail[1][1];
+    }
+    if (p < P) slabA[(size_t)blockIdx.x * P + p] = s;
+    else slabB[(size_t)blockIdx.x * 4 + 0] = s;
+  }
+  if (tid < 3) slabB[(size_t)blockIdx.x * 4 + 1 + tid] = 0.0;
 }
 
 // ================================================================================================
@@ -321,11 +556,12 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     tb2[1] = vb2[1];
   }
   const float b2_0 = b2[0], b2_1 = b2[1];
-  float m[NT][A * 6];
+  // backward accumulators on the matrix pipe (see k_critic_step_mfma): 12 columns = 3 feature groups of 4
+  f32x4 dacc[NT][3];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int k = 0; k < A * 6; ++k) m[t][k] = 0.0f;
+    for (int fg = 0; fg < 3; ++fg) dacc[t][fg] = (f32x4){0, 0, 0, 0};
   const float big = 0x1p126f;
   double sum0 = 0.0, sum1 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
   wave_lds_fence();
@@ -333,15 +569,16 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   auto flush = [&]() {
     if (MODE == PASS_EVAL) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int j = t * 32 + n;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int k = 0; k < A * 6; ++k) {
-        float v = m[t][k] + __shfl_xor(m[t][k], 32, 64);
-        if (hf == 0) acc64[j * 12 + k] += (double)v;
-        m[t][k] = 0.0f;
-      }
-    }
+      for (int fg = 0; fg < 3; ++fg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = dacc[t][fg][i] + __shfl_xor(dacc[t][fg][i], 32, 64);
+          const int j = t * 32 + 4 * (n >> 2) + i, k = 4 * fg + (n & 3);
+          if (hf == 0) acc64[j * 12 + k] += (double)v;
+          dacc[t][fg][i] = 0.0f;
+        }
   };
   // sum over the 32 source lanes of 16 per-lane partials: LDS transpose, result for sample n in both halves
   auto lane_sum = [&](const float(&yp)[16]) {
@@ -400,8 +637,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
           hb = hb > 0 ? hb : 0;
           float h = __builtin_bit_cast(float, hb);
           c[r] = h;
-          float gsel;
-          asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(gsel) : "v"(h), "s"(big));
+          const float gsel = __builtin_amdgcn_fmed3f(h * big, 0.0f, 1.0f);
           float dh = gsel * tc[r];
           // d z_a = sum_j (W2[a][j] dh_j + V2[a][j] h_j)   (J v through the output layer)
           y0[r] = __builtin_fmaf(dh, w2v[t][0], y0[r]);
@@ -494,16 +730,14 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
-        float4 u0 = src[0], u1 = src[1], u2 = src[2];
-        const float u[12] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w, u2.x, u2.y, u2.z, u2.w};
+        const float *urow = &Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0];
+        const float ub0 = urow[lane & 3], ub1 = urow[4 + (lane & 3)], ub2 = urow[8 + (lane & 3)];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const float h = acc[t][r];
-          float gsel;
-          asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(gsel) : "v"(h), "s"(big));
-#pragma unroll
-          for (int k = 0; k < 12; ++k) m[t][k] = __builtin_fmaf(gsel, u[k], m[t][k]);
+          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
+          dacc[t][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub0, dacc[t][0], 0, 0, 0);
+          dacc[t][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub1, dacc[t][1], 0, 0, 0);
+          dacc[t][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub2, dacc[t][2], 0, 0, 0);
         }
       }
       wave_lds_fence();
@@ -575,8 +809,14 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
   ProfScope ps(traj->eng, RL_K_BACKWARD);
   float two_over_B = 2.0f / (float)B_total;
-  hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbV2), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
-                     critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
+  if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile: the faster of the two variants measured
+    hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbV2), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
+                       critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
+  } else {  // variant 2: two waves per tile (A/B measurements)
+    hipLaunchKernelGGL(k_critic_step_pair, dim3(traj->nbPair), dim3(128), 0, traj->eng->stream, traj->d,
+                       critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P,
+                       traj->pair_tiles_per_block);
+  }
   return true;
 }
 
