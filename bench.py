@@ -165,36 +165,44 @@ def main():
     value = total_steps / elapsed
     B_local = n_local * T
 
-    # ---- roofline of the dominant kernel: k_mlp_backward (class "backward") ----------------------------
-    # Algorithmic flops per sample and launch: the backward of the 2-layer MLP is two
-    # forward-equivalents — recompute of layer 1 (2*D*H) + dW1 (2*D*H) + dh (2*A*H) + dW2 (2*A*H):
-    #   critic (A=1): 3072 flop/sample   policy (A=2): 3584 flop/sample.
+    # ---- roofline of the dominant kernel: k_critic_step_mfma (class "critic_fused") -------------------------
+    # One launch = forward + MSE loss + backward of the 5-128-1 critic over every sample of the rank.
+    # Algorithmic flops per sample: 3 x critic forward = 3 x 2 x (5*128 + 128*1) = 4608.
     roofline = None
     phases = None
     if prof is not None:
-        bw_ms, bw_n = prof["backward"]
-        n_critic = args.critic_steps * args.steps
-        n_policy = bw_n - n_critic
-        flop_c = 2 * (2 * 5 * H) + 2 * (2 * 1 * H)
-        flop_p = 2 * (2 * 5 * H) + 2 * (2 * 2 * H)
-        alg_flops = (n_critic * flop_c + n_policy * flop_p) * B_local
-        achieved = alg_flops / (bw_ms * 1e-3) / 1e12 if bw_ms > 0 else 0.0
+        flop_c = 3 * 2 * (5 * H + H * 1)
+        cf_ms, cf_n = prof["critic_fused"]
+        if cf_n == 0:  # v1 kernels (hidden != 128): the separate forward + backward pair
+            cf_ms = prof["critic_fwd"][0] + prof["backward"][0]
+            cf_n = prof["critic_fwd"][1]
+        achieved = flop_c * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.envs // world == 65536 and T == 128:
+            traffic = json.load(open(tpath)).get("k_critic_step_mfma", {}).get("hbm_bytes_per_launch")
         roofline = {
-            "kernel": "k_mlp_backward", "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS, "traffic": None,
-            "launches": int(bw_n), "avg_launch_us": 1e3 * bw_ms / max(bw_n, 1),
-            "algorithmic_flop_per_sample": {"critic": flop_c, "policy": flop_p},
-            "note": "f32 vector/matrix peak 157.3 TFLOP/s; per-rank figures",
+            "kernel": "k_critic_step_mfma", "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic,
+            "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1),
+            "algorithmic_flop_per_sample": flop_c, "samples_per_launch": B_local,
+            "note": "f32: 157.3 TFLOP/s is both the f32 MFMA and the (packed) f32 vector peak; per-rank figures; "
+                    "traffic (bytes/launch) from rocprofv3 PMC passes, see profiles/README.md",
         }
         tot = sum(v[0] for v in prof.values())
         phases = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
                       "share": (v[0] / tot if tot > 0 else 0.0)} for k, v in prof.items() if v[1]}
-        # fused rollout: 26 B/env-step trajectory record
+        pf_ms, pf_n = prof["policy_fused"]
+        if pf_n:
+            # gradient / Fisher-vector launches do forward + 2x backward (+ tangent forward), evaluations forward only
+            phases["policy_fused"]["avg_launch_us"] = 1e3 * pf_ms / pf_n
+        # fused rollout: 26 B/env-step trajectory record; policy forward 1792 flop/env-step
         ro_ms, ro_n = prof["rollout"]
         if ro_n:
             gbs = 26.0 * B_local * ro_n / (ro_ms * 1e-3) / 1e9
             phases["rollout"]["hbm_GBps_at_26B_per_step"] = gbs
             phases["rollout"]["hbm_frac"] = gbs / HBM_PEAK_GBS
+            phases["rollout"]["policy_forward_TFLOPs"] = 1792.0 * B_local * ro_n / (ro_ms * 1e-3) / 1e12
 
     # ---- standalone env-step kernel: 100 B/env-step, HBM roofline --------------------------
     env_step = None

@@ -29,7 +29,7 @@ LIMIT_NONE, LIMIT_LATENT, LIMIT_VISIBLE = 0, 1, 2
 (TRAJ_OBS, TRAJ_ACTION, TRAJ_REWARD, TRAJ_FLAG, TRAJ_TERM_OBS, TRAJ_VALUES, TRAJ_ADVANTAGES,
  TRAJ_RETURNS) = range(8)
 KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backward", "reduce", "small",
-                  "critic_fwd", "allreduce"]
+                  "critic_fwd", "allreduce", "critic_fused", "policy_fused"]
 
 # every symbol include/relearn_hip.h declares (checked by tests/test_abi_symbols.py against the header)
 ABI_SYMBOLS = [
@@ -137,12 +137,9 @@ def _register(obj):
 @atexit.register
 def _close_all():
     objs = list(_live)
-    for o in objs:
-        if not isinstance(o, Engine):
-            o.close()
-    for o in objs:
-        if isinstance(o, Engine):
-            o.close()
+    order = {"Adam": 0, "Trajectory": 1, "CartPoleEnv": 2, "Mlp": 3, "Engine": 4}
+    for o in sorted(objs, key=lambda o: order.get(type(o).__name__, 2)):
+        o.close()
 
 
 class _Handle:

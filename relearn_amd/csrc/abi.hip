@@ -969,6 +969,7 @@ int32_t rl_adam_create(rl_mlp *module, const rl_adam_config *cfg, rl_adam **out)
     rl_engine *e = module->eng;
     RL_HIP_CHECK(hipSetDevice(e->device));
     std::unique_ptr<rl_adam> o(new rl_adam());
+    o->eng = e;
     o->mod = module;
     o->cfg = *cfg;
     o->d_m = dalloc<float>(module->P);
@@ -985,12 +986,12 @@ int32_t rl_adam_create(rl_mlp *module, const rl_adam_config *cfg, rl_adam **out)
 
 int32_t rl_adam_destroy(rl_adam *o) {
   if (!o) return RL_OK;
-  (void)hipSetDevice(o->mod->eng->device);
-  (void)hipStreamSynchronize(o->mod->eng->stream);
+  (void)hipSetDevice(o->eng->device);
+  (void)hipStreamSynchronize(o->eng->stream);
   dfree(o->d_m);
   dfree(o->d_v);
   dfree(o->d_step);
-  rl_engine *eng = o->mod->eng;
+  rl_engine *eng = o->eng;
   delete o;
   engine_release_child(eng);
   return RL_OK;

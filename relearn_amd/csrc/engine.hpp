@@ -124,6 +124,7 @@ struct rl_mlp {
 };
 
 struct rl_adam {
+  rl_engine *eng;  // kept separately: the module may be destroyed before its optimizer
   rl_mlp *mod;
   rl_adam_config cfg;
   float *d_m = nullptr, *d_v = nullptr;

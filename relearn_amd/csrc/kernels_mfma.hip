@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
 // ---------------------------------------------------------------- launcher
 bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
-  ProfScope ps(traj->eng, RL_K_BACKWARD);
+  ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
   if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile: the faster of the two variants measured
     hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbV2), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
@@ -824,7 +824,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip) {
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
-  ProfScope ps(traj->eng, mode == PASS_EVAL ? RL_K_POLICY_PASS : RL_K_BACKWARD);
+  ProfScope ps(traj->eng, RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
   hipStream_t s = traj->eng->stream;
