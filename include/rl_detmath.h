@@ -14,7 +14,7 @@
  * differ in the last ulp, CartPole is chaotic, and a categorical sample flips when p moves by
  * one ulp across the uniform draw — so "bit-exact action indices" (BASELINE.json north_star)
  * is only reachable with a shared definition.  Accuracy vs glibc is pinned by
- * tests/test_detmath.py (sincos <= 1 ulp on the CartPole range, expf/logf <= 2 ulp).
+ * tests/test_detmath_prng.py (sincos <= 1 ulp on the CartPole range, expf/logf <= 2 ulp).
  *
  * Algorithms: Cody-Waite 3-term reduction by pi/2 with fma + the classic fdlibm kernel
  * polynomials (public domain, Sun Microsystems 1993) for f64 sin/cos; fdlibm-style expf/logf.
