@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -120,7 +121,7 @@ void rccl_check(int rc, const char *what) {
 }  // namespace
 
 void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
-  if (e->n_ranks <= 1 || !e->comm) return;
+  if (!e->comm) return;
   ProfScope ps(e, RL_K_ALLREDUCE);
   // ncclFloat32 = 7, ncclSum = 0
   rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 7, 0, e->comm, e->stream), "ncclAllReduce");
@@ -292,7 +293,9 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
     RL_REQUIRE(!e->comm, "communicator already initialised");
     e->rank = rank;
     e->n_ranks = n_ranks;
-    if (n_ranks == 1) return;
+    // a single rank needs no communicator; RELEARN_FORCE_RCCL=1 creates a 1-rank one anyway so that the whole
+    // RCCL call path (dlopen, ncclCommInitRank, ncclAllReduce on the engine stream) can be exercised on one GPU
+    if (n_ranks == 1 && !std::getenv("RELEARN_FORCE_RCCL")) return;
     rccl_load();
     RL_HIP_CHECK(hipSetDevice(e->device));
     UniqueId id;

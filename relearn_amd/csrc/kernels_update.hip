@@ -290,14 +290,29 @@ __global__ void __launch_bounds__(1024) k_reduce(const double *__restrict__ slab
   __shared__ double part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 64 + lane;
-  double acc = 0.0;
+  // 8 independent partial sums per lane keep 8 loads in flight (the loop is latency-bound otherwise); the
+  // summation order is fixed, so the result is bitwise reproducible
+  double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (p < P) {
-    if (useA)
-      for (uint32_t r = w; r < nbA; r += 16) acc = acc + slabA[(size_t)r * P + p];
+    if (useA) {
+      uint32_t r = w;
+      for (; r + 7 * 16 < nbA; r += 8 * 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabA[(size_t)(r + u * 16) * P + p];
+      }
+      for (; r < nbA; r += 16) a8[0] = a8[0] + slabA[(size_t)r * P + p];
+    }
   } else if (p < P + 4) {
-    if (useB)
-      for (uint32_t r = w; r < nbB; r += 16) acc = acc + slabB[(size_t)r * 4 + (p - P)];
+    if (useB) {
+      uint32_t r = w;
+      for (; r + 7 * 16 < nbB; r += 8 * 16) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabB[(size_t)(r + u * 16) * 4 + (p - P)];
+      }
+      for (; r < nbB; r += 16) a8[0] = a8[0] + slabB[(size_t)r * 4 + (p - P)];
+    }
   }
+  double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   part[w][lane] = acc;
   __syncthreads();
   if (w == 0 && p < P + 4) {
@@ -312,7 +327,7 @@ __global__ void __launch_bounds__(1024) k_reduce(const double *__restrict__ slab
 }
 
 // ---------------------------------------------------------------- single-workgroup bookkeeping kernels
-constexpr int SB = 1024;
+constexpr int SB = 256;  // P <= 1026: four entries per thread, 8 barrier rounds per block-wide sum
 
 // after the gradient reduction: x = 0; r = p = g; rr = g.g   (solve_conjugate_gradient prologue,
 // conjugate_gradient.rs:377-384) + initial loss / entropy scalars

@@ -451,3 +451,36 @@ def test_error_paths(engine):
                   engine.h)
     assert e.value.code == ra.ERR_INVALID_ARGUMENT
     assert b"unknown trajectory field" in ra.lib().rl_last_error(engine.h)
+
+
+def test_rccl_call_path_single_rank():
+    """dlopen of librccl, ncclGetUniqueId, ncclCommInitRank and ncclAllReduce(sum, f32) on the engine's own
+    stream, exercised with a 1-rank communicator (RELEARN_FORCE_RCCL=1): results must equal the no-communicator
+    run bit for bit (an all-reduce over one rank is the identity)."""
+    import os
+    uid = ra.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    results = []
+    for force in (False, True):
+        if force:
+            os.environ["RELEARN_FORCE_RCCL"] = "1"
+        try:
+            eng = ra.Engine(0)
+            if force:
+                eng.comm_init(0, 1, ra.comm_unique_id())
+            policy, critic, traj, x, a, adv, rtg = _with_advantages(eng, 256, 32)
+            st = ra.trpo_update(policy, traj)
+            opt = ra.Adam(critic)
+            cst = ra.critic_update(critic, opt, traj, 5)
+            results.append((policy.get_params(), critic.get_params(), st.step_size, cst.loss_last))
+            if force:
+                prof_on = eng.profile_enable(True)
+                ra.critic_update(critic, opt, traj, 2)
+                assert eng.profile_read()["allreduce"][1] == 2  # the collective really ran
+            for o in (opt, traj, critic, policy):
+                o.close()
+            eng.close()
+        finally:
+            os.environ.pop("RELEARN_FORCE_RCCL", None)
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    assert results[0][2] == results[1][2] and results[0][3] == results[1][3]
