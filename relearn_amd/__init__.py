@@ -15,7 +15,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librelearn_hip.so")
+LIB_PATH = os.environ.get("RELEARN_LIB", os.path.join(_HERE, "librelearn_hip.so"))  # override: ablation builds
 CSRC = os.path.join(_HERE, "csrc")
 
 # status codes (include/relearn_hip.h)

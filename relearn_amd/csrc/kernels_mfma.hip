@@ -22,6 +22,9 @@
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
+#ifndef RL_ABLATE
+#define RL_ABLATE 0  // timing-only ablation builds (scripts/ablate.sh); 0 in every shipped build
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -143,9 +146,14 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if (RL_ABLATE & 4)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = o.a0 * wb[t][0] + (float)r;
+#else
       c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0, wb[t][0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1, wb[t][1], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a2, wb[t][2], c, 0, 0, 0);
+#endif
       acc[t] = c;
     }
   };
@@ -164,7 +172,11 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         hb = hb > 0 ? hb : 0;
         float h = __builtin_bit_cast(float, hb);
         acc[t][r] = h;
+#if !(RL_ABLATE & 2)
         yp[r] = __builtin_fmaf(h, w2v[t], yp[r]);
+#else
+        if (t == 0) yp[r] = h;
+#endif
       }
     // transpose through LDS: row = sample, column = source lane
 #pragma unroll
@@ -215,8 +227,12 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
           const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
+#if !(RL_ABLATE & 1)
 #pragma unroll
           for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[q][k], m[t][k]);
+#else
+          m[t][0] = m[t][0] + gsel * u[q][0];
+#endif
         }
       }
     }
@@ -809,7 +825,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
-  if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile: the faster of the two variants measured
+  if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile
     hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbV2), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
                        critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
   } else {  // variant 2: two waves per tile (A/B measurements)

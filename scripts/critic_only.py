@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import relearn_amd as ra
 n, T, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 128, int(sys.argv[2]) if len(sys.argv) > 2 else 10
 eng = ra.Engine(0)
+if len(sys.argv) > 3: eng.set_kernel_variant(int(sys.argv[3]))
 env = ra.CartPoleEnv(eng, n)
 pol = ra.Mlp(eng, 5, 128, 2); pol.init(2)
 cri = ra.Mlp(eng, 5, 128, 1); cri.init(3)
