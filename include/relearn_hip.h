@@ -259,6 +259,18 @@ int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t o
                          float *losses_out);
 int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * CPU-only plumbing configuration (BASELINE.json configs[0]): examples/chain-tabular-q.rs — Chain
+ * (src/envs/chain.rs:20-106) + epsilon-greedy tabular Q-learning (src/agents/tabular.rs:88-233) driven by
+ * train_parallel (src/simulation/train.rs:68-186) with `n_threads` worker threads.  Runs on the host, like the
+ * reference; q_values_out / counts_out are [5][2] row-major. */
+int32_t rl_chain_tabular_q_train(uint64_t seed, uint64_t n_threads, uint64_t n_periods, uint64_t min_worker_steps,
+                                 double exploration_rate, double *q_values_out, uint64_t *counts_out,
+                                 uint64_t *total_steps_out);
+/* evaluation run of examples/chain-tabular-q.rs:47-50: greedy actor, SimSeed::Root(seed), n_steps steps */
+int32_t rl_chain_tabular_q_eval(const double *q_values, uint64_t seed, uint64_t n_steps, uint8_t *actions_out,
+                                double *total_reward_out);
+
 #ifdef __cplusplus
 }
 #endif

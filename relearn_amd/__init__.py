@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient",
+    "rl_chain_tabular_q_train", "rl_chain_tabular_q_eval",
 ]
 
 
@@ -449,3 +450,24 @@ def critic_gradient(critic, traj):
     loss = C.c_float()
     _check(lib().rl_critic_gradient(critic.h, traj.h, g.ctypes.data_as(C.c_void_p), C.byref(loss)), traj.eng.h)
     return g, loss.value
+
+
+def chain_tabular_q_train(seed=0, n_threads=4, n_periods=10, min_worker_steps=10000, exploration_rate=0.2):
+    """examples/chain-tabular-q.rs on the host (CPU-only configuration, like the reference)."""
+    q = np.zeros((5, 2), dtype=np.float64)
+    counts = np.zeros((5, 2), dtype=np.uint64)
+    total = C.c_uint64()
+    _check(lib().rl_chain_tabular_q_train(C.c_uint64(seed), C.c_uint64(n_threads), C.c_uint64(n_periods),
+                                          C.c_uint64(min_worker_steps), C.c_double(exploration_rate),
+                                          q.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                          C.byref(total)))
+    return q, counts, total.value
+
+
+def chain_tabular_q_eval(q, seed=0, n_steps=10000):
+    q, qp = _ptr(q, np.float64)
+    actions = np.zeros(n_steps, dtype=np.uint8)
+    total = C.c_double()
+    _check(lib().rl_chain_tabular_q_eval(qp, C.c_uint64(seed), C.c_uint64(n_steps),
+                                         actions.ctypes.data_as(C.c_void_p), C.byref(total)))
+    return actions, total.value
