@@ -73,6 +73,7 @@ typedef struct rl_env rl_env;
 typedef struct rl_mlp rl_mlp;
 typedef struct rl_traj rl_traj;
 typedef struct rl_adam rl_adam;
+typedef struct rl_dqn rl_dqn;
 
 /* ---------------------------------------------------------------------------------------------
  * Engine (one per GPU).  Stands in for `Device::cuda_if_available()` + the libtorch runtime the
@@ -258,6 +259,81 @@ typedef struct {
 int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
                          float *losses_out);
 int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * DQN with the replay buffer resident in HBM (BASELINE.json configs[2]).
+ *   DqnConfig / DqnAgent / DqnActor     src/torch/agents/dqn.rs:26-72,110-380
+ *   ExplorationRateSchedule, DataCollectionSchedule   src/torch/agents/schedules.rs:7-69
+ *   ReplayBuffer                        src/agents/buffers/replay.rs:11-127
+ * Every lane is one ReplayBuffer of `buffer_capacity` steps (the reference has one per worker thread,
+ * dqn.rs:129-130): step data lives in a per-lane ring `[capacity][n_lanes]`, the eviction rule "drop the whole
+ * oldest episode when full" runs inside the collecting kernel.  Minibatch episodes are drawn with the agent's own
+ * Prng exactly like dqn.rs:280-291 (cycle over the buffers, `Uniform::new(0, num_episodes)`, stop after the
+ * episode that reaches `minibatch_steps`) — by a device kernel that evaluates the draws in parallel and keeps the
+ * sequential semantics.  Targets (dqn.rs:300-309), the MSE loss on the taken action's value (dqn.rs:316-326) and
+ * Adam (n_backward_steps, src/torch/agents/mod.rs:35-72) follow. */
+enum { RL_DQN_TARGET_REWARD_TO_GO = 0, RL_DQN_TARGET_ONE_STEP_TD = 1 }; /* StepValueTarget, critics/mod.rs:203-214 */
+enum { RL_SCHEDULE_CONSTANT = 0, RL_SCHEDULE_LINEAR_ANNEALED = 1 };     /* schedules.rs:7-15 */
+enum { RL_COLLECT_CONSTANT = 0, RL_COLLECT_FIRST_REST = 1 };            /* schedules.rs:50-56 */
+typedef struct {
+  int32_t target;
+  int32_t exploration_kind;
+  double exploration_start, exploration_end; /* Constant(rate): rate = exploration_start */
+  uint64_t exploration_period;
+  uint64_t minibatch_steps;      /* dqn.rs:63 */
+  uint64_t opt_steps_per_update; /* dqn.rs:64 */
+  uint64_t buffer_capacity;      /* steps PER LANE (dqn.rs:129-130 "capacity of each individual buffer") */
+  uint64_t episode_capacity;     /* episode-end slots per lane; 0 = buffer_capacity (never binds, like the deque) */
+  int32_t update_kind;
+  uint64_t update_first, update_rest; /* Constant(value): value = update_first */
+  float discount_factor;         /* env.discount_factor() as f32 (dqn.rs:179) */
+  uint32_t agent_key[8];         /* the agent's Prng seed words: Prng::from_rng(rng) in build_agent (dqn.rs:94) */
+} rl_dqn_config;
+/* DqnConfig::default (dqn.rs:57-72) with buffer_capacity left at 0 (the caller divides its step budget over the
+ * lanes) and discount 0.99 (CartPole, src/envs/cartpole.rs:203-213) */
+int32_t rl_dqn_config_default(rl_dqn_config *cfg);
+/* `qnet` maps obs_dim -> n_actions; `opt` must have been created for `qnet` */
+int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_config *cfg, rl_dqn **out);
+int32_t rl_dqn_destroy(rl_dqn *dqn);
+/* ExplorationRateSchedule::exploration_rate(global_steps, mode) (schedules.rs:35-45); training = 0 -> 0.0 */
+int32_t rl_dqn_exploration_rate(const rl_dqn *dqn, int32_t training, double *rate_out);
+/* DqnAgent::min_update_size (dqn.rs:207-209): the step bound of the next collection, summed over all lanes */
+int32_t rl_dqn_min_update_size(const rl_dqn *dqn, uint64_t *min_steps_out, uint64_t *slack_steps_out);
+typedef struct {
+  double exploration_rate;
+  uint64_t steps;          /* steps written (all lanes of this rank) */
+  uint64_t episodes_ended; /* Terminate + Interrupt flags among them (incl. the horizon cut) */
+} rl_dqn_collect_stats;
+/* `horizon` env-actor steps on every lane with the epsilon-greedy actor (DqnActor::act, dqn.rs:360-379), written
+ * to the replay rings.  RL_ERR_BUFFER_FULL when an episode outgrows a lane's capacity (replay.rs:93-94). */
+int32_t rl_dqn_collect(rl_dqn *dqn, uint64_t horizon, rl_dqn_collect_stats *stats /* may be NULL */);
+typedef struct {
+  double loss_first, loss_last;
+  uint64_t opt_steps;
+  uint64_t global_steps;         /* after the update (dqn.rs:276) */
+  uint64_t last_minibatch_steps, last_minibatch_episodes;
+} rl_dqn_update_stats;
+/* DqnAgent::batch_update (dqn.rs:263-337): opt_steps_per_update x {sample minibatch, targets, MSE, Adam} */
+int32_t rl_dqn_update(rl_dqn *dqn, rl_dqn_update_stats *stats, float *losses_out /* may be NULL */);
+
+/* Inspection of the replay store and of single minibatches (what the reference's tests reach through
+ * ReplayBuffer::{episodes, num_steps, total_step_count}, replay.rs:52-86). */
+enum { RL_REPLAY_HEAD = 0, RL_REPLAY_COUNT = 1, RL_REPLAY_EP_HEAD = 2, RL_REPLAY_EP_COUNT = 3, RL_REPLAY_TOTAL = 4,
+       RL_REPLAY_EP_END = 5 /* u32 [E][n] */, RL_REPLAY_OBS = 6 /* f32 [D][C][n] */, RL_REPLAY_NEXT_OBS = 7,
+       RL_REPLAY_ACTION = 8 /* u8 [C][n] */, RL_REPLAY_REWARD = 9 /* f32 [C][n] */, RL_REPLAY_FLAG = 10 /* u8 */,
+       RL_REPLAY_ACTOR_POS = 11 /* u64 [n] */, RL_REPLAY_LAST_FLAGS = 12 /* u8 [T][n] of the last collection */ };
+int32_t rl_dqn_replay_field_bytes(const rl_dqn *dqn, int32_t field, uint64_t *bytes);
+int32_t rl_dqn_replay_read(rl_dqn *dqn, int32_t field, void *host, uint64_t bytes);
+/* draw one minibatch (advances the agent Prng) and build its observation / action / target arrays;
+ * `sequential` != 0 forces the one-thread sampler that the parallel one falls back to when a draw is rejected */
+int32_t rl_dqn_minibatch_sample(rl_dqn *dqn, int32_t sequential, uint64_t *n_episodes_out, uint64_t *n_steps_out);
+enum { RL_MB_EP_LANE = 0, RL_MB_EP_START = 1, RL_MB_EP_LEN = 2, RL_MB_EP_OFFSET = 3 /* u32 [n_episodes] */,
+       RL_MB_OBS = 4 /* f32 [D][n_steps] */, RL_MB_ACTION = 5 /* u8 [n_steps] */, RL_MB_TARGET = 6 /* f32 */ };
+int32_t rl_dqn_minibatch_read(rl_dqn *dqn, int32_t field, void *host, uint64_t bytes);
+/* gradient of the MSE loss on the current minibatch (no parameter change) */
+int32_t rl_dqn_minibatch_gradient(rl_dqn *dqn, float *grad_out, float *loss_out);
+/* word position of the agent Prng (stream 0 of agent_key) */
+int32_t rl_dqn_agent_rng_pos(rl_dqn *dqn, uint64_t *pos_out);
 
 /* ---------------------------------------------------------------------------------------------
  * CPU-only plumbing configuration (BASELINE.json configs[0]): examples/chain-tabular-q.rs — Chain

@@ -302,6 +302,37 @@ def _declare(L):
     L.oracle_lanes_to_vecbuffer.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_uint8),
                                             P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int, P(C.c_uint64)]
     L.oracle_lanes_to_vecbuffer.restype = P(VecBuffer)
+    L.oracle_prng_word_pos.argtypes = [P(Prng)]
+    L.oracle_prng_word_pos.restype = C.c_uint64
+    L.oracle_prng_from_seed.argtypes = [P(Prng), P(C.c_uint32)]
+    L.oracle_dqn_store_new.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+    L.oracle_dqn_store_new.restype = C.c_void_p
+    L.oracle_dqn_store_free.argtypes = [C.c_void_p]
+    L.oracle_dqn_store_actor_pos.argtypes = [C.c_void_p, C.c_uint64]
+    L.oracle_dqn_store_actor_pos.restype = C.c_uint64
+    L.oracle_dqn_store_lane_info.argtypes = [C.c_void_p, C.c_uint64, P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+    L.oracle_dqn_store_lane_dump.argtypes = [C.c_void_p, C.c_uint64, P(C.c_int32), P(C.c_uint64)]
+    L.oracle_dqn_store_step.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_uint8),
+                                        P(C.c_float), P(C.c_uint8), P(C.c_float)]
+    L.oracle_lanes_rollout_dqn.argtypes = [P(Lanes), C.c_void_p, MlpShape, P(C.c_float), C.c_uint64, C.c_double,
+                                           P(C.c_uint8)]
+    L.oracle_lanes_rollout_dqn.restype = C.c_int
+    L.oracle_dqn_sample.argtypes = [C.c_void_p, P(Prng), C.c_uint64, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32),
+                                    C.c_uint64, P(C.c_uint64)]
+    L.oracle_dqn_sample.restype = C.c_int64
+    L.oracle_dqn_minibatch.argtypes = [C.c_void_p, C.c_uint64, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32), MlpShape,
+                                       P(C.c_float), C.c_float, C.c_int, P(C.c_float), P(C.c_int64), P(C.c_float)]
+    L.oracle_dqn_grad_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), P(C.c_float), C.c_uint64,
+                                      P(C.c_float), P(C.c_float)]
+    L.oracle_dqn_grad_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), P(C.c_double),
+                                      C.c_uint64, P(C.c_double), P(C.c_double)]
+    L.oracle_dqn_update_f32.argtypes = [C.c_void_p, P(Prng), MlpShape, P(C.c_float), P(AdamState), P(AdamCfg),
+                                        C.c_uint64, C.c_uint64, C.c_float, C.c_int, P(C.c_float)]
+    L.oracle_dqn_update_f32.restype = C.c_int
+    L.oracle_exploration_rate.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int]
+    L.oracle_exploration_rate.restype = C.c_double
+    L.oracle_collection_update_size.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.oracle_collection_update_size.restype = Bound
     L.oracle_cartpole_trpo_period.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
                                               C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_float), P(AdamState),
                                               C.c_uint64, P(PeriodStats)]
@@ -430,3 +461,116 @@ def flat_samples(traj):
     x = np.ascontiguousarray(obs[:, :T, :].reshape(D, T * n).T, dtype=np.float32)
     a = np.ascontiguousarray(traj["action"].reshape(T * n).astype(np.int64))
     return x, a
+
+
+def u32p(a):
+    assert a.dtype == np.uint32 and a.flags.c_contiguous
+    return _p(a, C.c_uint32)
+
+
+class DqnSim:
+    """The DQN path restated on the lane model: per-lane ReplayBuffers + agent Prng + Adam (oracle/dqn.c)."""
+
+    def __init__(self, sim, qshape, qparams, capacity, agent_key, minibatch_steps, gamma=0.99, one_step_td=False,
+                 adam_cfg=None):
+        L = lib()
+        self.sim = sim
+        self.qshape = qshape
+        self.qparams = np.ascontiguousarray(qparams, dtype=np.float32).copy()
+        self.capacity = capacity
+        self.store = L.oracle_dqn_store_new(sim.n, capacity, sim.D)
+        self.agent_rng = Prng()
+        key = (C.c_uint32 * 8)(*[int(k) for k in agent_key])
+        L.oracle_prng_from_seed(C.byref(self.agent_rng), key)
+        self.minibatch_steps = minibatch_steps
+        self.gamma = gamma
+        self.td = 1 if one_step_td else 0
+        self.acfg = adam_cfg
+        if self.acfg is None:
+            self.acfg = AdamCfg()
+            L.oracle_adam_cfg_default(C.byref(self.acfg))
+        self.opt = L.oracle_adam_new(len(self.qparams))
+
+    def __del__(self):
+        if getattr(self, "store", None):
+            lib().oracle_dqn_store_free(self.store)
+            lib().oracle_adam_free(self.opt)
+            self.store = None
+
+    def collect(self, T, eps):
+        flags = np.zeros((T, self.sim.n), dtype=np.uint8)
+        full = lib().oracle_lanes_rollout_dqn(self.sim.ptr, self.store, self.qshape, f32p(self.qparams), T, eps,
+                                              u8p(flags))
+        return flags, bool(full)
+
+    def lane_info(self, lane):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().oracle_dqn_store_lane_info(self.store, lane, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value  # num_steps, num_episodes, total_step_count
+
+    def lane_dump(self, lane):
+        ns, ne, _ = self.lane_info(lane)
+        tags = np.zeros(max(ns, 1), dtype=np.int32)
+        lens = np.zeros(max(ne, 1), dtype=np.uint64)
+        lib().oracle_dqn_store_lane_dump(self.store, lane, i32p(tags), u64p(lens))
+        return tags[:ns], lens[:ne]
+
+    def actor_pos(self):
+        return np.array([lib().oracle_dqn_store_actor_pos(self.store, i) for i in range(self.sim.n)],
+                        dtype=np.uint64)
+
+    def step_data(self, lane, abs_index):
+        D = self.sim.D
+        obs = np.zeros(D, dtype=np.float32)
+        nobs = np.zeros(D, dtype=np.float32)
+        a, nx, r = C.c_uint8(), C.c_uint8(), C.c_float()
+        lib().oracle_dqn_store_step(self.store, lane, abs_index, f32p(obs), C.byref(a), C.byref(r), C.byref(nx),
+                                    f32p(nobs))
+        return obs, a.value, r.value, nx.value, nobs
+
+    def agent_pos(self):
+        return lib().oracle_prng_word_pos(C.byref(self.agent_rng))
+
+    def sample(self):
+        cap = self.minibatch_steps
+        lanes = np.zeros(cap, dtype=np.uint32)
+        starts = np.zeros(cap, dtype=np.uint32)
+        lens = np.zeros(cap, dtype=np.uint32)
+        ns = C.c_uint64()
+        ne = lib().oracle_dqn_sample(self.store, C.byref(self.agent_rng), self.minibatch_steps, u32p(lanes),
+                                     u32p(starts), u32p(lens), cap, C.byref(ns))
+        assert ne >= 0, "a lane holds no complete episode"
+        return lanes[:ne].copy(), starts[:ne].copy(), lens[:ne].copy(), ns.value
+
+    def minibatch(self, lanes, starts, lens):
+        n = int(lens.sum())
+        obs = np.zeros((n, self.sim.D), dtype=np.float32)
+        actions = np.zeros(n, dtype=np.int64)
+        targets = np.zeros(n, dtype=np.float32)
+        lib().oracle_dqn_minibatch(self.store, len(lanes), u32p(lanes), u32p(starts), u32p(lens), self.qshape,
+                                   f32p(self.qparams), self.gamma, self.td, f32p(obs), i64p(actions), f32p(targets))
+        return obs, actions, targets
+
+    def grad(self, obs, actions, targets, f64=False):
+        L = lib()
+        if f64:
+            g = np.zeros(len(self.qparams), dtype=np.float64)
+            loss = C.c_double()
+            L.oracle_dqn_grad_f64(self.qshape, f64p(self.qparams.astype(np.float64)),
+                                  f64p(np.ascontiguousarray(obs, dtype=np.float64)), i64p(actions),
+                                  f64p(np.ascontiguousarray(targets, dtype=np.float64)), len(actions), f64p(g),
+                                  C.byref(loss))
+        else:
+            g = np.zeros(len(self.qparams), dtype=np.float32)
+            loss = C.c_float()
+            L.oracle_dqn_grad_f32(self.qshape, f32p(self.qparams), f32p(obs), i64p(actions), f32p(targets),
+                                  len(actions), f32p(g), C.byref(loss))
+        return g, loss.value
+
+    def update(self, opt_steps):
+        losses = np.zeros(max(opt_steps, 1), dtype=np.float32)
+        rc = lib().oracle_dqn_update_f32(self.store, C.byref(self.agent_rng), self.qshape, f32p(self.qparams),
+                                         self.opt, C.byref(self.acfg), self.minibatch_steps, opt_steps, self.gamma,
+                                         self.td, f32p(losses))
+        assert rc == 0
+        return losses[:opt_steps]

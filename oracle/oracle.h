@@ -41,6 +41,7 @@ void oracle_prng_from_seed(oracle_prng *r, const uint32_t key[8]);
 void oracle_prng_from_rng(oracle_prng *out, oracle_prng *src);
 void oracle_prng_set_stream(oracle_prng *r, uint64_t stream);
 void oracle_prng_set_word_pos(oracle_prng *r, uint64_t word_pos);
+uint64_t oracle_prng_word_pos(const oracle_prng *r);
 uint32_t oracle_prng_next_u32(oracle_prng *r);
 uint64_t oracle_prng_next_u64(oracle_prng *r);
 float oracle_prng_gen_f32(oracle_prng *r);
@@ -306,6 +307,35 @@ void oracle_lanes_gae(oracle_mlp_shape cs, const float *critic_params, uint64_t 
 oracle_vecbuffer *oracle_lanes_to_vecbuffer(uint64_t n, uint64_t T, uint32_t D, const float *obs,
                                             const uint8_t *action, const float *reward, const uint8_t *flag,
                                             const float *term_obs, int keep_last, uint64_t *lane_t_index_out);
+
+/* ---------------------------------------------------------------- DQN (src/torch/agents/dqn.rs), dqn.c */
+typedef struct oracle_dqn_store oracle_dqn_store; /* one ReplayBuffer (replay.rs:11-27) per lane */
+oracle_dqn_store *oracle_dqn_store_new(uint64_t n_lanes, uint64_t capacity, uint32_t obs_dim);
+void oracle_dqn_store_free(oracle_dqn_store *s);
+uint64_t oracle_dqn_store_actor_pos(const oracle_dqn_store *s, uint64_t lane);
+void oracle_dqn_store_lane_info(const oracle_dqn_store *s, uint64_t lane, uint64_t *num_steps, uint64_t *num_episodes,
+                                uint64_t *total_step_count);
+void oracle_dqn_store_lane_dump(const oracle_dqn_store *s, uint64_t lane, int32_t *tags, uint64_t *episode_lens);
+void oracle_dqn_store_step(const oracle_dqn_store *s, uint64_t lane, uint64_t abs_index, float *obs, uint8_t *action,
+                           float *reward, uint8_t *next, float *next_obs);
+int oracle_lanes_rollout_dqn(oracle_lanes *l, oracle_dqn_store *st, oracle_mlp_shape qs, const float *qparams,
+                             uint64_t T, double eps, uint8_t *flags_out);
+int64_t oracle_dqn_sample(const oracle_dqn_store *st, oracle_prng *agent_rng, uint64_t minibatch_steps,
+                          uint32_t *lane_out, uint32_t *start_out, uint32_t *len_out, uint64_t cap,
+                          uint64_t *n_steps_out);
+void oracle_dqn_minibatch(const oracle_dqn_store *st, uint64_t n_eps, const uint32_t *lanes, const uint32_t *starts,
+                          const uint32_t *lens, oracle_mlp_shape qs, const float *qparams, float gamma,
+                          int one_step_td, float *obs_out, int64_t *actions_out, float *targets_out);
+void oracle_dqn_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const int64_t *actions,
+                         const float *targets, uint64_t n, float *grad_out, float *loss_out);
+void oracle_dqn_grad_f64(oracle_mlp_shape s, const double *params, const double *obs, const int64_t *actions,
+                         const double *targets, uint64_t n, double *grad_out, double *loss_out);
+int oracle_dqn_update_f32(const oracle_dqn_store *st, oracle_prng *agent_rng, oracle_mlp_shape qs, float *qparams,
+                          oracle_adam_state *opt, const oracle_adam_cfg *acfg, uint64_t minibatch_steps,
+                          uint64_t opt_steps, float gamma, int one_step_td, float *losses_out);
+double oracle_exploration_rate(int kind, double start, double end, uint64_t period, uint64_t global_steps,
+                               int training);
+oracle_bound oracle_collection_update_size(int kind, uint64_t first, uint64_t rest, uint64_t global_steps);
 
 /* ---------------------------------------------------------------- CPU baseline (simulation/train.rs:68-186) */
 typedef struct {

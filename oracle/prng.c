@@ -86,6 +86,9 @@ void oracle_prng_set_word_pos(oracle_prng *r, uint64_t word_pos) {
   r->index = (uint32_t)(word_pos % 16);
 }
 
+/* get_word_pos: flat index of the next unread word of the stream */
+uint64_t oracle_prng_word_pos(const oracle_prng *r) { return r->counter * 16 - 64 + (uint64_t)r->index; }
+
 float oracle_prng_gen_f32(oracle_prng *r) { return rl_u32_to_unit_f32(oracle_prng_next_u32(r)); }
 double oracle_prng_gen_f64(oracle_prng *r) { return rl_u64_to_unit_f64(oracle_prng_next_u64(r)); }
 

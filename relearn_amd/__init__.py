@@ -46,6 +46,9 @@ ABI_SYMBOLS = [
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient",
+    "rl_dqn_config_default", "rl_dqn_create", "rl_dqn_destroy", "rl_dqn_exploration_rate",
+    "rl_dqn_min_update_size", "rl_dqn_collect", "rl_dqn_update", "rl_dqn_replay_field_bytes", "rl_dqn_replay_read",
+    "rl_dqn_minibatch_sample", "rl_dqn_minibatch_read", "rl_dqn_minibatch_gradient", "rl_dqn_agent_rng_pos",
     "rl_chain_tabular_q_train", "rl_chain_tabular_q_eval",
 ]
 
@@ -138,7 +141,7 @@ def _register(obj):
 @atexit.register
 def _close_all():
     objs = list(_live)
-    order = {"Adam": 0, "Trajectory": 1, "CartPoleEnv": 2, "Mlp": 3, "Engine": 4}
+    order = {"Dqn": -1, "Adam": 0, "Trajectory": 1, "CartPoleEnv": 2, "Mlp": 3, "Engine": 4}
     for o in sorted(objs, key=lambda o: order.get(type(o).__name__, 2)):
         o.close()
 
@@ -450,6 +453,124 @@ def critic_gradient(critic, traj):
     loss = C.c_float()
     _check(lib().rl_critic_gradient(critic.h, traj.h, g.ctypes.data_as(C.c_void_p), C.byref(loss)), traj.eng.h)
     return g, loss.value
+
+
+DQN_TARGET_REWARD_TO_GO, DQN_TARGET_ONE_STEP_TD = 0, 1
+SCHEDULE_CONSTANT, SCHEDULE_LINEAR_ANNEALED = 0, 1
+COLLECT_CONSTANT, COLLECT_FIRST_REST = 0, 1
+(REPLAY_HEAD, REPLAY_COUNT, REPLAY_EP_HEAD, REPLAY_EP_COUNT, REPLAY_TOTAL, REPLAY_EP_END, REPLAY_OBS,
+ REPLAY_NEXT_OBS, REPLAY_ACTION, REPLAY_REWARD, REPLAY_FLAG, REPLAY_ACTOR_POS, REPLAY_LAST_FLAGS) = range(13)
+MB_EP_LANE, MB_EP_START, MB_EP_LEN, MB_EP_OFFSET, MB_OBS, MB_ACTION, MB_TARGET = range(7)
+
+
+class DqnConfig(C.Structure):
+    _fields_ = [("target", C.c_int32), ("exploration_kind", C.c_int32), ("exploration_start", C.c_double),
+                ("exploration_end", C.c_double), ("exploration_period", C.c_uint64),
+                ("minibatch_steps", C.c_uint64), ("opt_steps_per_update", C.c_uint64),
+                ("buffer_capacity", C.c_uint64), ("episode_capacity", C.c_uint64), ("update_kind", C.c_int32),
+                ("update_first", C.c_uint64), ("update_rest", C.c_uint64), ("discount_factor", C.c_float),
+                ("agent_key", C.c_uint32 * 8)]
+
+
+class DqnCollectStats(C.Structure):
+    _fields_ = [("exploration_rate", C.c_double), ("steps", C.c_uint64), ("episodes_ended", C.c_uint64)]
+
+
+class DqnUpdateStats(C.Structure):
+    _fields_ = [("loss_first", C.c_double), ("loss_last", C.c_double), ("opt_steps", C.c_uint64),
+                ("global_steps", C.c_uint64), ("last_minibatch_steps", C.c_uint64),
+                ("last_minibatch_episodes", C.c_uint64)]
+
+
+def dqn_config_default():
+    c = DqnConfig()
+    _check(lib().rl_dqn_config_default(C.byref(c)))
+    return c
+
+
+class Dqn(_Handle):
+    """`DqnConfig::build_agent` + the replay store of all lanes, resident in HBM (src/torch/agents/dqn.rs)."""
+
+    def __init__(self, env, qnet, opt, cfg):
+        self.eng, self.env, self.qnet, self.opt, self.cfg = env.eng, env, qnet, opt, cfg
+        self.h = C.c_void_p()
+        _check(lib().rl_dqn_create(env.h, qnet.h, opt.h, C.byref(cfg), C.byref(self.h)), env.eng.h)
+        _register(self)
+        self.n, self.D = env.n, env.D
+        self.C = cfg.buffer_capacity
+        self.E = cfg.episode_capacity or cfg.buffer_capacity
+        self.n_eps = self.n_steps = 0
+
+    def close(self):
+        if self.h:
+            lib().rl_dqn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def exploration_rate(self, training=True):
+        r = C.c_double()
+        _check(lib().rl_dqn_exploration_rate(self.h, C.c_int32(1 if training else 0), C.byref(r)), self.eng.h)
+        return r.value
+
+    def min_update_size(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().rl_dqn_min_update_size(self.h, C.byref(a), C.byref(b)), self.eng.h)
+        return a.value, b.value
+
+    def collect(self, horizon, want_stats=True):
+        st = DqnCollectStats()
+        _check(lib().rl_dqn_collect(self.h, C.c_uint64(horizon), C.byref(st) if want_stats else None), self.eng.h)
+        self.last_horizon = horizon
+        return st
+
+    def update(self, want_losses=False):
+        st = DqnUpdateStats()
+        K = self.cfg.opt_steps_per_update
+        losses = np.zeros(max(K, 1), dtype=np.float32)
+        _check(lib().rl_dqn_update(self.h, C.byref(st), losses.ctypes.data_as(C.c_void_p) if want_losses else None),
+               self.eng.h)
+        return (st, losses[:K]) if want_losses else st
+
+    def replay_read(self, field):
+        n, Cc, E, D = self.n, self.C, self.E, self.D
+        shape, dt = {
+            REPLAY_HEAD: ((n,), np.uint32), REPLAY_COUNT: ((n,), np.uint32), REPLAY_EP_HEAD: ((n,), np.uint32),
+            REPLAY_EP_COUNT: ((n,), np.uint32), REPLAY_TOTAL: ((n,), np.uint32), REPLAY_EP_END: ((E, n), np.uint32),
+            REPLAY_OBS: ((D, Cc, n), np.float32), REPLAY_NEXT_OBS: ((D, Cc, n), np.float32),
+            REPLAY_ACTION: ((Cc, n), np.uint8), REPLAY_REWARD: ((Cc, n), np.float32),
+            REPLAY_FLAG: ((Cc, n), np.uint8), REPLAY_ACTOR_POS: ((n,), np.uint64),
+            REPLAY_LAST_FLAGS: ((getattr(self, "last_horizon", 0), n), np.uint8)}[field]
+        out = np.zeros(shape, dtype=dt)
+        _check(lib().rl_dqn_replay_read(self.h, C.c_int32(field), out.ctypes.data_as(C.c_void_p),
+                                        C.c_uint64(out.nbytes)), self.eng.h)
+        return out
+
+    def minibatch_sample(self, sequential=False):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().rl_dqn_minibatch_sample(self.h, C.c_int32(1 if sequential else 0), C.byref(a), C.byref(b)),
+               self.eng.h)
+        self.n_eps, self.n_steps = a.value, b.value
+        return a.value, b.value
+
+    def minibatch_read(self, field):
+        ne, ns, D = self.n_eps, self.n_steps, self.D
+        shape, dt = {MB_EP_LANE: ((ne,), np.uint32), MB_EP_START: ((ne,), np.uint32), MB_EP_LEN: ((ne,), np.uint32),
+                     MB_EP_OFFSET: ((ne,), np.uint32), MB_OBS: ((D, ns), np.float32), MB_ACTION: ((ns,), np.uint8),
+                     MB_TARGET: ((ns,), np.float32)}[field]
+        out = np.zeros(shape, dtype=dt)
+        _check(lib().rl_dqn_minibatch_read(self.h, C.c_int32(field), out.ctypes.data_as(C.c_void_p),
+                                           C.c_uint64(out.nbytes)), self.eng.h)
+        return out
+
+    def minibatch_gradient(self):
+        g = np.zeros(self.qnet.P, dtype=np.float32)
+        loss = C.c_float()
+        _check(lib().rl_dqn_minibatch_gradient(self.h, g.ctypes.data_as(C.c_void_p), C.byref(loss)), self.eng.h)
+        return g, loss.value
+
+    def agent_rng_pos(self):
+        p = C.c_uint64()
+        _check(lib().rl_dqn_agent_rng_pos(self.h, C.byref(p)), self.eng.h)
+        return p.value
 
 
 def chain_tabular_q_train(seed=0, n_threads=4, n_periods=10, min_worker_steps=10000, exploration_rate=0.2):

@@ -659,77 +659,94 @@ static void traj_field(const rl_traj *t, int32_t field, void **ptr, uint64_t *by
   }
 }
 
+// launch geometry of the update kernels for B samples
+static void traj_plan(rl_traj *t, uint64_t B) {
+  rl_engine *e = t->eng;
+  t->B = B;
+  // backward: <= 1024 workgroups of 128 threads, chunk a multiple of 8 samples
+  uint64_t chunk = (B + 1023) / 1024;
+  chunk = ((chunk + 7) / 8) * 8;
+  if (chunk < 64) chunk = 64;
+  t->bwd_chunk = (uint32_t)chunk;
+  t->nbA = (uint32_t)((B + chunk - 1) / chunk);
+  uint64_t nbB = (B + 255) / 256;
+  if (nbB > 2048) nbB = 2048;
+  t->nbB = (uint32_t)nbB;
+  // v2 kernels: persistent grid of 4-wave workgroups, 2 per CU, one 32-sample tile per wave and iteration
+  uint64_t n_tiles = (B + 31) / 32;
+  uint64_t nbV2 = (n_tiles + 3) / 4;
+  uint64_t max_v2 = 2ull * (uint64_t)e->prop.multiProcessorCount;
+  if (nbV2 > max_v2) nbV2 = max_v2;
+  t->nbV2 = (uint32_t)nbV2;
+  // pair kernels: 2-wave workgroups, 8 per CU (4 waves per SIMD), a contiguous run of tiles per workgroup
+  uint64_t max_pair = 8ull * (uint64_t)e->prop.multiProcessorCount;
+  uint64_t tpb = (n_tiles + max_pair - 1) / max_pair;
+  if (tpb == 0) tpb = 1;
+  t->pair_tiles_per_block = (uint32_t)tpb;
+  t->nbPair = (uint32_t)((n_tiles + tpb - 1) / tpb);
+}
+
+// `resizable`: the sample count changes between launches (DQN minibatches): slabs are sized for the largest grid
+// any B <= n_lanes * horizon can plan
+static rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, bool resizable) {
+  RL_REQUIRE(n_lanes > 0 && n_lanes < (1ull << 31), "bad n_lanes");
+  RL_REQUIRE(horizon > 0 && horizon < (1ull << 20), "bad horizon");
+  RL_REQUIRE(obs_dim == 4 || obs_dim == 5, "obs_dim must be 4 or 5");
+  RL_REQUIRE(n_lanes * horizon < (1ull << 32), "T * n must fit 32 bits");
+  RL_HIP_CHECK(hipSetDevice(e->device));
+  std::unique_ptr<rl_traj> t(new rl_traj());
+  t->eng = e;
+  t->d.n = (uint32_t)n_lanes;
+  t->d.T = (uint32_t)horizon;
+  t->d.D = obs_dim;
+  uint64_t n = n_lanes, T = horizon, D = obs_dim;
+  t->d.obs = dalloc<float>(D * (T + 1) * n);
+  t->d.action = dalloc<uint8_t>(T * n);
+  t->d.reward = dalloc<float>(T * n);
+  t->d.flag = dalloc<uint8_t>(T * n);
+  t->d.term_obs = dalloc<float>(D * T * n);
+  t->d.values = dalloc<float>((T + 1) * n);
+  t->d.adv = dalloc<float>(T * n);
+  t->d.rtg = dalloc<float>(T * n);
+  t->lp0 = dalloc<float>(2 * n * T);
+  t->dz = dalloc<float>(2 * n * T);
+  t->Pmax = 128 * 5 + 128 + 2 * 128 + 2;
+  traj_plan(t.get(), n * T);
+  uint32_t rows = t->nbA;
+  if (t->nbV2 > rows) rows = t->nbV2;
+  if (t->nbPair > rows) rows = t->nbPair;
+  uint32_t rowsB = t->nbB > rows ? t->nbB : rows;
+  if (resizable) {
+    uint32_t cap = 8u * (uint32_t)e->prop.multiProcessorCount;
+    if (cap < 2048) cap = 2048;
+    rows = rowsB = cap;
+  }
+  t->slabA = dalloc<double>((size_t)rows * t->Pmax);
+  t->slabB = dalloc<double>((size_t)rowsB * 4);
+  t->vec = dalloc<float>(t->Pmax + 4);
+  t->cg_x = dalloc<float>(t->Pmax);
+  t->cg_r = dalloc<float>(t->Pmax);
+  t->cg_p = dalloc<float>(t->Pmax);
+  t->prev_params = dalloc<float>(t->Pmax);
+  t->descent = dalloc<float>(t->Pmax);
+  t->max_losses = 4096;
+  t->losses = dalloc<float>(t->max_losses);
+  t->trpo = dalloc<TrpoStateDev>(1);
+  RL_HIP_CHECK(hipMemsetAsync(t->d.term_obs, 0, D * T * n * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(t->d.values, 0, (T + 1) * n * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(t->d.adv, 0, T * n * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(t->d.rtg, 0, T * n * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(t->trpo, 0, sizeof(TrpoStateDev), e->stream));
+  RL_HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->live_handles += 1;
+  return t.release();
+}
+
 int32_t rl_traj_create(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, rl_traj **out) {
   return guarded(e, [&] {
     RL_REQUIRE(e && out, "NULL argument");
     *out = nullptr;
-    RL_REQUIRE(n_lanes > 0 && n_lanes < (1ull << 31), "bad n_lanes");
-    RL_REQUIRE(horizon > 0 && horizon < (1ull << 20), "bad horizon");
-    RL_REQUIRE(obs_dim == 4 || obs_dim == 5, "obs_dim must be 4 or 5");
-    RL_REQUIRE(n_lanes * horizon < (1ull << 32), "T * n must fit 32 bits");
-    RL_HIP_CHECK(hipSetDevice(e->device));
-    std::unique_ptr<rl_traj> t(new rl_traj());
-    t->eng = e;
-    t->d.n = (uint32_t)n_lanes;
-    t->d.T = (uint32_t)horizon;
-    t->d.D = obs_dim;
-    uint64_t n = n_lanes, T = horizon, D = obs_dim;
-    t->B = n * T;
-    t->d.obs = dalloc<float>(D * (T + 1) * n);
-    t->d.action = dalloc<uint8_t>(T * n);
-    t->d.reward = dalloc<float>(T * n);
-    t->d.flag = dalloc<uint8_t>(T * n);
-    t->d.term_obs = dalloc<float>(D * T * n);
-    t->d.values = dalloc<float>((T + 1) * n);
-    t->d.adv = dalloc<float>(T * n);
-    t->d.rtg = dalloc<float>(T * n);
-    t->lp0 = dalloc<float>(2 * t->B);
-    t->dz = dalloc<float>(2 * t->B);
-    t->Pmax = 128 * 5 + 128 + 2 * 128 + 2;
-    // backward: <= 1024 workgroups of 128 threads, chunk a multiple of 8 samples
-    uint64_t chunk = (t->B + 1023) / 1024;
-    chunk = ((chunk + 7) / 8) * 8;
-    if (chunk < 64) chunk = 64;
-    t->bwd_chunk = (uint32_t)chunk;
-    t->nbA = (uint32_t)((t->B + chunk - 1) / chunk);
-    uint64_t nbB = (t->B + 255) / 256;
-    if (nbB > 2048) nbB = 2048;
-    t->nbB = (uint32_t)nbB;
-    // v2 kernels: persistent grid of 4-wave workgroups, 2 per CU, one 32-sample tile per wave and iteration
-    uint64_t n_tiles = (t->B + 31) / 32;
-    uint64_t nbV2 = (n_tiles + 3) / 4;
-    uint64_t max_v2 = 2ull * (uint64_t)e->prop.multiProcessorCount;
-    if (nbV2 > max_v2) nbV2 = max_v2;
-    t->nbV2 = (uint32_t)nbV2;
-    // pair kernels: 2-wave workgroups, 8 per CU (4 waves per SIMD), a contiguous run of tiles per workgroup
-    uint64_t max_pair = 8ull * (uint64_t)e->prop.multiProcessorCount;
-    uint64_t tpb = (n_tiles + max_pair - 1) / max_pair;
-    if (tpb == 0) tpb = 1;
-    t->pair_tiles_per_block = (uint32_t)tpb;
-    t->nbPair = (uint32_t)((n_tiles + tpb - 1) / tpb);
-    uint32_t rows = t->nbA;
-    if (t->nbV2 > rows) rows = t->nbV2;
-    if (t->nbPair > rows) rows = t->nbPair;
-    uint32_t rowsB = t->nbB > rows ? t->nbB : rows;
-    t->slabA = dalloc<double>((size_t)rows * t->Pmax);
-    t->slabB = dalloc<double>((size_t)rowsB * 4);
-    t->vec = dalloc<float>(t->Pmax + 4);
-    t->cg_x = dalloc<float>(t->Pmax);
-    t->cg_r = dalloc<float>(t->Pmax);
-    t->cg_p = dalloc<float>(t->Pmax);
-    t->prev_params = dalloc<float>(t->Pmax);
-    t->descent = dalloc<float>(t->Pmax);
-    t->max_losses = 4096;
-    t->losses = dalloc<float>(t->max_losses);
-    t->trpo = dalloc<TrpoStateDev>(1);
-    RL_HIP_CHECK(hipMemsetAsync(t->d.term_obs, 0, D * T * n * 4, e->stream));
-    RL_HIP_CHECK(hipMemsetAsync(t->d.values, 0, (T + 1) * n * 4, e->stream));
-    RL_HIP_CHECK(hipMemsetAsync(t->d.adv, 0, T * n * 4, e->stream));
-    RL_HIP_CHECK(hipMemsetAsync(t->d.rtg, 0, T * n * 4, e->stream));
-    RL_HIP_CHECK(hipMemsetAsync(t->trpo, 0, sizeof(TrpoStateDev), e->stream));
-    sync(e);
-    e->live_handles += 1;
-    *out = t.release();
+    *out = traj_alloc(e, n_lanes, horizon, obs_dim, false);
   });
 }
 
@@ -1070,6 +1087,364 @@ int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float
     d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     if (loss_out) *loss_out = (float)((double)h[P] / (double)b_total(traj));
+  });
+}
+
+// ---------------------------------------------------------------- DQN (src/torch/agents/dqn.rs)
+int32_t rl_dqn_config_default(rl_dqn_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    std::memset(c, 0, sizeof(*c));
+    c->target = RL_DQN_TARGET_REWARD_TO_GO;               // StepValueTarget::default (critics/mod.rs:211-215)
+    c->exploration_kind = RL_SCHEDULE_LINEAR_ANNEALED;    // schedules.rs:23-31
+    c->exploration_start = 1.0;
+    c->exploration_end = 0.1;
+    c->exploration_period = 10000000;
+    c->minibatch_steps = 100000;                          // dqn.rs:63-70
+    c->opt_steps_per_update = 50;
+    c->buffer_capacity = 0;
+    c->episode_capacity = 0;
+    c->update_kind = RL_COLLECT_FIRST_REST;
+    c->update_first = 1000000;
+    c->update_rest = 100000;
+    c->discount_factor = 0.99f;
+  });
+}
+
+static double dqn_exploration_rate(const rl_dqn *q, bool training) {
+  if (!training) return 0.0;  // schedules.rs:38
+  if (q->cfg.exploration_kind == RL_SCHEDULE_CONSTANT) return q->cfg.exploration_start;
+  double frac = (double)q->global_steps / (double)q->cfg.exploration_period;
+  if (!(frac < 1.0)) frac = 1.0;  // f64::min(1.0)
+  return frac * (q->cfg.exploration_end - q->cfg.exploration_start) + q->cfg.exploration_start;
+}
+
+static ReplayDev replay_alloc(rl_engine *e, uint32_t N, uint32_t C, uint32_t E, uint32_t D) {
+  ReplayDev r{};
+  r.N = N;
+  r.C = C;
+  r.E = E;
+  r.D = D;
+  size_t cn = (size_t)C * N;
+  r.obs = dalloc<float>(cn * D);
+  r.next_obs = dalloc<float>(cn * D);
+  r.action = dalloc<uint8_t>(cn);
+  r.reward = dalloc<float>(cn);
+  r.flag = dalloc<uint8_t>(cn);
+  r.head = dalloc<uint32_t>(N);
+  r.count = dalloc<uint32_t>(N);
+  r.ep_head = dalloc<uint32_t>(N);
+  r.ep_count = dalloc<uint32_t>(N);
+  r.total = dalloc<uint32_t>(N);
+  r.ep_end = dalloc<uint32_t>((size_t)E * N);
+  r.actor_pos = dalloc<uint64_t>(N);
+  r.error = dalloc<int32_t>(1);
+  uint32_t *zero_u32[] = {r.head, r.count, r.ep_head, r.ep_count, r.total};
+  for (uint32_t *p : zero_u32) RL_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)N * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.actor_pos, 0, (size_t)N * 8, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.error, 0, 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.next_obs, 0, cn * D * 4, e->stream));
+  return r;
+}
+
+static void replay_free(ReplayDev &r) {
+  void *ptrs[] = {r.obs,      r.next_obs, r.action, r.reward, r.flag,      r.head, r.count,
+                  r.ep_head,  r.ep_count, r.total,  r.ep_end, r.actor_pos, r.error};
+  for (void *p : ptrs) dfree(p);
+  r = ReplayDev{};
+}
+
+int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_config *cfg, rl_dqn **out) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && qnet && opt && cfg && out, "NULL argument");
+    *out = nullptr;
+    rl_engine *e = env->eng;
+    RL_REQUIRE(qnet->eng == e && opt->eng == e, "handles belong to different engines");
+    RL_REQUIRE(opt->mod == qnet, "optimizer does not belong to the action-value module");
+    RL_REQUIRE(qnet->in_dim == env->D && qnet->out_dim == env->A, "action-value module does not match the env");
+    RL_REQUIRE(env->A == 2, "DQN kernels are built for 2-action envs");
+    RL_REQUIRE(cfg->target == RL_DQN_TARGET_REWARD_TO_GO || cfg->target == RL_DQN_TARGET_ONE_STEP_TD, "bad target");
+    RL_REQUIRE(cfg->minibatch_steps > 0 && cfg->minibatch_steps < (1ull << 30), "bad minibatch_steps");
+    RL_REQUIRE(cfg->buffer_capacity > 0 && cfg->buffer_capacity < (1ull << 31), "bad buffer_capacity");
+    uint64_t E = cfg->episode_capacity ? cfg->episode_capacity : cfg->buffer_capacity;
+    RL_REQUIRE(E <= cfg->buffer_capacity, "episode_capacity exceeds buffer_capacity");
+    RL_REQUIRE(cfg->opt_steps_per_update <= 4096, "too many optimisation steps per update");
+    if (cfg->exploration_kind == RL_SCHEDULE_LINEAR_ANNEALED)
+      RL_REQUIRE(cfg->exploration_period > 0, "exploration_period must be positive");
+    uint64_t N = env->cfg.n_lanes;
+    RL_REQUIRE(cfg->buffer_capacity * N * 46 < (200ull << 30), "replay store would not fit in HBM");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_dqn> q(new rl_dqn());
+    q->eng = e;
+    q->env = env;
+    q->qnet = qnet;
+    q->opt = opt;
+    q->cfg = *cfg;
+    q->cfg.episode_capacity = E;
+    q->rp = replay_alloc(e, (uint32_t)N, (uint32_t)cfg->buffer_capacity, (uint32_t)E, env->D);
+    q->d_agent_pos = dalloc<uint64_t>(1);
+    RL_HIP_CHECK(hipMemsetAsync(q->d_agent_pos, 0, 8, e->stream));
+    // take_while accepts episodes while total < minibatch_steps and every episode has >= 1 step
+    q->max_eps = (uint32_t)cfg->minibatch_steps;
+    q->max_steps_mb = cfg->minibatch_steps - 1 + cfg->buffer_capacity;
+    q->d_ep_lane = dalloc<uint32_t>(q->max_eps);
+    q->d_ep_start = dalloc<uint32_t>(q->max_eps);
+    q->d_ep_len = dalloc<uint32_t>(q->max_eps);
+    q->d_ep_off = dalloc<uint32_t>(q->max_eps);
+    q->d_counts = dalloc<DqnCountsDev>(1);
+    RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, sizeof(DqnCountsDev), e->stream));
+    q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
+    sync(e);
+    e->live_handles += 1;
+    *out = q.release();
+  });
+}
+
+int32_t rl_dqn_destroy(rl_dqn *q) {
+  if (!q) return RL_OK;
+  (void)hipSetDevice(q->eng->device);
+  (void)hipStreamSynchronize(q->eng->stream);
+  replay_free(q->rp);
+  void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags};
+  for (void *p : ptrs) dfree(p);
+  rl_traj_destroy(q->mb);
+  rl_engine *eng = q->eng;
+  delete q;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_dqn_exploration_rate(const rl_dqn *q, int32_t training, double *rate_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && rate_out, "NULL argument");
+    *rate_out = dqn_exploration_rate(q, training != 0);
+  });
+}
+
+int32_t rl_dqn_min_update_size(const rl_dqn *q, uint64_t *min_steps_out, uint64_t *slack_steps_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && min_steps_out && slack_steps_out, "NULL argument");
+    // DataCollectionSchedule::update_size (schedules.rs:58-68)
+    uint64_t min_steps;
+    if (q->cfg.update_kind == RL_COLLECT_CONSTANT) min_steps = q->cfg.update_first;
+    else min_steps = q->global_steps < q->cfg.update_first ? q->cfg.update_first : q->cfg.update_rest;
+    *min_steps_out = min_steps;
+    // HistoryDataBound::with_default_slack (src/agents/buffers/mod.rs:54-63): 1 % of min_steps, between 5 and 1000
+    uint64_t slack = min_steps / 100;
+    slack = slack < 5 ? 5 : (slack > 1000 ? 1000 : slack);
+    *slack_steps_out = slack;
+  });
+}
+
+int32_t rl_dqn_collect(rl_dqn *q, uint64_t horizon, rl_dqn_collect_stats *stats) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q, "NULL argument");
+    RL_REQUIRE(horizon > 0 && horizon < (1ull << 31), "bad horizon");
+    rl_engine *e = q->eng;
+    uint64_t N = q->rp.N;
+    if (q->flags_cap < horizon * N) {
+      dfree(q->d_flags);
+      q->d_flags = nullptr;
+      q->flags_cap = 0;
+      q->d_flags = dalloc<uint8_t>(horizon * N);
+      q->flags_cap = horizon * N;
+    }
+    // DqnAgent::actor(Training) (dqn.rs:200-211) + Bernoulli::new(p) of rand 0.8.5: p_int = (p * 2^64) as u64,
+    // p == 1.0 always true without a draw
+    double eps = dqn_exploration_rate(q, true);
+    RL_REQUIRE(eps >= 0.0 && eps <= 1.0, "exploration rate outside [0, 1]");
+    int always = eps == 1.0 ? 1 : 0;
+    uint64_t p_int = always ? ~0ull : (uint64_t)(eps * 18446744073709551616.0);
+    launch_rollout_dqn(q->env, q->qnet, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
+    q->env->t_global += horizon;
+    q->steps_per_lane += horizon;
+    q->last_horizon = horizon;
+    int32_t err = 0;
+    d2h(e, &err, q->rp.error, sizeof(err));
+    if (err != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full: an episode outgrew the lane capacity");
+    if (stats) {
+      std::vector<uint8_t> fl(horizon * N);
+      d2h(e, fl.data(), q->d_flags, fl.size());
+      uint64_t ended = 0;
+      for (uint8_t f : fl) ended += f != RL_SUCC_CONTINUE;
+      stats->exploration_rate = eps;
+      stats->steps = horizon * N;
+      stats->episodes_ended = ended;
+    }
+  });
+}
+
+static AgentKey dqn_key(const rl_dqn *q) {
+  AgentKey k;
+  std::memcpy(k.w, q->cfg.agent_key, sizeof(k.w));
+  return k;
+}
+
+// one sample_minibatch (dqn.rs:279-314): draw episodes, gather them, compute targets
+static void dqn_sample_minibatch(rl_dqn *q, int sequential) {
+  rl_engine *e = q->eng;
+  launch_dqn_sample(e, q->rp, dqn_key(q), q->d_agent_pos, (uint32_t)q->cfg.minibatch_steps, q->max_eps,
+                    q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, sequential);
+  DqnCountsDev c;
+  d2h(e, &c, q->d_counts, sizeof(c));
+  if (c.error == 2)
+    throw RlError(RL_ERR_INVALID_ARGUMENT, "minibatch sampling from a lane without a complete episode");
+  if (c.error != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full");
+  RL_REQUIRE(c.n_eps <= q->max_eps && c.n_steps <= q->max_steps_mb, "minibatch exceeds its workspace");
+  RL_REQUIRE(c.n_steps > 0, "empty minibatch");
+  q->last_n_eps = c.n_eps;
+  q->last_n_steps = c.n_steps;
+  // the loss is a mean over all ranks' samples: sum the per-rank counts (two 16-bit halves, exact in f32)
+  uint64_t total = c.n_steps;
+  if (e->n_ranks > 1) {
+    float halves[2] = {(float)(c.n_steps & 0xffffu), (float)(c.n_steps >> 16)};
+    h2d(e, q->mb->vec, halves, sizeof(halves));
+    rl_allreduce_sum_f32(e, q->mb->vec, 2);
+    d2h(e, halves, q->mb->vec, sizeof(halves));
+    total = (uint64_t)halves[0] + ((uint64_t)halves[1] << 16);
+  }
+  q->last_total_steps = total;
+  rl_traj *mb = q->mb;
+  mb->d.n = c.n_steps;
+  mb->d.T = 1;
+  traj_plan(mb, c.n_steps);
+  launch_dqn_build_minibatch(e, q->rp, c.n_eps, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, mb->d.obs,
+                             (size_t)2 * c.n_steps, mb->d.action, mb->d.adv, q->cfg.discount_factor,
+                             q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD ? 1 : 0, q->qnet);
+}
+
+// gradient of mean((Q(s)[a] - target)^2) over the current minibatch -> mb->vec[0..P), loss sum -> mb->vec[P]
+static void dqn_gradient(rl_dqn *q) {
+  rl_traj *mb = q->mb;
+  uint32_t P = (uint32_t)q->qnet->P;
+  if (q->eng->kernel_variant != 1 && launch_policy_v2(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr)) {
+    launch_reduce(mb, P, true, true, mb->nbV2, mb->nbV2);
+  } else {
+    launch_policy_pass(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr);
+    launch_mlp_backward(mb, q->qnet, nullptr);
+    launch_reduce(mb, P, true, true, mb->nbA, mb->nbB);
+  }
+  rl_allreduce_sum_f32(q->eng, mb->vec, P + 4);
+}
+
+int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q, "NULL argument");
+    rl_engine *e = q->eng;
+    // self.global_steps = sum of total_step_count over the buffers (dqn.rs:276); every lane of every rank has
+    // taken the same number of steps and the horizon rule drops none
+    q->global_steps = q->steps_per_lane * (uint64_t)q->rp.N * (uint64_t)e->n_ranks;
+    uint64_t K = q->cfg.opt_steps_per_update;
+    for (uint64_t k = 0; k < K; ++k) {
+      dqn_sample_minibatch(q, 0);
+      dqn_gradient(q);
+      launch_adam_step(q->mb, q->opt, (int)k, q->last_total_steps);
+    }
+    std::vector<float> h(K ? K : 1, 0.0f);
+    if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
+    if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
+    if (stats) {
+      stats->opt_steps = K;
+      stats->loss_first = K ? (double)h[0] : 0.0;
+      stats->loss_last = K ? (double)h[K - 1] : 0.0;
+      stats->global_steps = q->global_steps;
+      stats->last_minibatch_steps = q->last_n_steps;
+      stats->last_minibatch_episodes = q->last_n_eps;
+    }
+  });
+}
+
+static void replay_field(const rl_dqn *q, int32_t field, void **ptr, uint64_t *bytes) {
+  const ReplayDev &r = q->rp;
+  uint64_t N = r.N, C = r.C, E = r.E, D = r.D;
+  switch (field) {
+    case RL_REPLAY_HEAD: *ptr = r.head; *bytes = N * 4; break;
+    case RL_REPLAY_COUNT: *ptr = r.count; *bytes = N * 4; break;
+    case RL_REPLAY_EP_HEAD: *ptr = r.ep_head; *bytes = N * 4; break;
+    case RL_REPLAY_EP_COUNT: *ptr = r.ep_count; *bytes = N * 4; break;
+    case RL_REPLAY_TOTAL: *ptr = r.total; *bytes = N * 4; break;
+    case RL_REPLAY_EP_END: *ptr = r.ep_end; *bytes = E * N * 4; break;
+    case RL_REPLAY_OBS: *ptr = r.obs; *bytes = D * C * N * 4; break;
+    case RL_REPLAY_NEXT_OBS: *ptr = r.next_obs; *bytes = D * C * N * 4; break;
+    case RL_REPLAY_ACTION: *ptr = r.action; *bytes = C * N; break;
+    case RL_REPLAY_REWARD: *ptr = r.reward; *bytes = C * N * 4; break;
+    case RL_REPLAY_FLAG: *ptr = r.flag; *bytes = C * N; break;
+    case RL_REPLAY_ACTOR_POS: *ptr = r.actor_pos; *bytes = N * 8; break;
+    case RL_REPLAY_LAST_FLAGS: *ptr = q->d_flags; *bytes = q->last_horizon * N; break;
+    default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown replay field");
+  }
+}
+
+int32_t rl_dqn_replay_field_bytes(const rl_dqn *q, int32_t field, uint64_t *bytes) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && bytes, "NULL argument");
+    void *p;
+    replay_field(q, field, &p, bytes);
+  });
+}
+
+int32_t rl_dqn_replay_read(rl_dqn *q, int32_t field, void *host, uint64_t bytes) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && host, "NULL argument");
+    void *p;
+    uint64_t need;
+    replay_field(q, field, &p, &need);
+    RL_REQUIRE(bytes == need, "byte count mismatch for replay field");
+    if (bytes) d2h(q->eng, host, p, bytes);
+  });
+}
+
+int32_t rl_dqn_minibatch_sample(rl_dqn *q, int32_t sequential, uint64_t *n_episodes_out, uint64_t *n_steps_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q, "NULL argument");
+    dqn_sample_minibatch(q, sequential);
+    if (n_episodes_out) *n_episodes_out = q->last_n_eps;
+    if (n_steps_out) *n_steps_out = q->last_n_steps;
+  });
+}
+
+int32_t rl_dqn_minibatch_read(rl_dqn *q, int32_t field, void *host, uint64_t bytes) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && host, "NULL argument");
+    uint64_t ne = q->last_n_eps, ns = q->last_n_steps, D = q->rp.D;
+    RL_REQUIRE(ns > 0, "no minibatch has been sampled");
+    rl_engine *e = q->eng;
+    switch (field) {
+      case RL_MB_EP_LANE: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_lane, bytes); break;
+      case RL_MB_EP_START: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_start, bytes); break;
+      case RL_MB_EP_LEN: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_len, bytes); break;
+      case RL_MB_EP_OFFSET: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_off, bytes); break;
+      case RL_MB_OBS: {
+        RL_REQUIRE(bytes == D * ns * 4, "byte count mismatch");
+        // feature planes are 2 * n_steps apart in the workspace (T = 1 trajectory layout)
+        for (uint64_t d = 0; d < D; ++d)
+          d2h(e, (char *)host + d * ns * 4, q->mb->d.obs + d * 2 * ns, ns * 4);
+        break;
+      }
+      case RL_MB_ACTION: RL_REQUIRE(bytes == ns, "byte count mismatch"); d2h(e, host, q->mb->d.action, bytes); break;
+      case RL_MB_TARGET: RL_REQUIRE(bytes == ns * 4, "byte count mismatch"); d2h(e, host, q->mb->d.adv, bytes); break;
+      default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown minibatch field");
+    }
+  });
+}
+
+int32_t rl_dqn_minibatch_gradient(rl_dqn *q, float *grad_out, float *loss_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && grad_out, "NULL argument");
+    RL_REQUIRE(q->last_n_steps > 0, "no minibatch has been sampled");
+    uint32_t P = (uint32_t)q->qnet->P;
+    dqn_gradient(q);
+    std::vector<float> h(P + 4);
+    d2h(q->eng, h.data(), q->mb->vec, (P + 4) * sizeof(float));
+    std::memcpy(grad_out, h.data(), P * sizeof(float));
+    if (loss_out) *loss_out = (float)((double)h[P] / (double)q->last_total_steps);
+  });
+}
+
+int32_t rl_dqn_agent_rng_pos(rl_dqn *q, uint64_t *pos_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && pos_out, "NULL argument");
+    d2h(q->eng, pos_out, q->d_agent_pos, sizeof(uint64_t));
   });
 }
 

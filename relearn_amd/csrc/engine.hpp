@@ -60,6 +60,27 @@ struct TrajDev {
   uint32_t n, T, D;
 };
 
+// the DQN replay store: every lane is one ReplayBuffer (src/agents/buffers/replay.rs:11-27); step data in a
+// per-lane time ring `[C][N]` (lane fastest), bookkeeping per lane, see replay.hpp
+struct ReplayDev {
+  float *obs;       // [D][C][N]
+  float *next_obs;  // [D][C][N] meaningful where flag == INTERRUPT
+  uint8_t *action;  // [C][N]
+  float *reward;    // [C][N]
+  uint8_t *flag;    // [C][N]
+  uint32_t *head, *count, *ep_head, *ep_count, *total;  // [N] LaneRing fields
+  uint32_t *ep_end;     // [E][N] absolute one-past-the-end step index of each stored episode
+  uint64_t *actor_pos;  // [N] word position of the lane's actor stream
+  int32_t *error;       // != 0: a lane hit WriteExperienceError::Full / an empty buffer was sampled
+  uint32_t N, C, E, D;
+};
+
+struct DqnCountsDev {
+  uint32_t n_eps, n_steps;
+  int32_t error;
+  uint32_t pad;
+};
+
 // scalar state of one TRPO update, lives in HBM so that the whole update needs no host round trip
 struct TrpoStateDev {
   float rr;            // CG residual norm squared
@@ -146,6 +167,27 @@ struct rl_traj {
   TrpoStateDev *trpo = nullptr;
   uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbPair = 0, pair_tiles_per_block = 0, Pmax = 0, max_losses = 0;
   uint32_t bwd_chunk = 0;   // samples per backward block
+};
+
+struct rl_dqn {
+  rl_engine *eng;
+  rl_env *env;
+  rl_mlp *qnet;
+  rl_adam *opt;
+  rl_dqn_config cfg;
+  ReplayDev rp;
+  uint64_t *d_agent_pos = nullptr;   // word position of the agent's Prng (stream 0 of cfg.agent_key)
+  uint32_t *d_ep_lane = nullptr, *d_ep_start = nullptr, *d_ep_len = nullptr, *d_ep_off = nullptr;  // [max_eps]
+  DqnCountsDev *d_counts = nullptr;
+  uint8_t *d_flags = nullptr;        // [T_cap][N] successor codes of the last collection
+  uint64_t flags_cap = 0, last_horizon = 0;
+  uint32_t max_eps = 0;
+  uint64_t max_steps_mb = 0;         // sample capacity of the minibatch workspace
+  rl_traj *mb = nullptr;             // minibatch workspace: T = 1, n = current minibatch size
+  uint64_t global_steps = 0;         // as of the last update (dqn.rs:276)
+  uint64_t steps_per_lane = 0;       // collected so far
+  uint32_t last_n_eps = 0, last_n_steps = 0;
+  uint64_t last_total_steps = 0;     // minibatch size summed over ranks
 };
 
 // ---- profiling helper: wraps a launch with events when enabled ---------------------------------------

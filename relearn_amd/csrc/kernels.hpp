@@ -12,10 +12,12 @@ void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);
 void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa);
 
 // kernels_update.hip
-enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2 };
+enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2, PASS_DQN = 3 };
 // PASS_INIT : lp0 <- log pi(.|s); dz <- d(-mean(ratio*A))/dz at theta0; slabB <- {sum A, sum entropy}
 // PASS_EVAL : slabB <- {sum ratio*A, sum KL(pi0||pi)}                      (skipped when *skip_flag != 0)
 // PASS_JVP  : dz <- (diag(p) - p p^T) J v / B_total                         (skipped when *skip_flag != 0)
+// PASS_DQN  : outputs are action values; dz[a] <- [a == action] 2 (Q_a - target) / B_total with the target in
+//             `adv`; slabB <- {sum (Q_a - target)^2}                        (dqn.rs:316-326)
 void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                         const int32_t *d_skip_flag);
 void launch_critic_fwd(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
@@ -39,3 +41,15 @@ void launch_adam_step_vec(rl_adam *opt, const float *d_grad);
 bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip_flag);
+
+// kernels_dqn.hip
+void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
+                        int always_explore, uint8_t *d_flags);
+struct AgentKey { uint32_t w[8]; };
+void launch_dqn_sample(rl_engine *eng, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
+                       uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,
+                       uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential);
+void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,
+                                const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
+                                float *d_obs, size_t out_plane, uint8_t *d_action, float *d_target, float gamma,
+                                int one_step_td, const rl_mlp *qnet);

@@ -689,9 +689,17 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
       dz1 = op.valid ? p1 * (dzt1 - pdz) * inv_B : 0.0f;
     } else {
       float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
-      log_softmax_lane<2>(z, lp);
       const float adv = op.valid ? tr.adv[sidx] : 0.0f;
       const int act = op.valid ? (int)tr.action[sidx] : 0;
+      if (MODE == PASS_DQN) {
+        // MSE on the taken action's value against the target held in `adv` (dqn.rs:316-326); inv_B = 2 / B
+        const float dq = (act == 0 ? z[0] : z[1]) - adv;
+        const float g = op.valid ? dq * inv_B : 0.0f;
+        dz0 = act == 0 ? g : 0.0f;
+        dz1 = act == 1 ? g : 0.0f;
+        if (op.valid && hf == 0) sum0 += (double)(dq * dq);
+      } else {
+      log_softmax_lane<2>(z, lp);
       if (MODE == PASS_INIT) {
         if (op.valid && hf == 0) {
           lp0[sidx] = lp[0];
@@ -729,6 +737,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
           sum0 += (double)(ratio * adv);
           sum1 += (double)kl;
         }
+      }
       }
     }
     if (MODE != PASS_EVAL) {
@@ -848,8 +857,10 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
 #define PLAUNCH(MM)                                                                                              \
   hipLaunchKernelGGL((k_policy_mfma<MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0, traj->slabA, \
                      traj->slabB, inv_B, P, d_skip)
+  if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
   if (mode == PASS_INIT) PLAUNCH(PASS_INIT);
   else if (mode == PASS_JVP) PLAUNCH(PASS_JVP);
+  else if (mode == PASS_DQN) PLAUNCH(PASS_DQN);
   else PLAUNCH(PASS_EVAL);
 #undef PLAUNCH
   return true;

@@ -81,8 +81,17 @@ __global__ void __launch_bounds__(256) k_policy_pass(TrajDev tr, const float *__
     } else {
       float z[A], lp[A];
       mlp_forward_lane<D, A>(params, H, x, z);
-      log_softmax_lane<A>(z, lp);
       float adv = tr.adv[b];
+      if (MODE == PASS_DQN) {
+        // action_values.gather(-1, actions).mse_loss(targets, Mean) + backward (dqn.rs:316-326); inv_B = 2 / B
+        float dq = (act == 0 ? z[0] : z[1]) - adv;
+        float g = dq * inv_B;
+        dz[b] = act == 0 ? g : 0.0f;
+        dz[B + b] = act == 1 ? g : 0.0f;
+        s0 += (double)(dq * dq);
+        continue;
+      }
+      log_softmax_lane<A>(z, lp);
       if (MODE == PASS_INIT) {
         float lpa = act == 0 ? lp[0] : lp[1];
         float ratio = rl_expf(lpa - lpa);
@@ -524,13 +533,16 @@ void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const flo
 #define PASS(DD, MM)                                                                                           \
   hipLaunchKernelGGL((k_policy_pass<DD, MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, H, traj->lp0, \
                      traj->dz, traj->slabB, inv_B, d_skip)
+  if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
   if (traj->d.D == 5) {
     if (mode == PASS_INIT) PASS(5, PASS_INIT);
     else if (mode == PASS_EVAL) PASS(5, PASS_EVAL);
+    else if (mode == PASS_DQN) PASS(5, PASS_DQN);
     else PASS(5, PASS_JVP);
   } else {
     if (mode == PASS_INIT) PASS(4, PASS_INIT);
     else if (mode == PASS_EVAL) PASS(4, PASS_EVAL);
+    else if (mode == PASS_DQN) PASS(4, PASS_DQN);
     else PASS(4, PASS_JVP);
   }
 #undef PASS

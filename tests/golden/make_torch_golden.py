@@ -195,6 +195,43 @@ def gae_case(seed=5):
             "episodes": out}
 
 
+def dqn_case(dtype, D=5, H=8, A=2, n=30, steps=5, seed=23):
+    """DQN loss (dqn.rs:316-326): mse_loss(Q(obs).gather(-1, a).squeeze(-1), targets) + Adam steps, and the
+    OneStepTd target r + gamma * amax(Q(next)) with terminal successors masked to 0 (critics/mod.rs:116-148)."""
+    g = torch.Generator().manual_seed(seed)
+    P = H * D + H + A * H + A
+    params0 = (torch.rand(P, generator=g, dtype=torch.float64) * 0.8 - 0.4).to(dtype)
+    x = (torch.randn(n, D, generator=g, dtype=torch.float64) * 0.5).to(dtype)
+    nx = (torch.randn(n, D, generator=g, dtype=torch.float64) * 0.5).to(dtype)
+    actions = torch.randint(0, A, (n,), generator=g)
+    rewards = torch.randn(n, generator=g, dtype=torch.float64).to(dtype)
+    terminal = torch.rand(n, generator=g) < 0.3
+    gamma = 0.97
+    with torch.no_grad():
+        vnext = mlp_forward(params0, nx, D, H, A).amax(-1)
+        vnext = vnext.masked_fill(terminal, 0.0)
+        targets = rewards + torch.tensor(gamma, dtype=dtype) * vnext
+    params = params0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([params], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    losses, grads0 = [], None
+    for k in range(steps):
+        q = mlp_forward(params, x, D, H, A).gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+        loss = torch.nn.functional.mse_loss(q, targets)
+        opt.zero_grad()
+        loss.backward()
+        if k == 0:
+            grads0 = params.grad.detach().clone()
+        losses.append(float(loss))
+        opt.step()
+    return {
+        "dims": [D, H, A], "n": n, "dtype": str(dtype).replace("torch.", ""), "steps": steps, "gamma": gamma,
+        "params0": params0.double().tolist(), "obs": x.double().tolist(), "next_obs": nx.double().tolist(),
+        "actions": actions.tolist(), "rewards": rewards.double().tolist(), "terminal": terminal.int().tolist(),
+        "td_targets": targets.double().tolist(), "grad0": grads0.double().tolist(), "losses": losses,
+        "params_final": params.detach().double().tolist(),
+    }
+
+
 def main():
     data = {
         "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
@@ -207,6 +244,14 @@ def main():
     with open(os.path.join(HERE, "torch_golden.json"), "w") as f:
         json.dump(data, f)
     print("wrote torch_golden.json")
+    dqn = {
+        "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
+        "dqn_f32": dqn_case(torch.float32),
+        "dqn_f64": dqn_case(torch.float64),
+    }
+    with open(os.path.join(HERE, "torch_golden_dqn.json"), "w") as f:
+        json.dump(dqn, f)
+    print("wrote torch_golden_dqn.json")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,205 @@
+"""GPU parity tests of the DQN path (BASELINE.json configs[2]): epsilon-greedy collection into the HBM replay
+rings, the parallel minibatch sampler, value targets, the fused MSE gradient and the Adam loop — through the C ABI,
+against oracle/dqn.c on the same seeds.
+
+Bars: bit-exact for everything integer or on the rollout path (actions, flags, ring bookkeeping, episode picks,
+Prng positions, reward-to-go and TD targets — identical op order on both sides); fp32 tolerance, stated below, for
+sums over the minibatch (gradient, loss, parameters after Adam).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ra = pytest.importorskip("relearn_amd")
+
+KEY = [0x9E3779B9, 0x7F4A7C15, 3, 4, 5, 6, 7, 0xFFFFFFFF]
+GRAD_RTOL = 2e-6   # vs the f64 evaluation of the same minibatch, relative to max |g|
+PARAM_ATOL = 2e-5  # after a handful of Adam steps at lr 1e-3 (sign-sensitive where |g| is tiny)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(params=[0, 1], ids=["kernels-best", "kernels-v1"])
+def variant(engine, request):
+    engine.set_kernel_variant(request.param)
+    yield request.param
+    engine.set_kernel_variant(0)
+
+
+def make(engine, n=256, hidden=128, capacity=64, minibatch=500, max_steps=23, td=False, opt_steps=4, limit=None,
+         eps=("const", 0.3), lane_offset=0, episode_capacity=0):
+    limit = ra.LIMIT_VISIBLE if limit is None else limit
+    D = 5 if limit == ra.LIMIT_VISIBLE else 4
+    env = ra.CartPoleEnv(engine, n, max_steps=max_steps, limit=limit, seed_env=21, seed_actor=34,
+                         lane_offset=lane_offset)
+    sim = O.LaneSim(n, max_steps=max_steps, limit=limit, seed_env=21, seed_actor=34, lane_offset=lane_offset)
+    qs = O.MlpShape(D, hidden, 2)
+    q = ra.Mlp(engine, D, hidden, 2)
+    q.init(77)
+    opt = ra.Adam(q)
+    cfg = ra.dqn_config_default()
+    cfg.target = ra.DQN_TARGET_ONE_STEP_TD if td else ra.DQN_TARGET_REWARD_TO_GO
+    if eps[0] == "const":
+        cfg.exploration_kind, cfg.exploration_start = ra.SCHEDULE_CONSTANT, eps[1]
+    else:
+        cfg.exploration_kind = ra.SCHEDULE_LINEAR_ANNEALED
+        cfg.exploration_start, cfg.exploration_end, cfg.exploration_period = eps[1:]
+    cfg.minibatch_steps = minibatch
+    cfg.opt_steps_per_update = opt_steps
+    cfg.buffer_capacity = capacity
+    cfg.episode_capacity = episode_capacity
+    cfg.discount_factor = 0.99
+    for i, k in enumerate(KEY):
+        cfg.agent_key[i] = k
+    dqn = ra.Dqn(env, q, opt, cfg)
+    osim = O.DqnSim(sim, qs, O.mlp_init(qs, 77), capacity, KEY, minibatch, gamma=np.float32(0.99), one_step_td=td)
+    return dqn, osim
+
+
+def check_store(dqn, osim):
+    """ring bookkeeping and contents of every lane against the oracle's ReplayBuffers"""
+    head, count = dqn.replay_read(ra.REPLAY_HEAD), dqn.replay_read(ra.REPLAY_COUNT)
+    eph, epc = dqn.replay_read(ra.REPLAY_EP_HEAD), dqn.replay_read(ra.REPLAY_EP_COUNT)
+    total, ep_end = dqn.replay_read(ra.REPLAY_TOTAL), dqn.replay_read(ra.REPLAY_EP_END)
+    obs, nobs = dqn.replay_read(ra.REPLAY_OBS), dqn.replay_read(ra.REPLAY_NEXT_OBS)
+    act, rew, flag = (dqn.replay_read(f) for f in (ra.REPLAY_ACTION, ra.REPLAY_REWARD, ra.REPLAY_FLAG))
+    assert np.array_equal(dqn.replay_read(ra.REPLAY_ACTOR_POS), osim.actor_pos())
+    Cc, E = dqn.C, dqn.E
+    for i in range(dqn.n):
+        ns, ne, tot = osim.lane_info(i)
+        assert (count[i], epc[i], total[i]) == (ns, ne, tot)
+        tags, lens = osim.lane_dump(i)
+        if ns:
+            assert head[i] == tags[0]
+        ends = [int(ep_end[(eph[i] + k) % E, i]) for k in range(ne)]
+        assert ends == list(int(head[i]) + np.cumsum(lens.astype(np.int64)))
+        for k in tags[:: max(1, ns // 7)]:  # a spread of the stored steps, compared field by field
+            o, a, r, nx, no = osim.step_data(i, int(k))
+            slot = int(k) % Cc
+            assert np.array_equal(obs[:, slot, i], o) and act[slot, i] == a and rew[slot, i] == r
+            assert flag[slot, i] == nx
+            if nx == O.INTERRUPT:
+                assert np.array_equal(nobs[:, slot, i], no)
+
+
+@pytest.mark.parametrize("limit", [ra.LIMIT_VISIBLE, ra.LIMIT_NONE])
+def test_collection_bit_exact_with_eviction(engine, limit):
+    # n is not a multiple of the wave size; capacity 48 forces evictions from the second collection on
+    for eps, T in [(1.0, 30), (0.5, 45), (0.0, 31)]:
+        dqn, osim = make(engine, n=200, capacity=48, limit=limit, max_steps=23, eps=("const", eps))
+        for rep in range(3):
+            st = dqn.collect(T)
+            flags_o, full = osim.collect(T, eps)
+            assert not full and st.exploration_rate == eps
+            flags_d = dqn.replay_read(ra.REPLAY_LAST_FLAGS)
+            assert np.array_equal(flags_d, flags_o)
+            assert st.steps == T * dqn.n and st.episodes_ended == int((flags_o != 0).sum())
+            check_store(dqn, osim)
+        st_d, st_o = dqn.env.get_state(), osim.sim.get_state()
+        for a, b in zip(st_d, st_o):
+            assert np.array_equal(a, b)
+        dqn.close()
+
+
+def test_buffer_full_is_an_error(engine):
+    dqn, osim = make(engine, n=64, capacity=6, max_steps=500, eps=("const", 0.0))
+    with pytest.raises(ra.RelearnError) as e:
+        dqn.collect(30)
+    assert e.value.code == ra.ERR_BUFFER_FULL
+    assert osim.collect(30, 0.0)[1]
+
+
+def test_linear_schedule_and_collection_bound(engine):
+    dqn, osim = make(engine, n=128, capacity=64, eps=("linear", 1.0, 0.1, 20000), minibatch=300, opt_steps=1)
+    L = O.lib()
+    cfgk = (1, 1.0, 0.1, 20000)
+    assert dqn.exploration_rate(True) == L.oracle_exploration_rate(*cfgk, 0, 1) == 1.0
+    assert dqn.exploration_rate(False) == 0.0
+    b = L.oracle_collection_update_size(1, 1_000_000, 100_000, 0)
+    assert dqn.min_update_size() == (b.min_steps, b.slack_steps)
+    steps = 0
+    for T in (40, 50):
+        st = dqn.collect(T)
+        eps_o = L.oracle_exploration_rate(*cfgk, steps, 1)
+        assert st.exploration_rate == eps_o  # global_steps is refreshed by the update, as in dqn.rs:276
+        flags_o, _ = osim.collect(T, eps_o)
+        assert np.array_equal(dqn.replay_read(ra.REPLAY_LAST_FLAGS), flags_o)
+        us = dqn.update()
+        steps += T * dqn.n
+        assert us.global_steps == steps
+        osim.qparams[:] = dqn.qnet.get_params()  # keep the greedy branch of both sides on identical parameters
+    assert dqn.exploration_rate(True) == L.oracle_exploration_rate(*cfgk, steps, 1) < 1.0
+
+
+@pytest.mark.parametrize("td", [False, True], ids=["reward-to-go", "one-step-td"])
+def test_sampling_and_targets_bit_exact(engine, td):
+    dqn, osim = make(engine, n=300, capacity=64, minibatch=25000, td=td)
+    for T in (40, 45):
+        dqn.collect(T)
+        osim.collect(T, 0.3)
+    for k in range(4):
+        sequential = k == 2  # the one-thread fallback path must give the same answer as the parallel one
+        ne, ns = dqn.minibatch_sample(sequential=sequential)
+        lanes, starts, lens, ns_o = osim.sample()
+        assert (ne, ns) == (len(lanes), ns_o)
+        assert ne > 1024  # more than one 1024-candidate chunk
+        assert np.array_equal(dqn.minibatch_read(ra.MB_EP_LANE), lanes)
+        assert np.array_equal(dqn.minibatch_read(ra.MB_EP_START), starts)
+        assert np.array_equal(dqn.minibatch_read(ra.MB_EP_LEN), lens)
+        assert np.array_equal(dqn.minibatch_read(ra.MB_EP_OFFSET), np.cumsum(lens) - lens)
+        assert dqn.agent_rng_pos() == osim.agent_pos()
+        obs_o, act_o, tgt_o = osim.minibatch(lanes, starts, lens)
+        assert np.array_equal(dqn.minibatch_read(ra.MB_OBS).T, obs_o)
+        assert np.array_equal(dqn.minibatch_read(ra.MB_ACTION), act_o.astype(np.uint8))
+        assert np.array_equal(dqn.minibatch_read(ra.MB_TARGET), tgt_o)
+
+
+@pytest.mark.parametrize("hidden,limit", [(128, ra.LIMIT_VISIBLE), (64, ra.LIMIT_VISIBLE), (128, ra.LIMIT_NONE)])
+def test_minibatch_gradient(engine, variant, hidden, limit):
+    dqn, osim = make(engine, n=256, hidden=hidden, capacity=96, minibatch=6000, limit=limit, td=True)
+    dqn.collect(60)
+    osim.collect(60, 0.3)
+    dqn.minibatch_sample()
+    lanes, starts, lens, _ = osim.sample()
+    obs, act, tgt = osim.minibatch(lanes, starts, lens)
+    g_d, loss_d = dqn.minibatch_gradient()
+    g64, loss64 = osim.grad(obs, act, tgt, f64=True)
+    g32, loss32 = osim.grad(obs, act, tgt)
+    assert rel_err(g_d, g64) < GRAD_RTOL, (rel_err(g_d, g64), rel_err(g32, g64))
+    assert abs(loss_d - loss64) <= 2e-6 * abs(loss64)
+    assert np.isfinite(g_d).all() and np.abs(g_d).max() > 0
+
+
+@pytest.mark.parametrize("td", [False, True], ids=["reward-to-go", "one-step-td"])
+def test_update_against_oracle(engine, variant, td):
+    dqn, osim = make(engine, n=256, capacity=96, minibatch=4000, td=td, opt_steps=6)
+    dqn.collect(70)
+    osim.collect(70, 0.3)
+    st, losses_d = dqn.update(want_losses=True)
+    losses_o = osim.update(6)
+    assert st.opt_steps == 6 and st.global_steps == 70 * 256
+    assert dqn.agent_rng_pos() == osim.agent_pos()  # the same episodes were drawn in every step
+    assert np.max(np.abs(losses_d - losses_o) / np.abs(losses_o)) < 2e-5
+    assert np.abs(dqn.qnet.get_params() - osim.qparams).max() < PARAM_ATOL
+    assert losses_d[-1] < losses_d[0]
+
+
+def test_cartpole_dqn_learns_something(engine):
+    """A few collect/update rounds of the whole loop: the loss falls and nothing is NaN.  (The reference's own DQN
+    test, learns_deterministic_bandit at dqn.rs:391-414, needs the bandit env; this is the CartPole analogue.)"""
+    dqn, _ = make(engine, n=512, capacity=400, minibatch=20000, opt_steps=20, max_steps=200,
+                  eps=("linear", 1.0, 0.1, 200000))
+    first = last = None
+    for it in range(4):
+        dqn.collect(100)
+        st = dqn.update()
+        first = st.loss_first if first is None else first
+        last = st.loss_last
+        assert np.isfinite(st.loss_first) and np.isfinite(st.loss_last)
+    assert last < first
