@@ -187,7 +187,6 @@ def test_update_against_oracle(engine, variant, td):
     assert dqn.agent_rng_pos() == osim.agent_pos()  # the same episodes were drawn in every step
     assert np.max(np.abs(losses_d - losses_o) / np.abs(losses_o)) < 2e-5
     assert np.abs(dqn.qnet.get_params() - osim.qparams).max() < PARAM_ATOL
-    assert losses_d[-1] < losses_d[0]
 
 
 def test_cartpole_dqn_learns_something(engine):
