@@ -48,6 +48,11 @@ def test_defaults_match_reference_configs():
             t.accept_violation) == (10, 15, 0.8, 1e-5, 0.01, 0)
     a = ra.adam_config_default()
     assert (a.learning_rate, a.beta1, a.beta2, a.weight_decay, a.eps) == (1e-3, 0.9, 0.999, 0.0, 1e-8)
+    d = ra.dqn_config_default()  # DqnConfig::default (dqn.rs:57-72), ExplorationRateSchedule::default
+    assert (d.target, d.minibatch_steps, d.opt_steps_per_update) == (ra.DQN_TARGET_REWARD_TO_GO, 100_000, 50)
+    assert (d.exploration_kind, d.exploration_start, d.exploration_end, d.exploration_period) == (
+        ra.SCHEDULE_LINEAR_ANNEALED, 1.0, 0.1, 10_000_000)
+    assert (d.update_kind, d.update_first, d.update_rest) == (ra.COLLECT_FIRST_REST, 1_000_000, 100_000)
 
 
 def test_no_cpu_fallback():
