@@ -261,6 +261,28 @@ int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t o
 int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * First-order policy updates and the critic-free advantage (the rest of the ActorCriticConfig matrix,
+ * src/torch/agents/actor_critic.rs:20-45).
+ *   Ppo::update        src/torch/agents/policies/ppo.rs:97-146  (clipped surrogate, n_backward_steps with Adam)
+ *   Reinforce::update  src/torch/agents/policies/reinforce.rs:64-88 (one Adam step on -mean(log pi(a) * A))
+ *   RewardToGo critic  src/torch/agents/critics/rtg.rs:28-33 (advantages = discounted reward-to-go, no update) */
+typedef struct {
+  uint64_t opt_steps_per_update; /* 10 */
+  double clip_distance;          /* 0.2 */
+} rl_ppo_config;
+int32_t rl_ppo_config_default(rl_ppo_config *cfg); /* PpoConfig::default, ppo.rs:27-41 */
+typedef struct {
+  double entropy;               /* mean entropy at the initial parameters ("entropy", ppo.rs:114; reinforce.rs:84) */
+  double loss_first, loss_last; /* surrogate loss before the first / last optimisation step */
+  uint64_t steps;
+} rl_policy_opt_stats;
+int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_config *cfg,
+                      rl_policy_opt_stats *stats, float *losses_out /* may be NULL */);
+int32_t rl_reinforce_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, rl_policy_opt_stats *stats);
+/* RL_TRAJ_ADVANTAGES = RL_TRAJ_RETURNS = reward-to-go (reward_to_go, critics/mod.rs:101-105) */
+int32_t rl_reward_to_go(rl_traj *traj, float gamma);
+
+/* ---------------------------------------------------------------------------------------------
  * DQN with the replay buffer resident in HBM (BASELINE.json configs[2]).
  *   DqnConfig / DqnAgent / DqnActor     src/torch/agents/dqn.rs:26-72,110-380
  *   ExplorationRateSchedule, DataCollectionSchedule   src/torch/agents/schedules.rs:7-69

@@ -302,6 +302,26 @@ def _declare(L):
     L.oracle_lanes_to_vecbuffer.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_uint8),
                                             P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int, P(C.c_uint64)]
     L.oracle_lanes_to_vecbuffer.restype = P(VecBuffer)
+    L.oracle_policy_logp_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), C.c_uint64,
+                                         P(C.c_float), P(C.c_float)]
+    L.oracle_policy_logp_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), C.c_uint64,
+                                         P(C.c_double), P(C.c_double)]
+    L.oracle_ppo_grad_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), P(C.c_float),
+                                      P(C.c_float), C.c_uint64, C.c_float, C.c_float, P(C.c_float), P(C.c_float)]
+    L.oracle_ppo_grad_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), P(C.c_double),
+                                      P(C.c_double), C.c_uint64, C.c_double, C.c_double, P(C.c_double),
+                                      P(C.c_double)]
+    L.oracle_reinforce_loss_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), P(C.c_float),
+                                            C.c_uint64]
+    L.oracle_reinforce_loss_f32.restype = C.c_float
+    L.oracle_reinforce_loss_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), P(C.c_double),
+                                            C.c_uint64]
+    L.oracle_reinforce_loss_f64.restype = C.c_double
+    L.oracle_ppo_update_f32.argtypes = [MlpShape, P(C.c_float), P(AdamState), P(AdamCfg), P(C.c_float),
+                                        P(C.c_int64), P(C.c_float), C.c_uint64, C.c_uint64, C.c_double,
+                                        P(C.c_float), P(C.c_float)]
+    L.oracle_reinforce_update_f32.argtypes = [MlpShape, P(C.c_float), P(AdamState), P(AdamCfg), P(C.c_float),
+                                              P(C.c_int64), P(C.c_float), C.c_uint64, P(C.c_float), P(C.c_float)]
     L.oracle_prng_word_pos.argtypes = [P(Prng)]
     L.oracle_prng_word_pos.restype = C.c_uint64
     L.oracle_prng_from_seed.argtypes = [P(Prng), P(C.c_uint32)]

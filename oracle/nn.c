@@ -256,3 +256,39 @@ void oracle_critic_update_f32(oracle_mlp_shape s, float *params, oracle_adam_sta
   }
   free(g);
 }
+
+/* ------------------------------------------------------------------ PPO / REINFORCE updates
+ * Ppo::update (policies/ppo.rs:97-146): initial log-probs under no_grad, then n_backward_steps with Adam.
+ * losses_out[k] = loss before step k; *entropy_out = mean entropy at the initial parameters. */
+void oracle_ppo_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,
+                           const float *obs, const int64_t *actions, const float *adv, uint64_t n, uint64_t n_steps,
+                           double clip_distance, float *losses_out, float *entropy_out) {
+  uint64_t P = oracle_mlp_num_params(s);
+  float *g = (float *)malloc(sizeof(float) * P);
+  float *lp0 = (float *)malloc(sizeof(float) * (n ? n : 1));
+  oracle_policy_logp_f32(s, params, obs, actions, n, lp0, entropy_out);
+  float lo = (float)(1.0 - clip_distance), hi = (float)(1.0 + clip_distance);
+  for (uint64_t k = 0; k < n_steps; ++k) {
+    float loss;
+    oracle_ppo_grad_f32(s, params, obs, actions, adv, lp0, n, lo, hi, g, &loss);
+    if (losses_out) losses_out[k] = loss;
+    oracle_adam_step_f32(st, cfg, params, g);
+  }
+  free(lp0);
+  free(g);
+}
+
+/* Reinforce::update (policies/reinforce.rs:64-88): one backward_step */
+void oracle_reinforce_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,
+                                 const float *obs, const int64_t *actions, const float *adv, uint64_t n,
+                                 float *loss_out, float *entropy_out) {
+  uint64_t P = oracle_mlp_num_params(s);
+  float *g = (float *)malloc(sizeof(float) * P);
+  float *lp = (float *)malloc(sizeof(float) * (n ? n : 1));
+  oracle_policy_logp_f32(s, params, obs, actions, n, lp, entropy_out);
+  if (loss_out) *loss_out = oracle_reinforce_loss_f32(s, params, obs, actions, adv, n);
+  oracle_policy_grad_f32(s, params, obs, actions, adv, n, g, NULL);
+  oracle_adam_step_f32(st, cfg, params, g);
+  free(lp);
+  free(g);
+}

@@ -247,6 +247,28 @@ void oracle_critic_update_f32(oracle_mlp_shape s, float *params, oracle_adam_sta
                               const float *obs, const float *targets, uint64_t n, uint64_t n_steps,
                               float *losses_out);
 
+/* PPO (policies/ppo.rs:97-146), REINFORCE (policies/reinforce.rs:64-88) */
+void oracle_policy_logp_f32(oracle_mlp_shape s, const float *params, const float *obs, const int64_t *actions,
+                            uint64_t n, float *logp_out, float *entropy_out);
+void oracle_policy_logp_f64(oracle_mlp_shape s, const double *params, const double *obs, const int64_t *actions,
+                            uint64_t n, double *logp_out, double *entropy_out);
+void oracle_ppo_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const int64_t *actions,
+                         const float *adv, const float *logp0, uint64_t n, float clip_lo, float clip_hi,
+                         float *grad_out, float *loss_out);
+void oracle_ppo_grad_f64(oracle_mlp_shape s, const double *params, const double *obs, const int64_t *actions,
+                         const double *adv, const double *logp0, uint64_t n, double clip_lo, double clip_hi,
+                         double *grad_out, double *loss_out);
+float oracle_reinforce_loss_f32(oracle_mlp_shape s, const float *params, const float *obs, const int64_t *actions,
+                                const float *adv, uint64_t n);
+double oracle_reinforce_loss_f64(oracle_mlp_shape s, const double *params, const double *obs, const int64_t *actions,
+                                 const double *adv, uint64_t n);
+void oracle_ppo_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,
+                           const float *obs, const int64_t *actions, const float *adv, uint64_t n, uint64_t n_steps,
+                           double clip_distance, float *losses_out, float *entropy_out);
+void oracle_reinforce_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,
+                                 const float *obs, const int64_t *actions, const float *adv, uint64_t n,
+                                 float *loss_out, float *entropy_out);
+
 /* ---------------------------------------------------------------- tabular Q (src/agents/tabular.rs) */
 typedef struct {
   uint64_t n_obs, n_act;

@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient",
+    "rl_ppo_config_default", "rl_ppo_update", "rl_reinforce_update", "rl_reward_to_go",
     "rl_dqn_config_default", "rl_dqn_create", "rl_dqn_destroy", "rl_dqn_exploration_rate",
     "rl_dqn_min_update_size", "rl_dqn_collect", "rl_dqn_update", "rl_dqn_replay_field_bytes", "rl_dqn_replay_read",
     "rl_dqn_minibatch_sample", "rl_dqn_minibatch_read", "rl_dqn_minibatch_gradient", "rl_dqn_agent_rng_pos",
@@ -571,6 +572,41 @@ class Dqn(_Handle):
         p = C.c_uint64()
         _check(lib().rl_dqn_agent_rng_pos(self.h, C.byref(p)), self.eng.h)
         return p.value
+
+
+class PpoConfig(C.Structure):
+    _fields_ = [("opt_steps_per_update", C.c_uint64), ("clip_distance", C.c_double)]
+
+
+class PolicyOptStats(C.Structure):
+    _fields_ = [("entropy", C.c_double), ("loss_first", C.c_double), ("loss_last", C.c_double),
+                ("steps", C.c_uint64)]
+
+
+def ppo_config_default():
+    c = PpoConfig()
+    _check(lib().rl_ppo_config_default(C.byref(c)))
+    return c
+
+
+def ppo_update(policy, opt, traj, cfg=None, want_losses=False):
+    cfg = cfg if cfg is not None else ppo_config_default()
+    st = PolicyOptStats()
+    K = cfg.opt_steps_per_update
+    losses = np.zeros(max(K, 1), dtype=np.float32)
+    _check(lib().rl_ppo_update(policy.h, opt.h, traj.h, C.byref(cfg), C.byref(st),
+                               losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
+    return (st, losses[:K]) if want_losses else st
+
+
+def reinforce_update(policy, opt, traj):
+    st = PolicyOptStats()
+    _check(lib().rl_reinforce_update(policy.h, opt.h, traj.h, C.byref(st)), traj.eng.h)
+    return st
+
+
+def reward_to_go(traj, gamma):
+    _check(lib().rl_reward_to_go(traj.h, C.c_float(gamma)), traj.eng.h)
 
 
 def chain_tabular_q_train(seed=0, n_threads=4, n_periods=10, min_worker_steps=10000, exploration_rate=0.2):

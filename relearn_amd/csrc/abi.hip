@@ -1090,6 +1090,89 @@ int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float
   });
 }
 
+// ---------------------------------------------------------------- PPO / REINFORCE / RewardToGo
+int32_t rl_ppo_config_default(rl_ppo_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    c->opt_steps_per_update = 10;  // PpoConfig::default (ppo.rs:27-41)
+    c->clip_distance = 0.2;
+  });
+}
+
+// PASS_PPO gradient of the clipped surrogate against lp0 -> vec[0..P), sum of min(...) -> vec[P]
+static void run_policy_ppo(rl_mlp *policy, rl_traj *traj, float lo, float hi) {
+  uint32_t P = (uint32_t)policy->P;
+  if (traj->eng->kernel_variant != 1 &&
+      launch_policy_v2(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi)) {
+    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi);
+    launch_mlp_backward(traj, policy, nullptr);
+    launch_reduce(traj, P, true, true, traj->nbA, traj->nbB);
+  }
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_config *cfg,
+                      rl_policy_opt_stats *stats, float *losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(opt && opt->mod == policy, "optimizer does not belong to this module");
+    RL_REQUIRE(cfg, "cfg is NULL");
+    RL_REQUIRE(cfg->opt_steps_per_update <= traj->max_losses, "too many optimisation steps per update");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj), K = cfg->opt_steps_per_update;
+    // initial_log_probs and the logged entropy (ppo.rs:107-118): the PASS_INIT pass stores log pi_0
+    run_policy_gradient(policy, traj);
+    float h0[4];
+    d2h(e, h0, traj->vec + P, sizeof(h0));
+    // clip(1 - d, 1 + d): f64 scalars applied to a Float tensor
+    float lo = (float)(1.0 - cfg->clip_distance), hi = (float)(1.0 + cfg->clip_distance);
+    for (uint64_t k = 0; k < K; ++k) {
+      run_policy_ppo(policy, traj, lo, hi);
+      launch_adam_step(traj, opt, (int)k, Bt);
+    }
+    std::vector<float> h(K ? K : 1, 0.0f);
+    if (K) d2h(e, h.data(), traj->losses, K * sizeof(float));
+    for (auto &v : h) v = -v;  // loss = -mean(min(...))
+    if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
+    if (stats) {
+      stats->entropy = (double)h0[1] / (double)Bt;
+      stats->steps = K;
+      stats->loss_first = K ? (double)h[0] : 0.0;
+      stats->loss_last = K ? (double)h[K - 1] : 0.0;
+    }
+  });
+}
+
+int32_t rl_reinforce_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, rl_policy_opt_stats *stats) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(opt && opt->mod == policy, "optimizer does not belong to this module");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj);
+    // d(-mean(log pi(a) A))/d theta equals the surrogate gradient at ratio = 1 that PASS_INIT computes
+    run_policy_gradient(policy, traj);
+    float h0[4];
+    d2h(e, h0, traj->vec + P, sizeof(h0));
+    launch_adam_step(traj, opt, -1, Bt);
+    if (stats) {
+      stats->entropy = (double)h0[1] / (double)Bt;
+      stats->steps = 1;
+      stats->loss_first = stats->loss_last = -((double)h0[2] / (double)Bt);
+    }
+  });
+}
+
+int32_t rl_reward_to_go(rl_traj *traj, float gamma) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    RL_REQUIRE(traj, "NULL argument");
+    launch_gae(traj, nullptr, gamma, 0.0f);
+  });
+}
+
 // ---------------------------------------------------------------- DQN (src/torch/agents/dqn.rs)
 int32_t rl_dqn_config_default(rl_dqn_config *c) {
   return guarded(nullptr, [&] {

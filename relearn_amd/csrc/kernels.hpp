@@ -8,18 +8,19 @@ void launch_env_observe(rl_env *env, float *d_obs);
 void launch_env_step(rl_env *env);
 void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 void launch_values(rl_traj *traj, const rl_mlp *critic);
-void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);
+void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);  // critic NULL: adv = rtg only
 void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa);
 
 // kernels_update.hip
-enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2, PASS_DQN = 3 };
+enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2, PASS_DQN = 3, PASS_PPO = 4 };
 // PASS_INIT : lp0 <- log pi(.|s); dz <- d(-mean(ratio*A))/dz at theta0; slabB <- {sum A, sum entropy}
 // PASS_EVAL : slabB <- {sum ratio*A, sum KL(pi0||pi)}                      (skipped when *skip_flag != 0)
 // PASS_JVP  : dz <- (diag(p) - p p^T) J v / B_total                         (skipped when *skip_flag != 0)
+// PASS_PPO  : dz <- d(-mean(min(ratio A, clip(ratio, lo, hi) A)))/dz against lp0; slabB <- {sum min(..)}  (ppo.rs:124-137)
 // PASS_DQN  : outputs are action values; dz[a] <- [a == action] 2 (Q_a - target) / B_total with the target in
 //             `adv`; slabB <- {sum (Q_a - target)^2}                        (dqn.rs:316-326)
 void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
-                        const int32_t *d_skip_flag);
+                        const int32_t *d_skip_flag, float clip_lo = 0.0f, float clip_hi = 0.0f);
 void launch_critic_fwd(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
 // J^T dz accumulated per block into slabA (lane = hidden unit, samples broadcast through scalar loads)
 void launch_mlp_backward(rl_traj *traj, const rl_mlp *mlp, const int32_t *d_skip_flag);
@@ -40,7 +41,7 @@ void launch_adam_step_vec(rl_adam *opt, const float *d_grad);
 // returns false when the shape is not supported (caller falls back to the v1 kernels)
 bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total);
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
-                      const int32_t *d_skip_flag);
+                      const int32_t *d_skip_flag, float clip_lo = 0.0f, float clip_hi = 0.0f);
 
 // kernels_dqn.hip
 void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,

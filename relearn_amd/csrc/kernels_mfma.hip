@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(128, 4)
 // Reference semantics: Trpo::update closure + HessianVectorProduct (src/torch/agents/policies/trpo.rs:97-146,
 // src/torch/optimizers/conjugate_gradient.rs:262-339) and Categorical (src/torch/distributions/categorical.rs).
 // ================================================================================================
-constexpr int PIMG = 128 * 12 + 4;  // per-wave f64 image: M_a[j][k] (a*6+k), then db2[0], db2[1], sum0, sum1
+constexpr int PIMG = 128 * 12 + 5;  // per-wave f64 image: M_a[j][k] (a*6+k), then db2[0], db2[1], sum0, sum1, sum2
 
 struct PolicyTile {
   float a0, a1, a2;
@@ -526,7 +526,7 @@ template <int MODE>  // PASS_INIT (gradient), PASS_JVP (Fisher-vector product), 
 __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     k_policy_mfma(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
                   float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
-                  uint32_t P, const int32_t *__restrict__ skip) {
+                  uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   constexpr int D = 5, H = 128, NT = V2_NT, A = 2;
   __shared__ float Ysh[V2_WAVES][32][33];
   __shared__ float Ush[V2_WAVES][32][12];
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
 #pragma unroll
     for (int fg = 0; fg < 3; ++fg) dacc[t][fg] = (f32x4){0, 0, 0, 0};
   const float big = 0x1p126f;
-  double sum0 = 0.0, sum1 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
+  double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
   wave_lds_fence();
 
   auto flush = [&]() {
@@ -698,6 +698,21 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         dz0 = act == 0 ? g : 0.0f;
         dz1 = act == 1 ? g : 0.0f;
         if (op.valid && hf == 0) sum0 += (double)(dq * dq);
+      } else if (MODE == PASS_PPO) {
+        // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
+        log_softmax_lane<2>(z, lp);
+        float l0a = 0.0f;
+        if (op.valid) l0a = lp0[(size_t)act * B + sidx];
+        const float lpa = act == 0 ? lp[0] : lp[1];
+        const float ratio = rl_expf(lpa - l0a);
+        const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
+        const float u1 = ratio * adv, u2 = clipped * adv;
+        const bool inside = ratio >= clip_lo && ratio <= clip_hi;
+        const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
+        const float c = -(gr * ratio) * inv_B;
+        dz0 = op.valid ? c * ((act == 0 ? 1.0f : 0.0f) - rl_expf(lp[0])) : 0.0f;
+        dz1 = op.valid ? c * ((act == 1 ? 1.0f : 0.0f) - rl_expf(lp[1])) : 0.0f;
+        if (op.valid && hf == 0) sum0 += (double)(u1 < u2 ? u1 : u2);
       } else {
       log_softmax_lane<2>(z, lp);
       if (MODE == PASS_INIT) {
@@ -718,6 +733,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         if (op.valid && hf == 0) {
           sum0 += (double)(ratio * adv);
           sum1 += (double)(-ent);
+          sum2 += (double)(lpa * adv);
         }
       } else {  // PASS_EVAL
         float l00 = 0.0f, l01 = 0.0f;
@@ -781,12 +797,14 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
   };
   double r0 = hf == 0 ? sum0 : 0.0, r1 = hf == 0 ? sum1 : 0.0, r2 = hf == 0 ? db2_0 : 0.0, r3 = hf == 0 ? db2_1 : 0.0;
+  double r4 = hf == 0 ? sum2 : 0.0;
 #pragma unroll
   for (int s = 16; s > 0; s >>= 1) {
     r0 = r0 + xlane(r0, s);
     r1 = r1 + xlane(r1, s);
     r2 = r2 + xlane(r2, s);
     r3 = r3 + xlane(r3, s);
+    if (MODE == PASS_INIT) r4 = r4 + xlane(r4, s);
   }
   constexpr int TAIL = MODE == PASS_EVAL ? 0 : H * 12;
   if (lane == 0) {
@@ -794,6 +812,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     acc64[TAIL + 1] = r3;
     acc64[TAIL + 2] = r0;
     acc64[TAIL + 3] = r1;
+    if (MODE == PASS_INIT) acc64[TAIL + 4] = r4;
   }
   __syncthreads();
   auto tot = [&](int src) {
@@ -825,6 +844,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   if (threadIdx.x < 4) {
     double v = 0.0;
     if (MODE != PASS_JVP && threadIdx.x < 2) v = tot(TAIL + 2 + threadIdx.x);
+    if (MODE == PASS_INIT && threadIdx.x == 2) v = tot(TAIL + 4);
     slabB[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
   }
 }
@@ -847,7 +867,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
 
 // gradient (PASS_INIT), Fisher-vector product (PASS_JVP) or loss/KL evaluation (PASS_EVAL) in one launch
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
-                      const int32_t *d_skip) {
+                      const int32_t *d_skip, float clip_lo, float clip_hi) {
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
   ProfScope ps(traj->eng, RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
@@ -856,11 +876,12 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   uint32_t P = (uint32_t)policy->P;
 #define PLAUNCH(MM)                                                                                              \
   hipLaunchKernelGGL((k_policy_mfma<MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0, traj->slabA, \
-                     traj->slabB, inv_B, P, d_skip)
+                     traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
   if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
   if (mode == PASS_INIT) PLAUNCH(PASS_INIT);
   else if (mode == PASS_JVP) PLAUNCH(PASS_JVP);
   else if (mode == PASS_DQN) PLAUNCH(PASS_DQN);
+  else if (mode == PASS_PPO) PLAUNCH(PASS_PPO);
   else PLAUNCH(PASS_EVAL);
 #undef PLAUNCH
   return true;

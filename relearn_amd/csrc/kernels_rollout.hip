@@ -141,12 +141,29 @@ __global__ void __launch_bounds__(256) k_mlp_forward_rows(const float *__restric
 // Algorithmic traffic: r 4 + V 4 + flag 1 in, adv 4 + rtg 4 out = 17 B/sample.
 template <int D>
 __global__ void __launch_bounds__(256) k_gae_scan(TrajDev tr, const float *__restrict__ critic, int H, float gamma,
-                                                  float lambda) {
+                                                  float lambda, int rtg_only) {
   const uint32_t n = tr.n, T = tr.T;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float disc = lambda * gamma;
   float adv_next = 0.0f, rtg_next = 0.0f;
+  if (rtg_only) {
+    // RewardToGo critic (critics/rtg.rs:28-33): the "advantage" is the empirical discounted return
+    for (uint32_t t = T; t-- > 0;) {
+      size_t o = (size_t)t * n + i;
+      float r = tr.reward[o], g;
+      if (tr.flag[o] != RL_SUCC_CONTINUE || t == T - 1) {
+        g = r;
+      } else {
+        float pg = rtg_next * gamma;
+        g = r + pg;
+      }
+      tr.adv[o] = g;
+      tr.rtg[o] = g;
+      rtg_next = g;
+    }
+    return;
+  }
   float v_next = tr.values[(size_t)T * n + i];
   for (uint32_t t = T; t-- > 0;) {
     size_t o = (size_t)t * n + i;
@@ -249,11 +266,13 @@ void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) 
   ProfScope ps(traj->eng, RL_K_GAE);
   uint32_t n = traj->d.n;
   if (traj->d.D == 5)
-    hipLaunchKernelGGL(k_gae_scan<5>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d, critic->d_params,
-                       (int)critic->hidden, gamma, lambda);
+    hipLaunchKernelGGL(k_gae_scan<5>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d,
+                       critic ? critic->d_params : (const float *)nullptr, critic ? (int)critic->hidden : 0, gamma, lambda,
+                       critic ? 0 : 1);
   else
-    hipLaunchKernelGGL(k_gae_scan<4>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d, critic->d_params,
-                       (int)critic->hidden, gamma, lambda);
+    hipLaunchKernelGGL(k_gae_scan<4>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d,
+                       critic ? critic->d_params : (const float *)nullptr, critic ? (int)critic->hidden : 0, gamma, lambda,
+                       critic ? 0 : 1);
 }
 
 void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa) {

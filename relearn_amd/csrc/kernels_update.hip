@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256) k_policy_pass(TrajDev tr, const float *__
                                                      const float *__restrict__ tangent, int H,
                                                      float *__restrict__ lp0, float *__restrict__ dz,
                                                      double *__restrict__ slabB, float inv_B,
-                                                     const int32_t *__restrict__ skip) {
+                                                     const int32_t *__restrict__ skip, float clip_lo,
+                                                     float clip_hi) {
   constexpr int A = 2;
   __shared__ double red[256];
   if (skip != nullptr && *skip != 0) return;
@@ -35,7 +36,7 @@ __global__ void __launch_bounds__(256) k_policy_pass(TrajDev tr, const float *__
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   // per-sample terms are f32 (as the reference's Kind::Float tensors); their sum over samples is carried
   // in f64 so that the mean is rounded once (what a pairwise/blocked torch reduction approximates)
-  double s0 = 0.0, s1 = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) {
     float x[D];
 #pragma unroll
@@ -92,8 +93,28 @@ __global__ void __launch_bounds__(256) k_policy_pass(TrajDev tr, const float *__
         continue;
       }
       log_softmax_lane<A>(z, lp);
+      if (MODE == PASS_PPO) {
+        // clipped surrogate of Ppo::update (policies/ppo.rs:124-137) and its torch-autograd gradient: minimum()
+        // splits a tie between its arguments, clamp() passes the gradient inside [lo, hi] (bounds included)
+        float l0a = lp0[(size_t)act * B + b];
+        float lpa = act == 0 ? lp[0] : lp[1];
+        float ratio = rl_expf(lpa - l0a);
+        float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
+        float u1 = ratio * adv, u2 = clipped * adv;
+        bool inside = ratio >= clip_lo && ratio <= clip_hi;
+        float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
+        float c = -(gr * ratio) * inv_B;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          float ind = a == act ? 1.0f : 0.0f;
+          dz[(size_t)a * B + b] = c * (ind - rl_expf(lp[a]));
+        }
+        s0 += (double)(u1 < u2 ? u1 : u2);
+        continue;
+      }
       if (MODE == PASS_INIT) {
         float lpa = act == 0 ? lp[0] : lp[1];
+        s2 += (double)(lpa * adv);
         float ratio = rl_expf(lpa - lpa);
         float c = -(ratio * adv) * inv_B;
         float ent = 0.0f;
@@ -130,10 +151,11 @@ __global__ void __launch_bounds__(256) k_policy_pass(TrajDev tr, const float *__
   if (MODE != PASS_JVP) {
     double t0 = block_sum<256>(s0, red);
     double t1 = block_sum<256>(s1, red);
+    double t2 = block_sum<256>(s2, red);
     if (threadIdx.x == 0) {
       slabB[blockIdx.x * 4 + 0] = t0;
       slabB[blockIdx.x * 4 + 1] = t1;
-      slabB[blockIdx.x * 4 + 2] = 0.0;
+      slabB[blockIdx.x * 4 + 2] = t2;
       slabB[blockIdx.x * 4 + 3] = 0.0;
     }
   }
@@ -523,7 +545,7 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
 
 // ---------------------------------------------------------------- launchers
 void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
-                        const int32_t *d_skip) {
+                        const int32_t *d_skip, float clip_lo, float clip_hi) {
   ProfScope ps(traj->eng, RL_K_POLICY_PASS);
   RL_REQUIRE(policy->out_dim == 2, "policy pass: only 2-action categorical policies are built");
   float inv_B = 1.0f / (float)B_total;
@@ -532,17 +554,19 @@ void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const flo
   int H = (int)policy->hidden;
 #define PASS(DD, MM)                                                                                           \
   hipLaunchKernelGGL((k_policy_pass<DD, MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, H, traj->lp0, \
-                     traj->dz, traj->slabB, inv_B, d_skip)
+                     traj->dz, traj->slabB, inv_B, d_skip, clip_lo, clip_hi)
   if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
   if (traj->d.D == 5) {
     if (mode == PASS_INIT) PASS(5, PASS_INIT);
     else if (mode == PASS_EVAL) PASS(5, PASS_EVAL);
     else if (mode == PASS_DQN) PASS(5, PASS_DQN);
+    else if (mode == PASS_PPO) PASS(5, PASS_PPO);
     else PASS(5, PASS_JVP);
   } else {
     if (mode == PASS_INIT) PASS(4, PASS_INIT);
     else if (mode == PASS_EVAL) PASS(4, PASS_EVAL);
     else if (mode == PASS_DQN) PASS(4, PASS_DQN);
+    else if (mode == PASS_PPO) PASS(4, PASS_PPO);
     else PASS(4, PASS_JVP);
   }
 #undef PASS

@@ -232,6 +232,53 @@ def dqn_case(dtype, D=5, H=8, A=2, n=30, steps=5, seed=23):
     }
 
 
+def ppo_case(dtype, D=5, H=8, A=2, n=40, steps=4, seed=31, clip=0.2):
+    """Ppo::update (policies/ppo.rs:97-146) and Reinforce::update's loss (reinforce.rs:71-78) with real autograd.
+    The parameters are perturbed away from the ones that produced the initial log-probs so that ratios fall on
+    both sides of the clip range."""
+    g = torch.Generator().manual_seed(seed)
+    P = H * D + H + A * H + A
+    params_old = (torch.rand(P, generator=g, dtype=torch.float64) * 2.0 - 1.0).to(dtype)
+    params0 = (params_old.double() + (torch.rand(P, generator=g, dtype=torch.float64) - 0.5) * 0.6).to(dtype)
+    x = (torch.randn(n, D, generator=g, dtype=torch.float64)).to(dtype)
+    actions = torch.randint(0, A, (n,), generator=g)
+    adv = torch.randn(n, generator=g, dtype=torch.float64).to(dtype)
+    adv[0] = 0.0  # a zero advantage: both branches of minimum() tie
+    with torch.no_grad():
+        lp_old = torch.log_softmax(mlp_forward(params_old, x, D, H, A), -1).gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+    params = params0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([params], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    losses, grad0, ratios0 = [], None, None
+    for k in range(steps):
+        lp = torch.log_softmax(mlp_forward(params, x, D, H, A), -1).gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+        ratio = (lp - lp_old).exp()
+        clipped = ratio.clip(1.0 - clip, 1.0 + clip)
+        loss = -torch.minimum(ratio * adv, clipped * adv).mean()
+        opt.zero_grad()
+        loss.backward()
+        if k == 0:
+            grad0 = params.grad.detach().clone()
+            ratios0 = ratio.detach().clone()
+        losses.append(float(loss.detach()))
+        opt.step()
+    # REINFORCE at params0
+    pr = params0.clone().requires_grad_(True)
+    lsm = torch.log_softmax(mlp_forward(pr, x, D, H, A), -1)
+    lp = lsm.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+    rloss = -(lp * adv).mean()
+    rloss.backward()
+    entropy = -(lsm.detach() * lsm.detach().exp()).sum(-1).mean()
+    return {
+        "dims": [D, H, A], "n": n, "dtype": str(dtype).replace("torch.", ""), "steps": steps, "clip": clip,
+        "params_old": params_old.double().tolist(), "params0": params0.double().tolist(), "obs": x.double().tolist(),
+        "actions": actions.tolist(), "adv": adv.double().tolist(), "logp_old": lp_old.double().tolist(),
+        "ratios0": ratios0.double().tolist(), "grad0": grad0.double().tolist(), "losses": losses,
+        "params_final": params.detach().double().tolist(),
+        "reinforce_loss": float(rloss.detach()), "reinforce_grad": pr.grad.double().tolist(),
+        "entropy0": float(entropy),
+    }
+
+
 def main():
     data = {
         "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
@@ -252,6 +299,14 @@ def main():
     with open(os.path.join(HERE, "torch_golden_dqn.json"), "w") as f:
         json.dump(dqn, f)
     print("wrote torch_golden_dqn.json")
+    ppo = {
+        "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
+        "ppo_f32": ppo_case(torch.float32),
+        "ppo_f64": ppo_case(torch.float64),
+    }
+    with open(os.path.join(HERE, "torch_golden_ppo.json"), "w") as f:
+        json.dump(ppo, f)
+    print("wrote torch_golden_ppo.json")
 
 
 if __name__ == "__main__":
