@@ -186,4 +186,29 @@ RL_HD float rl_logf(float x) {
   return s * (hfsq + R) + dk * LN2LO - hfsq + f + dk * LN2HI;
 }
 
+/* ---- f32 sigmoid / tanh (GRU gates, torch gru_cell: sigmoid_, tanh_) ---------------------- */
+/* 1 / (1 + exp(-x)); exp(-x) = +inf for x < -88.7 gives exactly 0, exp(-x) = 0 gives exactly 1. */
+RL_HD float rl_sigmoidf(float x) { return 1.0f / (1.0f + rl_expf(-x)); }
+
+/* tanh: odd polynomial below 0.25 (truncation error < 4e-11 relative), (1 - e^-2|x|) / (1 + e^-2|x|) above;
+ * exactly +-1 once e^-2|x| underflows below half an ulp of 1 (|x| > 9.02). */
+RL_HD float rl_tanhf(float x) {
+  if (x != x) return x;
+  float ax = x < 0.0f ? -x : x;
+  float y;
+  if (ax < 0.25f) {
+    float x2 = ax * ax;
+    float p = -8.8632355e-03f;                 /* -1382/155925 */
+    p = 2.1869488e-02f + x2 * p;               /*  62/2835 */
+    p = -5.3968254e-02f + x2 * p;              /* -17/315 */
+    p = 1.3333334e-01f + x2 * p;               /*  2/15 */
+    p = -3.3333334e-01f + x2 * p;              /* -1/3 */
+    y = ax + ax * (x2 * p);
+  } else {
+    float t = rl_expf(-2.0f * ax);
+    y = (1.0f - t) / (1.0f + t);
+  }
+  return x < 0.0f ? -y : y;
+}
+
 #endif /* RL_DETMATH_H */

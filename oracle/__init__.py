@@ -90,6 +90,17 @@ class Features(C.Structure):
                 ("rewards", C.POINTER(C.c_float)), ("src_index", C.POINTER(C.c_uint64))]
 
 
+class GruShape(C.Structure):
+    _fields_ = [("in_dim", C.c_uint32), ("hidden", C.c_uint32), ("mlp_hidden", C.c_uint32), ("out_dim", C.c_uint32)]
+
+
+class ChainLanes(C.Structure):
+    _fields_ = [("env", Chain), ("limit_kind", C.c_int), ("max_steps", C.c_uint64), ("seed_env", C.c_uint64),
+                ("seed_actor", C.c_uint64), ("n_lanes", C.c_uint64), ("lane_offset", C.c_uint64),
+                ("state", C.POINTER(C.c_uint64)), ("steps_remaining", C.POINTER(C.c_uint64)),
+                ("reset_count", C.POINTER(C.c_uint64)), ("t_global", C.c_uint64)]
+
+
 class Lanes(C.Structure):
     _fields_ = [("env", CartPole), ("limit_kind", C.c_int), ("max_steps", C.c_uint64), ("seed_env", C.c_uint64),
                 ("seed_actor", C.c_uint64), ("n_lanes", C.c_uint64), ("lane_offset", C.c_uint64),
@@ -302,6 +313,37 @@ def _declare(L):
     L.oracle_lanes_to_vecbuffer.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_uint8),
                                             P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int, P(C.c_uint64)]
     L.oracle_lanes_to_vecbuffer.restype = P(VecBuffer)
+    L.oracle_gru_num_params.argtypes = [GruShape]
+    L.oracle_gru_num_params.restype = C.c_uint64
+    L.oracle_gru_init.argtypes = [GruShape, C.c_uint64, P(C.c_float)]
+    L.oracle_gru_step_f32.argtypes = [GruShape, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]
+    L.oracle_gru_step_f64.argtypes = [GruShape, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]
+    L.oracle_gru_seq_forward_f32.argtypes = [GruShape, P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float),
+                                             P(C.c_uint8), P(C.c_float), P(C.c_float), P(C.c_float)]
+    L.oracle_gru_seq_forward_f64.argtypes = [GruShape, P(C.c_double), C.c_uint64, C.c_uint64, P(C.c_double),
+                                             P(C.c_uint8), P(C.c_double), P(C.c_double), P(C.c_double)]
+    L.oracle_gru_seq_backward_f32.argtypes = [GruShape, P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float),
+                                              P(C.c_uint8), P(C.c_float), P(C.c_float)]
+    L.oracle_gru_seq_backward_f64.argtypes = [GruShape, P(C.c_double), C.c_uint64, C.c_uint64, P(C.c_double),
+                                              P(C.c_uint8), P(C.c_double), P(C.c_double)]
+    L.oracle_chain_lanes_new.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_uint64]
+    L.oracle_chain_lanes_new.restype = P(ChainLanes)
+    L.oracle_chain_lanes_free.argtypes = [P(ChainLanes)]
+    L.oracle_chain_lanes_reset.argtypes = [P(ChainLanes)]
+    L.oracle_chain_lanes_obs_dim.argtypes = [P(ChainLanes)]
+    L.oracle_chain_lanes_obs_dim.restype = C.c_uint32
+    L.oracle_chain_lanes_observe.argtypes = [P(ChainLanes), P(C.c_float)]
+    L.oracle_chain_lanes_get_state.argtypes = [P(ChainLanes), P(C.c_uint64), P(C.c_uint64), P(C.c_uint64)]
+    L.oracle_chain_lanes_step.argtypes = [P(ChainLanes), P(C.c_uint8), P(C.c_float), P(C.c_uint8), P(C.c_float),
+                                          P(C.c_float)]
+    L.oracle_chain_lanes_rollout_gru.argtypes = [P(ChainLanes), GruShape, P(C.c_float), C.c_uint64, P(C.c_float),
+                                                 P(C.c_uint8), P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int]
+    L.oracle_seq_gae.argtypes = [C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8),
+                                 C.c_float, C.c_float, P(C.c_float), P(C.c_float)]
+    L.oracle_seq_policy_dlogits_f32.argtypes = [C.c_uint64, P(C.c_float), P(C.c_uint8), P(C.c_float), P(C.c_float),
+                                                C.c_int, C.c_float, C.c_float, P(C.c_float), P(C.c_float),
+                                                P(C.c_double), P(C.c_double)]
     L.oracle_policy_logp_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), C.c_uint64,
                                          P(C.c_float), P(C.c_float)]
     L.oracle_policy_logp_f64.argtypes = [MlpShape, P(C.c_double), P(C.c_double), P(C.c_int64), C.c_uint64,
@@ -594,3 +636,117 @@ class DqnSim:
                                          self.td, f32p(losses))
         assert rc == 0
         return losses[:opt_steps]
+
+
+# ---------------------------------------------------------------------------------------------
+# recurrent configuration (oracle/seq.c)
+
+
+def gru_init(shape, seed):
+    p = np.zeros(int(lib().oracle_gru_num_params(shape)), dtype=np.float32)
+    lib().oracle_gru_init(shape, seed, f32p(p))
+    return p
+
+
+def gru_seq_forward(shape, params, traj, f64=False, want_succ=True):
+    """teacher-forced forward over a lane trajectory dict; returns (out [A][T][n], succ_out or None)"""
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    dt = np.float64 if f64 else np.float32
+    ptr = f64p if f64 else f32p
+    out = np.zeros((shape.out_dim, T, n), dtype=dt)
+    succ = np.zeros((shape.out_dim, T, n), dtype=dt) if want_succ else None
+    fn = lib().oracle_gru_seq_forward_f64 if f64 else lib().oracle_gru_seq_forward_f32
+    fn(shape, ptr(np.ascontiguousarray(params, dtype=dt)), n, T, ptr(np.ascontiguousarray(obs, dtype=dt)),
+       u8p(traj["flag"]), ptr(np.ascontiguousarray(traj["term_obs"], dtype=dt)), ptr(out),
+       ptr(succ) if want_succ else None)
+    return out, succ
+
+
+def gru_seq_backward(shape, params, traj, dout, f64=False):
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    dt = np.float64 if f64 else np.float32
+    ptr = f64p if f64 else f32p
+    g = np.zeros(len(params), dtype=dt)
+    fn = lib().oracle_gru_seq_backward_f64 if f64 else lib().oracle_gru_seq_backward_f32
+    fn(shape, ptr(np.ascontiguousarray(params, dtype=dt)), n, T, ptr(np.ascontiguousarray(obs, dtype=dt)),
+       u8p(traj["flag"]), ptr(np.ascontiguousarray(dout, dtype=dt)), ptr(g))
+    return g
+
+
+def seq_gae(values, succ_values, traj, gamma, lam):
+    T, n = traj["reward"].shape
+    adv = np.zeros((T, n), dtype=np.float32)
+    rtg = np.zeros((T, n), dtype=np.float32)
+    lib().oracle_seq_gae(n, T, f32p(np.ascontiguousarray(values, dtype=np.float32)),
+                         f32p(np.ascontiguousarray(succ_values, dtype=np.float32)), f32p(traj["reward"]),
+                         u8p(traj["flag"]), gamma, lam, f32p(adv), f32p(rtg))
+    return adv, rtg
+
+
+def seq_policy_dlogits(logits, actions, adv, logp0=None, clip=None):
+    """logits [2][T][n] -> (dlogits [2][T][n], logp [T][n], loss_sum, entropy_sum); PPO mode when logp0 is given"""
+    A, T, n = logits.shape
+    B = T * n
+    dl = np.zeros((A, T, n), dtype=np.float32)
+    lp = np.zeros((T, n), dtype=np.float32)
+    loss, ent = C.c_double(), C.c_double()
+    mode = 0 if logp0 is None else 1
+    lo, hi = (0.0, 0.0) if clip is None else (np.float32(1.0 - clip), np.float32(1.0 + clip))
+    lib().oracle_seq_policy_dlogits_f32(B, f32p(np.ascontiguousarray(logits, dtype=np.float32)),
+                                        u8p(np.ascontiguousarray(actions, dtype=np.uint8)),
+                                        f32p(np.ascontiguousarray(adv, dtype=np.float32)),
+                                        f32p(np.ascontiguousarray(logp0, dtype=np.float32)) if mode else None,
+                                        mode, lo, hi, f32p(dl), f32p(lp), C.byref(loss), C.byref(ent))
+    return dl, lp, loss.value, ent.value
+
+
+class ChainLaneSim:
+    """numpy view of oracle_chain_lanes: Chain (+ step limit) over lanes with the engine's stream discipline
+    (slip draw of global step t = word t of the lane's env stream; actor draw = word t of its actor stream)."""
+
+    def __init__(self, n_lanes, max_steps=100, limit=LIMIT_LATENT, lane_offset=0, seed_env=0, seed_actor=1, size=5):
+        self.ptr = lib().oracle_chain_lanes_new(size, limit, max_steps, n_lanes, lane_offset, seed_env, seed_actor)
+        self.n = n_lanes
+        self.D = int(lib().oracle_chain_lanes_obs_dim(self.ptr))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().oracle_chain_lanes_free(self.ptr)
+            self.ptr = None
+
+    def reset(self):
+        lib().oracle_chain_lanes_reset(self.ptr)
+
+    def observe(self):
+        obs = np.zeros((self.D, self.n), dtype=np.float32)
+        lib().oracle_chain_lanes_observe(self.ptr, f32p(obs))
+        return obs
+
+    def get_state(self):
+        a, b, c = (np.zeros(self.n, dtype=np.uint64) for _ in range(3))
+        lib().oracle_chain_lanes_get_state(self.ptr, u64p(a), u64p(b), u64p(c))
+        return a, b, c
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        reward = np.zeros(self.n, dtype=np.float32)
+        flag = np.zeros(self.n, dtype=np.uint8)
+        obs = np.zeros((self.D, self.n), dtype=np.float32)
+        term = np.zeros((self.D, self.n), dtype=np.float32)
+        lib().oracle_chain_lanes_step(self.ptr, u8p(actions), f32p(reward), u8p(flag), f32p(obs), f32p(term))
+        return reward, flag, obs, term
+
+    def rollout_gru(self, shape, params, T, threads=8):
+        n, D = self.n, self.D
+        obs = np.zeros((D, T + 1, n), dtype=np.float32)
+        action = np.zeros((T, n), dtype=np.uint8)
+        reward = np.zeros((T, n), dtype=np.float32)
+        flag = np.zeros((T, n), dtype=np.uint8)
+        term = np.zeros((D, T, n), dtype=np.float32)
+        lib().oracle_chain_lanes_rollout_gru(self.ptr, shape, f32p(params), T, f32p(obs), u8p(action), f32p(reward),
+                                             u8p(flag), f32p(term), threads)
+        return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)

@@ -359,6 +359,48 @@ double oracle_exploration_rate(int kind, double start, double end, uint64_t peri
                                int training);
 oracle_bound oracle_collection_update_size(int kind, uint64_t first, uint64_t rest, uint64_t global_steps);
 
+/* ---------------------------------------------------------------- recurrent configuration (seq.c, seq_impl.inc) */
+typedef struct { uint32_t in_dim, hidden, mlp_hidden, out_dim; } oracle_gru_shape; /* GruMlpConfig (modules/mod.rs:14) */
+/* flat parameter order = trainable_variables(): W_ih [3H,in], W_hh [3H,H], b_ih, b_hh, W1 [H2,H], b1, W2 [A,H2], b2 */
+uint64_t oracle_gru_num_params(oracle_gru_shape s);
+void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params);
+void oracle_gru_step_f32(oracle_gru_shape s, const float *params, const float *x, float *h, float *out);
+void oracle_gru_step_f64(oracle_gru_shape s, const double *params, const double *x, double *h, double *out);
+void oracle_gru_seq_forward_f32(oracle_gru_shape s, const float *params, uint64_t n, uint64_t T, const float *obs,
+                                const uint8_t *flag, const float *term_obs, float *out, float *succ_out);
+void oracle_gru_seq_forward_f64(oracle_gru_shape s, const double *params, uint64_t n, uint64_t T, const double *obs,
+                                const uint8_t *flag, const double *term_obs, double *out, double *succ_out);
+void oracle_gru_seq_backward_f32(oracle_gru_shape s, const float *params, uint64_t n, uint64_t T, const float *obs,
+                                 const uint8_t *flag, const float *dout, float *grad_out);
+void oracle_gru_seq_backward_f64(oracle_gru_shape s, const double *params, uint64_t n, uint64_t T, const double *obs,
+                                 const uint8_t *flag, const double *dout, double *grad_out);
+
+typedef struct {
+  oracle_chain env;
+  int limit_kind;
+  uint64_t max_steps, seed_env, seed_actor, n_lanes, lane_offset;
+  uint64_t *state, *steps_remaining, *reset_count;
+  uint64_t t_global;
+} oracle_chain_lanes;
+oracle_chain_lanes *oracle_chain_lanes_new(uint64_t size, int limit_kind, uint64_t max_steps, uint64_t n_lanes,
+                                           uint64_t lane_offset, uint64_t seed_env, uint64_t seed_actor);
+void oracle_chain_lanes_free(oracle_chain_lanes *l);
+void oracle_chain_lanes_reset(oracle_chain_lanes *l);
+uint32_t oracle_chain_lanes_obs_dim(const oracle_chain_lanes *l);
+void oracle_chain_lanes_observe(const oracle_chain_lanes *l, float *obs_soa);
+void oracle_chain_lanes_get_state(const oracle_chain_lanes *l, uint64_t *state, uint64_t *steps_remaining,
+                                  uint64_t *reset_count);
+void oracle_chain_lanes_step(oracle_chain_lanes *l, const uint8_t *actions, float *reward, uint8_t *flag,
+                             float *obs_next_soa, float *term_obs_soa);
+void oracle_chain_lanes_rollout_gru(oracle_chain_lanes *l, oracle_gru_shape ps, const float *params, uint64_t T,
+                                    float *obs, uint8_t *action, float *reward, uint8_t *flag, float *term_obs,
+                                    int n_threads);
+void oracle_seq_gae(uint64_t n, uint64_t T, const float *values, const float *succ_values, const float *reward,
+                    const uint8_t *flag, float gamma, float lambda, float *adv_out, float *rtg_out);
+void oracle_seq_policy_dlogits_f32(uint64_t B, const float *logits, const uint8_t *actions, const float *adv,
+                                   const float *logp0, int mode, float clip_lo, float clip_hi, float *dlogits,
+                                   float *logp_out, double *loss_sum_out, double *entropy_sum_out);
+
 /* ---------------------------------------------------------------- CPU baseline (simulation/train.rs:68-186) */
 typedef struct {
   double rollout_seconds, update_seconds;

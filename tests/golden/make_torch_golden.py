@@ -279,6 +279,63 @@ def ppo_case(dtype, D=5, H=8, A=2, n=40, steps=4, seed=31, clip=0.2):
     }
 
 
+def gru_case(dtype, D=3, H=4, H2=5, A=2, n=3, T=7, seed=41):
+    """Chain<Gru, Mlp> (modules/chain.rs:127-186) over lane trajectories with episode boundaries: per-step outputs
+    (torch.gru_cell, relu, two Linear layers), successor outputs at cut episodes, and the gradient of
+    sum(dout * out) through time by autograd.  Flat parameter order = trainable_variables()."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = [3 * H * D, 3 * H * H, 3 * H, 3 * H, H2 * H, H2, A * H2, A]
+    P = sum(sizes)
+    params = ((torch.rand(P, generator=g, dtype=torch.float64) * 2 - 1) * 0.7).to(dtype).requires_grad_(True)
+    obs = torch.randn(D, T + 1, n, generator=g, dtype=torch.float64).to(dtype)
+    term_obs = torch.randn(D, T, n, generator=g, dtype=torch.float64).to(dtype)
+    flag = torch.zeros(T, n, dtype=torch.int64)
+    flag[2, 0] = 1   # Terminate
+    flag[4, 0] = 2   # Interrupt
+    flag[3, 1] = 2
+    flag[T - 1, 2] = 1
+    dout = torch.randn(A, T, n, generator=g, dtype=torch.float64).to(dtype)
+    o = 0
+    parts = []
+    for sz in sizes:
+        parts.append(params[o:o + sz])
+        o += sz
+    Wih, Whh, bih, bhh = parts[0].reshape(3 * H, D), parts[1].reshape(3 * H, H), parts[2], parts[3]
+    W1, b1, W2, b2 = parts[4].reshape(H2, H), parts[5], parts[6].reshape(A, H2), parts[7]
+
+    def head(h):
+        return torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(torch.relu(h), W1, b1)), W2, b2)
+
+    out = torch.zeros(A, T, n, dtype=dtype)
+    succ = torch.zeros(A, T, n, dtype=dtype)
+    outs = []
+    for i in range(n):
+        h = torch.zeros(1, H, dtype=dtype)
+        for t in range(T):
+            h = torch.gru_cell(obs[:, t, i].unsqueeze(0), h, Wih, Whh, bih, bhh)
+            y = head(h).squeeze(0)
+            outs.append((i, t, y))
+            f = int(flag[t, i])
+            if f == 2 or (f == 0 and t == T - 1):
+                xs = term_obs[:, t, i] if f == 2 else obs[:, T, i]
+                hs = torch.gru_cell(xs.unsqueeze(0), h, Wih, Whh, bih, bhh)
+                succ[:, t, i] = head(hs).squeeze(0).detach()
+            if f != 0:
+                h = torch.zeros(1, H, dtype=dtype)
+    loss = 0
+    for i, t, y in outs:
+        out[:, t, i] = y.detach()
+        loss = loss + (dout[:, t, i] * y).sum()
+    loss.backward()
+    return {
+        "dims": [D, H, H2, A], "n": n, "T": T, "dtype": str(dtype).replace("torch.", ""),
+        "params": params.detach().double().tolist(), "obs": obs.double().flatten().tolist(),
+        "term_obs": term_obs.double().flatten().tolist(), "flag": flag.flatten().tolist(),
+        "dout": dout.double().flatten().tolist(), "out": out.double().flatten().tolist(),
+        "succ_out": succ.double().flatten().tolist(), "grad": params.grad.double().tolist(),
+    }
+
+
 def main():
     data = {
         "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
@@ -307,6 +364,14 @@ def main():
     with open(os.path.join(HERE, "torch_golden_ppo.json"), "w") as f:
         json.dump(ppo, f)
     print("wrote torch_golden_ppo.json")
+    gru = {
+        "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
+        "gru_f32": gru_case(torch.float32),
+        "gru_f64": gru_case(torch.float64),
+    }
+    with open(os.path.join(HERE, "torch_golden_gru.json"), "w") as f:
+        json.dump(gru, f)
+    print("wrote torch_golden_gru.json")
 
 
 if __name__ == "__main__":
