@@ -129,7 +129,7 @@ typedef struct {
 int32_t rl_cartpole_params_default(rl_cartpole_params *p);
 
 typedef struct {
-  int32_t kind;          /* RL_ENV_CARTPOLE */
+  int32_t kind;          /* RL_ENV_CARTPOLE | RL_ENV_CHAIN (Chain::default, src/envs/chain.rs:38-45: obs = one-hot(5)) */
   int32_t limit_kind;    /* RL_LIMIT_* : `env.wrap(VisibleStepLimit::new(max_steps))` */
   uint64_t max_steps;    /* max_steps_per_episode (< 2^32) */
   uint64_t n_lanes;      /* lanes resident on THIS engine */
@@ -137,6 +137,7 @@ typedef struct {
   uint64_t seed_env;     /* env stream seed   (the `rng_env` of Steps, src/simulation/steps.rs:15-28) */
   uint64_t seed_actor;   /* actor stream seed (the `rng_actor` of Steps) */
   rl_cartpole_params cartpole;
+  uint64_t chain_size;   /* RL_ENV_CHAIN: number of states (Chain::default: 5; the kernels are built for 5); 0 = 5 */
 } rl_env_config;
 
 int32_t rl_env_create(rl_engine *engine, const rl_env_config *cfg, rl_env **out);
@@ -178,6 +179,16 @@ int32_t rl_params_set(rl_mlp *mlp, const float *host, uint64_t n);
 /* Forward::forward on host rows [n_rows][in_dim] -> [n_rows][out_dim] (test/utility path) */
 int32_t rl_mlp_forward(rl_mlp *mlp, const float *rows, uint64_t n_rows, float *out);
 
+/* Recurrent module `GruMlpConfig = ChainConfig<GruConfig, MlpConfig>` (src/torch/modules/mod.rs:14;
+ * chain.rs:12-56; seq/rnn/mod.rs:20-45,223-257; seq/rnn/gru.rs:20-98): in_dim -> GRU(gru_hidden) -> ReLU ->
+ * Linear(gru_hidden, mlp_hidden) -> ReLU -> Linear(mlp_hidden, out_dim).  The handle type is shared with the MLP:
+ * every entry point that takes a module dispatches on its kind.  Flat parameter order = trainable_variables():
+ * W_ih [3H, in] (gate rows r, z, n), W_hh [3H, H], b_ih [3H], b_hh [3H], then the MLP's kernel/bias pairs.
+ * Built for gru_hidden = mlp_hidden = 128, in_dim = 5, out_dim in {1, 2}; lanes in multiples of 32.
+ * rl_mlp_init: Glorot-uniform W_ih, orthogonal W_hh, zero biases (RnnBaseConfig::default), Linear::new for the MLP. */
+int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden,
+                          uint32_t out_dim, rl_mlp **out);
+
 /* ---------------------------------------------------------------------------------------------
  * Trajectory store (replaces VecBuffer + LazyHistoryFeatures: src/agents/buffers/vec.rs:15-143,
  * src/torch/agents/features.rs:48-213 — trajectories are born in HBM, no H2D per update). */
@@ -206,6 +217,10 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 /* critic.advantages + reward_to_go (src/torch/agents/critics/mod.rs:101-199; opt.rs:95-104).
  * gamma = min(max_discount_factor, env discount) as f32 (opt.rs:73), lambda f32 (critics/mod.rs:78). */
 int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);
+/* SeqPacked::seq_packed of a recurrent module on a trajectory (modules/chain.rs:151-161): outputs for every step,
+ * host [out_dim][T][n]; succ_out (may be NULL): outputs at the successor observation of every cut episode
+ * (Interrupt / horizon), 0 elsewhere.  The recurrent state restarts at t = 0 and after every episode end. */
+int32_t rl_seq_forward(rl_mlp *module, rl_traj *traj, float *out, float *succ_out);
 
 /* ---------------------------------------------------------------------------------------------
  * TRPO policy update: Trpo::update (src/torch/agents/policies/trpo.rs:97-164) =

@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
     "rl_mlp_create", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_params_get", "rl_params_set",
-    "rl_mlp_forward",
+    "rl_mlp_forward", "rl_gru_mlp_create", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
@@ -69,7 +69,7 @@ class CartPoleParams(C.Structure):
 class EnvConfig(C.Structure):
     _fields_ = [("kind", C.c_int32), ("limit_kind", C.c_int32), ("max_steps", C.c_uint64), ("n_lanes", C.c_uint64),
                 ("lane_offset", C.c_uint64), ("seed_env", C.c_uint64), ("seed_actor", C.c_uint64),
-                ("cartpole", CartPoleParams)]
+                ("cartpole", CartPoleParams), ("chain_size", C.c_uint64)]
 
 
 class TrpoConfig(C.Structure):
@@ -142,7 +142,8 @@ def _register(obj):
 @atexit.register
 def _close_all():
     objs = list(_live)
-    order = {"Dqn": -1, "Adam": 0, "Trajectory": 1, "CartPoleEnv": 2, "Mlp": 3, "Engine": 4}
+    order = {"Dqn": -1, "Adam": 0, "Trajectory": 1, "CartPoleEnv": 2, "ChainEnv": 2, "Mlp": 3, "GruMlp": 3,
+             "Engine": 4}
     for o in sorted(objs, key=lambda o: order.get(type(o).__name__, 2)):
         o.close()
 
@@ -287,6 +288,68 @@ class CartPoleEnv(_Handle):
         _check(lib().rl_env_set_state(self.h, sp, np_, rp, cp), self.eng.h)
 
 
+class ChainEnv(_Handle):
+    """N Chain lanes wrapped in a step limit — `Chain::default().wrap(LatentStepLimit::new(100))`."""
+
+    def __init__(self, engine, n_lanes, max_steps=100, limit=LIMIT_LATENT, lane_offset=0, seed_env=0, seed_actor=1):
+        self.eng = engine
+        cfg = EnvConfig()
+        cfg.kind = ENV_CHAIN
+        cfg.limit_kind = limit
+        cfg.max_steps = max_steps
+        cfg.n_lanes = n_lanes
+        cfg.lane_offset = lane_offset
+        cfg.seed_env = seed_env
+        cfg.seed_actor = seed_actor
+        cfg.cartpole = cartpole_params_default()
+        cfg.chain_size = 5
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _check(lib().rl_env_create(engine.h, C.byref(cfg), C.byref(self.h)), engine.h)
+        _register(self)
+        self.n = n_lanes
+        d, a = C.c_uint32(), C.c_uint32()
+        _check(lib().rl_env_dims(self.h, C.byref(d), C.byref(a)), engine.h)
+        self.D, self.A = d.value, a.value
+
+    close = CartPoleEnv.close
+    reset = CartPoleEnv.reset
+    observe = CartPoleEnv.observe
+    step = CartPoleEnv.step
+
+    def get_state(self):
+        """(state index, steps_remaining, reset_count) per lane"""
+        st, _, rem, rc = CartPoleEnv.get_state(self)
+        return st[0].astype(np.uint64), rem, rc
+
+
+class GruMlp(_Handle):
+    """`GruMlpConfig::default().build_module(in, out)`: GRU(128) -> ReLU -> MLP([128]); flat reference order."""
+
+    def __init__(self, engine, in_dim, out_dim, gru_hidden=128, mlp_hidden=128):
+        self.eng = engine
+        self.h = C.c_void_p()
+        _check(lib().rl_gru_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(gru_hidden), C.c_uint32(mlp_hidden),
+                                       C.c_uint32(out_dim), C.byref(self.h)), engine.h)
+        _register(self)
+        n = C.c_uint64()
+        _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)
+        self.P = n.value
+        self.in_dim, self.hidden, self.out_dim, self.gru_hidden = in_dim, mlp_hidden, out_dim, gru_hidden
+
+    close = None  # set below
+    init = None
+    get_params = None
+    set_params = None
+
+    def seq_forward(self, traj, want_succ=True):
+        out = np.zeros((self.out_dim, traj.T, traj.n), dtype=np.float32)
+        succ = np.zeros_like(out) if want_succ else None
+        _check(lib().rl_seq_forward(self.h, traj.h, out.ctypes.data_as(C.c_void_p),
+                                    succ.ctypes.data_as(C.c_void_p) if want_succ else None), self.eng.h)
+        return out, succ
+
+
 class Mlp(_Handle):
     """`MlpConfig{hidden_sizes:[H], activation: Relu}.build_module(in, out)`; flat params in reference order."""
 
@@ -325,6 +388,11 @@ class Mlp(_Handle):
                self.eng.h)
         return out
 
+
+GruMlp.close = Mlp.close
+GruMlp.init = Mlp.init
+GruMlp.get_params = Mlp.get_params
+GruMlp.set_params = Mlp.set_params
 
 _TRAJ_DTYPES = {TRAJ_OBS: np.float32, TRAJ_ACTION: np.uint8, TRAJ_REWARD: np.float32, TRAJ_FLAG: np.uint8,
                 TRAJ_TERM_OBS: np.float32, TRAJ_VALUES: np.float32, TRAJ_ADVANTAGES: np.float32,

@@ -7,6 +7,7 @@
 #include <memory>
 
 #include "../../include/rl_chacha.h"
+#include "../../include/rl_detmath.h"
 #include "engine.hpp"
 #include "kernels.hpp"
 
@@ -341,8 +342,9 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
   return guarded(e, [&] {
     RL_REQUIRE(e && cfg && out, "NULL argument");
     *out = nullptr;
-    if (cfg->kind != RL_ENV_CARTPOLE)
-      throw RlError(RL_ERR_BUILD_ENV, "only RL_ENV_CARTPOLE has a device implementation in this build");
+    if (cfg->kind != RL_ENV_CARTPOLE && cfg->kind != RL_ENV_CHAIN) throw RlError(RL_ERR_BUILD_ENV, "unknown env kind");
+    if (cfg->kind == RL_ENV_CHAIN && !(cfg->chain_size == 0 || cfg->chain_size == 5))
+      throw RlError(RL_ERR_BUILD_ENV, "the Chain kernels are built for Chain::default (5 states)");
     if (cfg->limit_kind != RL_LIMIT_NONE && (cfg->max_steps == 0 || cfg->max_steps >= (1ull << 32)))
       throw RlError(RL_ERR_BUILD_ENV, "step limit must be positive and < 2^32");  // StepLimit::new asserts > 0
     if (cfg->n_lanes == 0 || cfg->n_lanes >= (1ull << 31)) throw RlError(RL_ERR_BUILD_ENV, "bad n_lanes");
@@ -350,7 +352,11 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     std::unique_ptr<rl_env> env(new rl_env());
     env->eng = e;
     env->cfg = *cfg;
-    env->D = cfg->limit_kind == RL_LIMIT_VISIBLE ? 5 : 4;
+    env->kind = cfg->kind;
+    if (cfg->kind == RL_ENV_CHAIN)
+      env->D = 5 + (cfg->limit_kind == RL_LIMIT_VISIBLE ? 1 : 0);  // one-hot(5) [+ remaining]
+    else
+      env->D = cfg->limit_kind == RL_LIMIT_VISIBLE ? 5 : 4;
     env->A = 2;
     const rl_cartpole_params &p = cfg->cartpole;
     CartPoleDev &d = env->dev;
@@ -375,6 +381,7 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     d.lane_offset = cfg->lane_offset;
     d.max_steps = cfg->max_steps < (1ull << 32) ? (uint32_t)cfg->max_steps : 0u;
     d.limit_kind = cfg->limit_kind;
+    d.chain_size = 5;
     size_t n = cfg->n_lanes;
     env->st.x = dalloc<double>(n);
     env->st.xdot = dalloc<double>(n);
@@ -389,6 +396,9 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     env->d_obs = dalloc<float>(n * env->D);
     env->d_term_obs = dalloc<float>(n * env->D);
     RL_HIP_CHECK(hipMemsetAsync(env->st.reset_count, 0, n * sizeof(uint32_t), e->stream));
+    for (double *p : {env->st.x, env->st.xdot, env->st.th, env->st.thdot})
+      RL_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(double), e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(env->st.nv_pos, 0, n, e->stream));
     RL_HIP_CHECK(hipMemsetAsync(env->d_actions, 0, n, e->stream));
     RL_HIP_CHECK(hipMemsetAsync(env->d_term_obs, 0, n * env->D * sizeof(float), e->stream));
     launch_env_reset(env.get());
@@ -549,6 +559,97 @@ int32_t rl_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t hidden, uint32_t o
   });
 }
 
+int32_t rl_gru_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden, uint32_t out_dim,
+                          rl_mlp **out) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && out, "NULL argument");
+    *out = nullptr;
+    if (in_dim != 5 || gru_hidden != 128 || mlp_hidden != 128 || !(out_dim == 1 || out_dim == 2))
+      throw RlError(RL_ERR_BUILD_AGENT, "supported GRU-MLP shape: in_dim 5, gru_hidden 128, mlp_hidden 128, out_dim in {1,2}");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_mlp> m(new rl_mlp());
+    m->eng = e;
+    m->kind = RL_MODULE_GRU_MLP;
+    m->in_dim = in_dim;
+    m->gru_hidden = gru_hidden;
+    m->hidden = mlp_hidden;
+    m->out_dim = out_dim;
+    uint64_t H = gru_hidden, D = in_dim, H2 = mlp_hidden, A = out_dim;
+    m->P = 3 * H * D + 3 * H * H + 6 * H + H2 * H + H2 + A * H2 + A;
+    m->d_params = dalloc<float>(m->P);
+    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+    sync(e);
+    e->live_handles += 1;
+    *out = m.release();
+  });
+}
+
+// RnnWeights::new with RnnBaseConfig::default (seq/rnn/mod.rs:36-45,223-257) + the MLP's Linear::new layers.
+// Engine-defined stream: ChaCha8(seed), stream 0, one Standard f32 per uniform element; normals for the orthogonal
+// matrix by Box-Muller on consecutive draw pairs, QR by modified Gram-Schmidt applied twice in f64 (positive
+// diagonal of R, so the sign fold of init_orthogonal, initializers.rs:345-348, is the identity).
+static void gru_mlp_init_host(const rl_mlp *m, uint64_t seed, std::vector<float> &h) {
+  const uint64_t H = m->gru_hidden, D = m->in_dim, H2 = m->hidden, A = m->out_dim, R = 3 * H;
+  h.assign(m->P, 0.0f);
+  uint32_t key[8];
+  rl_seed_from_u64(seed, key);
+  uint32_t words[16];
+  uint64_t widx = 0;
+  auto next_f32 = [&]() {
+    if ((widx & 15) == 0) rl_chacha_block(key, widx >> 4, 0, 4, words);
+    float u = rl_u32_to_unit_f32(words[widx & 15]);
+    widx += 1;
+    return u;
+  };
+  size_t k = 0;
+  float lim = (float)std::sqrt(3.0 * (2.0 / ((double)D + (double)R)));
+  for (uint64_t i = 0; i < R * D; ++i) {
+    float u = next_f32();
+    float t = 2.0f * u;
+    t = t - 1.0f;
+    h[k++] = t * lim;
+  }
+  std::vector<double> rowmajor(R * H), a(R * H);
+  const double two_pi = 6.283185307179586;
+  for (uint64_t i = 0; i < R * H; i += 2) {
+    double u1 = (double)next_f32(), u2 = (double)next_f32();
+    double rho = std::sqrt(-2.0 * std::log(1.0 - u1)), sn, cs;
+    rl_sincos(two_pi * u2, &sn, &cs);
+    rowmajor[i] = rho * cs;
+    if (i + 1 < R * H) rowmajor[i + 1] = rho * sn;
+  }
+  for (uint64_t row = 0; row < R; ++row)
+    for (uint64_t c = 0; c < H; ++c) a[c * R + row] = rowmajor[row * H + c];
+  for (uint64_t c = 0; c < H; ++c) {
+    double *v = a.data() + c * R;
+    for (int pass = 0; pass < 2; ++pass)
+      for (uint64_t q = 0; q < c; ++q) {
+        const double *w = a.data() + q * R;
+        double dot = 0.0;
+        for (uint64_t row = 0; row < R; ++row) dot += w[row] * v[row];
+        for (uint64_t row = 0; row < R; ++row) v[row] -= dot * w[row];
+      }
+    double nrm = 0.0;
+    for (uint64_t row = 0; row < R; ++row) nrm += v[row] * v[row];
+    nrm = std::sqrt(nrm);
+    for (uint64_t row = 0; row < R; ++row) v[row] /= nrm;
+  }
+  for (uint64_t row = 0; row < R; ++row)
+    for (uint64_t c = 0; c < H; ++c) h[k++] = (float)a[c * R + row];
+  k += 2 * R;  // biases stay zero
+  uint64_t dims[2][2] = {{H, H2}, {H2, A}};
+  for (int l = 0; l < 2; ++l) {
+    uint64_t in = dims[l][0], out = dims[l][1];
+    float lm = (float)std::sqrt(3.0 * (2.0 / ((double)(in + 1) + (double)out)));
+    for (uint64_t i = 0; i < in * out + out; ++i) {
+      float u = next_f32();
+      float t = 2.0f * u;
+      t = t - 1.0f;
+      h[k++] = t * lm;
+    }
+  }
+}
+
 int32_t rl_mlp_destroy(rl_mlp *m) {
   if (!m) return RL_OK;
   (void)hipSetDevice(m->eng->device);
@@ -570,6 +671,12 @@ int32_t rl_mlp_num_params(const rl_mlp *m, uint64_t *n) {
 int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
   return guarded(m ? m->eng : nullptr, [&] {
     RL_REQUIRE(m, "mlp is NULL");
+    if (m->kind == RL_MODULE_GRU_MLP) {
+      std::vector<float> hp;
+      gru_mlp_init_host(m, seed, hp);
+      h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
+      return;
+    }
     // Linear::new (reference src/torch/modules/ff/linear.rs:54-68; initializers.rs:31-38,78-108,159-163):
     // Uniform(+-sqrt(3 * 2 / (fan_in + fan_out))) with fan_in = in_dim + 1 for kernel and bias.
     // Stream (engine-defined, libtorch's RNG is unseeded in the reference): ChaCha8(seed), stream 0,
@@ -620,6 +727,8 @@ int32_t rl_params_set(rl_mlp *m, const float *host, uint64_t n) {
 
 int32_t rl_mlp_forward(rl_mlp *m, const float *rows, uint64_t n_rows, float *out) {
   return guarded(m ? m->eng : nullptr, [&] {
+    if (m && m->kind != RL_MODULE_MLP)
+      throw RlError(RL_ERR_UNSUPPORTED, "row-wise forward is for feed-forward modules; use rl_seq_forward");
     RL_REQUIRE(m && rows && out, "NULL argument");
     if (n_rows == 0) return;
     rl_engine *e = m->eng;
@@ -750,6 +859,8 @@ int32_t rl_traj_create(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_
   });
 }
 
+static void seq_free(rl_traj *t);
+
 int32_t rl_traj_destroy(rl_traj *t) {
   if (!t) return RL_OK;
   (void)hipSetDevice(t->eng->device);
@@ -758,6 +869,7 @@ int32_t rl_traj_destroy(rl_traj *t) {
                   t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
                   t->losses, t->trpo};
   for (void *p : ptrs) dfree(p);
+  seq_free(t);
   rl_engine *eng = t->eng;
   delete t;
   engine_release_child(eng);
@@ -794,6 +906,70 @@ int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t byte
   });
 }
 
+// ---------------------------------------------------------------- recurrent workspace
+static void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
+  RL_REQUIRE(mod->kind == RL_MODULE_GRU_MLP, "not a recurrent module");
+  RL_REQUIRE(t->d.n % 32 == 0, "the recurrent kernels work on tiles of 32 lanes: n_lanes must be a multiple of 32");
+  RL_REQUIRE(t->d.D == 5 && mod->in_dim == 5, "recurrent path: built for 5 observation features");
+  SeqDev &q = t->seq;
+  uint64_t n = t->d.n, T = t->d.T;
+  if (q.out == nullptr) {
+    q.tiles = (uint32_t)(n / 32);
+    q.out = dalloc<float>(2 * T * n);
+    q.succ = dalloc<float>(2 * T * n);
+  }
+  if (training && q.act == nullptr) {
+    uint64_t blocks = T * q.tiles;
+    q.act = dalloc<float>(blocks * 7 * 128 * 32);
+    q.dpre = dalloc<float>(blocks * 5 * 128 * 32);
+    // weight-gradient partials: contiguous runs of (t, tile) blocks per workgroup, <= 1024 workgroups and at most
+    // ~2048 samples accumulated in f32 before the f64 reduction
+    uint64_t bpc = (blocks + 1023) / 1024;
+    if (bpc < 1) bpc = 1;
+    if (bpc > 64) bpc = 64;
+    q.blocks_per_chunk = (uint32_t)bpc;
+    q.chunks = (uint32_t)((blocks + bpc - 1) / bpc);
+  }
+  if (training && q.P < mod->P) {
+    dfree(q.wg_slab);
+    q.wg_slab = nullptr;
+    q.wg_slab = dalloc<float>((size_t)q.chunks * mod->P);
+    q.P = mod->P;
+    // the P-sized vectors of the update workspace grow with the module
+    if (t->Pmax < mod->P) {
+      for (float **p : {&t->vec, &t->cg_x, &t->cg_r, &t->cg_p, &t->prev_params, &t->descent}) {
+        dfree(*p);
+        *p = nullptr;
+      }
+      t->Pmax = (uint32_t)mod->P;
+      t->vec = dalloc<float>(t->Pmax + 4);
+      t->cg_x = dalloc<float>(t->Pmax);
+      t->cg_r = dalloc<float>(t->Pmax);
+      t->cg_p = dalloc<float>(t->Pmax);
+      t->prev_params = dalloc<float>(t->Pmax);
+      t->descent = dalloc<float>(t->Pmax);
+    }
+  }
+}
+
+static void seq_free(rl_traj *t) {
+  SeqDev &q = t->seq;
+  for (float *p : {q.act, q.dpre, q.out, q.succ, q.wg_slab}) dfree(p);
+  q = SeqDev{};
+}
+
+int32_t rl_seq_forward(rl_mlp *mod, rl_traj *traj, float *out, float *succ_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    RL_REQUIRE(mod && traj && out, "NULL argument");
+    RL_REQUIRE(mod->eng == traj->eng, "handles belong to different engines");
+    seq_ensure(traj, mod, false);
+    launch_gru_seq_forward(traj, mod, traj->seq.out, succ_out ? traj->seq.succ : nullptr, nullptr);
+    uint64_t bytes = (uint64_t)mod->out_dim * traj->d.T * traj->d.n * sizeof(float);
+    d2h(traj->eng, out, traj->seq.out, bytes);
+    if (succ_out) d2h(traj->eng, succ_out, traj->seq.succ, bytes);
+  });
+}
+
 // ---------------------------------------------------------------- rollout + GAE
 int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   return guarded(env ? env->eng : nullptr, [&] {
@@ -801,7 +977,16 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     RL_REQUIRE(env->eng == traj->eng && env->eng == policy->eng, "handles belong to different engines");
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
-    launch_rollout(env, policy, traj);
+    if (policy->kind == RL_MODULE_GRU_MLP) {
+      if (env->kind != RL_ENV_CHAIN)
+        throw RlError(RL_ERR_UNSUPPORTED, "the recurrent rollout kernel is built for RL_ENV_CHAIN");
+      seq_ensure(traj, policy, false);
+      launch_rollout_chain_gru(env, policy, traj);
+    } else {
+      if (env->kind != RL_ENV_CARTPOLE)
+        throw RlError(RL_ERR_UNSUPPORTED, "the MLP rollout kernel is built for RL_ENV_CARTPOLE");
+      launch_rollout(env, policy, traj);
+    }
     env->t_global += traj->d.T;
   });
 }
@@ -810,6 +995,12 @@ int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     RL_REQUIRE(traj && critic, "NULL argument");
     RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
+    if (critic->kind == RL_MODULE_GRU_MLP) {
+      seq_ensure(traj, critic, false);
+      launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
+      launch_seq_gae(traj, gamma, lambda);
+      return;
+    }
     launch_values(traj, critic);
     launch_gae(traj, critic, gamma, lambda);
   });

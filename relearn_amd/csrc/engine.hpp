@@ -39,10 +39,11 @@ struct CartPoleDev {
   uint64_t lane_offset;
   uint32_t max_steps;
   int32_t limit_kind;
+  uint32_t chain_size;  // RL_ENV_CHAIN only (the common fields above are shared by both env kinds)
 };
 
 struct EnvStateDev {
-  double *x, *xdot, *th, *thdot;  // [n]
+  double *x, *xdot, *th, *thdot;  // [n]; RL_ENV_CHAIN keeps its state index in x (exact in f64)
   uint8_t *nv_pos;                // [n] cached_normal_velocity_is_positive
   uint32_t *steps_remaining;      // [n]
   uint32_t *reset_count;          // [n]
@@ -128,6 +129,7 @@ struct rl_engine {
 struct rl_env {
   rl_engine *eng;
   rl_env_config cfg;
+  int kind = RL_ENV_CARTPOLE;
   CartPoleDev dev;
   EnvStateDev st;
   uint32_t D, A;
@@ -137,11 +139,26 @@ struct rl_env {
   float *d_reward = nullptr, *d_obs = nullptr, *d_term_obs = nullptr;
 };
 
+enum { RL_MODULE_MLP = 0, RL_MODULE_GRU_MLP = 1 };
+
 struct rl_mlp {
   rl_engine *eng;
-  uint32_t in_dim, hidden, out_dim;
+  uint32_t in_dim, hidden, out_dim;  // GRU_MLP: hidden = the MLP's hidden width
   uint64_t P;
   float *d_params = nullptr;
+  int kind = RL_MODULE_MLP;
+  uint32_t gru_hidden = 0;
+};
+
+// workspace of the recurrent path, attached to a trajectory on first use (tiles of 32 lanes)
+struct SeqDev {
+  float *act = nullptr;     // [T][tiles][7][128][32]: r, z, n, gh_n, h_prev, relu(h'), u
+  float *dpre = nullptr;    // [T][tiles][5][128][32]: d pre_r, d pre_z, d pre_n, d pre_n * r, d u_pre
+  float *out = nullptr;     // [2][T][n] module outputs (logits / values)
+  float *succ = nullptr;    // [2][T][n] outputs at successor observations of cut episodes
+  float *wg_slab = nullptr; // [chunks][P] partial weight gradients (f32)
+  uint32_t tiles = 0, chunks = 0, blocks_per_chunk = 0;
+  uint64_t P = 0;
 };
 
 struct rl_adam {
@@ -167,6 +184,7 @@ struct rl_traj {
   TrpoStateDev *trpo = nullptr;
   uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbPair = 0, pair_tiles_per_block = 0, Pmax = 0, max_losses = 0;
   uint32_t bwd_chunk = 0;   // samples per backward block
+  SeqDev seq;
 };
 
 struct rl_dqn {

@@ -54,3 +54,12 @@ void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_
                                 const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                                 float *d_obs, size_t out_plane, uint8_t *d_action, float *d_target, float gamma,
                                 int one_step_td, const rl_mlp *qnet);
+
+// kernels_seq.hip (recurrent configuration: Chain lanes, GRU -> ReLU -> MLP module; tiles of 32 lanes)
+void launch_chain_reset(rl_env *env);
+void launch_chain_observe(rl_env *env, float *d_obs);
+void launch_chain_step(rl_env *env);
+void launch_rollout_chain_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj);
+// teacher-forced forward: d_out [A][T][n]; d_succ (may be NULL) [A][T][n]; d_act (may be NULL) activation record
+void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act);
+void launch_seq_gae(rl_traj *traj, float gamma, float lambda);  // reads traj->seq.out / succ (plane 0)
