@@ -1006,6 +1006,30 @@ int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
   });
 }
 
+// ---------------------------------------------------------------- recurrent gradient passes
+// policy: teacher-forced forward (activation record) -> d loss / d logits -> [backward through time -> weight
+// gradients -> reduce] -> traj->vec[0..P) and the per-sample sums in vec[P..P+4)
+static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backward, float lo, float hi) {
+  seq_ensure(traj, policy, true);
+  uint32_t P = (uint32_t)policy->P;
+  launch_gru_seq_forward(traj, policy, traj->seq.out, nullptr, backward ? traj->seq.act : nullptr);
+  launch_seq_policy_dlogits(traj, mode, b_total(traj), lo, hi);
+  if (backward) launch_gru_backward(traj, policy);
+  launch_reduce(traj, P, false, true, 0, traj->nbB);
+  if (backward) rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+  else rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
+}
+
+static void seq_critic_pass(rl_mlp *critic, rl_traj *traj) {
+  seq_ensure(traj, critic, true);
+  uint32_t P = (uint32_t)critic->P;
+  launch_gru_seq_forward(traj, critic, traj->seq.out, nullptr, traj->seq.act);
+  launch_seq_critic_dvalues(traj, b_total(traj));
+  launch_gru_backward(traj, critic);
+  launch_reduce(traj, P, false, true, 0, traj->nbB);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
 // ---------------------------------------------------------------- TRPO
 int32_t rl_trpo_config_default(rl_trpo_config *c) {
   return guarded(nullptr, [&] {
@@ -1028,6 +1052,7 @@ static void check_policy(const rl_mlp *policy, const rl_traj *traj) {
 
 // gradient pass: PASS_INIT -> backward -> reduce(A+B) -> allreduce
 static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_pass(policy, traj, PASS_INIT, true, 0.0f, 0.0f);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
     launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
@@ -1068,6 +1093,10 @@ int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg,
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
     RL_REQUIRE(cfg && stats, "NULL argument");
+    if (policy->kind != RL_MODULE_MLP)
+      throw RlError(RL_ERR_UNSUPPORTED, "TRPO needs Hessian-vector products through the recurrent module, which this "
+                                        "build does not have (the reference disables cuDNN for them, trpo.rs:104-108); "
+                                        "use rl_ppo_update / rl_reinforce_update");
     rl_engine *e = traj->eng;
     uint32_t P = (uint32_t)policy->P;
     uint64_t Bt = b_total(traj);
@@ -1128,6 +1157,7 @@ int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float
 int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, float *out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
+    if (policy->kind != RL_MODULE_MLP) throw RlError(RL_ERR_UNSUPPORTED, "feed-forward policies only");
     RL_REQUIRE(v && out, "NULL argument");
     uint32_t P = (uint32_t)policy->P;
     run_policy_gradient(policy, traj);  // the product is taken at the current parameters: refresh log pi_0
@@ -1142,6 +1172,7 @@ int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, 
 int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, float *loss_out, float *kl_out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
+    if (policy->kind != RL_MODULE_MLP) throw RlError(RL_ERR_UNSUPPORTED, "feed-forward policies only");
     RL_REQUIRE(params0 && loss_out && kl_out, "NULL argument");
     rl_engine *e = traj->eng;
     uint32_t P = (uint32_t)policy->P;
@@ -1232,6 +1263,7 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
 }
 
 static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
+  if (critic->kind == RL_MODULE_GRU_MLP) return seq_critic_pass(critic, traj);
   uint32_t P = (uint32_t)critic->P;
   if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
     uint32_t rows = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbV2;
@@ -1292,6 +1324,7 @@ int32_t rl_ppo_config_default(rl_ppo_config *c) {
 
 // PASS_PPO gradient of the clipped surrogate against lp0 -> vec[0..P), sum of min(...) -> vec[P]
 static void run_policy_ppo(rl_mlp *policy, rl_traj *traj, float lo, float hi) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_pass(policy, traj, PASS_PPO, true, lo, hi);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 &&
       launch_policy_v2(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi)) {
@@ -1315,7 +1348,8 @@ int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_
     uint32_t P = (uint32_t)policy->P;
     uint64_t Bt = b_total(traj), K = cfg->opt_steps_per_update;
     // initial_log_probs and the logged entropy (ppo.rs:107-118): the PASS_INIT pass stores log pi_0
-    run_policy_gradient(policy, traj);
+    if (policy->kind == RL_MODULE_GRU_MLP) seq_policy_pass(policy, traj, PASS_INIT, false, 0.0f, 0.0f);
+    else run_policy_gradient(policy, traj);
     float h0[4];
     d2h(e, h0, traj->vec + P, sizeof(h0));
     // clip(1 - d, 1 + d): f64 scalars applied to a Float tensor

@@ -552,3 +552,378 @@ void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, floa
     hipLaunchKernelGGL((k_gru_seq_forward<5, 1>), dim3(tiles), dim3(256), 0, traj->eng->stream, traj->d,
                        mod->d_params, d_out, d_succ, d_act);
 }
+
+// =====================================================================================================
+// Training passes: per-sample output gradients, backward through time, weight-gradient GEMMs.
+// Reference: what libtorch's autograd does for `loss.backward()` in COptimizer::backward_step
+// (src/torch/optimizers/coptimizer.rs:13-26) on gru_data + linear layers over a packed batch.
+// =====================================================================================================
+
+// ---------------------------------------------------------------- d loss / d logits (policy)
+// MODE_INIT: surrogate at ratio 1, loss = -mean(A): stores log pi_0, sums {ratio A, entropy, log pi(a) A}
+// MODE_PPO : clipped surrogate against log pi_0 (policies/ppo.rs:124-137), sums {min(...)}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_seq_policy_dlogits(TrajDev tr, const float *__restrict__ logits,
+                                                            float *__restrict__ lp0, float *__restrict__ dz,
+                                                            double *__restrict__ slabB, float inv_B, float clip_lo,
+                                                            float clip_hi) {
+  __shared__ double red[256];
+  const size_t B = (size_t)tr.T * tr.n;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) {
+    float z[2] = {logits[b], logits[B + b]}, lp[2];
+    log_softmax_lane<2>(z, lp);
+    const int act = tr.action[b];
+    const float adv = tr.adv[b];
+    const float pa0 = rl_expf(lp[0]), pa1 = rl_expf(lp[1]);
+    const float lpa = act == 0 ? lp[0] : lp[1];
+    float c;
+    if (MODE == PASS_INIT) {
+      lp0[b] = lp[0];
+      lp0[B + b] = lp[1];
+      const float ratio = rl_expf(lpa - lpa);
+      c = -(ratio * adv) * inv_B;
+      const float cl0 = lp[0] < -3.402823466e+38f ? -3.402823466e+38f : lp[0];
+      const float cl1 = lp[1] < -3.402823466e+38f ? -3.402823466e+38f : lp[1];
+      float ent = cl0 * pa0;
+      ent += cl1 * pa1;
+      s0 += (double)(ratio * adv);
+      s1 += (double)(-ent);
+      s2 += (double)(lpa * adv);
+    } else {
+      const float l0a = lp0[(size_t)act * B + b];
+      const float ratio = rl_expf(lpa - l0a);
+      const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
+      const float u1 = ratio * adv, u2 = clipped * adv;
+      const bool inside = ratio >= clip_lo && ratio <= clip_hi;
+      const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
+      c = -(gr * ratio) * inv_B;
+      s0 += (double)(u1 < u2 ? u1 : u2);
+    }
+    dz[b] = c * ((act == 0 ? 1.0f : 0.0f) - pa0);
+    dz[B + b] = c * ((act == 1 ? 1.0f : 0.0f) - pa1);
+  }
+  const double t0 = block_sum<256>(s0, red), t1 = block_sum<256>(s1, red), t2 = block_sum<256>(s2, red);
+  if (threadIdx.x == 0) {
+    slabB[blockIdx.x * 4 + 0] = t0;
+    slabB[blockIdx.x * 4 + 1] = t1;
+    slabB[blockIdx.x * 4 + 2] = t2;
+    slabB[blockIdx.x * 4 + 3] = 0.0;
+  }
+}
+
+// critic: d mse_loss(V, target, Mean) / d V = 2 (V - target) / B (critics/opt.rs:109-115); sums {(V - target)^2}
+__global__ void __launch_bounds__(256) k_seq_critic_dvalues(TrajDev tr, const float *__restrict__ values,
+                                                            float *__restrict__ dz, double *__restrict__ slabB,
+                                                            float two_over_B) {
+  __shared__ double red[256];
+  const size_t B = (size_t)tr.T * tr.n;
+  double s0 = 0.0;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) {
+    const float d = values[b] - tr.rtg[b];
+    dz[b] = d * two_over_B;
+    s0 += (double)(d * d);
+  }
+  const double t0 = block_sum<256>(s0, red);
+  if (threadIdx.x == 0) {
+    slabB[blockIdx.x * 4 + 0] = t0;
+    slabB[blockIdx.x * 4 + 1] = 0.0;
+    slabB[blockIdx.x * 4 + 2] = 0.0;
+    slabB[blockIdx.x * 4 + 3] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------- backward through time
+// One workgroup per tile, t = T-1 .. 0.  Wave w owns units k in [32w, 32w+32) of every back-propagated vector:
+// its slices of W1^T (64 B-operands) and W_hh^T (3 x 64) stay in registers, the vectors being multiplied pass
+// through one [128][33] LDS buffer, gate by gate.  Writes the five per-step arrays the weight-gradient GEMMs read.
+template <int A>
+__global__ void __launch_bounds__(256, 1) k_gru_bptt(TrajDev tr, const float *__restrict__ params, int D,
+                                                     const float *__restrict__ dz, const float *__restrict__ act,
+                                                     float *__restrict__ dpre) {
+  __shared__ float bufT[GH][TL + 1];
+  __shared__ float dzS[2][TL];
+  __shared__ int endS[TL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const uint32_t N = tr.n, T = tr.T;
+  const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
+  const size_t B = (size_t)T * N;
+  const GruParams g = gru_params(params, D, A);
+  float whhT[3][GH / 2], w1T[MH / 2], w2c[A];
+#pragma unroll
+  for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks) whhT[gte][ks] = g.Whh[(size_t)(gte * GH + 2 * ks + hf) * GH + j];
+#pragma unroll
+  for (int ks = 0; ks < MH / 2; ++ks) w1T[ks] = g.W1[(size_t)(2 * ks + hf) * GH + j];
+#pragma unroll
+  for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
+  float dhc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dhc[r] = 0.0f;
+  for (uint32_t t = T; t-- > 0;) {
+    const size_t blk = (size_t)t * tiles + tile;
+    const float *__restrict__ ab = act + blk * SEQ_ARR * GH * TL;
+    float *__restrict__ db = dpre + blk * DPRE_ARR * GH * TL;
+    if (wave == 0 && lane < TL) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) dzS[a][lane] = dz[(size_t)a * B + (size_t)t * N + lane0 + lane];
+      endS[lane] = tr.flag[(size_t)t * N + lane0 + lane] != RL_SUCC_CONTINUE;
+    }
+    __syncthreads();
+    // head: d u_pre = [u > 0] W2^T dz
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = acc_row(r, hf);
+      const float u = ab[(size_t)ACT_U * GH * TL + j * TL + m];
+      float du = 0.0f;
+#pragma unroll
+      for (int a = 0; a < A; ++a) du = __builtin_fmaf(dzS[a][m], w2c[a], du);
+      du = u > 0.0f ? du : 0.0f;
+      bufT[j][m] = du;
+      db[(size_t)4 * GH * TL + j * TL + m] = du;
+    }
+    __syncthreads();
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < MH / 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bufT[2 * ks + hf][n], w1T[ks], acc, 0, 0, 0);
+    __syncthreads();
+    // cell: h' = (h - n) z + n
+    float gr[16], gz[16], gnr[16], dhdir[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = acc_row(r, hf);
+      const size_t o = (size_t)j * TL + m;
+      const float a1 = ab[(size_t)ACT_A1 * GH * TL + o];
+      const float rr = ab[(size_t)ACT_R * GH * TL + o], zz = ab[(size_t)ACT_Z * GH * TL + o];
+      const float nn = ab[(size_t)ACT_N * GH * TL + o], ghn = ab[(size_t)ACT_GHN * GH * TL + o];
+      const float hp = ab[(size_t)ACT_HPREV * GH * TL + o];
+      float dh = endS[m] ? 0.0f : dhc[r];
+      dh = dh + (a1 > 0.0f ? acc[r] : 0.0f);
+      const float dzg = dh * (hp - nn);
+      const float dn = dh * (1.0f - zz);
+      const float dpn = dn * (1.0f - nn * nn);
+      const float dr = dpn * ghn;
+      gr[r] = dr * rr * (1.0f - rr);
+      gz[r] = dzg * zz * (1.0f - zz);
+      gnr[r] = dpn * rr;
+      dhdir[r] = dh * zz;
+      db[(size_t)0 * GH * TL + o] = gr[r];
+      db[(size_t)1 * GH * TL + o] = gz[r];
+      db[(size_t)2 * GH * TL + o] = dpn;
+      db[(size_t)3 * GH * TL + o] = gnr[r];
+    }
+    // d h_prev = dh z + sum over gates of W_hh[g]^T d gh_g
+    acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int gte = 0; gte < 3; ++gte) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bufT[j][acc_row(r, hf)] = gte == 0 ? gr[r] : (gte == 1 ? gz[r] : gnr[r]);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < GH / 2; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bufT[2 * ks + hf][n], whhT[gte][ks], acc, 0, 0, 0);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dhc[r] = dhdir[r] + acc[r];
+  }
+}
+
+// ---------------------------------------------------------------- weight-gradient GEMMs
+// dW_hh = sum dgh (x) h_prev [384 x 128], dW1 = sum du (x) relu(h') [128 x 128] on the matrix cores with the
+// sample index as the MFMA k dimension (k-pair (ks, hf) <-> sample m = 16 hf + ks, so every operand is 16
+// consecutive floats of a [unit][32] row); dW_ih, the biases and dW2 on the VALU.  A workgroup accumulates a
+// contiguous run of (t, tile) blocks in f32 and writes one row of partials; k_seq_reduce sums the rows in f64.
+template <int D, int A>
+__global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *__restrict__ dz,
+                                                      const float *__restrict__ act, const float *__restrict__ dpre,
+                                                      float *__restrict__ slab, uint32_t P, uint32_t tiles,
+                                                      uint32_t blocks, uint32_t blocks_per_chunk) {
+  __shared__ float xS[TL][8];
+  __shared__ float dzS[2][TL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const uint32_t N = tr.n, T = tr.T;
+  const size_t B = (size_t)T * N, plane = (size_t)(T + 1) * N;
+  f32x16 acc_hh[12], acc_w1[4];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) acc_hh[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc_w1[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float dwih[3][D], dbih[3] = {0, 0, 0}, dbhh[3] = {0, 0, 0}, db1 = 0.0f, dw2[A], db2 = 0.0f;
+#pragma unroll
+  for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+    for (int d = 0; d < D; ++d) dwih[gte][d] = 0.0f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) dw2[a] = 0.0f;
+  const uint32_t b0 = blockIdx.x * blocks_per_chunk;
+  const uint32_t b1 = b0 + blocks_per_chunk < blocks ? b0 + blocks_per_chunk : blocks;
+  for (uint32_t blk = b0; blk < b1; ++blk) {
+    const uint32_t t = blk / tiles, tile = blk % tiles, lane0 = tile * TL;
+    const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
+    const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
+    __syncthreads();  // the previous block's readers of xS / dzS are done
+    if (wave == 0 && lane < TL) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) xS[lane][d] = tr.obs[d * plane + (size_t)t * N + lane0 + lane];
+#pragma unroll
+      for (int a = 0; a < A; ++a) dzS[a][lane] = dz[(size_t)a * B + (size_t)t * N + lane0 + lane];
+    }
+    __syncthreads();
+    // B operands of this wave's column tile: h_prev and relu(h') rows of unit k = j, samples 16 hf .. 16 hf + 15
+    float hpB[16], a1B[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      hpB[ks] = ab[(size_t)ACT_HPREV * GH * TL + j * TL + 16 * hf + ks];
+      a1B[ks] = ab[(size_t)ACT_A1 * GH * TL + j * TL + 16 * hf + ks];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 12; ++mt) {
+      const int gte = mt >> 2, row = 32 * (mt & 3) + n;  // unit of this lane's A row
+      const int arr = gte == 2 ? 3 : gte;
+      float av[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) av[ks] = db[(size_t)arr * GH * TL + row * TL + 16 * hf + ks];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        acc_hh[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], hpB[ks], acc_hh[mt], 0, 0, 0);
+      if ((mt & 3) == wave) {
+        // this wave owns rows 32 * wave + n of gate `gte` for the VALU-side sums
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int m = 16 * hf + ks;
+          const float dgh = av[ks];
+          const float dgi = gte == 2 ? db[(size_t)2 * GH * TL + row * TL + m] : dgh;
+          dbhh[gte] += dgh;
+          dbih[gte] += dgi;
+#pragma unroll
+          for (int d = 0; d < D; ++d) dwih[gte][d] = __builtin_fmaf(dgi, xS[m][d], dwih[gte][d]);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = 32 * mt + n;
+      float av[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) av[ks] = db[(size_t)4 * GH * TL + row * TL + 16 * hf + ks];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        acc_w1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], a1B[ks], acc_w1[mt], 0, 0, 0);
+      if (mt == wave) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int m = 16 * hf + ks;
+          db1 += av[ks];
+          const float u = ab[(size_t)ACT_U * GH * TL + row * TL + m];
+#pragma unroll
+          for (int a = 0; a < A; ++a) dw2[a] = __builtin_fmaf(dzS[a][m], u, dw2[a]);
+        }
+      }
+    }
+    if (wave == 0 && lane < A * TL) db2 += dzS[lane >> 5][lane & 31];  // lane = (a = hf, m = n)
+  }
+  // ---- write this workgroup's row of partials
+  float *__restrict__ out = slab + (size_t)blockIdx.x * P;
+  const size_t oWih = 0, oWhh = oWih + (size_t)3 * GH * D, obih = oWhh + (size_t)3 * GH * GH, obhh = obih + 3 * GH;
+  const size_t oW1 = obhh + 3 * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH, ob2 = oW2 + (size_t)A * MH;
+#pragma unroll
+  for (int mt = 0; mt < 12; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[oWhh + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_hh[mt][r];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[oW1 + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_w1[mt][r];
+  // VALU sums: the two halves of a wave hold samples 0..15 and 16..31 of the same rows
+#pragma unroll
+  for (int gte = 0; gte < 3; ++gte) {
+    const int row = gte * GH + j;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float v = dwih[gte][d] + __shfl_xor(dwih[gte][d], 32, 64);
+      if (hf == 0) out[oWih + (size_t)row * D + d] = v;
+    }
+    const float vi = dbih[gte] + __shfl_xor(dbih[gte], 32, 64), vh = dbhh[gte] + __shfl_xor(dbhh[gte], 32, 64);
+    if (hf == 0) {
+      out[obih + row] = vi;
+      out[obhh + row] = vh;
+    }
+  }
+  {
+    const float v = db1 + __shfl_xor(db1, 32, 64);
+    if (hf == 0) out[ob1 + j] = v;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const float v2 = dw2[a] + __shfl_xor(dw2[a], 32, 64);
+      if (hf == 0) out[oW2 + (size_t)a * MH + j] = v2;
+    }
+  }
+  if (wave == 0) {
+    float v = db2;  // lanes of half `a` hold the per-sample-slot sums of output a
+#pragma unroll
+    for (int s = 16; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    if (n == 0 && hf < A) out[ob2 + hf] = v;
+  }
+}
+
+// rows of f32 partials -> one f32 vector, accumulated in f64 in a fixed order
+__global__ void __launch_bounds__(256) k_seq_reduce(const float *__restrict__ slab, uint32_t rows, uint32_t P,
+                                                    float *__restrict__ vec) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  double s = 0.0;
+  for (uint32_t r = 0; r < rows; ++r) s += (double)slab[(size_t)r * P + p];
+  vec[p] = (float)s;
+}
+
+void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi) {
+  ProfScope ps(traj->eng, RL_K_POLICY_PASS);
+  float inv_B = 1.0f / (float)B_total;
+  dim3 g(traj->nbB), b(256);
+  if (mode == PASS_INIT)
+    hipLaunchKernelGGL(k_seq_policy_dlogits<PASS_INIT>, g, b, 0, traj->eng->stream, traj->d, traj->seq.out, traj->lp0,
+                       traj->dz, traj->slabB, inv_B, clip_lo, clip_hi);
+  else
+    hipLaunchKernelGGL(k_seq_policy_dlogits<PASS_PPO>, g, b, 0, traj->eng->stream, traj->d, traj->seq.out, traj->lp0,
+                       traj->dz, traj->slabB, inv_B, clip_lo, clip_hi);
+}
+
+void launch_seq_critic_dvalues(rl_traj *traj, uint64_t B_total) {
+  ProfScope ps(traj->eng, RL_K_CRITIC_FWD);
+  hipLaunchKernelGGL(k_seq_critic_dvalues, dim3(traj->nbB), dim3(256), 0, traj->eng->stream, traj->d, traj->seq.out,
+                     traj->dz, traj->slabB, 2.0f / (float)B_total);
+}
+
+// backward through time + weight-gradient GEMMs + reduction: traj->vec[0..P) <- sum over this rank's samples
+void launch_gru_backward(rl_traj *traj, const rl_mlp *mod) {
+  rl_engine *e = traj->eng;
+  const SeqDev &q = traj->seq;
+  uint32_t P = (uint32_t)mod->P, blocks = traj->d.T * q.tiles;
+  {
+    ProfScope ps(e, RL_K_BACKWARD);
+    if (mod->out_dim == 2)
+      hipLaunchKernelGGL(k_gru_bptt<2>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
+                         q.act, q.dpre);
+    else
+      hipLaunchKernelGGL(k_gru_bptt<1>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
+                         q.act, q.dpre);
+  }
+  {
+    ProfScope ps(e, RL_K_CRITIC_FUSED);
+    if (mod->out_dim == 2)
+      hipLaunchKernelGGL((k_gru_wgrad<5, 2>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, q.act, q.dpre,
+                         q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk);
+    else
+      hipLaunchKernelGGL((k_gru_wgrad<5, 1>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, q.act, q.dpre,
+                         q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk);
+  }
+  {
+    ProfScope ps(e, RL_K_REDUCE);
+    hipLaunchKernelGGL(k_seq_reduce, dim3(cdiv_s(P, 256)), dim3(256), 0, e->stream, q.wg_slab, q.chunks, P, traj->vec);
+  }
+}

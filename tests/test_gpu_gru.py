@@ -95,3 +95,151 @@ def test_seq_forward_and_gae_bit_exact(engine, max_steps):
     adv_o, rtg_o = O.seq_gae(v_o[0], s_o[0], want, np.float32(0.95), np.float32(0.9))
     assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), adv_o)
     assert np.array_equal(traj.read(ra.TRAJ_RETURNS), rtg_o)
+
+
+# ------------------------------------------------------------------ gradients through time and the update loops
+GRAD_RTOL = 5e-6   # device f32 (MFMA partial sums over <= 2048 samples, then f64) vs the f64 evaluation, rel. to max|g|
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def setup_update(engine, n=64, T=30, max_steps=9, lr=1e-3):
+    env, sim = chain_pair(engine, n, max_steps=max_steps)
+    pol, cri = ra.GruMlp(engine, 5, 2), ra.GruMlp(engine, 5, 1)
+    pol.init(21)
+    cri.init(22)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    want = sim.rollout_gru(PS, pol.get_params(), T)
+    ra.gae(traj, cri, 0.95, 0.9)
+    want["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
+    want["rtg"] = traj.read(ra.TRAJ_RETURNS)
+    acfg = ra.adam_config_default()
+    acfg.learning_rate = lr
+    ocfg = O.AdamCfg()
+    L.oracle_adam_cfg_default(C.byref(ocfg))
+    ocfg.lr = lr
+    return pol, cri, traj, want, acfg, ocfg
+
+
+def policy_grad_f64(p, want):
+    """-mean(ratio * A) at ratio 1 through time, everything in f64 (numpy softmax + the f64 BPTT oracle)"""
+    logits, _ = O.gru_seq_forward(PS, p, want, f64=True, want_succ=False)
+    B = logits[0].size
+    z = logits - logits.max(0)
+    lp = z - np.log(np.exp(z).sum(0))
+    pr = np.exp(lp)
+    a = want["action"].astype(np.int64)
+    ind = np.stack([a == 0, a == 1]).astype(np.float64)
+    dl = -(want["adv"].astype(np.float64) / B) * (ind - pr)
+    return O.gru_seq_backward(PS, p, want, dl, f64=True)
+
+
+def test_policy_gradient_through_time(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p = pol.get_params()
+    g_d, loss_d, ent_d = ra.policy_gradient(pol, traj)
+    logits, _ = O.gru_seq_forward(PS, p, want, want_succ=False)
+    dl, lp, loss_sum, ent_sum = O.seq_policy_dlogits(logits, want["action"], want["adv"])
+    g32 = O.gru_seq_backward(PS, p, want, dl)
+    g64 = policy_grad_f64(p, want)
+    B = want["action"].size
+    assert rel_err(g_d, g64) < GRAD_RTOL, (rel_err(g_d, g64), rel_err(g32, g64))
+    assert abs(loss_d + loss_sum / B) <= 1e-5 * max(1.0, abs(loss_sum / B))
+    assert abs(ent_d - ent_sum / B) < 1e-5
+    # every parameter block receives gradient
+    H, D = 128, 5
+    cuts = np.cumsum([3 * H * D, 3 * H * H, 3 * H, 3 * H, H * H, H, 2 * H, 2])
+    for lo, hi in zip(np.r_[0, cuts[:-1]], cuts):
+        assert np.abs(g_d[lo:hi]).max() > 0
+        assert rel_err(g_d[lo:hi], g64[lo:hi]) < 50 * GRAD_RTOL
+
+
+def test_critic_gradient_through_time(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p = cri.get_params()
+    g_d, loss_d = ra.critic_gradient(cri, traj)
+    v, _ = O.gru_seq_forward(CS, p, want, f64=True, want_succ=False)
+    B = v[0].size
+    d = v - want["rtg"].astype(np.float64)[None]
+    g64 = O.gru_seq_backward(CS, p, want, 2.0 * d / B, f64=True)
+    assert rel_err(g_d, g64) < GRAD_RTOL
+    assert abs(loss_d - (d * d).mean()) <= 1e-5 * (d * d).mean()
+
+
+def oracle_ppo_loop(p, want, ocfg, steps, clip):
+    p = p.copy()
+    st = L.oracle_adam_new(len(p))
+    logits, _ = O.gru_seq_forward(PS, p, want, want_succ=False)
+    _, lp0, _, ent_sum = O.seq_policy_dlogits(logits, want["action"], want["adv"])
+    B = want["action"].size
+    losses = []
+    for k in range(steps):
+        logits, _ = O.gru_seq_forward(PS, p, want, want_succ=False)
+        dl, _, obj, _ = O.seq_policy_dlogits(logits, want["action"], want["adv"], logp0=lp0, clip=clip)
+        losses.append(-obj / B)
+        g = O.gru_seq_backward(PS, p, want, dl)
+        L.oracle_adam_step_f32(st, C.byref(ocfg), O.f32p(p), O.f32p(g))
+    L.oracle_adam_free(st)
+    return p, np.array(losses), ent_sum / B
+
+
+@pytest.mark.parametrize("lr,steps", [(1e-3, 4), (1e-2, 5)], ids=["default-lr", "clipping-active"])
+def test_ppo_update_recurrent(engine, lr, steps):
+    pol, cri, traj, want, acfg, ocfg = setup_update(engine, lr=lr)
+    p0 = pol.get_params().copy()
+    opt = ra.Adam(pol, acfg)
+    cfg = ra.ppo_config_default()
+    cfg.opt_steps_per_update = steps
+    st, losses_d = ra.ppo_update(pol, opt, traj, cfg, want_losses=True)
+    p_o, losses_o, ent_o = oracle_ppo_loop(p0, want, ocfg, steps, 0.2)
+    assert abs(st.entropy - ent_o) < 1e-5
+    assert np.max(np.abs(losses_d - losses_o)) < 3e-5 * max(1.0, np.abs(losses_o).max()), (losses_d, losses_o)
+    diff = np.abs(pol.get_params() - p_o)
+    assert np.mean(diff < 3e-5) > 0.97  # Adam amplifies rounding-level gradient differences where |g| ~ 0
+    assert losses_d[-1] < losses_d[0]
+
+
+def test_reinforce_and_critic_updates_recurrent(engine):
+    pol, cri, traj, want, acfg, ocfg = setup_update(engine)
+    # REINFORCE: one Adam step along the surrogate gradient
+    p0 = pol.get_params().copy()
+    st = ra.reinforce_update(pol, ra.Adam(pol, acfg), traj)
+    logits, _ = O.gru_seq_forward(PS, p0, want, want_succ=False)
+    dl, lp, _, ent_sum = O.seq_policy_dlogits(logits, want["action"], want["adv"])
+    B = want["action"].size
+    assert abs(st.loss_first + float((lp.astype(np.float64) * want["adv"]).sum()) / B) < 1e-5
+    assert abs(st.entropy - ent_sum / B) < 1e-5
+    p_o = p0.copy()
+    ost = L.oracle_adam_new(len(p_o))
+    L.oracle_adam_step_f32(ost, C.byref(ocfg), O.f32p(p_o), O.f32p(O.gru_seq_backward(PS, p0, want, dl)))
+    L.oracle_adam_free(ost)
+    moved = np.abs(pol.get_params() - p0)
+    assert 0 < moved.max() <= 1.001e-3  # first Adam step: at most lr per parameter
+    assert np.mean(np.abs(pol.get_params() - p_o) < 3e-5) > 0.97
+    # critic: 3 x {MSE, backward through time, Adam}
+    c0 = cri.get_params().copy()
+    cst, losses_d = ra.critic_update(cri, ra.Adam(cri, acfg), traj, 3, want_losses=True)
+    p = c0.copy()
+    ost = L.oracle_adam_new(len(p))
+    losses_o = []
+    for k in range(3):
+        v, _ = O.gru_seq_forward(CS, p, want, want_succ=False)
+        d = v[0] - want["rtg"]
+        losses_o.append(float((d.astype(np.float64) ** 2).mean()))
+        g = O.gru_seq_backward(CS, p, want, (d * np.float32(2.0 / B))[None])
+        L.oracle_adam_step_f32(ost, C.byref(ocfg), O.f32p(p), O.f32p(g))
+    L.oracle_adam_free(ost)
+    assert np.max(np.abs(losses_d - np.array(losses_o)) / np.array(losses_o)) < 2e-5
+    assert np.mean(np.abs(cri.get_params() - p) < 3e-5) > 0.97
+    assert losses_d[-1] < losses_d[0]
+
+
+def test_trpo_is_refused_for_recurrent_modules(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    with pytest.raises(ra.RelearnError) as e:
+        ra.trpo_update(pol, traj)
+    assert e.value.code == ra.ERR_UNSUPPORTED
