@@ -225,10 +225,17 @@ __device__ __forceinline__ void seq_cell(SeqFwdShared &sh, const SeqFwdWeights<D
       for (int d = 0; d < D; ++d) v = __builtin_fmaf(sh.xS[m][d], w.wih[gte][d], v);
       gi[gte] = v;
     }
+#if defined(SEQ_ABLATE) && (SEQ_ABLATE & 1)
+    const float rr = 0.5f + 0.01f * (acc[0][r] + gi[0]);
+    const float zz = 0.5f + 0.01f * (acc[1][r] + gi[1]);
+    const float rn = acc[2][r] * rr;
+    const float nn = 0.1f * (gi[2] + rn);
+#else
     const float rr = rl_sigmoidf(acc[0][r] + gi[0]);
     const float zz = rl_sigmoidf(acc[1][r] + gi[1]);
     const float rn = acc[2][r] * rr;
     const float nn = rl_tanhf(gi[2] + rn);
+#endif
     const float dn = hown[r] - nn;
     const float hz = dn * zz;
     const float hv = hz + nn;
@@ -265,8 +272,12 @@ __device__ __forceinline__ void seq_cell(SeqFwdShared &sh, const SeqFwdWeights<D
   if (wave == 0 && hf < A) {
     // out_a[m] = b2_a + sum_j u[m][j] W2[a][j], sequential chain (lane = (m = n, a = hf))
     float z = b2_mine;
+#if defined(SEQ_ABLATE) && (SEQ_ABLATE & 2)
+    for (int q = 0; q < 4; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
+#else
 #pragma unroll 8
     for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
+#endif
     sh.outS[hf][n] = z;
   }
   __syncthreads();

@@ -1,0 +1,56 @@
+"""BASELINE.json configs[4]: partially observed Chain (LatentStepLimit 100) with the GRU policy, 16,384 lanes, T = 100,
+one MI355X: rollout, GAE with a recurrent critic, PPO (10 steps) and critic (80 steps) updates through time.
+Prints one JSON line: device times (HIP events) per phase and per kernel class, and MFMA rates."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import relearn_amd as ra  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+critic_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 80
+periods = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+
+eng = ra.Engine(0)
+env = ra.ChainEnv(eng, N, max_steps=100)
+pol, cri = ra.GruMlp(eng, 5, 2), ra.GruMlp(eng, 5, 1)
+pol.init(1)
+cri.init(2)
+popt, copt = ra.Adam(pol), ra.Adam(cri)
+traj = ra.Trajectory(eng, N, T, 5)
+ppo = ra.ppo_config_default()
+
+
+def period():
+    t = {}
+    eng.timer_begin(); ra.rollout(env, pol, traj); t["rollout_ms"] = eng.timer_end()
+    eng.timer_begin(); ra.gae(traj, cri, 0.95, 0.95); t["gae_ms"] = eng.timer_end()
+    eng.timer_begin(); ps = ra.ppo_update(pol, popt, traj, ppo); t["ppo_ms"] = eng.timer_end()
+    eng.timer_begin(); cs = ra.critic_update(cri, copt, traj, critic_steps); t["critic_ms"] = eng.timer_end()
+    return t, ps, cs
+
+
+period()  # warm-up (allocates the activation records)
+eng.profile_enable(True)
+eng.profile_read(reset=True)
+acc = {}
+for _ in range(periods):
+    t, ps, cs = period()
+    for k, v in t.items():
+        acc[k] = acc.get(k, 0.0) + v / periods
+prof = eng.profile_read(reset=True)
+steps = N * T
+fwd_flop = 2.0 * (128 * 384 + 128 * 128) * steps            # one cell + MLP layer per sample-step (MFMA part)
+bwd_flop = fwd_flop                                         # W_hh^T and W1^T products
+wg_flop = 2.0 * (384 * 128 + 128 * 128) * steps             # dW_hh and dW1 GEMMs
+total_ms = sum(acc.values())
+out = {"lanes": N, "horizon": T, "env_steps_per_period": steps, **acc, "period_ms": total_ms,
+       "env_steps_per_s": steps / total_ms * 1e3,
+       "rollout_tflops": fwd_flop / acc["rollout_ms"] / 1e9,
+       "policy_loss": [ps.loss_first, ps.loss_last], "critic_loss": [cs.loss_first, cs.loss_last],
+       "kernel_ms_per_period": {k: v[0] / periods for k, v in prof.items() if v[1]},
+       "kernel_launches_per_period": {k: v[1] / periods for k, v in prof.items() if v[1]},
+       "flop_per_pass": {"forward": fwd_flop, "bptt": bwd_flop, "wgrad": wg_flop}}
+print(json.dumps(out))
