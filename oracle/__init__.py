@@ -326,6 +326,10 @@ def _declare(L):
                                               P(C.c_uint8), P(C.c_float), P(C.c_float)]
     L.oracle_gru_seq_backward_f64.argtypes = [GruShape, P(C.c_double), C.c_uint64, C.c_uint64, P(C.c_double),
                                               P(C.c_uint8), P(C.c_double), P(C.c_double)]
+    L.oracle_gru_seq_jvp_f32.argtypes = [GruShape, P(C.c_float), P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float),
+                                         P(C.c_uint8), P(C.c_float)]
+    L.oracle_gru_seq_jvp_f64.argtypes = [GruShape, P(C.c_double), P(C.c_double), C.c_uint64, C.c_uint64,
+                                         P(C.c_double), P(C.c_uint8), P(C.c_double)]
     L.oracle_chain_lanes_new.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.c_uint64]
     L.oracle_chain_lanes_new.restype = P(ChainLanes)
@@ -675,6 +679,33 @@ def gru_seq_backward(shape, params, traj, dout, f64=False):
     fn(shape, ptr(np.ascontiguousarray(params, dtype=dt)), n, T, ptr(np.ascontiguousarray(obs, dtype=dt)),
        u8p(traj["flag"]), ptr(np.ascontiguousarray(dout, dtype=dt)), ptr(g))
     return g
+
+
+def gru_seq_jvp(shape, params, tangent, traj, f64=False):
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    dt = np.float64 if f64 else np.float32
+    ptr = f64p if f64 else f32p
+    out = np.zeros((shape.out_dim, T, n), dtype=dt)
+    fn = lib().oracle_gru_seq_jvp_f64 if f64 else lib().oracle_gru_seq_jvp_f32
+    fn(shape, ptr(np.ascontiguousarray(params, dtype=dt)), ptr(np.ascontiguousarray(tangent, dtype=dt)), n, T,
+       ptr(np.ascontiguousarray(obs, dtype=dt)), u8p(traj["flag"]), ptr(out))
+    return out
+
+
+def gru_policy_fvp(shape, params, v, traj, reg, f64=False):
+    """Fisher-vector product of the mean KL at params (J^T (diag(p) - p p^T) J v / B + reg v) through time"""
+    dt = np.float64 if f64 else np.float32
+    logits, _ = gru_seq_forward(shape, params, traj, f64=f64, want_succ=False)
+    od = gru_seq_jvp(shape, params, v, traj, f64=f64)
+    z = logits - logits.max(0)
+    lp = z - np.log(np.exp(z).sum(0))
+    pr = np.exp(lp).astype(dt)
+    B = logits[0].size
+    pdz = (pr * od).sum(0)
+    dz = (pr * (od - pdz) / dt(B)).astype(dt)
+    return gru_seq_backward(shape, params, traj, dz, f64=f64) + dt(reg) * np.asarray(v, dtype=dt)
 
 
 def seq_gae(values, succ_values, traj, gamma, lam):

@@ -375,6 +375,11 @@ void oracle_gru_seq_backward_f32(oracle_gru_shape s, const float *params, uint64
 void oracle_gru_seq_backward_f64(oracle_gru_shape s, const double *params, uint64_t n, uint64_t T, const double *obs,
                                  const uint8_t *flag, const double *dout, double *grad_out);
 
+void oracle_gru_seq_jvp_f32(oracle_gru_shape s, const float *params, const float *tangent, uint64_t n, uint64_t T,
+                            const float *obs, const uint8_t *flag, float *out_dot);
+void oracle_gru_seq_jvp_f64(oracle_gru_shape s, const double *params, const double *tangent, uint64_t n, uint64_t T,
+                            const double *obs, const uint8_t *flag, double *out_dot);
+
 typedef struct {
   oracle_chain env;
   int limit_kind;

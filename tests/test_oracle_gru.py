@@ -140,3 +140,40 @@ def test_rollout_teacher_forcing_consistency_and_gae():
     te = t_end[0]
     delta = (traj["reward"][te, 3] + np.float32(0.95) * sv[0][te, 3]) - v[0][te, 3]
     assert adv[te, 3] == delta
+
+
+@pytest.mark.parametrize("name,rtol", [("gru_f32", 3e-5), ("gru_f64", 1e-11)])
+def test_forward_mode_derivative_through_time(name, rtol):
+    """oracle_gru_seq_jvp against torch.autograd.functional.jvp of all step outputs along a parameter tangent"""
+    c, s, traj = _case(name)
+    f64 = name.endswith("f64")
+    od = O.gru_seq_jvp(s, np.array(c["params"]), np.array(c["tangent"]), traj, f64=f64)
+    want = np.array(c["out_dot"]).reshape(od.shape)
+    assert np.max(np.abs(od - want)) <= rtol * np.max(np.abs(want))
+
+
+def test_fisher_vector_product_is_symmetric_positive_and_matches_finite_differences():
+    """F = J^T M J / B: v.Fw == w.Fv, v.Fv >= 0, and F v = d/de grad KL(pi_theta0 || pi_theta0+e v) at e -> 0"""
+    s = O.GruShape(5, 16, 12, 2)
+    sim = O.ChainLaneSim(24, max_steps=7, seed_env=2, seed_actor=3)
+    p = O.gru_init(s, 4).astype(np.float64)
+    traj = sim.rollout_gru(s, p.astype(np.float32), 18, threads=2)
+    rng = np.random.default_rng(0)
+    v, w = rng.normal(size=len(p)), rng.normal(size=len(p))
+    Fv = O.gru_policy_fvp(s, p, v, traj, 0.0, f64=True)
+    Fw = O.gru_policy_fvp(s, p, w, traj, 0.0, f64=True)
+    assert abs(v @ Fw - w @ Fv) <= 1e-10 * abs(v @ Fw)
+    assert v @ Fv > 0
+
+    def kl_grad(theta):
+        l0, _ = O.gru_seq_forward(s, p, traj, f64=True, want_succ=False)
+        l1, _ = O.gru_seq_forward(s, theta, traj, f64=True, want_succ=False)
+        lp0 = l0 - np.log(np.exp(l0).sum(0))
+        lp1 = l1 - np.log(np.exp(l1).sum(0))
+        # d KL(p0 || p1) / d logits1 = (p1 - p0) / B
+        dz = (np.exp(lp1) - np.exp(lp0)) / l0[0].size
+        return O.gru_seq_backward(s, theta, traj, dz, f64=True)
+
+    e = 1e-5
+    fd = (kl_grad(p + e * v) - kl_grad(p - e * v)) / (2 * e)
+    assert np.max(np.abs(fd - Fv)) <= 2e-5 * np.max(np.abs(Fv))
