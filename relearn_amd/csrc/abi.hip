@@ -1020,6 +1020,25 @@ static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backwa
   else rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
 }
 
+// (loss, KL) of the current parameters against log pi_0: forward without a record -> sums in vec[P..P+4)
+static void seq_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
+  seq_ensure(traj, policy, true);
+  uint32_t P = (uint32_t)policy->P;
+  launch_gru_seq_forward(traj, policy, traj->seq.out, nullptr, nullptr, d_skip);
+  launch_seq_policy_dlogits(traj, PASS_EVAL, b_total(traj), 0.0f, 0.0f, d_skip);
+  launch_reduce(traj, P, false, true, 0, traj->nbB);
+  rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
+}
+
+// Fisher-vector product with the tangent d_v at the parameters whose activation record is in place (the last
+// seq_policy_pass with backward = true): vec[0..P) <- J^T (diag(p) - p p^T) J v / B
+static void seq_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
+  seq_ensure(traj, policy, true);
+  launch_gru_tangent(traj, policy, d_v, b_total(traj), d_skip);
+  launch_gru_backward(traj, policy, d_skip);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, (uint32_t)policy->P);
+}
+
 static void seq_critic_pass(rl_mlp *critic, rl_traj *traj) {
   seq_ensure(traj, critic, true);
   uint32_t P = (uint32_t)critic->P;
@@ -1066,6 +1085,7 @@ static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
 
 // (loss, KL) of the current parameters against lp0: PASS_EVAL -> reduce(B) -> allreduce
 static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_eval(policy, traj, d_skip);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
     launch_reduce(traj, P, false, true, traj->nbV2, traj->nbV2);
@@ -1078,6 +1098,7 @@ static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip
 
 // Fisher/Hessian-vector product pass with tangent d_v: PASS_JVP -> backward -> reduce(A) -> allreduce
 static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_fvp(policy, traj, d_v, d_skip);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
     launch_reduce(traj, P, true, false, traj->nbV2, traj->nbV2);
@@ -1093,10 +1114,6 @@ int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg,
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
     RL_REQUIRE(cfg && stats, "NULL argument");
-    if (policy->kind != RL_MODULE_MLP)
-      throw RlError(RL_ERR_UNSUPPORTED, "TRPO needs Hessian-vector products through the recurrent module, which this "
-                                        "build does not have (the reference disables cuDNN for them, trpo.rs:104-108); "
-                                        "use rl_ppo_update / rl_reinforce_update");
     rl_engine *e = traj->eng;
     uint32_t P = (uint32_t)policy->P;
     uint64_t Bt = b_total(traj);
@@ -1157,11 +1174,10 @@ int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float
 int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, float *out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
-    if (policy->kind != RL_MODULE_MLP) throw RlError(RL_ERR_UNSUPPORTED, "feed-forward policies only");
     RL_REQUIRE(v && out, "NULL argument");
     uint32_t P = (uint32_t)policy->P;
     run_policy_gradient(policy, traj);  // the product is taken at the current parameters: refresh log pi_0
-    h2d(traj->eng, traj->cg_x, v, P * sizeof(float));
+    h2d(traj->eng, traj->cg_x, v, P * sizeof(float));  // (the recurrent pass above has grown the workspace)
     run_policy_fvp(policy, traj, traj->cg_x, nullptr);
     std::vector<float> h(P);
     d2h(traj->eng, h.data(), traj->vec, P * sizeof(float));
@@ -1172,7 +1188,6 @@ int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, 
 int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, float *loss_out, float *kl_out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
-    if (policy->kind != RL_MODULE_MLP) throw RlError(RL_ERR_UNSUPPORTED, "feed-forward policies only");
     RL_REQUIRE(params0 && loss_out && kl_out, "NULL argument");
     rl_engine *e = traj->eng;
     uint32_t P = (uint32_t)policy->P;

@@ -61,8 +61,14 @@ void launch_chain_observe(rl_env *env, float *d_obs);
 void launch_chain_step(rl_env *env);
 void launch_rollout_chain_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 // teacher-forced forward: d_out [A][T][n]; d_succ (may be NULL) [A][T][n]; d_act (may be NULL) activation record
-void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act);
+void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,
+                            const int32_t *d_skip = nullptr);
 void launch_seq_gae(rl_traj *traj, float gamma, float lambda);  // reads traj->seq.out / succ (plane 0)
-void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi);
+void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi,
+                               const int32_t *d_skip = nullptr);
 void launch_seq_critic_dvalues(rl_traj *traj, uint64_t B_total);
-void launch_gru_backward(rl_traj *traj, const rl_mlp *mod);  // traj->dz, seq.act -> traj->vec[0..P)
+void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip = nullptr);  // dz, seq.act -> vec[0..P)
+// Fisher-vector product pieces: static tangent terms (dpre, seq.succ) from the tangent parameters, then the recurrent
+// tangent pass -> seq.out = d logits . tangent, then dz <- (diag(p) - p p^T) (.) / B
+void launch_gru_tangent(rl_traj *traj, const rl_mlp *mod, const float *d_tangent, uint64_t B_total,
+                        const int32_t *d_skip);

@@ -238,8 +238,98 @@ def test_reinforce_and_critic_updates_recurrent(engine):
     assert losses_d[-1] < losses_d[0]
 
 
-def test_trpo_is_refused_for_recurrent_modules(engine):
+def test_fisher_vector_product_through_time(engine):
     pol, cri, traj, want, _, _ = setup_update(engine)
-    with pytest.raises(ra.RelearnError) as e:
-        ra.trpo_update(pol, traj)
-    assert e.value.code == ra.ERR_UNSUPPORTED
+    p = pol.get_params()
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=len(p)).astype(np.float32)
+    reg = 1e-5
+    hv_d = ra.policy_fvp(pol, traj, v, reg)
+    hv64 = O.gru_policy_fvp(PS, p.astype(np.float64), v.astype(np.float64), want, reg, f64=True)
+    hv32 = O.gru_policy_fvp(PS, p, v, want, reg)
+    assert rel_err(hv_d, hv64) < 2e-5, (rel_err(hv_d, hv64), rel_err(hv32, hv64))
+    assert rel_err(hv_d, hv64) < 4 * rel_err(hv32, hv64) + 2e-6
+    # loss / KL of perturbed parameters against the old policy
+    p1 = p + 0.05 * v / np.abs(v).max()
+    pol.set_params(p1)
+    loss_d, kl_d = ra.policy_loss_kl(pol, traj, p)
+    l0, _ = O.gru_seq_forward(PS, p, want, f64=True, want_succ=False)
+    l1, _ = O.gru_seq_forward(PS, p1, want, f64=True, want_succ=False)
+    lp0, lp1 = l0 - np.log(np.exp(l0).sum(0)), l1 - np.log(np.exp(l1).sum(0))
+    a = want["action"].astype(np.int64)
+    sel = lambda lp: np.where(a == 0, lp[0], lp[1])
+    loss_o = -(np.exp(sel(lp1) - sel(lp0)) * want["adv"]).mean()
+    kl_o = (np.exp(lp0) * (lp0 - lp1)).sum(0).mean()
+    assert abs(loss_d - loss_o) <= 2e-5 * max(1.0, abs(loss_o))
+    # per-sample KL terms are f32 differences of log-probabilities: absolute error ~1e-8 on the mean
+    assert abs(kl_d - kl_o) <= 1e-4 * kl_o + 3e-8 and kl_o > 1e-5
+
+
+def oracle_trpo_loop(p0, want, f64, iterations=10, max_backtracks=15, ratio=0.8, reg=1e-5, max_kl=0.01):
+    """trust_region_backward_step + backtracking_line_search (conjugate_gradient.rs:115-255) on the oracle's
+    recurrent gradient / Fisher-vector / loss-KL pieces; arithmetic in f32 or f64"""
+    dt = np.float64 if f64 else np.float32
+    p0 = p0.astype(dt)
+    a = want["action"].astype(np.int64)
+    adv = want["adv"].astype(dt)
+    B = a.size
+
+    def logp(p):
+        l, _ = O.gru_seq_forward(PS, p, want, f64=f64, want_succ=False)
+        l = l.astype(dt)
+        z = l - l.max(0)
+        return (z - np.log(np.exp(z).sum(0))).astype(dt)
+
+    lp0 = logp(p0)
+    sel = lambda lp: np.where(a == 0, lp[0], lp[1])
+    pr = np.exp(lp0)
+    ind = np.stack([a == 0, a == 1]).astype(dt)
+    g = O.gru_seq_backward(PS, p0, want, (-(adv / dt(B)) * (ind - pr)).astype(dt), f64=f64).astype(dt)
+    loss0 = dt(-(adv.astype(np.float64)).mean())
+    fvp = lambda v: O.gru_policy_fvp(PS, p0, v, want, reg, f64=f64).astype(dt)
+    x = np.zeros_like(g)
+    r, pp = g.copy(), g.copy()
+    rr = dt(r @ r)
+    iters = 0
+    for _ in range(iterations):
+        z = fvp(pp)
+        alpha = dt(rr / dt(pp @ z))
+        x = (x + alpha * pp).astype(dt)
+        r = (r - alpha * z).astype(dt)
+        new_rr = dt(r @ r)
+        iters += 1
+        if float(new_rr) < 1e-10:
+            break
+        pp = (r + dt(new_rr / rr) * pp).astype(dt)
+        rr = new_rr
+    xhx = float(x @ fvp(x))
+    step_size = np.sqrt(1.0 / (xhx + 1e-8) * max_kl * 2.0)
+    descent = (dt(step_size) * x).astype(dt)
+    for i in range(max_backtracks):
+        cand = (p0 - dt(ratio ** i) * descent).astype(dt)
+        lp1 = logp(cand)
+        loss = -(np.exp(sel(lp1) - sel(lp0)).astype(np.float64) * adv).mean()
+        kl = (np.exp(lp0).astype(np.float64) * (lp0 - lp1)).sum(0).mean()
+        if loss < float(loss0) and kl <= max_kl:
+            return cand, step_size, i, loss, kl, iters
+    return p0, step_size, -1, float(loss0), 0.0, iters
+
+
+def test_trpo_update_through_time(engine):
+    """Same tolerance rule as the feed-forward TRPO test: f32 CG is ill-conditioned, so the device result is
+    compared with the f64 evaluation and must be no farther from it than twice the f32 restatement is."""
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p0 = pol.get_params().copy()
+    st = ra.trpo_update(pol, traj)
+    p64, ss64, bt64, loss64, kl64, it64 = oracle_trpo_loop(p0, want, True)
+    p32, ss32, bt32, loss32, kl32, it32 = oracle_trpo_loop(p0, want, False)
+    assert st.status == ra.OPT_OK and st.cg_iterations == it64 == it32 == 10
+    assert abs(st.step_size - ss64) <= 2.0 * abs(ss32 - ss64) + 1e-3 * ss64, (st.step_size, ss32, ss64)
+    assert min(bt32, bt64) - 1 <= st.num_backtracks <= max(bt32, bt64) + 1
+    assert st.constraint_val_final <= 0.01 and st.loss_final < st.loss_initial
+    # what was accepted is what the device says: re-evaluate the new parameters independently
+    p1 = pol.get_params()
+    loss_d, kl_d = ra.policy_loss_kl(pol, traj, p0)
+    assert abs(loss_d - st.loss_final) <= 1e-5 * max(1.0, abs(st.loss_final))
+    assert abs(kl_d - st.constraint_val_final) <= 1e-5 + 1e-3 * kl_d
+    assert np.abs(p1 - p0).max() > 0
