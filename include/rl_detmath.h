@@ -187,28 +187,50 @@ RL_HD float rl_logf(float x) {
 }
 
 /* ---- f32 sigmoid / tanh (GRU gates, torch gru_cell: sigmoid_, tanh_) ---------------------- */
-/* 1 / (1 + exp(-x)); exp(-x) = +inf for x < -88.7 gives exactly 0, exp(-x) = 0 gives exactly 1. */
-RL_HD float rl_sigmoidf(float x) { return 1.0f / (1.0f + rl_expf(-x)); }
+/* e^y for y <= 0 without a division: y = k ln2 + r, |r| <= ln2 / 2, degree-7 Taylor polynomial of e^r by Horner
+ * with fma (truncation < 6e-9 relative), scaled by 2^k through the exponent field.  Returns 0 below -87 (the
+ * callers add 1 to the result).  One rounding per fma, so host and device agree bit for bit. */
+RL_HD float rl_exp_nonpos(float y) {
+  if (!(y > -87.0f)) return y != y ? y : 0.0f;
+  const float kf = (float)(int)(y * 1.4426950216e+00f - 0.5f); /* round to nearest, y <= 0 */
+  float r = __builtin_fmaf(kf, -6.9314575195e-01f, y);         /* ln2 high part, exact product for |k| < 2^11 */
+  r = __builtin_fmaf(kf, -1.4286067653e-06f, r);
+  float p = 1.9841270114e-04f;               /* 1/5040 */
+  p = __builtin_fmaf(p, r, 1.3888889225e-03f); /* 1/720 */
+  p = __builtin_fmaf(p, r, 8.3333337680e-03f); /* 1/120 */
+  p = __builtin_fmaf(p, r, 4.1666667908e-02f); /* 1/24 */
+  p = __builtin_fmaf(p, r, 1.6666667163e-01f); /* 1/6 */
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  return p * rl_f32_from_bits((uint32_t)((int)kf + 127) << 23);
+}
+
+/* sigmoid(x) = 1 / (1 + e^-|x|) for x >= 0 and e^-|x| / (1 + e^-|x|) for x < 0: one exp, one division */
+RL_HD float rl_sigmoidf(float x) {
+  if (x != x) return x;
+  const float t = rl_exp_nonpos(x < 0.0f ? x : -x);
+  const float s = 1.0f / (1.0f + t);
+  return x < 0.0f ? t * s : s;
+}
 
 /* tanh: odd polynomial below 0.25 (truncation error < 4e-11 relative), (1 - e^-2|x|) / (1 + e^-2|x|) above;
- * exactly +-1 once e^-2|x| underflows below half an ulp of 1 (|x| > 9.02). */
+ * exactly +-1 once e^-2|x| underflows below half an ulp of 1 (|x| > 9.02).  Both branches are cheap enough to be
+ * evaluated unconditionally on the GPU (no divergence). */
 RL_HD float rl_tanhf(float x) {
   if (x != x) return x;
-  float ax = x < 0.0f ? -x : x;
-  float y;
-  if (ax < 0.25f) {
-    float x2 = ax * ax;
-    float p = -8.8632355e-03f;                 /* -1382/155925 */
-    p = 2.1869488e-02f + x2 * p;               /*  62/2835 */
-    p = -5.3968254e-02f + x2 * p;              /* -17/315 */
-    p = 1.3333334e-01f + x2 * p;               /*  2/15 */
-    p = -3.3333334e-01f + x2 * p;              /* -1/3 */
-    y = ax + ax * (x2 * p);
-  } else {
-    float t = rl_expf(-2.0f * ax);
-    y = (1.0f - t) / (1.0f + t);
-  }
-  return x < 0.0f ? -y : y;
+  const float ax = x < 0.0f ? -x : x;
+  const float x2 = ax * ax;
+  float p = -8.8632355e-03f;                 /* -1382/155925 */
+  p = 2.1869488e-02f + x2 * p;               /*  62/2835 */
+  p = -5.3968254e-02f + x2 * p;              /* -17/315 */
+  p = 1.3333334e-01f + x2 * p;               /*  2/15 */
+  p = -3.3333334e-01f + x2 * p;              /* -1/3 */
+  const float small = ax + ax * (x2 * p);
+  const float t = rl_exp_nonpos(-2.0f * ax);
+  const float big = (1.0f - t) / (1.0f + t);
+  const float y = ax < 0.25f ? small : big;
+  return rl_f32_from_bits(rl_f32_bits(y) | (rl_f32_bits(x) & 0x80000000u)); /* odd, tanh(-0) = -0 */
 }
 
 #endif /* RL_DETMATH_H */

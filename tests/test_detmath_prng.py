@@ -21,6 +21,8 @@ PROBE_C = r'''
 void probe_sincos(const double *x, int n, double *s, double *c) { for (int i = 0; i < n; ++i) rl_sincos(x[i], s + i, c + i); }
 void probe_expf(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = rl_expf(x[i]); }
 void probe_logf(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = rl_logf(x[i]); }
+void probe_sigmoidf(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = rl_sigmoidf(x[i]); }
+void probe_tanhf(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = rl_tanhf(x[i]); }
 void probe_block(const uint32_t *key, uint64_t counter, uint64_t stream, int dr, uint32_t *out) { rl_chacha_block(key, counter, stream, dr, out); }
 void probe_seed(uint64_t s, uint32_t *key) { rl_seed_from_u64(s, key); }
 double probe_scale(double lo, double hi) { return rl_uniform_f64_inclusive_scale(lo, hi); }
@@ -84,6 +86,34 @@ def test_expf_logf_accuracy(probe):
     out = np.zeros_like(sp)
     probe.probe_logf(O.f32p(sp), len(sp), O.f32p(out))
     assert out[0] == 0.0 and out[1] == np.float32(np.log(2.0)) and out[2] == -np.inf and np.isnan(out[3])
+
+
+def test_sigmoid_tanh_accuracy(probe):
+    """GRU gate functions: within 3 ulp of the exact value over the whole range, exact limits and symmetry"""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-1, 1, 200000), rng.uniform(-12, 12, 200000), rng.uniform(-100, 100, 50000),
+                        rng.uniform(-0.3, 0.3, 100000)]).astype(np.float32)
+    y = np.zeros_like(x)
+    probe.probe_sigmoidf(O.f32p(x), len(x), O.f32p(y))
+    ref = 1.0 / (1.0 + np.exp(-x.astype(np.longdouble)))
+    m = ref > 1e-35
+    assert ulps32(y[m], ref[m].astype(np.float64)).max() <= 3.0
+    probe.probe_tanhf(O.f32p(x), len(x), O.f32p(y))
+    ref = np.tanh(x.astype(np.longdouble)).astype(np.float64)
+    m = np.abs(ref) > 0
+    assert ulps32(y[m], ref[m]).max() <= 3.0
+    sp = np.array([0.0, -0.0, 30.0, -30.0, 200.0, -200.0, np.nan, 1e-20], np.float32)
+    out = np.zeros_like(sp)
+    probe.probe_tanhf(O.f32p(sp), len(sp), O.f32p(out))
+    assert out[0] == 0.0 and np.signbit(out[1]) and out[2] == 1.0 and out[3] == -1.0 and out[4] == 1.0
+    assert out[5] == -1.0 and np.isnan(out[6]) and out[7] == np.float32(1e-20)
+    probe.probe_sigmoidf(O.f32p(sp), len(sp), O.f32p(out))
+    assert out[0] == 0.5 and out[1] == 0.5 and out[4] == 1.0 and out[5] == 0.0 and np.isnan(out[6])
+    a = rng.uniform(-8, 8, 1000).astype(np.float32)
+    ya, yb = np.zeros_like(a), np.zeros_like(a)
+    probe.probe_tanhf(O.f32p(a), len(a), O.f32p(ya))
+    probe.probe_tanhf(O.f32p(-a), len(a), O.f32p(yb))
+    assert np.array_equal(ya, -yb)
 
 
 def test_chacha_known_answers(probe):
