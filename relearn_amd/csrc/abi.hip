@@ -1277,17 +1277,23 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
   RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
 }
 
-static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
-  if (critic->kind == RL_MODULE_GRU_MLP) return seq_critic_pass(critic, traj);
-  uint32_t P = (uint32_t)critic->P;
+// per-workgroup partial sums of the critic's MSE gradient and loss -> slabA / slabB (feed-forward modules)
+static void critic_slabs(rl_mlp *critic, rl_traj *traj, uint32_t *rowsA, uint32_t *rowsB) {
   if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
-    uint32_t rows = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbV2;
-    launch_reduce(traj, P, true, true, rows, rows);
+    *rowsA = *rowsB = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbV2;
   } else {
     launch_critic_fwd(traj, critic, b_total(traj));
     launch_mlp_backward(traj, critic, nullptr);
-    launch_reduce(traj, P, true, true, traj->nbA, traj->nbB);
+    *rowsA = traj->nbA;
+    *rowsB = traj->nbB;
   }
+}
+
+static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
+  if (critic->kind == RL_MODULE_GRU_MLP) return seq_critic_pass(critic, traj);
+  uint32_t P = (uint32_t)critic->P, rowsA, rowsB;
+  critic_slabs(critic, traj, &rowsA, &rowsB);
+  launch_reduce(traj, P, true, true, rowsA, rowsB);
   rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
 }
 
@@ -1298,9 +1304,16 @@ int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t o
     RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
     RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
     uint64_t Bt = b_total(traj);
+    const bool fused = critic->kind == RL_MODULE_MLP && traj->eng->comm == nullptr;
     for (uint64_t k = 0; k < opt_steps; ++k) {
-      run_critic_gradient(critic, traj);
-      launch_adam_step(traj, opt, (int)k, Bt);
+      if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
+        uint32_t rowsA, rowsB;
+        critic_slabs(critic, traj, &rowsA, &rowsB);
+        launch_reduce_adam(traj, opt, rowsA, rowsB, (int)k, Bt);
+      } else {
+        run_critic_gradient(critic, traj);
+        launch_adam_step(traj, opt, (int)k, Bt);
+      }
     }
     if (stats || losses_out) {
       std::vector<float> h(opt_steps ? opt_steps : 1);

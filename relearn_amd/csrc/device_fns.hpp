@@ -137,6 +137,9 @@ __device__ __forceinline__ void mlp_forward_lane(const float *__restrict__ param
   const float *__restrict__ b2 = W2 + A * H;
 #pragma unroll
   for (int a = 0; a < A; ++a) z[a] = b2[a];
+  // the hidden units are independent of one another (only the A output chains are sequential in j): unrolling
+  // lets one wave keep several of the 5-deep fma chains in flight
+#pragma unroll 8
   for (int j = 0; j < H; ++j) {
     float acc = b1[j];
 #pragma unroll

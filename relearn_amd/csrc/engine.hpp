@@ -167,6 +167,7 @@ struct rl_adam {
   rl_adam_config cfg;
   float *d_m = nullptr, *d_v = nullptr;
   uint64_t *d_step = nullptr;
+  uint64_t host_step = 0;  // == *d_step once the stream has drained (every Adam launch increments both)
 };
 
 struct rl_traj {

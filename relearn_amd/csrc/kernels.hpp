@@ -36,6 +36,8 @@ void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, dou
 void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept_violation);
 void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_total);     // after critic reduce
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad);
+// reduce(A + B) and Adam in one launch (single-rank runs: no all-reduce between the two)
+void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t rowsB, int loss_slot, uint64_t B_total);
 
 // kernels_mfma.hip ("v2": f32-MFMA layer 1, lane = hidden unit backward; H = 128, D = 5 only)
 // returns false when the shape is not supported (caller falls back to the v1 kernels)

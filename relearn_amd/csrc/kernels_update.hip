@@ -543,6 +543,66 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
   }
 }
 
+// k_reduce followed by the Adam update of the 64 entries each workgroup has just reduced (Adam is elementwise, so
+// no second launch is needed when no all-reduce sits between the two: single-rank runs).  Same arithmetic as
+// k_reduce + k_adam_step; `step` is the 1-based step index, tracked by the host.
+__global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__ slabA, uint32_t nbA, uint32_t P,
+                                                      const double *__restrict__ slabB, uint32_t nbB,
+                                                      float *__restrict__ vec, float *__restrict__ params,
+                                                      float *__restrict__ m, float *__restrict__ v,
+                                                      uint64_t *step_ptr, uint64_t step, double lr, double beta1,
+                                                      double beta2, double eps, double weight_decay, double inv_B,
+                                                      float *__restrict__ loss_out) {
+  __shared__ double part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t p = blockIdx.x * 64 + lane;
+  double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (p < P) {
+    uint32_t r = w;
+    for (; r + 7 * 16 < nbA; r += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabA[(size_t)(r + u * 16) * P + p];
+    }
+    for (; r < nbA; r += 16) a8[0] = a8[0] + slabA[(size_t)r * P + p];
+  } else if (p < P + 4) {
+    uint32_t r = w;
+    for (; r + 7 * 16 < nbB; r += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabB[(size_t)(r + u * 16) * 4 + (p - P)];
+    }
+    for (; r < nbB; r += 16) a8[0] = a8[0] + slabB[(size_t)r * 4 + (p - P)];
+  }
+  double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w != 0 || p >= P + 4) return;
+  double t = part[0][lane];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) t = t + part[k][lane];
+  const float gsum = (float)t;
+  vec[p] = gsum;
+  if (p == 0) *step_ptr = step;
+  if (p >= P) {
+    if (p == P && loss_out) *loss_out = (float)((double)gsum * inv_B);
+    return;
+  }
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float b1 = (float)beta1, b2 = (float)beta2;
+  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+  const float sqrt_bc2 = (float)sqrt(bc2);
+  const float neg_step_size = -(float)(lr / bc1);
+  const float epsf = (float)eps;
+  float g = gsum;
+  if (weight_decay != 0.0) g = g + (float)weight_decay * params[p];
+  const float mi = m[p] * b1 + omb1 * g;
+  const float vi = v[p] * b2 + omb2 * g * g;
+  m[p] = mi;
+  v[p] = vi;
+  const float denom = __fsqrt_rn(vi) / sqrt_bc2 + epsf;
+  params[p] = params[p] + (neg_step_size * mi) / denom;
+}
+
 // ---------------------------------------------------------------- launchers
 void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                         const int32_t *d_skip, float clip_lo, float clip_hi) {
@@ -649,7 +709,20 @@ void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept
                      (uint32_t)policy->P, max_kl, accept_violation, traj->trpo);
 }
 
+void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t rowsB, int loss_slot,
+                        uint64_t B_total) {
+  ProfScope ps(traj->eng, RL_K_REDUCE);
+  uint32_t P = (uint32_t)opt->mod->P;
+  opt->host_step += 1;
+  hipLaunchKernelGGL(k_reduce_adam, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
+                     traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
+                     opt->host_step, opt->cfg.learning_rate, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
+                     opt->cfg.weight_decay, 1.0 / (double)B_total,
+                     loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr);
+}
+
 void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_total) {
+  opt->host_step += 1;
   ProfScope ps(traj->eng, RL_K_SMALL);
   uint32_t P = (uint32_t)opt->mod->P;
   hipLaunchKernelGGL(k_adam_step, dim3(1), dim3(SB), 0, traj->eng->stream, opt->mod->d_params, traj->vec, opt->d_m,
@@ -659,6 +732,7 @@ void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_tot
 }
 
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
+  opt->host_step += 1;
   ProfScope ps(opt->mod->eng, RL_K_SMALL);
   uint32_t P = (uint32_t)opt->mod->P;
   hipLaunchKernelGGL(k_adam_step, dim3(1), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
