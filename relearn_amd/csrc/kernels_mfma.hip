@@ -512,6 +512,12 @@ __global__ void __launch_bounds__(128, 4)
 //   - the backward accumulates M_a[j][k] = sum_s [pre_sj > 0] dz_sa x~_sk for a = 0, 1 (12 values per hidden
 //     unit); at the end  dW1[j][k] = sum_a W2[a][j] M_a[j][k],  db1[j] = sum_a W2[a][j] M_a[j][5],
 //     dW2[a][j] = sum_k W~1[j][k] M_a[j][k]  (because h_sj = [pre_sj > 0] W~1[j].x~_s),  db2[a] = sum_s dz_sa.
+// Two-action softmax heads (every mode except PASS_DQN): the logit gradient of anything that depends on the logits
+// only through log-softmax is antisymmetric, dz_1 = -dz_0 (the rows of the softmax Jacobian sum to zero), so
+//   M_0 = -M_1 = M_d := sum_s [pre_sj > 0] g_s x~_sk  with  g_s = (dz_s0 - dz_s1) / 2,
+//   dW1[j][k] = (W2[0][j] - W2[1][j]) M_d[j][k],  dW2[0][j] = -dW2[1][j] = sum_k W~1[j][k] M_d[j][k].
+// One channel of 6 columns instead of two: the backward then runs as VALU FMAs with lane = hidden unit, exactly
+// like the critic's (k_critic_step_mfma), at half the work.  db2 keeps its two exact per-channel sums.
 // Reference semantics: Trpo::update closure + HessianVectorProduct (src/torch/agents/policies/trpo.rs:97-146,
 // src/torch/optimizers/conjugate_gradient.rs:262-339) and Categorical (src/torch/distributions/categorical.rs).
 // ================================================================================================
@@ -528,8 +534,9 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
                   float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
                   uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   constexpr int D = 5, H = 128, NT = V2_NT, A = 2;
+  constexpr bool ANTI = MODE != PASS_DQN;  // antisymmetric logit gradient: one backward channel on the VALU
   __shared__ float Ysh[V2_WAVES][32][33];
-  __shared__ float Ush[V2_WAVES][32][12];
+  __shared__ __attribute__((aligned(16))) float Ush[V2_WAVES][32][12];
   __shared__ double Acc[V2_WAVES][MODE == PASS_EVAL ? 4 : PIMG];
   if (skip != nullptr && *skip != 0) return;
 
@@ -574,16 +581,35 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   const float b2_0 = b2[0], b2_1 = b2[1];
   // backward accumulators on the matrix pipe (see k_critic_step_mfma): 12 columns = 3 feature groups of 4
   f32x4 dacc[NT][3];
+  float md[NT][6];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int fg = 0; fg < 3; ++fg) dacc[t][fg] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) md[t][k] = 0.0f;
+  }
+  if (ANTI)  // columns 6..11 of the U rows are never written in this mode; 6, 7 are read as float4 padding
+    for (int p = lane; p < 32 * 12; p += 64) (&Ush[wave][0][0])[p] = 0.0f;
   const float big = 0x1p126f;
   double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
   wave_lds_fence();
 
   auto flush = [&]() {
     if (MODE == PASS_EVAL) return;
+    if (ANTI) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int j = t * 32 + n;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float v = md[t][k] + __shfl_xor(md[t][k], 32, 64);
+          if (hf == 0) acc64[j * 12 + k] += (double)v;
+          md[t][k] = 0.0f;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -761,6 +787,33 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         db2_0 += (double)dz0;
         db2_1 += (double)dz1;
       }
+      if (ANTI) {
+        // one channel: u[sample][k] = g * x~_k with g = (dz_0 - dz_1) / 2, then lane = hidden unit FMAs
+        const float gd = 0.5f * (dz0 - dz1);
+        Ush[wave][n][hf] = gd * op.a0;
+        Ush[wave][n][2 + hf] = gd * op.a1;
+        Ush[wave][n][4 + hf] = gd * op.a2;
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
+          const float4 lo = src[0], hi = src[1];
+          const float u[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) md[t][k] = __builtin_fmaf(gsel, u[k], md[t][k]);
+          }
+        }
+        wave_lds_fence();
+        if (++since_flush == V2_FLUSH) {
+          since_flush = 0;
+          flush();
+        }
+        op = next;
+        continue;
+      }
       // publish u[sample][a*6 + k] = dz_a * x~_k
       Ush[wave][n][hf] = dz0 * op.a0;
       Ush[wave][n][2 + hf] = dz0 * op.a1;
@@ -824,7 +877,22 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   if (MODE != PASS_EVAL) {
     for (uint32_t p = threadIdx.x; p < P; p += V2_WAVES * 64) {
       double s = 0.0;
-      if (p < (uint32_t)(H * D)) {
+      if (ANTI && p < (uint32_t)(H * D + H + A * H)) {
+        // M_0 = M_d, M_1 = -M_d
+        if (p < (uint32_t)(H * D)) {
+          int j = p / D, k = p % D;
+          s = tot(j * 12 + k) * ((double)W2[j] - (double)W2[H + j]);
+        } else if (p < (uint32_t)(H * D + H)) {
+          int j = p - H * D;
+          s = tot(j * 12 + 5) * ((double)W2[j] - (double)W2[H + j]);
+        } else {
+          int q = p - H * D - H, a = q / H, j = q % H;
+          s = tot(j * 12 + 5) * (double)b1[j];
+#pragma unroll
+          for (int k = 0; k < D; ++k) s += tot(j * 12 + k) * (double)W1[j * D + k];
+          if (a == 1) s = -s;
+        }
+      } else if (p < (uint32_t)(H * D)) {
         int j = p / D, k = p % D;
         s = tot(j * 12 + k) * (double)W2[j] + tot(j * 12 + 6 + k) * (double)W2[H + j];
       } else if (p < (uint32_t)(H * D + H)) {
