@@ -578,6 +578,12 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     tb2[0] = vb2[0];
     tb2[1] = vb2[1];
   }
+  float w2d[NT], t2d[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    w2d[t] = w2v[t][0] - w2v[t][1];
+    t2d[t] = MODE == PASS_JVP ? t2v[t][0] - t2v[t][1] : 0.0f;
+  }
   const float b2_0 = b2[0], b2_1 = b2[1];
   // backward accumulators on the matrix pipe (see k_critic_step_mfma): 12 columns = 3 feature groups of 4
   f32x4 dacc[NT][3];
@@ -681,11 +687,11 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
           c[r] = h;
           const float gsel = __builtin_amdgcn_fmed3f(h * big, 0.0f, 1.0f);
           float dh = gsel * tc[r];
-          // d z_a = sum_j (W2[a][j] dh_j + V2[a][j] h_j)   (J v through the output layer)
-          y0[r] = __builtin_fmaf(dh, w2v[t][0], y0[r]);
-          y1[r] = __builtin_fmaf(dh, w2v[t][1], y1[r]);
-          y0[r] = __builtin_fmaf(h, t2v[t][0], y0[r]);
-          y1[r] = __builtin_fmaf(h, t2v[t][1], y1[r]);
+          // Only the DIFFERENCE of the two tangent logits enters the Fisher metric of a 2-way softmax:
+          // (diag(p) - p p^T) dz = p0 p1 (dz_0 - dz_1) (1, -1).  One chain with the differenced output weights:
+          // dz_0 - dz_1 = sum_j ((W2[0][j] - W2[1][j]) dh_j + (V2[0][j] - V2[1][j]) h_j) + (vb2_0 - vb2_1)
+          y0[r] = __builtin_fmaf(dh, w2d[t], y0[r]);
+          y0[r] = __builtin_fmaf(h, t2d[t], y0[r]);
         }
       } else {
 #pragma unroll
@@ -700,19 +706,18 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
       }
       acc[t] = c;
     }
-    const float s0 = lane_sum(y0), s1 = lane_sum(y1);
+    const float s0 = lane_sum(y0), s1 = MODE == PASS_JVP ? 0.0f : lane_sum(y1);
     // ---- per-sample math on the owner lanes (lane n and n+32 both hold sample n)
     float dz0 = 0.0f, dz1 = 0.0f;
     if (MODE == PASS_JVP) {
-      float dzt0 = s0 + tb2[0], dzt1 = s1 + tb2[1];
+      const float delta = s0 + (tb2[0] - tb2[1]);
       float p0 = 0.0f, p1 = 0.0f;
       if (op.valid) {
         p0 = rl_expf(lp0[sidx]);
         p1 = rl_expf(lp0[B + sidx]);
       }
-      float pdz = __builtin_fmaf(p1, dzt1, __builtin_fmaf(p0, dzt0, 0.0f));
-      dz0 = op.valid ? p0 * (dzt0 - pdz) * inv_B : 0.0f;
-      dz1 = op.valid ? p1 * (dzt1 - pdz) * inv_B : 0.0f;
+      dz0 = op.valid ? (p0 * p1) * delta * inv_B : 0.0f;
+      dz1 = -dz0;
     } else {
       float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
       const float adv = op.valid ? tr.adv[sidx] : 0.0f;
