@@ -373,6 +373,26 @@ int32_t rl_dqn_minibatch_gradient(rl_dqn *dqn, float *grad_out, float *loss_out)
 int32_t rl_dqn_agent_rng_pos(rl_dqn *dqn, uint64_t *pos_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Actor serialisation in the reference's on-disk format: the CBOR document that
+ * `serde_cbor::to_writer(file, &agent.actor(ActorMode::Evaluation))` writes (examples/cartpole-trpo.rs:71-76,
+ * examples/cartpole-dqn.rs) and `serde_cbor::from_reader` loads for evaluation (:82-93).
+ *   PolicyActor { observation_space, action_space, policy_module }      src/torch/agents/policies/actor.rs:10-14
+ *   DqnActor { observation_space, action_space, action_value_fn, exploration_rate }  src/torch/agents/dqn.rs:340-346
+ *   Mlp { layers: [Linear { kernel, bias }], activation, output_activation }         src/torch/modules/ff/mlp.rs:45-50
+ *   Chain { first: RnnBase { weights { flat_weights, has_biases }, hidden_size, dropout, type_ }, second: Mlp,
+ *           activation }                                  src/torch/modules/chain.rs:58-63, seq/rnn/mod.rs:90-99,186-191
+ *   TensorDef { kind, shape, requires_grad, byte_order, data }                       src/torch/serialize.rs:62-81
+ * observation / action spaces are those of the env the actor was trained on (NonEmptyFeatures<...>). */
+enum { RL_ACTOR_POLICY = 0, RL_ACTOR_DQN = 1 };
+/* Writes the document into `buf` (capacity `cap`) and its length into *len_out; with buf == NULL only the length is
+ * returned.  `exploration_rate` is used by RL_ACTOR_DQN only (evaluation actors carry 0.0, schedules.rs:38). */
+int32_t rl_actor_to_cbor(rl_env *env, rl_mlp *module, int32_t actor_kind, double exploration_rate, uint8_t *buf,
+                         uint64_t cap, uint64_t *len_out);
+/* Loads the module parameters of such a document (either actor kind) into `module`; the document's module must
+ * have the handle's structure and shapes (RL_ERR_INVALID_ARGUMENT otherwise). */
+int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len);
+
+/* ---------------------------------------------------------------------------------------------
  * CPU-only plumbing configuration (BASELINE.json configs[0]): examples/chain-tabular-q.rs — Chain
  * (src/envs/chain.rs:20-106) + epsilon-greedy tabular Q-learning (src/agents/tabular.rs:88-233) driven by
  * train_parallel (src/simulation/train.rs:68-186) with `n_threads` worker threads.  Runs on the host, like the

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient",
     "rl_ppo_config_default", "rl_ppo_update", "rl_reinforce_update", "rl_reward_to_go",
+    "rl_actor_to_cbor", "rl_module_from_cbor",
     "rl_dqn_config_default", "rl_dqn_create", "rl_dqn_destroy", "rl_dqn_exploration_rate",
     "rl_dqn_min_update_size", "rl_dqn_collect", "rl_dqn_update", "rl_dqn_replay_field_bytes", "rl_dqn_replay_read",
     "rl_dqn_minibatch_sample", "rl_dqn_minibatch_read", "rl_dqn_minibatch_gradient", "rl_dqn_agent_rng_pos",
@@ -675,6 +676,25 @@ def reinforce_update(policy, opt, traj):
 
 def reward_to_go(traj, gamma):
     _check(lib().rl_reward_to_go(traj.h, C.c_float(gamma)), traj.eng.h)
+
+
+ACTOR_POLICY, ACTOR_DQN = 0, 1
+
+
+def actor_to_cbor(env, module, actor_kind=ACTOR_POLICY, exploration_rate=0.0):
+    """the bytes `serde_cbor::to_writer(file, &agent.actor(ActorMode::Evaluation))` writes for this env / module"""
+    n = C.c_uint64()
+    _check(lib().rl_actor_to_cbor(env.h, module.h, C.c_int32(actor_kind), C.c_double(exploration_rate), None,
+                                  C.c_uint64(0), C.byref(n)), env.eng.h)
+    buf = (C.c_uint8 * n.value)()
+    _check(lib().rl_actor_to_cbor(env.h, module.h, C.c_int32(actor_kind), C.c_double(exploration_rate), buf,
+                                  C.c_uint64(n.value), C.byref(n)), env.eng.h)
+    return bytes(buf)
+
+
+def module_from_cbor(module, data):
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    _check(lib().rl_module_from_cbor(module.h, buf, C.c_uint64(len(data))), module.eng.h)
 
 
 def chain_tabular_q_train(seed=0, n_threads=4, n_periods=10, min_worker_steps=10000, exploration_rate=0.2):
