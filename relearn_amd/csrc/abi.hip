@@ -1,10 +1,14 @@
 // abi.hip — extern "C" entry points of include/relearn_hip.h (host side only; kernels live in kernels_*.hip).
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 
 #include "../../include/rl_chacha.h"
 #include "../../include/rl_detmath.h"
@@ -122,7 +126,63 @@ void rccl_check(int rc, const char *what) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------- in-process loopback collective
+// RELEARN_LOOPBACK_COMM=1: rl_comm_init joins the engines of ONE process that present the same unique id into a
+// group whose all-reduce is a kernel summing the ranks' buffers in rank order (all engines on the same GPU, each
+// driven by its own host thread).  It exists so that the multi-rank arithmetic — lane sharding by global lane id,
+// sample-weighted means over all ranks, identical redundant updates — can be exercised on a one-GPU box; the RCCL
+// call path itself is exercised with a one-rank communicator (RELEARN_FORCE_RCCL=1).
+__global__ void k_loopback_sum(float *const *bufs, int n_ranks, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = bufs[0][i];
+  for (int r = 1; r < n_ranks; ++r) s = s + bufs[r][i];
+  for (int r = 0; r < n_ranks; ++r) bufs[r][i] = s;
+}
+
+struct LoopbackGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n_ranks = 0, arrived = 0, joined = 0;
+  uint64_t generation = 0;
+  std::vector<float *> bufs;
+  float **d_bufs = nullptr;
+  void barrier(std::unique_lock<std::mutex> &lk) {
+    const uint64_t gen = generation;
+    if (++arrived == n_ranks) {
+      arrived = 0;
+      generation += 1;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+static std::mutex g_loopback_mu;
+static std::map<std::string, std::shared_ptr<LoopbackGroup>> g_loopback_groups;
+
+static void loopback_allreduce(rl_engine *e, float *d_buf, size_t count) {
+  LoopbackGroup *g = e->loopback;
+  RL_HIP_CHECK(hipStreamSynchronize(e->stream));  // this rank's contribution is complete
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->bufs[e->rank] = d_buf;
+  g->barrier(lk);
+  if (e->rank == 0) {
+    RL_HIP_CHECK(hipMemcpyAsync(g->d_bufs, g->bufs.data(), g->n_ranks * sizeof(float *), hipMemcpyHostToDevice,
+                                e->stream));
+    hipLaunchKernelGGL(k_loopback_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, g->d_bufs,
+                       g->n_ranks, count);
+    RL_HIP_CHECK(hipStreamSynchronize(e->stream));
+  }
+  g->barrier(lk);
+}
+
 void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
+  if (e->loopback) {
+    ProfScope ps(e, RL_K_ALLREDUCE);
+    loopback_allreduce(e, d_buf, count);
+    return;
+  }
   if (!e->comm) return;
   ProfScope ps(e, RL_K_ALLREDUCE);
   // ncclFloat32 = 7, ncclSum = 0
@@ -283,6 +343,13 @@ int32_t rl_profile_read(rl_engine *e, double *total_ms_out, uint64_t *launches_o
 int32_t rl_comm_unique_id(uint8_t id_out[128]) {
   return guarded(nullptr, [&] {
     RL_REQUIRE(id_out, "id_out is NULL");
+    if (std::getenv("RELEARN_LOOPBACK_COMM")) {
+      static std::atomic<uint64_t> counter{0};
+      std::memset(id_out, 0, 128);
+      uint64_t v = ++counter;
+      std::memcpy(id_out, &v, sizeof(v));
+      return;
+    }
     rccl_load();
     rccl_check(g_rccl.GetUniqueId(id_out), "ncclGetUniqueId");
   });
@@ -297,6 +364,23 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
     e->n_ranks = n_ranks;
     // a single rank needs no communicator; RELEARN_FORCE_RCCL=1 creates a 1-rank one anyway so that the whole
     // RCCL call path (dlopen, ncclCommInitRank, ncclAllReduce on the engine stream) can be exercised on one GPU
+    if (std::getenv("RELEARN_LOOPBACK_COMM")) {
+      RL_REQUIRE(!e->loopback, "communicator already initialised");
+      std::lock_guard<std::mutex> lk(g_loopback_mu);
+      std::string key((const char *)unique_id, 128);
+      auto &grp = g_loopback_groups[key];
+      if (!grp) {
+        grp = std::make_shared<LoopbackGroup>();
+        grp->n_ranks = n_ranks;
+        grp->bufs.assign(n_ranks, nullptr);
+        RL_HIP_CHECK(hipSetDevice(e->device));
+        grp->d_bufs = dalloc<float *>(n_ranks);
+      }
+      RL_REQUIRE(grp->n_ranks == n_ranks, "loopback group: inconsistent n_ranks");
+      grp->joined += 1;
+      e->loopback = grp.get();
+      return;
+    }
     if (n_ranks == 1 && !std::getenv("RELEARN_FORCE_RCCL")) return;
     rccl_load();
     RL_HIP_CHECK(hipSetDevice(e->device));
@@ -315,6 +399,7 @@ int32_t rl_comm_destroy(rl_engine *e) {
       rccl_check(g_rccl.CommDestroy(e->comm), "ncclCommDestroy");
       e->comm = nullptr;
     }
+    e->loopback = nullptr;  // groups live for the life of the process (test facility)
     e->rank = 0;
     e->n_ranks = 1;
   });
@@ -1305,7 +1390,7 @@ int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t o
     RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
     RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
     uint64_t Bt = b_total(traj);
-    const bool fused = critic->kind == RL_MODULE_MLP && traj->eng->comm == nullptr;
+    const bool fused = critic->kind == RL_MODULE_MLP && traj->eng->comm == nullptr && traj->eng->loopback == nullptr;
     for (uint64_t k = 0; k < opt_steps; ++k) {
       if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
         uint32_t rowsA, rowsB;

@@ -99,6 +99,7 @@ struct TrpoStateDev {
 
 // ---- host-side handle structs ----------------------------------------------------------------------
 struct RcclApi;  // dlopen'ed entry points (comm.cpp)
+struct LoopbackGroup;
 
 struct rl_engine {
   int device = -1;
@@ -114,6 +115,7 @@ struct rl_engine {
   std::vector<hipEvent_t> prof_event_pool;
   // comm
   void *comm = nullptr;  // ncclComm_t
+  struct LoopbackGroup *loopback = nullptr;  // in-process test collective (RELEARN_LOOPBACK_COMM=1)
   int rank = 0, n_ranks = 1;
   // host pinned scratch for small readbacks
   void *pinned = nullptr;

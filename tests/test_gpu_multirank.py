@@ -1,0 +1,115 @@
+"""Multi-rank arithmetic on ONE GPU: two engines in one process, each driven by its own host thread, joined by the
+library's in-process loopback collective (RELEARN_LOOPBACK_COMM=1, relearn_amd/csrc/abi.hip).  Everything except
+the RCCL call itself (exercised separately with a one-rank communicator) is the code the 2/4/8-GPU runs execute:
+lane sharding by global lane id, all-reduced gradients / Fisher-vector products / loss sums, sample-weighted means
+over all ranks, identical redundant updates on every rank.  The sharded result must equal the single-engine result
+up to the order of the f32 partial sums."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ra = pytest.importorskip("relearn_amd")
+
+H = 128
+
+
+def run_rank(rank, world, uid, n_total, T, out, barrier):
+    try:
+        eng = ra.Engine(0)
+        eng.profile_enable(True)
+        if world > 1:
+            eng.comm_init(rank, world, uid)
+        n = n_total // world
+        env = ra.CartPoleEnv(eng, n, max_steps=40, lane_offset=rank * n, seed_env=5, seed_actor=6)
+        pol, cri = ra.Mlp(eng, 5, H, 2), ra.Mlp(eng, 5, H, 1)
+        pol.init(2)
+        cri.init(3)
+        opt = ra.Adam(cri)
+        traj = ra.Trajectory(eng, n, T, 5)
+        res = {}
+        for period in range(2):
+            ra.rollout(env, pol, traj)
+            ra.gae(traj, cri, 0.99, 0.95)
+            st = ra.trpo_update(pol, traj)
+            cs, losses = ra.critic_update(cri, opt, traj, 10, want_losses=True)
+            res[period] = dict(action=traj.read(ra.TRAJ_ACTION), adv=traj.read(ra.TRAJ_ADVANTAGES),
+                               policy=pol.get_params(), critic=cri.get_params(), trpo=st.as_dict(), losses=losses)
+        # DQN on the same lanes: the minibatch size is summed over ranks, gradients all-reduced
+        q = ra.Mlp(eng, 5, H, 2)
+        q.init(7)
+        cfg = ra.dqn_config_default()
+        cfg.exploration_kind, cfg.exploration_start = ra.SCHEDULE_CONSTANT, 0.3
+        cfg.minibatch_steps, cfg.opt_steps_per_update, cfg.buffer_capacity = 2000 // world, 3, 128
+        for i in range(8):
+            cfg.agent_key[i] = 100 + i + rank  # every rank samples its own lanes with its own stream
+        dqn = ra.Dqn(env, q, ra.Adam(q), cfg)
+        dqn.collect(60)
+        dst, dl = dqn.update(want_losses=True)
+        res["dqn"] = dict(q=q.get_params(), losses=dl, global_steps=dst.global_steps)
+        res["allreduce_launches"] = eng.profile_read()["allreduce"][1]
+        out[rank] = res
+    except BaseException as exc:  # surface the failure in the main thread
+        out[rank] = exc
+        raise
+    finally:
+        try:
+            barrier.abort() if isinstance(out.get(rank), BaseException) else None
+        except Exception:
+            pass
+
+
+def launch(world, n_total, T):
+    os.environ["RELEARN_LOOPBACK_COMM"] = "1"
+    try:
+        uid = ra.comm_unique_id()
+        out = {}
+        barrier = threading.Barrier(world)
+        threads = [threading.Thread(target=run_rank, args=(r, world, uid, n_total, T, out, barrier)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        for r in range(world):
+            assert r in out and not isinstance(out[r], BaseException), out.get(r)
+        return out
+    finally:
+        os.environ.pop("RELEARN_LOOPBACK_COMM", None)
+
+
+def test_two_ranks_equal_one_rank():
+    n_total, T = 512, 48
+    single = launch(1, n_total, T)[0]
+    double = launch(2, n_total, T)
+    half = n_total // 2
+    # the collective really ran: gradient + Fisher-vector + line-search + critic + DQN vectors, on both ranks
+    assert single["allreduce_launches"] == 0
+    assert double[0]["allreduce_launches"] == double[1]["allreduce_launches"] > 2 * (1 + 11 + 1 + 10)
+    for period in range(2):
+        s = single[period]
+        # every rank holds identical replicas after every update
+        assert np.array_equal(double[0][period]["policy"], double[1][period]["policy"])
+        assert np.array_equal(double[0][period]["critic"], double[1][period]["critic"])
+        if period == 0:
+            # identical parameters -> the sharded rollout is the single rollout, lane for lane, bit for bit
+            act = np.concatenate([double[0][0]["action"], double[1][0]["action"]], axis=1)
+            assert np.array_equal(act, s["action"])
+            adv = np.concatenate([double[0][0]["adv"], double[1][0]["adv"]], axis=1)
+            assert np.array_equal(adv, s["adv"])
+            # same samples, different order of the f32 partial sums
+            assert abs(double[0][0]["trpo"]["loss_initial"] - s["trpo"]["loss_initial"]) < 1e-6
+            assert abs(double[0][0]["trpo"]["entropy"] - s["trpo"]["entropy"]) < 1e-6
+            assert double[0][0]["trpo"]["cg_iterations"] == s["trpo"]["cg_iterations"]
+            assert abs(double[0][0]["trpo"]["step_size"] - s["trpo"]["step_size"]) < 2e-2 * s["trpo"]["step_size"]
+            assert np.max(np.abs(double[0][0]["losses"] - s["losses"]) / s["losses"]) < 1e-5
+            assert np.mean(np.abs(double[0][0]["critic"] - s["critic"]) < 2e-5) > 0.97
+    assert half * 2 == n_total
+    # DQN: both ranks step in lockstep and end with identical networks; global_steps counts all ranks' lanes
+    assert np.array_equal(double[0]["dqn"]["q"], double[1]["dqn"]["q"])
+    assert double[0]["dqn"]["global_steps"] == single["dqn"]["global_steps"] == 60 * n_total
+    assert np.all(np.isfinite(double[0]["dqn"]["losses"]))
