@@ -169,6 +169,7 @@ def main():
     # One launch = forward + MSE loss + backward of the 5-128-1 critic over every sample of the rank.
     # Algorithmic flops per sample: 3 x critic forward = 3 x 2 x (5*128 + 128*1) = 4608.
     roofline = None
+    roofline_policy = None
     phases = None
     if prof is not None:
         flop_c = 3 * 2 * (5 * H + H * 1)
@@ -192,6 +193,16 @@ def main():
         tot = sum(v[0] for v in prof.values())
         phases = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
                       "share": (v[0] / tot if tot > 0 else 0.0)} for k, v in prof.items() if v[1]}
+        fv_ms, fv_n = prof.get("policy_fvp", (0.0, 0))
+        if fv_n:
+            # Fisher-vector product launch of the fused policy kernel: forward + tangent forward + 2x backward of
+            # the 5-128-2 MLP = 4 x 2 x (5*128 + 128*2) = 7168 algorithmic flop per sample
+            flop_p = 4 * 2 * (5 * H + H * 2)
+            ach = flop_p * B_local * fv_n / (fv_ms * 1e-3) / 1e12
+            roofline_policy = {"kernel": "k_policy_mfma<PASS_JVP>", "bound": "mfma", "achieved": ach,
+                               "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_PEAK_TFLOPS,
+                               "launches": int(fv_n), "avg_launch_us": 1e3 * fv_ms / fv_n,
+                               "algorithmic_flop_per_sample": flop_p, "samples_per_launch": B_local}
         pf_ms, pf_n = prof["policy_fused"]
         if pf_n:
             # gradient / Fisher-vector launches do forward + 2x backward (+ tangent forward), evaluations forward only
@@ -269,6 +280,7 @@ def main():
                 "critic_steps": args.critic_steps, "parallelism": "env-sharded x%d + RCCL all-reduce" % world,
             },
             "roofline": roofline,
+            "roofline_policy": roofline_policy,
             "roofline_env_step": env_step,
             "cpu_baseline": cpu,
             "phases": phases,

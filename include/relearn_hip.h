@@ -100,7 +100,8 @@ int32_t rl_timer_end(rl_engine *engine, float *elapsed_ms);
 typedef enum {
   RL_K_ENV_STEP = 0, RL_K_ROLLOUT = 1, RL_K_VALUES = 2, RL_K_GAE = 3, RL_K_POLICY_PASS = 4, RL_K_BACKWARD = 5,
   RL_K_REDUCE = 6, RL_K_SMALL = 7, RL_K_CRITIC_FWD = 8, RL_K_ALLREDUCE = 9, RL_K_CRITIC_FUSED = 10,
-  RL_K_POLICY_FUSED = 11, RL_K_CLASS_COUNT = 12
+  RL_K_POLICY_FUSED = 11, RL_K_POLICY_FVP = 12 /* Fisher-vector launches of the fused policy kernel */,
+  RL_K_CLASS_COUNT = 13
 } rl_kernel_class;
 int32_t rl_profile_enable(rl_engine *engine, int32_t on);
 int32_t rl_profile_read(rl_engine *engine, double *total_ms_out /*[RL_K_CLASS_COUNT]*/,

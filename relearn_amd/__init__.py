@@ -29,7 +29,7 @@ LIMIT_NONE, LIMIT_LATENT, LIMIT_VISIBLE = 0, 1, 2
 (TRAJ_OBS, TRAJ_ACTION, TRAJ_REWARD, TRAJ_FLAG, TRAJ_TERM_OBS, TRAJ_VALUES, TRAJ_ADVANTAGES,
  TRAJ_RETURNS) = range(8)
 KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backward", "reduce", "small",
-                  "critic_fwd", "allreduce", "critic_fused", "policy_fused"]
+                  "critic_fwd", "allreduce", "critic_fused", "policy_fused", "policy_fvp"]
 
 # every symbol include/relearn_hip.h declares (checked by tests/test_abi_symbols.py against the header)
 ABI_SYMBOLS = [

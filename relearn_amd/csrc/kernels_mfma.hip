@@ -942,7 +942,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
-  ProfScope ps(traj->eng, RL_K_POLICY_FUSED);
+  ProfScope ps(traj->eng, mode == PASS_JVP ? RL_K_POLICY_FVP : RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
   hipStream_t s = traj->eng->stream;
