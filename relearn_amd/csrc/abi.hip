@@ -871,6 +871,10 @@ static void traj_plan(rl_traj *t, uint64_t B) {
   uint64_t n_tiles = (B + 31) / 32;
   uint64_t nbV2 = (n_tiles + 3) / 4;
   uint64_t max_v2 = 2ull * (uint64_t)e->prop.multiProcessorCount;
+  // the critic step fits three workgroups per CU (168 VGPRs, 50 KB LDS each)
+  uint64_t nbC = nbV2, max_c = 3ull * (uint64_t)e->prop.multiProcessorCount;
+  if (nbC > max_c) nbC = max_c;
+  t->nbC = (uint32_t)nbC;
   if (nbV2 > max_v2) nbV2 = max_v2;
   t->nbV2 = (uint32_t)nbV2;
   // pair kernels: 2-wave workgroups, 8 per CU (4 waves per SIMD), a contiguous run of tiles per workgroup
@@ -909,6 +913,7 @@ static rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uin
   traj_plan(t.get(), n * T);
   uint32_t rows = t->nbA;
   if (t->nbV2 > rows) rows = t->nbV2;
+  if (t->nbC > rows) rows = t->nbC;
   if (t->nbPair > rows) rows = t->nbPair;
   uint32_t rowsB = t->nbB > rows ? t->nbB : rows;
   if (resizable) {
@@ -1366,7 +1371,7 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
 // per-workgroup partial sums of the critic's MSE gradient and loss -> slabA / slabB (feed-forward modules)
 static void critic_slabs(rl_mlp *critic, rl_traj *traj, uint32_t *rowsA, uint32_t *rowsB) {
   if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
-    *rowsA = *rowsB = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbV2;
+    *rowsA = *rowsB = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbC;
   } else {
     launch_critic_fwd(traj, critic, b_total(traj));
     launch_mlp_backward(traj, critic, nullptr);

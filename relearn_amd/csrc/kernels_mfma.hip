@@ -40,14 +40,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 constexpr int V2_WAVES = 4;        // waves per workgroup
 constexpr int V2_NT = 4;           // 32-unit hidden tiles (H = 128)
-constexpr int V2_NV = 4;           // hidden tiles whose backward runs on the VALU (the rest: 4x4x1 MFMA)
 constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 samples per accumulator)
 
 // ---------------------------------------------------------------- critic: forward + loss + backward fused
+// 168 VGPRs: three workgroups (12 waves) per CU, three waves per SIMD — the kernel is VALU-issue bound and a third
+// wave per SIMD raises the VALU utilisation (measured 0.378 -> 0.355 ms per launch at 8.4 M samples).
 // per 32-sample tile and wave:  MFMA 12 issues (768 cycles on the matrix pipe)
 //                               VALU ~128 (relu, y partials) + ~50 (owner math) + 576 (backward) instructions
 // Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2x backward of the 5-128-1 MLP).
-__global__ void __launch_bounds__(V2_WAVES * 64, 2)
+__global__ void __launch_bounds__(V2_WAVES * 64, 3)
     k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
                        double *__restrict__ slabB, float two_over_B, uint32_t P) {
   constexpr int D = 5, H = 128, NT = V2_NT;
@@ -76,22 +77,14 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
     w2v[t] = W2[j];
   }
-  // Backward accumulators: the gradient GEMM  M[j][k] += [pre_sj > 0] * u_sk  is issued as 16-block 4x4x1 f32
-  // MFMAs (one sample per issue, A = mask of 64 lane-resident hidden units, B = 4 features of u): lane l,
-  // register i of dacc[t][fg] holds M[t*32 + 4*((l&31)>>2) + i][4*fg + (l&3)] for the samples of its lane half.
-  // The VALU is this kernel's busiest pipe (relu, layer 2, masks), the matrix pipe idles 3/4 of the time after
-  // layer 1; so the backward is SPLIT: hidden tiles [0, NV) accumulate with VALU FMAs (lane = hidden unit),
-  // tiles [NV, NT) with the 4x4x1 MFMAs.
-  constexpr int NV = V2_NV;
-  f32x4 dacc[NT][2];
+  // Backward accumulators: M[j][k] += [pre_sj > 0] * u_sk with lane = hidden unit j (six f32 registers per hidden
+  // tile), VALU FMAs.  (Measured alternatives — the same GEMM as 4x4x1 MFMAs, a VALU/MFMA split — are slower on
+  // this part)
   float m[NT][6];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    dacc[t][0] = (f32x4){0, 0, 0, 0};
-    dacc[t][1] = (f32x4){0, 0, 0, 0};
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int k = 0; k < 6; ++k) m[t][k] = 0.0f;
-  }
   const float big = 0x1p126f;
   double loss64 = 0.0, db2_64 = 0.0;
   wave_lds_fence();
@@ -99,7 +92,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   // f32 -> f64 flush: add the two lane halves (same hidden unit, different samples), then accumulate in LDS
   auto flush = [&]() {
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int j = t * 32 + n;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -108,17 +101,6 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         m[t][k] = 0.0f;
       }
     }
-#pragma unroll
-    for (int t = NV; t < NT; ++t)
-#pragma unroll
-      for (int fg = 0; fg < 2; ++fg)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = dacc[t][fg][i] + __shfl_xor(dacc[t][fg][i], 32, 64);
-          const int j = t * 32 + 4 * (n >> 2) + i, k = 4 * fg + (n & 3);
-          if (hf == 0 && k < 6) acc64[j * 7 + k] += (double)v;
-          dacc[t][fg][i] = 0.0f;
-        }
   };
 
   const size_t n_tiles = (B + 31) / 32;
@@ -199,41 +181,22 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     Ush[wave][n][2 + hf] = dy * o.a1;
     Ush[wave][n][4 + hf] = dy * o.a2;
     wave_lds_fence();
-    // backward on the matrix pipe: per sample row r two 4x4x1 issues per hidden tile (features 0-3, 4-7)
+    // backward: lane = hidden unit, one sample row at a time
 #pragma unroll
-    for (int rc = 0; rc < 8; ++rc) {
-      float ub[2][2], u[2][8];
+    for (int r = 0; r < 16; ++r) {
+      const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
+      const float4 lo = src[0], hi = src[1];
+      const float u[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int r = rc * 2 + q;
-        const float *urow = &Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0];
-        ub[q][0] = urow[lane & 3];
-        ub[q][1] = urow[4 + (lane & 3)];
-        const float4 *src = reinterpret_cast<const float4 *>(urow);
-        float4 lo = src[0], hi = src[1];
-        u[q][0] = lo.x; u[q][1] = lo.y; u[q][2] = lo.z; u[q][3] = lo.w;
-        u[q][4] = hi.x; u[q][5] = hi.y; u[q][6] = hi.z; u[q][7] = hi.w;
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int r = rc * 2 + q;
+      for (int t = 0; t < NT; ++t) {
         // relu'(pre) as one VALU op: clamp(h * 2^126) is 1 for every normal h > 0 and 0 for h == 0
-#pragma unroll
-        for (int t = NV; t < NT; ++t) {
-          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
-          dacc[t][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub[q][0], dacc[t][0], 0, 0, 0);
-          dacc[t][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub[q][1], dacc[t][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < NV; ++t) {
-          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
+        const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
 #if !(RL_ABLATE & 1)
 #pragma unroll
-          for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[q][k], m[t][k]);
+        for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[k], m[t][k]);
 #else
-          m[t][0] = m[t][0] + gsel * u[q][0];
+        m[t][0] = m[t][0] + gsel * u[0];
 #endif
-        }
       }
     }
     wave_lds_fence();  // Ysh / Ush are rewritten by the next tile
@@ -928,7 +891,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
   if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile
-    hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbV2), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
+    hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
                        critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
   } else {  // variant 2: two waves per tile (A/B measurements)
     hipLaunchKernelGGL(k_critic_step_pair, dim3(traj->nbPair), dim3(128), 0, traj->eng->stream, traj->d,
