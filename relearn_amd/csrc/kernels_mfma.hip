@@ -492,15 +492,17 @@ struct PolicyTile {
 };
 
 template <int MODE>  // PASS_INIT (gradient), PASS_JVP (Fisher-vector product), PASS_EVAL (loss / KL only)
-__global__ void __launch_bounds__(V2_WAVES * 64, 2)
+__global__ void __launch_bounds__(V2_WAVES * 64, 2)  // (three waves per SIMD: 30 spills and 10 % slower, measured)
     k_policy_mfma(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
                   float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
                   uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   constexpr int D = 5, H = 128, NT = V2_NT, A = 2;
   constexpr bool ANTI = MODE != PASS_DQN;  // antisymmetric logit gradient: one backward channel on the VALU
+  constexpr int IW = ANTI ? 7 : 12;        // f64 image slots per hidden unit (one or two channels of six columns)
+  constexpr int PIMG_M = H * IW + 5;       // then db2[0], db2[1], sum0, sum1, sum2
   __shared__ float Ysh[V2_WAVES][32][33];
-  __shared__ __attribute__((aligned(16))) float Ush[V2_WAVES][32][12];
-  __shared__ double Acc[V2_WAVES][MODE == PASS_EVAL ? 4 : PIMG];
+  __shared__ __attribute__((aligned(16))) float Ush[V2_WAVES][32][ANTI ? 8 : 12];
+  __shared__ double Acc[V2_WAVES][MODE == PASS_EVAL ? 4 : PIMG_M];
   if (skip != nullptr && *skip != 0) return;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   double *acc64 = Acc[wave];
   if (MODE != PASS_EVAL)
-    for (int p = lane; p < PIMG; p += 64) acc64[p] = 0.0;
+    for (int p = lane; p < PIMG_M; p += 64) acc64[p] = 0.0;
 
   float wb[NT][3], w2v[NT][A];
 #pragma unroll
@@ -558,8 +560,8 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
 #pragma unroll
     for (int k = 0; k < 6; ++k) md[t][k] = 0.0f;
   }
-  if (ANTI)  // columns 6..11 of the U rows are never written in this mode; 6, 7 are read as float4 padding
-    for (int p = lane; p < 32 * 12; p += 64) (&Ush[wave][0][0])[p] = 0.0f;
+  if (ANTI)  // columns 6, 7 of the U rows are read as float4 padding and never written
+    for (int p = lane; p < 32 * 8; p += 64) (&Ush[wave][0][0])[p] = 0.0f;
   const float big = 0x1p126f;
   double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
   wave_lds_fence();
@@ -573,7 +575,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           float v = md[t][k] + __shfl_xor(md[t][k], 32, 64);
-          if (hf == 0) acc64[j * 12 + k] += (double)v;
+          if (hf == 0) acc64[j * IW + k] += (double)v;
           md[t][k] = 0.0f;
         }
       }
@@ -782,6 +784,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         op = next;
         continue;
       }
+      if constexpr (!ANTI) {
       // publish u[sample][a*6 + k] = dz_a * x~_k
       Ush[wave][n][hf] = dz0 * op.a0;
       Ush[wave][n][2 + hf] = dz0 * op.a1;
@@ -807,6 +810,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         since_flush = 0;
         flush();
       }
+      }
     }
     op = next;
   }
@@ -827,7 +831,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     r3 = r3 + xlane(r3, s);
     if (MODE == PASS_INIT) r4 = r4 + xlane(r4, s);
   }
-  constexpr int TAIL = MODE == PASS_EVAL ? 0 : H * 12;
+  constexpr int TAIL = MODE == PASS_EVAL ? 0 : H * IW;
   if (lane == 0) {
     acc64[TAIL + 0] = r2;
     acc64[TAIL + 1] = r3;
@@ -849,15 +853,15 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
         // M_0 = M_d, M_1 = -M_d
         if (p < (uint32_t)(H * D)) {
           int j = p / D, k = p % D;
-          s = tot(j * 12 + k) * ((double)W2[j] - (double)W2[H + j]);
+          s = tot(j * IW + k) * ((double)W2[j] - (double)W2[H + j]);
         } else if (p < (uint32_t)(H * D + H)) {
           int j = p - H * D;
-          s = tot(j * 12 + 5) * ((double)W2[j] - (double)W2[H + j]);
+          s = tot(j * IW + 5) * ((double)W2[j] - (double)W2[H + j]);
         } else {
           int q = p - H * D - H, a = q / H, j = q % H;
-          s = tot(j * 12 + 5) * (double)b1[j];
+          s = tot(j * IW + 5) * (double)b1[j];
 #pragma unroll
-          for (int k = 0; k < D; ++k) s += tot(j * 12 + k) * (double)W1[j * D + k];
+          for (int k = 0; k < D; ++k) s += tot(j * IW + k) * (double)W1[j * D + k];
           if (a == 1) s = -s;
         }
       } else if (p < (uint32_t)(H * D)) {
