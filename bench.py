@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="do not wrap launches in HIP events inside the timed region")
+    ap.add_argument("--profile-steps", type=int, default=1,
+                    help="number of timed periods (the last ones) whose launches are wrapped in HIP events")
     ap.add_argument("--cpu-sample-steps", type=int, default=262144,
                     help="total env-steps of the bounded CPU-baseline sample (split over the host cores)")
     return ap.parse_args()
@@ -144,12 +146,16 @@ def main():
     for _ in range(args.warmup):
         period()
     barrier()
-    if not args.no_kernel_profile:
-        eng.profile_enable(True)
-        eng.profile_read(reset=True)
+    # Per-kernel HIP events (two per launch) cost ~2 ms of host time per period when they wrap all ~220 launches, so
+    # they are switched on for the LAST `--profile-steps` periods of the timed region only; `roofline` / `phases`
+    # are averages over those periods' launches.
+    prof_steps = 0 if args.no_kernel_profile else max(1, min(args.profile_steps, args.steps))
+    eng.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if prof_steps and k == args.steps - prof_steps:
+            eng.profile_enable(True)
         period()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -191,7 +197,7 @@ def main():
                     "traffic (bytes/launch) from rocprofv3 PMC passes, see profiles/README.md",
         }
         tot = sum(v[0] for v in prof.values())
-        phases = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps,
+        phases = {k: {"ms_per_step": v[0] / prof_steps, "launches_per_step": v[1] / prof_steps,
                       "share": (v[0] / tot if tot > 0 else 0.0)} for k, v in prof.items() if v[1]}
         fv_ms, fv_n = prof.get("policy_fvp", (0.0, 0))
         if fv_n:
