@@ -484,7 +484,6 @@ __global__ void __launch_bounds__(128, 4)
 // Reference semantics: Trpo::update closure + HessianVectorProduct (src/torch/agents/policies/trpo.rs:97-146,
 // src/torch/optimizers/conjugate_gradient.rs:262-339) and Categorical (src/torch/distributions/categorical.rs).
 // ================================================================================================
-constexpr int PIMG = 128 * 12 + 5;  // per-wave f64 image: M_a[j][k] (a*6+k), then db2[0], db2[1], sum0, sum1, sum2
 
 struct PolicyTile {
   float a0, a1, a2;
