@@ -1,0 +1,577 @@
+// agents.hpp — C++ host side above the C ABI: the reference's trait surface for the accelerated path, same names,
+// argument meaning and error behaviour (the reference is Rust; this image has no Rust toolchain, INTEGRATION.md shows
+// the equivalent `extern "C"` binding a relearn maintainer adds).  Header-only; link against librelearn_hip.so.
+//
+//   EnvStructure / Environment     src/envs/mod.rs:76-127,165-193     -> CartPoleLanes, ChainLanes (vectorised)
+//   BuildModule, MlpConfig, GruMlpConfig   src/torch/modules/mod.rs:14, ff/mlp.rs:13-34   -> MlpConfig, GruMlpConfig
+//   BuildAgent / Agent / Actor / BatchUpdate / ActorMode   src/agents/mod.rs:48-59,101-114,144,167-215
+//   ActorCriticConfig / ActorCriticAgent   src/torch/agents/actor_critic.rs:20-136,176-211
+//   TrpoConfig / PpoConfig / ReinforceConfig   src/torch/agents/policies/{trpo,ppo,reinforce}.rs
+//   ValuesOptConfig / RewardToGoConfig       src/torch/agents/critics/{opt,rtg}.rs
+//   DqnConfig / DqnAgent                      src/torch/agents/dqn.rs:26-140,263-337
+//   StatsLogger (log_scalar / log_counter_increment / log_duration / with_scope)   src/logging/mod.rs:25-140
+//   train_parallel's period loop and its metric names   src/simulation/train.rs:68-186
+#pragma once
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../../include/relearn_hip.h"
+
+namespace relearn {
+
+// ---------------------------------------------------------------- errors (the reference's error enums)
+struct Error : std::runtime_error {
+  int32_t code;
+  Error(int32_t c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+struct BuildAgentError : Error { using Error::Error; };        // src/agents/mod.rs:219-226
+struct BuildEnvError : Error { using Error::Error; };          // src/envs/builders.rs:62-66
+struct WriteExperienceFull : Error { using Error::Error; };    // WriteExperienceError::Full, buffers/mod.rs:225-228
+struct OptimizerNanError : Error { using Error::Error; };      // panic in Trpo::update, policies/trpo.rs:154-162
+struct NoDeviceError : Error { using Error::Error; };
+
+inline void check(int32_t rc, const rl_engine *eng = nullptr) {
+  if (rc == RL_OK) return;
+  const char *m = rl_last_error(eng);
+  std::string msg = m ? m : "";
+  switch (rc) {
+    case RL_ERR_BUILD_AGENT: throw BuildAgentError(rc, msg);
+    case RL_ERR_BUILD_ENV: throw BuildEnvError(rc, msg);
+    case RL_ERR_BUFFER_FULL: throw WriteExperienceFull(rc, msg);
+    case RL_ERR_OPT_NAN: throw OptimizerNanError(rc, msg);
+    case RL_ERR_NO_DEVICE: throw NoDeviceError(rc, msg);
+    default: throw Error(rc, msg);
+  }
+}
+
+// ---------------------------------------------------------------- logging (src/logging/mod.rs)
+class StatsLogger {
+ public:
+  virtual ~StatsLogger() = default;
+  virtual void log_scalar(const std::string &id, double value) = 0;
+  virtual void log_counter_increment(const std::string &id, uint64_t increment) = 0;
+  virtual void log_duration(const std::string &id, double seconds) = 0;
+};
+
+// `logger.with_scope("policy")`: prepends "policy/" to every id
+class ScopedLogger : public StatsLogger {
+ public:
+  ScopedLogger(StatsLogger &inner, std::string scope) : inner_(inner), prefix_(std::move(scope) + "/") {}
+  void log_scalar(const std::string &id, double v) override { inner_.log_scalar(prefix_ + id, v); }
+  void log_counter_increment(const std::string &id, uint64_t n) override { inner_.log_counter_increment(prefix_ + id, n); }
+  void log_duration(const std::string &id, double s) override { inner_.log_duration(prefix_ + id, s); }
+
+ private:
+  StatsLogger &inner_;
+  std::string prefix_;
+};
+
+// keeps the last value of every scalar / duration and the running counters (tests, simple front ends)
+class RecordingLogger : public StatsLogger {
+ public:
+  std::map<std::string, double> scalars, durations;
+  std::map<std::string, uint64_t> counters;
+  void log_scalar(const std::string &id, double v) override { scalars[id] = v; }
+  void log_counter_increment(const std::string &id, uint64_t n) override { counters[id] += n; }
+  void log_duration(const std::string &id, double s) override { durations[id] = s; }
+};
+
+template <typename F>
+auto log_elapsed(StatsLogger &logger, const std::string &id, F &&f) {  // StatsLogger::log_elapsed
+  const auto t0 = std::chrono::steady_clock::now();
+  f();
+  logger.log_duration(id, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+}
+
+// ---------------------------------------------------------------- engine + handles
+class Engine {
+ public:
+  explicit Engine(int device = 0) { check(rl_engine_create(device, &h_)); }
+  ~Engine() { rl_engine_destroy(h_); }
+  Engine(const Engine &) = delete;
+  Engine &operator=(const Engine &) = delete;
+  rl_engine *handle() const { return h_; }
+  void sync() { check(rl_engine_sync(h_), h_); }
+
+ private:
+  rl_engine *h_ = nullptr;
+};
+
+enum class ActorMode { Training, Evaluation };  // src/agents/mod.rs:144
+enum class StepLimit { None = RL_LIMIT_NONE, Latent = RL_LIMIT_LATENT, Visible = RL_LIMIT_VISIBLE };
+
+// EnvStructure of N vectorised lanes (the spaces are those of the wrapped reference env)
+class EnvLanes {
+ public:
+  ~EnvLanes() { rl_env_destroy(h_); }
+  EnvLanes(const EnvLanes &) = delete;
+  EnvLanes &operator=(const EnvLanes &) = delete;
+  rl_env *handle() const { return h_; }
+  Engine &engine() const { return eng_; }
+  uint64_t num_lanes() const { return cfg_.n_lanes; }
+  uint32_t num_observation_features() const { return obs_dim_; }
+  uint32_t num_actions() const { return n_actions_; }
+  double discount_factor() const { return discount_; }
+  // Environment::{initial_state, observe, step} for every lane (src/envs/mod.rs:76-127)
+  void initial_state() { check(rl_env_reset(h_), eng_.handle()); }
+  std::vector<float> observe() {
+    std::vector<float> obs((size_t)obs_dim_ * cfg_.n_lanes);
+    check(rl_env_observe(h_, obs.data()), eng_.handle());
+    return obs;
+  }
+  struct StepResult {
+    std::vector<float> reward, next_obs, interrupt_obs;
+    std::vector<uint8_t> successor;  // RL_SUCC_CONTINUE / TERMINATE / INTERRUPT
+  };
+  StepResult step(const std::vector<uint8_t> &actions) {
+    if (actions.size() != cfg_.n_lanes) throw Error(RL_ERR_INVALID_ARGUMENT, "one action per lane");
+    StepResult r;
+    r.reward.resize(cfg_.n_lanes);
+    r.successor.resize(cfg_.n_lanes);
+    r.next_obs.resize((size_t)obs_dim_ * cfg_.n_lanes);
+    r.interrupt_obs.resize((size_t)obs_dim_ * cfg_.n_lanes);
+    check(rl_env_step(h_, actions.data(), r.reward.data(), r.successor.data(), r.next_obs.data(),
+                      r.interrupt_obs.data()), eng_.handle());
+    return r;
+  }
+
+ protected:
+  EnvLanes(Engine &eng, const rl_env_config &cfg, double discount) : eng_(eng), cfg_(cfg), discount_(discount) {
+    check(rl_env_create(eng.handle(), &cfg_, &h_), eng.handle());
+    check(rl_env_dims(h_, &obs_dim_, &n_actions_), eng.handle());
+  }
+  Engine &eng_;
+  rl_env_config cfg_;
+  rl_env *h_ = nullptr;
+  uint32_t obs_dim_ = 0, n_actions_ = 0;
+  double discount_;
+};
+
+// `CartPole::default().wrap(VisibleStepLimit::new(max_steps))` x n_lanes (src/envs/cartpole.rs, wrappers/step_limit.rs)
+class CartPoleLanes : public EnvLanes {
+ public:
+  CartPoleLanes(Engine &eng, uint64_t n_lanes, uint64_t max_steps = 500, StepLimit limit = StepLimit::Visible,
+                uint64_t seed_env = 0, uint64_t seed_actor = 1, uint64_t lane_offset = 0)
+      : EnvLanes(eng, config(n_lanes, max_steps, limit, seed_env, seed_actor, lane_offset), 0.99) {}
+
+ private:
+  static rl_env_config config(uint64_t n, uint64_t max_steps, StepLimit limit, uint64_t se, uint64_t sa, uint64_t off) {
+    rl_env_config c{};
+    c.kind = RL_ENV_CARTPOLE;
+    c.limit_kind = (int32_t)limit;
+    c.max_steps = max_steps;
+    c.n_lanes = n;
+    c.lane_offset = off;
+    c.seed_env = se;
+    c.seed_actor = sa;
+    check(rl_cartpole_params_default(&c.cartpole));
+    return c;
+  }
+};
+
+// `Chain::default().wrap(LatentStepLimit::new(max_steps))` x n_lanes (src/envs/chain.rs)
+class ChainLanes : public EnvLanes {
+ public:
+  ChainLanes(Engine &eng, uint64_t n_lanes, uint64_t max_steps = 100, StepLimit limit = StepLimit::Latent,
+             uint64_t seed_env = 0, uint64_t seed_actor = 1, uint64_t lane_offset = 0)
+      : EnvLanes(eng, config(n_lanes, max_steps, limit, seed_env, seed_actor, lane_offset), 0.95) {}
+
+ private:
+  static rl_env_config config(uint64_t n, uint64_t max_steps, StepLimit limit, uint64_t se, uint64_t sa, uint64_t off) {
+    rl_env_config c{};
+    c.kind = RL_ENV_CHAIN;
+    c.limit_kind = (int32_t)limit;
+    c.max_steps = max_steps;
+    c.n_lanes = n;
+    c.lane_offset = off;
+    c.seed_env = se;
+    c.seed_actor = sa;
+    check(rl_cartpole_params_default(&c.cartpole));
+    c.chain_size = 5;
+    return c;
+  }
+};
+
+// ---------------------------------------------------------------- modules (BuildModule)
+class Module {
+ public:
+  ~Module() { rl_mlp_destroy(h_); }
+  Module(const Module &) = delete;
+  Module &operator=(const Module &) = delete;
+  rl_mlp *handle() const { return h_; }
+  uint64_t num_parameters() const { return n_; }
+  std::vector<float> parameters() const {  // trainable_variables() flattened, reference order
+    std::vector<float> p(n_);
+    check(rl_params_get(h_, p.data(), n_), eng_.handle());
+    return p;
+  }
+  void set_parameters(const std::vector<float> &p) { check(rl_params_set(h_, p.data(), p.size()), eng_.handle()); }
+
+ protected:
+  Module(Engine &eng, rl_mlp *h) : eng_(eng), h_(h) { check(rl_mlp_num_params(h_, &n_), eng.handle()); }
+  friend struct MlpConfig;
+  friend struct GruMlpConfig;
+  Engine &eng_;
+  rl_mlp *h_;
+  uint64_t n_ = 0;
+};
+
+struct MlpConfig {  // MlpConfig::default: hidden_sizes [128], Relu (ff/mlp.rs:25-34)
+  uint32_t hidden_size = 128;
+  std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
+    rl_mlp *h = nullptr;
+    check(rl_mlp_create(eng.handle(), in_dim, hidden_size, out_dim, &h), eng.handle());
+    std::unique_ptr<Module> m(new Module(eng, h));
+    check(rl_mlp_init(h, seed), eng.handle());
+    return m;
+  }
+};
+
+struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mod.rs:14, chain.rs:19-32)
+  uint32_t hidden_dim = 128;
+  MlpConfig second_config;
+  std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
+    rl_mlp *h = nullptr;
+    check(rl_gru_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.hidden_size, out_dim, &h), eng.handle());
+    std::unique_ptr<Module> m(new Module(eng, h));
+    check(rl_mlp_init(h, seed), eng.handle());
+    return m;
+  }
+};
+
+struct AdamConfig {  // optimizers/coptimizer.rs:136-156
+  double learning_rate = 1e-3, beta1 = 0.9, beta2 = 0.999, weight_decay = 0.0;
+  rl_adam *build_optimizer(Module &m, Engine &eng) const {
+    rl_adam_config c;
+    check(rl_adam_config_default(&c));
+    c.learning_rate = learning_rate;
+    c.beta1 = beta1;
+    c.beta2 = beta2;
+    c.weight_decay = weight_decay;
+    rl_adam *o = nullptr;
+    check(rl_adam_create(m.handle(), &c, &o), eng.handle());
+    return o;
+  }
+};
+
+// ---------------------------------------------------------------- device-resident history (VecBuffer's stand-in)
+class DeviceHistory {
+ public:
+  DeviceHistory(Engine &eng, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim) : n_(n_lanes), T_(horizon) {
+    check(rl_traj_create(eng.handle(), n_lanes, horizon, obs_dim, &h_), eng.handle());
+  }
+  ~DeviceHistory() { rl_traj_destroy(h_); }
+  DeviceHistory(const DeviceHistory &) = delete;
+  DeviceHistory &operator=(const DeviceHistory &) = delete;
+  rl_traj *handle() const { return h_; }
+  uint64_t num_steps() const { return n_ * T_; }
+  uint64_t num_lanes() const { return n_; }
+  uint64_t horizon() const { return T_; }
+  std::vector<uint8_t> successors() const {
+    std::vector<uint8_t> f(n_ * T_);
+    check(rl_traj_read(h_, RL_TRAJ_FLAG, f.data(), f.size()));
+    return f;
+  }
+
+ private:
+  rl_traj *h_ = nullptr;
+  uint64_t n_, T_;
+};
+
+// ---------------------------------------------------------------- policies and critics
+struct ConjugateGradientOptimizerConfig {  // conjugate_gradient.rs:41-65
+  uint64_t iterations = 10, max_backtracks = 15;
+  double backtrack_ratio = 0.8, hpv_reg_coeff = 1e-5;
+  bool accept_violation = false;
+};
+template <typename MB = MlpConfig>
+struct TrpoConfig {  // policies/trpo.rs:18-41
+  MB policy_fn_config;
+  ConjugateGradientOptimizerConfig optimizer_config;
+  double max_policy_step_kl = 0.01;
+};
+template <typename MB = MlpConfig>
+struct PpoConfig {  // policies/ppo.rs:13-41
+  MB policy_fn_config;
+  AdamConfig optimizer_config;
+  uint64_t opt_steps_per_update = 10;
+  double clip_distance = 0.2;
+};
+template <typename MB = MlpConfig>
+struct ReinforceConfig {  // policies/reinforce.rs
+  MB policy_fn_config;
+  AdamConfig optimizer_config;
+};
+template <typename MB = MlpConfig>
+struct ValuesOptConfig {  // critics/opt.rs:13-37
+  MB state_value_fn_config;
+  AdamConfig optimizer_config;
+  double gae_lambda = 0.95;          // AdvantageFn::Gae { lambda }
+  uint64_t opt_steps_per_update = 80;
+  double max_discount_factor = 0.99;
+};
+struct RewardToGoConfig {};  // critics/rtg.rs
+
+enum class PolicyKind { Trpo, Ppo, Reinforce };
+template <typename P, typename C>
+struct ActorCriticConfig;
+
+// ActorCriticAgent (actor_critic.rs:72-136) over device modules; `batch_update` follows batch_update_slice
+// (actor_critic.rs:176-211): advantages, policy update, critic update, with the reference's metric names.
+class ActorCriticAgent {
+ public:
+  ~ActorCriticAgent() {
+    rl_adam_destroy(policy_opt_);
+    rl_adam_destroy(critic_opt_);
+  }
+  Module &policy_module() { return *policy_; }
+  Module *critic_module() { return critic_.get(); }
+  // Agent::actor(mode): the policy module is the actor's state; rollouts sample, evaluation is the host's business
+  Module &actor(ActorMode) { return *policy_; }
+  DeviceHistory buffer(uint64_t horizon) const { return DeviceHistory(eng_, n_lanes_, horizon, obs_dim_); }
+
+  // BatchUpdate::batch_update
+  void batch_update(DeviceHistory &history, StatsLogger &logger) {
+    log_elapsed(logger, "adv_est_time", [&] {
+      if (critic_) check(rl_gae(history.handle(), critic_->handle(), gamma_, (float)gae_lambda_), eng_.handle());
+      else check(rl_reward_to_go(history.handle(), gamma_), eng_.handle());
+      eng_.sync();
+    });
+    ScopedLogger pl(logger, "policy");
+    log_elapsed(pl, "update_time", [&] { update_policy(history, pl); eng_.sync(); });
+    ScopedLogger cl(logger, "critic");
+    log_elapsed(cl, "update_time", [&] {
+      if (!critic_) return;  // RewardToGo::update does nothing
+      rl_critic_stats cs{};
+      check(rl_critic_update(critic_->handle(), critic_opt_, history.handle(), critic_steps_, &cs, nullptr), eng_.handle());
+      cl.log_scalar("loss", cs.loss_last);  // n_backward_steps, ToLog::All (torch/agents/mod.rs:68-70)
+    });
+  }
+
+  // one data-collection pass of every lane with the current policy (train.rs:124-158's thread fan-out)
+  void collect(EnvLanes &env, DeviceHistory &history) { check(rl_rollout(env.handle(), policy_->handle(), history.handle()), eng_.handle()); }
+
+ private:
+  template <typename P, typename C>
+  friend struct ActorCriticConfig;
+  ActorCriticAgent(Engine &eng) : eng_(eng) {}
+  void update_policy(DeviceHistory &history, StatsLogger &logger) {
+    if (kind_ == PolicyKind::Trpo) {
+      rl_trpo_stats st{};
+      const int32_t rc = rl_trpo_update(policy_->handle(), history.handle(), &trpo_, &st);
+      if (rc == RL_ERR_OPT_NAN) check(rc, eng_.handle());  // the reference panics here (trpo.rs:154-162)
+      check(rc, eng_.handle());
+      logger.log_scalar("entropy", st.entropy);                  // trpo.rs:119
+      logger.log_scalar("step_size", st.step_size);              // conjugate_gradient.rs:164
+      logger.log_scalar("loss_initial", st.loss_initial);        // :200
+      if (st.num_backtracks >= 0) {
+        logger.log_scalar("num_backtracks", (double)st.num_backtracks);  // :219
+        logger.log_scalar("step_scale", st.step_scale);                  // :220
+      }
+      logger.log_scalar("loss_final", st.loss_final);            // :225
+      logger.log_scalar("constraint_val_final", st.constraint_val_final);  // :226
+      last_status_ = st.status;  // OptimizerStepError::{LossNotImproving, ConstraintViolated}: warn and continue
+    } else if (kind_ == PolicyKind::Ppo) {
+      rl_policy_opt_stats st{};
+      check(rl_ppo_update(policy_->handle(), policy_opt_, history.handle(), &ppo_, &st, nullptr), eng_.handle());
+      logger.log_scalar("entropy", st.entropy);  // ppo.rs:114 (ToLog::NoAbsLoss: no final loss)
+    } else {
+      rl_policy_opt_stats st{};
+      check(rl_reinforce_update(policy_->handle(), policy_opt_, history.handle(), &st), eng_.handle());
+      logger.log_scalar("loss", st.loss_first);
+      logger.log_scalar("entropy", st.entropy);  // reinforce.rs:84
+    }
+  }
+  Engine &eng_;
+  std::unique_ptr<Module> policy_, critic_;
+  rl_adam *policy_opt_ = nullptr, *critic_opt_ = nullptr;
+  PolicyKind kind_ = PolicyKind::Trpo;
+  rl_trpo_config trpo_{};
+  rl_ppo_config ppo_{};
+  uint64_t critic_steps_ = 80, n_lanes_ = 0;
+  uint32_t obs_dim_ = 0;
+  float gamma_ = 0.99f;
+  double gae_lambda_ = 0.95;
+
+ public:
+  int32_t last_status_ = RL_OPT_OK;
+};
+
+template <typename P, typename C>
+struct ActorCriticConfig {  // actor_critic.rs:20-45
+  P policy_config;
+  C critic_config;
+
+  // BuildAgent::build_agent(env, rng): `seed` seeds the engine-defined initialisation streams
+  std::unique_ptr<ActorCriticAgent> build_agent(EnvLanes &env, uint64_t seed) const {
+    Engine &eng = env.engine();
+    std::unique_ptr<ActorCriticAgent> a(new ActorCriticAgent(eng));
+    a->n_lanes_ = env.num_lanes();
+    a->obs_dim_ = env.num_observation_features();
+    a->policy_ = policy_config.policy_fn_config.build_module(eng, env.num_observation_features(), env.num_actions(), seed);
+    build_policy(*a, policy_config, eng);
+    build_critic(*a, critic_config, env, eng, seed + 1);
+    return a;
+  }
+
+ private:
+  template <typename MB>
+  static void build_policy(ActorCriticAgent &a, const TrpoConfig<MB> &c, Engine &) {
+    a.kind_ = PolicyKind::Trpo;
+    check(rl_trpo_config_default(&a.trpo_));
+    a.trpo_.iterations = c.optimizer_config.iterations;
+    a.trpo_.max_backtracks = c.optimizer_config.max_backtracks;
+    a.trpo_.backtrack_ratio = c.optimizer_config.backtrack_ratio;
+    a.trpo_.hpv_reg_coeff = c.optimizer_config.hpv_reg_coeff;
+    a.trpo_.accept_violation = c.optimizer_config.accept_violation ? 1 : 0;
+    a.trpo_.max_policy_step_kl = c.max_policy_step_kl;
+  }
+  template <typename MB>
+  static void build_policy(ActorCriticAgent &a, const PpoConfig<MB> &c, Engine &eng) {
+    a.kind_ = PolicyKind::Ppo;
+    a.ppo_.opt_steps_per_update = c.opt_steps_per_update;
+    a.ppo_.clip_distance = c.clip_distance;
+    a.policy_opt_ = c.optimizer_config.build_optimizer(*a.policy_, eng);
+  }
+  template <typename MB>
+  static void build_policy(ActorCriticAgent &a, const ReinforceConfig<MB> &c, Engine &eng) {
+    a.kind_ = PolicyKind::Reinforce;
+    a.policy_opt_ = c.optimizer_config.build_optimizer(*a.policy_, eng);
+  }
+  template <typename MB>
+  static void build_critic(ActorCriticAgent &a, const ValuesOptConfig<MB> &c, EnvLanes &env, Engine &eng, uint64_t seed) {
+    a.critic_ = c.state_value_fn_config.build_module(eng, env.num_observation_features(), 1, seed);
+    a.critic_opt_ = c.optimizer_config.build_optimizer(*a.critic_, eng);
+    a.critic_steps_ = c.opt_steps_per_update;
+    a.gae_lambda_ = c.gae_lambda;
+    const double g = env.discount_factor() < c.max_discount_factor ? env.discount_factor() : c.max_discount_factor;
+    a.gamma_ = (float)g;  // critics/opt.rs:73
+  }
+  static void build_critic(ActorCriticAgent &a, const RewardToGoConfig &, EnvLanes &env, Engine &, uint64_t) {
+    a.gamma_ = (float)env.discount_factor();  // critics/rtg.rs:14-20
+  }
+};
+
+// ---------------------------------------------------------------- DQN (src/torch/agents/dqn.rs)
+template <typename VB = MlpConfig>
+struct DqnConfig {  // dqn.rs:26-72
+  VB action_value_fn_config;
+  AdamConfig optimizer_config;
+  bool one_step_td = false;  // StepValueTarget::{RewardToGo, OneStepTd}
+  double exploration_start = 1.0, exploration_end = 0.1;
+  uint64_t exploration_period = 10000000;
+  uint64_t minibatch_steps = 100000, opt_steps_per_update = 50;
+  uint64_t buffer_capacity = 10000000;  // TOTAL steps; divided over the lanes (each lane is one ReplayBuffer)
+  uint64_t update_first = 1000000, update_rest = 100000;  // DataCollectionSchedule::FirstRest
+};
+
+class DqnAgent;
+template <typename VB>
+std::unique_ptr<DqnAgent> build_dqn_agent(const DqnConfig<VB> &c, EnvLanes &env, uint64_t seed, const uint32_t (&agent_key)[8]);
+
+class DqnAgent {
+ public:
+  ~DqnAgent() {
+    rl_dqn_destroy(dqn_);
+    rl_adam_destroy(opt_);
+  }
+  Module &action_value_fn() { return *q_; }
+  struct Bound { uint64_t min_steps, slack_steps; };
+  Bound min_update_size() const {  // dqn.rs:207-209
+    Bound b{};
+    check(rl_dqn_min_update_size(dqn_, &b.min_steps, &b.slack_steps), eng_.handle());
+    return b;
+  }
+  double exploration_rate(ActorMode mode) const {
+    double r = 0.0;
+    check(rl_dqn_exploration_rate(dqn_, mode == ActorMode::Training ? 1 : 0, &r), eng_.handle());
+    return r;
+  }
+  // every lane takes ceil(min_steps / lanes) steps with the epsilon-greedy actor (HistoryDataBound::divide)
+  void collect(StatsLogger &logger) {
+    const Bound b = min_update_size();
+    const uint64_t horizon = (b.min_steps + n_lanes_ - 1) / n_lanes_;
+    rl_dqn_collect_stats st{};
+    check(rl_dqn_collect(dqn_, horizon, &st), eng_.handle());  // WriteExperienceFull when an episode outgrows a lane
+    ScopedLogger sim(logger, "sim");
+    sim.log_counter_increment("step/count", st.steps);           // train.rs:175
+    sim.log_counter_increment("ep/count", st.episodes_ended);    // train.rs:171
+  }
+  void batch_update(StatsLogger &logger) {  // dqn.rs:263-337
+    logger.log_scalar("exploration_rate", exploration_rate(ActorMode::Training));  // :268-272
+    rl_dqn_update_stats st{};
+    check(rl_dqn_update(dqn_, &st, nullptr), eng_.handle());
+    logger.log_scalar("loss", st.loss_last);  // ToLog::All
+    global_steps_ = st.global_steps;
+  }
+  uint64_t global_steps() const { return global_steps_; }
+
+ private:
+  template <typename VB>
+  friend std::unique_ptr<DqnAgent> build_dqn_agent(const DqnConfig<VB> &, EnvLanes &, uint64_t, const uint32_t (&)[8]);
+  explicit DqnAgent(Engine &eng) : eng_(eng) {}
+  Engine &eng_;
+  std::unique_ptr<Module> q_;
+  rl_adam *opt_ = nullptr;
+  rl_dqn *dqn_ = nullptr;
+  uint64_t n_lanes_ = 0, global_steps_ = 0;
+};
+
+// BuildAgent for DqnConfig (dqn.rs:74-96); `agent_key` is the 32-byte seed `Prng::from_rng(rng)` draws
+template <typename VB>
+std::unique_ptr<DqnAgent> build_dqn_agent(const DqnConfig<VB> &c, EnvLanes &env, uint64_t seed, const uint32_t (&agent_key)[8]) {
+  Engine &eng = env.engine();
+  std::unique_ptr<DqnAgent> a(new DqnAgent(eng));
+  a->n_lanes_ = env.num_lanes();
+  a->q_ = c.action_value_fn_config.build_module(eng, env.num_observation_features(), env.num_actions(), seed);
+  a->opt_ = c.optimizer_config.build_optimizer(*a->q_, eng);
+  rl_dqn_config d;
+  check(rl_dqn_config_default(&d));
+  d.target = c.one_step_td ? RL_DQN_TARGET_ONE_STEP_TD : RL_DQN_TARGET_REWARD_TO_GO;
+  d.exploration_kind = RL_SCHEDULE_LINEAR_ANNEALED;
+  d.exploration_start = c.exploration_start;
+  d.exploration_end = c.exploration_end;
+  d.exploration_period = c.exploration_period;
+  d.minibatch_steps = c.minibatch_steps;
+  d.opt_steps_per_update = c.opt_steps_per_update;
+  d.buffer_capacity = (c.buffer_capacity + env.num_lanes() - 1) / env.num_lanes();
+  d.update_kind = RL_COLLECT_FIRST_REST;
+  d.update_first = c.update_first;
+  d.update_rest = c.update_rest;
+  d.discount_factor = (float)env.discount_factor();
+  std::memcpy(d.agent_key, agent_key, sizeof(d.agent_key));
+  check(rl_dqn_create(env.handle(), a->q_->handle(), a->opt_, &d, &a->dqn_), eng.handle());
+  return a;
+}
+
+// ---------------------------------------------------------------- the period loop of train_parallel (train.rs:68-186)
+inline void train_batched(ActorCriticAgent &agent, EnvLanes &env, DeviceHistory &history, uint64_t num_periods,
+                          StatsLogger &logger) {
+  for (uint64_t period = 0; period < num_periods; ++period) {
+    const auto collect_start = std::chrono::steady_clock::now();
+    agent.collect(env, history);
+    env.engine().sync();
+    {
+      ScopedLogger sim(logger, "sim");
+      uint64_t episodes = 0;
+      for (uint8_t f : history.successors()) episodes += f != RL_SUCC_CONTINUE;
+      sim.log_counter_increment("ep/count", episodes);                 // train.rs:171
+      sim.log_counter_increment("step/count", history.num_steps());    // train.rs:175
+      sim.log_duration("time", std::chrono::duration<double>(std::chrono::steady_clock::now() - collect_start).count());
+    }
+    const auto update_start = std::chrono::steady_clock::now();
+    agent.batch_update(history, logger);
+    ScopedLogger up(logger, "agent_update");
+    up.log_duration("time", std::chrono::duration<double>(std::chrono::steady_clock::now() - update_start).count());
+    up.log_counter_increment("count", 1);  // train.rs:182-184
+  }
+}
+
+}  // namespace relearn

@@ -1,0 +1,99 @@
+// host_api_demo.cpp — the C++ host API (relearn_amd/csrc/host/agents.hpp) used the way the reference's examples use
+// its traits: examples/cartpole-trpo.rs (ActorCriticConfig<TrpoConfig<MlpConfig>, ValuesOptConfig<MlpConfig>>,
+// train_parallel), a PPO agent with the recurrent module on Chain, and examples/cartpole-dqn.rs.
+// Prints one JSON object: logged metric names/values and a checksum of every module's parameters, which
+// tests/test_gpu_host_api.py compares with the same runs driven through the ctypes binding.
+#include <cinttypes>
+#include <cstdio>
+
+#include "../../relearn_amd/csrc/host/agents.hpp"
+
+using namespace relearn;
+
+static double checksum(const std::vector<float> &p) {
+  double s = 0.0;
+  for (size_t i = 0; i < p.size(); ++i) s += (double)p[i] * (double)(1 + (i % 7));
+  return s;
+}
+
+static void dump(const char *name, const RecordingLogger &log, double pol, double cri, bool last) {
+  std::printf("\"%s\": {\"policy_checksum\": %.17g, \"critic_checksum\": %.17g, \"scalars\": {", name, pol, cri);
+  bool first = true;
+  for (auto &kv : log.scalars) {
+    std::printf("%s\"%s\": %.17g", first ? "" : ", ", kv.first.c_str(), kv.second);
+    first = false;
+  }
+  std::printf("}, \"counters\": {");
+  first = true;
+  for (auto &kv : log.counters) {
+    std::printf("%s\"%s\": %" PRIu64, first ? "" : ", ", kv.first.c_str(), kv.second);
+    first = false;
+  }
+  std::printf("}, \"durations\": [");
+  first = true;
+  for (auto &kv : log.durations) {
+    std::printf("%s\"%s\"", first ? "" : ", ", kv.first.c_str());
+    first = false;
+  }
+  std::printf("]}%s\n", last ? "" : ",");
+}
+
+int main() {
+  try {
+    Engine eng(0);
+    std::printf("{\n");
+    {  // examples/cartpole-trpo.rs
+      CartPoleLanes env(eng, 256, 500, StepLimit::Visible, /*seed_env=*/0, /*seed_actor=*/1);
+      ActorCriticConfig<TrpoConfig<MlpConfig>, ValuesOptConfig<MlpConfig>> cfg;
+      cfg.critic_config.opt_steps_per_update = 5;
+      auto agent = cfg.build_agent(env, /*seed=*/2);
+      DeviceHistory history = agent->buffer(32);
+      RecordingLogger log;
+      train_batched(*agent, env, history, 2, log);
+      dump("trpo", log, checksum(agent->policy_module().parameters()), checksum(agent->critic_module()->parameters()), false);
+    }
+    {  // PPO over the recurrent module on the partially observed Chain
+      ChainLanes env(eng, 64, 100, StepLimit::Latent, 3, 4);
+      ActorCriticConfig<PpoConfig<GruMlpConfig>, ValuesOptConfig<GruMlpConfig>> cfg;
+      cfg.policy_config.opt_steps_per_update = 2;
+      cfg.critic_config.opt_steps_per_update = 2;
+      auto agent = cfg.build_agent(env, 11);
+      DeviceHistory history = agent->buffer(20);
+      RecordingLogger log;
+      train_batched(*agent, env, history, 1, log);
+      dump("ppo_gru", log, checksum(agent->policy_module().parameters()), checksum(agent->critic_module()->parameters()), false);
+    }
+    {  // examples/cartpole-dqn.rs, shrunk
+      CartPoleLanes env(eng, 128, 500, StepLimit::Visible, 0, 1);
+      DqnConfig<MlpConfig> cfg;
+      cfg.minibatch_steps = 1000;
+      cfg.opt_steps_per_update = 3;
+      cfg.buffer_capacity = 128 * 256;
+      cfg.update_first = 128 * 40;
+      cfg.update_rest = 128 * 10;
+      cfg.exploration_period = 100000;
+      const uint32_t key[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+      auto agent = build_dqn_agent(cfg, env, 7, key);
+      RecordingLogger log;
+      for (int period = 0; period < 2; ++period) {
+        agent->collect(log);
+        agent->batch_update(log);
+      }
+      log.scalars["global_steps"] = (double)agent->global_steps();
+      dump("dqn", log, checksum(agent->action_value_fn().parameters()), 0.0, true);
+    }
+    std::printf("}\n");
+    // error behaviour: an unsupported module shape is a BuildAgentError
+    try {
+      MlpConfig bad;
+      bad.hidden_size = 4096;
+      bad.build_module(eng, 5, 2, 0);
+      return 2;
+    } catch (const BuildAgentError &) {
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+}
