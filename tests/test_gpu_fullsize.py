@@ -1,0 +1,176 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need a full-size oracle run:
+lanes are independent, so slices of a full-size device rollout are compared bit for bit with the oracle run on just
+those lanes (same global lane ids); sharding invariance; linearity of sample sums; the trust-region acceptance rule;
+replay-ring invariants; agreement of the parallel and the sequential minibatch samplers."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ra = pytest.importorskip("relearn_amd")
+
+H = 128
+PS, CS = O.MlpShape(5, H, 2), O.MlpShape(5, H, 1)
+N, T = 65536, 128  # configs[1] / configs[3]: 65,536 CartPole lanes, horizon 128
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def full(engine):
+    env = ra.CartPoleEnv(engine, N, max_steps=500, seed_env=0, seed_actor=1)
+    pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+    pol.init(2)
+    cri.init(3)
+    traj = ra.Trajectory(engine, N, T, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    return dict(env=env, pol=pol, cri=cri, traj=traj, data=traj.read_all(), adv=traj.read(ra.TRAJ_ADVANTAGES),
+                rtg=traj.read(ra.TRAJ_RETURNS), values=traj.read(ra.TRAJ_VALUES))
+
+
+@pytest.mark.parametrize("lo", [0, 31337, N - 96])
+def test_full_size_rollout_slices_equal_the_oracle(full, lo):
+    n = 96
+    sim = O.LaneSim(n, max_steps=500, lane_offset=lo, seed_env=0, seed_actor=1)
+    want = sim.rollout(PS, full["pol"].get_params(), T)
+    got = full["data"]
+    for k in ("obs", "action", "reward", "flag"):
+        assert np.array_equal(got[k][..., lo:lo + n], want[k]), k
+    v_o, adv_o, rtg_o = O.lanes_gae(CS, full["cri"].get_params(), want, np.float32(0.99), np.float32(0.95))
+    assert np.array_equal(full["values"][:, lo:lo + n], v_o)
+    assert np.array_equal(full["adv"][:, lo:lo + n], adv_o)
+    assert np.array_equal(full["rtg"][:, lo:lo + n], rtg_o)
+
+
+def test_full_size_sharding_invariance_and_gradient_linearity(engine, full):
+    """two 32,768-lane shards (what two GPUs hold) reproduce the full rollout bit for bit; the full-batch gradient is
+    the sample-weighted mean of the shard gradients"""
+    halves = []
+    for r in range(2):
+        env = ra.CartPoleEnv(engine, N // 2, max_steps=500, lane_offset=r * (N // 2), seed_env=0, seed_actor=1)
+        traj = ra.Trajectory(engine, N // 2, T, 5)
+        ra.rollout(env, full["pol"], traj)
+        ra.gae(traj, full["cri"], 0.99, 0.95)
+        assert np.array_equal(traj.read(ra.TRAJ_ACTION), full["data"]["action"][:, r * (N // 2):(r + 1) * (N // 2)])
+        assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), full["adv"][:, r * (N // 2):(r + 1) * (N // 2)])
+        g, loss, ent = ra.policy_gradient(full["pol"], traj)
+        gc, lc = ra.critic_gradient(full["cri"], traj)
+        halves.append((g, loss, ent, gc, lc))
+    g, loss, ent = ra.policy_gradient(full["pol"], full["traj"])
+    gc, lc = ra.critic_gradient(full["cri"], full["traj"])
+    assert rel_err(0.5 * (halves[0][0] + halves[1][0]), g) < 2e-6
+    assert rel_err(0.5 * (halves[0][3] + halves[1][3]), gc) < 2e-6
+    assert abs(0.5 * (halves[0][1] + halves[1][1]) - loss) < 1e-6 * max(1.0, abs(loss))
+    assert abs(0.5 * (halves[0][4] + halves[1][4]) - lc) < 1e-5 * lc
+    assert abs(0.5 * (halves[0][2] + halves[1][2]) - ent) < 1e-6
+
+
+def test_full_size_return_scan_properties(engine, full):
+    """gamma = 1 with unit rewards: the return is the number of steps to the end of the lane's episode segment;
+    returns restart after every episode end; scaling gamma * lambda to 0 makes advantages one-step residuals"""
+    traj = full["traj"]
+    ra.reward_to_go(traj, 1.0)
+    rtg = traj.read(ra.TRAJ_RETURNS)
+    flag = full["data"]["flag"]
+    ends = flag != 0
+    ends[T - 1, :] = True
+    # steps to the next end, computed with numpy on the full array
+    idx = np.where(ends, np.arange(T)[:, None], T + 1)
+    nxt = np.minimum.accumulate(idx[::-1], axis=0)[::-1]
+    assert np.array_equal(rtg, (nxt - np.arange(T)[:, None] + 1).astype(np.float32))
+    ra.gae(traj, full["cri"], 0.99, 0.0)
+    adv0 = traj.read(ra.TRAJ_ADVANTAGES)
+    v = full["values"]
+    cont = ~ends
+    delta = (1.0 + np.float32(0.99) * v[1:]) - v[:-1]
+    assert np.array_equal(adv0[cont], delta.astype(np.float32)[cont])
+    ra.gae(traj, full["cri"], 0.99, 0.95)  # restore for the tests below
+    assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), full["adv"])
+
+
+def test_full_size_update_obeys_the_trust_region(engine, full):
+    pol, cri, traj = full["pol"], full["cri"], full["traj"]
+    p0, c0 = pol.get_params().copy(), cri.get_params().copy()
+    st = ra.trpo_update(pol, traj)
+    assert st.status == ra.OPT_OK and st.cg_iterations == 10
+    assert st.constraint_val_final <= 0.01 and st.loss_final < st.loss_initial
+    loss_d, kl_d = ra.policy_loss_kl(pol, traj, p0)  # independent re-evaluation of what was accepted
+    assert abs(loss_d - st.loss_final) <= 1e-5 * max(1.0, abs(st.loss_final))
+    assert abs(kl_d - st.constraint_val_final) <= 1e-6 + 1e-3 * kl_d
+    cs, losses = ra.critic_update(cri, ra.Adam(cri), traj, 80, want_losses=True)
+    assert losses[-1] < losses[0] and np.all(np.isfinite(losses))
+    pol.set_params(p0)
+    cri.set_params(c0)
+
+
+def test_config3_replay_invariants_and_samplers(engine):
+    """configs[2]: 4,096 lanes, 50 M-step store (12,207 steps per lane), 100 k-step minibatches"""
+    n, cap = 4096, 50_000_000 // 4096
+    env = ra.CartPoleEnv(engine, n, max_steps=500, seed_env=0, seed_actor=1)
+    q = ra.Mlp(engine, 5, H, 2)
+    q.init(2)
+    cfg = ra.dqn_config_default()
+    cfg.buffer_capacity = cap
+    cfg.exploration_kind, cfg.exploration_start = ra.SCHEDULE_CONSTANT, 0.5
+    for i in range(8):
+        cfg.agent_key[i] = 40 + i
+    dqn = ra.Dqn(env, q, ra.Adam(q), cfg)
+    total = 0
+    for horizon in (5000, 5000, 4000):  # 14,000 > capacity: every lane evicts
+        dqn.collect(horizon, want_stats=False)
+        total += horizon
+    head, count = dqn.replay_read(ra.REPLAY_HEAD).astype(np.int64), dqn.replay_read(ra.REPLAY_COUNT).astype(np.int64)
+    eph, epc = dqn.replay_read(ra.REPLAY_EP_HEAD).astype(np.int64), dqn.replay_read(ra.REPLAY_EP_COUNT).astype(np.int64)
+    assert np.all(dqn.replay_read(ra.REPLAY_TOTAL) == total) and np.all(count <= cap) and np.all(head > 0)
+    assert np.all(head + count == total)  # nothing dangling: the horizon rule closes every episode
+    ep_end, flag = dqn.replay_read(ra.REPLAY_EP_END), dqn.replay_read(ra.REPLAY_FLAG)
+    for lane in (0, 1, 777, n - 1):
+        ends = np.array([ep_end[(eph[lane] + k) % dqn.E, lane] for k in range(epc[lane])], dtype=np.int64)
+        assert np.all(np.diff(ends) > 0) and ends[-1] == total and ends[0] > head[lane]
+        # whole episodes only: the stored flags are non-zero exactly at the recorded episode ends
+        slots = np.arange(head[lane], total) % cap
+        nz = np.nonzero(flag[slots, lane])[0] + head[lane] + 1
+        assert np.array_equal(nz, ends)
+    pos0 = dqn.agent_rng_pos()
+    ne, ns = dqn.minibatch_sample()
+    lens = dqn.minibatch_read(ra.MB_EP_LEN).astype(np.int64)
+    assert ns == lens.sum() >= 100_000 and ns - lens[-1] < 100_000
+    assert dqn.agent_rng_pos() - pos0 == 2 * (ne + 1)  # one u64 per candidate, including the refused one
+    lanes_par = dqn.minibatch_read(ra.MB_EP_LANE)
+    assert np.array_equal(lanes_par, np.arange(ne) % n)  # the buffers are cycled in order
+    tgt = dqn.minibatch_read(ra.MB_TARGET)
+    off = dqn.minibatch_read(ra.MB_EP_OFFSET).astype(np.int64)
+    # reward-to-go of unit rewards with gamma 0.99: the last step of every episode has target 1
+    assert np.all(tgt[off + lens - 1] == 1.0) and np.all(np.diff(tgt[off[5]:off[5] + lens[5]]) < 0)
+    st = dqn.update()
+    assert np.isfinite(st.loss_last) and st.global_steps == total * n
+
+
+def test_config5_rollout_slices_and_update(engine):
+    """configs[4]: 16,384 Chain lanes under LatentStepLimit(100), GRU policy, T = 100"""
+    n, Tc = 16384, 100
+    gs = O.GruShape(5, 128, 128, 2)
+    env = ra.ChainEnv(engine, n, max_steps=100, seed_env=3, seed_actor=4)
+    pol, cri = ra.GruMlp(engine, 5, 2), ra.GruMlp(engine, 5, 1)
+    pol.init(11)
+    cri.init(12)
+    traj = ra.Trajectory(engine, n, Tc, 5)
+    ra.rollout(env, pol, traj)
+    got = traj.read_all()
+    for lo in (0, 9001, n - 32):
+        sim = O.ChainLaneSim(32, max_steps=100, lane_offset=lo, seed_env=3, seed_actor=4)
+        want = sim.rollout_gru(gs, pol.get_params(), Tc)
+        for k in ("obs", "action", "reward", "flag"):
+            assert np.array_equal(got[k][..., lo:lo + 32], want[k]), (lo, k)
+    assert np.all(got["flag"][Tc - 1] == O.INTERRUPT) and not got["flag"][:Tc - 1].any()
+    ra.gae(traj, cri, 0.95, 0.95)
+    cfg = ra.ppo_config_default()
+    cfg.opt_steps_per_update = 3
+    st, losses = ra.ppo_update(pol, ra.Adam(pol), traj, cfg, want_losses=True)
+    assert losses[-1] < losses[0] and 0.0 < st.entropy <= np.log(2.0) + 1e-6
