@@ -283,27 +283,150 @@ __device__ __forceinline__ void seq_cell(SeqFwdShared &sh, const SeqFwdWeights<D
   __syncthreads();
 }
 
+// ---------------------------------------------------------------- 16-unit ownership (v_mfma_f32_16x16x4_f32)
+// The same cell with EIGHT waves per tile: wave w owns hidden units [16w, 16w+16) of every gate and of the MLP layer,
+// ~180 registers, so two waves share a SIMD (workgroup of 512 threads, one per CU) and one wave's ds_reads / gate
+// transcendentals run under the other's MFMAs.  16x16x4 lane maps (measured, scripts/probe/mfma16_arith.hip):
+// A[m = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15], C register i of lane l = C[4 (l >> 4) + i][l & 15]; the four
+// k-products of an instruction and chained instructions form one sequential fma chain over k ascending, so the
+// results are bit-identical to the 32x32x2 formulation and to the oracle.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int W16 = 8;  // waves per tile
+
+template <int D>
+struct SeqFwdWeights16 {
+  float whh[3][GH / 4];
+  float w1[GH / 4];
+  float wih[3][D];
+  float bih[3], bhh[3], b1;
+};
+
+template <int D>
+__device__ __forceinline__ void seq_load_weights16(SeqFwdWeights16<D> &w, const GruParams &g, int wave, int lane) {
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
+#pragma unroll
+  for (int gte = 0; gte < 3; ++gte) {
+    const int row = gte * GH + j;
+#pragma unroll
+    for (int ks = 0; ks < GH / 4; ++ks) w.whh[gte][ks] = g.Whh[(size_t)row * GH + 4 * ks + g4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) w.wih[gte][d] = g.Wih[(size_t)row * D + d];
+    w.bih[gte] = g.bih[row];
+    w.bhh[gte] = g.bhh[row];
+  }
+#pragma unroll
+  for (int ks = 0; ks < GH / 4; ++ks) w.w1[ks] = g.W1[(size_t)j * GH + 4 * ks + g4];
+  w.b1 = g.b1[j];
+}
+
+// sample owned by accumulator register i of M-tile mt in lane group g4
+__device__ __forceinline__ int acc16_row(int mt, int i, int g4) { return 16 * mt + 4 * g4 + i; }
+
+template <int D, int A>
+__device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights16<D> &w, int cur,
+                                           const float (&hown)[8], float (&hnew)[8], float b2_mine,
+                                           float *__restrict__ store, int wave, int lane) {
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16, nxt = cur ^ 1;
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[gte][mt] = (f32x4){w.bhh[gte], w.bhh[gte], w.bhh[gte], w.bhh[gte]};
+#pragma unroll
+  for (int ks = 0; ks < GH / 4; ++ks) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float a = sh.hT[cur][4 * ks + g4][16 * mt + n16];
+#pragma unroll
+      for (int gte = 0; gte < 3; ++gte)
+        acc[gte][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w.whh[gte][ks], acc[gte][mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = acc16_row(mt, i, g4), r = 4 * mt + i;
+      float gi[3];
+#pragma unroll
+      for (int gte = 0; gte < 3; ++gte) {
+        float v = w.bih[gte];
+#pragma unroll
+        for (int d = 0; d < D; ++d) v = __builtin_fmaf(sh.xS[m][d], w.wih[gte][d], v);
+        gi[gte] = v;
+      }
+      const float rr = rl_sigmoidf(acc[0][mt][i] + gi[0]);
+      const float zz = rl_sigmoidf(acc[1][mt][i] + gi[1]);
+      const float rn = acc[2][mt][i] * rr;
+      const float nn = rl_tanhf(gi[2] + rn);
+      const float dn = hown[r] - nn;
+      const float hz = dn * zz;
+      const float hv = hz + nn;
+      hnew[r] = hv;
+      sh.hT[nxt][j][m] = hv;
+      if (store != nullptr) {
+        store[(size_t)ACT_R * GH * TL + j * TL + m] = rr;
+        store[(size_t)ACT_Z * GH * TL + j * TL + m] = zz;
+        store[(size_t)ACT_N * GH * TL + j * TL + m] = nn;
+        store[(size_t)ACT_GHN * GH * TL + j * TL + m] = acc[2][mt][i];
+        store[(size_t)ACT_HPREV * GH * TL + j * TL + m] = hown[r];
+        store[(size_t)ACT_A1 * GH * TL + j * TL + m] = hv > 0.0f ? hv : 0.0f;
+      }
+    }
+  __syncthreads();
+  f32x4 acc1[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) acc1[mt] = (f32x4){w.b1, w.b1, w.b1, w.b1};
+#pragma unroll
+  for (int ks = 0; ks < GH / 4; ++ks) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float a = sh.hT[nxt][4 * ks + g4][16 * mt + n16];
+      a = a > 0.0f ? a : 0.0f;  // Chain activation between the modules (chain.rs:165)
+      acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w.w1[ks], acc1[mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = acc16_row(mt, i, g4);
+      const float u = acc1[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
+      sh.uS[m][j] = u;
+      if (store != nullptr) store[(size_t)ACT_U * GH * TL + j * TL + m] = u;
+    }
+  __syncthreads();
+  if (wave == 0 && (lane >> 5) < A) {
+    const int n = lane & 31, hf = lane >> 5;
+    float z = b2_mine;
+#pragma unroll 8
+    for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
+    sh.outS[hf][n] = z;
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------- rollout (Chain env, recurrent policy)
 // PolicyActor::act over SeqIterative::step (policies/actor.rs:42-55; chain.rs:175-186) for T steps of every lane.
 // The episode state starts at zero at the beginning of the launch and after every episode end.
 template <int D>
-__global__ void __launch_bounds__(256, 1) k_rollout_chain_gru(CartPoleDev c, EnvStateDev st, TrajDev tr,
+__global__ void __launch_bounds__(W16 * 64, 2) k_rollout_chain_gru(CartPoleDev c, EnvStateDev st, TrajDev tr,
                                                               const float *__restrict__ params, uint64_t t_global) {
   constexpr int A = 2;
   __shared__ SeqFwdShared sh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const int n16 = lane & 15, g4 = lane >> 4, hf = lane >> 5, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const uint32_t lane0 = blockIdx.x * TL;
   const GruParams g = gru_params(params, D, A);
-  SeqFwdWeights<D> w;
-  seq_load_weights<D>(w, g, wave, lane);
-  for (int q = threadIdx.x; q < A * MH; q += 256) sh.w2S[q / MH][q % MH] = g.W2[q];
-  for (int q = threadIdx.x; q < 2 * GH * (TL + 1); q += 256) (&sh.hT[0][0][0])[q] = 0.0f;
+  SeqFwdWeights16<D> w;
+  seq_load_weights16<D>(w, g, wave, lane);
+  for (int q = threadIdx.x; q < A * MH; q += W16 * 64) sh.w2S[q / MH][q % MH] = g.W2[q];
+  for (int q = threadIdx.x; q < 2 * GH * (TL + 1); q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
   const float b2_mine = hf < A ? g.b2[hf] : 0.0f;
-  float hown[16];
+  float hown[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) hown[r] = 0.0f;
+  for (int r = 0; r < 8; ++r) hown[r] = 0.0f;
   // env state of the tile: lanes 0..31 of wave 0
   const bool env_lane = wave == 0 && lane < TL;
   const uint32_t i = lane0 + (uint32_t)lane;
@@ -323,8 +446,8 @@ __global__ void __launch_bounds__(256, 1) k_rollout_chain_gru(CartPoleDev c, Env
   __syncthreads();
   int cur = 0;
   for (uint32_t t = 0; t < T; ++t) {
-    float hnew[16];
-    seq_cell<D, A>(sh, w, cur, hown, hnew, b2_mine, nullptr, wave, lane);
+    float hnew[8];
+    seq_cell16<D, A>(sh, w, cur, hown, hnew, b2_mine, nullptr, wave, lane);
     if (env_lane) {
       float z[2] = {sh.outS[0][lane], sh.outS[1][lane]}, lp[2];
       log_softmax_lane<2>(z, lp);
@@ -355,8 +478,8 @@ __global__ void __launch_bounds__(256, 1) k_rollout_chain_gru(CartPoleDev c, Env
     __syncthreads();
     const int nxt = cur ^ 1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = acc_row(r, hf);
+    for (int r = 0; r < 8; ++r) {
+      const int m = acc16_row(r >> 2, r & 3, g4);
       const bool ended = sh.endS[m] != 0;
       hown[r] = ended ? 0.0f : hnew[r];
       if (ended) sh.hT[nxt][j][m] = 0.0f;
@@ -372,25 +495,25 @@ __global__ void __launch_bounds__(256, 1) k_rollout_chain_gru(CartPoleDev c, Env
 // outputs out[a][t][lane]; optionally the outputs at the successor observations of cut episodes (extended
 // observation sequences, features.rs:132-178) and the activation record for the backward pass.
 template <int D, int A>
-__global__ void __launch_bounds__(256, 1) k_gru_seq_forward(TrajDev tr, const float *__restrict__ params,
+__global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, const float *__restrict__ params,
                                                             float *__restrict__ out, float *__restrict__ succ_out,
                                                             float *__restrict__ act,
                                                             const int32_t *__restrict__ skip) {
   __shared__ SeqFwdShared sh;
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const int n16 = lane & 15, g4 = lane >> 4, hf = lane >> 5, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
   const GruParams g = gru_params(params, D, A);
-  SeqFwdWeights<D> w;
-  seq_load_weights<D>(w, g, wave, lane);
-  for (int q = threadIdx.x; q < A * MH; q += 256) sh.w2S[q / MH][q % MH] = g.W2[q];
-  for (int q = threadIdx.x; q < 2 * GH * (TL + 1); q += 256) (&sh.hT[0][0][0])[q] = 0.0f;
+  SeqFwdWeights16<D> w;
+  seq_load_weights16<D>(w, g, wave, lane);
+  for (int q = threadIdx.x; q < A * MH; q += W16 * 64) sh.w2S[q / MH][q % MH] = g.W2[q];
+  for (int q = threadIdx.x; q < 2 * GH * (TL + 1); q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
   const float b2_mine = hf < A ? g.b2[hf] : 0.0f;
-  float hown[16];
+  float hown[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) hown[r] = 0.0f;
+  for (int r = 0; r < 8; ++r) hown[r] = 0.0f;
   const bool io_lane = wave == 0 && lane < TL;
   const uint32_t i = lane0 + (uint32_t)lane;
   const size_t plane = (size_t)(T + 1) * N;
@@ -410,9 +533,9 @@ __global__ void __launch_bounds__(256, 1) k_gru_seq_forward(TrajDev tr, const fl
       if (threadIdx.x == 0) sh.peek = 0;
     }
     __syncthreads();
-    float hout[16];
+    float hout[8];
     float *store = (act != nullptr && !peeking) ? act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL : nullptr;
-    seq_cell<D, A>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
+    seq_cell16<D, A>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
     if (io_lane) {
       if (!peeking) {
 #pragma unroll
@@ -437,15 +560,15 @@ __global__ void __launch_bounds__(256, 1) k_gru_seq_forward(TrajDev tr, const fl
     if (!peeking && sh.peek != 0) {
       // keep the post-step state as the input of the peek iteration; the reset of ended lanes waits
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hown[r] = hout[r];
+      for (int r = 0; r < 8; ++r) hown[r] = hout[r];
       cur ^= 1;
       peeking = true;
     } else {
       // commit: restart the state of lanes whose episode ended at step t
       const int buf = peeking ? cur : (cur ^ 1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = acc_row(r, hf);
+      for (int r = 0; r < 8; ++r) {
+        const int m = acc16_row(r >> 2, r & 3, g4);
         const bool ended = sh.endS[m] != 0;
         const float hv = peeking ? hown[r] : hout[r];
         hown[r] = ended ? 0.0f : hv;
@@ -550,7 +673,7 @@ void launch_rollout_chain_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj) 
   ProfScope ps(env->eng, RL_K_ROLLOUT);
   RL_REQUIRE(env->D == 5, "recurrent rollout: built for 5 observation features (Chain under a latent step limit)");
   uint32_t tiles = traj->d.n / TL;
-  hipLaunchKernelGGL(k_rollout_chain_gru<5>, dim3(tiles), dim3(256), 0, env->eng->stream, env->dev, env->st, traj->d,
+  hipLaunchKernelGGL(k_rollout_chain_gru<5>, dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev, env->st, traj->d,
                      policy->d_params, env->t_global);
 }
 
@@ -560,10 +683,10 @@ void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, floa
   RL_REQUIRE(traj->d.D == 5, "recurrent forward: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;
   if (mod->out_dim == 2)
-    hipLaunchKernelGGL((k_gru_seq_forward<5, 2>), dim3(tiles), dim3(256), 0, traj->eng->stream, traj->d,
+    hipLaunchKernelGGL((k_gru_seq_forward<5, 2>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d,
                        mod->d_params, d_out, d_succ, d_act, d_skip);
   else
-    hipLaunchKernelGGL((k_gru_seq_forward<5, 1>), dim3(tiles), dim3(256), 0, traj->eng->stream, traj->d,
+    hipLaunchKernelGGL((k_gru_seq_forward<5, 1>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d,
                        mod->d_params, d_out, d_succ, d_act, d_skip);
 }
 
