@@ -786,35 +786,36 @@ __global__ void __launch_bounds__(256) k_seq_critic_dvalues(TrajDev tr, const fl
 }
 
 // ---------------------------------------------------------------- backward through time
-// One workgroup per tile, t = T-1 .. 0.  Wave w owns units k in [32w, 32w+32) of every back-propagated vector:
-// its slices of W1^T (64 B-operands) and W_hh^T (3 x 64) stay in registers, the vectors being multiplied pass
+// One workgroup (eight waves) per tile, t = T-1 .. 0.  Wave w owns units k in [16w, 16w+16) of every
+// back-propagated vector: its slices of W1^T (32 B-operands of 16x16x4 MFMAs) and W_hh^T (3 x 32) stay in registers, the vectors being multiplied pass
 // through one [128][33] LDS buffer, gate by gate.  Writes the five per-step arrays the weight-gradient GEMMs read.
 template <int A>
-__global__ void __launch_bounds__(256, 1) k_gru_bptt(TrajDev tr, const float *__restrict__ params, int D,
-                                                     const float *__restrict__ dz, const float *__restrict__ act,
-                                                     float *__restrict__ dpre, const int32_t *__restrict__ skip) {
+__global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const float *__restrict__ params, int D,
+                                                          const float *__restrict__ dz, const float *__restrict__ act,
+                                                          float *__restrict__ dpre, const int32_t *__restrict__ skip) {
   __shared__ float bufT[GH][TL + 1];
-  if (skip != nullptr && *skip != 0) return;
   __shared__ float dzS[2][TL];
   __shared__ int endS[TL];
+  if (skip != nullptr && *skip != 0) return;
+  // eight waves per tile, wave w owns units k in [16w, 16w+16) of every back-propagated vector (16x16x4 MFMAs)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
   const size_t B = (size_t)T * N;
   const GruParams g = gru_params(params, D, A);
-  float whhT[3][GH / 2], w1T[MH / 2], w2c[A];
+  float whhT[3][GH / 4], w1T[MH / 4], w2c[A];
 #pragma unroll
   for (int gte = 0; gte < 3; ++gte)
 #pragma unroll
-    for (int ks = 0; ks < GH / 2; ++ks) whhT[gte][ks] = g.Whh[(size_t)(gte * GH + 2 * ks + hf) * GH + j];
+    for (int ks = 0; ks < GH / 4; ++ks) whhT[gte][ks] = g.Whh[(size_t)(gte * GH + 4 * ks + g4) * GH + j];
 #pragma unroll
-  for (int ks = 0; ks < MH / 2; ++ks) w1T[ks] = g.W1[(size_t)(2 * ks + hf) * GH + j];
+  for (int ks = 0; ks < MH / 4; ++ks) w1T[ks] = g.W1[(size_t)(4 * ks + g4) * GH + j];
 #pragma unroll
   for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
-  float dhc[16];
+  float dhc[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dhc[r] = 0.0f;
+  for (int r = 0; r < 8; ++r) dhc[r] = 0.0f;
   for (uint32_t t = T; t-- > 0;) {
     const size_t blk = (size_t)t * tiles + tile;
     const float *__restrict__ ab = act + blk * SEQ_ARR * GH * TL;
@@ -827,8 +828,8 @@ __global__ void __launch_bounds__(256, 1) k_gru_bptt(TrajDev tr, const float *__
     __syncthreads();
     // head: d u_pre = [u > 0] W2^T dz
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = acc_row(r, hf);
+    for (int r = 0; r < 8; ++r) {
+      const int m = acc16_row(r >> 2, r & 3, g4);
       const float u = ab[(size_t)ACT_U * GH * TL + j * TL + m];
       float du = 0.0f;
 #pragma unroll
@@ -838,23 +839,26 @@ __global__ void __launch_bounds__(256, 1) k_gru_bptt(TrajDev tr, const float *__
       db[(size_t)4 * GH * TL + j * TL + m] = du;
     }
     __syncthreads();
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc[2];
+    acc[0] = acc[1] = (f32x4){0, 0, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < MH / 2; ++ks)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bufT[2 * ks + hf][n], w1T[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < MH / 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufT[4 * ks + g4][16 * mt + n16], w1T[ks], acc[mt], 0, 0, 0);
     __syncthreads();
     // cell: h' = (h - n) z + n
-    float gr[16], gz[16], gnr[16], dhdir[16];
+    float gr[8], gz[8], gnr[8], dhdir[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = acc_row(r, hf);
+    for (int r = 0; r < 8; ++r) {
+      const int m = acc16_row(r >> 2, r & 3, g4);
       const size_t o = (size_t)j * TL + m;
       const float a1 = ab[(size_t)ACT_A1 * GH * TL + o];
       const float rr = ab[(size_t)ACT_R * GH * TL + o], zz = ab[(size_t)ACT_Z * GH * TL + o];
       const float nn = ab[(size_t)ACT_N * GH * TL + o], ghn = ab[(size_t)ACT_GHN * GH * TL + o];
       const float hp = ab[(size_t)ACT_HPREV * GH * TL + o];
       float dh = endS[m] ? 0.0f : dhc[r];
-      dh = dh + (a1 > 0.0f ? acc[r] : 0.0f);
+      dh = dh + (a1 > 0.0f ? acc[r >> 2][r & 3] : 0.0f);
       const float dzg = dh * (hp - nn);
       const float dn = dh * (1.0f - zz);
       const float dpn = dn * (1.0f - nn * nn);
@@ -869,19 +873,22 @@ __global__ void __launch_bounds__(256, 1) k_gru_bptt(TrajDev tr, const float *__
       db[(size_t)3 * GH * TL + o] = gnr[r];
     }
     // d h_prev = dh z + sum over gates of W_hh[g]^T d gh_g
-    acc = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc[0] = acc[1] = (f32x4){0, 0, 0, 0};
 #pragma unroll
     for (int gte = 0; gte < 3; ++gte) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bufT[j][acc_row(r, hf)] = gte == 0 ? gr[r] : (gte == 1 ? gz[r] : gnr[r]);
+      for (int r = 0; r < 8; ++r)
+        bufT[j][acc16_row(r >> 2, r & 3, g4)] = gte == 0 ? gr[r] : (gte == 1 ? gz[r] : gnr[r]);
       __syncthreads();
 #pragma unroll
-      for (int ks = 0; ks < GH / 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bufT[2 * ks + hf][n], whhT[gte][ks], acc, 0, 0, 0);
+      for (int ks = 0; ks < GH / 4; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufT[4 * ks + g4][16 * mt + n16], whhT[gte][ks], acc[mt], 0, 0, 0);
       __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dhc[r] = dhdir[r] + acc[r];
+    for (int r = 0; r < 8; ++r) dhc[r] = dhdir[r] + acc[r >> 2][r & 3];
   }
 }
 
@@ -1064,10 +1071,10 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   {
     ProfScope ps(e, RL_K_BACKWARD);
     if (mod->out_dim == 2)
-      hipLaunchKernelGGL(k_gru_bptt<2>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
+      hipLaunchKernelGGL(k_gru_bptt<2>, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
                          q.act, q.dpre, d_skip);
     else
-      hipLaunchKernelGGL(k_gru_bptt<1>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
+      hipLaunchKernelGGL(k_gru_bptt<1>, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
                          q.act, q.dpre, d_skip);
   }
   {
