@@ -343,6 +343,10 @@ def _declare(L):
                                           P(C.c_float)]
     L.oracle_chain_lanes_rollout_gru.argtypes = [P(ChainLanes), GruShape, P(C.c_float), C.c_uint64, P(C.c_float),
                                                  P(C.c_uint8), P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int]
+    L.oracle_chain_lanes_rollout_mlp.argtypes = [P(ChainLanes), MlpShape, P(C.c_float), C.c_uint64, P(C.c_float),
+                                                 P(C.c_uint8), P(C.c_float), P(C.c_uint8), P(C.c_float)]
+    L.oracle_lanes_rollout_gru.argtypes = [P(Lanes), GruShape, P(C.c_float), C.c_uint64, P(C.c_float), P(C.c_uint8),
+                                           P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_int]
     L.oracle_seq_gae.argtypes = [C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_uint8),
                                  C.c_float, C.c_float, P(C.c_float), P(C.c_float)]
     L.oracle_seq_policy_dlogits_f32.argtypes = [C.c_uint64, P(C.c_float), P(C.c_uint8), P(C.c_float), P(C.c_float),
@@ -485,6 +489,21 @@ class LaneSim:
         lib().oracle_lanes_rollout(self.ptr, pshape, f32p(pparams), T, f32p(obs), u8p(action), f32p(reward),
                                    u8p(flag), f32p(term), threads)
         return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
+
+
+def _lanesim_rollout_gru(self, shape, params, T, threads=8):
+    n, D = self.n, self.D
+    obs = np.zeros((D, T + 1, n), dtype=np.float32)
+    action = np.zeros((T, n), dtype=np.uint8)
+    reward = np.zeros((T, n), dtype=np.float32)
+    flag = np.zeros((T, n), dtype=np.uint8)
+    term = np.zeros((D, T, n), dtype=np.float32)
+    lib().oracle_lanes_rollout_gru(self.ptr, shape, f32p(params), T, f32p(obs), u8p(action), f32p(reward), u8p(flag),
+                                   f32p(term), threads)
+    return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
+
+
+LaneSim.rollout_gru = _lanesim_rollout_gru
 
 
 def trpo_update(pshape, params, x, a, adv, cfg=None, f64=False):
@@ -770,6 +789,17 @@ class ChainLaneSim:
         term = np.zeros((self.D, self.n), dtype=np.float32)
         lib().oracle_chain_lanes_step(self.ptr, u8p(actions), f32p(reward), u8p(flag), f32p(obs), f32p(term))
         return reward, flag, obs, term
+
+    def rollout_mlp(self, shape, params, T):
+        n, D = self.n, self.D
+        obs = np.zeros((D, T + 1, n), dtype=np.float32)
+        action = np.zeros((T, n), dtype=np.uint8)
+        reward = np.zeros((T, n), dtype=np.float32)
+        flag = np.zeros((T, n), dtype=np.uint8)
+        term = np.zeros((D, T, n), dtype=np.float32)
+        lib().oracle_chain_lanes_rollout_mlp(self.ptr, shape, f32p(params), T, f32p(obs), u8p(action), f32p(reward),
+                                             u8p(flag), f32p(term))
+        return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
 
     def rollout_gru(self, shape, params, T, threads=8):
         n, D = self.n, self.D

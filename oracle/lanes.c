@@ -176,6 +176,48 @@ void oracle_lanes_rollout(oracle_lanes *l, oracle_mlp_shape ps, const float *pol
   l->t_global += T;
 }
 
+/* T env-actor steps of CartPole lanes with the recurrent policy (Chain<Gru, Mlp>::step, modules/chain.rs:175-186):
+ * as oracle_lanes_rollout, the actor's episode state restarting at zero at the start of the call and after every
+ * episode end. */
+void oracle_lanes_rollout_gru(oracle_lanes *l, oracle_gru_shape ps, const float *params, uint64_t T, float *obs,
+                              uint8_t *action, float *reward, uint8_t *flag, float *term_obs, int n_threads) {
+  uint32_t D = lanes_obs_dim(l);
+  uint64_t n = l->n_lanes;
+  (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads > 0 ? n_threads : 1) schedule(static)
+#endif
+  for (uint64_t i = 0; i < n; ++i) {
+    oracle_prng env_rng, act_rng;
+    lane_env_rng(l, i, &env_rng);
+    oracle_prng_seed_from_u64(&act_rng, l->seed_actor);
+    oracle_prng_set_stream(&act_rng, l->lane_offset + i);
+    oracle_prng_set_word_pos(&act_rng, l->t_global);
+    float f[5], tf[5], z[16], lp[16];
+    float *h = (float *)calloc(ps.hidden, sizeof(float));
+    for (uint64_t t = 0; t < T; ++t) {
+      oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
+      for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + t) * n + i] = f[d];
+      float u = oracle_prng_gen_f32(&act_rng);
+      oracle_gru_step_f32(ps, params, f, h, z);
+      oracle_log_softmax_f32(z, ps.out_dim, lp, 0);
+      int a = oracle_categorical_sample_u(lp, ps.out_dim, u, 0);
+      float r;
+      int succ = lane_step(l, i, a, &env_rng, &r, tf);
+      action[t * n + i] = (uint8_t)a;
+      reward[t * n + i] = r;
+      flag[t * n + i] = (uint8_t)succ;
+      if (succ == ORACLE_INTERRUPT && term_obs)
+        for (uint32_t d = 0; d < D; ++d) term_obs[(d * T + t) * n + i] = tf[d];
+      if (succ != ORACLE_CONTINUE) memset(h, 0, sizeof(float) * ps.hidden);
+    }
+    oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
+    for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + T) * n + i] = f[d];
+    free(h);
+  }
+  l->t_global += T;
+}
+
 /* Lane-major GAE and reward-to-go.  Same arithmetic as critics/mod.rs:158-199 + packed.rs:312-342
  * (delta = (r + gamma*V') - V with each op rounded; a = a + (b * discount)), applied along each lane;
  * an episode cut by the horizon is an Interrupt whose successor observation is obs[T]. */

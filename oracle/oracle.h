@@ -400,6 +400,10 @@ void oracle_chain_lanes_step(oracle_chain_lanes *l, const uint8_t *actions, floa
 void oracle_chain_lanes_rollout_gru(oracle_chain_lanes *l, oracle_gru_shape ps, const float *params, uint64_t T,
                                     float *obs, uint8_t *action, float *reward, uint8_t *flag, float *term_obs,
                                     int n_threads);
+void oracle_chain_lanes_rollout_mlp(oracle_chain_lanes *l, oracle_mlp_shape ps, const float *params, uint64_t T,
+                                    float *obs, uint8_t *action, float *reward, uint8_t *flag, float *term_obs);
+void oracle_lanes_rollout_gru(oracle_lanes *l, oracle_gru_shape ps, const float *params, uint64_t T, float *obs,
+                              uint8_t *action, float *reward, uint8_t *flag, float *term_obs, int n_threads);
 void oracle_seq_gae(uint64_t n, uint64_t T, const float *values, const float *succ_values, const float *reward,
                     const uint8_t *flag, float gamma, float lambda, float *adv_out, float *rtg_out);
 void oracle_seq_policy_dlogits_f32(uint64_t B, const float *logits, const uint8_t *actions, const float *adv,

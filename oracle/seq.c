@@ -249,6 +249,40 @@ void oracle_chain_lanes_rollout_gru(oracle_chain_lanes *l, oracle_gru_shape ps, 
   l->t_global += T;
 }
 
+/* T env-actor steps of Chain lanes with a feed-forward policy (PolicyActor::act over Mlp, policies/actor.rs:42-55) */
+void oracle_chain_lanes_rollout_mlp(oracle_chain_lanes *l, oracle_mlp_shape ps, const float *params, uint64_t T,
+                                    float *obs, uint8_t *action, float *reward, uint8_t *flag, float *term_obs) {
+  uint32_t D = oracle_chain_lanes_obs_dim(l);
+  uint64_t n = l->n_lanes;
+  for (uint64_t i = 0; i < n; ++i) {
+    oracle_prng env_rng, act_rng;
+    oracle_prng_seed_from_u64(&env_rng, l->seed_env);
+    oracle_prng_set_stream(&env_rng, l->lane_offset + i);
+    oracle_prng_seed_from_u64(&act_rng, l->seed_actor);
+    oracle_prng_set_stream(&act_rng, l->lane_offset + i);
+    oracle_prng_set_word_pos(&act_rng, l->t_global);
+    float f[16], tf[16], z[16], lp[16];
+    for (uint64_t t = 0; t < T; ++t) {
+      chain_features(l, i, f);
+      for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + t) * n + i] = f[d];
+      float u = oracle_prng_gen_f32(&act_rng);
+      oracle_mlp_forward_f32(ps, params, f, z);
+      oracle_log_softmax_f32(z, ps.out_dim, lp, 0);
+      int a = oracle_categorical_sample_u(lp, ps.out_dim, u, 0);
+      float r;
+      int succ = chain_lane_step(l, i, a, &env_rng, l->t_global + t, &r, tf);
+      action[t * n + i] = (uint8_t)a;
+      reward[t * n + i] = r;
+      flag[t * n + i] = (uint8_t)succ;
+      if (succ == ORACLE_INTERRUPT && term_obs)
+        for (uint32_t d = 0; d < D; ++d) term_obs[(d * T + t) * n + i] = tf[d];
+    }
+    chain_features(l, i, f);
+    for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + T) * n + i] = f[d];
+  }
+  l->t_global += T;
+}
+
 /* ------------------------------------------------------------------ GAE with a recurrent critic
  * values[t][lane] = V at obs[t]; succ_values[t][lane] = V of the successor observation where the episode is cut
  * (Interrupt or horizon), both from oracle_gru_seq_forward.  Same arithmetic as oracle_lanes_gae. */

@@ -1069,13 +1069,11 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
     if (policy->kind == RL_MODULE_GRU_MLP) {
-      if (env->kind != RL_ENV_CHAIN)
-        throw RlError(RL_ERR_UNSUPPORTED, "the recurrent rollout kernel is built for RL_ENV_CHAIN");
       seq_ensure(traj, policy, false);
-      launch_rollout_chain_gru(env, policy, traj);
+      launch_rollout_gru(env, policy, traj);
+    } else if (env->kind == RL_ENV_CHAIN) {
+      launch_rollout_chain_mlp(env, policy, traj);
     } else {
-      if (env->kind != RL_ENV_CARTPOLE)
-        throw RlError(RL_ERR_UNSUPPORTED, "the MLP rollout kernel is built for RL_ENV_CARTPOLE");
       launch_rollout(env, policy, traj);
     }
     env->t_global += traj->d.T;

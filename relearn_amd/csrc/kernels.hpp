@@ -61,7 +61,8 @@ void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_
 void launch_chain_reset(rl_env *env);
 void launch_chain_observe(rl_env *env, float *d_obs);
 void launch_chain_step(rl_env *env);
-void launch_rollout_chain_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj);
+void launch_rollout_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj);        // recurrent policy, either env kind
+void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj);  // feed-forward policy on Chain lanes
 // teacher-forced forward: d_out [A][T][n]; d_succ (may be NULL) [A][T][n]; d_act (may be NULL) activation record
 void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,
                             const int32_t *d_skip = nullptr);

@@ -90,6 +90,38 @@ __device__ __forceinline__ uint32_t stream_word(const uint32_t *key, uint64_t st
   return v;
 }
 
+// The env side of the fused rollouts, for both env kinds (the policy side is chosen by the kernel)
+struct ChainOps {
+  using State = ChainLane;
+  static __device__ __forceinline__ void load(const EnvStateDev &st, uint32_t i, State &s) { chain_load(st, i, s); }
+  static __device__ __forceinline__ void store(const EnvStateDev &st, uint32_t i, const State &s) { chain_store(st, i, s); }
+  template <int D>
+  static __device__ __forceinline__ void features(const CartPoleDev &c, const State &s, float (&f)[D]) {
+    chain_features<D>(c, s, f);
+  }
+  // Environment::step; the slip draw of global step `word` is word `word` of the lane's env stream
+  static __device__ __forceinline__ int step(const CartPoleDev &c, State &s, int a, uint64_t glane, uint64_t word,
+                                             float &reward) {
+    return chain_step(c, s, a, stream_word(c.key_env, glane, word), reward);
+  }
+  static __device__ __forceinline__ void reset(const CartPoleDev &c, State &s, uint64_t) { chain_reset(c, s); }
+};
+
+struct CartPoleOps {
+  using State = LaneState;
+  static __device__ __forceinline__ void load(const EnvStateDev &st, uint32_t i, State &s) { lane_load(st, i, s); }
+  static __device__ __forceinline__ void store(const EnvStateDev &st, uint32_t i, const State &s) { lane_store(st, i, s); }
+  template <int D>
+  static __device__ __forceinline__ void features(const CartPoleDev &c, const State &s, float (&f)[D]) {
+    cp_features<D>(c, s, f);
+  }
+  static __device__ __forceinline__ int step(const CartPoleDev &c, State &s, int a, uint64_t, uint64_t, float &reward) {
+    reward = 1.0f;  // CartPole::step (cartpole.rs:140)
+    return cp_step(c, s, a);
+  }
+  static __device__ __forceinline__ void reset(const CartPoleDev &c, State &s, uint64_t glane) { cp_reset(c, s, glane); }
+};
+
 __global__ void k_chain_reset(CartPoleDev c, EnvStateDev st, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -406,11 +438,11 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
   __syncthreads();
 }
 
-// ---------------------------------------------------------------- rollout (Chain env, recurrent policy)
+// ---------------------------------------------------------------- rollout (recurrent policy, either env kind)
 // PolicyActor::act over SeqIterative::step (policies/actor.rs:42-55; chain.rs:175-186) for T steps of every lane.
 // The episode state starts at zero at the beginning of the launch and after every episode end.
-template <int D>
-__global__ void __launch_bounds__(W16 * 64, 2) k_rollout_chain_gru(CartPoleDev c, EnvStateDev st, TrajDev tr,
+template <int D, class Env>
+__global__ void __launch_bounds__(W16 * 64, 2) k_rollout_gru(CartPoleDev c, EnvStateDev st, TrajDev tr,
                                                               const float *__restrict__ params, uint64_t t_global) {
   constexpr int A = 2;
   __shared__ SeqFwdShared sh;
@@ -431,12 +463,12 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_chain_gru(CartPoleDev c
   const bool env_lane = wave == 0 && lane < TL;
   const uint32_t i = lane0 + (uint32_t)lane;
   const uint64_t glane = c.lane_offset + i;
-  ChainLane s{0, 0, 0};
+  typename Env::State s{};
   const size_t plane = (size_t)(T + 1) * N;
   if (env_lane) {
-    chain_load(st, i, s);
+    Env::load(st, i, s);
     float f[D];
-    chain_features<D>(c, s, f);
+    Env::template features<D>(c, s, f);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       sh.xS[lane][d] = f[d];
@@ -455,19 +487,19 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_chain_gru(CartPoleDev c
       const float u = rl_u32_to_unit_f32(stream_word(c.key_actor, glane, word));
       const int a = categorical_sample_lane<2>(lp, u);
       float rew;
-      const int succ = chain_step(c, s, a, stream_word(c.key_env, glane, word), rew);
+      const int succ = Env::step(c, s, a, glane, word, rew);
       const size_t o = (size_t)t * N + i;
       tr.action[o] = (uint8_t)a;
       tr.reward[o] = rew;
       tr.flag[o] = (uint8_t)succ;
       float f[D];
       if (succ == RL_SUCC_INTERRUPT) {
-        chain_features<D>(c, s, f);
+        Env::template features<D>(c, s, f);
 #pragma unroll
         for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * N + o] = f[d];
       }
-      if (succ != RL_SUCC_CONTINUE) chain_reset(c, s);
-      chain_features<D>(c, s, f);
+      if (succ != RL_SUCC_CONTINUE) Env::reset(c, s, glane);
+      Env::template features<D>(c, s, f);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         sh.xS[lane][d] = f[d];
@@ -487,7 +519,52 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_chain_gru(CartPoleDev c
     __syncthreads();
     cur = nxt;
   }
-  if (env_lane) chain_store(st, i, s);
+  if (env_lane) Env::store(st, i, s);
+}
+
+// ---------------------------------------------------------------- rollout (Chain lanes, feed-forward policy)
+// k_rollout_cartpole's lane-per-thread loop (kernels_rollout.hip) over Chain: features -> in-lane MLP -> log-softmax
+// -> inverse-CDF sample with the lane's actor word -> Chain::step with the lane's env word -> step limit -> reset.
+template <int D, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_rollout_chain_mlp(CartPoleDev c, EnvStateDev st, TrajDev tr,
+                                                             const float *__restrict__ policy, int H,
+                                                             uint64_t t_global) {
+  const uint32_t n = tr.n, T = tr.T;
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t glane = c.lane_offset + i;
+  ChainLane s;
+  chain_load(st, i, s);
+  const size_t plane = (size_t)(T + 1) * n;
+  for (uint32_t t = 0; t < T; ++t) {
+    float f[D];
+    chain_features<D>(c, s, f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)t * n + i] = f[d];
+    const uint64_t word = t_global + t;
+    const float u = rl_u32_to_unit_f32(stream_word(c.key_actor, glane, word));
+    float z[2], lp[2];
+    mlp_forward_lane<D, 2>(policy, H, f, z);
+    log_softmax_lane<2>(z, lp);
+    const int a = categorical_sample_lane<2>(lp, u);
+    float rew;
+    const int succ = chain_step(c, s, a, stream_word(c.key_env, glane, word), rew);
+    const size_t o = (size_t)t * n + i;
+    tr.action[o] = (uint8_t)a;
+    tr.reward[o] = rew;
+    tr.flag[o] = (uint8_t)succ;
+    if (succ == RL_SUCC_INTERRUPT) {
+      chain_features<D>(c, s, f);
+#pragma unroll
+      for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * n + o] = f[d];
+    }
+    if (succ != RL_SUCC_CONTINUE) chain_reset(c, s);
+  }
+  float f[D];
+  chain_features<D>(c, s, f);
+#pragma unroll
+  for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)T * n + i] = f[d];
+  chain_store(st, i, s);
 }
 
 // ---------------------------------------------------------------- teacher-forced forward over a trajectory
@@ -669,12 +746,24 @@ void launch_chain_step(rl_env *env) {
                        env->t_global, env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs);
 }
 
-void launch_rollout_chain_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
+void launch_rollout_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
-  RL_REQUIRE(env->D == 5, "recurrent rollout: built for 5 observation features (Chain under a latent step limit)");
+  RL_REQUIRE(env->D == 5, "recurrent rollout: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;
-  hipLaunchKernelGGL(k_rollout_chain_gru<5>, dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev, env->st, traj->d,
-                     policy->d_params, env->t_global);
+  if (env->kind == RL_ENV_CHAIN)
+    hipLaunchKernelGGL((k_rollout_gru<5, ChainOps>), dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev, env->st,
+                       traj->d, policy->d_params, env->t_global);
+  else
+    hipLaunchKernelGGL((k_rollout_gru<5, CartPoleOps>), dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev,
+                       env->st, traj->d, policy->d_params, env->t_global);
+}
+
+void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
+  ProfScope ps(env->eng, RL_K_ROLLOUT);
+  RL_REQUIRE(env->D == 5, "Chain rollout: built for the 5 one-hot features (latent or no step limit)");
+  uint32_t n = (uint32_t)env->cfg.n_lanes;
+  hipLaunchKernelGGL((k_rollout_chain_mlp<5, 64>), dim3(cdiv_s(n, 64)), dim3(64), 0, env->eng->stream, env->dev, env->st,
+                     traj->d, policy->d_params, (int)policy->hidden, env->t_global);
 }
 
 void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,

@@ -333,3 +333,53 @@ def test_trpo_update_through_time(engine):
     assert abs(loss_d - st.loss_final) <= 1e-5 * max(1.0, abs(st.loss_final))
     assert abs(kl_d - st.constraint_val_final) <= 1e-5 + 1e-3 * kl_d
     assert np.abs(p1 - p0).max() > 0
+
+
+# ------------------------------------------------------------------ every env kind with every module kind
+def test_cartpole_lanes_with_the_recurrent_policy(engine):
+    n, T = 64, 40
+    env = ra.CartPoleEnv(engine, n, max_steps=25, seed_env=5, seed_actor=6)
+    sim = O.LaneSim(n, max_steps=25, seed_env=5, seed_actor=6)
+    pol = ra.GruMlp(engine, 5, 2)
+    pol.init(31)
+    traj = ra.Trajectory(engine, n, T, 5)
+    for period in range(2):
+        ra.rollout(env, pol, traj)
+        want = sim.rollout_gru(PS, pol.get_params(), T)
+        got = traj.read_all()
+        for k in ("obs", "action", "reward", "flag"):
+            assert np.array_equal(got[k], want[k]), (period, k)
+    assert (want["flag"] == O.TERMINATE).any() and (want["flag"] == O.INTERRUPT).any()
+    for a, b in zip(env.get_state(), sim.get_state()):
+        assert np.array_equal(a, b)
+    lo_d, _ = pol.seq_forward(traj, want_succ=False)
+    lo_o, _ = O.gru_seq_forward(PS, pol.get_params(), want, want_succ=False)
+    assert np.array_equal(lo_d, lo_o)
+    ra.reward_to_go(traj, 0.99)
+    cfg = ra.ppo_config_default()
+    cfg.opt_steps_per_update = 3
+    st, losses = ra.ppo_update(pol, ra.Adam(pol), traj, cfg, want_losses=True)
+    assert losses[-1] < losses[0]
+
+
+def test_chain_lanes_with_the_feed_forward_policy(engine):
+    n, T = 200, 45
+    ms, cs = O.MlpShape(5, 128, 2), O.MlpShape(5, 128, 1)
+    env, sim = chain_pair(engine, n, max_steps=9)
+    pol, cri = ra.Mlp(engine, 5, 128, 2), ra.Mlp(engine, 5, 128, 1)
+    pol.init(41)
+    cri.init(42)
+    traj = ra.Trajectory(engine, n, T, 5)
+    for period in range(2):
+        ra.rollout(env, pol, traj)
+        want = sim.rollout_mlp(ms, pol.get_params(), T)
+        got = traj.read_all()
+        for k in ("obs", "action", "reward", "flag"):
+            assert np.array_equal(got[k], want[k]), (period, k)
+        m = want["flag"] == O.INTERRUPT
+        assert m.any() and np.array_equal(got["term_obs"][:, m], want["term_obs"][:, m])
+    ra.gae(traj, cri, 0.95, 0.9)
+    v_o, adv_o, rtg_o = O.lanes_gae(cs, cri.get_params(), want, np.float32(0.95), np.float32(0.9))
+    assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), adv_o) and np.array_equal(traj.read(ra.TRAJ_RETURNS), rtg_o)
+    st = ra.trpo_update(pol, traj)
+    assert st.status == ra.OPT_OK and st.constraint_val_final <= 0.01 and st.loss_final < st.loss_initial
