@@ -160,7 +160,8 @@ int32_t rl_env_step(rl_env *env, const uint8_t *actions, float *reward_out, uint
 int32_t rl_env_upload_actions(rl_env *env, const uint8_t *actions);
 int32_t rl_env_step_resident(rl_env *env);
 /* raw lane state for parity tests: state4 [4][n] f64 (x, xdot, theta, thetadot), nv_pos[n] i32 (cached sign),
- * steps_remaining[n] u64, reset_count[n] u64 */
+ * steps_remaining[n] u64, reset_count[n] u64.  RL_ENV_CHAIN: state4[0][lane] holds the state index (exact in f64),
+ * the other state4 rows and nv_pos are unused */
 int32_t rl_env_get_state(rl_env *env, double *state4, int32_t *nv_pos, uint64_t *steps_remaining,
                          uint64_t *reset_count);
 int32_t rl_env_set_state(rl_env *env, const double *state4, const int32_t *nv_pos, const uint64_t *steps_remaining,

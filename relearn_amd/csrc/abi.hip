@@ -23,6 +23,11 @@ template <typename F>
 static int32_t guarded(rl_engine *eng, F &&f) {
   try {
     f();
+    if (eng != nullptr) {
+      // a kernel that could not be launched (bad configuration, out of resources) leaves only a sticky error behind
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) throw RlError(RL_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
+    }
     return RL_OK;
   } catch (const RlError &e) {
     (eng ? eng->last_error : g_last_error_no_engine) = e.what();
