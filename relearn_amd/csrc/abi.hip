@@ -1831,12 +1831,14 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     // take_while accepts episodes while total < minibatch_steps and every episode has >= 1 step
     q->max_eps = (uint32_t)cfg->minibatch_steps;
     q->max_steps_mb = cfg->minibatch_steps - 1 + cfg->buffer_capacity;
-    q->d_ep_lane = dalloc<uint32_t>(q->max_eps);
-    q->d_ep_start = dalloc<uint32_t>(q->max_eps);
-    q->d_ep_len = dalloc<uint32_t>(q->max_eps);
-    q->d_ep_off = dalloc<uint32_t>(q->max_eps);
-    q->d_counts = dalloc<DqnCountsDev>(1);
-    RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, sizeof(DqnCountsDev), e->stream));
+    // the episode lists of all opt_steps_per_update minibatches of an update are drawn in one launch
+    const size_t nb = cfg->opt_steps_per_update ? cfg->opt_steps_per_update : 1;
+    q->d_ep_lane = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_ep_start = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_ep_len = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_ep_off = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_counts = dalloc<DqnCountsDev>(nb);
+    RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, nb * sizeof(DqnCountsDev), e->stream));
     q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
     sync(e);
     e->live_handles += 1;
@@ -1925,50 +1927,84 @@ static AgentKey dqn_key(const rl_dqn *q) {
 }
 
 // one sample_minibatch (dqn.rs:279-314): draw episodes, gather them, compute targets
-static void dqn_sample_minibatch(rl_dqn *q, int sequential) {
+// draw the episode lists of `n_batches` consecutive minibatches (dqn.rs:280-291) in one launch and read back their
+// sizes: the draws do not depend on the network, so the whole update needs this one host round trip
+static void dqn_draw_minibatches(rl_dqn *q, int sequential, uint32_t n_batches, std::vector<DqnCountsDev> &counts,
+                                 std::vector<uint64_t> &totals) {
   rl_engine *e = q->eng;
   launch_dqn_sample(e, q->rp, dqn_key(q), q->d_agent_pos, (uint32_t)q->cfg.minibatch_steps, q->max_eps,
-                    q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, sequential);
-  DqnCountsDev c;
-  d2h(e, &c, q->d_counts, sizeof(c));
-  if (c.error == 2)
-    throw RlError(RL_ERR_INVALID_ARGUMENT, "minibatch sampling from a lane without a complete episode");
-  if (c.error != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full");
-  RL_REQUIRE(c.n_eps <= q->max_eps && c.n_steps <= q->max_steps_mb, "minibatch exceeds its workspace");
-  RL_REQUIRE(c.n_steps > 0, "empty minibatch");
+                    q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, sequential, n_batches);
+  counts.resize(n_batches);
+  d2h(e, counts.data(), q->d_counts, n_batches * sizeof(DqnCountsDev));
+  for (const DqnCountsDev &c : counts) {
+    if (c.error == 2)
+      throw RlError(RL_ERR_INVALID_ARGUMENT, "minibatch sampling from a lane without a complete episode");
+    if (c.error != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full");
+    RL_REQUIRE(c.n_eps <= q->max_eps && c.n_steps <= q->max_steps_mb, "minibatch exceeds its workspace");
+    RL_REQUIRE(c.n_steps > 0, "empty minibatch");
+  }
+  // the loss is a mean over all ranks' samples: sum the per-rank counts (two 16-bit halves each, exact in f32)
+  totals.resize(n_batches);
+  for (uint32_t k = 0; k < n_batches; ++k) totals[k] = counts[k].n_steps;
+  if (e->n_ranks > 1) {
+    std::vector<float> halves(2 * n_batches);
+    for (uint32_t k = 0; k < n_batches; ++k) {
+      halves[2 * k] = (float)(counts[k].n_steps & 0xffffu);
+      halves[2 * k + 1] = (float)(counts[k].n_steps >> 16);
+    }
+    RL_REQUIRE(2 * n_batches <= q->mb->Pmax, "too many minibatches for the exchange buffer");
+    h2d(e, q->mb->vec, halves.data(), halves.size() * sizeof(float));
+    rl_allreduce_sum_f32(e, q->mb->vec, halves.size());
+    d2h(e, halves.data(), q->mb->vec, halves.size() * sizeof(float));
+    for (uint32_t k = 0; k < n_batches; ++k) totals[k] = (uint64_t)halves[2 * k] + ((uint64_t)halves[2 * k + 1] << 16);
+  }
+}
+
+// gather minibatch `k` of the last draw and compute its targets (dqn.rs:293-314)
+static void dqn_build_minibatch(rl_dqn *q, uint32_t k, const DqnCountsDev &c, uint64_t total) {
   q->last_n_eps = c.n_eps;
   q->last_n_steps = c.n_steps;
-  // the loss is a mean over all ranks' samples: sum the per-rank counts (two 16-bit halves, exact in f32)
-  uint64_t total = c.n_steps;
-  if (e->n_ranks > 1) {
-    float halves[2] = {(float)(c.n_steps & 0xffffu), (float)(c.n_steps >> 16)};
-    h2d(e, q->mb->vec, halves, sizeof(halves));
-    rl_allreduce_sum_f32(e, q->mb->vec, 2);
-    d2h(e, halves, q->mb->vec, sizeof(halves));
-    total = (uint64_t)halves[0] + ((uint64_t)halves[1] << 16);
-  }
   q->last_total_steps = total;
+  q->last_batch_index = k;
   rl_traj *mb = q->mb;
   mb->d.n = c.n_steps;
   mb->d.T = 1;
   traj_plan(mb, c.n_steps);
-  launch_dqn_build_minibatch(e, q->rp, c.n_eps, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, mb->d.obs,
-                             (size_t)2 * c.n_steps, mb->d.action, mb->d.adv, q->cfg.discount_factor,
-                             q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD ? 1 : 0, q->qnet);
+  const size_t o = (size_t)k * q->max_eps;
+  launch_dqn_build_minibatch(q->eng, q->rp, c.n_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o,
+                             q->d_ep_off + o, mb->d.obs, (size_t)2 * c.n_steps, mb->d.action, mb->d.adv,
+                             q->cfg.discount_factor, q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD ? 1 : 0, q->qnet);
+}
+
+static void dqn_sample_minibatch(rl_dqn *q, int sequential) {
+  std::vector<DqnCountsDev> counts;
+  std::vector<uint64_t> totals;
+  dqn_draw_minibatches(q, sequential, 1, counts, totals);
+  dqn_build_minibatch(q, 0, counts[0], totals[0]);
 }
 
 // gradient of mean((Q(s)[a] - target)^2) over the current minibatch -> mb->vec[0..P), loss sum -> mb->vec[P]
-static void dqn_gradient(rl_dqn *q) {
+// `step_opt` != nullptr: also take the optimiser step, recording the loss in slot `loss_slot`; without an all-reduce
+// between them the reduction and the (elementwise) step are one launch
+static void dqn_gradient(rl_dqn *q, rl_adam *step_opt = nullptr, int loss_slot = -1) {
   rl_traj *mb = q->mb;
   uint32_t P = (uint32_t)q->qnet->P;
+  uint32_t rowsA, rowsB;
   if (q->eng->kernel_variant != 1 && launch_policy_v2(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr)) {
-    launch_reduce(mb, P, true, true, mb->nbV2, mb->nbV2);
+    rowsA = rowsB = mb->nbV2;
   } else {
     launch_policy_pass(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr);
     launch_mlp_backward(mb, q->qnet, nullptr);
-    launch_reduce(mb, P, true, true, mb->nbA, mb->nbB);
+    rowsA = mb->nbA;
+    rowsB = mb->nbB;
   }
+  if (step_opt && q->eng->comm == nullptr && q->eng->loopback == nullptr) {
+    launch_reduce_adam(mb, step_opt, rowsA, rowsB, loss_slot, q->last_total_steps);
+    return;
+  }
+  launch_reduce(mb, P, true, true, rowsA, rowsB);
   rl_allreduce_sum_f32(q->eng, mb->vec, P + 4);
+  if (step_opt) launch_adam_step(mb, step_opt, loss_slot, q->last_total_steps);
 }
 
 int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) {
@@ -1979,10 +2015,12 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
     // taken the same number of steps and the horizon rule drops none
     q->global_steps = q->steps_per_lane * (uint64_t)q->rp.N * (uint64_t)e->n_ranks;
     uint64_t K = q->cfg.opt_steps_per_update;
+    std::vector<DqnCountsDev> counts;
+    std::vector<uint64_t> totals;
+    if (K) dqn_draw_minibatches(q, 0, (uint32_t)K, counts, totals);
     for (uint64_t k = 0; k < K; ++k) {
-      dqn_sample_minibatch(q, 0);
-      dqn_gradient(q);
-      launch_adam_step(q->mb, q->opt, (int)k, q->last_total_steps);
+      dqn_build_minibatch(q, (uint32_t)k, counts[k], totals[k]);
+      dqn_gradient(q, q->opt, (int)k);
     }
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
@@ -2054,10 +2092,10 @@ int32_t rl_dqn_minibatch_read(rl_dqn *q, int32_t field, void *host, uint64_t byt
     RL_REQUIRE(ns > 0, "no minibatch has been sampled");
     rl_engine *e = q->eng;
     switch (field) {
-      case RL_MB_EP_LANE: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_lane, bytes); break;
-      case RL_MB_EP_START: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_start, bytes); break;
-      case RL_MB_EP_LEN: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_len, bytes); break;
-      case RL_MB_EP_OFFSET: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_off, bytes); break;
+      case RL_MB_EP_LANE: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_lane + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_EP_START: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_start + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_EP_LEN: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_len + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_EP_OFFSET: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_off + (size_t)q->last_batch_index * q->max_eps, bytes); break;
       case RL_MB_OBS: {
         RL_REQUIRE(bytes == D * ns * 4, "byte count mismatch");
         // feature planes are 2 * n_steps apart in the workspace (T = 1 trajectory layout)

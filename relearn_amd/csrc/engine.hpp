@@ -207,7 +207,7 @@ struct rl_dqn {
   rl_traj *mb = nullptr;             // minibatch workspace: T = 1, n = current minibatch size
   uint64_t global_steps = 0;         // as of the last update (dqn.rs:276)
   uint64_t steps_per_lane = 0;       // collected so far
-  uint32_t last_n_eps = 0, last_n_steps = 0;
+  uint32_t last_n_eps = 0, last_n_steps = 0, last_batch_index = 0;
   uint64_t last_total_steps = 0;     // minibatch size summed over ranks
 };
 

@@ -51,7 +51,8 @@ void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, ui
 struct AgentKey { uint32_t w[8]; };
 void launch_dqn_sample(rl_engine *eng, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
                        uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,
-                       uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential);
+                       uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential,
+                       uint32_t n_batches = 1);
 void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,
                                 const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                                 float *d_obs, size_t out_plane, uint8_t *d_action, float *d_target, float gamma,

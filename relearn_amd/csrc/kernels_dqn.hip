@@ -255,11 +255,16 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
                                                              uint32_t *__restrict__ ep_start,
                                                              uint32_t *__restrict__ ep_len,
                                                              uint32_t *__restrict__ ep_off, DqnCountsDev *counts,
-                                                             int sequential) {
+                                                             int sequential, uint32_t n_batches) {
   __shared__ uint32_t scan[SAMPLE_BLOCK];
   __shared__ int s_flag[2];  // [0] rejected draw in this chunk, [1] empty buffer
   const uint32_t tid = threadIdx.x;
-  const uint64_t pos0 = *agent_pos;
+  // `n_batches` consecutive minibatches in one launch (the draws of minibatch b + 1 continue where b stopped);
+  // minibatch b writes its lists at offset b * max_eps and its counts at counts[b]
+  for (uint32_t batch = 0; batch < n_batches; ++batch, ep_lane += max_eps, ep_start += max_eps, ep_len += max_eps,
+                ep_off += max_eps, ++counts) {
+  __syncthreads();  // the previous minibatch's final position is visible
+  const uint64_t pos0 = *(volatile uint64_t *)agent_pos;
   uint32_t total = 0;   // steps taken so far
   uint32_t n_eps = 0;   // episodes taken so far
   uint64_t draws = 0;   // u64 draws consumed so far
@@ -349,15 +354,17 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
     counts->n_steps = total;
     counts->error = err != 0 ? err : (*rp.error != 0 ? 1 : 0);
     counts->pad = 0;
+    __threadfence_block();
+  }
   }
 }
 
 void launch_dqn_sample(rl_engine *eng, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
                        uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,
-                       uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential) {
+                       uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential, uint32_t n_batches) {
   ProfScope ps(eng, RL_K_SMALL);
   hipLaunchKernelGGL(k_dqn_sample, dim3(1), dim3(SAMPLE_BLOCK), 0, eng->stream, rp, key, d_agent_pos,
-                     minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential);
+                     minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential, n_batches);
 }
 
 static inline uint32_t cdiv_d(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
