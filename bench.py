@@ -138,9 +138,13 @@ def main():
         last["critic"] = ra.critic_update(critic, opt, traj, args.critic_steps)
 
     def barrier():
+        # eng.sync() = hipStreamSynchronize(engine stream) + hipDeviceSynchronize(); torch.cuda.synchronize() is the
+        # same device-wide wait, spelled the way the bench contract does (torch is only imported for world > 1)
         eng.sync()
         if dist is not None:
+            torch.cuda.synchronize(local_rank)
             dist.barrier()
+            torch.cuda.synchronize(local_rank)
         eng.sync()
 
     for _ in range(args.warmup):

@@ -280,6 +280,9 @@ int32_t rl_engine_sync(rl_engine *e) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
     sync(e);
+    // also drain anything a collective library queued on streams of its own
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    RL_HIP_CHECK(hipDeviceSynchronize());
   });
 }
 

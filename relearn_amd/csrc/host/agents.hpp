@@ -9,7 +9,7 @@
 //   TrpoConfig / PpoConfig / ReinforceConfig   src/torch/agents/policies/{trpo,ppo,reinforce}.rs
 //   ValuesOptConfig / RewardToGoConfig       src/torch/agents/critics/{opt,rtg}.rs
 //   DqnConfig / DqnAgent                      src/torch/agents/dqn.rs:26-140,263-337
-//   StatsLogger (log_scalar / log_counter_increment / log_duration / with_scope)   src/logging/mod.rs:25-140
+//   StatsLogger, ChunkLogger, ByCounter / ByTime, Display / TensorBoard back ends   src/logging/ -> logging.hpp
 //   train_parallel's period loop and its metric names   src/simulation/train.rs:68-186
 #pragma once
 #include <chrono>
@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../../include/relearn_hip.h"
+#include "logging.hpp"
 
 namespace relearn {
 
@@ -49,45 +50,6 @@ inline void check(int32_t rc, const rl_engine *eng = nullptr) {
     case RL_ERR_NO_DEVICE: throw NoDeviceError(rc, msg);
     default: throw Error(rc, msg);
   }
-}
-
-// ---------------------------------------------------------------- logging (src/logging/mod.rs)
-class StatsLogger {
- public:
-  virtual ~StatsLogger() = default;
-  virtual void log_scalar(const std::string &id, double value) = 0;
-  virtual void log_counter_increment(const std::string &id, uint64_t increment) = 0;
-  virtual void log_duration(const std::string &id, double seconds) = 0;
-};
-
-// `logger.with_scope("policy")`: prepends "policy/" to every id
-class ScopedLogger : public StatsLogger {
- public:
-  ScopedLogger(StatsLogger &inner, std::string scope) : inner_(inner), prefix_(std::move(scope) + "/") {}
-  void log_scalar(const std::string &id, double v) override { inner_.log_scalar(prefix_ + id, v); }
-  void log_counter_increment(const std::string &id, uint64_t n) override { inner_.log_counter_increment(prefix_ + id, n); }
-  void log_duration(const std::string &id, double s) override { inner_.log_duration(prefix_ + id, s); }
-
- private:
-  StatsLogger &inner_;
-  std::string prefix_;
-};
-
-// keeps the last value of every scalar / duration and the running counters (tests, simple front ends)
-class RecordingLogger : public StatsLogger {
- public:
-  std::map<std::string, double> scalars, durations;
-  std::map<std::string, uint64_t> counters;
-  void log_scalar(const std::string &id, double v) override { scalars[id] = v; }
-  void log_counter_increment(const std::string &id, uint64_t n) override { counters[id] += n; }
-  void log_duration(const std::string &id, double s) override { durations[id] = s; }
-};
-
-template <typename F>
-auto log_elapsed(StatsLogger &logger, const std::string &id, F &&f) {  // StatsLogger::log_elapsed
-  const auto t0 = std::chrono::steady_clock::now();
-  f();
-  logger.log_duration(id, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 }
 
 // ---------------------------------------------------------------- engine + handles
