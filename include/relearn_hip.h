@@ -65,7 +65,7 @@ enum { RL_SUCC_CONTINUE = 0, RL_SUCC_TERMINATE = 1, RL_SUCC_INTERRUPT = 2 };
 enum { RL_OPT_OK = 0, RL_OPT_LOSS_NOT_IMPROVING = 1, RL_OPT_CONSTRAINT_VIOLATED = 2, RL_OPT_NAN_LOSS = 3,
        RL_OPT_NAN_CONSTRAINT = 4 };
 /* env kinds / step-limit wrappers (src/envs/cartpole.rs, chain.rs, wrappers/step_limit.rs:13,97) */
-enum { RL_ENV_CARTPOLE = 0, RL_ENV_CHAIN = 1 };
+enum { RL_ENV_CARTPOLE = 0, RL_ENV_CHAIN = 1, RL_ENV_MEMORY = 2 };
 enum { RL_LIMIT_NONE = 0, RL_LIMIT_LATENT = 1, RL_LIMIT_VISIBLE = 2 };
 
 typedef struct rl_engine rl_engine;
@@ -130,7 +130,8 @@ typedef struct {
 int32_t rl_cartpole_params_default(rl_cartpole_params *p);
 
 typedef struct {
-  int32_t kind;          /* RL_ENV_CARTPOLE | RL_ENV_CHAIN (Chain::default, src/envs/chain.rs:38-45: obs = one-hot(5)) */
+  int32_t kind;          /* RL_ENV_CARTPOLE | RL_ENV_CHAIN (Chain::default, src/envs/chain.rs:38-45: obs = one-hot(5)) |
+                          * RL_ENV_MEMORY (MemoryGame, src/envs/memory.rs:24-115: obs = one-hot(num_actions + history_len)) */
   int32_t limit_kind;    /* RL_LIMIT_* : `env.wrap(VisibleStepLimit::new(max_steps))` */
   uint64_t max_steps;    /* max_steps_per_episode (< 2^32) */
   uint64_t n_lanes;      /* lanes resident on THIS engine */
@@ -139,6 +140,11 @@ typedef struct {
   uint64_t seed_actor;   /* actor stream seed (the `rng_actor` of Steps) */
   rl_cartpole_params cartpole;
   uint64_t chain_size;   /* RL_ENV_CHAIN: number of states (Chain::default: 5; the kernels are built for 5); 0 = 5 */
+  /* RL_ENV_MEMORY: MemoryGame { num_actions, history_len } (memory.rs:24-40).  The device kernels are built for 2
+   * actions and 5 observation features, i.e. MemoryGame::new(2, 3); other sizes -> RL_ERR_BUILD_ENV (the scalar host
+   * env takes any).  0 / 0 = (2, 3).  Episodes last history_len + 1 steps; the only random draw is
+   * `gen_range(0..num_actions)` in initial_state, taken sequentially from the lane's env stream. */
+  uint64_t memory_num_actions, memory_history_len;
 } rl_env_config;
 
 int32_t rl_env_create(rl_engine *engine, const rl_env_config *cfg, rl_env **out);
@@ -160,7 +166,8 @@ int32_t rl_env_step(rl_env *env, const uint8_t *actions, float *reward_out, uint
 int32_t rl_env_upload_actions(rl_env *env, const uint8_t *actions);
 int32_t rl_env_step_resident(rl_env *env);
 /* raw lane state for parity tests: state4 [4][n] f64 (x, xdot, theta, thetadot), nv_pos[n] i32 (cached sign),
- * steps_remaining[n] u64, reset_count[n] u64.  RL_ENV_CHAIN: state4[0][lane] holds the state index (exact in f64),
+ * steps_remaining[n] u64, reset_count[n] u64.  RL_ENV_CHAIN / RL_ENV_MEMORY: state4[0][lane] holds the state index (exact
+ * in f64); RL_ENV_MEMORY: state4[1] the episode's initial state, state4[2] the word position of the lane's env stream;
  * the other state4 rows and nv_pos are unused */
 int32_t rl_env_get_state(rl_env *env, double *state4, int32_t *nv_pos, uint64_t *steps_remaining,
                          uint64_t *reset_count);

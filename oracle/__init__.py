@@ -94,11 +94,16 @@ class GruShape(C.Structure):
     _fields_ = [("in_dim", C.c_uint32), ("hidden", C.c_uint32), ("mlp_hidden", C.c_uint32), ("out_dim", C.c_uint32)]
 
 
+class MemoryGame(C.Structure):
+    _fields_ = [("num_actions", C.c_uint64), ("history_len", C.c_uint64), ("discount_factor", C.c_double)]
+
+
 class ChainLanes(C.Structure):
-    _fields_ = [("env", Chain), ("limit_kind", C.c_int), ("max_steps", C.c_uint64), ("seed_env", C.c_uint64),
-                ("seed_actor", C.c_uint64), ("n_lanes", C.c_uint64), ("lane_offset", C.c_uint64),
-                ("state", C.POINTER(C.c_uint64)), ("steps_remaining", C.POINTER(C.c_uint64)),
-                ("reset_count", C.POINTER(C.c_uint64)), ("t_global", C.c_uint64)]
+    _fields_ = [("env", Chain), ("memory", MemoryGame), ("limit_kind", C.c_int), ("max_steps", C.c_uint64),
+                ("seed_env", C.c_uint64), ("seed_actor", C.c_uint64), ("n_lanes", C.c_uint64),
+                ("lane_offset", C.c_uint64), ("state", C.POINTER(C.c_uint64)),
+                ("steps_remaining", C.POINTER(C.c_uint64)), ("reset_count", C.POINTER(C.c_uint64)),
+                ("initial", C.POINTER(C.c_uint64)), ("env_pos", C.POINTER(C.c_uint64)), ("t_global", C.c_uint64)]
 
 
 class Lanes(C.Structure):
@@ -333,6 +338,10 @@ def _declare(L):
     L.oracle_chain_lanes_new.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.c_uint64]
     L.oracle_chain_lanes_new.restype = P(ChainLanes)
+    L.oracle_memory_lanes_new.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                          C.c_uint64, C.c_uint64]
+    L.oracle_memory_lanes_new.restype = P(ChainLanes)
+    L.oracle_memory_lanes_get_extra.argtypes = [P(ChainLanes), P(C.c_uint64), P(C.c_uint64)]
     L.oracle_chain_lanes_free.argtypes = [P(ChainLanes)]
     L.oracle_chain_lanes_reset.argtypes = [P(ChainLanes)]
     L.oracle_chain_lanes_obs_dim.argtypes = [P(ChainLanes)]
@@ -811,3 +820,22 @@ class ChainLaneSim:
         lib().oracle_chain_lanes_rollout_gru(self.ptr, shape, f32p(params), T, f32p(obs), u8p(action), f32p(reward),
                                              u8p(flag), f32p(term), threads)
         return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
+
+
+class MemoryLaneSim(ChainLaneSim):
+    """MemoryGame lanes (src/envs/memory.rs): the shared index-env lane oracle with `memory.num_actions` set; the
+    initial-state draws come sequentially from each lane's env stream."""
+
+    def __init__(self, n_lanes, num_actions=2, history_len=3, max_steps=0, limit=LIMIT_NONE, lane_offset=0, seed_env=0,
+                 seed_actor=1):
+        self.ptr = lib().oracle_memory_lanes_new(num_actions, history_len, limit, max_steps, n_lanes, lane_offset,
+                                                 seed_env, seed_actor)
+        self.n = n_lanes
+        self.D = int(lib().oracle_chain_lanes_obs_dim(self.ptr))
+
+    def get_state(self):
+        """(current, initial, env word position, steps_remaining, reset_count)"""
+        cur, rem, rc = ChainLaneSim.get_state(self)
+        ini, pos = (np.zeros(self.n, dtype=np.uint64) for _ in range(2))
+        lib().oracle_memory_lanes_get_extra(self.ptr, u64p(ini), u64p(pos))
+        return cur, ini, pos, rem, rc

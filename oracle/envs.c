@@ -130,6 +130,30 @@ int oracle_chain_step(const oracle_chain *env, uint64_t *state, int action, orac
   return ORACLE_CONTINUE;
 }
 
+/* MemoryGame::default / initial_state / step (src/envs/memory.rs:33-40, 87-114) */
+void oracle_memory_default(oracle_memory *env) {
+  env->num_actions = 2;
+  env->history_len = 1;
+  env->discount_factor = 1.0;
+}
+
+void oracle_memory_initial_state(const oracle_memory *env, oracle_prng *rng, uint64_t *current, uint64_t *initial) {
+  uint64_t state = oracle_prng_gen_range_u64(rng, 0, env->num_actions); /* rng.gen_range(0..num_actions) */
+  *current = state;
+  *initial = state;
+}
+
+int oracle_memory_step(const oracle_memory *env, uint64_t *current, uint64_t initial, uint64_t action,
+                       double *reward) {
+  if (*current == env->num_actions + env->history_len - 1) {
+    *reward = action == initial ? 1.0 : -1.0;
+    return ORACLE_TERMINATE;
+  }
+  *current = *current < env->num_actions ? env->num_actions : *current + 1;
+  *reward = 0.0;
+  return ORACLE_CONTINUE;
+}
+
 /* Wrapped<E, {Latent,Visible}StepLimit>::step tail (wrappers/step_limit.rs:82-88, 216-222) */
 int oracle_step_limit_apply(int inner_successor, uint64_t *steps_remaining) {
   if (inner_successor == ORACLE_TERMINATE) return ORACLE_TERMINATE;

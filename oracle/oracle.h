@@ -80,6 +80,14 @@ typedef struct { uint64_t size; double discount_factor; } oracle_chain;
 void oracle_chain_default(oracle_chain *env);
 int oracle_chain_step(const oracle_chain *env, uint64_t *state, int action, oracle_prng *rng, double *reward);
 
+/* ---------------------------------------------------------------- MemoryGame (src/envs/memory.rs) */
+typedef struct { uint64_t num_actions, history_len; double discount_factor; } oracle_memory;
+void oracle_memory_default(oracle_memory *env);
+/* state = (current_state, initial_state) */
+void oracle_memory_initial_state(const oracle_memory *env, oracle_prng *rng, uint64_t *current, uint64_t *initial);
+int oracle_memory_step(const oracle_memory *env, uint64_t *current, uint64_t initial, uint64_t action,
+                       double *reward);
+
 /* ---------------------------------------------------------------- step limits (src/envs/wrappers/step_limit.rs) */
 enum { ORACLE_LIMIT_NONE = 0, ORACLE_LIMIT_LATENT = 1, ORACLE_LIMIT_VISIBLE = 2 };
 /* apply the wrapper's post-step rule: decrement, Continue -> Interrupt at 0 (step_limit.rs:216-222) */
@@ -380,13 +388,22 @@ void oracle_gru_seq_jvp_f32(oracle_gru_shape s, const float *params, const float
 void oracle_gru_seq_jvp_f64(oracle_gru_shape s, const double *params, const double *tangent, uint64_t n, uint64_t T,
                             const double *obs, const uint8_t *flag, double *out_dot);
 
+/* Lanes of an env with IndexSpace observations: Chain (`memory.num_actions == 0`) or MemoryGame.  MemoryGame lanes
+ * draw their initial states from the lane's env stream SEQUENTIALLY (`env_pos` = the stream's word position; the
+ * step itself draws nothing), exactly like one worker thread's env Prng in the reference. */
 typedef struct {
   oracle_chain env;
+  oracle_memory memory;
   int limit_kind;
   uint64_t max_steps, seed_env, seed_actor, n_lanes, lane_offset;
   uint64_t *state, *steps_remaining, *reset_count;
+  uint64_t *initial, *env_pos; /* MemoryGame only */
   uint64_t t_global;
 } oracle_chain_lanes;
+oracle_chain_lanes *oracle_memory_lanes_new(uint64_t num_actions, uint64_t history_len, int limit_kind,
+                                            uint64_t max_steps, uint64_t n_lanes, uint64_t lane_offset,
+                                            uint64_t seed_env, uint64_t seed_actor);
+void oracle_memory_lanes_get_extra(const oracle_chain_lanes *l, uint64_t *initial, uint64_t *env_pos);
 oracle_chain_lanes *oracle_chain_lanes_new(uint64_t size, int limit_kind, uint64_t max_steps, uint64_t n_lanes,
                                            uint64_t lane_offset, uint64_t seed_env, uint64_t seed_actor);
 void oracle_chain_lanes_free(oracle_chain_lanes *l);

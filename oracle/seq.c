@@ -120,6 +120,31 @@ oracle_chain_lanes *oracle_chain_lanes_new(uint64_t size, int limit_kind, uint64
   l->state = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
   l->steps_remaining = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
   l->reset_count = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->initial = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->env_pos = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  oracle_chain_lanes_reset(l);
+  return l;
+}
+
+oracle_chain_lanes *oracle_memory_lanes_new(uint64_t num_actions, uint64_t history_len, int limit_kind,
+                                            uint64_t max_steps, uint64_t n_lanes, uint64_t lane_offset,
+                                            uint64_t seed_env, uint64_t seed_actor) {
+  oracle_chain_lanes *l = (oracle_chain_lanes *)calloc(1, sizeof(*l));
+  oracle_memory_default(&l->memory);
+  l->memory.num_actions = num_actions;
+  l->memory.history_len = history_len;
+  l->env.size = num_actions + history_len; /* IndexSpace::new(num_actions + history_len), memory.rs:62-64 */
+  l->limit_kind = limit_kind;
+  l->max_steps = max_steps;
+  l->seed_env = seed_env;
+  l->seed_actor = seed_actor;
+  l->n_lanes = n_lanes;
+  l->lane_offset = lane_offset;
+  l->state = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->steps_remaining = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->reset_count = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->initial = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
+  l->env_pos = (uint64_t *)calloc(n_lanes, sizeof(uint64_t));
   oracle_chain_lanes_reset(l);
   return l;
 }
@@ -129,15 +154,34 @@ void oracle_chain_lanes_free(oracle_chain_lanes *l) {
   free(l->state);
   free(l->steps_remaining);
   free(l->reset_count);
+  free(l->initial);
+  free(l->env_pos);
   free(l);
 }
 
-void oracle_chain_lanes_reset(oracle_chain_lanes *l) {
-  for (uint64_t i = 0; i < l->n_lanes; ++i) {
+void oracle_memory_lanes_get_extra(const oracle_chain_lanes *l, uint64_t *initial, uint64_t *env_pos) {
+  memcpy(initial, l->initial, sizeof(uint64_t) * l->n_lanes);
+  memcpy(env_pos, l->env_pos, sizeof(uint64_t) * l->n_lanes);
+}
+
+/* a new episode in lane i */
+static void index_lane_reset(oracle_chain_lanes *l, uint64_t i) {
+  if (l->memory.num_actions) {
+    oracle_prng r;
+    oracle_prng_seed_from_u64(&r, l->seed_env);
+    oracle_prng_set_stream(&r, l->lane_offset + i);
+    oracle_prng_set_word_pos(&r, l->env_pos[i]);
+    oracle_memory_initial_state(&l->memory, &r, &l->state[i], &l->initial[i]);
+    l->env_pos[i] = oracle_prng_word_pos(&r);
+  } else {
     l->state[i] = 0; /* Chain::initial_state (chain.rs:75-77) draws nothing */
-    l->steps_remaining[i] = l->max_steps;
-    l->reset_count[i] += 1;
   }
+  l->steps_remaining[i] = l->max_steps;
+  l->reset_count[i] += 1;
+}
+
+void oracle_chain_lanes_reset(oracle_chain_lanes *l) {
+  for (uint64_t i = 0; i < l->n_lanes; ++i) index_lane_reset(l, i);
 }
 
 uint32_t oracle_chain_lanes_obs_dim(const oracle_chain_lanes *l) {
@@ -170,16 +214,17 @@ void oracle_chain_lanes_get_state(const oracle_chain_lanes *l, uint64_t *state, 
 static int chain_lane_step(oracle_chain_lanes *l, uint64_t i, int action, oracle_prng *env_rng, uint64_t word,
                            float *reward, float *term_f) {
   double r;
-  oracle_prng_set_word_pos(env_rng, word);
-  int succ = oracle_chain_step(&l->env, &l->state[i], action, env_rng, &r);
+  int succ;
+  if (l->memory.num_actions) {
+    succ = oracle_memory_step(&l->memory, &l->state[i], l->initial[i], (uint64_t)action, &r);
+  } else {
+    oracle_prng_set_word_pos(env_rng, word);
+    succ = oracle_chain_step(&l->env, &l->state[i], action, env_rng, &r);
+  }
   if (l->limit_kind != ORACLE_LIMIT_NONE) succ = oracle_step_limit_apply(succ, &l->steps_remaining[i]);
   *reward = (float)r;
   if (succ == ORACLE_INTERRUPT && term_f) chain_features(l, i, term_f);
-  if (succ != ORACLE_CONTINUE) {
-    l->state[i] = 0;
-    l->steps_remaining[i] = l->max_steps;
-    l->reset_count[i] += 1;
-  }
+  if (succ != ORACLE_CONTINUE) index_lane_reset(l, i);
   return succ;
 }
 

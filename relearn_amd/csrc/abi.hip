@@ -436,7 +436,12 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
   return guarded(e, [&] {
     RL_REQUIRE(e && cfg && out, "NULL argument");
     *out = nullptr;
-    if (cfg->kind != RL_ENV_CARTPOLE && cfg->kind != RL_ENV_CHAIN) throw RlError(RL_ERR_BUILD_ENV, "unknown env kind");
+    if (cfg->kind != RL_ENV_CARTPOLE && cfg->kind != RL_ENV_CHAIN && cfg->kind != RL_ENV_MEMORY)
+      throw RlError(RL_ERR_BUILD_ENV, "unknown env kind");
+    const uint64_t mem_actions = cfg->memory_num_actions ? cfg->memory_num_actions : 2;
+    const uint64_t mem_history = cfg->memory_num_actions || cfg->memory_history_len ? cfg->memory_history_len : 3;
+    if (cfg->kind == RL_ENV_MEMORY && !(mem_actions == 2 && mem_history == 3))
+      throw RlError(RL_ERR_BUILD_ENV, "the MemoryGame kernels are built for MemoryGame::new(2, 3) (5 observation features)");
     if (cfg->kind == RL_ENV_CHAIN && !(cfg->chain_size == 0 || cfg->chain_size == 5))
       throw RlError(RL_ERR_BUILD_ENV, "the Chain kernels are built for Chain::default (5 states)");
     if (cfg->limit_kind != RL_LIMIT_NONE && (cfg->max_steps == 0 || cfg->max_steps >= (1ull << 32)))
@@ -447,7 +452,7 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     env->eng = e;
     env->cfg = *cfg;
     env->kind = cfg->kind;
-    if (cfg->kind == RL_ENV_CHAIN)
+    if (cfg->kind == RL_ENV_CHAIN || cfg->kind == RL_ENV_MEMORY)
       env->D = 5 + (cfg->limit_kind == RL_LIMIT_VISIBLE ? 1 : 0);  // one-hot(5) [+ remaining]
     else
       env->D = cfg->limit_kind == RL_LIMIT_VISIBLE ? 5 : 4;
@@ -476,6 +481,7 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     d.max_steps = cfg->max_steps < (1ull << 32) ? (uint32_t)cfg->max_steps : 0u;
     d.limit_kind = cfg->limit_kind;
     d.chain_size = 5;
+    d.mem_actions = cfg->kind == RL_ENV_MEMORY ? (uint32_t)mem_actions : 0u;
     size_t n = cfg->n_lanes;
     env->st.x = dalloc<double>(n);
     env->st.xdot = dalloc<double>(n);
@@ -1079,7 +1085,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     if (policy->kind == RL_MODULE_GRU_MLP) {
       seq_ensure(traj, policy, false);
       launch_rollout_gru(env, policy, traj);
-    } else if (env->kind == RL_ENV_CHAIN) {
+    } else if (env->kind != RL_ENV_CARTPOLE) {
       launch_rollout_chain_mlp(env, policy, traj);
     } else {
       launch_rollout(env, policy, traj);
@@ -1612,7 +1618,7 @@ static void cbor_observation_space(cbor::Writer &w, const rl_env *env) {
   w.map(1);  // NonEmptyFeatures { inner } (spaces/nonempty_features.rs:20-25)
   w.key("inner");
   auto inner = [&]() {
-    if (env->kind == RL_ENV_CHAIN) {
+    if (env->kind != RL_ENV_CARTPOLE) {
       w.map(1);  // IndexSpace { size } (spaces/index.rs:19-22)
       w.key("size");
       w.uint(env->dev.chain_size);

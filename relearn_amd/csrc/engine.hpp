@@ -39,11 +39,13 @@ struct CartPoleDev {
   uint64_t lane_offset;
   uint32_t max_steps;
   int32_t limit_kind;
-  uint32_t chain_size;  // RL_ENV_CHAIN only (the common fields above are shared by both env kinds)
+  uint32_t chain_size;   // RL_ENV_CHAIN / RL_ENV_MEMORY: number of states = one-hot width
+  uint32_t mem_actions;  // RL_ENV_MEMORY: num_actions (0 selects Chain in the shared lane code)
 };
 
 struct EnvStateDev {
-  double *x, *xdot, *th, *thdot;  // [n]; RL_ENV_CHAIN keeps its state index in x (exact in f64)
+  double *x, *xdot, *th, *thdot;  // [n]; RL_ENV_CHAIN / RL_ENV_MEMORY keep their state index in x, MEMORY also its
+                                  // initial state in xdot and its env-stream word position in th (exact in f64)
   uint8_t *nv_pos;                // [n] cached_normal_velocity_is_positive
   uint32_t *steps_remaining;      // [n]
   uint32_t *reset_count;          // [n]

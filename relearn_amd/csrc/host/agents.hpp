@@ -161,6 +161,33 @@ class ChainLanes : public EnvLanes {
   }
 };
 
+// `MemoryGame::new(2, 3)` x n_lanes, optionally under a step limit (src/envs/memory.rs); discount factor 1.0
+class MemoryGameLanes : public EnvLanes {
+ public:
+  MemoryGameLanes(Engine &eng, uint64_t n_lanes, uint64_t num_actions = 2, uint64_t history_len = 3,
+                  uint64_t max_steps = 0, StepLimit limit = StepLimit::None, uint64_t seed_env = 0,
+                  uint64_t seed_actor = 1, uint64_t lane_offset = 0)
+      : EnvLanes(eng, config(n_lanes, num_actions, history_len, max_steps, limit, seed_env, seed_actor, lane_offset),
+                 1.0) {}
+
+ private:
+  static rl_env_config config(uint64_t n, uint64_t na, uint64_t hl, uint64_t max_steps, StepLimit limit, uint64_t se,
+                              uint64_t sa, uint64_t off) {
+    rl_env_config c{};
+    c.kind = RL_ENV_MEMORY;
+    c.limit_kind = (int32_t)limit;
+    c.max_steps = max_steps;
+    c.n_lanes = n;
+    c.lane_offset = off;
+    c.seed_env = se;
+    c.seed_actor = sa;
+    check(rl_cartpole_params_default(&c.cartpole));
+    c.memory_num_actions = na;
+    c.memory_history_len = hl;
+    return c;
+  }
+};
+
 // ---------------------------------------------------------------- modules (BuildModule)
 class Module {
  public:
@@ -207,6 +234,12 @@ struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mo
     return m;
   }
 };
+
+// The reference defines `pub type LstmMlpConfig = ChainConfig<GruConfig, MlpConfig>` (modules/mod.rs:15): its
+// "LSTM-MLP" configuration builds the GRU chain.  Kept as is, so that a configuration written against the reference
+// builds the same network here.  (The `Lstm` module itself, seq/rnn/lstm.rs, is not reachable from any agent
+// configuration of the reference and has no device implementation in this library.)
+using LstmMlpConfig = GruMlpConfig;
 
 struct AdamConfig {  // optimizers/coptimizer.rs:136-156
   double learning_rate = 1e-3, beta1 = 0.9, beta2 = 0.999, weight_decay = 0.0;

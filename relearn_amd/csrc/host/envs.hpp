@@ -58,6 +58,31 @@ struct Chain {
   }
 };
 
+// MemoryGame (src/envs/memory.rs:24-115): start in one of `num_actions` states at random, walk through `history_len`
+// further states whatever the action, then answer: +1 iff the action equals the initial state, else -1 (terminal)
+struct MemoryGame {
+  using State = std::pair<uint64_t, uint64_t>;  // (current_state, initial_state)
+  using Observation = uint64_t;
+  using Action = uint64_t;
+  uint64_t num_actions_ = 2, history_len = 1;  // MemoryGame::default
+  double discount_factor = 1.0;
+
+  MemoryGame() = default;
+  MemoryGame(uint64_t num_actions, uint64_t history) : num_actions_(num_actions), history_len(history) {}
+  uint64_t num_observations() const { return num_actions_ + history_len; }
+  uint64_t num_actions() const { return num_actions_; }
+  State initial_state(Prng &rng) const {
+    const uint64_t s = rng.gen_range(0, num_actions_);
+    return {s, s};
+  }
+  Observation observe(const State &s, Prng &) const { return s.first; }
+  std::pair<Successor<State>, double> step(State s, Action a, Prng &) const {
+    if (s.first == num_actions_ + history_len - 1) return {Successor<State>::Terminate(), a == s.second ? 1.0 : -1.0};
+    const uint64_t next = s.first < num_actions_ ? num_actions_ : s.first + 1;
+    return {Successor<State>::Continue({next, s.second}), 0.0};
+  }
+};
+
 // Wrapped<E, LatentStepLimit> (src/envs/wrappers/step_limit.rs:13-89): the limit is not observable
 template <typename E>
 struct WithLatentStepLimit {

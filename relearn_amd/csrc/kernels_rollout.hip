@@ -211,14 +211,14 @@ __global__ void __launch_bounds__(256) k_gae_scan(TrajDev tr, const float *__res
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
 void launch_env_reset(rl_env *env) {
-  if (env->kind == RL_ENV_CHAIN) return launch_chain_reset(env);
+  if (env->kind != RL_ENV_CARTPOLE) return launch_chain_reset(env);
   ProfScope ps(env->eng, RL_K_SMALL);
   uint32_t n = (uint32_t)env->cfg.n_lanes;
   hipLaunchKernelGGL(k_env_reset, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n);
 }
 
 void launch_env_observe(rl_env *env, float *d_obs) {
-  if (env->kind == RL_ENV_CHAIN) return launch_chain_observe(env, d_obs);
+  if (env->kind != RL_ENV_CARTPOLE) return launch_chain_observe(env, d_obs);
   ProfScope ps(env->eng, RL_K_SMALL);
   uint32_t n = (uint32_t)env->cfg.n_lanes;
   if (env->D == 5)
@@ -230,7 +230,7 @@ void launch_env_observe(rl_env *env, float *d_obs) {
 }
 
 void launch_env_step(rl_env *env) {
-  if (env->kind == RL_ENV_CHAIN) return launch_chain_step(env);
+  if (env->kind != RL_ENV_CARTPOLE) return launch_chain_step(env);
   ProfScope ps(env->eng, RL_K_ENV_STEP);
   uint32_t n = (uint32_t)env->cfg.n_lanes;
   if (env->D == 5)

@@ -29,19 +29,29 @@ constexpr int SEQ_ARR = 7;   // activation arrays per step: r, z, n, gh_n, h_pre
 constexpr int DPRE_ARR = 5;  // backward arrays per step: d pre_r, d pre_z, d pre_n, d pre_n * r, d u_pre
 enum { ACT_R = 0, ACT_Z = 1, ACT_N = 2, ACT_GHN = 3, ACT_HPREV = 4, ACT_A1 = 5, ACT_U = 6 };
 
-// ---------------------------------------------------------------- Chain lanes
+// ---------------------------------------------------------------- lanes of the IndexSpace-observation envs
+// Chain (chain.rs) and MemoryGame (memory.rs) share the lane code: `c.mem_actions` == 0 selects Chain (a launch-uniform
+// branch).  MemoryGame keeps (current_state, initial_state) and the word position of the lane's env stream: its only
+// random draw is `rng.gen_range(0..num_actions)` in initial_state, taken SEQUENTIALLY from the lane's stream like one
+// worker's env Prng in the reference (a rejection loop, so the number of words per reset is not fixed).
 struct ChainLane {
   uint32_t state, steps_remaining, reset_count;
+  uint32_t initial;   // MemoryGame: the state the episode started in
+  uint64_t env_pos;   // MemoryGame: next unread word of the lane's env stream (always even: u64 draws only)
 };
 
 __device__ __forceinline__ void chain_load(const EnvStateDev &st, uint32_t i, ChainLane &s) {
   s.state = (uint32_t)st.x[i];
+  s.initial = (uint32_t)st.xdot[i];
+  s.env_pos = (uint64_t)st.th[i];
   s.steps_remaining = st.steps_remaining[i];
   s.reset_count = st.reset_count[i];
 }
 
 __device__ __forceinline__ void chain_store(const EnvStateDev &st, uint32_t i, const ChainLane &s) {
   st.x[i] = (double)s.state;
+  st.xdot[i] = (double)s.initial;
+  st.th[i] = (double)s.env_pos;  // exact below 2^53 words
   st.steps_remaining[i] = s.steps_remaining;
   st.reset_count[i] = s.reset_count;
 }
@@ -54,24 +64,63 @@ __device__ __forceinline__ void chain_features(const CartPoleDev &c, const Chain
   if (D == 6) f[5] = (float)((double)s.steps_remaining / (double)c.max_steps);
 }
 
-__device__ __forceinline__ void chain_reset(const CartPoleDev &c, ChainLane &s) {
-  s.state = 0;  // Chain::initial_state (chain.rs:75-77), no random draw
+// rand 0.8.5 `gen_range(0..range)` for u64/usize (UniformInt::sample_single): widening multiply, accept when the low
+// half is inside the zone `(range << leading_zeros(range)) - 1`; every attempt reads one u64 = stream words
+// (pos, pos + 1), low word first.  The loop ends with probability 1; 64 attempts bound it (each fails w.p. <= 1/2).
+__device__ __forceinline__ uint32_t lane_gen_range(const uint32_t *key, uint64_t glane, uint64_t &pos, uint64_t range) {
+  const uint64_t zone = (range << __clzll((long long)range)) - 1;
+  uint64_t hi = 0;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    uint32_t w[16];
+    rl_chacha_block(key, pos >> 4, glane, 4, w);
+    uint32_t lo32 = 0, hi32 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2)
+      if (k == (int)(pos & 15)) {
+        lo32 = w[k];
+        hi32 = w[k + 1];
+      }
+    pos += 2;
+    const uint64_t v = ((uint64_t)hi32 << 32) | lo32;
+    hi = __umul64hi(v, range);
+    if (v * range <= zone) break;
+  }
+  return (uint32_t)hi;
+}
+
+__device__ __forceinline__ void chain_reset(const CartPoleDev &c, ChainLane &s, uint64_t glane) {
+  if (c.mem_actions) {  // MemoryGame::initial_state (memory.rs:87-90)
+    s.state = lane_gen_range(c.key_env, glane, s.env_pos, c.mem_actions);
+    s.initial = s.state;
+  } else {
+    s.state = 0;  // Chain::initial_state (chain.rs:75-77), no random draw
+  }
   s.steps_remaining = c.max_steps;
   s.reset_count += 1;
 }
 
-// Chain::step (chain.rs:83-105) + the step-limit tail; `word` is the lane's env-stream word for this global step
+// Chain::step (chain.rs:83-105) / MemoryGame::step (memory.rs:96-114) + the step-limit tail; `word` is the lane's
+// env-stream word for this global step (Chain's slip draw)
 __device__ __forceinline__ int chain_step(const CartPoleDev &c, ChainLane &s, int action, uint32_t word,
                                           float &reward) {
-  if (rl_u32_to_unit_f32(word) < 0.2f) action = 1 - action;  // Move::invert
-  if (action == 0) {  // Move::Left
-    s.state = 0;
-    reward = 2.0f;
-  } else if (s.state == c.chain_size - 1) {
-    reward = 10.0f;
-  } else {
-    s.state += 1;
+  if (c.mem_actions) {
+    if (s.state == c.chain_size - 1) {  // the last of num_actions + history_len states: the answer step
+      reward = (uint32_t)action == s.initial ? 1.0f : -1.0f;
+      return RL_SUCC_TERMINATE;  // passes through the step limit untouched (step_limit.rs:216-222)
+    }
+    s.state = s.state < c.mem_actions ? c.mem_actions : s.state + 1;
     reward = 0.0f;
+  } else {
+    if (rl_u32_to_unit_f32(word) < 0.2f) action = 1 - action;  // Move::invert
+    if (action == 0) {  // Move::Left
+      s.state = 0;
+      reward = 2.0f;
+    } else if (s.state == c.chain_size - 1) {
+      reward = 10.0f;
+    } else {
+      s.state += 1;
+      reward = 0.0f;
+    }
   }
   if (c.limit_kind != RL_LIMIT_NONE) {
     s.steps_remaining -= 1;
@@ -104,7 +153,7 @@ struct ChainOps {
                                              float &reward) {
     return chain_step(c, s, a, stream_word(c.key_env, glane, word), reward);
   }
-  static __device__ __forceinline__ void reset(const CartPoleDev &c, State &s, uint64_t) { chain_reset(c, s); }
+  static __device__ __forceinline__ void reset(const CartPoleDev &c, State &s, uint64_t glane) { chain_reset(c, s, glane); }
 };
 
 struct CartPoleOps {
@@ -126,8 +175,8 @@ __global__ void k_chain_reset(CartPoleDev c, EnvStateDev st, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   ChainLane s;
-  s.reset_count = st.reset_count[i];
-  chain_reset(c, s);
+  chain_load(st, i, s);
+  chain_reset(c, s, c.lane_offset + i);
   chain_store(st, i, s);
 }
 
@@ -160,7 +209,7 @@ __global__ void __launch_bounds__(256) k_chain_step(CartPoleDev c, EnvStateDev s
 #pragma unroll
     for (int d = 0; d < D; ++d) term_obs[(size_t)d * n + i] = f[d];
   }
-  if (succ != RL_SUCC_CONTINUE) chain_reset(c, s);
+  if (succ != RL_SUCC_CONTINUE) chain_reset(c, s, c.lane_offset + i);
   chain_features<D>(c, s, f);
 #pragma unroll
   for (int d = 0; d < D; ++d) obs_next[(size_t)d * n + i] = f[d];
@@ -558,7 +607,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_chain_mlp(CartPoleDev c, EnvS
 #pragma unroll
       for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * n + o] = f[d];
     }
-    if (succ != RL_SUCC_CONTINUE) chain_reset(c, s);
+    if (succ != RL_SUCC_CONTINUE) chain_reset(c, s, glane);
   }
   float f[D];
   chain_features<D>(c, s, f);
@@ -750,7 +799,7 @@ void launch_rollout_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
   RL_REQUIRE(env->D == 5, "recurrent rollout: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;
-  if (env->kind == RL_ENV_CHAIN)
+  if (env->kind != RL_ENV_CARTPOLE)
     hipLaunchKernelGGL((k_rollout_gru<5, ChainOps>), dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev, env->st,
                        traj->d, policy->d_params, env->t_global);
   else

@@ -63,6 +63,16 @@ int main() {
       train_batched(*agent, env, history, 1, log);
       dump("ppo_gru", log, checksum(agent->policy_module().parameters()), checksum(agent->critic_module()->parameters()), false);
     }
+    {  // PPO with the critic-free reward-to-go advantage on MemoryGame lanes; `LstmMlpConfig` as the reference defines it
+      MemoryGameLanes env(eng, 64, 2, 3, 0, StepLimit::None, 5, 6);
+      ActorCriticConfig<PpoConfig<LstmMlpConfig>, RewardToGoConfig> cfg;
+      cfg.policy_config.opt_steps_per_update = 2;
+      auto agent = cfg.build_agent(env, 13);
+      DeviceHistory history = agent->buffer(24);
+      RecordingLogger log;
+      train_batched(*agent, env, history, 1, log);
+      dump("ppo_memory", log, checksum(agent->policy_module().parameters()), 0.0, false);
+    }
     {  // examples/cartpole-dqn.rs, shrunk
       CartPoleLanes env(eng, 128, 500, StepLimit::Visible, 0, 1);
       DqnConfig<MlpConfig> cfg;

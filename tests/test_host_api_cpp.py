@@ -84,6 +84,19 @@ def test_cpp_host_api_matches_the_ctypes_path(engine):
     g = out["ppo_gru"]
     assert g["policy_checksum"] == checksum(gp.get_params()) and g["critic_checksum"] == checksum(gc.get_params())
     assert g["scalars"]["policy/entropy"] == ps.entropy and g["scalars"]["critic/loss"] == gcs.loss_last
+    # ---- PPO + reward-to-go on MemoryGame lanes (discount factor 1.0: memory.rs:74-76)
+    menv = ra.MemoryEnv(engine, 64, seed_env=5, seed_actor=6)
+    mp = ra.GruMlp(engine, 5, 2)
+    mp.init(13)
+    mtraj = ra.Trajectory(engine, 64, 24, 5)
+    ra.rollout(menv, mp, mtraj)
+    ra.reward_to_go(mtraj, 1.0)  # RewardToGo uses the env's own discount factor (critics/rtg.rs:14-20)
+    mcfg = ra.ppo_config_default()
+    mcfg.opt_steps_per_update = 2
+    ms = ra.ppo_update(mp, ra.Adam(mp), mtraj, mcfg)
+    g = out["ppo_memory"]
+    assert g["policy_checksum"] == checksum(mp.get_params()) and g["scalars"]["policy/entropy"] == ms.entropy
+    assert g["counters"]["sim/ep/count"] == 64 * 6 and g["counters"]["sim/step/count"] == 64 * 24
     # ---- examples/cartpole-dqn.rs shape
     denv = ra.CartPoleEnv(engine, 128, max_steps=500, seed_env=0, seed_actor=1)
     q = ra.Mlp(engine, 5, 128, 2)
