@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--critic-steps", type=int, default=80)
     ap.add_argument("--max-episode-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=("rccl", "gloo"), default=os.environ.get("RELEARN_BENCH_COMM", "rccl"),
+                    help="data-plane collective for N > 1: RCCL on the engine stream (default), or the host-staged "
+                         "fallback over the gloo control group (also taken when RCCL cannot be initialised)")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="do not wrap launches in HIP events inside the timed region")
     ap.add_argument("--profile-steps", type=int, default=1,
@@ -112,11 +115,40 @@ def main():
     n_local = args.envs // world
     T, H = args.horizon, args.hidden
 
-    eng = ra.Engine(local_rank)
+    # one process per GPU; RELEARN_BENCH_SINGLE_DEVICE=1 puts every rank on device 0 (a rehearsal of the multi-process
+    # path on a one-GPU box, only meaningful with --comm gloo: RCCL refuses two ranks on one device)
+    device = 0 if os.environ.get("RELEARN_BENCH_SINGLE_DEVICE") else local_rank
+    eng = ra.Engine(device)
+    comm_kind = "none"
     if world > 1:
-        ids = [ra.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(rank, world, ids[0])
+        comm_kind = args.comm
+        if comm_kind == "rccl":
+            # single-node job: RCCL's bootstrap sockets may use the loopback interface (the box may have no other)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            ok, ids = 1, [None]
+            if rank == 0:
+                try:
+                    ids = [ra.comm_unique_id()]
+                except ra.RelearnError as exc:
+                    print("bench.py: RCCL unavailable (%s)" % exc, file=sys.stderr)
+            dist.broadcast_object_list(ids, src=0)
+            if ids[0] is None:
+                ok = 0
+            else:
+                try:
+                    eng.comm_init(rank, world, ids[0])
+                except ra.RelearnError as exc:
+                    print("bench.py: rank %d: RCCL communicator not created (%s)" % (rank, exc), file=sys.stderr)
+                    ok = 0
+            agreed = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)  # every rank takes the same path
+            if int(agreed.item()) == 0:
+                eng.comm_destroy()
+                comm_kind = "gloo"
+                if rank == 0:
+                    print("bench.py: falling back to the host-staged collective over gloo", file=sys.stderr)
+        if comm_kind == "gloo":
+            eng.comm_init_host(rank, world, lambda a: dist.all_reduce(torch.from_numpy(a)))
 
     env = ra.CartPoleEnv(eng, n_local, max_steps=args.max_episode_steps, limit=ra.LIMIT_VISIBLE,
                          lane_offset=rank * n_local, seed_env=0, seed_actor=1)
@@ -142,9 +174,9 @@ def main():
         # same device-wide wait, spelled the way the bench contract does (torch is only imported for world > 1)
         eng.sync()
         if dist is not None:
-            torch.cuda.synchronize(local_rank)
+            torch.cuda.synchronize(device)
             dist.barrier()
-            torch.cuda.synchronize(local_rank)
+            torch.cuda.synchronize(device)
         eng.sync()
 
     for _ in range(args.warmup):
@@ -287,7 +319,9 @@ def main():
                             "5-%d-1, CG 10, <=15 backtracks, %d Adam critic steps per period" % (
                                 args.max_episode_steps, args.envs, T, H, H, args.critic_steps),
                 "n_envs_total": args.envs, "n_envs_per_gpu": n_local, "horizon": T, "hidden": H,
-                "critic_steps": args.critic_steps, "parallelism": "env-sharded x%d + RCCL all-reduce" % world,
+                "critic_steps": args.critic_steps,
+                "parallelism": "env-sharded x%d + %s" % (world, {"none": "no collective (one rank)", "rccl": "RCCL all-reduce",
+                                                               "gloo": "host-staged all-reduce over gloo (fallback)"}[comm_kind]),
             },
             "roofline": roofline,
             "roofline_policy": roofline_policy,

@@ -116,6 +116,13 @@ int32_t rl_profile_read(rl_engine *engine, double *total_ms_out /*[RL_K_CLASS_CO
 int32_t rl_comm_unique_id(uint8_t id_out[128]);
 int32_t rl_comm_init(rl_engine *engine, int32_t rank, int32_t n_ranks, const uint8_t unique_id[128]);
 int32_t rl_comm_destroy(rl_engine *engine);
+/* Host-staged collective for machines (or tests) without a usable RCCL communicator: for every all-reduce the library
+ * copies the vector to the host, calls `fn(ctx, buf, count)` — which must sum `buf` element-wise over all ranks in place
+ * (a gloo / MPI all-reduce, for instance) and return 0 — and copies the result back.  Same arithmetic contract as
+ * rl_comm_init (sample-weighted means over all ranks, identical redundant updates); two PCIe hops and one host
+ * collective per call, so it is a fallback, not the fast path.  Undone by rl_comm_destroy. */
+typedef int32_t (*rl_host_allreduce_fn)(void *ctx, float *buf, uint64_t count);
+int32_t rl_comm_init_host(rl_engine *engine, int32_t rank, int32_t n_ranks, rl_host_allreduce_fn fn, void *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * Environments.  Mirrors `Environment::{initial_state, observe, step}` (src/envs/mod.rs:76-127) for N

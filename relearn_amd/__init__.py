@@ -35,7 +35,7 @@ KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backwa
 ABI_SYMBOLS = [
     "rl_abi_version", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
     "rl_last_error", "rl_engine_info", "rl_engine_set_kernel_variant", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
-    "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy",
+    "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy", "rl_comm_init_host",
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
@@ -53,6 +53,9 @@ ABI_SYMBOLS = [
     "rl_dqn_minibatch_sample", "rl_dqn_minibatch_read", "rl_dqn_minibatch_gradient", "rl_dqn_agent_rng_pos",
     "rl_chain_tabular_q_train", "rl_chain_tabular_q_eval",
 ]
+
+
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.c_uint64)
 
 
 class RelearnError(RuntimeError):
@@ -204,6 +207,25 @@ class Engine(_Handle):
     def comm_init(self, rank, n_ranks, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         _check(lib().rl_comm_init(self.h, C.c_int32(rank), C.c_int32(n_ranks), buf), self.h)
+
+    def comm_destroy(self):
+        _check(lib().rl_comm_destroy(self.h), self.h)
+        self._host_allreduce = None
+
+    def comm_init_host(self, rank, n_ranks, allreduce):
+        """Host-staged collective (rl_comm_init_host): `allreduce(array)` must sum the float32 numpy array over all ranks
+        in place, e.g. `lambda a: dist.all_reduce(torch.from_numpy(a))` on a gloo group."""
+        def thunk(_ctx, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_allreduce = HOST_ALLREDUCE_FN(thunk)  # keep the callback object alive
+        _check(lib().rl_comm_init_host(self.h, C.c_int32(rank), C.c_int32(n_ranks), self._host_allreduce, None),
+               self.h)
 
 
 def comm_unique_id():

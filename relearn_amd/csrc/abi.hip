@@ -188,6 +188,19 @@ void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
     loopback_allreduce(e, d_buf, count);
     return;
   }
+  if (e->host_allreduce) {
+    ProfScope ps(e, RL_K_ALLREDUCE);
+    e->host_allreduce_buf.resize(count);
+    RL_HIP_CHECK(hipMemcpyAsync(e->host_allreduce_buf.data(), d_buf, count * sizeof(float), hipMemcpyDeviceToHost,
+                                e->stream));
+    RL_HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->host_allreduce(e->host_allreduce_ctx, e->host_allreduce_buf.data(), count) != 0)
+      throw RlError(RL_ERR_COMM, "the host all-reduce callback failed");
+    RL_HIP_CHECK(hipMemcpyAsync(d_buf, e->host_allreduce_buf.data(), count * sizeof(float), hipMemcpyHostToDevice,
+                                e->stream));
+    RL_HIP_CHECK(hipStreamSynchronize(e->stream));
+    return;
+  }
   if (!e->comm) return;
   ProfScope ps(e, RL_K_ALLREDUCE);
   // ncclFloat32 = 7, ncclSum = 0
@@ -367,7 +380,7 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
   return guarded(e, [&] {
     RL_REQUIRE(e && unique_id, "NULL argument");
     RL_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
-    RL_REQUIRE(!e->comm, "communicator already initialised");
+    RL_REQUIRE(!e->has_collective(), "communicator already initialised");
     e->rank = rank;
     e->n_ranks = n_ranks;
     // a single rank needs no communicator; RELEARN_FORCE_RCCL=1 creates a 1-rank one anyway so that the whole
@@ -399,9 +412,23 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
   });
 }
 
+int32_t rl_comm_init_host(rl_engine *e, int32_t rank, int32_t n_ranks, rl_host_allreduce_fn fn, void *ctx) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && fn, "NULL argument");
+    RL_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
+    RL_REQUIRE(!e->has_collective(), "communicator already initialised");
+    e->rank = rank;
+    e->n_ranks = n_ranks;
+    e->host_allreduce = fn;
+    e->host_allreduce_ctx = ctx;
+  });
+}
+
 int32_t rl_comm_destroy(rl_engine *e) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
+    e->host_allreduce = nullptr;
+    e->host_allreduce_ctx = nullptr;
     if (e->comm) {
       sync(e);
       rccl_check(g_rccl.CommDestroy(e->comm), "ncclCommDestroy");
@@ -1407,7 +1434,7 @@ int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t o
     RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
     RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
     uint64_t Bt = b_total(traj);
-    const bool fused = critic->kind == RL_MODULE_MLP && traj->eng->comm == nullptr && traj->eng->loopback == nullptr;
+    const bool fused = critic->kind == RL_MODULE_MLP && !traj->eng->has_collective();
     for (uint64_t k = 0; k < opt_steps; ++k) {
       if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
         uint32_t rowsA, rowsB;
@@ -2007,7 +2034,7 @@ static void dqn_gradient(rl_dqn *q, rl_adam *step_opt = nullptr, int loss_slot =
     rowsA = mb->nbA;
     rowsB = mb->nbB;
   }
-  if (step_opt && q->eng->comm == nullptr && q->eng->loopback == nullptr) {
+  if (step_opt && !q->eng->has_collective()) {
     launch_reduce_adam(mb, step_opt, rowsA, rowsB, loss_slot, q->last_total_steps);
     return;
   }

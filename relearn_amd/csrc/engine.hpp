@@ -118,6 +118,11 @@ struct rl_engine {
   // comm
   void *comm = nullptr;  // ncclComm_t
   struct LoopbackGroup *loopback = nullptr;  // in-process test collective (RELEARN_LOOPBACK_COMM=1)
+  rl_host_allreduce_fn host_allreduce = nullptr;  // host-staged collective (rl_comm_init_host)
+  void *host_allreduce_ctx = nullptr;
+  std::vector<float> host_allreduce_buf;
+  // any collective between a reduction and its consumer?  (false: the two may be fused into one launch)
+  bool has_collective() const { return comm != nullptr || loopback != nullptr || host_allreduce != nullptr; }
   int rank = 0, n_ranks = 1;
   // host pinned scratch for small readbacks
   void *pinned = nullptr;

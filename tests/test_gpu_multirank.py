@@ -113,3 +113,55 @@ def test_two_ranks_equal_one_rank():
     assert np.array_equal(double[0]["dqn"]["q"], double[1]["dqn"]["q"])
     assert double[0]["dqn"]["global_steps"] == single["dqn"]["global_steps"] == 60 * n_total
     assert np.all(np.isfinite(double[0]["dqn"]["losses"]))
+
+
+def run_bench(world, extra_env=None):
+    """bench.py exactly as the driver launches it (torch.distributed.run, one process per rank), on a small workload"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--envs", "2048", "--horizon", "32",
+            "--critic-steps", "5", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    if world == 1:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py")] + args
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()  # rank 0 prints ONE JSON line
+    res = json.loads(lines[0])
+    res["_stderr"] = out.stderr.decode()
+    return res
+
+
+def test_bench_as_two_processes_over_the_host_collective():
+    """The multi-process launch path of bench.py — RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, gloo control
+    group, lane sharding, barriers, max-over-ranks timing, one JSON line — rehearsed with two processes on this box's
+    one GPU.  RCCL refuses two ranks on one device, so the data-plane collective is the library's host-staged one
+    (rl_comm_init_host over the same gloo group); the RCCL call path itself is covered by the one-rank communicator test.
+    The sharded job must report the same update statistics as the one-process job (same samples, other sum order)."""
+    one = run_bench(1)
+    two = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "gloo"})
+    assert two["n_gpus"] == 2 and two["config"]["n_envs_per_gpu"] == 1024 and two["config"]["n_envs_total"] == 2048
+    assert "gloo" in two["config"]["parallelism"] and two["cpu_baseline"] is None
+    assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] * 1e-3 - 2048 * 32) < 1e-6 * 2048 * 32
+    assert two["phases"]["allreduce"]["launches_per_step"] >= 5 + 11 + 2
+    a, b = one["last_update"], two["last_update"]
+    assert a["trpo_status"] == b["trpo_status"]
+    # three periods of training with the f32 sums in another order: TRPO's CG amplifies rounding-level differences of
+    # the Fisher-vector products (DESIGN.md §6), so the runs stay close, not identical
+    assert abs(a["entropy"] - b["entropy"]) < 5e-3
+    assert abs(a["critic_loss_last"] - b["critic_loss_last"]) < 5e-2 * a["critic_loss_last"]
+
+
+def test_bench_falls_back_when_rccl_cannot_build_the_communicator():
+    """With both ranks on ONE device RCCL's bootstrap (unique id from rank 0 through the gloo group, socket rendezvous,
+    ncclCommInitRank on every rank) runs up to its duplicate-device check and is refused; every rank must then agree
+    on the host-staged collective and the job must still produce its line."""
+    two = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "rccl"})
+    assert "RCCL communicator not created" in two["_stderr"] and "falling back" in two["_stderr"]
+    assert "gloo" in two["config"]["parallelism"] and two["n_gpus"] == 2 and two["value"] > 0
