@@ -908,12 +908,13 @@ static void traj_plan(rl_traj *t, uint64_t B) {
   uint64_t nbB = (B + 255) / 256;
   if (nbB > 2048) nbB = 2048;
   t->nbB = (uint32_t)nbB;
-  // v2 kernels: persistent grid of 4-wave workgroups, 2 per CU, one 32-sample tile per wave and iteration
+  // v2 kernels: persistent grid, one workgroup per CU (fewer, fatter workgroups = fewer slab rows for the reduction
+  // that follows every launch), one 32-sample tile per wave and iteration; policy kernels run eight waves per workgroup
   uint64_t n_tiles = (B + 31) / 32;
-  uint64_t nbV2 = (n_tiles + 3) / 4;
-  uint64_t max_v2 = 2ull * (uint64_t)e->prop.multiProcessorCount;
-  // the critic step fits three workgroups per CU (168 VGPRs, 50 KB LDS each)
-  uint64_t nbC = nbV2, max_c = 3ull * (uint64_t)e->prop.multiProcessorCount;
+  uint64_t nbV2 = (n_tiles + 7) / 8;
+  uint64_t max_v2 = (uint64_t)e->prop.multiProcessorCount;
+  // the critic step runs one workgroup of twelve waves per CU (168 VGPRs: three waves per SIMD; 149 KB LDS)
+  uint64_t nbC = (n_tiles + 11) / 12, max_c = (uint64_t)e->prop.multiProcessorCount;
   if (nbC > max_c) nbC = max_c;
   t->nbC = (uint32_t)nbC;
   if (nbV2 > max_v2) nbV2 = max_v2;

@@ -38,7 +38,8 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int V2_WAVES = 4;        // waves per workgroup
+constexpr int V2_WAVES = 8;        // policy kernels: one workgroup of eight waves per CU (two per SIMD)
+constexpr int CRITIC_WAVES = 12;   // critic step: one workgroup of twelve waves per CU (three per SIMD)
 constexpr int V2_NT = 4;           // 32-unit hidden tiles (H = 128)
 constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 samples per accumulator)
 
@@ -48,14 +49,14 @@ constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 s
 // per 32-sample tile and wave:  MFMA 12 issues (768 cycles on the matrix pipe)
 //                               VALU ~128 (relu, y partials) + ~50 (owner math) + 576 (backward) instructions
 // Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2x backward of the 5-128-1 MLP).
-__global__ void __launch_bounds__(V2_WAVES * 64, 3)
+__global__ void __launch_bounds__(CRITIC_WAVES * 64, 3)
     k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
                        double *__restrict__ slabB, float two_over_B, uint32_t P) {
   constexpr int D = 5, H = 128, NT = V2_NT;
   constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] = sum_s [pre_sj > 0] dy_s x~_sk (slot 6 unused); + db2, loss
-  __shared__ float Ysh[V2_WAVES][32][33];
-  __shared__ float Ush[V2_WAVES][32][8];
-  __shared__ double Acc[V2_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
+  __shared__ float Ysh[CRITIC_WAVES][32][33];
+  __shared__ float Ush[CRITIC_WAVES][32][8];
+  __shared__ double Acc[CRITIC_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, hf = lane >> 5;
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 3)
   };
 
   const size_t n_tiles = (B + 31) / 32;
-  const size_t wave_id = (size_t)blockIdx.x * V2_WAVES + wave, n_waves = (size_t)gridDim.x * V2_WAVES;
+  const size_t wave_id = (size_t)blockIdx.x * CRITIC_WAVES + wave, n_waves = (size_t)gridDim.x * CRITIC_WAVES;
   int since_flush = 0;
   // A operand: x~[sample n][k = hf + 2*step]; x~5 = 1 (bias input).
   struct TileOp {
@@ -237,11 +238,11 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 3)
   // sum the per-wave images in wave order, turn M into gradients and write the workgroup's slab row:
   //   dL/dW1[j][k] = w2_j * M[j][k],  dL/db1[j] = w2_j * M[j][5],  dL/db2 = sum dy,
   //   dL/dW2[j] = sum_s dy_s h_sj = sum_s dy_s [pre_sj > 0] (W~1[j] . x~_s) = sum_k W~1[j][k] M[j][k]
-  for (uint32_t p = threadIdx.x; p <= P; p += V2_WAVES * 64) {
+  for (uint32_t p = threadIdx.x; p <= P; p += CRITIC_WAVES * 64) {
     auto tot = [&](int src) {
       double s = Acc[0][src];
 #pragma unroll
-      for (int w = 1; w < V2_WAVES; ++w) s = s + Acc[w][src];
+      for (int w = 1; w < CRITIC_WAVES; ++w) s = s + Acc[w][src];
       return s;
     };
     double s;
@@ -894,7 +895,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
   if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile
-    hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(V2_WAVES * 64), 0, traj->eng->stream, traj->d,
+    hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, traj->d,
                        critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
   } else {  // variant 2: two waves per tile (A/B measurements)
     hipLaunchKernelGGL(k_critic_step_pair, dim3(traj->nbPair), dim3(128), 0, traj->eng->stream, traj->d,
