@@ -25,6 +25,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GH = 128;      // GRU hidden width (ChainConfig::hidden_dim, chain.rs:28)
 constexpr int MH = 128;      // MLP hidden width (MlpConfig::default)
 constexpr int TL = 32;       // lanes per tile
+constexpr int TLS = TL + 16;  // LDS row stride of the [k][m] operand buffers read as 16x16x4 A operands: the four
+                              // k-rows of an instruction start 48 floats apart = banks 0 / 48 / 32 / 16: no conflict
 constexpr int SEQ_ARR = 7;   // activation arrays per step: r, z, n, gh_n, h_prev, relu(h'), u
 constexpr int DPRE_ARR = 5;  // backward arrays per step: d pre_r, d pre_z, d pre_n, d pre_n * r, d u_pre
 enum { ACT_R = 0, ACT_Z = 1, ACT_N = 2, ACT_GHN = 3, ACT_HPREV = 4, ACT_A1 = 5, ACT_U = 6 };
@@ -240,7 +242,7 @@ __device__ __forceinline__ int acc_row(int r, int hf) { return (r & 3) + 8 * (r 
 
 // LDS of the forward kernels
 struct SeqFwdShared {
-  float hT[2][GH][TL + 1];  // recurrent state, [k][m], double-buffered
+  float hT[2][GH][TLS];     // recurrent state, [k][m], double-buffered
   float uS[TL][MH + 1];     // MLP hidden activations, [m][j]
   float xS[TL][8];          // observation features of the current step
   float w2S[2][MH];
@@ -274,94 +276,6 @@ __device__ __forceinline__ void seq_load_weights(SeqFwdWeights<D> &w, const GruP
 #pragma unroll
   for (int ks = 0; ks < GH / 2; ++ks) w.w1[ks] = g.W1[(size_t)j * GH + 2 * ks + hf];
   w.b1 = g.b1[j];
-}
-
-// One cell + head evaluation for the tile.  Reads the state from sh.hT[cur] and `hown`, writes the new state to
-// sh.hT[cur ^ 1] and `hnew`; the head outputs land in sh.outS (valid after the function returns: it ends with a
-// barrier).  `store` != nullptr: record the 7 activation arrays of this (t, tile) block.
-template <int D, int A>
-__device__ __forceinline__ void seq_cell(SeqFwdShared &sh, const SeqFwdWeights<D> &w, int cur, const float (&hown)[16],
-                                         float (&hnew)[16], float b2_mine, float *__restrict__ store, int wave,
-                                         int lane) {
-  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n, nxt = cur ^ 1;
-  f32x16 acc[3];
-#pragma unroll
-  for (int gte = 0; gte < 3; ++gte)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[gte][r] = w.bhh[gte];
-#pragma unroll
-  for (int ks = 0; ks < GH / 2; ++ks) {
-    const float a = sh.hT[cur][2 * ks + hf][n];
-#pragma unroll
-    for (int gte = 0; gte < 3; ++gte) acc[gte] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.whh[gte][ks], acc[gte], 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = acc_row(r, hf);
-    float gi[3];
-#pragma unroll
-    for (int gte = 0; gte < 3; ++gte) {
-      float v = w.bih[gte];
-#pragma unroll
-      for (int d = 0; d < D; ++d) v = __builtin_fmaf(sh.xS[m][d], w.wih[gte][d], v);
-      gi[gte] = v;
-    }
-#if defined(SEQ_ABLATE) && (SEQ_ABLATE & 1)
-    const float rr = 0.5f + 0.01f * (acc[0][r] + gi[0]);
-    const float zz = 0.5f + 0.01f * (acc[1][r] + gi[1]);
-    const float rn = acc[2][r] * rr;
-    const float nn = 0.1f * (gi[2] + rn);
-#else
-    const float rr = rl_sigmoidf(acc[0][r] + gi[0]);
-    const float zz = rl_sigmoidf(acc[1][r] + gi[1]);
-    const float rn = acc[2][r] * rr;
-    const float nn = rl_tanhf(gi[2] + rn);
-#endif
-    const float dn = hown[r] - nn;
-    const float hz = dn * zz;
-    const float hv = hz + nn;
-    hnew[r] = hv;
-    sh.hT[nxt][j][m] = hv;
-    if (store != nullptr) {
-      // [arr][j][m]: this lane owns 4 runs of 4 consecutive m for its unit j
-      store[(size_t)ACT_R * GH * TL + j * TL + m] = rr;
-      store[(size_t)ACT_Z * GH * TL + j * TL + m] = zz;
-      store[(size_t)ACT_N * GH * TL + j * TL + m] = nn;
-      store[(size_t)ACT_GHN * GH * TL + j * TL + m] = acc[2][r];
-      store[(size_t)ACT_HPREV * GH * TL + j * TL + m] = hown[r];
-      store[(size_t)ACT_A1 * GH * TL + j * TL + m] = hv > 0.0f ? hv : 0.0f;
-    }
-  }
-  __syncthreads();
-  f32x16 acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc1[r] = w.b1;
-#pragma unroll
-  for (int ks = 0; ks < GH / 2; ++ks) {
-    float a = sh.hT[nxt][2 * ks + hf][n];
-    a = a > 0.0f ? a : 0.0f;  // Chain activation between the modules (chain.rs:165)
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.w1[ks], acc1, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = acc_row(r, hf);
-    const float u = acc1[r] > 0.0f ? acc1[r] : 0.0f;
-    sh.uS[m][j] = u;
-    if (store != nullptr) store[(size_t)ACT_U * GH * TL + j * TL + m] = u;
-  }
-  __syncthreads();
-  if (wave == 0 && hf < A) {
-    // out_a[m] = b2_a + sum_j u[m][j] W2[a][j], sequential chain (lane = (m = n, a = hf))
-    float z = b2_mine;
-#if defined(SEQ_ABLATE) && (SEQ_ABLATE & 2)
-    for (int q = 0; q < 4; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
-#else
-#pragma unroll 8
-    for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
-#endif
-    sh.outS[hf][n] = z;
-  }
-  __syncthreads();
 }
 
 // ---------------------------------------------------------------- 16-unit ownership (v_mfma_f32_16x16x4_f32)
@@ -403,6 +317,10 @@ __device__ __forceinline__ void seq_load_weights16(SeqFwdWeights16<D> &w, const 
 // sample owned by accumulator register i of M-tile mt in lane group g4
 __device__ __forceinline__ int acc16_row(int mt, int i, int g4) { return 16 * mt + 4 * g4 + i; }
 
+// One cell + head evaluation for the tile.  Reads the state from sh.hT[cur] and `hown`, writes the new state to
+// sh.hT[cur ^ 1] and `hnew`; the head outputs land in sh.outS (valid after the function returns: it ends with a
+// barrier).  `store` != nullptr: record the 7 activation arrays of this (t, tile) block ([unit][lane] rows: a lane's
+// four samples of an M-tile are contiguous, one 16-byte store per array and M-tile).
 template <int D, int A>
 __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights16<D> &w, int cur,
                                            const float (&hown)[8], float (&hnew)[8], float b2_mine,
@@ -424,7 +342,8 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
     }
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 rv, zv, nv, gv, pv, av;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = acc16_row(mt, i, g4), r = 4 * mt + i;
@@ -445,15 +364,23 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
       const float hv = hz + nn;
       hnew[r] = hv;
       sh.hT[nxt][j][m] = hv;
-      if (store != nullptr) {
-        store[(size_t)ACT_R * GH * TL + j * TL + m] = rr;
-        store[(size_t)ACT_Z * GH * TL + j * TL + m] = zz;
-        store[(size_t)ACT_N * GH * TL + j * TL + m] = nn;
-        store[(size_t)ACT_GHN * GH * TL + j * TL + m] = acc[2][mt][i];
-        store[(size_t)ACT_HPREV * GH * TL + j * TL + m] = hown[r];
-        store[(size_t)ACT_A1 * GH * TL + j * TL + m] = hv > 0.0f ? hv : 0.0f;
-      }
+      rv[i] = rr;
+      zv[i] = zz;
+      nv[i] = nn;
+      gv[i] = acc[2][mt][i];
+      pv[i] = hown[r];
+      av[i] = hv > 0.0f ? hv : 0.0f;
     }
+    if (store != nullptr) {
+      float *__restrict__ row = store + (size_t)j * TL + 16 * mt + 4 * g4;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_R * GH * TL) = rv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_Z * GH * TL) = zv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_N * GH * TL) = nv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_GHN * GH * TL) = gv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_HPREV * GH * TL) = pv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_A1 * GH * TL) = av;
+    }
+  }
   __syncthreads();
   f32x4 acc1[2];
 #pragma unroll
@@ -468,14 +395,18 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
     }
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 uv;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = acc16_row(mt, i, g4);
       const float u = acc1[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
       sh.uS[m][j] = u;
-      if (store != nullptr) store[(size_t)ACT_U * GH * TL + j * TL + m] = u;
+      uv[i] = u;
     }
+    if (store != nullptr)
+      *reinterpret_cast<f32x4 *>(store + (size_t)ACT_U * GH * TL + (size_t)j * TL + 16 * mt + 4 * g4) = uv;
+  }
   __syncthreads();
   if (wave == 0 && (lane >> 5) < A) {
     const int n = lane & 31, hf = lane >> 5;
@@ -503,7 +434,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_gru(CartPoleDev c, EnvS
   SeqFwdWeights16<D> w;
   seq_load_weights16<D>(w, g, wave, lane);
   for (int q = threadIdx.x; q < A * MH; q += W16 * 64) sh.w2S[q / MH][q % MH] = g.W2[q];
-  for (int q = threadIdx.x; q < 2 * GH * (TL + 1); q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
+  for (int q = threadIdx.x; q < 2 * GH * TLS; q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
   const float b2_mine = hf < A ? g.b2[hf] : 0.0f;
   float hown[8];
 #pragma unroll
@@ -635,7 +566,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
   SeqFwdWeights16<D> w;
   seq_load_weights16<D>(w, g, wave, lane);
   for (int q = threadIdx.x; q < A * MH; q += W16 * 64) sh.w2S[q / MH][q % MH] = g.W2[q];
-  for (int q = threadIdx.x; q < 2 * GH * (TL + 1); q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
+  for (int q = threadIdx.x; q < 2 * GH * TLS; q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
   const float b2_mine = hf < A ? g.b2[hf] : 0.0f;
   float hown[8];
 #pragma unroll
@@ -924,18 +855,23 @@ __global__ void __launch_bounds__(256) k_seq_critic_dvalues(TrajDev tr, const fl
 }
 
 // ---------------------------------------------------------------- backward through time
-// One workgroup (eight waves) per tile, t = T-1 .. 0.  Wave w owns units k in [16w, 16w+16) of every
-// back-propagated vector: its slices of W1^T (32 B-operands of 16x16x4 MFMAs) and W_hh^T (3 x 32) stay in registers, the vectors being multiplied pass
-// through one [128][33] LDS buffer, gate by gate.  Writes the five per-step arrays the weight-gradient GEMMs read.
+// One workgroup (eight waves) per tile, t = T-1 .. 0.  Wave w owns units k in [16w, 16w+16) of every back-propagated
+// vector: its slices of W1^T (32 B-operands of 16x16x4 MFMAs) and W_hh^T (3 x 32) stay in registers; the vectors being
+// multiplied pass through LDS ([128][33] per vector: d u_pre, then the three gate vectors side by side, so a step
+// needs two workgroup barriers).  The sums over k run as independent MFMA chains (two half-chains per M-tile for
+// W1^T, one chain per gate and M-tile for W_hh^T), added at the end: the matrix pipe stays busy instead of waiting
+// for one accumulator.  A lane's four samples of an M-tile are contiguous in the record ([unit][lane] rows), so every
+// record access is one 16-byte load / store; the record of step t-1 is requested as soon as step t has consumed its
+// own, and lands under the gate products.  Writes the five per-step arrays the weight-gradient GEMMs read.
+// (Gradients are compared with the oracle within fp32 tolerances, tests/test_gpu_gru.py: the order of these sums is
+// free, unlike the forward's.)
 template <int A>
 __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const float *__restrict__ params, int D,
                                                           const float *__restrict__ dz, const float *__restrict__ act,
                                                           float *__restrict__ dpre, const int32_t *__restrict__ skip) {
-  __shared__ float bufT[GH][TL + 1];
-  __shared__ float dzS[2][TL];
-  __shared__ int endS[TL];
+  __shared__ float bufU[GH][TLS];
+  __shared__ float bufG[3][GH][TLS];
   if (skip != nullptr && *skip != 0) return;
-  // eight waves per tile, wave w owns units k in [16w, 16w+16) of every back-propagated vector (16x16x4 MFMAs)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
@@ -951,82 +887,122 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
   for (int ks = 0; ks < MH / 4; ++ks) w1T[ks] = g.W1[(size_t)(4 * ks + g4) * GH + j];
 #pragma unroll
   for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
-  float dhc[8];
+
+  // one step's inputs: the lane's 2 x 4 samples of its unit in six record arrays + u, the logit gradients and the
+  // episode-end flags of those samples
+  struct StepIn {
+    f32x4 u[2], a1[2], r[2], z[2], n[2], ghn[2], hp[2], dzv[A][2];
+    uint32_t end[2];  // four flag bytes
+  };
+  const size_t lo = (size_t)j * TL + 4 * g4;  // + 16 mt: first of the lane's four contiguous samples
+  auto load_u = [&](StepIn &in, uint32_t t) {
+    const float *__restrict__ ab = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) dhc[r] = 0.0f;
-  for (uint32_t t = T; t-- > 0;) {
-    const size_t blk = (size_t)t * tiles + tile;
-    const float *__restrict__ ab = act + blk * SEQ_ARR * GH * TL;
-    float *__restrict__ db = dpre + blk * DPRE_ARR * GH * TL;
-    if (wave == 0 && lane < TL) {
+    for (int mt = 0; mt < 2; ++mt) {
+      in.u[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + 16 * mt);
 #pragma unroll
-      for (int a = 0; a < A; ++a) dzS[a][lane] = dz[(size_t)a * B + (size_t)t * N + lane0 + lane];
-      endS[lane] = tr.flag[(size_t)t * N + lane0 + lane] != RL_SUCC_CONTINUE;
+      for (int a = 0; a < A; ++a)
+        in.dzv[a][mt] = *reinterpret_cast<const f32x4 *>(dz + (size_t)a * B + (size_t)t * N + lane0 + 16 * mt + 4 * g4);
+      in.end[mt] = *reinterpret_cast<const uint32_t *>(tr.flag + (size_t)t * N + lane0 + 16 * mt + 4 * g4);
     }
-    __syncthreads();
+  };
+  auto load_cell = [&](StepIn &in, uint32_t t) {
+    const float *__restrict__ ab = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const size_t o = lo + 16 * mt;
+      in.a1[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + o);
+      in.r[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_R * GH * TL + o);
+      in.z[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_Z * GH * TL + o);
+      in.n[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_N * GH * TL + o);
+      in.ghn[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_GHN * GH * TL + o);
+      in.hp[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_HPREV * GH * TL + o);
+    }
+  };
+  StepIn in;
+  load_u(in, T - 1);
+  load_cell(in, T - 1);
+  f32x4 dhc[2];
+  dhc[0] = dhc[1] = (f32x4){0, 0, 0, 0};
+  for (uint32_t t = T; t-- > 0;) {
+    float *__restrict__ db = dpre + ((size_t)t * tiles + tile) * DPRE_ARR * GH * TL;
     // head: d u_pre = [u > 0] W2^T dz
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int m = acc16_row(r >> 2, r & 3, g4);
-      const float u = ab[(size_t)ACT_U * GH * TL + j * TL + m];
-      float du = 0.0f;
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 duv;
 #pragma unroll
-      for (int a = 0; a < A; ++a) du = __builtin_fmaf(dzS[a][m], w2c[a], du);
-      du = u > 0.0f ? du : 0.0f;
-      bufT[j][m] = du;
-      db[(size_t)4 * GH * TL + j * TL + m] = du;
+      for (int i = 0; i < 4; ++i) {
+        float du = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) du = __builtin_fmaf(in.dzv[a][mt][i], w2c[a], du);
+        du = in.u[mt][i] > 0.0f ? du : 0.0f;
+        bufU[j][16 * mt + 4 * g4 + i] = du;
+        duv[i] = du;
+      }
+      *reinterpret_cast<f32x4 *>(db + (size_t)4 * GH * TL + lo + 16 * mt) = duv;
     }
+    uint32_t endw[2] = {in.end[0], in.end[1]};
+    if (t > 0) load_u(in, t - 1);  // consumed at the top of the next step
     __syncthreads();
-    f32x4 acc[2];
-    acc[0] = acc[1] = (f32x4){0, 0, 0, 0};
+    // d relu(h') = W1^T d u_pre: two half-chains per M-tile
+    f32x4 acc1[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc1[mt][0] = acc1[mt][1] = (f32x4){0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < MH / 4; ++ks)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufT[4 * ks + g4][16 * mt + n16], w1T[ks], acc[mt], 0, 0, 0);
-    __syncthreads();
+        acc1[mt][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufU[4 * ks + g4][16 * mt + n16], w1T[ks],
+                                                                acc1[mt][ks & 1], 0, 0, 0);
     // cell: h' = (h - n) z + n
-    float gr[8], gz[8], gnr[8], dhdir[8];
+    f32x4 dhdir[2];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int m = acc16_row(r >> 2, r & 3, g4);
-      const size_t o = (size_t)j * TL + m;
-      const float a1 = ab[(size_t)ACT_A1 * GH * TL + o];
-      const float rr = ab[(size_t)ACT_R * GH * TL + o], zz = ab[(size_t)ACT_Z * GH * TL + o];
-      const float nn = ab[(size_t)ACT_N * GH * TL + o], ghn = ab[(size_t)ACT_GHN * GH * TL + o];
-      const float hp = ab[(size_t)ACT_HPREV * GH * TL + o];
-      float dh = endS[m] ? 0.0f : dhc[r];
-      dh = dh + (a1 > 0.0f ? acc[r >> 2][r & 3] : 0.0f);
-      const float dzg = dh * (hp - nn);
-      const float dn = dh * (1.0f - zz);
-      const float dpn = dn * (1.0f - nn * nn);
-      const float dr = dpn * ghn;
-      gr[r] = dr * rr * (1.0f - rr);
-      gz[r] = dzg * zz * (1.0f - zz);
-      gnr[r] = dpn * rr;
-      dhdir[r] = dh * zz;
-      db[(size_t)0 * GH * TL + o] = gr[r];
-      db[(size_t)1 * GH * TL + o] = gz[r];
-      db[(size_t)2 * GH * TL + o] = dpn;
-      db[(size_t)3 * GH * TL + o] = gnr[r];
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 grv, gzv, dpnv, gnrv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * mt + 4 * g4 + i;
+        const float rr = in.r[mt][i], zz = in.z[mt][i], nn = in.n[mt][i];
+        const bool ended = ((endw[mt] >> (8 * i)) & 0xffu) != RL_SUCC_CONTINUE;
+        float dh = ended ? 0.0f : dhc[mt][i];
+        dh = dh + (in.a1[mt][i] > 0.0f ? acc1[mt][0][i] + acc1[mt][1][i] : 0.0f);
+        const float dzg = dh * (in.hp[mt][i] - nn);
+        const float dn = dh * (1.0f - zz);
+        const float dpn = dn * (1.0f - nn * nn);
+        const float dr = dpn * in.ghn[mt][i];
+        grv[i] = dr * rr * (1.0f - rr);
+        gzv[i] = dzg * zz * (1.0f - zz);
+        gnrv[i] = dpn * rr;
+        dpnv[i] = dpn;
+        dhdir[mt][i] = dh * zz;
+        bufG[0][j][m] = grv[i];
+        bufG[1][j][m] = gzv[i];
+        bufG[2][j][m] = gnrv[i];
+      }
+      const size_t o = lo + 16 * mt;
+      *reinterpret_cast<f32x4 *>(db + (size_t)0 * GH * TL + o) = grv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)1 * GH * TL + o) = gzv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)2 * GH * TL + o) = dpnv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)3 * GH * TL + o) = gnrv;
     }
-    // d h_prev = dh z + sum over gates of W_hh[g]^T d gh_g
-    acc[0] = acc[1] = (f32x4){0, 0, 0, 0};
+    if (t > 0) load_cell(in, t - 1);  // lands under the gate products below
+    __syncthreads();
+    // d h_prev = dh z + sum over gates of W_hh[g]^T d gh_g: one chain per gate and M-tile
+    f32x4 accg[3][2];
 #pragma unroll
-    for (int gte = 0; gte < 3; ++gte) {
+    for (int gte = 0; gte < 3; ++gte) accg[gte][0] = accg[gte][1] = (f32x4){0, 0, 0, 0};
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        bufT[j][acc16_row(r >> 2, r & 3, g4)] = gte == 0 ? gr[r] : (gte == 1 ? gz[r] : gnr[r]);
-      __syncthreads();
+    for (int ks = 0; ks < GH / 4; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < GH / 4; ++ks)
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufT[4 * ks + g4][16 * mt + n16], whhT[gte][ks], acc[mt], 0, 0, 0);
-      __syncthreads();
-    }
+        for (int gte = 0; gte < 3; ++gte)
+          accg[gte][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufG[gte][4 * ks + g4][16 * mt + n16], whhT[gte][ks],
+                                                               accg[gte][mt], 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) dhc[r] = dhdir[r] + acc[r >> 2][r & 3];
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dhc[mt][i] = dhdir[mt][i] + ((accg[0][mt][i] + accg[1][mt][i]) + accg[2][mt][i]);
   }
 }
 
