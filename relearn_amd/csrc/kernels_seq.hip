@@ -1011,12 +1011,19 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
 // sample index as the MFMA k dimension (k-pair (ks, hf) <-> sample m = 16 hf + ks, so every operand is 16
 // consecutive floats of a [unit][32] row); dW_ih, the biases and dW2 on the VALU.  A workgroup accumulates a
 // contiguous run of (t, tile) blocks in f32 and writes one row of partials; k_seq_reduce sums the rows in f64.
+// The four A-operand arrays of a block (d gh_r, d gh_z, d gh_n, d u_pre: every wave needs all 512 rows) are fetched
+// ONCE per workgroup with fully coalesced 16-byte loads into registers while the previous block's products run, then
+// parked in LDS ([unit][36] rows: the 16-byte operand reads of 16 consecutive rows hit 64 different banks); a wave's B
+// rows (h_prev, relu(h') of its own 32 units) and the rows only its VALU sums need come straight from HBM.
 template <int D, int A>
 __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *__restrict__ dz,
                                                       const float *__restrict__ act, const float *__restrict__ dpre,
                                                       float *__restrict__ slab, uint32_t P, uint32_t tiles,
                                                       uint32_t blocks, uint32_t blocks_per_chunk,
                                                       const int32_t *__restrict__ skip) {
+  constexpr int RS = TL + 4;
+  enum { S_R = 0, S_Z = 1, S_GN = 2, S_DU = 3, S_N = 4 };
+  __shared__ __attribute__((aligned(16))) float aS[S_N][GH][RS];
   __shared__ float xS[TL][8];
   __shared__ float dzS[2][TL];
   if (skip != nullptr && *skip != 0) return;
@@ -1038,32 +1045,74 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
   for (int a = 0; a < A; ++a) dw2[a] = 0.0f;
   const uint32_t b0 = blockIdx.x * blocks_per_chunk;
   const uint32_t b1 = b0 + blocks_per_chunk < blocks ? b0 + blocks_per_chunk : blocks;
+
+  // staging registers: thread q holds the 16-byte pieces q, q + 256, q + 512, q + 768 of each [128][32] array
+  f32x4 stg[S_N][4];
+  float xn[D], dzn[A];  // wave 0, lanes < 32: the block's observation features and logit gradients
+  auto stage_load = [&](uint32_t blk) {
+    const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
+    const float *src[S_N] = {db, db + (size_t)1 * GH * TL, db + (size_t)3 * GH * TL, db + (size_t)4 * GH * TL};
+#pragma unroll
+    for (int a = 0; a < S_N; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stg[a][i] = *reinterpret_cast<const f32x4 *>(src[a] + 4 * (threadIdx.x + 256 * i));
+    if (wave == 0 && lane < TL) {
+      const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
+#pragma unroll
+      for (int d = 0; d < D; ++d) xn[d] = tr.obs[d * plane + (size_t)t * N + lane0 + lane];
+#pragma unroll
+      for (int a = 0; a < A; ++a) dzn[a] = dz[(size_t)a * B + (size_t)t * N + lane0 + lane];
+    }
+  };
+  if (b0 < b1) stage_load(b0);
   for (uint32_t blk = b0; blk < b1; ++blk) {
-    const uint32_t t = blk / tiles, tile = blk % tiles, lane0 = tile * TL;
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
-    __syncthreads();  // the previous block's readers of xS / dzS are done
+    __syncthreads();  // the previous block's readers of the LDS operands are done
+#pragma unroll
+    for (int a = 0; a < S_N; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i;
+        *reinterpret_cast<f32x4 *>(&aS[a][f >> 3][4 * (f & 7)]) = stg[a][i];
+      }
     if (wave == 0 && lane < TL) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) xS[lane][d] = tr.obs[d * plane + (size_t)t * N + lane0 + lane];
+      for (int d = 0; d < D; ++d) xS[lane][d] = xn[d];
 #pragma unroll
-      for (int a = 0; a < A; ++a) dzS[a][lane] = dz[(size_t)a * B + (size_t)t * N + lane0 + lane];
+      for (int a = 0; a < A; ++a) dzS[a][lane] = dzn[a];
+    }
+    // straight from HBM: the B operands of this wave's column tile (h_prev and relu(h') rows of unit k = j, samples
+    // 16 hf .. 16 hf + 15) and the owner rows' operands that only the VALU sums use (d pre_n, u)
+    f32x4 hp4[4], a14[4], dpnv[4], uv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t o = (size_t)j * TL + 16 * hf + 4 * q;
+      hp4[q] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_HPREV * GH * TL + o);
+      a14[q] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + o);
+      dpnv[q] = *reinterpret_cast<const f32x4 *>(db + (size_t)2 * GH * TL + o);
+      uv[q] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + o);
     }
     __syncthreads();
-    // B operands of this wave's column tile: h_prev and relu(h') rows of unit k = j, samples 16 hf .. 16 hf + 15
+    if (blk + 1 < b1) stage_load(blk + 1);  // lands under this block's products
     float hpB[16], a1B[16];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      hpB[ks] = ab[(size_t)ACT_HPREV * GH * TL + j * TL + 16 * hf + ks];
-      a1B[ks] = ab[(size_t)ACT_A1 * GH * TL + j * TL + 16 * hf + ks];
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hpB[4 * q + i] = hp4[q][i];
+        a1B[4 * q + i] = a14[q][i];
+      }
 #pragma unroll
     for (int mt = 0; mt < 12; ++mt) {
       const int gte = mt >> 2, row = 32 * (mt & 3) + n;  // unit of this lane's A row
-      const int arr = gte == 2 ? 3 : gte;
       float av[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) av[ks] = db[(size_t)arr * GH * TL + row * TL + 16 * hf + ks];
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(&aS[gte][row][16 * hf + 4 * q]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[4 * q + i] = v4[i];
+      }
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
         acc_hh[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], hpB[ks], acc_hh[mt], 0, 0, 0);
@@ -1073,7 +1122,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         for (int ks = 0; ks < 16; ++ks) {
           const int m = 16 * hf + ks;
           const float dgh = av[ks];
-          const float dgi = gte == 2 ? db[(size_t)2 * GH * TL + row * TL + m] : dgh;
+          const float dgi = gte == 2 ? dpnv[ks >> 2][ks & 3] : dgh;
           dbhh[gte] += dgh;
           dbih[gte] += dgi;
 #pragma unroll
@@ -1086,7 +1135,11 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
       const int row = 32 * mt + n;
       float av[16];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) av[ks] = db[(size_t)4 * GH * TL + row * TL + 16 * hf + ks];
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(&aS[S_DU][row][16 * hf + 4 * q]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[4 * q + i] = v4[i];
+      }
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
         acc_w1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], a1B[ks], acc_w1[mt], 0, 0, 0);
@@ -1095,7 +1148,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         for (int ks = 0; ks < 16; ++ks) {
           const int m = 16 * hf + ks;
           db1 += av[ks];
-          const float u = ab[(size_t)ACT_U * GH * TL + row * TL + m];
+          const float u = uv[ks >> 2][ks & 3];
 #pragma unroll
           for (int a = 0; a < A; ++a) dw2[a] = __builtin_fmaf(dzS[a][m], u, dw2[a]);
         }
@@ -1147,14 +1200,32 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
   }
 }
 
-// rows of f32 partials -> one f32 vector, accumulated in f64 in a fixed order
-__global__ void __launch_bounds__(256) k_seq_reduce(const float *__restrict__ slab, uint32_t rows, uint32_t P,
-                                                    float *__restrict__ vec) {
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
+// rows of f32 partials -> one f32 vector, accumulated in f64 in a fixed order: 64 columns per workgroup, the rows dealt
+// round-robin to 16 thread groups (eight loads in flight each), the 16 partial sums added in group order
+__global__ void __launch_bounds__(1024) k_seq_reduce(const float *__restrict__ slab, uint32_t rows, uint32_t P,
+                                                     float *__restrict__ vec) {
+  __shared__ double part[16][64];
+  const uint32_t c = threadIdx.x & 63, grp = threadIdx.x >> 6, p = blockIdx.x * 64 + c;
   double s = 0.0;
-  for (uint32_t r = 0; r < rows; ++r) s += (double)slab[(size_t)r * P + p];
-  vec[p] = (float)s;
+  if (p < P) {
+    uint32_t r = grp;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = slab[(size_t)(r + 16 * q) * P + p];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += (double)v[q];
+    }
+    for (; r < rows; r += 16) s += (double)slab[(size_t)r * P + p];
+  }
+  part[grp][c] = s;
+  __syncthreads();
+  if (grp == 0 && p < P) {
+    double t = part[0][c];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += part[q][c];
+    vec[p] = (float)t;
+  }
 }
 
 void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi,
@@ -1202,7 +1273,7 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   }
   {
     ProfScope ps(e, RL_K_REDUCE);
-    hipLaunchKernelGGL(k_seq_reduce, dim3(cdiv_s(P, 256)), dim3(256), 0, e->stream, q.wg_slab, q.chunks, P, traj->vec);
+    hipLaunchKernelGGL(k_seq_reduce, dim3(cdiv_s(P, 64)), dim3(1024), 0, e->stream, q.wg_slab, q.chunks, P, traj->vec);
   }
 }
 
