@@ -102,8 +102,8 @@ class CriticStats(C.Structure):
 
 def build(force=False):
     """Compile librelearn_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
+    # always through make: a no-op when the library is newer than every source, a rebuild of what changed otherwise
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
     return LIB_PATH
 
 

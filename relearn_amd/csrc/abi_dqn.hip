@@ -1,0 +1,402 @@
+// abi_dqn.hip — extern "C" entry points of include/relearn_hip.h, part: DQN with the replay store in HBM (host side only; kernels live in kernels_*.hip).
+#include "abi_internal.hpp"
+
+extern "C" {
+
+// ---------------------------------------------------------------- DQN (src/torch/agents/dqn.rs)
+int32_t rl_dqn_config_default(rl_dqn_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    std::memset(c, 0, sizeof(*c));
+    c->target = RL_DQN_TARGET_REWARD_TO_GO;               // StepValueTarget::default (critics/mod.rs:211-215)
+    c->exploration_kind = RL_SCHEDULE_LINEAR_ANNEALED;    // schedules.rs:23-31
+    c->exploration_start = 1.0;
+    c->exploration_end = 0.1;
+    c->exploration_period = 10000000;
+    c->minibatch_steps = 100000;                          // dqn.rs:63-70
+    c->opt_steps_per_update = 50;
+    c->buffer_capacity = 0;
+    c->episode_capacity = 0;
+    c->update_kind = RL_COLLECT_FIRST_REST;
+    c->update_first = 1000000;
+    c->update_rest = 100000;
+    c->discount_factor = 0.99f;
+  });
+}
+
+static double dqn_exploration_rate(const rl_dqn *q, bool training) {
+  if (!training) return 0.0;  // schedules.rs:38
+  if (q->cfg.exploration_kind == RL_SCHEDULE_CONSTANT) return q->cfg.exploration_start;
+  double frac = (double)q->global_steps / (double)q->cfg.exploration_period;
+  if (!(frac < 1.0)) frac = 1.0;  // f64::min(1.0)
+  return frac * (q->cfg.exploration_end - q->cfg.exploration_start) + q->cfg.exploration_start;
+}
+
+static ReplayDev replay_alloc(rl_engine *e, uint32_t N, uint32_t C, uint32_t E, uint32_t D) {
+  ReplayDev r{};
+  r.N = N;
+  r.C = C;
+  r.E = E;
+  r.D = D;
+  size_t cn = (size_t)C * N;
+  r.obs = dalloc<float>(cn * D);
+  r.next_obs = dalloc<float>(cn * D);
+  r.action = dalloc<uint8_t>(cn);
+  r.reward = dalloc<float>(cn);
+  r.flag = dalloc<uint8_t>(cn);
+  r.head = dalloc<uint32_t>(N);
+  r.count = dalloc<uint32_t>(N);
+  r.ep_head = dalloc<uint32_t>(N);
+  r.ep_count = dalloc<uint32_t>(N);
+  r.total = dalloc<uint32_t>(N);
+  r.ep_end = dalloc<uint32_t>((size_t)E * N);
+  r.actor_pos = dalloc<uint64_t>(N);
+  r.error = dalloc<int32_t>(1);
+  uint32_t *zero_u32[] = {r.head, r.count, r.ep_head, r.ep_count, r.total};
+  for (uint32_t *p : zero_u32) RL_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)N * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.actor_pos, 0, (size_t)N * 8, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.error, 0, 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.next_obs, 0, cn * D * 4, e->stream));
+  return r;
+}
+
+static void replay_free(ReplayDev &r) {
+  void *ptrs[] = {r.obs,      r.next_obs, r.action, r.reward, r.flag,      r.head, r.count,
+                  r.ep_head,  r.ep_count, r.total,  r.ep_end, r.actor_pos, r.error};
+  for (void *p : ptrs) dfree(p);
+  r = ReplayDev{};
+}
+
+int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_config *cfg, rl_dqn **out) {
+  return guarded(env ? env->eng : nullptr, [&] {
+    RL_REQUIRE(env && qnet && opt && cfg && out, "NULL argument");
+    *out = nullptr;
+    rl_engine *e = env->eng;
+    RL_REQUIRE(qnet->eng == e && opt->eng == e, "handles belong to different engines");
+    RL_REQUIRE(opt->mod == qnet, "optimizer does not belong to the action-value module");
+    RL_REQUIRE(qnet->in_dim == env->D && qnet->out_dim == env->A, "action-value module does not match the env");
+    RL_REQUIRE(env->A == 2, "DQN kernels are built for 2-action envs");
+    RL_REQUIRE(cfg->target == RL_DQN_TARGET_REWARD_TO_GO || cfg->target == RL_DQN_TARGET_ONE_STEP_TD, "bad target");
+    RL_REQUIRE(cfg->minibatch_steps > 0 && cfg->minibatch_steps < (1ull << 30), "bad minibatch_steps");
+    RL_REQUIRE(cfg->buffer_capacity > 0 && cfg->buffer_capacity < (1ull << 31), "bad buffer_capacity");
+    uint64_t E = cfg->episode_capacity ? cfg->episode_capacity : cfg->buffer_capacity;
+    RL_REQUIRE(E <= cfg->buffer_capacity, "episode_capacity exceeds buffer_capacity");
+    RL_REQUIRE(cfg->opt_steps_per_update <= 4096, "too many optimisation steps per update");
+    if (cfg->exploration_kind == RL_SCHEDULE_LINEAR_ANNEALED)
+      RL_REQUIRE(cfg->exploration_period > 0, "exploration_period must be positive");
+    uint64_t N = env->cfg.n_lanes;
+    RL_REQUIRE(cfg->buffer_capacity * N * 46 < (200ull << 30), "replay store would not fit in HBM");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_dqn> q(new rl_dqn());
+    q->eng = e;
+    q->env = env;
+    q->qnet = qnet;
+    q->opt = opt;
+    q->cfg = *cfg;
+    q->cfg.episode_capacity = E;
+    q->rp = replay_alloc(e, (uint32_t)N, (uint32_t)cfg->buffer_capacity, (uint32_t)E, env->D);
+    q->d_agent_pos = dalloc<uint64_t>(1);
+    RL_HIP_CHECK(hipMemsetAsync(q->d_agent_pos, 0, 8, e->stream));
+    // take_while accepts episodes while total < minibatch_steps and every episode has >= 1 step
+    q->max_eps = (uint32_t)cfg->minibatch_steps;
+    q->max_steps_mb = cfg->minibatch_steps - 1 + cfg->buffer_capacity;
+    // the episode lists of all opt_steps_per_update minibatches of an update are drawn in one launch
+    const size_t nb = cfg->opt_steps_per_update ? cfg->opt_steps_per_update : 1;
+    q->d_ep_lane = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_ep_start = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_ep_len = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_ep_off = dalloc<uint32_t>(nb * q->max_eps);
+    q->d_counts = dalloc<DqnCountsDev>(nb);
+    RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, nb * sizeof(DqnCountsDev), e->stream));
+    q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
+    sync(e);
+    e->live_handles += 1;
+    *out = q.release();
+  });
+}
+
+int32_t rl_dqn_destroy(rl_dqn *q) {
+  if (!q) return RL_OK;
+  (void)hipSetDevice(q->eng->device);
+  (void)hipStreamSynchronize(q->eng->stream);
+  replay_free(q->rp);
+  void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags};
+  for (void *p : ptrs) dfree(p);
+  rl_traj_destroy(q->mb);
+  rl_engine *eng = q->eng;
+  delete q;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_dqn_exploration_rate(const rl_dqn *q, int32_t training, double *rate_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && rate_out, "NULL argument");
+    *rate_out = dqn_exploration_rate(q, training != 0);
+  });
+}
+
+int32_t rl_dqn_min_update_size(const rl_dqn *q, uint64_t *min_steps_out, uint64_t *slack_steps_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && min_steps_out && slack_steps_out, "NULL argument");
+    // DataCollectionSchedule::update_size (schedules.rs:58-68)
+    uint64_t min_steps;
+    if (q->cfg.update_kind == RL_COLLECT_CONSTANT) min_steps = q->cfg.update_first;
+    else min_steps = q->global_steps < q->cfg.update_first ? q->cfg.update_first : q->cfg.update_rest;
+    *min_steps_out = min_steps;
+    // HistoryDataBound::with_default_slack (src/agents/buffers/mod.rs:54-63): 1 % of min_steps, between 5 and 1000
+    uint64_t slack = min_steps / 100;
+    slack = slack < 5 ? 5 : (slack > 1000 ? 1000 : slack);
+    *slack_steps_out = slack;
+  });
+}
+
+int32_t rl_dqn_collect(rl_dqn *q, uint64_t horizon, rl_dqn_collect_stats *stats) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q, "NULL argument");
+    RL_REQUIRE(horizon > 0 && horizon < (1ull << 31), "bad horizon");
+    rl_engine *e = q->eng;
+    uint64_t N = q->rp.N;
+    if (q->flags_cap < horizon * N) {
+      dfree(q->d_flags);
+      q->d_flags = nullptr;
+      q->flags_cap = 0;
+      q->d_flags = dalloc<uint8_t>(horizon * N);
+      q->flags_cap = horizon * N;
+    }
+    // DqnAgent::actor(Training) (dqn.rs:200-211) + Bernoulli::new(p) of rand 0.8.5: p_int = (p * 2^64) as u64,
+    // p == 1.0 always true without a draw
+    double eps = dqn_exploration_rate(q, true);
+    RL_REQUIRE(eps >= 0.0 && eps <= 1.0, "exploration rate outside [0, 1]");
+    int always = eps == 1.0 ? 1 : 0;
+    uint64_t p_int = always ? ~0ull : (uint64_t)(eps * 18446744073709551616.0);
+    launch_rollout_dqn(q->env, q->qnet, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
+    q->env->t_global += horizon;
+    q->steps_per_lane += horizon;
+    q->last_horizon = horizon;
+    int32_t err = 0;
+    d2h(e, &err, q->rp.error, sizeof(err));
+    if (err != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full: an episode outgrew the lane capacity");
+    if (stats) {
+      std::vector<uint8_t> fl(horizon * N);
+      d2h(e, fl.data(), q->d_flags, fl.size());
+      uint64_t ended = 0;
+      for (uint8_t f : fl) ended += f != RL_SUCC_CONTINUE;
+      stats->exploration_rate = eps;
+      stats->steps = horizon * N;
+      stats->episodes_ended = ended;
+    }
+  });
+}
+
+static AgentKey dqn_key(const rl_dqn *q) {
+  AgentKey k;
+  std::memcpy(k.w, q->cfg.agent_key, sizeof(k.w));
+  return k;
+}
+
+// one sample_minibatch (dqn.rs:279-314): draw episodes, gather them, compute targets
+// draw the episode lists of `n_batches` consecutive minibatches (dqn.rs:280-291) in one launch and read back their
+// sizes: the draws do not depend on the network, so the whole update needs this one host round trip
+static void dqn_draw_minibatches(rl_dqn *q, int sequential, uint32_t n_batches, std::vector<DqnCountsDev> &counts,
+                                 std::vector<uint64_t> &totals) {
+  rl_engine *e = q->eng;
+  launch_dqn_sample(e, q->rp, dqn_key(q), q->d_agent_pos, (uint32_t)q->cfg.minibatch_steps, q->max_eps,
+                    q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, sequential, n_batches);
+  counts.resize(n_batches);
+  d2h(e, counts.data(), q->d_counts, n_batches * sizeof(DqnCountsDev));
+  for (const DqnCountsDev &c : counts) {
+    if (c.error == 2)
+      throw RlError(RL_ERR_INVALID_ARGUMENT, "minibatch sampling from a lane without a complete episode");
+    if (c.error != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full");
+    RL_REQUIRE(c.n_eps <= q->max_eps && c.n_steps <= q->max_steps_mb, "minibatch exceeds its workspace");
+    RL_REQUIRE(c.n_steps > 0, "empty minibatch");
+  }
+  // the loss is a mean over all ranks' samples: sum the per-rank counts (two 16-bit halves each, exact in f32)
+  totals.resize(n_batches);
+  for (uint32_t k = 0; k < n_batches; ++k) totals[k] = counts[k].n_steps;
+  if (e->n_ranks > 1) {
+    std::vector<float> halves(2 * n_batches);
+    for (uint32_t k = 0; k < n_batches; ++k) {
+      halves[2 * k] = (float)(counts[k].n_steps & 0xffffu);
+      halves[2 * k + 1] = (float)(counts[k].n_steps >> 16);
+    }
+    RL_REQUIRE(2 * n_batches <= q->mb->Pmax, "too many minibatches for the exchange buffer");
+    h2d(e, q->mb->vec, halves.data(), halves.size() * sizeof(float));
+    rl_allreduce_sum_f32(e, q->mb->vec, halves.size());
+    d2h(e, halves.data(), q->mb->vec, halves.size() * sizeof(float));
+    for (uint32_t k = 0; k < n_batches; ++k) totals[k] = (uint64_t)halves[2 * k] + ((uint64_t)halves[2 * k + 1] << 16);
+  }
+}
+
+// gather minibatch `k` of the last draw and compute its targets (dqn.rs:293-314)
+static void dqn_build_minibatch(rl_dqn *q, uint32_t k, const DqnCountsDev &c, uint64_t total) {
+  q->last_n_eps = c.n_eps;
+  q->last_n_steps = c.n_steps;
+  q->last_total_steps = total;
+  q->last_batch_index = k;
+  rl_traj *mb = q->mb;
+  mb->d.n = c.n_steps;
+  mb->d.T = 1;
+  traj_plan(mb, c.n_steps);
+  const size_t o = (size_t)k * q->max_eps;
+  launch_dqn_build_minibatch(q->eng, q->rp, c.n_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o,
+                             q->d_ep_off + o, mb->d.obs, (size_t)2 * c.n_steps, mb->d.action, mb->d.adv,
+                             q->cfg.discount_factor, q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD ? 1 : 0, q->qnet);
+}
+
+static void dqn_sample_minibatch(rl_dqn *q, int sequential) {
+  std::vector<DqnCountsDev> counts;
+  std::vector<uint64_t> totals;
+  dqn_draw_minibatches(q, sequential, 1, counts, totals);
+  dqn_build_minibatch(q, 0, counts[0], totals[0]);
+}
+
+// gradient of mean((Q(s)[a] - target)^2) over the current minibatch -> mb->vec[0..P), loss sum -> mb->vec[P]
+// `step_opt` != nullptr: also take the optimiser step, recording the loss in slot `loss_slot`; without an all-reduce
+// between them the reduction and the (elementwise) step are one launch
+static void dqn_gradient(rl_dqn *q, rl_adam *step_opt = nullptr, int loss_slot = -1) {
+  rl_traj *mb = q->mb;
+  uint32_t P = (uint32_t)q->qnet->P;
+  uint32_t rowsA, rowsB;
+  if (q->eng->kernel_variant != 1 && launch_policy_v2(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr)) {
+    rowsA = rowsB = mb->nbV2;
+  } else {
+    launch_policy_pass(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr);
+    launch_mlp_backward(mb, q->qnet, nullptr);
+    rowsA = mb->nbA;
+    rowsB = mb->nbB;
+  }
+  if (step_opt && !q->eng->has_collective()) {
+    launch_reduce_adam(mb, step_opt, rowsA, rowsB, loss_slot, q->last_total_steps);
+    return;
+  }
+  launch_reduce(mb, P, true, true, rowsA, rowsB);
+  rl_allreduce_sum_f32(q->eng, mb->vec, P + 4);
+  if (step_opt) launch_adam_step(mb, step_opt, loss_slot, q->last_total_steps);
+}
+
+int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q, "NULL argument");
+    rl_engine *e = q->eng;
+    // self.global_steps = sum of total_step_count over the buffers (dqn.rs:276); every lane of every rank has
+    // taken the same number of steps and the horizon rule drops none
+    q->global_steps = q->steps_per_lane * (uint64_t)q->rp.N * (uint64_t)e->n_ranks;
+    uint64_t K = q->cfg.opt_steps_per_update;
+    std::vector<DqnCountsDev> counts;
+    std::vector<uint64_t> totals;
+    if (K) dqn_draw_minibatches(q, 0, (uint32_t)K, counts, totals);
+    for (uint64_t k = 0; k < K; ++k) {
+      dqn_build_minibatch(q, (uint32_t)k, counts[k], totals[k]);
+      dqn_gradient(q, q->opt, (int)k);
+    }
+    std::vector<float> h(K ? K : 1, 0.0f);
+    if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
+    if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
+    if (stats) {
+      stats->opt_steps = K;
+      stats->loss_first = K ? (double)h[0] : 0.0;
+      stats->loss_last = K ? (double)h[K - 1] : 0.0;
+      stats->global_steps = q->global_steps;
+      stats->last_minibatch_steps = q->last_n_steps;
+      stats->last_minibatch_episodes = q->last_n_eps;
+    }
+  });
+}
+
+static void replay_field(const rl_dqn *q, int32_t field, void **ptr, uint64_t *bytes) {
+  const ReplayDev &r = q->rp;
+  uint64_t N = r.N, C = r.C, E = r.E, D = r.D;
+  switch (field) {
+    case RL_REPLAY_HEAD: *ptr = r.head; *bytes = N * 4; break;
+    case RL_REPLAY_COUNT: *ptr = r.count; *bytes = N * 4; break;
+    case RL_REPLAY_EP_HEAD: *ptr = r.ep_head; *bytes = N * 4; break;
+    case RL_REPLAY_EP_COUNT: *ptr = r.ep_count; *bytes = N * 4; break;
+    case RL_REPLAY_TOTAL: *ptr = r.total; *bytes = N * 4; break;
+    case RL_REPLAY_EP_END: *ptr = r.ep_end; *bytes = E * N * 4; break;
+    case RL_REPLAY_OBS: *ptr = r.obs; *bytes = D * C * N * 4; break;
+    case RL_REPLAY_NEXT_OBS: *ptr = r.next_obs; *bytes = D * C * N * 4; break;
+    case RL_REPLAY_ACTION: *ptr = r.action; *bytes = C * N; break;
+    case RL_REPLAY_REWARD: *ptr = r.reward; *bytes = C * N * 4; break;
+    case RL_REPLAY_FLAG: *ptr = r.flag; *bytes = C * N; break;
+    case RL_REPLAY_ACTOR_POS: *ptr = r.actor_pos; *bytes = N * 8; break;
+    case RL_REPLAY_LAST_FLAGS: *ptr = q->d_flags; *bytes = q->last_horizon * N; break;
+    default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown replay field");
+  }
+}
+
+int32_t rl_dqn_replay_field_bytes(const rl_dqn *q, int32_t field, uint64_t *bytes) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && bytes, "NULL argument");
+    void *p;
+    replay_field(q, field, &p, bytes);
+  });
+}
+
+int32_t rl_dqn_replay_read(rl_dqn *q, int32_t field, void *host, uint64_t bytes) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && host, "NULL argument");
+    void *p;
+    uint64_t need;
+    replay_field(q, field, &p, &need);
+    RL_REQUIRE(bytes == need, "byte count mismatch for replay field");
+    if (bytes) d2h(q->eng, host, p, bytes);
+  });
+}
+
+int32_t rl_dqn_minibatch_sample(rl_dqn *q, int32_t sequential, uint64_t *n_episodes_out, uint64_t *n_steps_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q, "NULL argument");
+    dqn_sample_minibatch(q, sequential);
+    if (n_episodes_out) *n_episodes_out = q->last_n_eps;
+    if (n_steps_out) *n_steps_out = q->last_n_steps;
+  });
+}
+
+int32_t rl_dqn_minibatch_read(rl_dqn *q, int32_t field, void *host, uint64_t bytes) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && host, "NULL argument");
+    uint64_t ne = q->last_n_eps, ns = q->last_n_steps, D = q->rp.D;
+    RL_REQUIRE(ns > 0, "no minibatch has been sampled");
+    rl_engine *e = q->eng;
+    switch (field) {
+      case RL_MB_EP_LANE: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_lane + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_EP_START: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_start + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_EP_LEN: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_len + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_EP_OFFSET: RL_REQUIRE(bytes == ne * 4, "byte count mismatch"); d2h(e, host, q->d_ep_off + (size_t)q->last_batch_index * q->max_eps, bytes); break;
+      case RL_MB_OBS: {
+        RL_REQUIRE(bytes == D * ns * 4, "byte count mismatch");
+        // feature planes are 2 * n_steps apart in the workspace (T = 1 trajectory layout)
+        for (uint64_t d = 0; d < D; ++d)
+          d2h(e, (char *)host + d * ns * 4, q->mb->d.obs + d * 2 * ns, ns * 4);
+        break;
+      }
+      case RL_MB_ACTION: RL_REQUIRE(bytes == ns, "byte count mismatch"); d2h(e, host, q->mb->d.action, bytes); break;
+      case RL_MB_TARGET: RL_REQUIRE(bytes == ns * 4, "byte count mismatch"); d2h(e, host, q->mb->d.adv, bytes); break;
+      default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown minibatch field");
+    }
+  });
+}
+
+int32_t rl_dqn_minibatch_gradient(rl_dqn *q, float *grad_out, float *loss_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && grad_out, "NULL argument");
+    RL_REQUIRE(q->last_n_steps > 0, "no minibatch has been sampled");
+    uint32_t P = (uint32_t)q->qnet->P;
+    dqn_gradient(q);
+    std::vector<float> h(P + 4);
+    d2h(q->eng, h.data(), q->mb->vec, (P + 4) * sizeof(float));
+    std::memcpy(grad_out, h.data(), P * sizeof(float));
+    if (loss_out) *loss_out = (float)((double)h[P] / (double)q->last_total_steps);
+  });
+}
+
+int32_t rl_dqn_agent_rng_pos(rl_dqn *q, uint64_t *pos_out) {
+  return guarded(q ? q->eng : nullptr, [&] {
+    RL_REQUIRE(q && pos_out, "NULL argument");
+    d2h(q->eng, pos_out, q->d_agent_pos, sizeof(uint64_t));
+  });
+}
+
+}  // extern "C"

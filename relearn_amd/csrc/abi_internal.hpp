@@ -1,0 +1,76 @@
+// abi_internal.hpp — what the translation units of the C ABI (abi*.hip) share: error plumbing, device-memory and
+// copy helpers, and the few functions defined in one unit and used by another.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rl_chacha.h"
+#include "../../include/rl_detmath.h"
+#include "engine.hpp"
+#include "host/cbor.hpp"
+#include "kernels.hpp"
+
+// ---------------------------------------------------------------- error plumbing
+extern thread_local std::string g_last_error_no_engine;  // abi.hip
+
+template <typename F>
+static inline int32_t guarded(rl_engine *eng, F &&f) {
+  try {
+    f();
+    if (eng != nullptr) {
+      // a kernel that could not be launched (bad configuration, out of resources) leaves only a sticky error behind
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) throw RlError(RL_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
+    }
+    return RL_OK;
+  } catch (const RlError &e) {
+    (eng ? eng->last_error : g_last_error_no_engine) = e.what();
+    return e.code;
+  } catch (const std::exception &e) {
+    (eng ? eng->last_error : g_last_error_no_engine) = e.what();
+    return RL_ERR_INVALID_ARGUMENT;
+  } catch (...) {
+    (eng ? eng->last_error : g_last_error_no_engine) = "unknown error";
+    return RL_ERR_INVALID_ARGUMENT;
+  }
+}
+
+template <typename T>
+static inline T *dalloc(size_t count) {
+  void *p = nullptr;
+  RL_HIP_CHECK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+  return (T *)p;
+}
+
+static inline void dfree(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------- helpers
+static inline uint64_t b_total(const rl_traj *t) { return t->B * (uint64_t)t->eng->n_ranks; }
+
+static inline void sync(rl_engine *e) { RL_HIP_CHECK(hipStreamSynchronize(e->stream)); }
+
+static inline void h2d(rl_engine *e, void *d, const void *h, size_t bytes) {
+  RL_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
+  sync(e);
+}
+
+static inline void d2h(rl_engine *e, void *h, const void *d, size_t bytes) {
+  RL_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, e->stream));
+  sync(e);
+}
+
+// ---------------------------------------------------------------- shared between the units (C linkage like the entry
+// points they sit next to)
+extern "C" {
+// abi.hip
+void engine_release_child(rl_engine *e);
+void traj_plan(rl_traj *t, uint64_t B);
+rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, bool resizable);
+void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training);
+}

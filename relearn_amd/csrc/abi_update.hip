@@ -1,0 +1,426 @@
+// abi_update.hip — extern "C" entry points of include/relearn_hip.h, part: policy / critic updates (TRPO, PPO, REINFORCE, value fitting) (host side only; kernels live in kernels_*.hip).
+#include "abi_internal.hpp"
+
+extern "C" {
+
+// ---------------------------------------------------------------- recurrent gradient passes
+// policy: teacher-forced forward (activation record) -> d loss / d logits -> [backward through time -> weight
+// gradients -> reduce] -> traj->vec[0..P) and the per-sample sums in vec[P..P+4)
+static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backward, float lo, float hi) {
+  seq_ensure(traj, policy, true);
+  uint32_t P = (uint32_t)policy->P;
+  launch_gru_seq_forward(traj, policy, traj->seq.out, nullptr, backward ? traj->seq.act : nullptr);
+  launch_seq_policy_dlogits(traj, mode, b_total(traj), lo, hi);
+  if (backward) launch_gru_backward(traj, policy);
+  launch_reduce(traj, P, false, true, 0, traj->nbB);
+  if (backward) rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+  else rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
+}
+
+// (loss, KL) of the current parameters against log pi_0: forward without a record -> sums in vec[P..P+4)
+static void seq_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
+  seq_ensure(traj, policy, true);
+  uint32_t P = (uint32_t)policy->P;
+  launch_gru_seq_forward(traj, policy, traj->seq.out, nullptr, nullptr, d_skip);
+  launch_seq_policy_dlogits(traj, PASS_EVAL, b_total(traj), 0.0f, 0.0f, d_skip);
+  launch_reduce(traj, P, false, true, 0, traj->nbB);
+  rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
+}
+
+// Fisher-vector product with the tangent d_v at the parameters whose activation record is in place (the last
+// seq_policy_pass with backward = true): vec[0..P) <- J^T (diag(p) - p p^T) J v / B
+static void seq_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
+  seq_ensure(traj, policy, true);
+  launch_gru_tangent(traj, policy, d_v, b_total(traj), d_skip);
+  launch_gru_backward(traj, policy, d_skip);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, (uint32_t)policy->P);
+}
+
+static void seq_critic_pass(rl_mlp *critic, rl_traj *traj) {
+  seq_ensure(traj, critic, true);
+  uint32_t P = (uint32_t)critic->P;
+  launch_gru_seq_forward(traj, critic, traj->seq.out, nullptr, traj->seq.act);
+  launch_seq_critic_dvalues(traj, b_total(traj));
+  launch_gru_backward(traj, critic);
+  launch_reduce(traj, P, false, true, 0, traj->nbB);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+// ---------------------------------------------------------------- TRPO
+int32_t rl_trpo_config_default(rl_trpo_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    // ConjugateGradientOptimizerConfig::default (conjugate_gradient.rs:55-65), TrpoConfig::default (trpo.rs:29-41)
+    c->iterations = 10;
+    c->max_backtracks = 15;
+    c->backtrack_ratio = 0.8;
+    c->hpv_reg_coeff = 1e-5;
+    c->max_policy_step_kl = 0.01;
+    c->accept_violation = 0;
+  });
+}
+
+static void check_policy(const rl_mlp *policy, const rl_traj *traj) {
+  RL_REQUIRE(policy && traj, "NULL argument");
+  RL_REQUIRE(policy->eng == traj->eng, "handles belong to different engines");
+  RL_REQUIRE(policy->in_dim == traj->d.D && policy->out_dim == 2, "policy shape does not match the trajectory");
+}
+
+// gradient pass: PASS_INIT -> backward -> reduce(A+B) -> allreduce
+static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_pass(policy, traj, PASS_INIT, true, 0.0f, 0.0f);
+  uint32_t P = (uint32_t)policy->P;
+  if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
+    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr);
+    launch_mlp_backward(traj, policy, nullptr);
+    launch_reduce(traj, P, true, true, traj->nbA, traj->nbB);
+  }
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+// (loss, KL) of the current parameters against lp0: PASS_EVAL -> reduce(B) -> allreduce
+static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_eval(policy, traj, d_skip);
+  uint32_t P = (uint32_t)policy->P;
+  if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
+    launch_reduce(traj, P, false, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip);
+    launch_reduce(traj, P, false, true, traj->nbA, traj->nbB);
+  }
+  rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
+}
+
+// Fisher/Hessian-vector product pass with tangent d_v: PASS_JVP -> backward -> reduce(A) -> allreduce
+static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_fvp(policy, traj, d_v, d_skip);
+  uint32_t P = (uint32_t)policy->P;
+  if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
+    launch_reduce(traj, P, true, false, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip);
+    launch_mlp_backward(traj, policy, d_skip);
+    launch_reduce(traj, P, true, false, traj->nbA, traj->nbB);
+  }
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P);
+}
+
+int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(cfg && stats, "NULL argument");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj);
+    float reg = (float)cfg->hpv_reg_coeff;
+    // loss gradient at theta0 and CG prologue
+    run_policy_gradient(policy, traj);
+    launch_trpo_begin(traj, policy, Bt);
+    // x = A^-1 g by `iterations` CG steps (early exit handled on the device)
+    for (uint64_t it = 0; it < cfg->iterations; ++it) {
+      run_policy_fvp(policy, traj, traj->cg_p, &traj->trpo->cg_done);
+      launch_cg_step(traj, P, reg, 1e-10f);
+    }
+    launch_cg_finish(traj, P);
+    // step size from x^T A x
+    run_policy_fvp(policy, traj, traj->cg_x, nullptr);
+    launch_step_size(traj, policy, reg, cfg->max_policy_step_kl);
+    // backtracking line search
+    double ratio = 1.0;
+    for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
+      if (i > 0) ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
+      launch_ls_set_params(traj, policy, ratio);
+      run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
+      launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
+    }
+    launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
+    TrpoStateDev h;
+    d2h(e, &h, traj->trpo, sizeof(h));
+    stats->entropy = (double)h.entropy;
+    stats->step_size = h.step_size;
+    stats->loss_initial = (double)h.loss0;
+    stats->loss_final = (double)h.ls_loss;
+    stats->constraint_val_final = (double)h.ls_kl;
+    stats->step_scale = h.ls_accepted ? h.ls_ratio : 0.0;
+    stats->num_backtracks = h.ls_accepted ? (int64_t)h.ls_index : -1;
+    stats->status = h.status;
+    stats->cg_iterations = h.cg_iters;
+    if (h.status == RL_OPT_NAN_LOSS || h.status == RL_OPT_NAN_CONSTRAINT)
+      throw RlError(RL_ERR_OPT_NAN, h.status == RL_OPT_NAN_LOSS ? "NaN loss in policy optimization"
+                                                                : "NaN constraint in policy optimization");
+  });
+}
+
+int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float *loss_out, float *entropy_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(grad_out, "grad_out is NULL");
+    uint32_t P = (uint32_t)policy->P;
+    run_policy_gradient(policy, traj);
+    std::vector<float> h(P + 4);
+    d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
+    std::memcpy(grad_out, h.data(), P * sizeof(float));
+    double inv_B = 1.0 / (double)b_total(traj);
+    if (loss_out) *loss_out = (float)(-((double)h[P] * inv_B));
+    if (entropy_out) *entropy_out = (float)((double)h[P + 1] * inv_B);
+  });
+}
+
+int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, float *out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(v && out, "NULL argument");
+    uint32_t P = (uint32_t)policy->P;
+    run_policy_gradient(policy, traj);  // the product is taken at the current parameters: refresh log pi_0
+    h2d(traj->eng, traj->cg_x, v, P * sizeof(float));  // (the recurrent pass above has grown the workspace)
+    run_policy_fvp(policy, traj, traj->cg_x, nullptr);
+    std::vector<float> h(P);
+    d2h(traj->eng, h.data(), traj->vec, P * sizeof(float));
+    for (uint32_t i = 0; i < P; ++i) out[i] = h[i] + reg * v[i];
+  });
+}
+
+int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, float *loss_out, float *kl_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(params0 && loss_out && kl_out, "NULL argument");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj);
+    // lp0 under params0, then evaluate the current parameters against it
+    std::vector<float> cur(P);
+    d2h(e, cur.data(), policy->d_params, P * sizeof(float));
+    h2d(e, policy->d_params, params0, P * sizeof(float));
+    run_policy_gradient(policy, traj);  // fills lp0 under params0
+    h2d(e, policy->d_params, cur.data(), P * sizeof(float));
+    run_policy_eval(policy, traj, nullptr);
+    float h[4];
+    d2h(e, h, traj->vec + P, sizeof(h));
+    double inv_B = 1.0 / (double)Bt;
+    *loss_out = (float)(-((double)h[0] * inv_B));
+    *kl_out = (float)((double)h[1] * inv_B);
+  });
+}
+
+// ---------------------------------------------------------------- critic
+int32_t rl_adam_config_default(rl_adam_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    c->learning_rate = 1e-3;  // AdamConfig::default (coptimizer.rs:147-156)
+    c->beta1 = 0.9;
+    c->beta2 = 0.999;
+    c->weight_decay = 0.0;
+    c->eps = 1e-8;  // libtorch AdamOptions default
+  });
+}
+
+int32_t rl_adam_create(rl_mlp *module, const rl_adam_config *cfg, rl_adam **out) {
+  return guarded(module ? module->eng : nullptr, [&] {
+    RL_REQUIRE(module && cfg && out, "NULL argument");
+    *out = nullptr;
+    rl_engine *e = module->eng;
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_adam> o(new rl_adam());
+    o->eng = e;
+    o->mod = module;
+    o->cfg = *cfg;
+    o->d_m = dalloc<float>(module->P);
+    o->d_v = dalloc<float>(module->P);
+    o->d_step = dalloc<uint64_t>(1);
+    RL_HIP_CHECK(hipMemsetAsync(o->d_m, 0, module->P * sizeof(float), e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(o->d_v, 0, module->P * sizeof(float), e->stream));
+    RL_HIP_CHECK(hipMemsetAsync(o->d_step, 0, sizeof(uint64_t), e->stream));
+    sync(e);
+    e->live_handles += 1;
+    *out = o.release();
+  });
+}
+
+int32_t rl_adam_destroy(rl_adam *o) {
+  if (!o) return RL_OK;
+  (void)hipSetDevice(o->eng->device);
+  (void)hipStreamSynchronize(o->eng->stream);
+  dfree(o->d_m);
+  dfree(o->d_v);
+  dfree(o->d_step);
+  rl_engine *eng = o->eng;
+  delete o;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_adam_step_host(rl_adam *o, const float *grad) {
+  return guarded(o ? o->mod->eng : nullptr, [&] {
+    RL_REQUIRE(o && grad, "NULL argument");
+    rl_engine *e = o->mod->eng;
+    float *d_g = dalloc<float>(o->mod->P);
+    try {
+      h2d(e, d_g, grad, o->mod->P * sizeof(float));
+      launch_adam_step_vec(o, d_g);
+      sync(e);
+    } catch (...) {
+      dfree(d_g);
+      throw;
+    }
+    dfree(d_g);
+  });
+}
+
+static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
+  RL_REQUIRE(critic && traj, "NULL argument");
+  RL_REQUIRE(critic->eng == traj->eng, "handles belong to different engines");
+  RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
+}
+
+// per-workgroup partial sums of the critic's MSE gradient and loss -> slabA / slabB (feed-forward modules)
+static void critic_slabs(rl_mlp *critic, rl_traj *traj, uint32_t *rowsA, uint32_t *rowsB) {
+  if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
+    *rowsA = *rowsB = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbC;
+  } else {
+    launch_critic_fwd(traj, critic, b_total(traj));
+    launch_mlp_backward(traj, critic, nullptr);
+    *rowsA = traj->nbA;
+    *rowsB = traj->nbB;
+  }
+}
+
+static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
+  if (critic->kind == RL_MODULE_GRU_MLP) return seq_critic_pass(critic, traj);
+  uint32_t P = (uint32_t)critic->P, rowsA, rowsB;
+  critic_slabs(critic, traj, &rowsA, &rowsB);
+  launch_reduce(traj, P, true, true, rowsA, rowsB);
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
+                         float *losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_critic(critic, traj);
+    RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
+    RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
+    uint64_t Bt = b_total(traj);
+    const bool fused = critic->kind == RL_MODULE_MLP && !traj->eng->has_collective();
+    for (uint64_t k = 0; k < opt_steps; ++k) {
+      if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
+        uint32_t rowsA, rowsB;
+        critic_slabs(critic, traj, &rowsA, &rowsB);
+        launch_reduce_adam(traj, opt, rowsA, rowsB, (int)k, Bt);
+      } else {
+        run_critic_gradient(critic, traj);
+        launch_adam_step(traj, opt, (int)k, Bt);
+      }
+    }
+    if (stats || losses_out) {
+      std::vector<float> h(opt_steps ? opt_steps : 1);
+      if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
+      if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
+      if (stats) {
+        stats->steps = opt_steps;
+        stats->loss_first = opt_steps ? (double)h[0] : 0.0;
+        stats->loss_last = opt_steps ? (double)h[opt_steps - 1] : 0.0;
+      }
+    }
+  });
+}
+
+int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_critic(critic, traj);
+    RL_REQUIRE(grad_out, "grad_out is NULL");
+    uint32_t P = (uint32_t)critic->P;
+    run_critic_gradient(critic, traj);
+    std::vector<float> h(P + 4);
+    d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
+    std::memcpy(grad_out, h.data(), P * sizeof(float));
+    if (loss_out) *loss_out = (float)((double)h[P] / (double)b_total(traj));
+  });
+}
+
+// ---------------------------------------------------------------- PPO / REINFORCE / RewardToGo
+int32_t rl_ppo_config_default(rl_ppo_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    c->opt_steps_per_update = 10;  // PpoConfig::default (ppo.rs:27-41)
+    c->clip_distance = 0.2;
+  });
+}
+
+// PASS_PPO gradient of the clipped surrogate against lp0 -> vec[0..P), sum of min(...) -> vec[P]
+static void run_policy_ppo(rl_mlp *policy, rl_traj *traj, float lo, float hi) {
+  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_pass(policy, traj, PASS_PPO, true, lo, hi);
+  uint32_t P = (uint32_t)policy->P;
+  if (traj->eng->kernel_variant != 1 &&
+      launch_policy_v2(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi)) {
+    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+  } else {
+    launch_policy_pass(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi);
+    launch_mlp_backward(traj, policy, nullptr);
+    launch_reduce(traj, P, true, true, traj->nbA, traj->nbB);
+  }
+  rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
+}
+
+int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_config *cfg,
+                      rl_policy_opt_stats *stats, float *losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(opt && opt->mod == policy, "optimizer does not belong to this module");
+    RL_REQUIRE(cfg, "cfg is NULL");
+    RL_REQUIRE(cfg->opt_steps_per_update <= traj->max_losses, "too many optimisation steps per update");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj), K = cfg->opt_steps_per_update;
+    // initial_log_probs and the logged entropy (ppo.rs:107-118): the PASS_INIT pass stores log pi_0
+    if (policy->kind == RL_MODULE_GRU_MLP) seq_policy_pass(policy, traj, PASS_INIT, false, 0.0f, 0.0f);
+    else run_policy_gradient(policy, traj);
+    float h0[4];
+    d2h(e, h0, traj->vec + P, sizeof(h0));
+    // clip(1 - d, 1 + d): f64 scalars applied to a Float tensor
+    float lo = (float)(1.0 - cfg->clip_distance), hi = (float)(1.0 + cfg->clip_distance);
+    for (uint64_t k = 0; k < K; ++k) {
+      run_policy_ppo(policy, traj, lo, hi);
+      launch_adam_step(traj, opt, (int)k, Bt);
+    }
+    std::vector<float> h(K ? K : 1, 0.0f);
+    if (K) d2h(e, h.data(), traj->losses, K * sizeof(float));
+    for (auto &v : h) v = -v;  // loss = -mean(min(...))
+    if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
+    if (stats) {
+      stats->entropy = (double)h0[1] / (double)Bt;
+      stats->steps = K;
+      stats->loss_first = K ? (double)h[0] : 0.0;
+      stats->loss_last = K ? (double)h[K - 1] : 0.0;
+    }
+  });
+}
+
+int32_t rl_reinforce_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, rl_policy_opt_stats *stats) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(opt && opt->mod == policy, "optimizer does not belong to this module");
+    rl_engine *e = traj->eng;
+    uint32_t P = (uint32_t)policy->P;
+    uint64_t Bt = b_total(traj);
+    // d(-mean(log pi(a) A))/d theta equals the surrogate gradient at ratio = 1 that PASS_INIT computes
+    run_policy_gradient(policy, traj);
+    float h0[4];
+    d2h(e, h0, traj->vec + P, sizeof(h0));
+    launch_adam_step(traj, opt, -1, Bt);
+    if (stats) {
+      stats->entropy = (double)h0[1] / (double)Bt;
+      stats->steps = 1;
+      stats->loss_first = stats->loss_last = -((double)h0[2] / (double)Bt);
+    }
+  });
+}
+
+int32_t rl_reward_to_go(rl_traj *traj, float gamma) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    RL_REQUIRE(traj, "NULL argument");
+    launch_gae(traj, nullptr, gamma, 0.0f);
+  });
+}
+
+}  // extern "C"
