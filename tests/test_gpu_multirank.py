@@ -124,11 +124,15 @@ def run_bench(world, extra_env=None):
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--envs", "2048", "--horizon", "32",
             "--critic-steps", "5", "--no-cpu-baseline"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    import socket
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     if world == 1:
         cmd = [sys.executable, os.path.join(root, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py")] + args
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py")] + args
     out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
