@@ -150,6 +150,51 @@ __device__ __forceinline__ void mlp_forward_lane(const float *__restrict__ param
   }
 }
 
+// The same forward with the parameters parked in LDS as one 8-float record per hidden unit {W1[j][0..D), pad, b1[j],
+// W2[0][j], W2[1][j]} (two 16-byte broadcast reads per unit instead of a stream of scalar loads); `pk` also holds b2
+// behind the H records.  Same chain order as mlp_forward_lane: the results are bit-identical.
+template <int D>
+__device__ __forceinline__ void mlp_pack_lds(float *__restrict__ pk, const float *__restrict__ params, int H, int tid,
+                                             int nthreads) {
+  const float *__restrict__ W1 = params;
+  const float *__restrict__ b1 = W1 + H * D;
+  const float *__restrict__ W2 = b1 + H;
+  const float *__restrict__ b2 = W2 + 2 * H;
+  for (int q = tid; q < 8 * H + 2; q += nthreads) {
+    float v = 0.0f;
+    if (q >= 8 * H) {
+      v = b2[q - 8 * H];
+    } else {
+      const int j = q >> 3, k = q & 7;
+      if (k < D) v = W1[j * D + k];
+      else if (k == 5) v = b1[j];
+      else if (k == 6) v = W2[j];
+      else if (k == 7) v = W2[H + j];
+    }
+    pk[q] = v;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void mlp_forward_lane_lds(const float *__restrict__ pk, int H, const float (&x)[D],
+                                                     float (&z)[2]) {
+  static_assert(D <= 5, "the packed record holds at most five input weights");
+  z[0] = pk[8 * H];
+  z[1] = pk[8 * H + 1];
+#pragma unroll 8
+  for (int j = 0; j < H; ++j) {
+    const float4 lo = *reinterpret_cast<const float4 *>(pk + 8 * j);
+    const float4 hi = *reinterpret_cast<const float4 *>(pk + 8 * j + 4);
+    const float w[5] = {lo.x, lo.y, lo.z, lo.w, hi.x};
+    float acc = hi.y;
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(x[k], w[k], acc);
+    const float h = acc > 0.0f ? acc : 0.0f;
+    z[0] = __builtin_fmaf(h, hi.z, z[0]);
+    z[1] = __builtin_fmaf(h, hi.w, z[1]);
+  }
+}
+
 // Categorical::new: log_softmax (torch/distributions/categorical.rs:29-33)
 template <int A>
 __device__ __forceinline__ void log_softmax_lane(const float (&z)[A], float (&lp)[A]) {

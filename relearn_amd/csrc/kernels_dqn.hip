@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
                                                                 uint64_t p_int, int always_explore,
                                                                 uint8_t *__restrict__ flags_out) {
   __shared__ uint32_t words[16 * BLOCK];
+  __shared__ __attribute__((aligned(16))) float pk[8 * 128 + 4];  // the Q-network, one 8-float record per hidden unit
   const uint32_t n = rp.N;
+  mlp_pack_lds<D>(pk, qnet, H, threadIdx.x, BLOCK);
+  __syncthreads();
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint64_t lane = c.lane_offset + i;
@@ -81,7 +84,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
       }
     } else {
       float z[2];
-      mlp_forward_lane<D, 2>(qnet, H, f, z);
+      mlp_forward_lane_lds<D>(pk, H, f, z);
       a = z[1] > z[0] ? 1 : 0;  // argmax: first maximal index
     }
     int succ = cp_step(c, s, a);

@@ -68,7 +68,10 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
                                                             const float *__restrict__ policy, int H,
                                                             uint64_t t_global) {
   __shared__ uint32_t actor_words[16 * BLOCK];
+  __shared__ __attribute__((aligned(16))) float pk[8 * 128 + 4];  // the policy, one 8-float record per hidden unit
   const uint32_t n = tr.n, T = tr.T;
+  mlp_pack_lds<D>(pk, policy, H, threadIdx.x, BLOCK);
+  __syncthreads();
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;  // no barrier is used below, early exit is safe
   const uint64_t lane = c.lane_offset + i;
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
     }
     float u = rl_u32_to_unit_f32(actor_words[(uint32_t)(w & 15) * BLOCK + threadIdx.x]);
     float z[2], lp[2];
-    mlp_forward_lane<D, 2>(policy, H, f, z);
+    mlp_forward_lane_lds<D>(pk, H, f, z);
     log_softmax_lane<2>(z, lp);
     int a = categorical_sample_lane<2>(lp, u);
     int succ = cp_step(c, s, a);

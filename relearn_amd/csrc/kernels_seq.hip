@@ -509,7 +509,10 @@ template <int D, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_rollout_chain_mlp(CartPoleDev c, EnvStateDev st, TrajDev tr,
                                                              const float *__restrict__ policy, int H,
                                                              uint64_t t_global) {
+  __shared__ __attribute__((aligned(16))) float pk[8 * 128 + 4];  // the policy, one 8-float record per hidden unit
   const uint32_t n = tr.n, T = tr.T;
+  mlp_pack_lds<D>(pk, policy, H, threadIdx.x, BLOCK);
+  __syncthreads();
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint64_t glane = c.lane_offset + i;
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_chain_mlp(CartPoleDev c, EnvS
     const uint64_t word = t_global + t;
     const float u = rl_u32_to_unit_f32(stream_word(c.key_actor, glane, word));
     float z[2], lp[2];
-    mlp_forward_lane<D, 2>(policy, H, f, z);
+    mlp_forward_lane_lds<D>(pk, H, f, z);
     log_softmax_lane<2>(z, lp);
     const int a = categorical_sample_lane<2>(lp, u);
     float rew;
