@@ -100,10 +100,12 @@ class CriticStats(C.Structure):
     _fields_ = [("loss_first", C.c_double), ("loss_last", C.c_double), ("steps", C.c_uint64)]
 
 
-def build(force=False):
-    """Compile librelearn_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    # always through make: a no-op when the library is newer than every source, a rebuild of what changed otherwise
-    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
+def build(force=False, check=False):
+    """Compile librelearn_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  `check`: go through make even
+    when the library exists (a no-op when it is newer than every source) — what `__graft_entry__.build()` does; the
+    default leaves an existing library alone, so that a process which has it loaded never relinks it under itself."""
+    if force or check or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
     return LIB_PATH
 
 
