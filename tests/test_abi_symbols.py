@@ -75,3 +75,16 @@ def test_product_does_not_touch_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 bad = re.findall(r"import\s+oracle|from\s+oracle|#include\s*[<\"][^>\"]*oracle|liboracle|oracle/", src)
                 assert not bad, (os.path.join(dirpath, f), bad)
+
+
+def test_integration_doc_binds_every_symbol():
+    """INTEGRATION.md shows the reference-side `extern "C"` block: it must name every function the header declares
+    (a maintainer copying it gets the complete surface, and the struct layouts it shows are the current ones)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "relearn_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    declared = sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", header)))
+    assert [s for s in declared if "fn %s(" % s not in doc] == []
+    for field in ("chain_size", "memory_num_actions", "memory_history_len"):  # rl_env_config's latest fields
+        assert field in doc
