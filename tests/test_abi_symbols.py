@@ -88,3 +88,31 @@ def test_integration_doc_binds_every_symbol():
     assert [s for s in declared if "fn %s(" % s not in doc] == []
     for field in ("chain_size", "memory_num_actions", "memory_history_len"):  # rl_env_config's latest fields
         assert field in doc
+
+
+def test_integration_doc_struct_layouts_match_the_header():
+    """every plain-data struct of the header appears in INTEGRATION.md as #[repr(C)] with the same fields in the same order"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "relearn_hip.h")).read().split("\n")
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    rust = {}
+    for m in re.finditer(r"pub struct (rl_[a-z_]+)\s*\{(.*?)\}", doc, re.S):
+        rust[m.group(1)] = re.findall(r"pub ([a-z_0-9]+)\s*:", re.sub(r"//.*", "", m.group(2)))
+    checked = 0
+    for end, line in enumerate(header):
+        m = re.match(r"\} (rl_[a-z_]+);", line)
+        if not m:
+            continue
+        start = max(i for i in range(end) if header[i].startswith("typedef "))
+        if not header[start].startswith("typedef struct {"):
+            continue  # an enum
+        body = re.sub(r"/\*.*?\*/", "", "\n".join(header[start + 1:end]), flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                fields += [re.sub(r"\[.*\]", "", n).strip() for n in decl.split(None, 1)[1].split(",")]
+        assert rust.get(m.group(1)) == fields, (m.group(1), fields, rust.get(m.group(1)))
+        checked += 1
+    assert checked >= 11
