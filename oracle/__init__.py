@@ -91,7 +91,16 @@ class Features(C.Structure):
 
 
 class GruShape(C.Structure):
-    _fields_ = [("in_dim", C.c_uint32), ("hidden", C.c_uint32), ("mlp_hidden", C.c_uint32), ("out_dim", C.c_uint32)]
+    """shape of a recurrent chain module; `cell`: CELL_GRU (default) or CELL_LSTM"""
+    _fields_ = [("in_dim", C.c_uint32), ("hidden", C.c_uint32), ("mlp_hidden", C.c_uint32), ("out_dim", C.c_uint32),
+                ("cell", C.c_uint32)]
+
+
+CELL_GRU, CELL_LSTM = 0, 1
+
+
+def LstmShape(in_dim, hidden, mlp_hidden, out_dim):
+    return GruShape(in_dim, hidden, mlp_hidden, out_dim, CELL_LSTM)
 
 
 class MemoryGame(C.Structure):

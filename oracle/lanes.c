@@ -194,7 +194,7 @@ void oracle_lanes_rollout_gru(oracle_lanes *l, oracle_gru_shape ps, const float 
     oracle_prng_set_stream(&act_rng, l->lane_offset + i);
     oracle_prng_set_word_pos(&act_rng, l->t_global);
     float f[5], tf[5], z[16], lp[16];
-    float *h = (float *)calloc(ps.hidden, sizeof(float));
+    float *h = (float *)calloc((size_t)2 * ps.hidden, sizeof(float)); /* [h] or [h; c] */
     for (uint64_t t = 0; t < T; ++t) {
       oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
       for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + t) * n + i] = f[d];
@@ -209,7 +209,7 @@ void oracle_lanes_rollout_gru(oracle_lanes *l, oracle_gru_shape ps, const float 
       flag[t * n + i] = (uint8_t)succ;
       if (succ == ORACLE_INTERRUPT && term_obs)
         for (uint32_t d = 0; d < D; ++d) term_obs[(d * T + t) * n + i] = tf[d];
-      if (succ != ORACLE_CONTINUE) memset(h, 0, sizeof(float) * ps.hidden);
+      if (succ != ORACLE_CONTINUE) memset(h, 0, sizeof(float) * 2 * ps.hidden);
     }
     oracle_cartpole_features(&l->state[i], l->limit_kind, l->steps_remaining[i], l->max_steps, f);
     for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + T) * n + i] = f[d];

@@ -368,7 +368,10 @@ double oracle_exploration_rate(int kind, double start, double end, uint64_t peri
 oracle_bound oracle_collection_update_size(int kind, uint64_t first, uint64_t rest, uint64_t global_steps);
 
 /* ---------------------------------------------------------------- recurrent configuration (seq.c, seq_impl.inc) */
-typedef struct { uint32_t in_dim, hidden, mlp_hidden, out_dim; } oracle_gru_shape; /* GruMlpConfig (modules/mod.rs:14) */
+/* ChainConfig<GruConfig | LstmConfig, MlpConfig> (modules/mod.rs:14, chain.rs:12-56); `cell`: 0 = Gru (seq/rnn/gru.rs),
+ * 1 = Lstm (seq/rnn/lstm.rs).  The recurrent state handed to the step function is [h] resp. [h; c]. */
+enum { ORACLE_CELL_GRU = 0, ORACLE_CELL_LSTM = 1 };
+typedef struct { uint32_t in_dim, hidden, mlp_hidden, out_dim, cell; } oracle_gru_shape;
 /* flat parameter order = trainable_variables(): W_ih [3H,in], W_hh [3H,H], b_ih, b_hh, W1 [H2,H], b1, W2 [A,H2], b2 */
 uint64_t oracle_gru_num_params(oracle_gru_shape s);
 void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params);

@@ -18,7 +18,8 @@
 
 uint64_t oracle_gru_num_params(oracle_gru_shape s) {
   uint64_t H = s.hidden, D = s.in_dim, H2 = s.mlp_hidden, A = s.out_dim;
-  return 3 * H * D + 3 * H * H + 3 * H + 3 * H + H2 * H + H2 + A * H2 + A;
+  uint64_t G = s.cell == ORACLE_CELL_LSTM ? 4 : 3; /* RnnImpl::GATES_MULTIPLE (gru.rs / lstm.rs:20) */
+  return G * H * D + G * H * H + G * H + G * H + H2 * H + H2 + A * H2 + A;
 }
 
 #define REAL float
@@ -54,7 +55,8 @@ uint64_t oracle_gru_num_params(oracle_gru_shape s) {
  * (z0 = rho cos, z1 = rho sin, rho = sqrt(-2 ln(1 - u1)), angle 2 pi u2) in f64; QR by modified Gram-Schmidt
  * applied twice in f64 (R has a positive diagonal, so the sign fold is the identity). */
 void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params) {
-  const uint64_t H = s.hidden, D = s.in_dim, H2 = s.mlp_hidden, A = s.out_dim, R = 3 * H;
+  const uint64_t H = s.hidden, D = s.in_dim, H2 = s.mlp_hidden, A = s.out_dim;
+  const uint64_t R = (s.cell == ORACLE_CELL_LSTM ? 4 : 3) * H; /* rows of the gate matrices */
   oracle_prng r;
   oracle_prng_seed_from_u64(&r, seed);
   float *p = params;
@@ -270,7 +272,7 @@ void oracle_chain_lanes_rollout_gru(oracle_chain_lanes *l, oracle_gru_shape ps, 
     oracle_prng_set_stream(&act_rng, l->lane_offset + i);
     oracle_prng_set_word_pos(&act_rng, l->t_global);
     float f[16], tf[16], z[16], lp[16];
-    float *h = (float *)calloc(ps.hidden, sizeof(float));
+    float *h = (float *)calloc((size_t)2 * ps.hidden, sizeof(float)); /* [h] or [h; c] */
     for (uint64_t t = 0; t < T; ++t) {
       chain_features(l, i, f);
       for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + t) * n + i] = f[d];
@@ -285,7 +287,7 @@ void oracle_chain_lanes_rollout_gru(oracle_chain_lanes *l, oracle_gru_shape ps, 
       flag[t * n + i] = (uint8_t)succ;
       if (succ == ORACLE_INTERRUPT && term_obs)
         for (uint32_t d = 0; d < D; ++d) term_obs[(d * T + t) * n + i] = tf[d];
-      if (succ != ORACLE_CONTINUE) memset(h, 0, sizeof(float) * ps.hidden);
+      if (succ != ORACLE_CONTINUE) memset(h, 0, sizeof(float) * 2 * ps.hidden);
     }
     chain_features(l, i, f);
     for (uint32_t d = 0; d < D; ++d) obs[(d * (T + 1) + T) * n + i] = f[d];

@@ -362,6 +362,64 @@ def gru_case(dtype, D=3, H=4, H2=5, A=2, n=3, T=7, seed=41):
     }
 
 
+def lstm_case(dtype, D=3, H=4, H2=5, A=2, n=3, T=7, seed=43):
+    """Chain<Lstm, Mlp> (modules/chain.rs:127-186, seq/rnn/lstm.rs:17-51) over lane trajectories with episode
+    boundaries: per-step outputs (torch.lstm_cell with state (h, c), relu, two Linear layers), successor outputs at
+    cut episodes, and the gradient of sum(dout * out) through time by autograd.  Gate rows [i; f; g; o]."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = [4 * H * D, 4 * H * H, 4 * H, 4 * H, H2 * H, H2, A * H2, A]
+    P = sum(sizes)
+    params = ((torch.rand(P, generator=g, dtype=torch.float64) * 2 - 1) * 0.7).to(dtype).requires_grad_(True)
+    obs = torch.randn(D, T + 1, n, generator=g, dtype=torch.float64).to(dtype)
+    term_obs = torch.randn(D, T, n, generator=g, dtype=torch.float64).to(dtype)
+    flag = torch.zeros(T, n, dtype=torch.int64)
+    flag[2, 0] = 1   # Terminate
+    flag[4, 0] = 2   # Interrupt
+    flag[3, 1] = 2
+    flag[T - 1, 2] = 1
+    dout = torch.randn(A, T, n, generator=g, dtype=torch.float64).to(dtype)
+    o = 0
+    parts = []
+    for sz in sizes:
+        parts.append(params[o:o + sz])
+        o += sz
+    Wih, Whh, bih, bhh = parts[0].reshape(4 * H, D), parts[1].reshape(4 * H, H), parts[2], parts[3]
+    W1, b1, W2, b2 = parts[4].reshape(H2, H), parts[5], parts[6].reshape(A, H2), parts[7]
+
+    def head(h):
+        return torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(torch.relu(h), W1, b1)), W2, b2)
+
+    out = torch.zeros(A, T, n, dtype=dtype)
+    succ = torch.zeros(A, T, n, dtype=dtype)
+    outs = []
+    zeros = lambda: (torch.zeros(1, H, dtype=dtype), torch.zeros(1, H, dtype=dtype))
+    for i in range(n):
+        h, c = zeros()
+        for t in range(T):
+            h, c = torch.lstm_cell(obs[:, t, i].unsqueeze(0), (h, c), Wih, Whh, bih, bhh)
+            y = head(h).squeeze(0)
+            outs.append((i, t, y))
+            f = int(flag[t, i])
+            if f == 2 or (f == 0 and t == T - 1):
+                xs = term_obs[:, t, i] if f == 2 else obs[:, T, i]
+                hs, _ = torch.lstm_cell(xs.unsqueeze(0), (h, c), Wih, Whh, bih, bhh)
+                succ[:, t, i] = head(hs).squeeze(0).detach()
+            if f != 0:
+                h, c = zeros()
+    loss = 0
+    for i, t, y in outs:
+        out[:, t, i] = y.detach()
+        loss = loss + (dout[:, t, i] * y).sum()
+    loss.backward()
+    return {
+        "dims": [D, H, H2, A], "n": n, "T": T, "dtype": str(dtype).replace("torch.", ""),
+        "params": params.detach().double().tolist(), "obs": obs.double().flatten().tolist(),
+        "term_obs": term_obs.double().flatten().tolist(), "flag": flag.flatten().tolist(),
+        "dout": dout.double().flatten().tolist(), "out": out.double().flatten().tolist(),
+        "succ_out": succ.double().flatten().tolist(), "grad": params.grad.double().tolist(),
+    }
+
+
 def main():
     data = {
         "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
@@ -398,6 +456,14 @@ def main():
     with open(os.path.join(HERE, "torch_golden_gru.json"), "w") as f:
         json.dump(gru, f)
     print("wrote torch_golden_gru.json")
+    lstm = {
+        "generator": "tests/golden/make_torch_golden.py, torch %s CPU" % torch.__version__,
+        "lstm_f32": lstm_case(torch.float32),
+        "lstm_f64": lstm_case(torch.float64),
+    }
+    with open(os.path.join(HERE, "torch_golden_lstm.json"), "w") as f:
+        json.dump(lstm, f)
+    print("wrote torch_golden_lstm.json")
 
 
 if __name__ == "__main__":
