@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
     "rl_mlp_create", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_params_get", "rl_params_set",
-    "rl_mlp_forward", "rl_gru_mlp_create", "rl_seq_forward",
+    "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
@@ -409,6 +409,21 @@ class GruMlp(_Handle):
         _check(lib().rl_seq_forward(self.h, traj.h, out.ctypes.data_as(C.c_void_p),
                                     succ.ctypes.data_as(C.c_void_p) if want_succ else None), self.eng.h)
         return out, succ
+
+
+class LstmMlp(GruMlp):
+    """`ChainConfig<LstmConfig, MlpConfig>::default().build_module(in, out)`: LSTM(128) -> ReLU -> MLP([128])."""
+
+    def __init__(self, engine, in_dim, out_dim, lstm_hidden=128, mlp_hidden=128):
+        self.eng = engine
+        self.h = C.c_void_p()
+        _check(lib().rl_lstm_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(lstm_hidden), C.c_uint32(mlp_hidden),
+                                        C.c_uint32(out_dim), C.byref(self.h)), engine.h)
+        _register(self)
+        n = C.c_uint64()
+        _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)
+        self.P = n.value
+        self.in_dim, self.hidden, self.out_dim, self.gru_hidden = in_dim, mlp_hidden, out_dim, lstm_hidden
 
 
 class Mlp(_Handle):

@@ -630,29 +630,38 @@ int32_t rl_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t hidden, uint32_t o
   });
 }
 
+static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t rnn_hidden, uint32_t mlp_hidden,
+                              uint32_t out_dim, rl_mlp **out) {
+  RL_REQUIRE(e && out, "NULL argument");
+  *out = nullptr;
+  if (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128 || !(out_dim == 1 || out_dim == 2))
+    throw RlError(RL_ERR_BUILD_AGENT,
+                  "supported recurrent chain shape: in_dim 5, recurrent hidden 128, mlp_hidden 128, out_dim in {1,2}");
+  RL_HIP_CHECK(hipSetDevice(e->device));
+  std::unique_ptr<rl_mlp> m(new rl_mlp());
+  m->eng = e;
+  m->kind = kind;
+  m->in_dim = in_dim;
+  m->gru_hidden = rnn_hidden;
+  m->hidden = mlp_hidden;
+  m->out_dim = out_dim;
+  const uint64_t H = rnn_hidden, D = in_dim, H2 = mlp_hidden, A = out_dim, G = rl_module_gates(kind);
+  m->P = G * H * D + G * H * H + 2 * G * H + H2 * H + H2 + A * H2 + A;
+  m->d_params = dalloc<float>(m->P);
+  RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+  sync(e);
+  e->live_handles += 1;
+  *out = m.release();
+}
+
 int32_t rl_gru_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden, uint32_t out_dim,
                           rl_mlp **out) {
-  return guarded(e, [&] {
-    RL_REQUIRE(e && out, "NULL argument");
-    *out = nullptr;
-    if (in_dim != 5 || gru_hidden != 128 || mlp_hidden != 128 || !(out_dim == 1 || out_dim == 2))
-      throw RlError(RL_ERR_BUILD_AGENT, "supported GRU-MLP shape: in_dim 5, gru_hidden 128, mlp_hidden 128, out_dim in {1,2}");
-    RL_HIP_CHECK(hipSetDevice(e->device));
-    std::unique_ptr<rl_mlp> m(new rl_mlp());
-    m->eng = e;
-    m->kind = RL_MODULE_GRU_MLP;
-    m->in_dim = in_dim;
-    m->gru_hidden = gru_hidden;
-    m->hidden = mlp_hidden;
-    m->out_dim = out_dim;
-    uint64_t H = gru_hidden, D = in_dim, H2 = mlp_hidden, A = out_dim;
-    m->P = 3 * H * D + 3 * H * H + 6 * H + H2 * H + H2 + A * H2 + A;
-    m->d_params = dalloc<float>(m->P);
-    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
-    sync(e);
-    e->live_handles += 1;
-    *out = m.release();
-  });
+  return guarded(e, [&] { seq_module_create(e, RL_MODULE_GRU_MLP, in_dim, gru_hidden, mlp_hidden, out_dim, out); });
+}
+
+int32_t rl_lstm_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t lstm_hidden, uint32_t mlp_hidden, uint32_t out_dim,
+                           rl_mlp **out) {
+  return guarded(e, [&] { seq_module_create(e, RL_MODULE_LSTM_MLP, in_dim, lstm_hidden, mlp_hidden, out_dim, out); });
 }
 
 // RnnWeights::new with RnnBaseConfig::default (seq/rnn/mod.rs:36-45,223-257) + the MLP's Linear::new layers.
@@ -660,7 +669,7 @@ int32_t rl_gru_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t gru_hidden, ui
 // matrix by Box-Muller on consecutive draw pairs, QR by modified Gram-Schmidt applied twice in f64 (positive
 // diagonal of R, so the sign fold of init_orthogonal, initializers.rs:345-348, is the identity).
 static void gru_mlp_init_host(const rl_mlp *m, uint64_t seed, std::vector<float> &h) {
-  const uint64_t H = m->gru_hidden, D = m->in_dim, H2 = m->hidden, A = m->out_dim, R = 3 * H;
+  const uint64_t H = m->gru_hidden, D = m->in_dim, H2 = m->hidden, A = m->out_dim, R = rl_module_gates(m->kind) * H;
   h.assign(m->P, 0.0f);
   uint32_t key[8];
   rl_seed_from_u64(seed, key);
@@ -742,7 +751,7 @@ int32_t rl_mlp_num_params(const rl_mlp *m, uint64_t *n) {
 int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
   return guarded(m ? m->eng : nullptr, [&] {
     RL_REQUIRE(m, "mlp is NULL");
-    if (m->kind == RL_MODULE_GRU_MLP) {
+    if (rl_module_is_recurrent(m->kind)) {
       std::vector<float> hp;
       gru_mlp_init_host(m, seed, hp);
       h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
@@ -985,7 +994,7 @@ int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t byte
 
 // ---------------------------------------------------------------- recurrent workspace
 void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
-  RL_REQUIRE(mod->kind == RL_MODULE_GRU_MLP, "not a recurrent module");
+  RL_REQUIRE(rl_module_is_recurrent(mod->kind), "not a recurrent module");
   RL_REQUIRE(t->d.n % 32 == 0, "the recurrent kernels work on tiles of 32 lanes: n_lanes must be a multiple of 32");
   RL_REQUIRE(t->d.D == 5 && mod->in_dim == 5, "recurrent path: built for 5 observation features");
   SeqDev &q = t->seq;
@@ -997,8 +1006,8 @@ void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
   }
   if (training && q.act == nullptr) {
     uint64_t blocks = T * q.tiles;
-    q.act = dalloc<float>(blocks * 7 * 128 * 32);
-    q.dpre = dalloc<float>(blocks * 5 * 128 * 32);
+    q.act = dalloc<float>(blocks * RL_SEQ_ACT_ARRAYS * 128 * 32);
+    q.dpre = dalloc<float>(blocks * RL_SEQ_DPRE_ARRAYS * 128 * 32);
     // weight-gradient partials: contiguous runs of (t, tile) blocks per workgroup, <= 1024 workgroups and at most
     // ~2048 samples accumulated in f32 before the f64 reduction
     uint64_t bpc = (blocks + 1023) / 1024;
@@ -1054,7 +1063,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     RL_REQUIRE(env->eng == traj->eng && env->eng == policy->eng, "handles belong to different engines");
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
-    if (policy->kind == RL_MODULE_GRU_MLP) {
+    if (rl_module_is_recurrent(policy->kind)) {
       seq_ensure(traj, policy, false);
       launch_rollout_gru(env, policy, traj);
     } else if (env->kind != RL_ENV_CARTPOLE) {
@@ -1070,7 +1079,7 @@ int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     RL_REQUIRE(traj && critic, "NULL argument");
     RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
-    if (critic->kind == RL_MODULE_GRU_MLP) {
+    if (rl_module_is_recurrent(critic->kind)) {
       seq_ensure(traj, critic, false);
       launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
       launch_seq_gae(traj, gamma, lambda);

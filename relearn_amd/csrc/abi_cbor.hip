@@ -57,7 +57,8 @@ static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<floa
     cbor_mlp(w, p.data(), m->in_dim, m->hidden, m->out_dim);
     return;
   }
-  const int64_t H = m->gru_hidden, D = m->in_dim;
+  // Gru and Lstm are both RnnBase<impl> (seq/rnn/gru.rs:17, lstm.rs:12): the same document, gate rows 3H or 4H
+  const int64_t H = m->gru_hidden, D = m->in_dim, GHR = (int64_t)rl_module_gates(m->kind) * H;
   w.map(3);  // Chain { first, second, activation } (modules/chain.rs:58-63)
   w.key("first");
   w.map(4);  // RnnBase { weights, hidden_size, dropout, type_ } (`device` is #[serde(skip)], seq/rnn/mod.rs:90-99)
@@ -66,14 +67,14 @@ static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<floa
   w.key("flat_weights");
   w.array(4);
   const float *q = p.data();
-  cbor_tensor(w, q, {3 * H, D});
-  q += 3 * H * D;
-  cbor_tensor(w, q, {3 * H, H});
-  q += 3 * H * H;
-  cbor_tensor(w, q, {3 * H});
-  q += 3 * H;
-  cbor_tensor(w, q, {3 * H});
-  q += 3 * H;
+  cbor_tensor(w, q, {GHR, D});
+  q += GHR * D;
+  cbor_tensor(w, q, {GHR, H});
+  q += GHR * H;
+  cbor_tensor(w, q, {GHR});
+  q += GHR;
+  cbor_tensor(w, q, {GHR});
+  q += GHR;
   w.key("has_biases");
   w.boolean(true);
   w.key("hidden_size");
@@ -192,7 +193,7 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
     if (module->kind == RL_MODULE_MLP) {
       end = cbor_read_mlp(mod, module->in_dim, module->hidden, module->out_dim, p.data());
     } else {
-      const int64_t H = module->gru_hidden, D = module->in_dim;
+      const int64_t H = module->gru_hidden, D = module->in_dim, GHR = (int64_t)rl_module_gates(module->kind) * H;
       RL_REQUIRE(mod.at("activation").s == "Relu", "CBOR module: Chain activation must be Relu");
       const cbor::Value &rnn = mod.at("first");
       RL_REQUIRE(rnn.at("hidden_size").as_int() == H, "CBOR module: GRU hidden size mismatch");
@@ -202,14 +203,14 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
       const cbor::Value &fw = wts.at("flat_weights");
       RL_REQUIRE(fw.kind == cbor::Value::ARRAY && fw.items.size() == 4, "CBOR module: expected a one-layer GRU");
       float *q = p.data();
-      cbor_read_tensor(*fw.items[0], {3 * H, D}, q);
-      q += 3 * H * D;
-      cbor_read_tensor(*fw.items[1], {3 * H, H}, q);
-      q += 3 * H * H;
-      cbor_read_tensor(*fw.items[2], {3 * H}, q);
-      q += 3 * H;
-      cbor_read_tensor(*fw.items[3], {3 * H}, q);
-      q += 3 * H;
+      cbor_read_tensor(*fw.items[0], {GHR, D}, q);
+      q += GHR * D;
+      cbor_read_tensor(*fw.items[1], {GHR, H}, q);
+      q += GHR * H;
+      cbor_read_tensor(*fw.items[2], {GHR}, q);
+      q += GHR;
+      cbor_read_tensor(*fw.items[3], {GHR}, q);
+      q += GHR;
       end = cbor_read_mlp(mod.at("second"), H, module->hidden, module->out_dim, q);
     }
     RL_REQUIRE((uint64_t)(end - p.data()) == module->P, "CBOR module: parameter count mismatch");

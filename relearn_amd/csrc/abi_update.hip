@@ -68,7 +68,7 @@ static void check_policy(const rl_mlp *policy, const rl_traj *traj) {
 
 // gradient pass: PASS_INIT -> backward -> reduce(A+B) -> allreduce
 static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
-  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_pass(policy, traj, PASS_INIT, true, 0.0f, 0.0f);
+  if (rl_module_is_recurrent(policy->kind)) return seq_policy_pass(policy, traj, PASS_INIT, true, 0.0f, 0.0f);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
     launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
@@ -82,7 +82,7 @@ static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
 
 // (loss, KL) of the current parameters against lp0: PASS_EVAL -> reduce(B) -> allreduce
 static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
-  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_eval(policy, traj, d_skip);
+  if (rl_module_is_recurrent(policy->kind)) return seq_policy_eval(policy, traj, d_skip);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
     launch_reduce(traj, P, false, true, traj->nbV2, traj->nbV2);
@@ -95,7 +95,7 @@ static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip
 
 // Fisher/Hessian-vector product pass with tangent d_v: PASS_JVP -> backward -> reduce(A) -> allreduce
 static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
-  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_fvp(policy, traj, d_v, d_skip);
+  if (rl_module_is_recurrent(policy->kind)) return seq_policy_fvp(policy, traj, d_v, d_skip);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
     launch_reduce(traj, P, true, false, traj->nbV2, traj->nbV2);
@@ -287,7 +287,7 @@ static void critic_slabs(rl_mlp *critic, rl_traj *traj, uint32_t *rowsA, uint32_
 }
 
 static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
-  if (critic->kind == RL_MODULE_GRU_MLP) return seq_critic_pass(critic, traj);
+  if (rl_module_is_recurrent(critic->kind)) return seq_critic_pass(critic, traj);
   uint32_t P = (uint32_t)critic->P, rowsA, rowsB;
   critic_slabs(critic, traj, &rowsA, &rowsB);
   launch_reduce(traj, P, true, true, rowsA, rowsB);
@@ -349,7 +349,7 @@ int32_t rl_ppo_config_default(rl_ppo_config *c) {
 
 // PASS_PPO gradient of the clipped surrogate against lp0 -> vec[0..P), sum of min(...) -> vec[P]
 static void run_policy_ppo(rl_mlp *policy, rl_traj *traj, float lo, float hi) {
-  if (policy->kind == RL_MODULE_GRU_MLP) return seq_policy_pass(policy, traj, PASS_PPO, true, lo, hi);
+  if (rl_module_is_recurrent(policy->kind)) return seq_policy_pass(policy, traj, PASS_PPO, true, lo, hi);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 &&
       launch_policy_v2(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi)) {
@@ -373,7 +373,7 @@ int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_
     uint32_t P = (uint32_t)policy->P;
     uint64_t Bt = b_total(traj), K = cfg->opt_steps_per_update;
     // initial_log_probs and the logged entropy (ppo.rs:107-118): the PASS_INIT pass stores log pi_0
-    if (policy->kind == RL_MODULE_GRU_MLP) seq_policy_pass(policy, traj, PASS_INIT, false, 0.0f, 0.0f);
+    if (rl_module_is_recurrent(policy->kind)) seq_policy_pass(policy, traj, PASS_INIT, false, 0.0f, 0.0f);
     else run_policy_gradient(policy, traj);
     float h0[4];
     d2h(e, h0, traj->vec + P, sizeof(h0));

@@ -148,7 +148,10 @@ struct rl_env {
   float *d_reward = nullptr, *d_obs = nullptr, *d_term_obs = nullptr;
 };
 
-enum { RL_MODULE_MLP = 0, RL_MODULE_GRU_MLP = 1 };
+enum { RL_MODULE_MLP = 0, RL_MODULE_GRU_MLP = 1, RL_MODULE_LSTM_MLP = 2 };
+// a recurrent chain module (Chain<Gru | Lstm, Mlp>)?
+inline bool rl_module_is_recurrent(int kind) { return kind == RL_MODULE_GRU_MLP || kind == RL_MODULE_LSTM_MLP; }
+inline uint64_t rl_module_gates(int kind) { return kind == RL_MODULE_LSTM_MLP ? 4 : 3; }  // RnnImpl::GATES_MULTIPLE
 
 struct rl_mlp {
   rl_engine *eng;

@@ -1,5 +1,8 @@
 // kernels.hpp — host launchers implemented in the .hip translation units.
 #pragma once
+// arrays of [128 units][32 lanes] floats per (step, tile) block in the recurrent training workspace (kernels_seq.hip)
+#define RL_SEQ_ACT_ARRAYS 9
+#define RL_SEQ_DPRE_ARRAYS 6
 #include "engine.hpp"
 
 // kernels_rollout.hip

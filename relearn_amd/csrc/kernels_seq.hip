@@ -27,9 +27,15 @@ constexpr int MH = 128;      // MLP hidden width (MlpConfig::default)
 constexpr int TL = 32;       // lanes per tile
 constexpr int TLS = TL + 16;  // LDS row stride of the [k][m] operand buffers read as 16x16x4 A operands: the four
                               // k-rows of an instruction start 48 floats apart = banks 0 / 48 / 32 / 16: no conflict
-constexpr int SEQ_ARR = 7;   // activation arrays per step: r, z, n, gh_n, h_prev, relu(h'), u
-constexpr int DPRE_ARR = 5;  // backward arrays per step: d pre_r, d pre_z, d pre_n, d pre_n * r, d u_pre
+// Per (step, tile) block the training forward records SEQ_ARR [unit][lane] arrays and the backward DPRE_ARR (the strides
+// are those of the LSTM, the larger of the two cells; kernels.hpp: RL_SEQ_ACT_ARRAYS / RL_SEQ_DPRE_ARRAYS).
+//   GRU  record: r, z, n, gh_n, h_prev, relu(h'), u                        backward: d pre_r, d pre_z, d pre_n, d pre_n * r, d u_pre
+//   LSTM record: i, f, g, o, h_prev, relu(h'), u, c_prev, tanh(c')         backward: d pre_i, d pre_f, d pre_g, d pre_o, d u_pre, d relu(h')
+constexpr int SEQ_ARR = RL_SEQ_ACT_ARRAYS;
+constexpr int DPRE_ARR = RL_SEQ_DPRE_ARRAYS;
 enum { ACT_R = 0, ACT_Z = 1, ACT_N = 2, ACT_GHN = 3, ACT_HPREV = 4, ACT_A1 = 5, ACT_U = 6 };
+enum { LACT_I = 0, LACT_F = 1, LACT_G = 2, LACT_O = 3, LACT_CPREV = 7, LACT_TC = 8 };  // 4, 5, 6 as above
+enum { DPRE_DU = 4, DPRE_DA1 = 5 };
 
 // ---------------------------------------------------------------- lanes of the IndexSpace-observation envs
 // Chain (chain.rs) and MemoryGame (memory.rs) share the lane code: `c.mem_actions` == 0 selects Chain (a launch-uniform
@@ -225,23 +231,27 @@ struct GruParams {
   const float *Wih, *Whh, *bih, *bhh, *W1, *b1, *W2, *b2;
 };
 
-__host__ __device__ inline GruParams gru_params(const float *p, int D, int A) {
+// RnnWeights flat order (seq/rnn/mod.rs:223-257): w_ih [NG H, D], w_hh [NG H, H], b_ih, b_hh, then the MLP's two Linear
+// layers; NG = RnnImpl::GATES_MULTIPLE: 3 for the GRU ([r; z; n]), 4 for the LSTM ([i; f; g; o])
+__host__ __device__ inline GruParams seq_params(const float *p, int D, int A, int NG) {
   GruParams g;
   g.Wih = p;
-  g.Whh = g.Wih + 3 * GH * D;
-  g.bih = g.Whh + 3 * GH * GH;
-  g.bhh = g.bih + 3 * GH;
-  g.W1 = g.bhh + 3 * GH;
+  g.Whh = g.Wih + NG * GH * D;
+  g.bih = g.Whh + NG * GH * GH;
+  g.bhh = g.bih + NG * GH;
+  g.W1 = g.bhh + NG * GH;
   g.b1 = g.W1 + MH * GH;
   g.W2 = g.b1 + MH;
   g.b2 = g.W2 + A * MH;
   return g;
 }
+__host__ __device__ inline GruParams gru_params(const float *p, int D, int A) { return seq_params(p, D, A, 3); }
 
 __device__ __forceinline__ int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
 // LDS of the forward kernels
-struct SeqFwdShared {
+template <bool WITH_W1>
+struct SeqFwdSharedT {
   float hT[2][GH][TLS];     // recurrent state, [k][m], double-buffered
   float uS[TL][MH + 1];     // MLP hidden activations, [m][j]
   float xS[TL][8];          // observation features of the current step
@@ -249,7 +259,12 @@ struct SeqFwdShared {
   float outS[2][TL];
   int endS[TL];             // != 0: the lane's episode ended at this step (recurrent state restarts)
   int peek;                 // != 0: some lane of the tile needs a successor evaluation at this step
+  // LSTM only: the MLP's first layer as MFMA B operands, [wave][k-step][lane] (its four gate matrices fill the
+  // register budget the GRU spends on three gates + this layer)
+  float w1S[WITH_W1 ? 8 : 1][WITH_W1 ? GH / 4 : 1][WITH_W1 ? 64 : 1];
 };
+using SeqFwdShared = SeqFwdSharedT<false>;
+using LstmFwdShared = SeqFwdSharedT<true>;
 
 // Register-resident weight slices of one wave (unit j = 32 * wave + (lane & 31), k parity = lane >> 5)
 template <int D>
@@ -418,27 +433,197 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
   __syncthreads();
 }
 
+// ---------------------------------------------------------------- LSTM cell (seq/rnn/lstm.rs:17-51), same ownership
+// Wave w owns units [16w, 16w+16) of the four gates [i; f; g; o]: 4 x 32 B operands of W_hh in registers; the MLP's
+// first layer comes from LDS (w1S).  Per-lane state: h (registers 0..7) and the cell state c (registers 8..15), both
+// zero at the start of an episode (LstmImpl::initial_cell_state, lstm.rs:22-31); only h is shared through LDS.
+//   i = sigmoid(.), f = sigmoid(.), g = tanh(.), o = sigmoid(.);  c' = f * c + i * g;  h' = o * tanh(c')
+// with every pre-activation = (b_hh + W_hh h) + (b_ih + W_ih x), the same fma chains as the GRU's r and z gates.
+template <int D>
+struct LstmFwdWeights16 {
+  float whh[4][GH / 4];
+  float wih[4][D];
+  float bih[4], bhh[4], b1;
+};
+
+template <int D>
+__device__ __forceinline__ void lstm_load_weights16(LstmFwdWeights16<D> &w, const GruParams &g, LstmFwdShared &sh,
+                                                    int wave, int lane) {
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
+#pragma unroll
+  for (int gte = 0; gte < 4; ++gte) {
+    const int row = gte * GH + j;
+#pragma unroll
+    for (int ks = 0; ks < GH / 4; ++ks) w.whh[gte][ks] = g.Whh[(size_t)row * GH + 4 * ks + g4];
+#pragma unroll
+    for (int d = 0; d < D; ++d) w.wih[gte][d] = g.Wih[(size_t)row * D + d];
+    w.bih[gte] = g.bih[row];
+    w.bhh[gte] = g.bhh[row];
+  }
+  for (int ks = 0; ks < GH / 4; ++ks) sh.w1S[wave][ks][lane] = g.W1[(size_t)j * GH + 4 * ks + g4];
+  w.b1 = g.b1[j];
+}
+
+template <int D, int A>
+__device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeights16<D> &w, int cur,
+                                            const float (&sown)[16], float (&snew)[16], float b2_mine,
+                                            float *__restrict__ store, int wave, int lane) {
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16, nxt = cur ^ 1;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[gte][mt] = (f32x4){w.bhh[gte], w.bhh[gte], w.bhh[gte], w.bhh[gte]};
+#pragma unroll
+  for (int ks = 0; ks < GH / 4; ++ks) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float a = sh.hT[cur][4 * ks + g4][16 * mt + n16];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte)
+        acc[gte][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w.whh[gte][ks], acc[gte][mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 iv, fv, gv, ov, pv, av, cv, tv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = acc16_row(mt, i, g4), r = 4 * mt + i;
+      float pre[4];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) {
+        float v = w.bih[gte];
+#pragma unroll
+        for (int d = 0; d < D; ++d) v = __builtin_fmaf(sh.xS[m][d], w.wih[gte][d], v);
+        pre[gte] = acc[gte][mt][i] + v;
+      }
+      const float ig = rl_sigmoidf(pre[0]), fg = rl_sigmoidf(pre[1]), gg = rl_tanhf(pre[2]), og = rl_sigmoidf(pre[3]);
+      const float cprev = sown[8 + r];
+      const float fc = fg * cprev;
+      const float iga = ig * gg;
+      const float cn = fc + iga;
+      const float tc = rl_tanhf(cn);
+      const float hv = og * tc;
+      snew[r] = hv;
+      snew[8 + r] = cn;
+      sh.hT[nxt][j][m] = hv;
+      iv[i] = ig;
+      fv[i] = fg;
+      gv[i] = gg;
+      ov[i] = og;
+      pv[i] = sown[r];
+      av[i] = hv > 0.0f ? hv : 0.0f;
+      cv[i] = cprev;
+      tv[i] = tc;
+    }
+    if (store != nullptr) {
+      float *__restrict__ row = store + (size_t)j * TL + 16 * mt + 4 * g4;
+      *reinterpret_cast<f32x4 *>(row + (size_t)LACT_I * GH * TL) = iv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)LACT_F * GH * TL) = fv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)LACT_G * GH * TL) = gv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)LACT_O * GH * TL) = ov;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_HPREV * GH * TL) = pv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)ACT_A1 * GH * TL) = av;
+      *reinterpret_cast<f32x4 *>(row + (size_t)LACT_CPREV * GH * TL) = cv;
+      *reinterpret_cast<f32x4 *>(row + (size_t)LACT_TC * GH * TL) = tv;
+    }
+  }
+  __syncthreads();
+  f32x4 acc1[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) acc1[mt] = (f32x4){w.b1, w.b1, w.b1, w.b1};
+#pragma unroll 8
+  for (int ks = 0; ks < GH / 4; ++ks) {
+    const float b = sh.w1S[wave][ks][lane];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float a = sh.hT[nxt][4 * ks + g4][16 * mt + n16];
+      a = a > 0.0f ? a : 0.0f;  // Chain activation between the modules (chain.rs:165)
+      acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1[mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x4 uv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = acc16_row(mt, i, g4);
+      const float u = acc1[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
+      sh.uS[m][j] = u;
+      uv[i] = u;
+    }
+    if (store != nullptr)
+      *reinterpret_cast<f32x4 *>(store + (size_t)ACT_U * GH * TL + (size_t)j * TL + 16 * mt + 4 * g4) = uv;
+  }
+  __syncthreads();
+  if (wave == 0 && (lane >> 5) < A) {
+    const int n = lane & 31, hf = lane >> 5;
+    float z = b2_mine;
+#pragma unroll 8
+    for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
+    sh.outS[hf][n] = z;
+  }
+  __syncthreads();
+}
+
+// The two cells behind one interface for the rollout / teacher-forced forward loops.  NS = per-lane state registers
+// (the first eight are h, mirrored in LDS; the LSTM's second eight are c).
+struct GruCell16 {
+  static constexpr int NG = 3, NS = 8;
+  using Shared = SeqFwdShared;
+  template <int D>
+  using Weights = SeqFwdWeights16<D>;
+  template <int D>
+  static __device__ __forceinline__ void load(Weights<D> &w, const GruParams &g, Shared &, int wave, int lane) {
+    seq_load_weights16<D>(w, g, wave, lane);
+  }
+  template <int D, int A>
+  static __device__ __forceinline__ void cell(Shared &sh, const Weights<D> &w, int cur, const float (&sown)[NS],
+                                              float (&snew)[NS], float b2_mine, float *__restrict__ store, int wave,
+                                              int lane) {
+    seq_cell16<D, A>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
+  }
+};
+
+struct LstmCell16 {
+  static constexpr int NG = 4, NS = 16;
+  using Shared = LstmFwdShared;
+  template <int D>
+  using Weights = LstmFwdWeights16<D>;
+  template <int D>
+  static __device__ __forceinline__ void load(Weights<D> &w, const GruParams &g, Shared &sh, int wave, int lane) {
+    lstm_load_weights16<D>(w, g, sh, wave, lane);
+  }
+  template <int D, int A>
+  static __device__ __forceinline__ void cell(Shared &sh, const Weights<D> &w, int cur, const float (&sown)[NS],
+                                              float (&snew)[NS], float b2_mine, float *__restrict__ store, int wave,
+                                              int lane) {
+    lstm_cell16<D, A>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
+  }
+};
+
 // ---------------------------------------------------------------- rollout (recurrent policy, either env kind)
 // PolicyActor::act over SeqIterative::step (policies/actor.rs:42-55; chain.rs:175-186) for T steps of every lane.
 // The episode state starts at zero at the beginning of the launch and after every episode end.
-template <int D, class Env>
+template <int D, class Env, class Cell>
 __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_gru(CartPoleDev c, EnvStateDev st, TrajDev tr,
                                                               const float *__restrict__ params, uint64_t t_global) {
-  constexpr int A = 2;
-  __shared__ SeqFwdShared sh;
+  constexpr int A = 2, NS = Cell::NS;
+  __shared__ typename Cell::Shared sh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4, hf = lane >> 5, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const uint32_t lane0 = blockIdx.x * TL;
-  const GruParams g = gru_params(params, D, A);
-  SeqFwdWeights16<D> w;
-  seq_load_weights16<D>(w, g, wave, lane);
+  const GruParams g = seq_params(params, D, A, Cell::NG);
+  typename Cell::template Weights<D> w;
+  Cell::template load<D>(w, g, sh, wave, lane);
   for (int q = threadIdx.x; q < A * MH; q += W16 * 64) sh.w2S[q / MH][q % MH] = g.W2[q];
   for (int q = threadIdx.x; q < 2 * GH * TLS; q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
   const float b2_mine = hf < A ? g.b2[hf] : 0.0f;
-  float hown[8];
+  float hown[NS];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) hown[r] = 0.0f;
+  for (int r = 0; r < NS; ++r) hown[r] = 0.0f;
   // env state of the tile: lanes 0..31 of wave 0
   const bool env_lane = wave == 0 && lane < TL;
   const uint32_t i = lane0 + (uint32_t)lane;
@@ -458,8 +643,8 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_gru(CartPoleDev c, EnvS
   __syncthreads();
   int cur = 0;
   for (uint32_t t = 0; t < T; ++t) {
-    float hnew[8];
-    seq_cell16<D, A>(sh, w, cur, hown, hnew, b2_mine, nullptr, wave, lane);
+    float hnew[NS];
+    Cell::template cell<D, A>(sh, w, cur, hown, hnew, b2_mine, nullptr, wave, lane);
     if (env_lane) {
       float z[2] = {sh.outS[0][lane], sh.outS[1][lane]}, lp[2];
       log_softmax_lane<2>(z, lp);
@@ -490,11 +675,11 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_rollout_gru(CartPoleDev c, EnvS
     __syncthreads();
     const int nxt = cur ^ 1;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int m = acc16_row(r >> 2, r & 3, g4);
+    for (int r = 0; r < NS; ++r) {
+      const int m = acc16_row((r & 7) >> 2, r & 3, g4);
       const bool ended = sh.endS[m] != 0;
       hown[r] = ended ? 0.0f : hnew[r];
-      if (ended) sh.hT[nxt][j][m] = 0.0f;
+      if (ended && r < 8) sh.hT[nxt][j][m] = 0.0f;
     }
     __syncthreads();
     cur = nxt;
@@ -554,26 +739,27 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_chain_mlp(CartPoleDev c, EnvS
 // SeqPacked::seq_packed of Chain<Gru, Mlp> (chain.rs:151-161; gru.rs:76-98) on the lane layout.  Writes the module
 // outputs out[a][t][lane]; optionally the outputs at the successor observations of cut episodes (extended
 // observation sequences, features.rs:132-178) and the activation record for the backward pass.
-template <int D, int A>
+template <int D, int A, class Cell>
 __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, const float *__restrict__ params,
                                                             float *__restrict__ out, float *__restrict__ succ_out,
                                                             float *__restrict__ act,
                                                             const int32_t *__restrict__ skip) {
-  __shared__ SeqFwdShared sh;
+  constexpr int NS = Cell::NS;
+  __shared__ typename Cell::Shared sh;
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4, hf = lane >> 5, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
-  const GruParams g = gru_params(params, D, A);
-  SeqFwdWeights16<D> w;
-  seq_load_weights16<D>(w, g, wave, lane);
+  const GruParams g = seq_params(params, D, A, Cell::NG);
+  typename Cell::template Weights<D> w;
+  Cell::template load<D>(w, g, sh, wave, lane);
   for (int q = threadIdx.x; q < A * MH; q += W16 * 64) sh.w2S[q / MH][q % MH] = g.W2[q];
   for (int q = threadIdx.x; q < 2 * GH * TLS; q += W16 * 64) (&sh.hT[0][0][0])[q] = 0.0f;
   const float b2_mine = hf < A ? g.b2[hf] : 0.0f;
-  float hown[8];
+  float hown[NS];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) hown[r] = 0.0f;
+  for (int r = 0; r < NS; ++r) hown[r] = 0.0f;
   const bool io_lane = wave == 0 && lane < TL;
   const uint32_t i = lane0 + (uint32_t)lane;
   const size_t plane = (size_t)(T + 1) * N;
@@ -593,9 +779,9 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
       if (threadIdx.x == 0) sh.peek = 0;
     }
     __syncthreads();
-    float hout[8];
+    float hout[NS];
     float *store = (act != nullptr && !peeking) ? act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL : nullptr;
-    seq_cell16<D, A>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
+    Cell::template cell<D, A>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
     if (io_lane) {
       if (!peeking) {
 #pragma unroll
@@ -620,19 +806,19 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
     if (!peeking && sh.peek != 0) {
       // keep the post-step state as the input of the peek iteration; the reset of ended lanes waits
 #pragma unroll
-      for (int r = 0; r < 8; ++r) hown[r] = hout[r];
+      for (int r = 0; r < NS; ++r) hown[r] = hout[r];
       cur ^= 1;
       peeking = true;
     } else {
       // commit: restart the state of lanes whose episode ended at step t
       const int buf = peeking ? cur : (cur ^ 1);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int m = acc16_row(r >> 2, r & 3, g4);
+      for (int r = 0; r < NS; ++r) {
+        const int m = acc16_row((r & 7) >> 2, r & 3, g4);
         const bool ended = sh.endS[m] != 0;
         const float hv = peeking ? hown[r] : hout[r];
         hown[r] = ended ? 0.0f : hv;
-        if (ended) sh.hT[buf][j][m] = 0.0f;
+        if (ended && r < 8) sh.hT[buf][j][m] = 0.0f;
       }
       cur = buf;
       peeking = false;
@@ -733,12 +919,18 @@ void launch_rollout_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
   RL_REQUIRE(env->D == 5, "recurrent rollout: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;
-  if (env->kind != RL_ENV_CARTPOLE)
-    hipLaunchKernelGGL((k_rollout_gru<5, ChainOps>), dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev, env->st,
-                       traj->d, policy->d_params, env->t_global);
-  else
-    hipLaunchKernelGGL((k_rollout_gru<5, CartPoleOps>), dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev,
-                       env->st, traj->d, policy->d_params, env->t_global);
+#define ROLL(ENV, CELL)                                                                                           \
+  hipLaunchKernelGGL((k_rollout_gru<5, ENV, CELL>), dim3(tiles), dim3(W16 * 64), 0, env->eng->stream, env->dev, env->st, \
+                     traj->d, policy->d_params, env->t_global)
+  const bool lstm = policy->kind == RL_MODULE_LSTM_MLP;
+  if (env->kind != RL_ENV_CARTPOLE) {
+    if (lstm) ROLL(ChainOps, LstmCell16);
+    else ROLL(ChainOps, GruCell16);
+  } else {
+    if (lstm) ROLL(CartPoleOps, LstmCell16);
+    else ROLL(CartPoleOps, GruCell16);
+  }
+#undef ROLL
 }
 
 void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
@@ -754,12 +946,18 @@ void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, floa
   ProfScope ps(traj->eng, RL_K_POLICY_FUSED);
   RL_REQUIRE(traj->d.D == 5, "recurrent forward: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;
-  if (mod->out_dim == 2)
-    hipLaunchKernelGGL((k_gru_seq_forward<5, 2>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d,
-                       mod->d_params, d_out, d_succ, d_act, d_skip);
-  else
-    hipLaunchKernelGGL((k_gru_seq_forward<5, 1>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d,
-                       mod->d_params, d_out, d_succ, d_act, d_skip);
+#define FWD(AA, CELL)                                                                                        \
+  hipLaunchKernelGGL((k_gru_seq_forward<5, AA, CELL>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d, \
+                     mod->d_params, d_out, d_succ, d_act, d_skip)
+  const bool lstm = mod->kind == RL_MODULE_LSTM_MLP;
+  if (mod->out_dim == 2) {
+    if (lstm) FWD(2, LstmCell16);
+    else FWD(2, GruCell16);
+  } else {
+    if (lstm) FWD(1, LstmCell16);
+    else FWD(1, GruCell16);
+  }
+#undef FWD
 }
 
 // =====================================================================================================
@@ -1253,6 +1451,7 @@ void launch_seq_critic_dvalues(rl_traj *traj, uint64_t B_total) {
 
 // backward through time + weight-gradient GEMMs + reduction: traj->vec[0..P) <- sum over this rank's samples
 void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip) {
+  if (mod->kind == RL_MODULE_LSTM_MLP) throw RlError(RL_ERR_UNSUPPORTED, "backward through the LSTM chain is not built yet");
   rl_engine *e = traj->eng;
   const SeqDev &q = traj->seq;
   uint32_t P = (uint32_t)mod->P, blocks = traj->d.T * q.tiles;
@@ -1470,6 +1669,8 @@ __global__ void __launch_bounds__(256) k_seq_fvp_dlogits(TrajDev tr, const float
 
 void launch_gru_tangent(rl_traj *traj, const rl_mlp *mod, const float *d_tangent, uint64_t B_total,
                         const int32_t *d_skip) {
+  if (mod->kind == RL_MODULE_LSTM_MLP)
+    throw RlError(RL_ERR_UNSUPPORTED, "Fisher-vector products through the LSTM chain are not built (use PPO / REINFORCE)");
   rl_engine *e = traj->eng;
   const SeqDev &q = traj->seq;
   RL_REQUIRE(mod->out_dim == 2, "Fisher-vector products are for 2-action policies");
