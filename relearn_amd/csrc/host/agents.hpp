@@ -207,6 +207,7 @@ class Module {
   Module(Engine &eng, rl_mlp *h) : eng_(eng), h_(h) { check(rl_mlp_num_params(h_, &n_), eng.handle()); }
   friend struct MlpConfig;
   friend struct GruMlpConfig;
+  friend struct ChainLstmMlpConfig;
   Engine &eng_;
   rl_mlp *h_;
   uint64_t n_ = 0;
@@ -237,9 +238,22 @@ struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mo
 
 // The reference defines `pub type LstmMlpConfig = ChainConfig<GruConfig, MlpConfig>` (modules/mod.rs:15): its
 // "LSTM-MLP" configuration builds the GRU chain.  Kept as is, so that a configuration written against the reference
-// builds the same network here.  (The `Lstm` module itself, seq/rnn/lstm.rs, is not reachable from any agent
-// configuration of the reference and has no device implementation in this library.)
+// builds the same network here.
 using LstmMlpConfig = GruMlpConfig;
+
+// ChainConfig<LstmConfig, MlpConfig>::default (chain.rs:19-32 with Lstm = RnnBase<LstmImpl>, seq/rnn/lstm.rs:12-51): what a
+// user of the reference writes out to get an actual LSTM chain.  Every update except the trust-region one is built.
+struct ChainLstmMlpConfig {
+  uint32_t hidden_dim = 128;
+  MlpConfig second_config;
+  std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
+    rl_mlp *h = nullptr;
+    check(rl_lstm_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.hidden_size, out_dim, &h), eng.handle());
+    std::unique_ptr<Module> m(new Module(eng, h));
+    check(rl_mlp_init(h, seed), eng.handle());
+    return m;
+  }
+};
 
 struct AdamConfig {  // optimizers/coptimizer.rs:136-156
   double learning_rate = 1e-3, beta1 = 0.9, beta2 = 0.999, weight_decay = 0.0;

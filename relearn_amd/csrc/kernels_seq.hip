@@ -1207,6 +1207,157 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
   }
 }
 
+// ---------------------------------------------------------------- LSTM: backward through time
+// The LSTM's four W_hh^T slices fill the registers the GRU kernel shares between W_hh^T and W1^T, so the head's backward
+// (which has no recurrence) runs first as its own kernel over all (t, tile) blocks in parallel:
+//   d u_pre = [u > 0] W2^T dz          -> dpre[DPRE_DU]
+//   d relu(h') -> [relu(h') > 0] W1^T d u_pre   -> dpre[DPRE_DA1]
+// and k_lstm_bptt walks t = T-1 .. 0 with (dh, dc) carried in registers:
+//   dh = dh_next + d relu(h');  d o = dh tanh(c');  d c' = dc_next + dh o (1 - tanh(c')^2)
+//   d f = d c' c;  d i = d c' g;  d g = d c' i;  dc = d c' f;  pre-activation gradients with the gates' derivatives;
+//   dh_prev = sum over the four gates of W_hh[g]^T d pre_g     (one MFMA chain per gate and M-tile)
+template <int A>
+__global__ void __launch_bounds__(W16 * 64, 2) k_seq_head_backward(TrajDev tr, const float *__restrict__ params, int D,
+                                                                    int NG, const float *__restrict__ dz,
+                                                                    const float *__restrict__ act,
+                                                                    float *__restrict__ dpre, uint32_t tiles,
+                                                                    uint32_t blocks, const int32_t *__restrict__ skip) {
+  __shared__ float bufU[GH][TLS];
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
+  const uint32_t N = tr.n, T = tr.T;
+  const size_t B = (size_t)T * N;
+  const GruParams g = seq_params(params, D, A, NG);
+  float w1T[MH / 4], w2c[A];
+#pragma unroll
+  for (int ks = 0; ks < MH / 4; ++ks) w1T[ks] = g.W1[(size_t)(4 * ks + g4) * GH + j];
+#pragma unroll
+  for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
+  const size_t lo = (size_t)j * TL + 4 * g4;
+  for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
+    const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
+    const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
+    float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
+    __syncthreads();  // the previous block's readers of bufU are done
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 uv = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + 16 * mt);
+      f32x4 dzv[A], duv;
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        dzv[a] = *reinterpret_cast<const f32x4 *>(dz + (size_t)a * B + (size_t)t * N + lane0 + 16 * mt + 4 * g4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float du = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) du = __builtin_fmaf(dzv[a][i], w2c[a], du);
+        du = uv[i] > 0.0f ? du : 0.0f;
+        bufU[j][16 * mt + 4 * g4 + i] = du;
+        duv[i] = du;
+      }
+      *reinterpret_cast<f32x4 *>(db + (size_t)DPRE_DU * GH * TL + lo + 16 * mt) = duv;
+    }
+    __syncthreads();
+    f32x4 acc1[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc1[mt][0] = acc1[mt][1] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < MH / 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc1[mt][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufU[4 * ks + g4][16 * mt + n16], w1T[ks],
+                                                                acc1[mt][ks & 1], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + lo + 16 * mt);
+      f32x4 dav;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dav[i] = a1[i] > 0.0f ? acc1[mt][0][i] + acc1[mt][1][i] : 0.0f;
+      *reinterpret_cast<f32x4 *>(db + (size_t)DPRE_DA1 * GH * TL + lo + 16 * mt) = dav;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(W16 * 64, 2) k_lstm_bptt(TrajDev tr, const float *__restrict__ params, int D, int A,
+                                                           const float *__restrict__ act, float *__restrict__ dpre,
+                                                           const int32_t *__restrict__ skip) {
+  __shared__ float bufG[4][GH][TLS];
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
+  const uint32_t N = tr.n, T = tr.T;
+  const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
+  const GruParams g = seq_params(params, D, A, 4);
+  float whhT[4][GH / 4];
+#pragma unroll
+  for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+    for (int ks = 0; ks < GH / 4; ++ks) whhT[gte][ks] = g.Whh[(size_t)(gte * GH + 4 * ks + g4) * GH + j];
+  const size_t lo = (size_t)j * TL + 4 * g4;
+  f32x4 dhc[2], dcc[2];
+  dhc[0] = dhc[1] = dcc[0] = dcc[1] = (f32x4){0, 0, 0, 0};
+  for (uint32_t t = T; t-- > 0;) {
+    const float *__restrict__ ab = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
+    float *__restrict__ db = dpre + ((size_t)t * tiles + tile) * DPRE_ARR * GH * TL;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const size_t o = lo + 16 * mt;
+      const f32x4 iv = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_I * GH * TL + o);
+      const f32x4 fv = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_F * GH * TL + o);
+      const f32x4 gv = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_G * GH * TL + o);
+      const f32x4 ov = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_O * GH * TL + o);
+      const f32x4 cp = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_CPREV * GH * TL + o);
+      const f32x4 tc = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_TC * GH * TL + o);
+      const f32x4 da1 = *reinterpret_cast<const f32x4 *>(db + (size_t)DPRE_DA1 * GH * TL + o);
+      const uint32_t endw = *reinterpret_cast<const uint32_t *>(tr.flag + (size_t)t * N + lane0 + 16 * mt + 4 * g4);
+      f32x4 div, dfv, dgv, dov;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * mt + 4 * g4 + i;
+        const bool ended = ((endw >> (8 * i)) & 0xffu) != RL_SUCC_CONTINUE;
+        const float dh = (ended ? 0.0f : dhc[mt][i]) + da1[i];
+        const float dcn_in = ended ? 0.0f : dcc[mt][i];
+        const float dO = dh * tc[i];
+        const float dtc = dh * ov[i];
+        const float dcn = dcn_in + dtc * (1.0f - tc[i] * tc[i]);
+        const float dF = dcn * cp[i], dI = dcn * gv[i], dG = dcn * iv[i];
+        dcc[mt][i] = dcn * fv[i];
+        div[i] = dI * iv[i] * (1.0f - iv[i]);
+        dfv[i] = dF * fv[i] * (1.0f - fv[i]);
+        dgv[i] = dG * (1.0f - gv[i] * gv[i]);
+        dov[i] = dO * ov[i] * (1.0f - ov[i]);
+        bufG[0][j][m] = div[i];
+        bufG[1][j][m] = dfv[i];
+        bufG[2][j][m] = dgv[i];
+        bufG[3][j][m] = dov[i];
+      }
+      *reinterpret_cast<f32x4 *>(db + (size_t)0 * GH * TL + o) = div;
+      *reinterpret_cast<f32x4 *>(db + (size_t)1 * GH * TL + o) = dfv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)2 * GH * TL + o) = dgv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)3 * GH * TL + o) = dov;
+    }
+    __syncthreads();
+    f32x4 accg[4][2];
+#pragma unroll
+    for (int gte = 0; gte < 4; ++gte) accg[gte][0] = accg[gte][1] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < GH / 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte)
+          accg[gte][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufG[gte][4 * ks + g4][16 * mt + n16], whhT[gte][ks],
+                                                               accg[gte][mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        dhc[mt][i] = ((accg[0][mt][i] + accg[1][mt][i]) + accg[2][mt][i]) + accg[3][mt][i];
+    __syncthreads();  // bufG is rewritten by the next step
+  }
+}
+
 // ---------------------------------------------------------------- weight-gradient GEMMs
 // dW_hh = sum dgh (x) h_prev [384 x 128], dW1 = sum du (x) relu(h') [128 x 128] on the matrix cores with the
 // sample index as the MFMA k dimension (k-pair (ks, hf) <-> sample m = 16 hf + ks, so every operand is 16
@@ -1216,14 +1367,14 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
 // ONCE per workgroup with fully coalesced 16-byte loads into registers while the previous block's products run, then
 // parked in LDS ([unit][36] rows: the 16-byte operand reads of 16 consecutive rows hit 64 different banks); a wave's B
 // rows (h_prev, relu(h') of its own 32 units) and the rows only its VALU sums need come straight from HBM.
-template <int D, int A>
+template <int D, int A, int NG>  // NG gate blocks: 3 = GRU (staged: d gh_r, d gh_z, d gh_n = d pre_n * r), 4 = LSTM
 __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *__restrict__ dz,
                                                       const float *__restrict__ act, const float *__restrict__ dpre,
                                                       float *__restrict__ slab, uint32_t P, uint32_t tiles,
                                                       uint32_t blocks, uint32_t blocks_per_chunk,
                                                       const int32_t *__restrict__ skip) {
   constexpr int RS = TL + 4;
-  enum { S_R = 0, S_Z = 1, S_GN = 2, S_DU = 3, S_N = 4 };
+  constexpr int S_DU = NG, S_N = NG + 1;  // staged arrays: the NG hidden-side gate gradients, then d u_pre
   __shared__ __attribute__((aligned(16))) float aS[S_N][GH][RS];
   __shared__ float xS[TL][8];
   __shared__ float dzS[2][TL];
@@ -1232,16 +1383,18 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
   const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
   const uint32_t N = tr.n, T = tr.T;
   const size_t B = (size_t)T * N, plane = (size_t)(T + 1) * N;
-  f32x16 acc_hh[12], acc_w1[4];
+  f32x16 acc_hh[4 * NG], acc_w1[4];
 #pragma unroll
-  for (int q = 0; q < 12; ++q) acc_hh[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = 0; q < 4 * NG; ++q) acc_hh[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc_w1[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float dwih[3][D], dbih[3] = {0, 0, 0}, dbhh[3] = {0, 0, 0}, db1 = 0.0f, dw2[A], db2 = 0.0f;
+  float dwih[NG][D], dbih[NG], dbhh[NG], db1 = 0.0f, dw2[A], db2 = 0.0f;
 #pragma unroll
-  for (int gte = 0; gte < 3; ++gte)
+  for (int gte = 0; gte < NG; ++gte) {
+    dbih[gte] = dbhh[gte] = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) dwih[gte][d] = 0.0f;
+  }
 #pragma unroll
   for (int a = 0; a < A; ++a) dw2[a] = 0.0f;
   const uint32_t b0 = blockIdx.x * blocks_per_chunk;
@@ -1252,7 +1405,11 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
   float xn[D], dzn[A];  // wave 0, lanes < 32: the block's observation features and logit gradients
   auto stage_load = [&](uint32_t blk) {
     const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
-    const float *src[S_N] = {db, db + (size_t)1 * GH * TL, db + (size_t)3 * GH * TL, db + (size_t)4 * GH * TL};
+    // GRU: dpre arrays 0, 1, 3 (hidden side of the n gate), 4; LSTM: 0, 1, 2, 3, 4
+    const float *src[S_N];
+#pragma unroll
+    for (int a = 0; a < NG; ++a) src[a] = db + (size_t)((NG == 3 && a == 2) ? 3 : a) * GH * TL;
+    src[S_DU] = db + (size_t)DPRE_DU * GH * TL;
 #pragma unroll
     for (int a = 0; a < S_N; ++a)
 #pragma unroll
@@ -1305,7 +1462,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         a1B[4 * q + i] = a14[q][i];
       }
 #pragma unroll
-    for (int mt = 0; mt < 12; ++mt) {
+    for (int mt = 0; mt < 4 * NG; ++mt) {
       const int gte = mt >> 2, row = 32 * (mt & 3) + n;  // unit of this lane's A row
       float av[16];
 #pragma unroll
@@ -1323,7 +1480,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         for (int ks = 0; ks < 16; ++ks) {
           const int m = 16 * hf + ks;
           const float dgh = av[ks];
-          const float dgi = gte == 2 ? dpnv[ks >> 2][ks & 3] : dgh;
+          const float dgi = (NG == 3 && gte == 2) ? dpnv[ks >> 2][ks & 3] : dgh;  // GRU: input side of the n gate
           dbhh[gte] += dgh;
           dbih[gte] += dgi;
 #pragma unroll
@@ -1359,10 +1516,10 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
   }
   // ---- write this workgroup's row of partials
   float *__restrict__ out = slab + (size_t)blockIdx.x * P;
-  const size_t oWih = 0, oWhh = oWih + (size_t)3 * GH * D, obih = oWhh + (size_t)3 * GH * GH, obhh = obih + 3 * GH;
-  const size_t oW1 = obhh + 3 * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH, ob2 = oW2 + (size_t)A * MH;
+  const size_t oWih = 0, oWhh = oWih + (size_t)NG * GH * D, obih = oWhh + (size_t)NG * GH * GH, obhh = obih + NG * GH;
+  const size_t oW1 = obhh + NG * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH, ob2 = oW2 + (size_t)A * MH;
 #pragma unroll
-  for (int mt = 0; mt < 12; ++mt)
+  for (int mt = 0; mt < 4 * NG; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[oWhh + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_hh[mt][r];
 #pragma unroll
@@ -1371,7 +1528,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
     for (int r = 0; r < 16; ++r) out[oW1 + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_w1[mt][r];
   // VALU sums: the two halves of a wave hold samples 0..15 and 16..31 of the same rows
 #pragma unroll
-  for (int gte = 0; gte < 3; ++gte) {
+  for (int gte = 0; gte < NG; ++gte) {
     const int row = gte * GH + j;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -1451,27 +1608,43 @@ void launch_seq_critic_dvalues(rl_traj *traj, uint64_t B_total) {
 
 // backward through time + weight-gradient GEMMs + reduction: traj->vec[0..P) <- sum over this rank's samples
 void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip) {
-  if (mod->kind == RL_MODULE_LSTM_MLP) throw RlError(RL_ERR_UNSUPPORTED, "backward through the LSTM chain is not built yet");
   rl_engine *e = traj->eng;
   const SeqDev &q = traj->seq;
   uint32_t P = (uint32_t)mod->P, blocks = traj->d.T * q.tiles;
+  const bool lstm = mod->kind == RL_MODULE_LSTM_MLP;
   {
     ProfScope ps(e, RL_K_BACKWARD);
-    if (mod->out_dim == 2)
+    if (lstm) {
+      const uint32_t grid = blocks < 2048 ? blocks : 2048;
+      if (mod->out_dim == 2)
+        hipLaunchKernelGGL(k_seq_head_backward<2>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, 4,
+                           traj->dz, q.act, q.dpre, q.tiles, blocks, d_skip);
+      else
+        hipLaunchKernelGGL(k_seq_head_backward<1>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, 4,
+                           traj->dz, q.act, q.dpre, q.tiles, blocks, d_skip);
+      hipLaunchKernelGGL(k_lstm_bptt, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5,
+                         (int)mod->out_dim, q.act, q.dpre, d_skip);
+    } else if (mod->out_dim == 2) {
       hipLaunchKernelGGL(k_gru_bptt<2>, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
                          q.act, q.dpre, d_skip);
-    else
+    } else {
       hipLaunchKernelGGL(k_gru_bptt<1>, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
                          q.act, q.dpre, d_skip);
+    }
   }
   {
     ProfScope ps(e, RL_K_CRITIC_FUSED);
-    if (mod->out_dim == 2)
-      hipLaunchKernelGGL((k_gru_wgrad<5, 2>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, q.act, q.dpre,
-                         q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk, d_skip);
-    else
-      hipLaunchKernelGGL((k_gru_wgrad<5, 1>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, q.act, q.dpre,
-                         q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk, d_skip);
+#define WG(AA, NGG)                                                                                              \
+  hipLaunchKernelGGL((k_gru_wgrad<5, AA, NGG>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, q.act, \
+                     q.dpre, q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk, d_skip)
+    if (mod->out_dim == 2) {
+      if (lstm) WG(2, 4);
+      else WG(2, 3);
+    } else {
+      if (lstm) WG(1, 4);
+      else WG(1, 3);
+    }
+#undef WG
   }
   {
     ProfScope ps(e, RL_K_REDUCE);

@@ -78,3 +78,141 @@ def test_seq_forward_and_gae_bit_exact(engine, max_steps):
     assert np.array_equal(traj.read(ra.TRAJ_ADVANTAGES), adv_o) and np.array_equal(traj.read(ra.TRAJ_RETURNS), rtg_o)
     if max_steps < T:
         assert np.count_nonzero(succ_o) > 0  # cut episodes evaluate their successor observation from (h, c)
+
+
+# ------------------------------------------------------------------ gradients through time and the update loops
+GRAD_RTOL = 5e-6   # device f32 (MFMA partial sums over <= 2048 samples, then f64) vs the f64 evaluation, rel. to max|g|
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def setup_update(engine, n=64, T=30, max_steps=9, lr=1e-3):
+    env = ra.ChainEnv(engine, n, max_steps=max_steps, seed_env=3, seed_actor=4)
+    sim = O.ChainLaneSim(n, max_steps=max_steps, seed_env=3, seed_actor=4)
+    pol, cri = ra.LstmMlp(engine, 5, 2), ra.LstmMlp(engine, 5, 1)
+    pol.init(21)
+    cri.init(22)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    want = sim.rollout_gru(PS, pol.get_params(), T)
+    ra.gae(traj, cri, 0.95, 0.9)
+    want["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
+    want["rtg"] = traj.read(ra.TRAJ_RETURNS)
+    acfg = ra.adam_config_default()
+    acfg.learning_rate = lr
+    ocfg = O.AdamCfg()
+    L.oracle_adam_cfg_default(C.byref(ocfg))
+    ocfg.lr = lr
+    return pol, cri, traj, want, acfg, ocfg
+
+
+def test_policy_gradient_through_time(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p = pol.get_params()
+    g_d, loss_d, ent_d = ra.policy_gradient(pol, traj)
+    # -mean(ratio * A) at ratio 1 through time, everything in f64 (numpy softmax + the f64 BPTT oracle)
+    logits, _ = O.gru_seq_forward(PS, p, want, f64=True, want_succ=False)
+    B = logits[0].size
+    z = logits - logits.max(0)
+    lp = z - np.log(np.exp(z).sum(0))
+    a = want["action"].astype(np.int64)
+    ind = np.stack([a == 0, a == 1]).astype(np.float64)
+    g64 = O.gru_seq_backward(PS, p, want, -(want["adv"].astype(np.float64) / B) * (ind - np.exp(lp)), f64=True)
+    logits32, _ = O.gru_seq_forward(PS, p, want, want_succ=False)
+    _, _, loss_sum, ent_sum = O.seq_policy_dlogits(logits32, want["action"], want["adv"])
+    assert rel_err(g_d, g64) < GRAD_RTOL, rel_err(g_d, g64)
+    assert abs(loss_d + loss_sum / B) <= 1e-5 * max(1.0, abs(loss_sum / B))
+    assert abs(ent_d - ent_sum / B) < 1e-5
+    H, D = 128, 5  # every parameter block receives gradient: W_ih, W_hh, b_ih, b_hh (4 gate blocks each), W1, b1, W2, b2
+    cuts = np.cumsum([4 * H * D, 4 * H * H, 4 * H, 4 * H, H * H, H, 2 * H, 2])
+    for lo, hi in zip(np.r_[0, cuts[:-1]], cuts):
+        assert np.abs(g_d[lo:hi]).max() > 0
+        assert rel_err(g_d[lo:hi], g64[lo:hi]) < 50 * GRAD_RTOL
+    for gate in range(4):  # and every gate of the recurrent matrix
+        blk = slice(4 * H * D + gate * H * H, 4 * H * D + (gate + 1) * H * H)
+        assert np.abs(g_d[blk]).max() > 0 and rel_err(g_d[blk], g64[blk]) < 50 * GRAD_RTOL
+
+
+def test_critic_gradient_through_time(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p = cri.get_params()
+    g_d, loss_d = ra.critic_gradient(cri, traj)
+    v, _ = O.gru_seq_forward(CS, p, want, f64=True, want_succ=False)
+    B = v[0].size
+    d = v - want["rtg"].astype(np.float64)[None]
+    g64 = O.gru_seq_backward(CS, p, want, 2.0 * d / B, f64=True)
+    assert rel_err(g_d, g64) < GRAD_RTOL
+    assert abs(loss_d - (d * d).mean()) <= 1e-5 * (d * d).mean()
+
+
+def test_ppo_and_critic_updates(engine):
+    pol, cri, traj, want, acfg, ocfg = setup_update(engine)
+    p0 = pol.get_params().copy()
+    cfg = ra.ppo_config_default()
+    cfg.opt_steps_per_update = 4
+    st, losses_d = ra.ppo_update(pol, ra.Adam(pol, acfg), traj, cfg, want_losses=True)
+    # the same loop on the oracle: clipped surrogate against log pi_0, backward through time, Adam
+    p = p0.copy()
+    ost = L.oracle_adam_new(len(p))
+    logits, _ = O.gru_seq_forward(PS, p, want, want_succ=False)
+    _, lp0, _, ent_sum = O.seq_policy_dlogits(logits, want["action"], want["adv"])
+    B = want["action"].size
+    losses_o = []
+    for k in range(4):
+        logits, _ = O.gru_seq_forward(PS, p, want, want_succ=False)
+        dl, _, obj, _ = O.seq_policy_dlogits(logits, want["action"], want["adv"], logp0=lp0, clip=0.2)
+        losses_o.append(-obj / B)
+        L.oracle_adam_step_f32(ost, C.byref(ocfg), O.f32p(p), O.f32p(O.gru_seq_backward(PS, p, want, dl)))
+    L.oracle_adam_free(ost)
+    assert abs(st.entropy - ent_sum / B) < 1e-5
+    assert np.max(np.abs(losses_d - np.array(losses_o))) < 3e-5 * max(1.0, np.abs(losses_o).max())
+    assert np.mean(np.abs(pol.get_params() - p) < 3e-5) > 0.97  # Adam amplifies rounding-level differences where |g| ~ 0
+    assert losses_d[-1] < losses_d[0]
+    # critic: 3 x {MSE, backward through time, Adam}
+    c0 = cri.get_params().copy()
+    cst, closs_d = ra.critic_update(cri, ra.Adam(cri, acfg), traj, 3, want_losses=True)
+    p = c0.copy()
+    ost = L.oracle_adam_new(len(p))
+    closs_o = []
+    for k in range(3):
+        v, _ = O.gru_seq_forward(CS, p, want, want_succ=False)
+        d = v[0] - want["rtg"]
+        closs_o.append(float((d.astype(np.float64) ** 2).mean()))
+        L.oracle_adam_step_f32(ost, C.byref(ocfg), O.f32p(p), O.f32p(O.gru_seq_backward(CS, p, want, (d * np.float32(2.0 / B))[None])))
+    L.oracle_adam_free(ost)
+    assert np.max(np.abs(closs_d - np.array(closs_o)) / np.array(closs_o)) < 2e-5
+    assert np.mean(np.abs(cri.get_params() - p) < 3e-5) > 0.97 and closs_d[-1] < closs_d[0]
+
+
+def test_trust_region_update_is_refused(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p0 = pol.get_params().copy()
+    with pytest.raises(ra.RelearnError) as e:
+        ra.trpo_update(pol, traj)
+    assert e.value.code == ra.ERR_UNSUPPORTED
+    assert np.array_equal(pol.get_params(), p0)
+
+
+def test_the_lstm_policy_learns_the_memory_game(engine):
+    """the behavioural check of tests/test_gpu_memory.py with the LSTM cell: answering needs the first observation"""
+    n, T = 2048, 32
+    env = ra.MemoryEnv(engine, n, seed_env=21, seed_actor=22)
+    pol = ra.LstmMlp(engine, 5, 2)
+    pol.init(5)
+    traj = ra.Trajectory(engine, n, T, 5)
+    acfg = ra.adam_config_default()
+    acfg.learning_rate = 3e-3
+    opt = ra.Adam(pol, acfg)
+    cfg = ra.ppo_config_default()
+    cfg.opt_steps_per_update = 5
+    acc = []
+    for _ in range(26):
+        ra.rollout(env, pol, traj)
+        r = traj.read(ra.TRAJ_REWARD)
+        acc.append(float((r == 1.0).sum()) / float((r != 0.0).sum()))
+        ra.reward_to_go(traj, 1.0)
+        ra.ppo_update(pol, opt, traj, cfg)
+    assert 0.4 < acc[0] < 0.6 and acc[-1] >= 0.9, acc
