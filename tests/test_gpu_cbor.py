@@ -79,15 +79,19 @@ def test_dqn_actor_document(engine):
     assert np.array_equal(other.get_params(), q.get_params())
 
 
-def test_recurrent_policy_actor_document(engine):
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_recurrent_policy_actor_document(engine, cell):
+    """Gru and Lstm are both RnnBase<impl> (seq/rnn/gru.rs:17, lstm.rs:12): one document shape, 3H or 4H gate rows"""
     env = ra.ChainEnv(engine, 64, max_steps=100)
-    pol = ra.GruMlp(engine, 5, 2)
+    make = ra.GruMlp if cell == "gru" else ra.LstmMlp
+    G = 3 if cell == "gru" else 4
+    pol = make(engine, 5, 2)
     pol.init(13)
     p = pol.get_params()
     H, D = 128, 5
-    o = [3 * H * D, 3 * H * H, 3 * H, 3 * H]
+    o = [G * H * D, G * H * H, G * H, G * H]
     c = np.cumsum([0] + o)
-    flat = [tensor(p[c[0]:c[1]].reshape(3 * H, D)), tensor(p[c[1]:c[2]].reshape(3 * H, H)), tensor(p[c[2]:c[3]]),
+    flat = [tensor(p[c[0]:c[1]].reshape(G * H, D)), tensor(p[c[1]:c[2]].reshape(G * H, H)), tensor(p[c[2]:c[3]]),
             tensor(p[c[3]:c[4]])]
     want = {"observation_space": {"inner": {"size": 5}}, "action_space": {},
             "policy_module": {"first": {"weights": {"flat_weights": flat, "has_biases": True}, "hidden_size": 128,
@@ -95,9 +99,12 @@ def test_recurrent_policy_actor_document(engine):
                               "second": mlp_doc(p[c[4]:], 128, 128, 2), "activation": "Relu"}}
     data = ra.actor_to_cbor(env, pol)
     assert data == encode(want)
-    other = ra.GruMlp(engine, 5, 2)
+    other = make(engine, 5, 2)
     other.init(1)
     ra.module_from_cbor(other, data)
     assert np.array_equal(other.get_params(), p)
     with pytest.raises(ra.RelearnError):
         ra.module_from_cbor(other, data[:-10])  # truncated document
+    wrong = (ra.LstmMlp if cell == "gru" else ra.GruMlp)(engine, 5, 2)
+    with pytest.raises(ra.RelearnError):
+        ra.module_from_cbor(wrong, data)  # the other cell's gate blocks do not fit
