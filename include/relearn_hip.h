@@ -208,8 +208,8 @@ int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidde
  * src/torch/modules/seq/rnn/lstm.rs:12-51; note that the reference's alias `LstmMlpConfig` names the GRU chain,
  * modules/mod.rs:15).  Gate rows [i; f; g; o]: W_ih [4H, in], W_hh [4H, H], b_ih [4H], b_hh [4H]; the episode state
  * is (h, c), both zero at the start of an episode (lstm.rs:22-31); c' = f * c + i * g, h' = o * tanh(c').  Same
- * shapes, initialisation rule and entry points as the GRU chain, except the trust-region update: Fisher-vector
- * products through the LSTM are not built (rl_trpo_update / rl_policy_fvp return RL_ERR_UNSUPPORTED). */
+ * shapes, initialisation rule and entry points as the GRU chain (rollout, GAE, TRPO, PPO, REINFORCE, critic update,
+ * serialisation). */
 int32_t rl_lstm_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t lstm_hidden, uint32_t mlp_hidden,
                            uint32_t out_dim, rl_mlp **out);
 

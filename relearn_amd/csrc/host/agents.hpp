@@ -242,7 +242,7 @@ struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mo
 using LstmMlpConfig = GruMlpConfig;
 
 // ChainConfig<LstmConfig, MlpConfig>::default (chain.rs:19-32 with Lstm = RnnBase<LstmImpl>, seq/rnn/lstm.rs:12-51): what a
-// user of the reference writes out to get an actual LSTM chain.  Every update except the trust-region one is built.
+// user of the reference writes out to get an actual LSTM chain.
 struct ChainLstmMlpConfig {
   uint32_t hidden_dim = 128;
   MlpConfig second_config;

@@ -1825,6 +1825,184 @@ __global__ void __launch_bounds__(256, 1) k_gru_tangent_rec(TrajDev tr, const fl
   }
 }
 
+// ---------------------------------------------------------------- the same two kernels for the LSTM chain
+// p = pre-activation of a gate: p_dot = [V_hh h + v_bhh + V_ih x + v_bih] (static, k_lstm_tangent_pre -> stat[0..3])
+//                                        + W_hh h_dot (recurrent, k_lstm_tangent_rec);
+// i_dot = i (1 - i) p_dot_i, f_dot, o_dot alike, g_dot = (1 - g^2) p_dot_g;
+// c'_dot = f_dot c + f c_dot + i_dot g + i g_dot;  h'_dot = o_dot tanh(c') + o (1 - tanh(c')^2) c'_dot.
+template <int D, int A>
+__global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const float *__restrict__ tangent,
+                                                             const float *__restrict__ act, float *__restrict__ stat,
+                                                             float *__restrict__ out_stat, uint32_t tiles,
+                                                             uint32_t blocks, uint32_t blocks_per_chunk,
+                                                             const int32_t *__restrict__ skip) {
+  __shared__ float xS[TL][8];
+  __shared__ float v2S[2][MH];
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const uint32_t N = tr.n, T = tr.T;
+  const size_t plane = (size_t)(T + 1) * N;
+  const GruParams v = seq_params(tangent, D, A, 4);
+  float whh[4][GH / 2], w1[GH / 2], wih[4][D], bih[4], bhh[4];
+#pragma unroll
+  for (int gte = 0; gte < 4; ++gte) {
+    const int row = gte * GH + j;
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks) whh[gte][ks] = v.Whh[(size_t)row * GH + 2 * ks + hf];
+#pragma unroll
+    for (int d = 0; d < D; ++d) wih[gte][d] = v.Wih[(size_t)row * D + d];
+    bih[gte] = v.bih[row];
+    bhh[gte] = v.bhh[row];
+  }
+#pragma unroll
+  for (int ks = 0; ks < GH / 2; ++ks) w1[ks] = v.W1[(size_t)j * GH + 2 * ks + hf];
+  const float vb1 = v.b1[j];
+  for (int q = threadIdx.x; q < A * MH; q += 256) v2S[q / MH][q % MH] = v.W2[q];
+  const float vb2 = hf < A ? v.b2[hf] : 0.0f;
+  const uint32_t b0 = blockIdx.x * blocks_per_chunk;
+  const uint32_t b1 = b0 + blocks_per_chunk < blocks ? b0 + blocks_per_chunk : blocks;
+  for (uint32_t blk = b0; blk < b1; ++blk) {
+    const uint32_t t = blk / tiles, tile = blk % tiles, lane0 = tile * TL;
+    const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
+    float *__restrict__ sb = stat + (size_t)blk * DPRE_ARR * GH * TL;
+    __syncthreads();
+    if (wave == 0 && lane < TL)
+#pragma unroll
+      for (int d = 0; d < D; ++d) xS[lane][d] = tr.obs[d * plane + (size_t)t * N + lane0 + lane];
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[gte][r] = bhh[gte];
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks) {
+      const float a = ab[(size_t)ACT_HPREV * GH * TL + (2 * ks + hf) * TL + n];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte)
+        acc[gte] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, whh[gte][ks], acc[gte], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = acc_row(r, hf);
+      const size_t o = (size_t)j * TL + m;
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) {
+        float q = bih[gte];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q = __builtin_fmaf(xS[m][d], wih[gte][d], q);
+        sb[(size_t)gte * GH * TL + o] = acc[gte][r] + q;
+      }
+    }
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = vb1;
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks)
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + (2 * ks + hf) * TL + n], w1[ks], acc1,
+                                                  0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sb[(size_t)4 * GH * TL + (size_t)j * TL + acc_row(r, hf)] = acc1[r];
+    if (wave == 0 && hf < A) {
+      float z = vb2;
+#pragma unroll 8
+      for (int q = 0; q < MH; ++q) z = __builtin_fmaf(ab[(size_t)ACT_U * GH * TL + q * TL + n], v2S[hf][q], z);
+      out_stat[((size_t)hf * T + t) * N + lane0 + n] = z;
+    }
+  }
+}
+
+template <int A>
+__global__ void __launch_bounds__(256, 1) k_lstm_tangent_rec(TrajDev tr, const float *__restrict__ params, int D,
+                                                             const float *__restrict__ act,
+                                                             const float *__restrict__ stat,
+                                                             const float *__restrict__ out_stat,
+                                                             float *__restrict__ out_dot,
+                                                             const int32_t *__restrict__ skip) {
+  __shared__ float hdT[GH][TL + 1];
+  __shared__ float a1dT[GH][TL + 1];
+  __shared__ float udS[TL][MH + 1];
+  __shared__ float w2S[2][MH];
+  __shared__ int endS[TL];
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
+  const uint32_t N = tr.n, T = tr.T;
+  const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
+  const GruParams g = seq_params(params, D, A, 4);
+  float whh[4][GH / 2], w1[GH / 2];
+#pragma unroll
+  for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks) whh[gte][ks] = g.Whh[(size_t)(gte * GH + j) * GH + 2 * ks + hf];
+#pragma unroll
+  for (int ks = 0; ks < GH / 2; ++ks) w1[ks] = g.W1[(size_t)j * GH + 2 * ks + hf];
+  for (int q = threadIdx.x; q < A * MH; q += 256) w2S[q / MH][q % MH] = g.W2[q];
+  for (int q = threadIdx.x; q < GH * (TL + 1); q += 256) (&hdT[0][0])[q] = 0.0f;
+  float hd[16], cd[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hd[r] = cd[r] = 0.0f;
+  __syncthreads();
+  for (uint32_t t = 0; t < T; ++t) {
+    const size_t blk = (size_t)t * tiles + tile;
+    const float *__restrict__ ab = act + blk * SEQ_ARR * GH * TL;
+    const float *__restrict__ sb = stat + blk * DPRE_ARR * GH * TL;
+    if (wave == 0 && lane < TL) endS[lane] = tr.flag[(size_t)t * N + lane0 + lane] != RL_SUCC_CONTINUE;
+    f32x16 acc[4];
+#pragma unroll
+    for (int gte = 0; gte < 4; ++gte) acc[gte] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks) {
+      const float a = hdT[2 * ks + hf][n];
+#pragma unroll
+      for (int gte = 0; gte < 4; ++gte) acc[gte] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, whh[gte][ks], acc[gte], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has read the old h_dot (and endS is visible)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = acc_row(r, hf);
+      const size_t o = (size_t)j * TL + m;
+      const float ig = ab[(size_t)LACT_I * GH * TL + o], fg = ab[(size_t)LACT_F * GH * TL + o];
+      const float gg = ab[(size_t)LACT_G * GH * TL + o], og = ab[(size_t)LACT_O * GH * TL + o];
+      const float cp = ab[(size_t)LACT_CPREV * GH * TL + o], tc = ab[(size_t)LACT_TC * GH * TL + o];
+      const float a1 = ab[(size_t)ACT_A1 * GH * TL + o];
+      const float id = ig * (1.0f - ig) * (acc[0][r] + sb[(size_t)0 * GH * TL + o]);
+      const float fd = fg * (1.0f - fg) * (acc[1][r] + sb[(size_t)1 * GH * TL + o]);
+      const float gd = (1.0f - gg * gg) * (acc[2][r] + sb[(size_t)2 * GH * TL + o]);
+      const float od = og * (1.0f - og) * (acc[3][r] + sb[(size_t)3 * GH * TL + o]);
+      const float cnd = fd * cp + fg * cd[r] + id * gg + ig * gd;
+      const float tcd = (1.0f - tc * tc) * cnd;
+      const float v = od * tc + og * tcd;
+      const bool ended = endS[m] != 0;  // the next step of an ended episode starts from zero
+      hd[r] = ended ? 0.0f : v;
+      cd[r] = ended ? 0.0f : cnd;
+      hdT[j][m] = hd[r];
+      a1dT[j][m] = a1 > 0.0f ? v : 0.0f;
+    }
+    __syncthreads();
+    f32x16 acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < GH / 2; ++ks)
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1dT[2 * ks + hf][n], w1[ks], acc1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = acc_row(r, hf);
+      const size_t o = (size_t)j * TL + m;
+      const float u = ab[(size_t)ACT_U * GH * TL + o];
+      udS[m][j] = u > 0.0f ? acc1[r] + sb[(size_t)4 * GH * TL + o] : 0.0f;
+    }
+    __syncthreads();
+    if (wave == 0 && hf < A) {
+      float z = out_stat[((size_t)hf * T + t) * N + lane0 + n];
+#pragma unroll 8
+      for (int q = 0; q < MH; ++q) z = __builtin_fmaf(udS[n][q], w2S[hf][q], z);
+      out_dot[((size_t)hf * T + t) * N + lane0 + n] = z;
+    }
+    __syncthreads();
+  }
+}
+
 // dz <- (diag(p) - p p^T) out_dot / B with p = exp(log pi_0)  (the metric of the KL's Gauss-Newton form)
 __global__ void __launch_bounds__(256) k_seq_fvp_dlogits(TrajDev tr, const float *__restrict__ out_dot,
                                                          const float *__restrict__ lp0, float *__restrict__ dz,
@@ -1842,18 +2020,23 @@ __global__ void __launch_bounds__(256) k_seq_fvp_dlogits(TrajDev tr, const float
 
 void launch_gru_tangent(rl_traj *traj, const rl_mlp *mod, const float *d_tangent, uint64_t B_total,
                         const int32_t *d_skip) {
-  if (mod->kind == RL_MODULE_LSTM_MLP)
-    throw RlError(RL_ERR_UNSUPPORTED, "Fisher-vector products through the LSTM chain are not built (use PPO / REINFORCE)");
   rl_engine *e = traj->eng;
   const SeqDev &q = traj->seq;
   RL_REQUIRE(mod->out_dim == 2, "Fisher-vector products are for 2-action policies");
   uint32_t blocks = traj->d.T * q.tiles;
   {
     ProfScope ps(e, RL_K_POLICY_FUSED);
-    hipLaunchKernelGGL((k_gru_tangent_pre<5, 2>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, d_tangent, q.act,
-                       q.dpre, q.succ, q.tiles, blocks, q.blocks_per_chunk, d_skip);
-    hipLaunchKernelGGL(k_gru_tangent_rec<2>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, q.act,
-                       q.dpre, q.succ, q.out, d_skip);
+    if (mod->kind == RL_MODULE_LSTM_MLP) {
+      hipLaunchKernelGGL((k_lstm_tangent_pre<5, 2>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, d_tangent, q.act,
+                         q.dpre, q.succ, q.tiles, blocks, q.blocks_per_chunk, d_skip);
+      hipLaunchKernelGGL(k_lstm_tangent_rec<2>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, q.act,
+                         q.dpre, q.succ, q.out, d_skip);
+    } else {
+      hipLaunchKernelGGL((k_gru_tangent_pre<5, 2>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, d_tangent, q.act,
+                         q.dpre, q.succ, q.tiles, blocks, q.blocks_per_chunk, d_skip);
+      hipLaunchKernelGGL(k_gru_tangent_rec<2>, dim3(q.tiles), dim3(256), 0, e->stream, traj->d, mod->d_params, 5, q.act,
+                         q.dpre, q.succ, q.out, d_skip);
+    }
   }
   {
     ProfScope ps(e, RL_K_POLICY_PASS);

@@ -411,7 +411,33 @@ def lstm_case(dtype, D=3, H=4, H2=5, A=2, n=3, T=7, seed=43):
         out[:, t, i] = y.detach()
         loss = loss + (dout[:, t, i] * y).sum()
     loss.backward()
+    # forward-mode derivative of all outputs along a random parameter tangent (torch.autograd.functional.jvp)
+    tangent = (torch.randn(P, generator=g, dtype=torch.float64)).to(dtype)
+
+    def all_outputs(pv):
+        o2 = 0
+        pp = []
+        for sz in sizes:
+            pp.append(pv[o2:o2 + sz])
+            o2 += sz
+        wih, whh, b_ih, b_hh = pp[0].reshape(4 * H, D), pp[1].reshape(4 * H, H), pp[2], pp[3]
+        w1, bb1, w2, bb2 = pp[4].reshape(H2, H), pp[5], pp[6].reshape(A, H2), pp[7]
+        ys = []
+        for i in range(n):
+            h, c = zeros()
+            for t in range(T):
+                h, c = torch.lstm_cell(obs[:, t, i].unsqueeze(0), (h, c), wih, whh, b_ih, b_hh)
+                y = torch.nn.functional.linear(
+                    torch.relu(torch.nn.functional.linear(torch.relu(h), w1, bb1)), w2, bb2).squeeze(0)
+                ys.append(y)
+                if int(flag[t, i]) != 0:
+                    h, c = zeros()
+        return torch.stack(ys)  # [n * T, A]
+
+    _, jv = torch.autograd.functional.jvp(all_outputs, params.detach(), tangent)
+    out_dot = jv.reshape(n, T, A).permute(2, 1, 0).contiguous()
     return {
+        "tangent": tangent.double().tolist(), "out_dot": out_dot.double().flatten().tolist(),
         "dims": [D, H, H2, A], "n": n, "T": T, "dtype": str(dtype).replace("torch.", ""),
         "params": params.detach().double().tolist(), "obs": obs.double().flatten().tolist(),
         "term_obs": term_obs.double().flatten().tolist(), "flag": flag.flatten().tolist(),

@@ -187,13 +187,39 @@ def test_ppo_and_critic_updates(engine):
     assert np.mean(np.abs(cri.get_params() - p) < 3e-5) > 0.97 and closs_d[-1] < closs_d[0]
 
 
-def test_trust_region_update_is_refused(engine):
+def test_fisher_vector_product_through_time(engine):
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    p = pol.get_params()
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=len(p)).astype(np.float32)
+    reg = 1e-5
+    hv_d = ra.policy_fvp(pol, traj, v, reg)
+    hv64 = O.gru_policy_fvp(PS, p.astype(np.float64), v.astype(np.float64), want, reg, f64=True)
+    hv32 = O.gru_policy_fvp(PS, p, v, want, reg)
+    assert rel_err(hv_d, hv64) < 2e-5, (rel_err(hv_d, hv64), rel_err(hv32, hv64))
+    assert rel_err(hv_d, hv64) < 4 * rel_err(hv32, hv64) + 2e-6
+
+
+def test_trpo_update_through_time(engine):
+    """conjugate-gradient trust-region step through the LSTM: accepted inside the region, and what the device reports
+    is what an independent re-evaluation of the new parameters gives (the CG arithmetic itself is compared with the
+    oracle's in tests/test_gpu_gru.py: the same device code runs here on the LSTM's gradient / Fisher-vector passes)"""
     pol, cri, traj, want, _, _ = setup_update(engine)
     p0 = pol.get_params().copy()
-    with pytest.raises(ra.RelearnError) as e:
-        ra.trpo_update(pol, traj)
-    assert e.value.code == ra.ERR_UNSUPPORTED
-    assert np.array_equal(pol.get_params(), p0)
+    st = ra.trpo_update(pol, traj)
+    assert st.status == ra.OPT_OK and st.cg_iterations == 10
+    assert st.constraint_val_final <= 0.01 and st.loss_final < st.loss_initial
+    loss_d, kl_d = ra.policy_loss_kl(pol, traj, p0)
+    assert abs(loss_d - st.loss_final) <= 1e-5 * max(1.0, abs(st.loss_final))
+    assert abs(kl_d - st.constraint_val_final) <= 1e-5 + 1e-3 * kl_d
+    # against the f64 evaluation of the same accepted step
+    l0, _ = O.gru_seq_forward(PS, p0, want, f64=True, want_succ=False)
+    l1, _ = O.gru_seq_forward(PS, pol.get_params(), want, f64=True, want_succ=False)
+    lp0, lp1 = l0 - np.log(np.exp(l0).sum(0)), l1 - np.log(np.exp(l1).sum(0))
+    a = want["action"].astype(np.int64)
+    sel = lambda lp: np.where(a == 0, lp[0], lp[1])
+    assert abs(-(np.exp(sel(lp1) - sel(lp0)) * want["adv"]).mean() - st.loss_final) <= 2e-5 * max(1.0, abs(st.loss_final))
+    assert abs((np.exp(lp0) * (lp0 - lp1)).sum(0).mean() - st.constraint_val_final) <= 1e-4 * st.constraint_val_final + 3e-8
 
 
 def test_the_lstm_policy_learns_the_memory_game(engine):

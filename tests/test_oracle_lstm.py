@@ -96,3 +96,27 @@ def test_memory_lanes_rollout_with_the_lstm_policy():
     assert (tr["flag"] == O.TERMINATE).sum() == 8 * 6
     again = O.MemoryLaneSim(8, seed_env=1, seed_actor=2).rollout_gru(s, p, 24)
     assert all(np.array_equal(tr[k], again[k]) for k in tr)
+
+
+@pytest.mark.parametrize("name,rtol", [("lstm_f32", 2e-5), ("lstm_f64", 1e-11)])
+def test_forward_mode_derivative_through_time(name, rtol):
+    """the LSTM JVP against torch.autograd.functional.jvp of all step outputs along a parameter tangent"""
+    c, s, traj = _case(name)
+    f64 = name.endswith("f64")
+    od = O.gru_seq_jvp(s, np.array(c["params"]), np.array(c["tangent"]), traj, f64=f64)
+    want = np.array(c["out_dot"]).reshape(od.shape)
+    assert np.max(np.abs(od - want)) <= rtol * np.max(np.abs(want))
+
+
+def test_fisher_vector_product_is_symmetric_and_positive():
+    """F = J^T (diag p - p p^T) J / B through the LSTM: v.Fw == w.Fv and v.Fv > 0"""
+    s = O.LstmShape(5, 16, 12, 2)
+    sim = O.ChainLaneSim(24, max_steps=7, seed_env=2, seed_actor=3)
+    p = O.gru_init(s, 4).astype(np.float64)
+    traj = sim.rollout_gru(s, p.astype(np.float32), 18, threads=2)
+    rng = np.random.default_rng(0)
+    v, w = rng.normal(size=len(p)), rng.normal(size=len(p))
+    Fv = O.gru_policy_fvp(s, p, v, traj, 0.0, f64=True)
+    Fw = O.gru_policy_fvp(s, p, w, traj, 0.0, f64=True)
+    assert abs(v @ Fw - w @ Fv) <= 1e-10 * abs(v @ Fw)
+    assert v @ Fv > 0
