@@ -1367,14 +1367,17 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_lstm_bptt(TrajDev tr, const flo
 // ONCE per workgroup with fully coalesced 16-byte loads into registers while the previous block's products run, then
 // parked in LDS ([unit][36] rows: the 16-byte operand reads of 16 consecutive rows hit 64 different banks); a wave's B
 // rows (h_prev, relu(h') of its own 32 units) and the rows only its VALU sums need come straight from HBM.
-template <int D, int A, int NG>  // NG gate blocks: 3 = GRU (staged: d gh_r, d gh_z, d gh_n = d pre_n * r), 4 = LSTM
+// NGT gate blocks in the module: 3 = GRU (staged: d gh_r, d gh_z, d gh_n = d pre_n * r), 4 = LSTM.  One launch covers the
+// gates [G0, G0 + GN) and, WITH_W1, the head (W1, b1, W2, b2): the GRU takes everything in one launch (16 output tiles per
+// wave = 256 accumulator registers), the LSTM's 20 tiles are split into gates {i, f} + head and gates {g, o}.
+template <int D, int A, int NGT, int G0, int GN, bool WITH_W1>
 __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *__restrict__ dz,
                                                       const float *__restrict__ act, const float *__restrict__ dpre,
                                                       float *__restrict__ slab, uint32_t P, uint32_t tiles,
                                                       uint32_t blocks, uint32_t blocks_per_chunk,
                                                       const int32_t *__restrict__ skip) {
   constexpr int RS = TL + 4;
-  constexpr int S_DU = NG, S_N = NG + 1;  // staged arrays: the NG hidden-side gate gradients, then d u_pre
+  constexpr int S_DU = GN, S_N = GN + (WITH_W1 ? 1 : 0);  // staged arrays: the hidden-side gate gradients [, d u_pre]
   __shared__ __attribute__((aligned(16))) float aS[S_N][GH][RS];
   __shared__ float xS[TL][8];
   __shared__ float dzS[2][TL];
@@ -1383,14 +1386,14 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
   const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
   const uint32_t N = tr.n, T = tr.T;
   const size_t B = (size_t)T * N, plane = (size_t)(T + 1) * N;
-  f32x16 acc_hh[4 * NG], acc_w1[4];
+  f32x16 acc_hh[4 * GN], acc_w1[4];
 #pragma unroll
-  for (int q = 0; q < 4 * NG; ++q) acc_hh[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = 0; q < 4 * GN; ++q) acc_hh[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc_w1[q] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float dwih[NG][D], dbih[NG], dbhh[NG], db1 = 0.0f, dw2[A], db2 = 0.0f;
+  float dwih[GN][D], dbih[GN], dbhh[GN], db1 = 0.0f, dw2[A], db2 = 0.0f;
 #pragma unroll
-  for (int gte = 0; gte < NG; ++gte) {
+  for (int gte = 0; gte < GN; ++gte) {
     dbih[gte] = dbhh[gte] = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) dwih[gte][d] = 0.0f;
@@ -1408,8 +1411,8 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
     // GRU: dpre arrays 0, 1, 3 (hidden side of the n gate), 4; LSTM: 0, 1, 2, 3, 4
     const float *src[S_N];
 #pragma unroll
-    for (int a = 0; a < NG; ++a) src[a] = db + (size_t)((NG == 3 && a == 2) ? 3 : a) * GH * TL;
-    src[S_DU] = db + (size_t)DPRE_DU * GH * TL;
+    for (int a = 0; a < GN; ++a) src[a] = db + (size_t)((NGT == 3 && G0 + a == 2) ? 3 : G0 + a) * GH * TL;
+    if constexpr (WITH_W1) src[S_DU] = db + (size_t)DPRE_DU * GH * TL;
 #pragma unroll
     for (int a = 0; a < S_N; ++a)
 #pragma unroll
@@ -1462,8 +1465,8 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         a1B[4 * q + i] = a14[q][i];
       }
 #pragma unroll
-    for (int mt = 0; mt < 4 * NG; ++mt) {
-      const int gte = mt >> 2, row = 32 * (mt & 3) + n;  // unit of this lane's A row
+    for (int mt = 0; mt < 4 * GN; ++mt) {
+      const int gte = mt >> 2, row = 32 * (mt & 3) + n;  // local gate index; unit of this lane's A row
       float av[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1480,7 +1483,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         for (int ks = 0; ks < 16; ++ks) {
           const int m = 16 * hf + ks;
           const float dgh = av[ks];
-          const float dgi = (NG == 3 && gte == 2) ? dpnv[ks >> 2][ks & 3] : dgh;  // GRU: input side of the n gate
+          const float dgi = (NGT == 3 && G0 + gte == 2) ? dpnv[ks >> 2][ks & 3] : dgh;  // GRU: input side of the n gate
           dbhh[gte] += dgh;
           dbih[gte] += dgi;
 #pragma unroll
@@ -1488,6 +1491,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
         }
       }
     }
+    if constexpr (WITH_W1) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int row = 32 * mt + n;
@@ -1513,23 +1517,26 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
       }
     }
     if (wave == 0 && lane < A * TL) db2 += dzS[lane >> 5][lane & 31];  // lane = (a = hf, m = n)
+    }
   }
   // ---- write this workgroup's row of partials
   float *__restrict__ out = slab + (size_t)blockIdx.x * P;
-  const size_t oWih = 0, oWhh = oWih + (size_t)NG * GH * D, obih = oWhh + (size_t)NG * GH * GH, obhh = obih + NG * GH;
-  const size_t oW1 = obhh + NG * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH, ob2 = oW2 + (size_t)A * MH;
+  const size_t oWih = 0, oWhh = oWih + (size_t)NGT * GH * D, obih = oWhh + (size_t)NGT * GH * GH, obhh = obih + NGT * GH;
+  const size_t oW1 = obhh + NGT * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH, ob2 = oW2 + (size_t)A * MH;
 #pragma unroll
-  for (int mt = 0; mt < 4 * NG; ++mt)
+  for (int mt = 0; mt < 4 * GN; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[oWhh + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_hh[mt][r];
+    for (int r = 0; r < 16; ++r) out[oWhh + (size_t)(G0 * GH + 32 * mt + acc_row(r, hf)) * GH + j] = acc_hh[mt][r];
+  if constexpr (WITH_W1) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[oW1 + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_w1[mt][r];
+      for (int r = 0; r < 16; ++r) out[oW1 + (size_t)(32 * mt + acc_row(r, hf)) * GH + j] = acc_w1[mt][r];
+  }
   // VALU sums: the two halves of a wave hold samples 0..15 and 16..31 of the same rows
 #pragma unroll
-  for (int gte = 0; gte < NG; ++gte) {
-    const int row = gte * GH + j;
+  for (int gte = 0; gte < GN; ++gte) {
+    const int row = (G0 + gte) * GH + j;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const float v = dwih[gte][d] + __shfl_xor(dwih[gte][d], 32, 64);
@@ -1541,7 +1548,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
       out[obhh + row] = vh;
     }
   }
-  {
+  if constexpr (WITH_W1) {
     const float v = db1 + __shfl_xor(db1, 32, 64);
     if (hf == 0) out[ob1 + j] = v;
 #pragma unroll
@@ -1550,7 +1557,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
       if (hf == 0) out[oW2 + (size_t)a * MH + j] = v2;
     }
   }
-  if (wave == 0) {
+  if (WITH_W1 && wave == 0) {
     float v = db2;  // lanes of half `a` hold the per-sample-slot sums of output a
 #pragma unroll
     for (int s = 16; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
@@ -1634,15 +1641,23 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   }
   {
     ProfScope ps(e, RL_K_CRITIC_FUSED);
-#define WG(AA, NGG)                                                                                              \
-  hipLaunchKernelGGL((k_gru_wgrad<5, AA, NGG>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, q.act, \
-                     q.dpre, q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk, d_skip)
+#define WG(AA, NGT, G0, GN, W1)                                                                                   \
+  hipLaunchKernelGGL((k_gru_wgrad<5, AA, NGT, G0, GN, W1>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, \
+                     q.act, q.dpre, q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk, d_skip)
     if (mod->out_dim == 2) {
-      if (lstm) WG(2, 4);
-      else WG(2, 3);
+      if (lstm) {
+        WG(2, 4, 0, 2, true);
+        WG(2, 4, 2, 2, false);
+      } else {
+        WG(2, 3, 0, 3, true);
+      }
     } else {
-      if (lstm) WG(1, 4);
-      else WG(1, 3);
+      if (lstm) {
+        WG(1, 4, 0, 2, true);
+        WG(1, 4, 2, 2, false);
+      } else {
+        WG(1, 3, 0, 3, true);
+      }
     }
 #undef WG
   }
