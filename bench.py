@@ -335,6 +335,11 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
+        try:
+            eng.comm_destroy()  # every rank releases its communicator before the control group goes away
+        except ra.RelearnError as exc:
+            print("bench.py: rank %d: comm_destroy: %s" % (rank, exc), file=sys.stderr)
+        dist.barrier()
         dist.destroy_process_group()
 
 
