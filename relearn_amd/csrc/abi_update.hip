@@ -134,6 +134,14 @@ int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg,
       launch_ls_set_params(traj, policy, ratio);
       run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
       launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
+      // once a candidate is accepted the remaining iterations are no-ops on the device (every launch tests the flag);
+      // reading the flag back every second candidate spares their launches — and, with several ranks, their
+      // all-reduces.  Replicas are identical, so every rank leaves the loop at the same iteration.
+      if ((i & 1) == 1 && i + 1 < cfg->max_backtracks) {
+        int32_t accepted = 0;
+        d2h(e, &accepted, &traj->trpo->ls_accepted, sizeof(accepted));
+        if (accepted != 0) break;
+      }
     }
     launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
     TrpoStateDev h;
