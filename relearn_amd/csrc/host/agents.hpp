@@ -560,6 +560,22 @@ std::unique_ptr<DqnAgent> build_dqn_agent(const DqnConfig<VB> &c, EnvLanes &env,
   return a;
 }
 
+// ---------------------------------------------------------------- actor serialisation (examples/cartpole-trpo.rs:71-93)
+// `serde_cbor::to_writer(file, &agent.actor(ActorMode::Evaluation))` / `serde_cbor::from_reader(file)`
+inline std::vector<uint8_t> actor_to_cbor(EnvLanes &env, Module &module, int32_t actor_kind = RL_ACTOR_POLICY,
+                                          double exploration_rate = 0.0) {
+  uint64_t len = 0;
+  check(rl_actor_to_cbor(env.handle(), module.handle(), actor_kind, exploration_rate, nullptr, 0, &len),
+        env.engine().handle());
+  std::vector<uint8_t> buf(len);
+  check(rl_actor_to_cbor(env.handle(), module.handle(), actor_kind, exploration_rate, buf.data(), len, &len),
+        env.engine().handle());
+  return buf;
+}
+inline void module_from_cbor(Module &module, const std::vector<uint8_t> &doc, Engine &eng) {
+  check(rl_module_from_cbor(module.handle(), doc.data(), doc.size()), eng.handle());
+}
+
 // ---------------------------------------------------------------- the period loop of train_parallel (train.rs:68-186)
 inline void train_batched(ActorCriticAgent &agent, EnvLanes &env, DeviceHistory &history, uint64_t num_periods,
                           StatsLogger &logger) {
@@ -571,6 +587,9 @@ inline void train_batched(ActorCriticAgent &agent, EnvLanes &env, DeviceHistory 
       ScopedLogger sim(logger, "sim");
       uint64_t episodes = 0;
       for (uint8_t f : history.successors()) episodes += f != RL_SUCC_CONTINUE;
+      // train.rs:160-175 logs the period's StepsSummary; with lanes that persist across periods the episode statistics
+      // are per period: mean length = steps / episode ends (a moving estimate), CartPole's episode reward = its length
+      if (episodes > 0) sim.log_scalar("ep/length_mean", (double)history.num_steps() / (double)episodes);
       sim.log_counter_increment("ep/count", episodes);                 // train.rs:171
       sim.log_counter_increment("step/count", history.num_steps());    // train.rs:175
       sim.log_duration("time", std::chrono::duration<double>(std::chrono::steady_clock::now() - collect_start).count());

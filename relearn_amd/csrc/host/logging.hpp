@@ -120,6 +120,32 @@ class RecordingLogger : public StatsLogger {
   }
 };
 
+// two loggers at once: the reference implements StatsLogger for pairs `(A, B)` (mod.rs:360-386), which is how the
+// examples display and write TensorBoard files at the same time
+class TeeLogger : public StatsLogger {
+ public:
+  TeeLogger(StatsLogger &a, StatsLogger &b) : a_(a), b_(b) {}
+  void group_start() override {
+    a_.group_start();
+    b_.group_start();
+  }
+  void group_log(const std::string &id, const LogValue &v) override {
+    a_.group_log(id, v);
+    b_.group_log(id, v);
+  }
+  void group_end() override {
+    a_.group_end();
+    b_.group_end();
+  }
+  void flush() override {
+    a_.flush();
+    b_.flush();
+  }
+
+ private:
+  StatsLogger &a_, &b_;
+};
+
 // the no-op logger: `()` implements StatsLogger in the reference (mod.rs:347-358)
 class NullLogger : public StatsLogger {
  public:

@@ -121,3 +121,36 @@ def test_cpp_host_api_matches_the_ctypes_path(engine):
     assert d["scalars"]["loss"] == ust.loss_last and d["scalars"]["exploration_rate"] == rate
     assert d["scalars"]["global_steps"] == ust.global_steps == steps
     assert d["counters"] == {"sim/ep/count": eps, "sim/step/count": steps}
+
+
+def build_example():
+    ra.build()
+    out = os.path.join(tempfile.mkdtemp(), "cartpole_trpo")
+    libdir = os.path.join(ROOT, "relearn_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", ROOT,
+                           os.path.join(ROOT, "examples", "cartpole_trpo.cpp"), "-o", out, "-L", libdir,
+                           "-lrelearn_hip", "-Wl,-rpath," + libdir])
+    return out
+
+
+def test_cartpole_trpo_example_compiles():
+    assert os.path.exists(build_example())
+
+
+@pytest.mark.gpu
+def test_cartpole_trpo_example_trains_saves_and_evaluates():
+    """examples/cartpole_trpo.cpp, the counterpart of the reference's examples/cartpole-trpo.rs: trains with the display
+    and TensorBoard loggers, saves the evaluation actor as CBOR, reloads it and evaluates — and the agent has learned"""
+    exe = build_example()
+    out_dir = tempfile.mkdtemp()
+    log = subprocess.check_output([exe, "--lanes", "2048", "--periods", "24", "--out", out_dir], timeout=300).decode()
+    lengths = [float(l.split()[1]) for l in log.splitlines() if l.startswith("sim/ep/length_mean")]
+    assert len(lengths) == 12 and lengths[0] < 40 and lengths[-1] > 3 * lengths[0], lengths  # one display chunk per 2 updates
+    for name in ("policy/entropy", "policy/step_size", "critic/loss", "agent_update/count", "sim/step/count"):
+        assert any(l.startswith(name) for l in log.splitlines()), name
+    assert any(f.startswith("events.out.tfevents.") for f in os.listdir(out_dir))
+    actor = os.path.join(out_dir, "actor.cbor")
+    assert os.path.getsize(actor) > 4 * 1026
+    ev = subprocess.check_output([exe, actor], timeout=120).decode()
+    mean_len = float(ev.strip().split()[-1])
+    assert mean_len > 3 * lengths[0], ev  # the reloaded actor plays as well as the trained one
