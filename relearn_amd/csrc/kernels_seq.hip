@@ -217,6 +217,7 @@ struct SeqFwdSharedT {
   float w2S[2][MH];
   float outS[2][TL];
   int endS[TL];             // != 0: the lane's episode ended at this step (recurrent state restarts)
+  int endS2[TL];            // the teacher-forced forward stages step t + 1 while step t's flags are still being read
   int peek;                 // != 0: some lane of the tile needs a successor evaluation at this step
   // LSTM only: the MLP's first layer as MFMA B operands, [wave][k-step][lane] (its four gate matrices fill the
   // register budget the GRU spends on three gates + this layer)
@@ -263,7 +264,7 @@ __device__ __forceinline__ void seq_load_weights16(SeqFwdWeights16<D> &w, const 
 // sh.hT[cur ^ 1] and `hnew`; the head outputs land in sh.outS (valid after the function returns: it ends with a
 // barrier).  `store` != nullptr: record the 7 activation arrays of this (t, tile) block ([unit][lane] rows: a lane's
 // four samples of an M-tile are contiguous, one 16-byte store per array and M-tile).
-template <int D, int A>
+template <int D, int A, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights16<D> &w, int cur,
                                            const float (&hown)[8], float (&hnew)[8], float b2_mine,
                                            float *__restrict__ store, int wave, int lane) {
@@ -357,7 +358,15 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
     for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
     sh.outS[hf][n] = z;
   }
-  __syncthreads();
+  // the head's outputs are read by lanes of wave 0 only (the env / io lanes): a caller that syncs the workgroup later
+  // anyway needs just the in-wave ordering of these LDS writes
+  if (FINAL_BARRIER) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // ---------------------------------------------------------------- LSTM cell (seq/rnn/lstm.rs:17-51), same ownership
@@ -391,7 +400,7 @@ __device__ __forceinline__ void lstm_load_weights16(LstmFwdWeights16<D> &w, cons
   w.b1 = g.b1[j];
 }
 
-template <int D, int A>
+template <int D, int A, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeights16<D> &w, int cur,
                                             const float (&sown)[16], float (&snew)[16], float b2_mine,
                                             float *__restrict__ store, int wave, int lane) {
@@ -491,7 +500,15 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
     for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
     sh.outS[hf][n] = z;
   }
-  __syncthreads();
+  // the head's outputs are read by lanes of wave 0 only (the env / io lanes): a caller that syncs the workgroup later
+  // anyway needs just the in-wave ordering of these LDS writes
+  if (FINAL_BARRIER) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // The two cells behind one interface for the rollout / teacher-forced forward loops.  NS = per-lane state registers
@@ -505,11 +522,11 @@ struct GruCell16 {
   static __device__ __forceinline__ void load(Weights<D> &w, const GruParams &g, Shared &, int wave, int lane) {
     seq_load_weights16<D>(w, g, wave, lane);
   }
-  template <int D, int A>
+  template <int D, int A, bool FINAL_BARRIER = true>
   static __device__ __forceinline__ void cell(Shared &sh, const Weights<D> &w, int cur, const float (&sown)[NS],
                                               float (&snew)[NS], float b2_mine, float *__restrict__ store, int wave,
                                               int lane) {
-    seq_cell16<D, A>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
+    seq_cell16<D, A, FINAL_BARRIER>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
   }
 };
 
@@ -522,11 +539,11 @@ struct LstmCell16 {
   static __device__ __forceinline__ void load(Weights<D> &w, const GruParams &g, Shared &sh, int wave, int lane) {
     lstm_load_weights16<D>(w, g, sh, wave, lane);
   }
-  template <int D, int A>
+  template <int D, int A, bool FINAL_BARRIER = true>
   static __device__ __forceinline__ void cell(Shared &sh, const Weights<D> &w, int cur, const float (&sown)[NS],
                                               float (&snew)[NS], float b2_mine, float *__restrict__ store, int wave,
                                               int lane) {
-    lstm_cell16<D, A>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
+    lstm_cell16<D, A, FINAL_BARRIER>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
   }
 };
 
@@ -695,20 +712,23 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
   uint32_t t = 0;
   // One cell evaluation per iteration.  A step whose episode is cut in some lane of the tile is followed by a
   // "peek" iteration that evaluates the successor observation from the post-step state without advancing it.
-  while (t < T) {
-    if (!peeking) {
-      if (io_lane) {
+  // Two workgroup barriers per iteration: after the io lanes have seen the outputs (peek decision published), and
+  // after the commit, which also stages the next step's observation and flags (flags double-buffered by step parity:
+  // the commit of step t still reads its own while step t + 1's are written).
+  auto endbuf = [&](uint32_t tt) -> int * { return (tt & 1) ? sh.endS2 : sh.endS; };
+  auto stage = [&](uint32_t tt) {  // io lanes: observation and successor code of step tt
 #pragma unroll
-        for (int d = 0; d < D; ++d) sh.xS[lane][d] = tr.obs[d * plane + (size_t)t * N + i];
-        flag = tr.flag[(size_t)t * N + i];
-        sh.endS[lane] = flag != RL_SUCC_CONTINUE;
-      }
-      if (threadIdx.x == 0) sh.peek = 0;
-    }
-    __syncthreads();
+    for (int d = 0; d < D; ++d) sh.xS[lane][d] = tr.obs[d * plane + (size_t)tt * N + i];
+    flag = tr.flag[(size_t)tt * N + i];
+    endbuf(tt)[lane] = flag != RL_SUCC_CONTINUE;
+  };
+  if (io_lane) stage(0);
+  if (threadIdx.x == 0) sh.peek = 0;
+  __syncthreads();
+  while (t < T) {
     float hout[NS];
     float *store = (act != nullptr && !peeking) ? act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL : nullptr;
-    Cell::template cell<D, A>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
+    Cell::template cell<D, A, false>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
     if (io_lane) {
       if (!peeking) {
 #pragma unroll
@@ -739,17 +759,21 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
     } else {
       // commit: restart the state of lanes whose episode ended at step t
       const int buf = peeking ? cur : (cur ^ 1);
+      const int *ends = endbuf(t);
 #pragma unroll
       for (int r = 0; r < NS; ++r) {
         const int m = acc16_row((r & 7) >> 2, r & 3, g4);
-        const bool ended = sh.endS[m] != 0;
+        const bool ended = ends[m] != 0;
         const float hv = peeking ? hown[r] : hout[r];
         hown[r] = ended ? 0.0f : hv;
         if (ended && r < 8) sh.hT[buf][j][m] = 0.0f;
       }
       cur = buf;
+      // every thread has `peeking` in a register: the flag in LDS may be cleared while others still evaluate the branch
+      if (peeking && threadIdx.x == 0) sh.peek = 0;
       peeking = false;
       t += 1;
+      if (io_lane && t < T) stage(t);
     }
     __syncthreads();
   }
