@@ -493,7 +493,8 @@ struct PolicyTile {
 
 template <int MODE>  // PASS_INIT (gradient), PASS_JVP (Fisher-vector product), PASS_EVAL (loss / KL only)
 __global__ void __launch_bounds__(V2_WAVES * 64, 2)  // (three waves per SIMD: 30 spills and 10 % slower, measured;
-                                                     // with layer 1 recomputed for the backward, 12 spills, 9 % slower)
+                                                     // with layer 1 recomputed for the backward, 12 spills, 9 % slower;
+                                                     // recomputing only two of the four hidden tiles: 43 spills)
     k_policy_mfma(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
                   float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
                   uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
