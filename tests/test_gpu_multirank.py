@@ -161,6 +161,7 @@ def test_bench_as_two_processes_over_the_host_collective():
     one GPU.  RCCL refuses two ranks on one device, so the data-plane collective is the library's host-staged one
     (rl_comm_init_host over the same gloo group); the RCCL call path itself is covered by the one-rank communicator test.
     The sharded job must report the same update statistics as the one-process job (same samples, other sum order)."""
+    pytest.importorskip("torch")  # also pages the library in, so that the ranks below start within their time limit
     one = run_bench(1)
     two = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "gloo"})
     assert two["n_gpus"] == 2 and two["config"]["n_envs_per_gpu"] == 1024 and two["config"]["n_envs_total"] == 2048
