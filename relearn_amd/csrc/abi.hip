@@ -67,9 +67,26 @@ typedef int (*comm_init_rank_t)(void **, int, UniqueId, int);
 
 void rccl_load() {
   if (g_rccl.handle) return;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char *n : names) {
-    g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  // RCCL must run on the SAME HIP runtime as this library: a host program may have mapped a second copy of the ROCm
+  // libraries (PyTorch bundles libamdhip64 / librccl under torch/lib), and a communicator created by the other copy's
+  // RCCL cannot use this runtime's streams ("unhandled cuda error").  So: first the librccl that sits next to the
+  // libamdhip64 this library is bound to, then the usual names.
+  std::vector<std::string> names;
+  Dl_info info;
+  if (dladdr((void *)&hipGetDeviceCount, &info) != 0 && info.dli_fname != nullptr) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash);
+      names.push_back(dir + "/librccl.so.1");
+      names.push_back(dir + "/librccl.so");
+    }
+  }
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  names.push_back("/opt/rocm/lib/librccl.so.1");
+  for (const std::string &n : names) {
+    g_rccl.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (g_rccl.handle) break;
   }
   if (!g_rccl.handle) throw RlError(RL_ERR_COMM, std::string("cannot dlopen librccl: ") + dlerror());

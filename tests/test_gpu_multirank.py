@@ -161,7 +161,11 @@ def test_bench_as_two_processes_over_the_host_collective():
     one GPU.  RCCL refuses two ranks on one device, so the data-plane collective is the library's host-staged one
     (rl_comm_init_host over the same gloo group); the RCCL call path itself is covered by the one-rank communicator test.
     The sharded job must report the same update statistics as the one-process job (same samples, other sum order)."""
-    pytest.importorskip("torch")  # also pages the library in, so that the ranks below start within their time limit
+    # page torch in first (a cold image needs a minute or two for its first import), in a child process: importing it
+    # here would map a second copy of the ROCm runtime into the test process
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
     one = run_bench(1)
     two = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "gloo"})
     assert two["n_gpus"] == 2 and two["config"]["n_envs_per_gpu"] == 1024 and two["config"]["n_envs_total"] == 2048
@@ -174,3 +178,31 @@ def test_bench_as_two_processes_over_the_host_collective():
     # the Fisher-vector products, so the runs stay close, not identical
     assert abs(a["entropy"] - b["entropy"]) < 5e-3
     assert abs(a["critic_loss_last"] - b["critic_loss_last"]) < 5e-2 * a["critic_loss_last"]
+
+
+@pytest.mark.parametrize("order", ["torch_first", "engine_first"])
+def test_rccl_is_bound_next_to_the_hip_runtime_in_use(order):
+    """A multi-rank bench.py process imports torch (for its gloo control group) before the engine exists, so the library
+    runs on the ROCm copy torch bundles; other hosts load the engine first and torch later, which maps a second copy.
+    Either way RCCL must come from the directory of the libamdhip64 this library is bound to (rccl_load, abi.hip) — a
+    communicator from the other copy fails with "unhandled cuda error".  scripts/rccl_with_torch_first.py creates a
+    one-rank communicator and runs collective updates in a fresh process with the given import order."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.Popen([sys.executable, os.path.join(root, "scripts", "rccl_with_torch_first.py"), order], cwd=root,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=280)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.communicate()
+        raise AssertionError("rccl_with_torch_first.py %s did not finish within 280 s" % order)
+    text = out.decode()
+    assert proc.returncode == 0 and ("%s OK trpo 0" % order) in text, text[-1500:]
+    hip = [l for l in text.splitlines() if "libamdhip64" in l]
+    rccl = [l for l in text.splitlines() if l.startswith("Librccl path")]
+    assert rccl and any(os.path.dirname(rccl[0].split(":", 1)[1].strip()) == os.path.dirname(h.strip()) or
+                        os.path.realpath(os.path.dirname(rccl[0].split(":", 1)[1].strip())) ==
+                        os.path.realpath(os.path.dirname(h.strip())) for h in hip), (rccl, hip)
