@@ -416,6 +416,32 @@ int32_t rl_actor_to_cbor(rl_env *env, rl_mlp *module, int32_t actor_kind, double
  * have the handle's structure and shapes (RL_ERR_INVALID_ARGUMENT otherwise). */
 int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len);
 
+/* The serialisation leaves on their own (host-only, no engine needed) — what every tensor and the action space of an
+ * actor document are made of, and what the reference's serde_test token fixtures pin (src/torch/serialize.rs:187-352,
+ * src/spaces/indexed_type.rs:409-422):
+ *   TensorDef { kind: KindDef, shape: [i64], requires_grad: bool, byte_order: ByteOrder, data: bytes }
+ *                                                    src/torch/serialize.rs:62-81; `impl From<&Tensor>` :83-106
+ *   KindDef (remote definition of tch::Kind), variants in declaration order              src/torch/serialize.rs:12-31
+ *   IndexedTypeSpace<T>: its only field is #[serde(skip)] -> a struct of length 0       src/spaces/indexed_type.rs:57-64
+ * `data` holds the elements in row-major order, native (little-endian) byte order, element size of the kind.
+ * Writers: buf == NULL returns the length only.  Readers refuse documents with another field order, unknown variants,
+ * a non-native byte order (the reference panics there, serialize.rs:110-114) or a data length that does not match
+ * shape x element size. */
+typedef enum {
+  RL_KIND_UINT8 = 0, RL_KIND_INT8 = 1, RL_KIND_INT16 = 2, RL_KIND_INT = 3, RL_KIND_INT64 = 4, RL_KIND_HALF = 5,
+  RL_KIND_FLOAT = 6, RL_KIND_DOUBLE = 7, RL_KIND_COMPLEX_HALF = 8, RL_KIND_COMPLEX_FLOAT = 9,
+  RL_KIND_COMPLEX_DOUBLE = 10, RL_KIND_BOOL = 11, RL_KIND_QINT8 = 12, RL_KIND_QUINT8 = 13, RL_KIND_QINT32 = 14,
+  RL_KIND_BFLOAT16 = 15
+} rl_tensor_kind;
+int32_t rl_tensor_def_to_cbor(int32_t kind, const int64_t *shape, uint32_t rank, int32_t requires_grad,
+                              const void *data, uint64_t data_bytes, uint8_t *buf, uint64_t cap, uint64_t *len_out);
+/* shape_out receives at most shape_cap extents, data_out at most data_cap bytes (either may be NULL to query sizes
+ * through rank_out / data_bytes_out) */
+int32_t rl_tensor_def_from_cbor(const uint8_t *buf, uint64_t len, int32_t *kind_out, int64_t *shape_out,
+                                uint32_t shape_cap, uint32_t *rank_out, int32_t *requires_grad_out, void *data_out,
+                                uint64_t data_cap, uint64_t *data_bytes_out);
+int32_t rl_indexed_type_space_to_cbor(uint8_t *buf, uint64_t cap, uint64_t *len_out);
+
 /* ---------------------------------------------------------------------------------------------
  * CPU-only plumbing configuration (BASELINE.json configs[0]): examples/chain-tabular-q.rs — Chain
  * (src/envs/chain.rs:20-106) + epsilon-greedy tabular Q-learning (src/agents/tabular.rs:88-233) driven by

@@ -47,7 +47,8 @@ ABI_SYMBOLS = [
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient",
     "rl_ppo_config_default", "rl_ppo_update", "rl_reinforce_update", "rl_reward_to_go",
-    "rl_actor_to_cbor", "rl_module_from_cbor",
+    "rl_actor_to_cbor", "rl_module_from_cbor", "rl_tensor_def_to_cbor", "rl_tensor_def_from_cbor",
+    "rl_indexed_type_space_to_cbor",
     "rl_dqn_config_default", "rl_dqn_create", "rl_dqn_destroy", "rl_dqn_exploration_rate",
     "rl_dqn_min_update_size", "rl_dqn_collect", "rl_dqn_update", "rl_dqn_replay_field_bytes", "rl_dqn_replay_read",
     "rl_dqn_minibatch_sample", "rl_dqn_minibatch_read", "rl_dqn_minibatch_gradient", "rl_dqn_agent_rng_pos",
@@ -770,6 +771,45 @@ def actor_to_cbor(env, module, actor_kind=ACTOR_POLICY, exploration_rate=0.0):
 def module_from_cbor(module, data):
     buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
     _check(lib().rl_module_from_cbor(module.h, buf, C.c_uint64(len(data))), module.eng.h)
+
+
+# KindDef variants in declaration order (src/torch/serialize.rs:12-31) and the numpy dtype carrying their bytes
+TENSOR_KINDS = ["Uint8", "Int8", "Int16", "Int", "Int64", "Half", "Float", "Double", "ComplexHalf", "ComplexFloat",
+                "ComplexDouble", "Bool", "QInt8", "QUInt8", "QInt32", "BFloat16"]
+
+
+def tensor_def_to_cbor(kind, shape, requires_grad, data):
+    """TensorDef::from(&tensor) serialised by serde_cbor (host-only): `kind` a KindDef variant name, `data` the raw
+    little-endian element bytes in row-major order"""
+    data = bytes(data)
+    shp = (C.c_int64 * max(len(shape), 1))(*shape)
+    args = (C.c_int32(TENSOR_KINDS.index(kind)), shp, C.c_uint32(len(shape)), C.c_int32(1 if requires_grad else 0),
+            data, C.c_uint64(len(data)))
+    n = C.c_uint64()
+    _check(lib().rl_tensor_def_to_cbor(*args, None, C.c_uint64(0), C.byref(n)))
+    buf = (C.c_uint8 * max(n.value, 1))()
+    _check(lib().rl_tensor_def_to_cbor(*args, buf, C.c_uint64(n.value), C.byref(n)))
+    return bytes(buf[:n.value])
+
+
+def tensor_def_from_cbor(doc):
+    """-> (kind name, shape list, requires_grad, data bytes); raises RelearnError for anything serde would refuse"""
+    doc = bytes(doc)
+    kind, rank, rg, nbytes = C.c_int32(), C.c_uint32(), C.c_int32(), C.c_uint64()
+    _check(lib().rl_tensor_def_from_cbor(doc, C.c_uint64(len(doc)), C.byref(kind), None, C.c_uint32(0), C.byref(rank),
+                                         C.byref(rg), None, C.c_uint64(0), C.byref(nbytes)))
+    shape = (C.c_int64 * max(rank.value, 1))()
+    data = (C.c_uint8 * max(nbytes.value, 1))()
+    _check(lib().rl_tensor_def_from_cbor(doc, C.c_uint64(len(doc)), C.byref(kind), shape, C.c_uint32(rank.value),
+                                         C.byref(rank), C.byref(rg), data, C.c_uint64(nbytes.value), C.byref(nbytes)))
+    return TENSOR_KINDS[kind.value], list(shape[:rank.value]), bool(rg.value), bytes(data[:nbytes.value])
+
+
+def indexed_type_space_to_cbor():
+    n = C.c_uint64()
+    buf = (C.c_uint8 * 16)()
+    _check(lib().rl_indexed_type_space_to_cbor(buf, C.c_uint64(16), C.byref(n)))
+    return bytes(buf[:n.value])
 
 
 def chain_tabular_q_train(seed=0, n_threads=4, n_periods=10, min_worker_steps=10000, exploration_rate=0.2):

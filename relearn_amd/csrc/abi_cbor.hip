@@ -12,23 +12,75 @@ static void cbor_interval(cbor::Writer &w, double lo, double hi) {
   w.f64(hi);
 }
 
-static void cbor_tensor(cbor::Writer &w, const float *data, std::initializer_list<int64_t> shape) {
-  w.map(5);  // TensorDef (torch/serialize.rs:62-81)
+// KindDef variant names in declaration order, element sizes in bytes (torch/serialize.rs:12-31; tch Kind::elt_size_in_bytes)
+static const char *const kKindNames[16] = {"Uint8", "Int8", "Int16", "Int", "Int64", "Half", "Float", "Double",
+                                           "ComplexHalf", "ComplexFloat", "ComplexDouble", "Bool", "QInt8", "QUInt8",
+                                           "QInt32", "BFloat16"};
+static const uint32_t kKindSizes[16] = {1, 1, 2, 4, 8, 2, 4, 8, 4, 8, 16, 1, 1, 1, 4, 2};
+
+// TensorDef (torch/serialize.rs:62-81): the five fields in declaration order, `data` as a byte string
+static void cbor_tensor_def(cbor::Writer &w, int kind, const int64_t *shape, size_t rank, bool requires_grad,
+                            const void *data, size_t data_bytes) {
+  w.map(5);
   w.key("kind");
-  w.text("Float");
+  w.text(kKindNames[kind]);
   w.key("shape");
-  w.array(shape.size());
-  size_t count = 1;
-  for (int64_t d : shape) {
-    w.sint(d);
-    count *= (size_t)d;
-  }
+  w.array(rank);
+  for (size_t i = 0; i < rank; ++i) w.sint(shape[i]);
   w.key("requires_grad");
-  w.boolean(true);
+  w.boolean(requires_grad);
   w.key("byte_order");
-  w.text("LittleEndian");
+  w.text("LittleEndian");  // ByteOrder::native() of every machine this library runs on
   w.key("data");
-  w.bytes(data, count * sizeof(float));
+  w.bytes(data, data_bytes);
+}
+
+static void cbor_tensor(cbor::Writer &w, const float *data, std::initializer_list<int64_t> shape) {
+  size_t count = 1;
+  for (int64_t d : shape) count *= (size_t)d;
+  cbor_tensor_def(w, RL_KIND_FLOAT, shape.begin(), shape.size(), true, data, count * sizeof(float));
+}
+
+struct TensorDefView {
+  int kind = -1;
+  std::vector<int64_t> shape;
+  bool requires_grad = false;
+  const std::string *data = nullptr;
+};
+
+// the reader is strict about what serde's derived Deserialize accepts from serde_cbor's writer: five fields, known
+// variant names, native byte order (`From<&TensorDef> for Tensor` asserts it, serialize.rs:110-114), consistent sizes
+static TensorDefView cbor_parse_tensor_def(const cbor::Value &t) {
+  static const char *const order[5] = {"kind", "shape", "requires_grad", "byte_order", "data"};
+  RL_REQUIRE(t.kind == cbor::Value::MAP && t.fields.size() == 5, "CBOR tensor: expected the five TensorDef fields");
+  for (int i = 0; i < 5; ++i) RL_REQUIRE(t.fields[i].first == order[i], "CBOR tensor: unexpected field order");
+  TensorDefView v;
+  const cbor::Value &k = t.at("kind");
+  RL_REQUIRE(k.kind == cbor::Value::TEXT, "CBOR tensor: kind must be a unit variant name");
+  for (int i = 0; i < 16; ++i)
+    if (k.s == kKindNames[i]) v.kind = i;
+  RL_REQUIRE(v.kind >= 0, "CBOR tensor: unknown kind");
+  const cbor::Value &bo = t.at("byte_order");
+  RL_REQUIRE(bo.kind == cbor::Value::TEXT && (bo.s == "LittleEndian" || bo.s == "BigEndian"),
+             "CBOR tensor: unknown byte order");
+  RL_REQUIRE(bo.s == "LittleEndian", "CBOR tensor: data has non-native byte order");
+  const cbor::Value &sh = t.at("shape");
+  RL_REQUIRE(sh.kind == cbor::Value::ARRAY, "CBOR tensor: shape must be a sequence");
+  uint64_t count = 1;
+  for (auto &it : sh.items) {
+    const int64_t d = it->as_int();
+    RL_REQUIRE(d >= 0, "CBOR tensor: negative extent");
+    v.shape.push_back(d);
+    count *= (uint64_t)d;
+  }
+  const cbor::Value &rg = t.at("requires_grad");
+  RL_REQUIRE(rg.kind == cbor::Value::BOOL, "CBOR tensor: requires_grad must be a bool");
+  v.requires_grad = rg.b;
+  const cbor::Value &data = t.at("data");
+  RL_REQUIRE(data.kind == cbor::Value::BYTES && data.s.size() == count * kKindSizes[v.kind],
+             "CBOR tensor: bad data length");
+  v.data = &data.s;
+  return v;
 }
 
 // Mlp { layers, activation, output_activation } over `p` = [W1, b1, W2, b2] (ff/mlp.rs:45-50, ff/linear.rs:43-50)
@@ -89,6 +141,9 @@ static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<floa
   w.text("Relu");
 }
 
+// IndexedTypeSpace<T>: its only field is #[serde(skip)] (spaces/indexed_type.rs:57-64) -> a struct of length 0
+static void cbor_indexed_type_space(cbor::Writer &w) { w.map(0); }
+
 static void cbor_observation_space(cbor::Writer &w, const rl_env *env) {
   w.map(1);  // NonEmptyFeatures { inner } (spaces/nonempty_features.rs:20-25)
   w.key("inner");
@@ -136,7 +191,7 @@ int32_t rl_actor_to_cbor(rl_env *env, rl_mlp *module, int32_t actor_kind, double
     w.key("observation_space");
     cbor_observation_space(w, env);
     w.key("action_space");
-    w.map(0);  // IndexedTypeSpace<T>: its only field is #[serde(skip)] (spaces/indexed_type.rs:57-64)
+    cbor_indexed_type_space(w);
     w.key(actor_kind == RL_ACTOR_DQN ? "action_value_fn" : "policy_module");
     cbor_module(w, module, p);
     if (actor_kind == RL_ACTOR_DQN) {
@@ -152,18 +207,12 @@ int32_t rl_actor_to_cbor(rl_env *env, rl_mlp *module, int32_t actor_kind, double
 }
 
 static void cbor_read_tensor(const cbor::Value &t, std::initializer_list<int64_t> shape, float *dst) {
-  RL_REQUIRE(t.at("kind").s == "Float", "CBOR tensor: kind must be Float");
-  RL_REQUIRE(t.at("byte_order").s == "LittleEndian", "CBOR tensor: data has non-native byte order");
-  const cbor::Value &sh = t.at("shape");
-  RL_REQUIRE(sh.kind == cbor::Value::ARRAY && sh.items.size() == shape.size(), "CBOR tensor: unexpected rank");
-  size_t count = 1, i = 0;
-  for (int64_t d : shape) {
-    RL_REQUIRE(sh.items[i++]->as_int() == d, "CBOR tensor: unexpected shape");
-    count *= (size_t)d;
-  }
-  const cbor::Value &data = t.at("data");
-  RL_REQUIRE(data.kind == cbor::Value::BYTES && data.s.size() == count * sizeof(float), "CBOR tensor: bad data length");
-  std::memcpy(dst, data.s.data(), data.s.size());
+  const TensorDefView v = cbor_parse_tensor_def(t);
+  RL_REQUIRE(v.kind == RL_KIND_FLOAT, "CBOR tensor: kind must be Float");
+  RL_REQUIRE(v.shape.size() == shape.size(), "CBOR tensor: unexpected rank");
+  size_t i = 0;
+  for (int64_t d : shape) RL_REQUIRE(v.shape[i++] == d, "CBOR tensor: unexpected shape");
+  std::memcpy(dst, v.data->data(), v.data->size());
 }
 
 static float *cbor_read_mlp(const cbor::Value &m, int64_t in, int64_t hid, int64_t out, float *dst) {
@@ -215,6 +264,64 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
     }
     RL_REQUIRE((uint64_t)(end - p.data()) == module->P, "CBOR module: parameter count mismatch");
     h2d(module->eng, module->d_params, p.data(), module->P * sizeof(float));
+  });
+}
+
+int32_t rl_tensor_def_to_cbor(int32_t kind, const int64_t *shape, uint32_t rank, int32_t requires_grad,
+                              const void *data, uint64_t data_bytes, uint8_t *buf, uint64_t cap, uint64_t *len_out) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(len_out, "len_out is NULL");
+    RL_REQUIRE(kind >= 0 && kind < 16, "unknown tensor kind");
+    RL_REQUIRE(rank == 0 || shape, "shape is NULL");
+    uint64_t count = 1;
+    for (uint32_t i = 0; i < rank; ++i) {
+      RL_REQUIRE(shape[i] >= 0, "negative extent");
+      count *= (uint64_t)shape[i];
+    }
+    RL_REQUIRE(data_bytes == count * kKindSizes[kind], "data length does not match shape x element size");
+    RL_REQUIRE(data_bytes == 0 || data, "data is NULL");
+    cbor::Writer w;
+    cbor_tensor_def(w, kind, shape, rank, requires_grad != 0, data, (size_t)data_bytes);
+    *len_out = w.out.size();
+    if (buf != nullptr) {
+      RL_REQUIRE(cap >= w.out.size(), "buffer too small for the CBOR document");
+      std::memcpy(buf, w.out.data(), w.out.size());
+    }
+  });
+}
+
+int32_t rl_tensor_def_from_cbor(const uint8_t *buf, uint64_t len, int32_t *kind_out, int64_t *shape_out,
+                                uint32_t shape_cap, uint32_t *rank_out, int32_t *requires_grad_out, void *data_out,
+                                uint64_t data_cap, uint64_t *data_bytes_out) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(buf, "buf is NULL");
+    cbor::ValuePtr doc = cbor::Reader(buf, (size_t)len).parse();
+    const TensorDefView v = cbor_parse_tensor_def(*doc);
+    if (kind_out) *kind_out = v.kind;
+    if (rank_out) *rank_out = (uint32_t)v.shape.size();
+    if (requires_grad_out) *requires_grad_out = v.requires_grad ? 1 : 0;
+    if (data_bytes_out) *data_bytes_out = v.data->size();
+    if (shape_out) {
+      RL_REQUIRE(shape_cap >= v.shape.size(), "shape buffer too small");
+      for (size_t i = 0; i < v.shape.size(); ++i) shape_out[i] = v.shape[i];
+    }
+    if (data_out) {
+      RL_REQUIRE(data_cap >= v.data->size(), "data buffer too small");
+      std::memcpy(data_out, v.data->data(), v.data->size());
+    }
+  });
+}
+
+int32_t rl_indexed_type_space_to_cbor(uint8_t *buf, uint64_t cap, uint64_t *len_out) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(len_out, "len_out is NULL");
+    cbor::Writer w;
+    cbor_indexed_type_space(w);
+    *len_out = w.out.size();
+    if (buf != nullptr) {
+      RL_REQUIRE(cap >= w.out.size(), "buffer too small for the CBOR document");
+      std::memcpy(buf, w.out.data(), w.out.size());
+    }
   });
 }
 

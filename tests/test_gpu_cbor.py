@@ -108,3 +108,31 @@ def test_recurrent_policy_actor_document(engine, cell):
     wrong = (ra.LstmMlp if cell == "gru" else ra.GruMlp)(engine, 5, 2)
     with pytest.raises(ra.RelearnError):
         ra.module_from_cbor(wrong, data)  # the other cell's gate blocks do not fit
+
+
+def test_actor_document_leaves_match_the_reference_token_fixtures(engine):
+    """every TensorDef of an actor document and its action space tokenise the way the reference's serde_test
+    fixtures do (tests/golden/serde_token_fixtures.json; src/torch/serialize.rs:269-302, indexed_type.rs:409-422)"""
+    import json
+    import os
+
+    from serde_tokens import INDEXED_TYPE_SPACE, TENSOR_DEF, tokens
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "serde_token_fixtures.json")))
+    want = [f for f in fix["tensor_def"] if "1d_f32_tensor_requires_grad" in f["source"]][0]["tokens"]
+    env = ra.CartPoleEnv(engine, 64)
+    pol = ra.Mlp(engine, 5, 128, 2)
+    pol.init(5)
+    doc = decode(ra.actor_to_cbor(env, pol))
+    assert tokens(doc["action_space"], INDEXED_TYPE_SPACE) == fix["indexed_type_space"]["tokens"]
+    n = 0
+    for layer in doc["policy_module"]["layers"]:
+        for name in ("kernel", "bias"):
+            got = tokens(layer[name], TENSOR_DEF)
+            # same token kinds in the same order; kind / requires_grad / byte_order tokens identical to the fixture's
+            strip = lambda ts: [t for t in ts if t[0] not in ("I64", "BorrowedBytes", "Seq")]
+            assert strip(got) == strip(want)
+            # and the leaf writer of the ABI produces the same bytes for the same tensor
+            t = layer[name]
+            assert encode(t) == ra.tensor_def_to_cbor(t["kind"], t["shape"], t["requires_grad"], t["data"])
+            n += 1
+    assert n == 4
