@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 1
+#define RL_ABI_VERSION 2
 
 /* ---------------------------------------------------------------------------------------------
  * Status codes.  The non-generic ones mirror the reference's error enums:
@@ -224,7 +224,8 @@ typedef enum {
   RL_TRAJ_TERM_OBS = 4,  /* f32 [obs_dim][T][n], valid where flag == INTERRUPT */
   RL_TRAJ_VALUES = 5,    /* f32 [T+1][n] critic values of OBS (after rl_gae) */
   RL_TRAJ_ADVANTAGES = 6,/* f32 [T][n] */
-  RL_TRAJ_RETURNS = 7    /* f32 [T][n] discounted reward-to-go */
+  RL_TRAJ_RETURNS = 7,   /* f32 [T][n] discounted reward-to-go */
+  RL_TRAJ_TARGETS = 8    /* f32 [T][n] value targets of the last rl_values_opt_update (StepValueTarget::targets) */
 } rl_traj_field;
 
 int32_t rl_traj_create(rl_engine *engine, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, rl_traj **out);
@@ -298,6 +299,27 @@ typedef struct {
 int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
                          float *losses_out);
 int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float *loss_out);
+
+/* ValuesOpt::update with its configuration (src/torch/agents/critics/opt.rs:13-37,100-126): the targets are computed
+ * once, under no-grad, from the critic as it stands when the call begins — StepValueTarget::targets
+ * (critics/mod.rs:203-229):
+ *   RewardToGo  discounted_cumsum_from_end of the rewards                         (reward_to_go, critics/mod.rs:101-105)
+ *   OneStepTd   r_t + discount_factor * V(successor of step t)                    (one_step_values, critics/mod.rs:139-150)
+ *               with the masked extended values of eval_extended_state_values (:116-131): 0 after Terminate,
+ *               V(successor observation) after Interrupt (and at the horizon cut); `scalar * tensor` then
+ *               `tensor + tensor`, two f32 roundings
+ * — then opt_steps_per_update x {mse_loss(V(obs), targets, Mean); backward; Adam}.  The targets stay readable as
+ * RL_TRAJ_TARGETS; OneStepTd also refreshes RL_TRAJ_VALUES.  rl_critic_update above is the RewardToGo case on the
+ * returns rl_gae left in RL_TRAJ_RETURNS. */
+enum { RL_VALUE_TARGET_REWARD_TO_GO = 0, RL_VALUE_TARGET_ONE_STEP_TD = 1 }; /* StepValueTarget, critics/mod.rs:203-214 */
+typedef struct {
+  uint64_t opt_steps_per_update; /* 80 (opt.rs:46) */
+  int32_t target;                /* RL_VALUE_TARGET_* ; default RewardToGo (critics/mod.rs:211-215) */
+  float discount_factor;         /* max_discount_factor.min(env discount) as f32 (opt.rs:73); default 0.99 */
+} rl_values_opt_config;
+int32_t rl_values_opt_config_default(rl_values_opt_config *cfg);
+int32_t rl_values_opt_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, const rl_values_opt_config *cfg,
+                             rl_critic_stats *stats, float *losses_out /* may be NULL */);
 
 /* ---------------------------------------------------------------------------------------------
  * First-order policy updates and the critic-free advantage (the rest of the ActorCriticConfig matrix,

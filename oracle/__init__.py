@@ -270,6 +270,12 @@ def _declare(L):
     L.oracle_gae_packed.argtypes = [MlpShape, P(C.c_float), P(Features), C.c_float, C.c_float, P(C.c_float),
                                     P(C.c_float)]
     L.oracle_reward_to_go_packed.argtypes = [P(Features), C.c_float, P(C.c_float)]
+    L.oracle_one_step_values_packed.argtypes = [MlpShape, P(C.c_float), P(Features), C.c_float, P(C.c_float)]
+    L.oracle_lanes_one_step_targets.argtypes = [MlpShape, P(C.c_float), C.c_uint64, C.c_uint64, C.c_uint32,
+                                                P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float), C.c_float,
+                                                P(C.c_float)]
+    L.oracle_seq_one_step_targets.argtypes = [C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float), P(C.c_float),
+                                              P(C.c_uint8), C.c_float, P(C.c_float)]
 
     L.oracle_trpo_cfg_default.argtypes = [P(TrpoCfg)]
     L.oracle_policy_grad_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_int64), P(C.c_float),
@@ -556,6 +562,17 @@ def lanes_gae(cshape, cparams, traj, gamma, lam):
     return values, adv, rtg
 
 
+def lanes_one_step_targets(cshape, cparams, traj, gamma):
+    """StepValueTarget::OneStepTd on a lane trajectory: r + gamma * V(successor), [T][n]"""
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    out = np.zeros((T, n), dtype=np.float32)
+    lib().oracle_lanes_one_step_targets(cshape, f32p(cparams), n, T, D, f32p(obs), f32p(traj["reward"]),
+                                        u8p(traj["flag"]), f32p(traj["term_obs"]), gamma, f32p(out))
+    return out
+
+
 def flat_samples(traj):
     """[D][T+1][n] trajectory -> (obs [B][D], actions [B] i64) in the engine's flat sample order b = t*n + lane."""
     obs = traj["obs"]
@@ -753,6 +770,15 @@ def seq_gae(values, succ_values, traj, gamma, lam):
                          f32p(np.ascontiguousarray(succ_values, dtype=np.float32)), f32p(traj["reward"]),
                          u8p(traj["flag"]), gamma, lam, f32p(adv), f32p(rtg))
     return adv, rtg
+
+
+def seq_one_step_targets(values, succ_values, traj, gamma):
+    T, n = traj["reward"].shape
+    out = np.zeros((T, n), dtype=np.float32)
+    lib().oracle_seq_one_step_targets(n, T, f32p(np.ascontiguousarray(values, dtype=np.float32)),
+                                      f32p(np.ascontiguousarray(succ_values, dtype=np.float32)), f32p(traj["reward"]),
+                                      u8p(traj["flag"]), gamma, f32p(out))
+    return out
 
 
 def seq_policy_dlogits(logits, actions, adv, logp0=None, clip=None):

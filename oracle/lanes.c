@@ -270,6 +270,29 @@ void oracle_lanes_gae(oracle_mlp_shape cs, const float *critic_params, uint64_t 
   }
 }
 
+/* one_step_values (critics/mod.rs:139-150) on the lane layout, the engine's horizon rule (cut = Interrupt(obs[T])):
+ * target[t] = r[t] + gamma * V(successor of step t); Terminate -> 0, Interrupt -> V(term_obs) */
+void oracle_lanes_one_step_targets(oracle_mlp_shape cs, const float *critic_params, uint64_t n, uint64_t T, uint32_t D,
+                                   const float *obs, const float *reward, const uint8_t *flag, const float *term_obs,
+                                   float gamma, float *out) {
+  for (uint64_t i = 0; i < n; ++i)
+    for (uint64_t t = 0; t < T; ++t) {
+      float x[8], vnext;
+      uint8_t f = flag[t * n + i];
+      if (f == ORACLE_TERMINATE) {
+        vnext = 0.0f;
+      } else if (f == ORACLE_INTERRUPT) {
+        for (uint32_t d = 0; d < D; ++d) x[d] = term_obs[(d * T + t) * n + i];
+        oracle_mlp_forward_f32(cs, critic_params, x, &vnext);
+      } else {
+        for (uint32_t d = 0; d < D; ++d) x[d] = obs[(d * (T + 1) + t + 1) * n + i];
+        oracle_mlp_forward_f32(cs, critic_params, x, &vnext);
+      }
+      float dn = gamma * vnext;
+      out[t * n + i] = reward[t * n + i] + dn;
+    }
+}
+
 oracle_vecbuffer *oracle_lanes_to_vecbuffer(uint64_t n, uint64_t T, uint32_t D, const float *obs,
                                             const uint8_t *action, const float *reward, const uint8_t *flag,
                                             const float *term_obs, int keep_last, uint64_t *lane_t_index_out) {

@@ -152,6 +152,24 @@ void oracle_gae_packed(oracle_mlp_shape cs, const float *critic_params, const or
   free(ext);
 }
 
+/* one_step_values (critics/mod.rs:139-150), the OneStepTd arm of StepValueTarget::targets (:219-229):
+ * `rewards + discount_factor * estimated_next_values` with estimated_next_values = view_trim_start(1) of the masked
+ * extended values — Terminate (and a dropped dangling step) bootstraps from 0, Interrupt from V(successor).
+ * Scalar times tensor, then tensor plus tensor: two f32 roundings. */
+void oracle_one_step_values_packed(oracle_mlp_shape cs, const float *critic_params, const oracle_features *f,
+                                   float gamma, float *out) {
+  float *ext = (float *)malloc(sizeof(float) * (f->n_ext ? f->n_ext : 1));
+  oracle_mlp_forward_batch_f32(cs, critic_params, f->ext_obs, f->n_ext, ext);
+  for (uint64_t i = 0; i < f->n_ext; ++i)
+    if (f->is_invalid[i]) ext[i] = 0.0f; /* masked_fill_ */
+  const float *vnext = ext + f->n_episodes; /* view_trim_start(1) */
+  for (uint64_t i = 0; i < f->n_steps; ++i) {
+    float dn = gamma * vnext[i];
+    out[i] = f->rewards[i] + dn;
+  }
+  free(ext);
+}
+
 /* reward_to_go (critics/mod.rs:101-105) */
 void oracle_reward_to_go_packed(const oracle_features *f, float gamma, float *out) {
   memcpy(out, f->rewards, sizeof(float) * f->n_steps);

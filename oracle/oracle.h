@@ -198,6 +198,9 @@ float oracle_categorical_kl_f32(const float *lp_self, const float *lp_other, uin
 void oracle_gae_packed(oracle_mlp_shape cs, const float *critic_params, const oracle_features *f, float gamma,
                        float lambda, float *adv_out, float *ext_values_out);
 void oracle_reward_to_go_packed(const oracle_features *f, float gamma, float *out);
+/* StepValueTarget::OneStepTd (critics/mod.rs:139-150, 219-229) */
+void oracle_one_step_values_packed(oracle_mlp_shape cs, const float *critic_params, const oracle_features *f,
+                                   float gamma, float *out);
 
 /* ---------------------------------------------------------------- update math on flat sample arrays */
 typedef struct {
@@ -332,6 +335,9 @@ void oracle_lanes_rollout(oracle_lanes *l, oracle_mlp_shape ps, const float *pol
 void oracle_lanes_gae(oracle_mlp_shape cs, const float *critic_params, uint64_t n, uint64_t T, uint32_t D,
                       const float *obs, const float *reward, const uint8_t *flag, const float *term_obs, float gamma,
                       float lambda, float *values_out, float *adv_out, float *rtg_out);
+void oracle_lanes_one_step_targets(oracle_mlp_shape cs, const float *critic_params, uint64_t n, uint64_t T, uint32_t D,
+                                   const float *obs, const float *reward, const uint8_t *flag, const float *term_obs,
+                                   float gamma, float *out);
 /* convert a lane trajectory into reference-style episodes in a VecBuffer (one buffer, lanes in order);
  * horizon cut handled with keep_last (engine rule) or the reference's drop rule (buffers/mod.rs:237-261) */
 oracle_vecbuffer *oracle_lanes_to_vecbuffer(uint64_t n, uint64_t T, uint32_t D, const float *obs,
@@ -426,6 +432,10 @@ void oracle_lanes_rollout_gru(oracle_lanes *l, oracle_gru_shape ps, const float 
                               uint8_t *action, float *reward, uint8_t *flag, float *term_obs, int n_threads);
 void oracle_seq_gae(uint64_t n, uint64_t T, const float *values, const float *succ_values, const float *reward,
                     const uint8_t *flag, float gamma, float lambda, float *adv_out, float *rtg_out);
+/* one-step TD targets from the teacher-forced outputs of a recurrent critic (values / successor values as in
+ * oracle_seq_gae): r + gamma * V_next, Terminate -> 0, Interrupt / horizon cut -> succ */
+void oracle_seq_one_step_targets(uint64_t n, uint64_t T, const float *values, const float *succ_values,
+                                 const float *reward, const uint8_t *flag, float gamma, float *out);
 void oracle_seq_policy_dlogits_f32(uint64_t B, const float *logits, const uint8_t *actions, const float *adv,
                                    const float *logp0, int mode, float clip_lo, float clip_hi, float *dlogits,
                                    float *logp_out, double *loss_sum_out, double *entropy_sum_out);

@@ -374,6 +374,22 @@ void oracle_seq_gae(uint64_t n, uint64_t T, const float *values, const float *su
   }
 }
 
+/* one_step_values (critics/mod.rs:139-150) with a recurrent critic: the next value comes from the teacher-forced
+ * forward (next step's output inside an episode, the successor output where it is cut) */
+void oracle_seq_one_step_targets(uint64_t n, uint64_t T, const float *values, const float *succ_values,
+                                 const float *reward, const uint8_t *flag, float gamma, float *out) {
+  for (uint64_t i = 0; i < n; ++i)
+    for (uint64_t t = 0; t < T; ++t) {
+      uint8_t f = flag[t * n + i];
+      float vnext;
+      if (f == ORACLE_TERMINATE) vnext = 0.0f;
+      else if (f == ORACLE_INTERRUPT || t == T - 1) vnext = succ_values[t * n + i];
+      else vnext = values[(t + 1) * n + i];
+      float dn = gamma * vnext;
+      out[t * n + i] = reward[t * n + i] + dn;
+    }
+}
+
 /* ------------------------------------------------------------------ per-sample output gradients
  * logits [2][T][n] -> d loss / d logits for the policy losses, and log-probs / entropy / loss sums.
  * mode 0: surrogate at ratio 1 (REINFORCE / first TRPO / PPO gradient), loss = -mean(A)

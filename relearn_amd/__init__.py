@@ -27,7 +27,8 @@ OPT_OK, OPT_LOSS_NOT_IMPROVING, OPT_CONSTRAINT_VIOLATED, OPT_NAN_LOSS, OPT_NAN_C
 ENV_CARTPOLE, ENV_CHAIN, ENV_MEMORY = 0, 1, 2
 LIMIT_NONE, LIMIT_LATENT, LIMIT_VISIBLE = 0, 1, 2
 (TRAJ_OBS, TRAJ_ACTION, TRAJ_REWARD, TRAJ_FLAG, TRAJ_TERM_OBS, TRAJ_VALUES, TRAJ_ADVANTAGES,
- TRAJ_RETURNS) = range(8)
+ TRAJ_RETURNS, TRAJ_TARGETS) = range(9)
+VALUE_TARGET_REWARD_TO_GO, VALUE_TARGET_ONE_STEP_TD = 0, 1
 KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backward", "reduce", "small",
                   "critic_fwd", "allreduce", "critic_fused", "policy_fused", "policy_fvp"]
 
@@ -45,7 +46,7 @@ ABI_SYMBOLS = [
     "rl_rollout", "rl_gae",
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
-    "rl_critic_update", "rl_critic_gradient",
+    "rl_critic_update", "rl_critic_gradient", "rl_values_opt_config_default", "rl_values_opt_update",
     "rl_ppo_config_default", "rl_ppo_update", "rl_reinforce_update", "rl_reward_to_go",
     "rl_actor_to_cbor", "rl_module_from_cbor", "rl_tensor_def_to_cbor", "rl_tensor_def_from_cbor",
     "rl_indexed_type_space_to_cbor",
@@ -473,7 +474,7 @@ GruMlp.set_params = Mlp.set_params
 
 _TRAJ_DTYPES = {TRAJ_OBS: np.float32, TRAJ_ACTION: np.uint8, TRAJ_REWARD: np.float32, TRAJ_FLAG: np.uint8,
                 TRAJ_TERM_OBS: np.float32, TRAJ_VALUES: np.float32, TRAJ_ADVANTAGES: np.float32,
-                TRAJ_RETURNS: np.float32}
+                TRAJ_RETURNS: np.float32, TRAJ_TARGETS: np.float32}
 
 
 class Trajectory(_Handle):
@@ -494,7 +495,7 @@ class Trajectory(_Handle):
         n, T, D = self.n, self.T, self.D
         return {TRAJ_OBS: (D, T + 1, n), TRAJ_ACTION: (T, n), TRAJ_REWARD: (T, n), TRAJ_FLAG: (T, n),
                 TRAJ_TERM_OBS: (D, T, n), TRAJ_VALUES: (T + 1, n), TRAJ_ADVANTAGES: (T, n),
-                TRAJ_RETURNS: (T, n)}[field]
+                TRAJ_RETURNS: (T, n), TRAJ_TARGETS: (T, n)}[field]
 
     def read(self, field):
         out = np.zeros(self.shape(field), dtype=_TRAJ_DTYPES[field])
@@ -592,6 +593,27 @@ def critic_update(critic, opt, traj, opt_steps=80, want_losses=False):
     _check(lib().rl_critic_update(critic.h, opt.h, traj.h, C.c_uint64(opt_steps), C.byref(st),
                                   losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
     return (st, losses[:opt_steps]) if want_losses else st
+
+
+class ValuesOptConfig(C.Structure):
+    _fields_ = [("opt_steps_per_update", C.c_uint64), ("target", C.c_int32), ("discount_factor", C.c_float)]
+
+
+def values_opt_config_default():
+    c = ValuesOptConfig()
+    _check(lib().rl_values_opt_config_default(C.byref(c)))
+    return c
+
+
+def values_opt_update(critic, opt, traj, cfg=None, want_losses=False):
+    """ValuesOpt::update (critics/opt.rs:100-126) with its target selection (StepValueTarget)"""
+    cfg = cfg if cfg is not None else values_opt_config_default()
+    st = CriticStats()
+    K = cfg.opt_steps_per_update
+    losses = np.zeros(max(K, 1), dtype=np.float32)
+    _check(lib().rl_values_opt_update(critic.h, opt.h, traj.h, C.byref(cfg), C.byref(st),
+                                      losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
+    return (st, losses[:K]) if want_losses else st
 
 
 def critic_gradient(critic, traj):

@@ -861,6 +861,11 @@ static void traj_field(const rl_traj *t, int32_t field, void **ptr, uint64_t *by
     case RL_TRAJ_VALUES: *ptr = t->d.values; *bytes = (T + 1) * n * 4; break;
     case RL_TRAJ_ADVANTAGES: *ptr = t->d.adv; *bytes = T * n * 4; break;
     case RL_TRAJ_RETURNS: *ptr = t->d.rtg; *bytes = T * n * 4; break;
+    case RL_TRAJ_TARGETS:
+      RL_REQUIRE(t->td != nullptr, "no value targets yet: they are written by rl_values_opt_update");
+      *ptr = t->td;
+      *bytes = T * n * 4;
+      break;
     default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown trajectory field");
   }
 }
@@ -919,6 +924,7 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   t->d.values = dalloc<float>((T + 1) * n);
   t->d.adv = dalloc<float>(T * n);
   t->d.rtg = dalloc<float>(T * n);
+  t->d.tgt = t->d.rtg;  // the critic regresses on the returns unless rl_values_opt_update selects other targets
   t->lp0 = dalloc<float>(2 * n * T);
   t->dz = dalloc<float>(2 * n * T);
   t->Pmax = 128 * 5 + 128 + 2 * 128 + 2;
@@ -970,7 +976,7 @@ int32_t rl_traj_destroy(rl_traj *t) {
   (void)hipStreamSynchronize(t->eng->stream);
   void *ptrs[] = {t->d.obs, t->d.action, t->d.reward, t->d.flag, t->d.term_obs, t->d.values, t->d.adv, t->d.rtg,
                   t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
-                  t->losses, t->trpo};
+                  t->losses, t->trpo, t->td};
   for (void *p : ptrs) dfree(p);
   seq_free(t);
   rl_engine *eng = t->eng;

@@ -302,34 +302,79 @@ static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
   rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
 }
 
+// n_backward_steps (src/torch/agents/mod.rs:35-72) of full-batch MSE against traj->d.tgt with Adam
+static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
+                             float *losses_out) {
+  RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
+  uint64_t Bt = b_total(traj);
+  const bool fused = critic->kind == RL_MODULE_MLP && !traj->eng->has_collective();
+  for (uint64_t k = 0; k < opt_steps; ++k) {
+    if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
+      uint32_t rowsA, rowsB;
+      critic_slabs(critic, traj, &rowsA, &rowsB);
+      launch_reduce_adam(traj, opt, rowsA, rowsB, (int)k, Bt);
+    } else {
+      run_critic_gradient(critic, traj);
+      launch_adam_step(traj, opt, (int)k, Bt);
+    }
+  }
+  if (stats || losses_out) {
+    std::vector<float> h(opt_steps ? opt_steps : 1);
+    if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
+    if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
+    if (stats) {
+      stats->steps = opt_steps;
+      stats->loss_first = opt_steps ? (double)h[0] : 0.0;
+      stats->loss_last = opt_steps ? (double)h[opt_steps - 1] : 0.0;
+    }
+  }
+}
+
 int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
                          float *losses_out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_critic(critic, traj);
     RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
-    RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
-    uint64_t Bt = b_total(traj);
-    const bool fused = critic->kind == RL_MODULE_MLP && !traj->eng->has_collective();
-    for (uint64_t k = 0; k < opt_steps; ++k) {
-      if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
-        uint32_t rowsA, rowsB;
-        critic_slabs(critic, traj, &rowsA, &rowsB);
-        launch_reduce_adam(traj, opt, rowsA, rowsB, (int)k, Bt);
-      } else {
-        run_critic_gradient(critic, traj);
-        launch_adam_step(traj, opt, (int)k, Bt);
-      }
+    traj->d.tgt = traj->d.rtg;
+    critic_opt_steps(critic, opt, traj, opt_steps, stats, losses_out);
+  });
+}
+
+int32_t rl_values_opt_config_default(rl_values_opt_config *c) {
+  return guarded(nullptr, [&] {
+    RL_REQUIRE(c, "cfg is NULL");
+    c->opt_steps_per_update = 80;                // ValuesOptConfig::default (critics/opt.rs:40-51)
+    c->target = RL_VALUE_TARGET_REWARD_TO_GO;    // StepValueTarget::default (critics/mod.rs:211-215)
+    c->discount_factor = 0.99f;                  // max_discount_factor
+  });
+}
+
+int32_t rl_values_opt_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, const rl_values_opt_config *cfg,
+                             rl_critic_stats *stats, float *losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_critic(critic, traj);
+    RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
+    RL_REQUIRE(cfg, "cfg is NULL");
+    RL_REQUIRE(cfg->target == RL_VALUE_TARGET_REWARD_TO_GO || cfg->target == RL_VALUE_TARGET_ONE_STEP_TD,
+               "unknown value target");
+    RL_REQUIRE(cfg->discount_factor >= 0.0f && cfg->discount_factor <= 1.0f, "discount factor must be in [0, 1]");
+    if (traj->td == nullptr) {
+      RL_HIP_CHECK(hipSetDevice(traj->eng->device));
+      traj->td = dalloc<float>((size_t)traj->d.T * traj->d.n);
     }
-    if (stats || losses_out) {
-      std::vector<float> h(opt_steps ? opt_steps : 1);
-      if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
-      if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
-      if (stats) {
-        stats->steps = opt_steps;
-        stats->loss_first = opt_steps ? (double)h[0] : 0.0;
-        stats->loss_last = opt_steps ? (double)h[opt_steps - 1] : 0.0;
-      }
+    // targets: once, from the critic as it stands now (tch::no_grad, opt.rs:101-104)
+    traj->d.tgt = traj->td;
+    if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO) {
+      launch_value_targets(traj, nullptr, cfg->discount_factor);
+    } else if (rl_module_is_recurrent(critic->kind)) {
+      seq_ensure(traj, critic, false);
+      launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
+      launch_seq_value_targets(traj, cfg->discount_factor);
+    } else {
+      launch_values(traj, critic);
+      launch_value_targets(traj, critic, cfg->discount_factor);
     }
+    critic_opt_steps(critic, opt, traj, cfg->opt_steps_per_update, stats, losses_out);
   });
 }
 

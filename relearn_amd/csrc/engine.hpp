@@ -60,6 +60,7 @@ struct TrajDev {
   float *values;    // [T+1][n]
   float *adv;       // [T][n]
   float *rtg;       // [T][n]
+  float *tgt;       // [T][n] regression targets of the critic update: rtg, or the one-step TD targets (StepValueTarget)
   uint32_t n, T, D;
 };
 
@@ -193,6 +194,7 @@ struct rl_traj {
   double *slabB = nullptr;  // [nbB][4]
   float *vec = nullptr;     // reduced vector [Pmax + 4]
   float *cg_x = nullptr, *cg_r = nullptr, *cg_p = nullptr, *prev_params = nullptr, *descent = nullptr;
+  float *td = nullptr;      // [T][n] value targets of the last rl_values_opt_update (allocated on first use)
   float *losses = nullptr;  // [max critic steps]
   TrpoStateDev *trpo = nullptr;
   uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbC = 0, nbPair = 0, pair_tiles_per_block = 0, Pmax = 0, max_losses = 0;

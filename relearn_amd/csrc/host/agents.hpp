@@ -318,11 +318,13 @@ struct ReinforceConfig {  // policies/reinforce.rs
   MB policy_fn_config;
   AdamConfig optimizer_config;
 };
+enum class StepValueTarget { RewardToGo, OneStepTd };  // critics/mod.rs:203-215 (default RewardToGo)
 template <typename MB = MlpConfig>
 struct ValuesOptConfig {  // critics/opt.rs:13-37
   MB state_value_fn_config;
   AdamConfig optimizer_config;
   double gae_lambda = 0.95;          // AdvantageFn::Gae { lambda }
+  StepValueTarget target = StepValueTarget::RewardToGo;
   uint64_t opt_steps_per_update = 80;
   double max_discount_factor = 0.99;
 };
@@ -359,7 +361,12 @@ class ActorCriticAgent {
     log_elapsed(cl, "update_time", [&] {
       if (!critic_) return;  // RewardToGo::update does nothing
       rl_critic_stats cs{};
-      check(rl_critic_update(critic_->handle(), critic_opt_, history.handle(), critic_steps_, &cs, nullptr), eng_.handle());
+      // ValuesOpt::update (critics/opt.rs:100-126): targets once under no-grad, then n_backward_steps
+      rl_values_opt_config vc{};
+      vc.opt_steps_per_update = critic_steps_;
+      vc.target = critic_target_ == StepValueTarget::OneStepTd ? RL_VALUE_TARGET_ONE_STEP_TD : RL_VALUE_TARGET_REWARD_TO_GO;
+      vc.discount_factor = gamma_;
+      check(rl_values_opt_update(critic_->handle(), critic_opt_, history.handle(), &vc, &cs, nullptr), eng_.handle());
       cl.log_scalar("loss", cs.loss_last);  // n_backward_steps, ToLog::All (torch/agents/mod.rs:68-70)
     });
   }
@@ -408,6 +415,7 @@ class ActorCriticAgent {
   uint32_t obs_dim_ = 0;
   float gamma_ = 0.99f;
   double gae_lambda_ = 0.95;
+  StepValueTarget critic_target_ = StepValueTarget::RewardToGo;
 
  public:
   int32_t last_status_ = RL_OPT_OK;
@@ -460,6 +468,7 @@ struct ActorCriticConfig {  // actor_critic.rs:20-45
     a.critic_opt_ = c.optimizer_config.build_optimizer(*a.critic_, eng);
     a.critic_steps_ = c.opt_steps_per_update;
     a.gae_lambda_ = c.gae_lambda;
+    a.critic_target_ = c.target;
     const double g = env.discount_factor() < c.max_discount_factor ? env.discount_factor() : c.max_discount_factor;
     a.gamma_ = (float)g;  // critics/opt.rs:73
   }

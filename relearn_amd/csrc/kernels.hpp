@@ -12,6 +12,8 @@ void launch_env_step(rl_env *env);
 void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 void launch_values(rl_traj *traj, const rl_mlp *critic);
 void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);  // critic NULL: adv = rtg only
+// critic regression targets into traj->d.tgt: one-step TD from traj->d.values (critic != NULL) or reward-to-go (NULL)
+void launch_value_targets(rl_traj *traj, const rl_mlp *critic, float gamma);
 void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa);
 
 // kernels_update.hip
@@ -70,7 +72,8 @@ void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 // teacher-forced forward: d_out [A][T][n]; d_succ (may be NULL) [A][T][n]; d_act (may be NULL) activation record
 void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,
                             const int32_t *d_skip = nullptr);
-void launch_seq_gae(rl_traj *traj, float gamma, float lambda);  // reads traj->seq.out / succ (plane 0)
+void launch_seq_gae(rl_traj *traj, float gamma, float lambda);
+void launch_seq_value_targets(rl_traj *traj, float gamma);  // one-step TD targets from traj->seq.out / succ -> d.tgt  // reads traj->seq.out / succ (plane 0)
 void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi,
                                const int32_t *d_skip = nullptr);
 void launch_seq_critic_dvalues(rl_traj *traj, uint64_t B_total);

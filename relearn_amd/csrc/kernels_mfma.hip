@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 3)
       o.a0 = tr.obs[(size_t)hf * plane + sidx];
       o.a1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
       o.a2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
-      o.tgt = tr.rtg[sidx];
+      o.tgt = tr.tgt[sidx];
     }
     return o;
   };
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(128, 4)
     if (ovalid && oq == 0) {
 #pragma unroll
       for (int k = 0; k < D; ++k) ox[k] = tr.obs[(size_t)k * plane + osidx];
-      tgt = tr.rtg[osidx];
+      tgt = tr.tgt[osidx];
     }
     f32x16 acc[NT];
 #pragma unroll

@@ -210,6 +210,57 @@ __global__ void __launch_bounds__(256) k_gae_scan(TrajDev tr, const float *__res
   }
 }
 
+// ---------------------------------------------------------------- value targets of the critic update
+// StepValueTarget::targets (critics/mod.rs:203-229), evaluated once per update under no-grad (opt.rs:101-104).
+// OneStepTd = one_step_values (critics/mod.rs:139-150): rewards + discount_factor * estimated_next_values, where the
+// next value is the masked extended value of eval_extended_state_values (:116-131): 0 after Terminate, V(successor
+// observation) after Interrupt, V(obs[t+1]) inside an episode (slot T of `values` at the horizon cut).  One thread
+// per sample: no scan.  `scalar * tensor`, then `tensor + tensor`: two roundings.
+template <int D>
+__global__ void __launch_bounds__(256) k_value_targets_td(TrajDev tr, const float *__restrict__ critic, int H,
+                                                          float gamma) {
+  const uint32_t n = tr.n, T = tr.T;
+  const size_t B = (size_t)T * n;
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= B) return;
+  const uint8_t f = tr.flag[o];
+  float vn;
+  if (f == RL_SUCC_TERMINATE) {
+    vn = 0.0f;
+  } else if (f == RL_SUCC_INTERRUPT) {
+    float x[D], z[1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = tr.term_obs[(size_t)d * B + o];
+    mlp_forward_lane<D, 1>(critic, H, x, z);
+    vn = z[0];
+  } else {
+    vn = tr.values[o + n];
+  }
+  const float dn = gamma * vn;
+  tr.tgt[o] = tr.reward[o] + dn;
+}
+
+// RewardToGo = reward_to_go (critics/mod.rs:101-105): the lane's reverse scan of k_gae_scan, into the target plane
+__global__ void __launch_bounds__(64) k_value_targets_rtg(TrajDev tr, float gamma) {
+  const uint32_t n = tr.n, T = tr.T;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float next = 0.0f;
+  for (uint32_t t = T; t-- > 0;) {
+    const size_t o = (size_t)t * n + i;
+    const float r = tr.reward[o];
+    float g;
+    if (tr.flag[o] != RL_SUCC_CONTINUE || t == T - 1) {
+      g = r;
+    } else {
+      const float pg = next * gamma;
+      g = r + pg;
+    }
+    tr.tgt[o] = g;
+    next = g;
+  }
+}
+
 // ---------------------------------------------------------------- host launchers
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
@@ -279,6 +330,21 @@ void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) 
     hipLaunchKernelGGL(k_gae_scan<4>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d,
                        critic ? critic->d_params : (const float *)nullptr, critic ? (int)critic->hidden : 0, gamma, lambda,
                        critic ? 0 : 1);
+}
+
+void launch_value_targets(rl_traj *traj, const rl_mlp *critic, float gamma) {
+  ProfScope ps(traj->eng, RL_K_GAE);
+  if (critic == nullptr) {
+    hipLaunchKernelGGL(k_value_targets_rtg, dim3(cdiv(traj->d.n, 64)), dim3(64), 0, traj->eng->stream, traj->d, gamma);
+    return;
+  }
+  const size_t B = (size_t)traj->d.T * traj->d.n;
+  if (traj->d.D == 5)
+    hipLaunchKernelGGL(k_value_targets_td<5>, dim3(cdiv(B, 256)), dim3(256), 0, traj->eng->stream, traj->d,
+                       critic->d_params, (int)critic->hidden, gamma);
+  else
+    hipLaunchKernelGGL(k_value_targets_td<4>, dim3(cdiv(B, 256)), dim3(256), 0, traj->eng->stream, traj->d,
+                       critic->d_params, (int)critic->hidden, gamma);
 }
 
 void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa) {

@@ -830,6 +830,33 @@ __global__ void __launch_bounds__(64) k_seq_gae(TrajDev tr, const float *__restr
   }
 }
 
+// one_step_values (critics/mod.rs:139-150) with a recurrent critic: next values from the teacher-forced forward
+// (values [T][n]; succ [T][n] where an episode is cut), same selection rule as k_seq_gae; also mirrors the values
+__global__ void __launch_bounds__(256) k_seq_value_targets_td(TrajDev tr, const float *__restrict__ values,
+                                                              const float *__restrict__ succ, float gamma) {
+  const uint32_t n = tr.n, T = tr.T;
+  const size_t B = (size_t)T * n;
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= B) return;
+  const uint32_t t = (uint32_t)(o / n);
+  const uint8_t f = tr.flag[o];
+  float vn;
+  if (f == RL_SUCC_TERMINATE) vn = 0.0f;
+  else if (f == RL_SUCC_INTERRUPT || t == T - 1) vn = succ[o];
+  else vn = values[o + n];
+  const float dn = gamma * vn;
+  tr.tgt[o] = tr.reward[o] + dn;
+  tr.values[o] = values[o];
+  if (t == T - 1) tr.values[o + n] = succ[o];
+}
+
+void launch_seq_value_targets(rl_traj *traj, float gamma) {
+  ProfScope ps(traj->eng, RL_K_GAE);
+  const size_t B = (size_t)traj->d.T * traj->d.n;
+  hipLaunchKernelGGL(k_seq_value_targets_td, dim3(cdiv_s(B, 256)), dim3(256), 0, traj->eng->stream, traj->d,
+                     traj->seq.out, traj->seq.succ, gamma);
+}
+
 void launch_seq_gae(rl_traj *traj, float gamma, float lambda) {
   ProfScope ps(traj->eng, RL_K_GAE);
   uint32_t n = traj->d.n;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_seq_critic_dvalues(TrajDev tr, const fl
   const size_t B = (size_t)tr.T * tr.n;
   double s0 = 0.0;
   for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) {
-    const float d = values[b] - tr.rtg[b];
+    const float d = values[b] - tr.tgt[b];
     dz[b] = d * two_over_B;
     s0 += (double)(d * d);
   }

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) k_critic_fwd(TrajDev tr, const float *__r
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = tr.obs[d * plane + b];
     mlp_forward_lane<D, 1>(params, H, x, z);
-    float d = z[0] - tr.rtg[b];
+    float d = z[0] - tr.tgt[b];
     dz[b] = d * two_over_B;
     s0 += (double)(d * d);
   }

@@ -190,7 +190,9 @@ def gae_case(seed=5):
         for t in range(len(steps) - 2, -1, -1):
             adv[t] = adv[t] + adv[t + 1] * disc
             rtg[t] = rtg[t] + rtg[t + 1] * torch.tensor(gamma, dtype=torch.float32)
-        out.append({"adv": adv.tolist(), "rtg": rtg.tolist(), "values": v.tolist()})
+        # StepValueTarget::OneStepTd (critics/mod.rs:139-150): rewards + discount_factor * estimated_next_values
+        td = r + torch.tensor(gamma, dtype=torch.float32) * vnext
+        out.append({"adv": adv.tolist(), "rtg": rtg.tolist(), "values": v.tolist(), "td": td.tolist()})
     return {"critic_params": params.double().tolist(), "dims": [D, H, 1], "gamma": gamma, "lambda": lam,
             "episodes": out}
 

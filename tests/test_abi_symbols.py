@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     missing = [s for s in decl if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(ra.ABI_SYMBOLS) == decl, set(ra.ABI_SYMBOLS) ^ set(decl)
-    assert lib.rl_abi_version() == 1
+    assert lib.rl_abi_version() == 2
 
 
 def test_every_entry_point_cites_the_reference():
@@ -48,6 +48,9 @@ def test_defaults_match_reference_configs():
             t.accept_violation) == (10, 15, 0.8, 1e-5, 0.01, 0)
     a = ra.adam_config_default()
     assert (a.learning_rate, a.beta1, a.beta2, a.weight_decay, a.eps) == (1e-3, 0.9, 0.999, 0.0, 1e-8)
+    v = ra.values_opt_config_default()  # ValuesOptConfig::default (critics/opt.rs:40-51)
+    assert (v.opt_steps_per_update, v.target) == (80, ra.VALUE_TARGET_REWARD_TO_GO)
+    assert abs(v.discount_factor - 0.99) < 1e-7
     d = ra.dqn_config_default()  # DqnConfig::default (dqn.rs:57-72), ExplorationRateSchedule::default
     assert (d.target, d.minibatch_steps, d.opt_steps_per_update) == (ra.DQN_TARGET_REWARD_TO_GO, 100_000, 50)
     assert (d.exploration_kind, d.exploration_start, d.exploration_end, d.exploration_period) == (

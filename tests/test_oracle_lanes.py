@@ -43,6 +43,15 @@ def test_lane_gae_equals_reference_packed_gae():
     lane, t = lane_t // T, lane_t % T
     assert np.array_equal(adv_p, adv[t, lane])
     assert np.array_equal(rtg_p, rtg[t, lane])
+    # StepValueTarget::OneStepTd (critics/mod.rs:139-150): the lane form against the packed reference pipeline
+    td_p = np.zeros(ns, np.float32)
+    L.oracle_one_step_values_packed(CS, O.f32p(cp), feat, gamma, O.f32p(td_p))
+    td = O.lanes_one_step_targets(CS, cp, traj, gamma)
+    assert np.array_equal(td_p, td[t, lane])
+    assert (traj["flag"] == O.TERMINATE).any() and (traj["flag"] == O.INTERRUPT).any()  # all three successor kinds
+    # delta_t = target_t - V_t: the TD target is the residual of temporal_differences plus the value (same roundings)
+    assert np.array_equal((td - v[:-1]).astype(np.float32)[traj["flag"] != O.CONTINUE],
+                          adv[traj["flag"] != O.CONTINUE])
     # the flat sample arrays the update kernels use hold the same multiset of samples as the packed features
     x, a = O.flat_samples(traj)
     packed_obs = np.array([[feat.contents.obs[i * D + d] for d in range(D)] for i in range(ns)], np.float32)

@@ -141,15 +141,18 @@ def test_gae_on_reference_history_fixture():
     rtg = np.zeros(n, np.float32)
     L.oracle_gae_packed(cs, O.f32p(cp), feat, g["gamma"], g["lambda"], O.f32p(adv), None)
     L.oracle_reward_to_go_packed(feat, g["gamma"], O.f32p(rtg))
+    td = np.zeros(n, np.float32)  # StepValueTarget::OneStepTd (critics/mod.rs:139-150)
+    L.oracle_one_step_values_packed(cs, O.f32p(cp), feat, g["gamma"], O.f32p(td))
     # un-pack by source index (buffer order = episodes in fixture order)
     src = np.array([feat.contents.src_index[i] for i in range(n)])
-    adv_flat, rtg_flat = np.zeros(n, np.float32), np.zeros(n, np.float32)
-    adv_flat[src], rtg_flat[src] = adv, rtg
+    adv_flat, rtg_flat, td_flat = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    adv_flat[src], rtg_flat[src], td_flat[src] = adv, rtg, td
     k = 0
     for ep, exp in zip(eps, g["episodes"]):
         m = len(ep)
         assert np.allclose(adv_flat[k:k + m], exp["adv"], atol=2e-6)
         assert np.allclose(rtg_flat[k:k + m], exp["rtg"], atol=2e-6)
+        assert np.allclose(td_flat[k:k + m], exp["td"], atol=2e-6)
         k += m
     L.oracle_features_free(feat)
     L.oracle_vecbuffer_free(b)
