@@ -87,10 +87,9 @@ const char *rl_last_error(const rl_engine *engine);
 /* name of the device, gcnArchName (must start with "gfx950"), CU count */
 int32_t rl_engine_info(const rl_engine *engine, char *name_out, size_t name_cap, char *arch_out, size_t arch_cap,
                        int32_t *compute_units);
-/* Kernel selection: 0 (default) = best kernels for the shape (f32-MFMA fused update kernels at hidden 128,
- * obs_dim 5); 1 = the v1 reference kernels only (kept as an in-library cross-check; same results within the
- * tolerances stated in tests/test_gpu_parity.py); 2 = MFMA kernels with the two-waves-per-tile critic step (A/B
- * measurements; slower on MI355X). */
+/* Kernel selection: 0 (default) = best kernels for the shape (fused matrix-pipe update kernels at hidden 128,
+ * obs_dim 5); 1 = the v1 kernels only (what other shapes fall back to; kept selectable as an in-library cross-check:
+ * same results within the tolerances stated in tests/test_gpu_parity.py). */
 int32_t rl_engine_set_kernel_variant(rl_engine *engine, int32_t variant);
 /* HIP-event timing of everything enqueued between begin and end on the engine stream (milliseconds) */
 int32_t rl_timer_begin(rl_engine *engine);

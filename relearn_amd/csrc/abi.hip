@@ -291,7 +291,7 @@ int32_t rl_timer_end(rl_engine *e, float *elapsed_ms) {
 int32_t rl_engine_set_kernel_variant(rl_engine *e, int32_t variant) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
-    RL_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (best), 1 (v1 reference kernels) or 2");
+    RL_REQUIRE(variant == 0 || variant == 1, "kernel variant must be 0 (best) or 1 (v1 reference kernels)");
     e->kernel_variant = variant;
   });
 }
@@ -894,12 +894,6 @@ void traj_plan(rl_traj *t, uint64_t B) {
   t->nbC = (uint32_t)nbC;
   if (nbV2 > max_v2) nbV2 = max_v2;
   t->nbV2 = (uint32_t)nbV2;
-  // pair kernels: 2-wave workgroups, 8 per CU (4 waves per SIMD), a contiguous run of tiles per workgroup
-  uint64_t max_pair = 8ull * (uint64_t)e->prop.multiProcessorCount;
-  uint64_t tpb = (n_tiles + max_pair - 1) / max_pair;
-  if (tpb == 0) tpb = 1;
-  t->pair_tiles_per_block = (uint32_t)tpb;
-  t->nbPair = (uint32_t)((n_tiles + tpb - 1) / tpb);
 }
 
 // `resizable`: the sample count changes between launches (DQN minibatches): slabs are sized for the largest grid
@@ -932,7 +926,6 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   uint32_t rows = t->nbA;
   if (t->nbV2 > rows) rows = t->nbV2;
   if (t->nbC > rows) rows = t->nbC;
-  if (t->nbPair > rows) rows = t->nbPair;
   uint32_t rowsB = t->nbB > rows ? t->nbB : rows;
   if (resizable) {
     uint32_t cap = 8u * (uint32_t)e->prop.multiProcessorCount;

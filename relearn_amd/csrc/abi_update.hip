@@ -285,7 +285,7 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
 // per-workgroup partial sums of the critic's MSE gradient and loss -> slabA / slabB (feed-forward modules)
 static void critic_slabs(rl_mlp *critic, rl_traj *traj, uint32_t *rowsA, uint32_t *rowsB) {
   if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
-    *rowsA = *rowsB = traj->eng->kernel_variant == 2 ? traj->nbPair : traj->nbC;
+    *rowsA = *rowsB = traj->nbC;
   } else {
     launch_critic_fwd(traj, critic, b_total(traj));
     launch_mlp_backward(traj, critic, nullptr);

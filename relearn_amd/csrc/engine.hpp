@@ -197,7 +197,7 @@ struct rl_traj {
   float *td = nullptr;      // [T][n] value targets of the last rl_values_opt_update (allocated on first use)
   float *losses = nullptr;  // [max critic steps]
   TrpoStateDev *trpo = nullptr;
-  uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbC = 0, nbPair = 0, pair_tiles_per_block = 0, Pmax = 0, max_losses = 0;
+  uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbC = 0, Pmax = 0, max_losses = 0;
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
 };

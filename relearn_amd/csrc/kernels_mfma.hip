@@ -1,4 +1,5 @@
-// kernels_mfma.hip — "v2" fused full-batch MLP gradient kernels built around the f32 MFMA.
+// kernels_mfma.hip — fused full-batch policy-gradient kernels built around the f32 MFMA (the critic step, same tile
+// machinery with its backward on the bf16 matrix pipe, lives in kernels_critic.hip).
 //
 // One wavefront owns a tile of 32 samples at a time.  Layer 1 of the MLP (x~ [32 x 6] times W~1^T [6 x 128],
 // bias folded in as the 6th input) is 4 x 3 issues of v_mfma_f32_32x32x2_f32 whose D layout puts
@@ -22,9 +23,6 @@
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
-#ifndef RL_ABLATE
-#define RL_ABLATE 0  // timing-only ablation builds (scripts/ablate.sh); 0 in every shipped build
-#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -39,435 +37,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 constexpr int V2_WAVES = 8;        // policy kernels: one workgroup of eight waves per CU (two per SIMD)
-constexpr int CRITIC_WAVES = 12;   // critic step: one workgroup of twelve waves per CU (three per SIMD)
 constexpr int V2_NT = 4;           // 32-unit hidden tiles (H = 128)
 constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 samples per accumulator)
-
-// ---------------------------------------------------------------- critic: forward + loss + backward fused
-// 168 VGPRs: three workgroups (12 waves) per CU, three waves per SIMD — the kernel is VALU-issue bound and a third
-// wave per SIMD raises the VALU utilisation (measured 0.378 -> 0.355 ms per launch at 8.4 M samples).
-// per 32-sample tile and wave:  MFMA 12 issues (768 cycles on the matrix pipe)
-//                               VALU ~128 (relu, y partials) + ~50 (owner math) + 576 (backward) instructions
-// Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2x backward of the 5-128-1 MLP).
-__global__ void __launch_bounds__(CRITIC_WAVES * 64, 3)
-    k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
-                       double *__restrict__ slabB, float two_over_B, uint32_t P) {
-  constexpr int D = 5, H = 128, NT = V2_NT;
-  constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] = sum_s [pre_sj > 0] dy_s x~_sk (slot 6 unused); + db2, loss
-  __shared__ float Ysh[CRITIC_WAVES][32][33];
-  __shared__ float Ush[CRITIC_WAVES][32][8];
-  __shared__ double Acc[CRITIC_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, hf = lane >> 5;
-  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H;
-  const float b2 = W2[H];
-  const size_t B = (size_t)tr.T * tr.n;
-  const size_t plane = (size_t)(tr.T + 1) * tr.n;
-  double *acc64 = Acc[wave];
-  for (int p = lane; p < IMG; p += 64) acc64[p] = 0.0;
-  for (int p = lane; p < 32 * 8; p += 64) (&Ush[wave][0][0])[p] = 0.0f;  // columns 6, 7 stay zero
-
-  // B operand of the MFMA: W~1^T[k][j], k = hf + 2*step; k == 5 is the bias row
-  float wb[NT][3], w2v[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int j = t * 32 + n;
-    wb[t][0] = W1[j * D + hf];
-    wb[t][1] = W1[j * D + 2 + hf];
-    wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
-    w2v[t] = W2[j];
-  }
-  // Backward accumulators: M[j][k] += [pre_sj > 0] * u_sk with lane = hidden unit j (six f32 registers per hidden
-  // tile), VALU FMAs.  (Measured alternatives — the same GEMM as 4x4x1 MFMAs, a VALU/MFMA split — are slower on
-  // this part)
-  float m[NT][6];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) m[t][k] = 0.0f;
-  const float big = 0x1p126f;
-  double loss64 = 0.0, db2_64 = 0.0;
-  wave_lds_fence();
-
-  // f32 -> f64 flush: add the two lane halves (same hidden unit, different samples), then accumulate in LDS
-  auto flush = [&]() {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int j = t * 32 + n;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        float v = m[t][k] + __shfl_xor(m[t][k], 32, 64);
-        if (hf == 0) acc64[j * 7 + k] += (double)v;
-        m[t][k] = 0.0f;
-      }
-    }
-  };
-
-  const size_t n_tiles = (B + 31) / 32;
-  const size_t wave_id = (size_t)blockIdx.x * CRITIC_WAVES + wave, n_waves = (size_t)gridDim.x * CRITIC_WAVES;
-  int since_flush = 0;
-  // A operand: x~[sample n][k = hf + 2*step]; x~5 = 1 (bias input).
-  struct TileOp {
-    float a0, a1, a2, tgt;
-    bool valid;
-  };
-  auto load_tile = [&](size_t g) {
-    TileOp o;
-    const size_t sidx = g * 32 + n;
-    o.a0 = o.a1 = o.a2 = o.tgt = 0.0f;
-    o.valid = g < n_tiles && sidx < B;
-    if (o.valid) {
-      o.a0 = tr.obs[(size_t)hf * plane + sidx];
-      o.a1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
-      o.a2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
-      o.tgt = tr.tgt[sidx];
-    }
-    return o;
-  };
-  auto layer1 = [&](f32x16(&acc)[NT], const TileOp &o) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#if (RL_ABLATE & 4)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = o.a0 * wb[t][0] + (float)r;
-#else
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0, wb[t][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1, wb[t][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a2, wb[t][2], c, 0, 0, 0);
-#endif
-      acc[t] = c;
-    }
-  };
-  auto process = [&](f32x16(&acc)[NT], const TileOp &o) {
-    // relu in place + partial y over this lane's 4 hidden units
-    float yp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yp[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // relu on the bit pattern (one v_max_i32, no float canonicalisation of the MFMA output):
-        // negative floats and -0.0 are negative integers -> 0; positive floats are unchanged
-        int hb = __builtin_bit_cast(int, (float)acc[t][r]);
-        hb = hb > 0 ? hb : 0;
-        float h = __builtin_bit_cast(float, hb);
-        acc[t][r] = h;
-#if !(RL_ABLATE & 2)
-        yp[r] = __builtin_fmaf(h, w2v[t], yp[r]);
-#else
-        if (t == 0) yp[r] = h;
-#endif
-      }
-    // transpose through LDS: row = sample, column = source lane
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
-    wave_lds_fence();
-    float part = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) part = part + Ysh[wave][n][hf * 16 + c];
-    float other = __shfl_xor(part, 32, 64);
-    float p0 = hf == 0 ? part : other, p1 = hf == 0 ? other : part;
-    float y = (p0 + p1) + b2;
-    float d = y - o.tgt;
-    float dy = o.valid ? d * two_over_B : 0.0f;
-    if (hf == 0 && o.valid) {
-      loss64 += (double)(d * d);
-      db2_64 += (double)dy;
-    }
-    // publish u[sample][k] = dy * x~_k (k = 5: dy itself)
-    Ush[wave][n][hf] = dy * o.a0;
-    Ush[wave][n][2 + hf] = dy * o.a1;
-    Ush[wave][n][4 + hf] = dy * o.a2;
-    wave_lds_fence();
-    // backward: lane = hidden unit, one sample row at a time
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
-      const float4 lo = src[0], hi = src[1];
-      const float u[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        // relu'(pre) as one VALU op: clamp(h * 2^126) is 1 for every normal h > 0 and 0 for h == 0
-        const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
-#if !(RL_ABLATE & 1)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[k], m[t][k]);
-#else
-        m[t][0] = m[t][0] + gsel * u[0];
-#endif
-      }
-    }
-    wave_lds_fence();  // Ysh / Ush are rewritten by the next tile
-    if (++since_flush == V2_FLUSH) {
-      since_flush = 0;
-      flush();
-    }
-  };
-  // global loads run one tile ahead; the waves of a SIMD desynchronise so that one wave's matrix work runs
-  // under the other's VALU work
-  f32x16 acc[NT];
-  TileOp op = load_tile(wave_id);
-  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
-    TileOp next = load_tile(g + n_waves);
-    layer1(acc, op);
-    process(acc, op);
-    op = next;
-  }
-  flush();
-  // loss / db2: reduce over the 32 owner lanes of the wave (f64 moved as two 32-bit halves)
-  auto xlane = [](double v, int mask) {
-    uint64_t bits = rl_f64_bits(v);
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
-    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
-    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
-  };
-  double l = hf == 0 ? loss64 : 0.0, bsum = hf == 0 ? db2_64 : 0.0;
-#pragma unroll
-  for (int s = 16; s > 0; s >>= 1) {
-    l = l + xlane(l, s);
-    bsum = bsum + xlane(bsum, s);
-  }
-  if (lane == 0) {
-    acc64[H * 7] = bsum;   // db2
-    acc64[H * 7 + 1] = l;  // loss partial
-  }
-  __syncthreads();
-  // sum the per-wave images in wave order, turn M into gradients and write the workgroup's slab row:
-  //   dL/dW1[j][k] = w2_j * M[j][k],  dL/db1[j] = w2_j * M[j][5],  dL/db2 = sum dy,
-  //   dL/dW2[j] = sum_s dy_s h_sj = sum_s dy_s [pre_sj > 0] (W~1[j] . x~_s) = sum_k W~1[j][k] M[j][k]
-  for (uint32_t p = threadIdx.x; p <= P; p += CRITIC_WAVES * 64) {
-    auto tot = [&](int src) {
-      double s = Acc[0][src];
-#pragma unroll
-      for (int w = 1; w < CRITIC_WAVES; ++w) s = s + Acc[w][src];
-      return s;
-    };
-    double s;
-    if (p < (uint32_t)(H * D)) {
-      int j = p / D, k = p % D;
-      s = tot(j * 7 + k) * (double)W2[j];
-    } else if (p < (uint32_t)(H * D + H)) {
-      int j = p - H * D;
-      s = tot(j * 7 + 5) * (double)W2[j];
-    } else if (p < (uint32_t)(H * D + 2 * H)) {
-      int j = p - H * D - H;
-      s = tot(j * 7 + 5) * (double)b1[j];
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += tot(j * 7 + k) * (double)W1[j * D + k];
-    } else if (p == (uint32_t)(H * D + 2 * H)) {
-      s = tot(H * 7);
-    } else {
-      s = tot(H * 7 + 1);
-    }
-    if (p < P) slabA[(size_t)blockIdx.x * P + p] = s;
-    else slabB[(size_t)blockIdx.x * 4 + 0] = s;
-  }
-  if (threadIdx.x < 3) slabB[(size_t)blockIdx.x * 4 + 1 + threadIdx.x] = 0.0;
-}
-
-// ================================================================================================
-// "pair" variant of the fused critic step: a workgroup of TWO waves owns a 32-sample tile, each wave owning
-// 64 of the 128 hidden units (two 32-unit MFMA tiles).  Measured on MI355X: one wave issues a VALU op only every
-// ~10 cycles, two waves per SIMD reach ~45 % of the VALU rate, four reach ~85 % (scripts/probe/valu_rate.hip) —
-// so the register footprint per wave is what matters: 32 accumulator registers instead of 64 lets four
-// waves share a SIMD.  Costs: two workgroup barriers per tile and the y reduction now spans two waves.
-// ================================================================================================
-constexpr int PAIR_NT = 2;  // hidden tiles per wave
-
-__global__ void __launch_bounds__(128, 4)
-    k_critic_step_pair(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
-                       double *__restrict__ slabB, float two_over_B, uint32_t P, uint32_t tiles_per_block) {
-  constexpr int D = 5, H = 128, NT = PAIR_NT;
-  constexpr int IMG = H * 7 + 2;
-  __shared__ float Ysh[32][65];   // row = sample, column = wave * 32 + source lane
-  __shared__ float Ush[32][8];    // u[sample][k] = dy * x~_k, columns 6, 7 zero
-  __shared__ double Acc[IMG];     // f64 level of the accumulation (each wave owns its hidden units' rows)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 31, hf = lane >> 5;
-  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H;
-  const float b2 = W2[H];
-  const size_t B = (size_t)tr.T * tr.n;
-  const size_t plane = (size_t)(tr.T + 1) * tr.n;
-  for (int p = tid; p < IMG; p += 128) Acc[p] = 0.0;
-  for (int p = tid; p < 32 * 8; p += 128) (&Ush[0][0])[p] = 0.0f;
-
-  float wb[NT][3], w2v[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int j = (wave * NT + t) * 32 + n;
-    wb[t][0] = W1[j * D + hf];
-    wb[t][1] = W1[j * D + 2 + hf];
-    wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
-    w2v[t] = W2[j];
-  }
-  float m[NT][6];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) m[t][k] = 0.0f;
-  const float big = 0x1p126f;
-  double loss64 = 0.0, db2_64 = 0.0;
-  __syncthreads();
-
-  auto flush = [&]() {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int j = (wave * NT + t) * 32 + n;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        float v = m[t][k] + __shfl_xor(m[t][k], 32, 64);
-        if (hf == 0) Acc[j * 7 + k] += (double)v;
-        m[t][k] = 0.0f;
-      }
-    }
-  };
-
-  const size_t n_tiles = (B + 31) / 32;
-  const size_t g0 = (size_t)blockIdx.x * tiles_per_block;
-  // owner role of this thread: sample `os` (16 samples per wave), quarter `oq` of the 64 partial columns
-  const int os = wave * 16 + (lane & 15), oq = lane >> 4;
-  int since_flush = 0;
-  float na0 = 0.0f, na1 = 0.0f, na2 = 0.0f;
-  auto load_ops = [&](size_t g) {
-    const size_t sidx = g * 32 + n;
-    na0 = na1 = na2 = 0.0f;
-    if (g < n_tiles && sidx < B) {
-      na0 = tr.obs[(size_t)hf * plane + sidx];
-      na1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
-      na2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
-    }
-  };
-  load_ops(g0);
-  for (uint32_t it = 0; it < tiles_per_block; ++it) {  // every wave of the grid runs the same trip count
-    const size_t g = g0 + it;
-    const float a0 = na0, a1 = na1, a2 = na2;
-    load_ops(g + 1 < g0 + tiles_per_block ? g + 1 : n_tiles);
-    // owner-side operands: all 6 inputs of sample `os` (for u = dy * x~) and its target
-    const size_t osidx = g * 32 + os;
-    const bool ovalid = g < n_tiles && osidx < B;
-    float ox[6] = {0, 0, 0, 0, 0, 1.0f}, tgt = 0.0f;
-    if (ovalid && oq == 0) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) ox[k] = tr.obs[(size_t)k * plane + osidx];
-      tgt = tr.tgt[osidx];
-    }
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wb[t][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wb[t][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, wb[t][2], c, 0, 0, 0);
-      acc[t] = c;
-    }
-    float yp[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yp[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int hb = __builtin_bit_cast(int, (float)acc[t][r]);
-        hb = hb > 0 ? hb : 0;
-        float h = __builtin_bit_cast(float, hb);
-        acc[t][r] = h;
-        yp[r] = __builtin_fmaf(h, w2v[t], yp[r]);
-      }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Ysh[(r & 3) + 8 * (r >> 2) + 4 * hf][wave * 32 + n] = yp[r];
-    __syncthreads();
-    // y of sample `os`: this lane sums its quarter of the 64 columns, the four quarters meet through shuffles
-    float part = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) part = part + Ysh[os][oq * 16 + c];
-    float q1 = part + __shfl_xor(part, 16, 64);
-    float y = (q1 + __shfl_xor(q1, 32, 64)) + b2;
-    if (oq == 0) {
-      float d = y - tgt;
-      float dy = ovalid ? d * two_over_B : 0.0f;
-      if (ovalid) {
-        loss64 += (double)(d * d);
-        db2_64 += (double)dy;
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Ush[os][k] = dy * ox[k];
-    }
-    __syncthreads();
-    // backward for this wave's hidden units over all 32 samples
-#pragma unroll
-    for (int rc = 0; rc < 8; ++rc) {
-      float u[2][8];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int r = rc * 2 + q;
-        const float4 *src = reinterpret_cast<const float4 *>(&Ush[(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
-        float4 lo = src[0], hi = src[1];
-        u[q][0] = lo.x; u[q][1] = lo.y; u[q][2] = lo.z; u[q][3] = lo.w;
-        u[q][4] = hi.x; u[q][5] = hi.y; u[q][6] = hi.z; u[q][7] = hi.w;
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][rc * 2 + q] * big, 0.0f, 1.0f);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) m[t][k] = __builtin_fmaf(gsel, u[q][k], m[t][k]);
-        }
-    }
-    if (++since_flush == V2_FLUSH) {
-      since_flush = 0;
-      flush();
-    }
-    // no barrier needed here: the next tile's Ysh writes come after this tile's Ysh reads (barrier 2 above), and
-    // its Ush writes come after its own barrier 1, which every wave reaches only after finishing this backward
-  }
-  flush();
-  // loss / db2 live on the oq == 0 lanes (16 per wave)
-  auto xlane = [](double v, int mask) {
-    uint64_t bits = rl_f64_bits(v);
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
-    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
-    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
-  };
-  double l = oq == 0 ? loss64 : 0.0, bsum = oq == 0 ? db2_64 : 0.0;
-#pragma unroll
-  for (int s = 8; s > 0; s >>= 1) {
-    l = l + xlane(l, s);
-    bsum = bsum + xlane(bsum, s);
-  }
-  __shared__ double tail[2][2];
-  if (lane == 0) {
-    tail[wave][0] = bsum;
-    tail[wave][1] = l;
-  }
-  __syncthreads();
-  for (uint32_t p = tid; p <= P; p += 128) {
-    double s;
-    if (p < (uint32_t)(H * D)) {
-      int j = p / D, k = p % D;
-      s = Acc[j * 7 + k] * (double)W2[j];
-    } else if (p < (uint32_t)(H * D + H)) {
-      int j = p - H * D;
-      s = Acc[j * 7 + 5] * (double)W2[j];
-    } else if (p < (uint32_t)(H * D + 2 * H)) {
-      int j = p - H * D - H;
-      s = Acc[j * 7 + 5] * (double)b1[j];
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += Acc[j * 7 + k] * (double)W1[j * D + k];
-    } else if (p == (uint32_t)(H * D + 2 * H)) {
-      s = tail[0][0] + tail[1][0];
-    } else {
-      s = tail[0][1] + tail[1][1];
-    }
-    if (p < P) slabA[(size_t)blockIdx.x * P + p] = s;
-    else slabB[(size_t)blockIdx.x * 4 + 0] = s;
-  }
-  if (tid < 3) slabB[(size_t)blockIdx.x * 4 + 1 + tid] = 0.0;
-}
 
 // ================================================================================================
 // Policy kernels (2-action categorical head).  Same tile machinery as the critic kernel; differences:
@@ -892,21 +463,6 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)  // (three waves per SIMD: 3
 }
 
 // ---------------------------------------------------------------- launcher
-bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
-  if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
-  ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
-  float two_over_B = 2.0f / (float)B_total;
-  if (traj->eng->kernel_variant != 2) {  // one wave per 32-sample tile
-    hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, traj->d,
-                       critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
-  } else {  // variant 2: two waves per tile (A/B measurements)
-    hipLaunchKernelGGL(k_critic_step_pair, dim3(traj->nbPair), dim3(128), 0, traj->eng->stream, traj->d,
-                       critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P,
-                       traj->pair_tiles_per_block);
-  }
-  return true;
-}
-
 // gradient (PASS_INIT), Fisher-vector product (PASS_JVP) or loss/KL evaluation (PASS_EVAL) in one launch
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
