@@ -1,0 +1,220 @@
+// bf16_tile.hpp — the tile machinery shared by the fused update kernels (kernels_critic.hip, kernels_mfma.hip):
+// layer 1 of the 5-128-A MLP and the masked-sum backward on the bf16 matrix pipe, every product exact.
+//
+// What the hardware dictates (measured, scripts/probe/pipe_overlap.hip): v_mfma_f32_32x32x2_f32 runs at the f32 vector
+// rate AND occupies the vector ALU — its time adds to every other wave's VALU time on the SIMD — while the bf16 matrix
+// pipe (v_mfma_f32_32x32x16_bf16, 36 cycles) runs beside vector work at the price of 8 issue cycles.  So the
+// GEMM-shaped parts run on the bf16 pipe:
+//   an f32 value splits EXACTLY into three bf16 pieces, v = p0 + p1 + p2 (8 + 8 + 8 significand bits; each residual is
+//   representable), and a product of two bf16 numbers is exact in the f32 accumulator.  The only roundings left are the
+//   f32 accumulations inside the instruction — measured below the error of a sequential f32 fma chain over the same
+//   terms (scripts/probe/mfma_bf16_mask.hip).  Nothing is computed at reduced precision.
+//
+// One wavefront owns a tile of 32 samples at a time.
+//   forward   pre[s][j] = sum_k x~[s][k] W~1[j][k]  (k = 5: bias, x~ = 1) as the sum over the 9 piece pairs of every k:
+//             48 contraction slots = 3 issues per 32-unit hidden tile, oriented with the HIDDEN UNIT on the lane
+//             (col = lane & 31) and the SAMPLE in the accumulator registers (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+//   backward  M[j][k] = sum_s [pre_sj > 0] . u_sk  with  u_sk = (dL/dy)_s . x~_sk — a masked sum: the mask is 0 or 1, u
+//             splits into three pieces, M = G^T [p0 | p1 | p2].  The forward accumulator tile is already laid out as this
+//             instruction's A operand (sum over its row index: "X^T . B", cdna_hip_programming.md §3), so the mask goes
+//             from registers to the matrix pipe without lane movement: per (sample, hidden unit) the VALU spends one
+//             multiply-clamp (relu') and half a convert instead of the seven operations of a 6-column fma backward.
+//             The 18 piece columns occupy 18 of the 32 output columns; the three pieces of a column are added when the
+//             f32 accumulators are flushed into the f64 level of the two-level accumulation (kernels_update.hip says why
+//             TRPO / Adam want that level).
+//
+// Contraction slots of the forward (48 = 3 issues x 16; lane half h of issue i holds slots 16 i + 8 h + 0..7, i.e. the
+// half's own list u = 8 i + j, 24 entries).  An entry pairs piece a of an input with piece b of the matching weight:
+//   u = 0..8    input 2h,     (a, b) = (0,0) (0,1) (0,2) (1,0) (1,1) (1,2) (2,0) (2,1) (2,2)
+//   u = 9..17   input 2h + 1, the same nine pairs
+//   u = 18..23  h = 0: input 4, (0,0) (0,1) (0,2) (1,0) (1,1) (1,2)
+//               h = 1: input 4, (2,0) (2,1) (2,2); then the bias input 1.0 (one piece) with the bias's three pieces
+// so every lane needs three observation features of its sample: 2h, 2h + 1 and 4.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace bt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 4;     // 32-unit hidden tiles (H = 128)
+constexpr int COLS = 19;  // piece columns of the backward: pcol(k) + p, k = input feature (5 = bias), p = piece; the three
+                          // pieces of a feature stay inside one 16-lane row (column 15 is unused), so the flush adds them
+                          // with row shifts
+constexpr int UROW = 36;  // halfwords per row of the piece image [piece column][sample] (72-byte rows: conflict-free)
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wavefront execute in program order; what is needed is that the compiler keeps that
+  // order across lanes it cannot see a dependence between.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// two f32 -> packed bf16 (element 0 in the low half), round to nearest even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 x = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2));
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __builtin_bit_cast(float, bits16 << 16); }
+// v = p0 + p1 + p2 exactly, each piece a bf16 bit pattern in the low half of a register
+__device__ __forceinline__ void split3(float v, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+  p0 = pack_bf16(v, 0.0f);
+  const float r1 = v - bf16_bits_to_f32(p0);
+  p1 = pack_bf16(r1, 0.0f);
+  const float r2 = r1 - bf16_bits_to_f32(p1);
+  p2 = pack_bf16(r2, 0.0f);
+}
+__device__ __forceinline__ uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
+
+union Frag {
+  bf16x8 v;
+  uint32_t u[4];
+  uint64_t q[2];
+  uint4 x;
+};
+
+// B operands of the forward for one hidden unit: its weights for inputs 2 hf, 2 hf + 1, 4 and its bias
+__device__ __forceinline__ void weight_frags(float wa, float wb, float w4, float bias, int hf, Frag (&f)[3]) {
+  uint32_t a0, a1, a2, c0, c1, c2, e0, e1, e2, g0, g1, g2;
+  split3(wa, a0, a1, a2);
+  split3(wb, c0, c1, c2);
+  split3(w4, e0, e1, e2);
+  split3(bias, g0, g1, g2);
+  f[0].u[0] = pk(a0, a1);
+  f[0].u[1] = pk(a2, a0);
+  f[0].u[2] = pk(a1, a2);
+  f[0].u[3] = pk(a0, a1);
+  f[1].u[0] = pk(a2, c0);
+  f[1].u[1] = pk(c1, c2);
+  f[1].u[2] = pk(c0, c1);
+  f[1].u[3] = pk(c2, c0);
+  f[2].u[0] = pk(c1, c2);
+  f[2].u[1] = pk(e0, e1);
+  f[2].u[2] = hf == 0 ? pk(e2, e0) : pk(e2, g0);
+  f[2].u[3] = hf == 0 ? pk(e1, e2) : pk(g1, g2);
+}
+
+// A operands of the forward for one sample: its features 2 hf, 2 hf + 1, 4 and the bias input (1, or 0 for a padding
+// sample)
+__device__ __forceinline__ void input_frags(float xa, float xb, float xc, bool valid, int hf, Frag (&f)[3]) {
+  uint32_t a0, a1, a2, c0, c1, c2, e0, e1, e2;
+  split3(xa, a0, a1, a2);
+  split3(xb, c0, c1, c2);
+  split3(xc, e0, e1, e2);
+  const uint32_t one = valid ? 0x3F80u : 0u;
+  const uint32_t x0 = hf == 0 ? e0 : e2, x1 = hf == 0 ? e1 : one;
+  f[0].u[0] = pk(a0, a0);
+  f[0].u[1] = pk(a0, a1);
+  f[0].u[2] = pk(a1, a1);
+  f[0].u[3] = pk(a2, a2);
+  f[1].u[0] = pk(a2, c0);
+  f[1].u[1] = pk(c0, c0);
+  f[1].u[2] = pk(c1, c1);
+  f[1].u[3] = pk(c1, c2);
+  f[2].u[0] = pk(c2, c2);
+  f[2].u[1] = pk(x0, x0);
+  f[2].u[2] = pk(x0, x1);
+  f[2].u[3] = pk(x1, x1);
+}
+
+// pre-activations of one 32-unit hidden tile for the wave's 32 samples
+__device__ __forceinline__ f32x16 layer1(const Frag (&fa)[3], const Frag (&fw)[3]) {
+  f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].v, fw[i].v, c, 0, 0, 0);
+  return c;
+}
+
+// relu'(pre) of a tile's 16 registers, packed as the two A operands (sample groups s = 0, 1) of the backward
+__device__ __forceinline__ void pack_mask(const float (&gm)[16], Frag (&ga)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[s].u[i] = pack_bf16(gm[8 * s + 2 * i], gm[8 * s + 2 * i + 1]);
+}
+// the same, and keep the packed form (8 registers) live instead of the tile's 16 pre-activations: for kernels whose
+// register budget is the tighter constraint
+__device__ __forceinline__ void pack_mask_now(const float (&gm)[16], Frag (&ga)[2]) {
+  pack_mask(gm, ga);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ga[s].u[i]));
+}
+
+__device__ __forceinline__ constexpr int pcol(int k) { return k < 5 ? 3 * k : 16; }
+
+// publish u[sample n][k] = g * x~_k for this lane's three k (half 0: k = 0, 1, 4; half 1: k = 2, 3 and 5, where
+// x~_5 = 1) as exact bf16 pieces in the wave's piece image
+__device__ __forceinline__ void publish_pieces(unsigned short (*ubf)[UROW], float g, float xa, float xb, float xc, int n,
+                                               int hf) {
+  const float uv[3] = {g * xa, g * xb, hf == 0 ? g * xc : g};
+  const int cc[3] = {6 * hf, 6 * hf + 3, hf == 0 ? 12 : 16};  // pcol of k = 2 hf, 2 hf + 1, 4 + hf
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    uint32_t q0, q1, q2;
+    split3(uv[q], q0, q1, q2);
+    ubf[cc[q] + 0][n] = (unsigned short)q0;
+    ubf[cc[q] + 1][n] = (unsigned short)q1;
+    ubf[cc[q] + 2][n] = (unsigned short)q2;
+  }
+}
+
+// B operands of the backward: element j of lane half hf = piece[column n][sample 16 s + 8 (j >> 2) + 4 hf + (j & 3)]
+__device__ __forceinline__ void piece_frags(const unsigned short (*ubf)[UROW], int n, int hf, Frag (&ub)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    ub[s].q[0] = 0;
+    ub[s].q[1] = 0;
+    if (n < COLS && n != 15) {  // column 15 is unused (never written)
+      ub[s].q[0] = *reinterpret_cast<const uint64_t *>(&ubf[n][16 * s + 4 * hf]);
+      ub[s].q[1] = *reinterpret_cast<const uint64_t *>(&ubf[n][16 * s + 8 + 4 * hf]);
+    }
+  }
+}
+
+__device__ __forceinline__ void backward(const Frag (&ga)[NT][2], const Frag (&ub)[2], f32x16 (&dm)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) dm[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[t][s].v, ub[s].v, dm[t], 0, 0, 0);
+}
+
+// f32 -> f64 flush of the backward accumulators into the wave's image acc64[j * stride + k] (LDS): the three pieces of
+// an input column sit in neighbouring lanes of one 16-lane row; add them (p0 + p1) + p2 with row shifts, then one
+// ds_add_f64 per value on the lane that holds piece 0 (every address belongs to exactly one lane: no contention, and
+// the order of the additions into an address is the program order of the flushes)
+__device__ __forceinline__ void flush(f32x16 (&dm)[NT], double *acc64, int stride, int n, int hf) {
+  const bool owner = (n < 15 && (n % 3) == 0) || n == 16;
+  const int k = n == 16 ? 5 : n / 3;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    float tot[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = dm[t][r];
+      // row_shl:1 / row_shl:2: lane i reads lane i + 1 / i + 2 of its 16-lane row (0 past the end of the row)
+      const float v1 = __builtin_bit_cast(
+          float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+      const float v2 = __builtin_bit_cast(
+          float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102, 0xf, 0xf, true));
+      tot[r] = (v + v1) + v2;
+      dm[t][r] = 0.0f;
+    }
+    if (owner) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        __hip_atomic_fetch_add(&acc64[j * stride + k], (double)tot[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+  }
+}
+
+}  // namespace bt

@@ -20,6 +20,7 @@
 //
 // Reference semantics: ValuesOpt::update (src/torch/agents/critics/opt.rs:100-126): loss = mse_loss(V(obs),
 // targets, Mean); backward; the Adam step itself is k_adam_step (kernels_update.hip).
+#include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
@@ -463,6 +464,352 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)  // (three waves per SIMD: 3
 }
 
 // ---------------------------------------------------------------- launcher
+// ================================================================================================
+// Policy passes on the bf16 matrix pipe (tile machinery: bf16_tile.hpp; every product exact, f32 accumulation).
+//   PASS_INIT / PASS_PPO   gradient of the (clipped) surrogate: forward, per-sample math, masked-sum backward
+//   PASS_JVP               Fisher-vector product J^T (diag p - p p^T) J v: forward for the relu' masks, tangent forward,
+//                          per-sample metric, masked-sum backward
+//   PASS_EVAL              surrogate loss and KL of candidate parameters: forward only
+// Forward output layer (INIT / PPO / EVAL): relu through |x| as in the critic step — for each of the two logits
+//   z_a = b2_a + (v_a . x~ + sum_j w2_aj |pre_j|) / 2,  v_ak = sum_j w2_aj W~1[j][k].
+// Tangent forward (JVP): the metric only needs the DIFFERENCE of the two tangent logits,
+//   dz_0 - dz_1 = sum_j relu'(pre_j) (w2d_j t_j + t2d_j pre_j) + (vb2_0 - vb2_1),   w2d = W2[0] - W2[1], t2d likewise,
+// and  w2d_j t_j + t2d_j pre_j = x~ . Z_j  with  Z_jk = w2d_j V~1[j][k] + t2d_j W~1[j][k]  — linear in the inputs, so it
+// is a second layer-1 product with Z as the weight matrix (its piece fragments are built once per launch and parked in
+// LDS: 12 KB shared by the workgroup's waves), one multiply-clamp and one fma per (sample, unit).
+// Backward: the logit gradient of a 2-way softmax is antisymmetric (dz_1 = -dz_0), so one channel g = (dz_0 - dz_1) / 2:
+//   M_d[j][k] = sum_s [pre_sj > 0] g_s x~_sk,  dW1[j][k] = (W2[0][j] - W2[1][j]) M_d[j][k],
+//   dW2[0][j] = -dW2[1][j] = sum_k W~1[j][k] M_d[j][k];  db2 keeps its two exact per-channel sums.
+// Reference semantics: Trpo::update closure + HessianVectorProduct (src/torch/agents/policies/trpo.rs:97-146,
+// src/torch/optimizers/conjugate_gradient.rs:262-339), Ppo::update (policies/ppo.rs:124-137), Categorical
+// (src/torch/distributions/categorical.rs).
+// ================================================================================================
+constexpr int PB_FLUSH = 16;  // f32 -> f64 flush period in tiles
+
+template <int MODE>
+__global__ void __launch_bounds__(V2_WAVES * 64, 2)
+    k_policy_bf16(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
+                  float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
+                  uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
+  using bt::Frag;
+  constexpr int D = 5, H = 128, NT = bt::NT, A = 2;
+  constexpr bool BWD = MODE != PASS_EVAL;
+  constexpr bool JVP = MODE == PASS_JVP;
+  constexpr int IW = 7;              // f64 image slots per hidden unit (six columns)
+  constexpr int PIMG_M = H * IW + 5; // then db2[0], db2[1], sum0, sum1, sum2
+  __shared__ float Ysh[V2_WAVES][32][33];
+  __shared__ __attribute__((aligned(8))) unsigned short Ubf[BWD ? V2_WAVES : 1][bt::COLS][bt::UROW];
+  __shared__ double Acc[V2_WAVES][BWD ? PIMG_M : 4];
+  __shared__ uint4 Fz[JVP ? NT * 3 : 1][64];  // piece fragments of Z (JVP): [tile * 3 + issue][lane]
+  if (skip != nullptr && *skip != 0) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5;
+  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H,
+                           *__restrict__ b2 = W2 + A * H;
+  const size_t B = (size_t)tr.T * tr.n;
+  const size_t plane = (size_t)(tr.T + 1) * tr.n;
+  double *acc64 = Acc[wave];
+  if (BWD)
+    for (int p = lane; p < PIMG_M; p += 64) acc64[p] = 0.0;
+
+  Frag fw[NT][3];
+  float w2v[NT][A];
+  float lv[A][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+  float tb2d = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = t * 32 + n;
+    const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
+    bt::weight_frags(wa, wb, w4, bj, hf, fw[t]);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      w2v[t][a] = W2[a * H + j];
+      if (!JVP) {
+        lv[a][0] = __builtin_fmaf(w2v[t][a], wa, lv[a][0]);
+        lv[a][1] = __builtin_fmaf(w2v[t][a], wb, lv[a][1]);
+        lv[a][2] = __builtin_fmaf(w2v[t][a], hf == 0 ? w4 : bj, lv[a][2]);
+      }
+    }
+    if (JVP && wave == t) {  // waves 0..3 build the fragments of Z for hidden tile t = wave
+      const float *__restrict__ V1 = tangent, *__restrict__ vb1 = V1 + H * D, *__restrict__ V2 = vb1 + H;
+      const float w2d = w2v[t][0] - w2v[t][1], t2d = V2[j] - V2[H + j];
+      auto zmix = [&](float v, float w) { return __builtin_fmaf(t2d, w, w2d * v); };
+      Frag fz[3];
+      bt::weight_frags(zmix(V1[j * D + 2 * hf], wa), zmix(V1[j * D + 2 * hf + 1], wb), zmix(V1[j * D + 4], w4),
+                       zmix(vb1[j], bj), hf, fz);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Fz[t * 3 + i][lane] = fz[i].x;
+    }
+  }
+  if (JVP) {
+    const float *__restrict__ vb2 = tangent + H * D + H + A * H;
+    tb2d = vb2[0] - vb2[1];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) lv[a][q] = lv[a][q] + __shfl_xor(lv[a][q], m, 64);
+  }
+  const float b2_0 = b2[0], b2_1 = b2[1];
+  bt::f32x16 dm[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) dm[t] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const float big = 0x1p126f;
+  double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
+  bt::wave_lds_fence();
+
+  // sum over the 32 source lanes of 16 per-lane partials (+ this half's linear part): LDS transpose, the result for
+  // sample n in both halves
+  auto lane_sum = [&](const float(&yp)[16], float lin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
+    bt::wave_lds_fence();
+    float part = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) part = part + Ysh[wave][n][hf * 16 + c];
+    part = part + lin;
+    const float other = __shfl_xor(part, 32, 64);
+    bt::wave_lds_fence();
+    return hf == 0 ? part + other : other + part;
+  };
+
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t wave_id = (size_t)blockIdx.x * V2_WAVES + wave, n_waves = (size_t)gridDim.x * V2_WAVES;
+  int since_flush = 0;
+  struct TileOp {
+    float xa, xb, xc;
+    bool valid;
+  };
+  // branch-free (padding lanes read sample B - 1 and are zeroed): the loads of tile i + 1 stay in flight across tile i
+  auto load_tile = [&](size_t g) {
+    TileOp o;
+    const size_t sidx = g * 32 + n;
+    o.valid = g < n_tiles && sidx < B;
+    const size_t sc = o.valid ? sidx : B - 1;
+    const float xa = tr.obs[(size_t)(2 * hf) * plane + sc], xb = tr.obs[(size_t)(2 * hf + 1) * plane + sc];
+    const float xc = tr.obs[(size_t)4 * plane + sc];
+    o.xa = o.valid ? xa : 0.0f;
+    o.xb = o.valid ? xb : 0.0f;
+    o.xc = o.valid ? xc : 0.0f;
+    return o;
+  };
+  TileOp op = load_tile(wave_id);
+  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
+    const TileOp next = load_tile(g + n_waves);
+    const size_t sidx = g * 32 + n;
+    Frag fa[3];
+    bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
+    Frag ga[NT][2];
+    float y0[16], y1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      y0[r] = 0.0f;
+      y1[r] = 0.0f;
+    }
+    bt::f32x16 c = bt::layer1(fa, fw[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bt::f32x16 cn = c;
+      if (t + 1 < NT) cn = bt::layer1(fa, fw[t + 1]);
+      float gm[16];
+      if (JVP) {
+        Frag fz[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fz[i].x = Fz[t * 3 + i][lane];
+        const bt::f32x16 both = bt::layer1(fa, fz);  // x~ . Z_j for the tile's units
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          gm[r] = __builtin_amdgcn_fmed3f((float)c[r] * big, 0.0f, 1.0f);
+          y0[r] = __builtin_fmaf(gm[r], both[r], y0[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pre = c[r], apre = __builtin_fabsf(pre);
+          y0[r] = __builtin_fmaf(apre, w2v[t][0], y0[r]);
+          y1[r] = __builtin_fmaf(apre, w2v[t][1], y1[r]);
+          if (BWD) gm[r] = __builtin_amdgcn_fmed3f(pre * big, 0.0f, 1.0f);
+        }
+      }
+      if (BWD) bt::pack_mask_now(gm, ga[t]);
+      c = cn;
+    }
+    float s0, s1 = 0.0f;
+    if (JVP) {
+      s0 = lane_sum(y0, 0.0f);
+    } else {
+      const float x3 = hf == 0 ? op.xc : 1.0f;
+      float lin0 = lv[0][0] * op.xa, lin1 = lv[1][0] * op.xa;
+      lin0 = __builtin_fmaf(lv[0][1], op.xb, lin0);
+      lin1 = __builtin_fmaf(lv[1][1], op.xb, lin1);
+      lin0 = __builtin_fmaf(lv[0][2], x3, lin0);
+      lin1 = __builtin_fmaf(lv[1][2], x3, lin1);
+      s0 = 0.5f * lane_sum(y0, lin0);
+      s1 = 0.5f * lane_sum(y1, lin1);
+    }
+    // ---- per-sample math on the owner lanes (lane n and n + 32 both hold sample n)
+    float dz0 = 0.0f, dz1 = 0.0f;
+    if (JVP) {
+      const float delta = s0 + tb2d;
+      float p0 = 0.0f, p1 = 0.0f;
+      if (op.valid) {
+        p0 = rl_expf(lp0[sidx]);
+        p1 = rl_expf(lp0[B + sidx]);
+      }
+      dz0 = op.valid ? (p0 * p1) * delta * inv_B : 0.0f;
+      dz1 = -dz0;
+    } else {
+      float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
+      const float adv = op.valid ? tr.adv[sidx] : 0.0f;
+      const int act = op.valid ? (int)tr.action[sidx] : 0;
+      log_softmax_lane<2>(z, lp);
+      if (MODE == PASS_PPO) {
+        // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
+        float l0a = 0.0f;
+        if (op.valid) l0a = lp0[(size_t)act * B + sidx];
+        const float lpa = act == 0 ? lp[0] : lp[1];
+        const float ratio = rl_expf(lpa - l0a);
+        const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
+        const float u1 = ratio * adv, u2 = clipped * adv;
+        const bool inside = ratio >= clip_lo && ratio <= clip_hi;
+        const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
+        const float cc = -(gr * ratio) * inv_B;
+        dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - rl_expf(lp[0])) : 0.0f;
+        dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - rl_expf(lp[1])) : 0.0f;
+        if (op.valid && hf == 0) sum0 += (double)(u1 < u2 ? u1 : u2);
+      } else if (MODE == PASS_INIT) {
+        if (op.valid && hf == 0) {
+          lp0[sidx] = lp[0];
+          lp0[B + sidx] = lp[1];
+        }
+        const float lpa = act == 0 ? lp[0] : lp[1];
+        const float ratio = rl_expf(lpa - lpa);
+        const float cc = -(ratio * adv) * inv_B;
+        const float pa0 = rl_expf(lp[0]), pa1 = rl_expf(lp[1]);
+        dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - pa0) : 0.0f;
+        dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - pa1) : 0.0f;
+        const float cl0 = lp[0] < -3.402823466e+38f ? -3.402823466e+38f : lp[0];
+        const float cl1 = lp[1] < -3.402823466e+38f ? -3.402823466e+38f : lp[1];
+        float ent = cl0 * pa0;
+        ent += cl1 * pa1;
+        if (op.valid && hf == 0) {
+          sum0 += (double)(ratio * adv);
+          sum1 += (double)(-ent);
+          sum2 += (double)(lpa * adv);
+        }
+      } else {  // PASS_EVAL
+        float l00 = 0.0f, l01 = 0.0f;
+        if (op.valid) {
+          l00 = lp0[sidx];
+          l01 = lp0[B + sidx];
+        }
+        const float lpa = act == 0 ? lp[0] : lp[1];
+        const float l0a = act == 0 ? l00 : l01;
+        const float ratio = rl_expf(lpa - l0a);
+        float rel0 = l00 - lp[0], rel1 = l01 - lp[1];
+        if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
+        if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
+        float kl = rel0 * rl_expf(l00);
+        kl += rel1 * rl_expf(l01);
+        if (op.valid && hf == 0) {
+          sum0 += (double)(ratio * adv);
+          sum1 += (double)kl;
+        }
+      }
+    }
+    if (BWD) {
+      if (hf == 0) {
+        db2_0 += (double)dz0;
+        db2_1 += (double)dz1;
+      }
+      // one channel: u[sample][k] = g * x~_k with g = (dz_0 - dz_1) / 2, masked sum over the samples on the matrix pipe
+      bt::publish_pieces(Ubf[wave], 0.5f * (dz0 - dz1), op.xa, op.xb, op.xc, n, hf);
+      bt::wave_lds_fence();
+      Frag ub[2];
+      bt::piece_frags(Ubf[wave], n, hf, ub);
+      bt::backward(ga, ub, dm);
+      bt::wave_lds_fence();
+      if (++since_flush == PB_FLUSH) {
+        since_flush = 0;
+        bt::flush(dm, acc64, IW, n, hf);
+      }
+    }
+    op = next;
+  }
+  if (BWD) bt::flush(dm, acc64, IW, n, hf);
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+  double r0 = hf == 0 ? sum0 : 0.0, r1 = hf == 0 ? sum1 : 0.0, r2 = hf == 0 ? db2_0 : 0.0, r3 = hf == 0 ? db2_1 : 0.0;
+  double r4 = hf == 0 ? sum2 : 0.0;
+#pragma unroll
+  for (int s = 16; s > 0; s >>= 1) {
+    r0 = r0 + xlane(r0, s);
+    r1 = r1 + xlane(r1, s);
+    r2 = r2 + xlane(r2, s);
+    r3 = r3 + xlane(r3, s);
+    if (MODE == PASS_INIT) r4 = r4 + xlane(r4, s);
+  }
+  constexpr int TAIL = BWD ? H * IW : 0;
+  if (lane == 0) {
+    if (BWD) {
+      acc64[TAIL + 0] = r2;
+      acc64[TAIL + 1] = r3;
+      acc64[TAIL + 2] = r0;
+      acc64[TAIL + 3] = r1;
+      if (MODE == PASS_INIT) acc64[TAIL + 4] = r4;
+    } else {
+      acc64[0] = r0;
+      acc64[1] = r1;
+    }
+  }
+  __syncthreads();
+  auto tot = [&](int src) {
+    double s = Acc[0][src];
+#pragma unroll
+    for (int w = 1; w < V2_WAVES; ++w) s = s + Acc[w][src];
+    return s;
+  };
+  if (BWD) {
+    for (uint32_t p = threadIdx.x; p < P; p += V2_WAVES * 64) {
+      double s = 0.0;
+      if (p < (uint32_t)(H * D)) {  // M_0 = M_d, M_1 = -M_d
+        int j = p / D, k = p % D;
+        s = tot(j * IW + k) * ((double)W2[j] - (double)W2[H + j]);
+      } else if (p < (uint32_t)(H * D + H)) {
+        int j = p - H * D;
+        s = tot(j * IW + 5) * ((double)W2[j] - (double)W2[H + j]);
+      } else if (p < (uint32_t)(H * D + H + A * H)) {
+        int q = p - H * D - H, a = q / H, j = q % H;
+        s = tot(j * IW + 5) * (double)b1[j];
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += tot(j * IW + k) * (double)W1[j * D + k];
+        if (a == 1) s = -s;
+      } else {
+        s = tot(TAIL + (int)(p - (H * D + H + A * H)));
+      }
+      slabA[(size_t)blockIdx.x * P + p] = s;
+    }
+  }
+  if (threadIdx.x < 4) {
+    double v = 0.0;
+    if (BWD) {
+      if (!JVP && threadIdx.x < 2) v = tot(TAIL + 2 + threadIdx.x);
+      if (MODE == PASS_INIT && threadIdx.x == 2) v = tot(TAIL + 4);
+    } else if (threadIdx.x < 2) {
+      v = tot(threadIdx.x);
+    }
+    slabB[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+  }
+}
+
 // gradient (PASS_INIT), Fisher-vector product (PASS_JVP) or loss/KL evaluation (PASS_EVAL) in one launch
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
@@ -475,12 +822,16 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
 #define PLAUNCH(MM)                                                                                              \
   hipLaunchKernelGGL((k_policy_mfma<MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0, traj->slabA, \
                      traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
+#define BLAUNCH(MM)                                                                                              \
+  hipLaunchKernelGGL((k_policy_bf16<MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0, traj->slabA, \
+                     traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
   if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
-  if (mode == PASS_INIT) PLAUNCH(PASS_INIT);
-  else if (mode == PASS_JVP) PLAUNCH(PASS_JVP);
+  if (mode == PASS_INIT) BLAUNCH(PASS_INIT);
+  else if (mode == PASS_JVP) BLAUNCH(PASS_JVP);
   else if (mode == PASS_DQN) PLAUNCH(PASS_DQN);
-  else if (mode == PASS_PPO) PLAUNCH(PASS_PPO);
-  else PLAUNCH(PASS_EVAL);
+  else if (mode == PASS_PPO) BLAUNCH(PASS_PPO);
+  else BLAUNCH(PASS_EVAL);
 #undef PLAUNCH
+#undef BLAUNCH
   return true;
 }
