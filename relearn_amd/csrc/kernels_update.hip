@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 
 #include <cfloat>
+#include <cmath>
 
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
@@ -315,35 +316,36 @@ __global__ void __launch_bounds__(128) k_mlp_backward(const float *__restrict__ 
 // ---------------------------------------------------------------- (3) deterministic slab reduction
 // Workgroup = 16 waves for 64 consecutive vector entries: wave w sums slab rows w, w+16, ... in order, the
 // 16 partials are combined in wave order; f64 throughout, rounded to f32 once.  Rows are 512-B coalesced reads.
+// sum of the slab rows r = w, w + 16, w + 32, ... of one column: the loads of up to 16 rows are issued before the first
+// add (one memory round trip for <= 256 rows — the launch is latency-bound), the additions run in row order
+__device__ __forceinline__ double column_partial(const double *__restrict__ slab, uint32_t nb, uint32_t stride,
+                                                 uint32_t col, int w) {
+  double acc = 0.0;
+  for (uint32_t r0 = w; r0 < nb; r0 += 16 * 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const uint32_t r = r0 + 16 * u;
+      v[u] = r < nb ? slab[(size_t)r * stride + col] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = acc + v[u];
+  }
+  return acc;
+}
+
 __global__ void __launch_bounds__(1024) k_reduce(const double *__restrict__ slabA, uint32_t nbA, uint32_t P,
                                                  const double *__restrict__ slabB, uint32_t nbB,
                                                  float *__restrict__ vec, int useA, int useB) {
   __shared__ double part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 64 + lane;
-  // 8 independent partial sums per lane keep 8 loads in flight (the loop is latency-bound otherwise); the
-  // summation order is fixed, so the result is bitwise reproducible
-  double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double acc = 0.0;
   if (p < P) {
-    if (useA) {
-      uint32_t r = w;
-      for (; r + 7 * 16 < nbA; r += 8 * 16) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabA[(size_t)(r + u * 16) * P + p];
-      }
-      for (; r < nbA; r += 16) a8[0] = a8[0] + slabA[(size_t)r * P + p];
-    }
+    if (useA) acc = column_partial(slabA, nbA, P, p, w);
   } else if (p < P + 4) {
-    if (useB) {
-      uint32_t r = w;
-      for (; r + 7 * 16 < nbB; r += 8 * 16) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabB[(size_t)(r + u * 16) * 4 + (p - P)];
-      }
-      for (; r < nbB; r += 16) a8[0] = a8[0] + slabB[(size_t)r * 4 + (p - P)];
-    }
+    if (useB) acc = column_partial(slabB, nbB, 4, p - P, w);
   }
-  double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
   part[w][lane] = acc;
   __syncthreads();
   if (w == 0 && p < P + 4) {
@@ -550,29 +552,23 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
                                                       const double *__restrict__ slabB, uint32_t nbB,
                                                       float *__restrict__ vec, float *__restrict__ params,
                                                       float *__restrict__ m, float *__restrict__ v,
-                                                      uint64_t *step_ptr, uint64_t step, double lr, double beta1,
-                                                      double beta2, double eps, double weight_decay, double inv_B,
+                                                      uint64_t *step_ptr, uint64_t step, float neg_step_size,
+                                                      float sqrt_bc2, double beta1, double beta2, double eps,
+                                                      double weight_decay, double inv_B,
                                                       float *__restrict__ loss_out) {
   __shared__ double part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 64 + lane;
-  double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (p < P) {
-    uint32_t r = w;
-    for (; r + 7 * 16 < nbA; r += 8 * 16) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabA[(size_t)(r + u * 16) * P + p];
-    }
-    for (; r < nbA; r += 16) a8[0] = a8[0] + slabA[(size_t)r * P + p];
-  } else if (p < P + 4) {
-    uint32_t r = w;
-    for (; r + 7 * 16 < nbB; r += 8 * 16) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a8[u] = a8[u] + slabB[(size_t)(r + u * 16) * 4 + (p - P)];
-    }
-    for (; r < nbB; r += 16) a8[0] = a8[0] + slabB[(size_t)r * 4 + (p - P)];
+  // the optimiser state of this column is requested first, so that it arrives under the slab loads
+  float p_old = 0.0f, m_old = 0.0f, v_old = 0.0f;
+  if (w == 0 && p < P) {
+    p_old = params[p];
+    m_old = m[p];
+    v_old = v[p];
   }
-  double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  double acc = 0.0;
+  if (p < P) acc = column_partial(slabA, nbA, P, p, w);
+  else if (p < P + 4) acc = column_partial(slabB, nbB, 4, p - P, w);
   part[w][lane] = acc;
   __syncthreads();
   if (w != 0 || p >= P + 4) return;
@@ -586,21 +582,18 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
     if (p == P && loss_out) *loss_out = (float)((double)gsum * inv_B);
     return;
   }
-  const double bc1 = 1.0 - pow(beta1, (double)step);
-  const double bc2 = 1.0 - pow(beta2, (double)step);
+  // neg_step_size = -(float)(lr / (1 - beta1^step)), sqrt_bc2 = (float)sqrt(1 - beta2^step): the host knows the step
   const float b1 = (float)beta1, b2 = (float)beta2;
   const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
-  const float sqrt_bc2 = (float)sqrt(bc2);
-  const float neg_step_size = -(float)(lr / bc1);
   const float epsf = (float)eps;
   float g = gsum;
-  if (weight_decay != 0.0) g = g + (float)weight_decay * params[p];
-  const float mi = m[p] * b1 + omb1 * g;
-  const float vi = v[p] * b2 + omb2 * g * g;
+  if (weight_decay != 0.0) g = g + (float)weight_decay * p_old;
+  const float mi = m_old * b1 + omb1 * g;
+  const float vi = v_old * b2 + omb2 * g * g;
   m[p] = mi;
   v[p] = vi;
   const float denom = __fsqrt_rn(vi) / sqrt_bc2 + epsf;
-  params[p] = params[p] + (neg_step_size * mi) / denom;
+  params[p] = p_old + (neg_step_size * mi) / denom;
 }
 
 // ---------------------------------------------------------------- launchers
@@ -714,9 +707,13 @@ void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t ro
   ProfScope ps(traj->eng, RL_K_REDUCE);
   uint32_t P = (uint32_t)opt->mod->P;
   opt->host_step += 1;
+  // bias corrections on the host, with the arithmetic of k_adam_step (which has to read the step from the device)
+  const double bc1 = 1.0 - std::pow(opt->cfg.beta1, (double)opt->host_step);
+  const double bc2 = 1.0 - std::pow(opt->cfg.beta2, (double)opt->host_step);
+  const float neg_step_size = -(float)(opt->cfg.learning_rate / bc1), sqrt_bc2 = (float)std::sqrt(bc2);
   hipLaunchKernelGGL(k_reduce_adam, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
                      traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
-                     opt->host_step, opt->cfg.learning_rate, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
+                     opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
                      opt->cfg.weight_decay, 1.0 / (double)B_total,
                      loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr);
 }
