@@ -125,9 +125,29 @@ __device__ __forceinline__ void lane_store(const EnvStateDev &st, uint32_t i, co
   st.reset_count[i] = s.reset_count;
 }
 
-// ---------------------------------------------------------------- MLP forward, one row per lane
-// Mlp::forward (torch/modules/ff/mlp.rs:139-151): relu(x W1^T + b1) W2^T + b2, weights wave-uniform
-// (scalar loads), chain order: acc = bias; acc = fma(x_k, w_k, acc) with k ascending.
+// ---------------------------------------------------------------- MLP forward
+// Mlp::forward (torch/modules/ff/mlp.rs:139-151): relu(x W1^T + b1) W2^T + b2.  Summation orders (shared with the oracle):
+//   layer 1: acc = bias; acc = fma(x_k, w_k, acc) with k ascending;
+//   output layer: MLP_GROUPS = 16 interleaved partial chains — unit j feeds chain j mod 16, every chain starts from 0 and
+//   runs acc = fma(h_j, w_j, acc), j ascending — combined by the fixed binary tree ((c0 + c1) + (c2 + c3)) + ... over
+//   neighbouring chains, bias added last.  One thread may own all sixteen chains of a row (mlp_forward_lane*: sixteen
+//   independent fma chains instead of one 128-long one), or G = 2, 4, 8, 16 cooperating threads own 16 / G neighbouring
+//   chains each and meet through xor-shuffles (mlp_forward_group_lds): the result does not depend on G.
+constexpr int MLP_GROUPS = 16;
+
+template <int A>
+__device__ __forceinline__ void mlp_tree(float (&c)[A][MLP_GROUPS], const float *__restrict__ b2, float (&z)[A]) {
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+#pragma unroll
+    for (int width = 1; width < MLP_GROUPS; width *= 2)
+#pragma unroll
+      for (int g = 0; g < MLP_GROUPS; g += 2 * width) c[a][g] = c[a][g] + c[a][g + width];
+    z[a] = c[a][0] + b2[a];
+  }
+}
+
+// weights wave-uniform (scalar loads), one row per lane
 template <int D, int A>
 __device__ __forceinline__ void mlp_forward_lane(const float *__restrict__ params, int H, const float (&x)[D],
                                                  float (&z)[A]) {
@@ -135,24 +155,42 @@ __device__ __forceinline__ void mlp_forward_lane(const float *__restrict__ param
   const float *__restrict__ b1 = W1 + H * D;
   const float *__restrict__ W2 = b1 + H;
   const float *__restrict__ b2 = W2 + A * H;
+  float c[A][MLP_GROUPS];
 #pragma unroll
-  for (int a = 0; a < A; ++a) z[a] = b2[a];
-  // the hidden units are independent of one another (only the A output chains are sequential in j): unrolling
-  // lets one wave keep several of the 5-deep fma chains in flight
-#pragma unroll 8
-  for (int j = 0; j < H; ++j) {
-    float acc = b1[j];
+  for (int a = 0; a < A; ++a)
 #pragma unroll
-    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(x[k], W1[j * D + k], acc);
-    float h = acc > 0.0f ? acc : 0.0f;
+    for (int g = 0; g < MLP_GROUPS; ++g) c[a][g] = 0.0f;
+  int j0 = 0;
+  for (; j0 + MLP_GROUPS <= H; j0 += MLP_GROUPS) {
 #pragma unroll
-    for (int a = 0; a < A; ++a) z[a] = __builtin_fmaf(h, W2[a * H + j], z[a]);
+    for (int g = 0; g < MLP_GROUPS; ++g) {
+      const int j = j0 + g;
+      float acc = b1[j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc = __builtin_fmaf(x[k], W1[j * D + k], acc);
+      const float h = acc > 0.0f ? acc : 0.0f;
+#pragma unroll
+      for (int a = 0; a < A; ++a) c[a][g] = __builtin_fmaf(h, W2[a * H + j], c[a][g]);
+    }
   }
+#pragma unroll
+  for (int g = 0; g < MLP_GROUPS; ++g) {  // hidden sizes that are not a multiple of 16
+    const int j = j0 + g;
+    if (j < H) {
+      float acc = b1[j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) acc = __builtin_fmaf(x[k], W1[j * D + k], acc);
+      const float h = acc > 0.0f ? acc : 0.0f;
+#pragma unroll
+      for (int a = 0; a < A; ++a) c[a][g] = __builtin_fmaf(h, W2[a * H + j], c[a][g]);
+    }
+  }
+  mlp_tree<A>(c, b2, z);
 }
 
 // The same forward with the parameters parked in LDS as one 8-float record per hidden unit {W1[j][0..D), pad, b1[j],
 // W2[0][j], W2[1][j]} (two 16-byte broadcast reads per unit instead of a stream of scalar loads); `pk` also holds b2
-// behind the H records.  Same chain order as mlp_forward_lane: the results are bit-identical.
+// behind the H records.
 template <int D>
 __device__ __forceinline__ void mlp_pack_lds(float *__restrict__ pk, const float *__restrict__ params, int H, int tid,
                                              int nthreads) {
@@ -175,24 +213,76 @@ __device__ __forceinline__ void mlp_pack_lds(float *__restrict__ pk, const float
   }
 }
 
+// NB hidden units j0, j0 + 1, ... from their LDS records, their layer-1 chains advancing side by side (NB independent
+// fma chains in flight, all records requested before the first use): relu and the units' terms of the output chains
+template <int D, int NB>
+__device__ __forceinline__ void mlp_units_lds(const float *__restrict__ pk, int j0, const float (&x)[D], float *c0,
+                                              float *c1) {
+  static_assert(D <= 5, "the packed record holds at most five input weights");
+  float4 lo[NB], hi[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    lo[u] = *reinterpret_cast<const float4 *>(pk + 8 * (j0 + u));
+    hi[u] = *reinterpret_cast<const float4 *>(pk + 8 * (j0 + u) + 4);
+  }
+  float acc[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) acc[u] = hi[u].y;
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const float w = k == 0 ? lo[u].x : k == 1 ? lo[u].y : k == 2 ? lo[u].z : k == 3 ? lo[u].w : hi[u].x;
+      acc[u] = __builtin_fmaf(x[k], w, acc[u]);
+    }
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const float h = acc[u] > 0.0f ? acc[u] : 0.0f;
+    c0[u] = __builtin_fmaf(h, hi[u].z, c0[u]);
+    c1[u] = __builtin_fmaf(h, hi[u].w, c1[u]);
+  }
+}
+
+// G cooperating threads per row (G = 1, 2, 4, 8, 16; the G threads of a row are G consecutive lanes, `g` = lane % G):
+// thread g owns the chains [g * 16 / G, (g + 1) * 16 / G), adds them by the tree's lower levels and meets its
+// neighbours through xor-shuffles for the upper ones; every thread of the row ends with the same z.
+template <int D, int G>
+__device__ __forceinline__ void mlp_forward_group_lds(const float *__restrict__ pk, int H, int g, const float (&x)[D],
+                                                      float (&z)[2]) {
+  constexpr int OWN = MLP_GROUPS / G;  // chains per thread
+  float c[2][OWN];
+#pragma unroll
+  for (int q = 0; q < OWN; ++q) c[0][q] = c[1][q] = 0.0f;
+  int j0 = 0;
+  constexpr int NB = OWN < 4 ? OWN : 4;  // units whose chains run side by side (eight measured slower)
+  for (; j0 + MLP_GROUPS <= H; j0 += MLP_GROUPS) {
+#pragma unroll
+    for (int q = 0; q < OWN; q += NB) mlp_units_lds<D, NB>(pk, j0 + g * OWN + q, x, &c[0][q], &c[1][q]);
+  }
+  if (j0 < H) {  // hidden sizes that are not a multiple of 16
+#pragma unroll
+    for (int q = 0; q < OWN; ++q) {
+      const int j = j0 + g * OWN + q;
+      if (j < H) mlp_units_lds<D, 1>(pk, j, x, &c[0][q], &c[1][q]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int width = 1; width < OWN; width *= 2)
+#pragma unroll
+      for (int q = 0; q < OWN; q += 2 * width) c[a][q] = c[a][q] + c[a][q + width];
+    float s = c[a][0];
+#pragma unroll
+    for (int m = 1; m < G; m *= 2) s = s + __shfl_xor(s, m, 64);  // a + b == b + a bit for bit: both partners agree
+    z[a] = s + pk[8 * H + a];
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void mlp_forward_lane_lds(const float *__restrict__ pk, int H, const float (&x)[D],
                                                      float (&z)[2]) {
-  static_assert(D <= 5, "the packed record holds at most five input weights");
-  z[0] = pk[8 * H];
-  z[1] = pk[8 * H + 1];
-#pragma unroll 8
-  for (int j = 0; j < H; ++j) {
-    const float4 lo = *reinterpret_cast<const float4 *>(pk + 8 * j);
-    const float4 hi = *reinterpret_cast<const float4 *>(pk + 8 * j + 4);
-    const float w[5] = {lo.x, lo.y, lo.z, lo.w, hi.x};
-    float acc = hi.y;
-#pragma unroll
-    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(x[k], w[k], acc);
-    const float h = acc > 0.0f ? acc : 0.0f;
-    z[0] = __builtin_fmaf(h, hi.z, z[0]);
-    z[1] = __builtin_fmaf(h, hi.w, z[1]);
-  }
+  mlp_forward_group_lds<D, 1>(pk, H, 0, x, z);
 }
 
 // Categorical::new: log_softmax (torch/distributions/categorical.rs:29-33)

@@ -2,6 +2,8 @@
 //
 // Layout: one env per lane, struct-of-arrays state in HBM, time-major trajectory planes so that every
 // global access of a wavefront is one contiguous 256-B (f32) / 64-B (u8) segment.
+#include <cstdlib>
+
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
@@ -62,8 +64,13 @@ __global__ void __launch_bounds__(256) k_env_step(CartPoleDev c, EnvStateDev st,
 // HBM traffic is the 26 B/step trajectory record (obs 20 + action 1 + reward 4 + flag 1) plus the sparse
 // interrupt successor observations.  The actor's uniform draw for global step t is word t of the lane's
 // ChaCha8 actor stream; a 16-word block is regenerated every 16 steps and parked in an LDS column that is
-// private to the lane (no bank conflicts: lanes are consecutive in the fastest dimension).
-template <int D, int BLOCK>
+// private to the thread (no bank conflicts: threads are consecutive in the fastest dimension).
+// A step is a chain of dependent work (features -> 128-unit MLP -> softmax -> sample -> f64 sincos + physics), so a
+// launch lasts T x the latency of one step whatever the lane count.  G threads per lane (G consecutive lanes of a wave)
+// share the MLP — each owns 16 / G of the output layer's sixteen partial chains (mlp_forward_group_lds) — and repeat the
+// cheap rest redundantly (a wavefront pays per instruction, not per active lane); thread 0 of the group stores.  The
+// host picks G so that the launch has up to two waves per SIMD: 16 at <= 8,192 lanes, 2 at 65,536.
+template <int D, int BLOCK, int G>
 __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvStateDev st, TrajDev tr,
                                                             const float *__restrict__ policy, int H,
                                                             uint64_t t_global) {
@@ -72,18 +79,24 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
   const uint32_t n = tr.n, T = tr.T;
   mlp_pack_lds<D>(pk, policy, H, threadIdx.x, BLOCK);
   __syncthreads();
-  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;  // no barrier is used below, early exit is safe
-  const uint64_t lane = c.lane_offset + i;
+  const uint32_t i = (blockIdx.x * BLOCK + threadIdx.x) / G;
+  const int g = threadIdx.x % G;
+  // lanes past the end follow lane n - 1 without storing: the group shuffles below need every lane of a group
+  const bool live = i < n;
+  const uint32_t il = live ? i : n - 1;
+  const bool writer = live && g == 0;
+  const uint64_t lane = c.lane_offset + il;
   LaneState s;
-  lane_load(st, i, s);
+  lane_load(st, il, s);
   const size_t plane = (size_t)(T + 1) * n;
   uint64_t cur_block = ~0ull;
   for (uint32_t t = 0; t < T; ++t) {
     float f[D];
     cp_features<D>(c, s, f);
+    if (writer) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)t * n + i] = f[d];
+      for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)t * n + il] = f[d];
+    }
     // actor draw
     uint64_t w = t_global + t;
     uint64_t blk = w >> 4;
@@ -96,26 +109,32 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
     }
     float u = rl_u32_to_unit_f32(actor_words[(uint32_t)(w & 15) * BLOCK + threadIdx.x]);
     float z[2], lp[2];
-    mlp_forward_lane_lds<D>(pk, H, f, z);
+    mlp_forward_group_lds<D, G>(pk, H, g, f, z);
     log_softmax_lane<2>(z, lp);
     int a = categorical_sample_lane<2>(lp, u);
     int succ = cp_step(c, s, a);
-    size_t o = (size_t)t * n + i;
-    tr.action[o] = (uint8_t)a;
-    tr.reward[o] = 1.0f;
-    tr.flag[o] = (uint8_t)succ;
+    size_t o = (size_t)t * n + il;
+    if (writer) {
+      tr.action[o] = (uint8_t)a;
+      tr.reward[o] = 1.0f;
+      tr.flag[o] = (uint8_t)succ;
+    }
     if (succ == RL_SUCC_INTERRUPT) {
       cp_features<D>(c, s, f);
+      if (writer) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * n + o] = f[d];
+        for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * n + o] = f[d];
+      }
     }
     if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, lane);
   }
   float f[D];
   cp_features<D>(c, s, f);
+  if (writer) {
 #pragma unroll
-  for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)T * n + i] = f[d];
-  lane_store(st, i, s);
+    for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)T * n + il] = f[d];
+    lane_store(st, il, s);
+  }
 }
 
 // ---------------------------------------------------------------- value forward over SoA rows
@@ -295,17 +314,37 @@ void launch_env_step(rl_env *env) {
                        env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs);
 }
 
+template <int D, int G>
+static void launch_rollout_g(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
+  constexpr int BLOCK = 64;  // one wave per workgroup: the workgroups spread over all CUs at every lane count
+  const uint32_t n = (uint32_t)env->cfg.n_lanes;
+  hipLaunchKernelGGL((k_rollout_cartpole<D, BLOCK, G>), dim3(cdiv((size_t)n * G, BLOCK)), dim3(BLOCK), 0,
+                     env->eng->stream, env->dev, env->st, traj->d, policy->d_params, (int)policy->hidden, env->t_global);
+}
+
 void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
-  uint32_t n = (uint32_t)env->cfg.n_lanes;
-  // 64-lane workgroups: N/64 workgroups spread over all 256 CUs even at N = 4096 (64 WGs) .. 65536 (1024 WGs)
-  constexpr int BLOCK = 64;
-  if (env->D == 5)
-    hipLaunchKernelGGL((k_rollout_cartpole<5, BLOCK>), dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream,
-                       env->dev, env->st, traj->d, policy->d_params, (int)policy->hidden, env->t_global);
-  else
-    hipLaunchKernelGGL((k_rollout_cartpole<4, BLOCK>), dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream,
-                       env->dev, env->st, traj->d, policy->d_params, (int)policy->hidden, env->t_global);
+  // threads per lane: up to two waves per SIMD (the launch is bound by the latency of a step, not by throughput).
+  // Measured, 128 steps, ms: 65,536 lanes 0.77 / 0.70 / 0.78 for G = 1 / 2 / 4; 16,384 lanes 0.42 / 0.41 / 0.51 for
+  // G = 4 / 8 / 16; 4,096 lanes 0.41 / 0.35 / 0.29 for G = 4 / 8 / 16 (profiles/r02_rollout_group_sweep.txt)
+  const uint64_t simds = 4ull * (uint64_t)env->eng->prop.multiProcessorCount, n = env->cfg.n_lanes;
+  int G = 1;
+  while (G < 16 && n * (uint64_t)(2 * G) <= 2 * simds * 64) G *= 2;
+  if (const char *o = std::getenv("RELEARN_ROLLOUT_G")) G = std::atoi(o);  // measurement override
+#define ROLL(DD)                                                   \
+  switch (G) {                                                     \
+    case 16: launch_rollout_g<DD, 16>(env, policy, traj); break;   \
+    case 8: launch_rollout_g<DD, 8>(env, policy, traj); break;     \
+    case 4: launch_rollout_g<DD, 4>(env, policy, traj); break;     \
+    case 2: launch_rollout_g<DD, 2>(env, policy, traj); break;     \
+    default: launch_rollout_g<DD, 1>(env, policy, traj); break;    \
+  }
+  if (env->D == 5) {
+    ROLL(5)
+  } else {
+    ROLL(4)
+  }
+#undef ROLL
 }
 
 void launch_values(rl_traj *traj, const rl_mlp *critic) {
