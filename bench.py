@@ -125,8 +125,12 @@ def main():
         if comm_kind == "rccl":
             # single-node job: RCCL's bootstrap sockets may use the loopback interface (the box may have no other)
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            ok, ids = 1, [None]
-            if rank == 0:
+            # 1. every rank checks that it can bind RCCL at all, and the job agrees on it BEFORE anyone enters the
+            #    collective ncclCommInitRank (a rank that failed here would leave its peers blocked in there)
+            can = torch.tensor([1 if ra.comm_available() else 0], dtype=torch.int32)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)
+            ok, ids = int(can.item()), [None]
+            if ok and rank == 0:
                 try:
                     ids = [ra.comm_unique_id()]
                 except ra.RelearnError as exc:
@@ -134,12 +138,22 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             if ids[0] is None:
                 ok = 0
-            else:
+            if ok:
+                # 2. the collective initialisation under a watchdog: a rank stuck in RCCL's bootstrap ends the job with
+                #    a non-zero exit (never a re-exec: this process has touched the GPU)
+                import threading
+                watchdog = threading.Timer(float(os.environ.get("RELEARN_COMM_INIT_TIMEOUT", "180")),
+                                           lambda: (print("bench.py: rank %d: ncclCommInitRank did not return" % rank,
+                                                          file=sys.stderr, flush=True), os._exit(3)))
+                watchdog.daemon = True
+                watchdog.start()
                 try:
                     eng.comm_init(rank, world, ids[0])
                 except ra.RelearnError as exc:
                     print("bench.py: rank %d: RCCL communicator not created (%s)" % (rank, exc), file=sys.stderr)
                     ok = 0
+                finally:
+                    watchdog.cancel()
             agreed = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)  # every rank takes the same path
             if int(agreed.item()) == 0:

@@ -112,6 +112,14 @@ int32_t rl_profile_read(rl_engine *engine, double *total_ms_out /*[RL_K_CLASS_CO
  * collective at all (threads + shared memory, src/simulation/train.rs:98-180); this replaces the
  * `Vec<buffer>` hand-off of train.rs:180.  `unique_id` is the 128-byte ncclUniqueId produced on
  * rank 0 and distributed by the caller (bench.py uses torch.distributed for that). */
+/* RL_OK when the collective library can be bound in this process (dlopen of the librccl next to the HIP runtime in
+ * use), RL_ERR_COMM otherwise.  Touches no GPU: every rank of a job calls it and the job agrees on the answer BEFORE
+ * any rank enters the collective rl_comm_init (a rank that cannot load RCCL must not leave its peers blocked there). */
+int32_t rl_comm_available(void);
+/* Which shared objects the collective runs on: the librccl this library bound (empty before it is bound) and the
+ * libamdhip64 this library is linked to — they must sit in the same directory (a host program may map a second copy of
+ * the ROCm libraries; a communicator of the other copy's RCCL cannot use this runtime's streams). */
+int32_t rl_comm_library_paths(char *rccl_out, size_t rccl_cap, char *hip_out, size_t hip_cap);
 int32_t rl_comm_unique_id(uint8_t id_out[128]);
 int32_t rl_comm_init(rl_engine *engine, int32_t rank, int32_t n_ranks, const uint8_t unique_id[128]);
 int32_t rl_comm_destroy(rl_engine *engine);

@@ -312,6 +312,9 @@ def _declare(L):
     L.oracle_tabular_q_new.restype = C.c_void_p
     L.oracle_tabular_q_free.argtypes = [C.c_void_p]
     L.oracle_tabular_q_step_update.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_uint64]
+    L.oracle_tabular_q_read.argtypes = [C.c_void_p, P(C.c_double), P(C.c_uint64)]
+    L.oracle_chain_step_draw.argtypes = [P(Chain), P(C.c_uint64), C.c_int, C.c_float, P(C.c_double)]
+    L.oracle_chain_step_draw.restype = C.c_int
     L.oracle_chain_tabular_q_train.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_double),
                                                P(C.c_uint64), P(C.c_uint64)]
     L.oracle_chain_tabular_q_eval.argtypes = [P(C.c_double), C.c_uint64, C.c_uint64, P(C.c_int32)]

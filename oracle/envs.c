@@ -117,7 +117,12 @@ void oracle_chain_default(oracle_chain *env) {
 }
 
 int oracle_chain_step(const oracle_chain *env, uint64_t *state, int action, oracle_prng *rng, double *reward) {
-  if (oracle_prng_gen_f32(rng) < 0.2f) action = !action; /* Move::invert */
+  return oracle_chain_step_draw(env, state, action, oracle_prng_gen_f32(rng), reward);
+}
+
+/* the same step with the slip draw `rng.gen::<f32>()` handed in (golden transition tables use recorded draws) */
+int oracle_chain_step_draw(const oracle_chain *env, uint64_t *state, int action, float draw, double *reward) {
+  if (draw < 0.2f) action = !action; /* Move::invert */
   if (action == 0) { /* Move::Left */
     *state = 0;
     *reward = 2.0;

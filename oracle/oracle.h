@@ -79,6 +79,7 @@ int oracle_cartpole_step(const oracle_cartpole *env, oracle_cartpole_state *s, i
 typedef struct { uint64_t size; double discount_factor; } oracle_chain;
 void oracle_chain_default(oracle_chain *env);
 int oracle_chain_step(const oracle_chain *env, uint64_t *state, int action, oracle_prng *rng, double *reward);
+int oracle_chain_step_draw(const oracle_chain *env, uint64_t *state, int action, float draw, double *reward);
 
 /* ---------------------------------------------------------------- MemoryGame (src/envs/memory.rs) */
 typedef struct { uint64_t num_actions, history_len; double discount_factor; } oracle_memory;
@@ -292,6 +293,7 @@ void oracle_tabular_q_free(oracle_tabular_q *q);
 int oracle_tabular_q_act(const oracle_tabular_q *q, uint64_t obs, int training, oracle_prng *rng);
 void oracle_tabular_q_step_update(oracle_tabular_q *q, uint64_t obs, uint64_t action, double reward, int next,
                                   uint64_t next_obs);
+void oracle_tabular_q_read(const oracle_tabular_q *q, double *values_out, uint64_t *counts_out);
 /* examples/chain-tabular-q.rs with `n_threads` workers run sequentially (results are independent of
  * thread interleaving because workers only share the immutable actor snapshot). */
 void oracle_chain_tabular_q_train(uint64_t seed, uint64_t n_threads, uint64_t n_periods, uint64_t min_worker_steps,

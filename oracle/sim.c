@@ -272,6 +272,11 @@ void oracle_tabular_q_step_update(oracle_tabular_q *q, uint64_t obs, uint64_t ac
   q->values[idx] += weight * value;
 }
 
+void oracle_tabular_q_read(const oracle_tabular_q *q, double *values_out, uint64_t *counts_out) {
+  if (values_out) memcpy(values_out, q->values, q->n_obs * q->n_act * sizeof(double));
+  if (counts_out) memcpy(counts_out, q->counts, q->n_obs * q->n_act * sizeof(uint64_t));
+}
+
 /* examples/chain-tabular-q.rs:12-45 through train_parallel (simulation/train.rs:68-186).
  *   rng = seed_from_u64(seed); env build / agent build draw nothing;
  *   rng_env = from_rng(rng); rng_agent = rng;

@@ -36,7 +36,7 @@ KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backwa
 ABI_SYMBOLS = [
     "rl_abi_version", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
     "rl_last_error", "rl_engine_info", "rl_engine_set_kernel_variant", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
-    "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy", "rl_comm_init_host",
+    "rl_comm_available", "rl_comm_library_paths", "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy", "rl_comm_init_host",
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
@@ -230,6 +230,18 @@ class Engine(_Handle):
         self._host_allreduce = HOST_ALLREDUCE_FN(thunk)  # keep the callback object alive
         _check(lib().rl_comm_init_host(self.h, C.c_int32(rank), C.c_int32(n_ranks), self._host_allreduce, None),
                self.h)
+
+
+def comm_available():
+    """can RCCL be bound in this process?  (no GPU touched; agree on it across ranks before comm_init)"""
+    return lib().rl_comm_available() == OK
+
+
+def comm_library_paths():
+    """(librccl bound by the library — '' before it is bound —, libamdhip64 the library runs on)"""
+    a, b = C.create_string_buffer(1024), C.create_string_buffer(1024)
+    _check(lib().rl_comm_library_paths(a, C.c_size_t(1024), b, C.c_size_t(1024)))
+    return a.value.decode(), b.value.decode()
 
 
 def comm_unique_id():

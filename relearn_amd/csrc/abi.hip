@@ -177,7 +177,12 @@ void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
     RL_HIP_CHECK(hipStreamSynchronize(e->stream));
     return;
   }
-  if (!e->comm) return;
+  if (!e->comm) {
+    // several ranks and nothing to exchange with: every update would scale by the global sample count while summing
+    // local samples only, and the replicas would drift apart silently
+    if (e->n_ranks > 1) throw RlError(RL_ERR_COMM, "engine has n_ranks > 1 but no collective (rl_comm_init failed?)");
+    return;
+  }
   ProfScope ps(e, RL_K_ALLREDUCE);
   // ncclFloat32 = 7, ncclSum = 0
   rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 7, 0, e->comm, e->stream), "ncclAllReduce");
@@ -322,6 +327,29 @@ int32_t rl_profile_read(rl_engine *e, double *total_ms_out, uint64_t *launches_o
 }
 
 // ---------------------------------------------------------------- comm
+int32_t rl_comm_available(void) {
+  return guarded(nullptr, [&] {
+    if (std::getenv("RELEARN_LOOPBACK_COMM")) return;
+    rccl_load();
+  });
+}
+
+int32_t rl_comm_library_paths(char *rccl_out, size_t rccl_cap, char *hip_out, size_t hip_cap) {
+  return guarded(nullptr, [&] {
+    Dl_info info;
+    if (rccl_out && rccl_cap) {
+      rccl_out[0] = 0;
+      if (g_rccl.AllReduce && dladdr((void *)g_rccl.AllReduce, &info) != 0 && info.dli_fname)
+        std::snprintf(rccl_out, rccl_cap, "%s", info.dli_fname);
+    }
+    if (hip_out && hip_cap) {
+      hip_out[0] = 0;
+      if (dladdr((void *)&hipGetDeviceCount, &info) != 0 && info.dli_fname)
+        std::snprintf(hip_out, hip_cap, "%s", info.dli_fname);
+    }
+  });
+}
+
 int32_t rl_comm_unique_id(uint8_t id_out[128]) {
   return guarded(nullptr, [&] {
     RL_REQUIRE(id_out, "id_out is NULL");
@@ -342,8 +370,7 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
     RL_REQUIRE(e && unique_id, "NULL argument");
     RL_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
     RL_REQUIRE(!e->has_collective(), "communicator already initialised");
-    e->rank = rank;
-    e->n_ranks = n_ranks;
+    // rank / n_ranks are set only once the collective exists: a failed initialisation leaves a one-rank engine
     // a single rank needs no communicator; RELEARN_FORCE_RCCL=1 creates a 1-rank one anyway so that the whole
     // RCCL call path (dlopen, ncclCommInitRank, ncclAllReduce on the engine stream) can be exercised on one GPU
     if (std::getenv("RELEARN_LOOPBACK_COMM")) {
@@ -361,6 +388,8 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
       RL_REQUIRE(grp->n_ranks == n_ranks, "loopback group: inconsistent n_ranks");
       grp->joined += 1;
       e->loopback = grp.get();
+      e->rank = rank;
+      e->n_ranks = n_ranks;
       return;
     }
     if (n_ranks == 1 && !std::getenv("RELEARN_FORCE_RCCL")) return;
@@ -369,7 +398,11 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
     UniqueId id;
     std::memcpy(id.bytes, unique_id, 128);
     comm_init_rank_t init = (comm_init_rank_t)(void *)g_rccl.CommInitRank;
-    rccl_check(init(&e->comm, n_ranks, id, rank), "ncclCommInitRank");
+    void *comm = nullptr;
+    rccl_check(init(&comm, n_ranks, id, rank), "ncclCommInitRank");
+    e->comm = comm;
+    e->rank = rank;
+    e->n_ranks = n_ranks;
   });
 }
 

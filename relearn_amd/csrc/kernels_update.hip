@@ -513,24 +513,21 @@ __global__ void __launch_bounds__(SB) k_ls_finalize(float *__restrict__ params, 
     for (uint32_t i = threadIdx.x; i < P; i += SB) params[i] = prev[i];
 }
 
-// torch::optim::Adam::step of libtorch 1.12 (third party; COptimizer::adam, coptimizer.rs:158-167)
+// torch::optim::Adam::step of libtorch 1.12 (third party; COptimizer::adam, coptimizer.rs:158-167).  The bias
+// corrections come from the host, which tracks the step count (rl_adam.host_step): neg_step_size = -(float)(lr /
+// (1 - beta1^step)), sqrt_bc2 = (float)sqrt(1 - beta2^step) — the same numbers for this kernel and for k_reduce_adam.
 __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, const float *__restrict__ grad,
                                                   float *__restrict__ m, float *__restrict__ v, uint64_t *step_ptr,
-                                                  uint32_t P, double lr, double beta1, double beta2, double eps,
-                                                  double weight_decay, const float *__restrict__ loss_sum,
-                                                  double inv_B, float *__restrict__ loss_out) {
-  uint64_t step = *step_ptr + 1;
-  __syncthreads();
+                                                  uint32_t P, uint64_t step, float neg_step_size, float sqrt_bc2,
+                                                  double beta1, double beta2, double eps, double weight_decay,
+                                                  const float *__restrict__ loss_sum, double inv_B,
+                                                  float *__restrict__ loss_out) {
   if (threadIdx.x == 0) {
     *step_ptr = step;
     if (loss_out) *loss_out = (float)((double)(*loss_sum) * inv_B);
   }
-  double bc1 = 1.0 - pow(beta1, (double)step);
-  double bc2 = 1.0 - pow(beta2, (double)step);
   float b1 = (float)beta1, b2 = (float)beta2;
   float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
-  float sqrt_bc2 = (float)sqrt(bc2);
-  float neg_step_size = -(float)(lr / bc1);
   float epsf = (float)eps;
   float wd = (float)weight_decay;
   for (uint32_t i = threadIdx.x; i < P; i += SB) {
@@ -702,15 +699,21 @@ void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept
                      (uint32_t)policy->P, max_kl, accept_violation, traj->trpo);
 }
 
+// bias corrections of the optimiser's NEXT step (advances the host's step count)
+static void adam_next_step(rl_adam *opt, float *neg_step_size, float *sqrt_bc2) {
+  opt->host_step += 1;
+  const double bc1 = 1.0 - std::pow(opt->cfg.beta1, (double)opt->host_step);
+  const double bc2 = 1.0 - std::pow(opt->cfg.beta2, (double)opt->host_step);
+  *neg_step_size = -(float)(opt->cfg.learning_rate / bc1);
+  *sqrt_bc2 = (float)std::sqrt(bc2);
+}
+
 void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t rowsB, int loss_slot,
                         uint64_t B_total) {
   ProfScope ps(traj->eng, RL_K_REDUCE);
   uint32_t P = (uint32_t)opt->mod->P;
-  opt->host_step += 1;
-  // bias corrections on the host, with the arithmetic of k_adam_step (which has to read the step from the device)
-  const double bc1 = 1.0 - std::pow(opt->cfg.beta1, (double)opt->host_step);
-  const double bc2 = 1.0 - std::pow(opt->cfg.beta2, (double)opt->host_step);
-  const float neg_step_size = -(float)(opt->cfg.learning_rate / bc1), sqrt_bc2 = (float)std::sqrt(bc2);
+  float neg_step_size, sqrt_bc2;
+  adam_next_step(opt, &neg_step_size, &sqrt_bc2);
   hipLaunchKernelGGL(k_reduce_adam, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
                      traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                      opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
@@ -719,20 +722,22 @@ void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t ro
 }
 
 void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_total) {
-  opt->host_step += 1;
   ProfScope ps(traj->eng, RL_K_SMALL);
   uint32_t P = (uint32_t)opt->mod->P;
+  float neg_step_size, sqrt_bc2;
+  adam_next_step(opt, &neg_step_size, &sqrt_bc2);
   hipLaunchKernelGGL(k_adam_step, dim3(1), dim3(SB), 0, traj->eng->stream, opt->mod->d_params, traj->vec, opt->d_m,
-                     opt->d_v, opt->d_step, P, opt->cfg.learning_rate, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
-                     opt->cfg.weight_decay, traj->vec + P, 1.0 / (double)B_total,
+                     opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
+                     opt->cfg.eps, opt->cfg.weight_decay, traj->vec + P, 1.0 / (double)B_total,
                      loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr);
 }
 
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
-  opt->host_step += 1;
   ProfScope ps(opt->mod->eng, RL_K_SMALL);
   uint32_t P = (uint32_t)opt->mod->P;
+  float neg_step_size, sqrt_bc2;
+  adam_next_step(opt, &neg_step_size, &sqrt_bc2);
   hipLaunchKernelGGL(k_adam_step, dim3(1), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
-                     opt->d_v, opt->d_step, P, opt->cfg.learning_rate, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
-                     opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr);
+                     opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
+                     opt->cfg.eps, opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr);
 }

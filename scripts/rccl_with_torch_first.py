@@ -22,4 +22,5 @@ st = ra.trpo_update(pol, traj)
 cs = ra.critic_update(cri, ra.Adam(cri), traj, 3)
 maps = sorted({l.split()[-1] for l in open("/proc/self/maps") if any(k in l for k in ("amdhip64", "librccl", "hsa-runtime"))})
 print(order, "OK trpo", st.status, "critic", cs.loss_last)
+print("BOUND rccl=%s hip=%s" % ra.comm_library_paths())
 print("\n".join(maps))

@@ -206,8 +206,8 @@ def test_rccl_is_bound_next_to_the_hip_runtime_in_use(order):
         raise AssertionError("rccl_with_torch_first.py %s did not finish within 280 s" % order)
     text = out.decode()
     assert proc.returncode == 0 and ("%s OK trpo 0" % order) in text, text[-1500:]
-    hip = [l for l in text.splitlines() if "libamdhip64" in l]
-    rccl = [l for l in text.splitlines() if l.startswith("Librccl path")]
-    assert rccl and any(os.path.dirname(rccl[0].split(":", 1)[1].strip()) == os.path.dirname(h.strip()) or
-                        os.path.realpath(os.path.dirname(rccl[0].split(":", 1)[1].strip())) ==
-                        os.path.realpath(os.path.dirname(h.strip())) for h in hip), (rccl, hip)
+    # the librccl the library bound (dladdr of its ncclAllReduce) sits next to the libamdhip64 the library runs on
+    bound = [l for l in text.splitlines() if l.startswith("BOUND ")]
+    assert bound, text[-1500:]
+    rccl, hip = (kv.split("=", 1)[1] for kv in bound[0].split()[1:3])
+    assert rccl and hip and os.path.realpath(os.path.dirname(rccl)) == os.path.realpath(os.path.dirname(hip)), bound

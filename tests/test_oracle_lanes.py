@@ -135,8 +135,14 @@ def test_chain_tabular_q_plumbing_config():
     assert total / 10000 > 3.0  # optimal policy earns ~3.6 per step with slip 0.2; greedy-left earns 2.0
     # step_update restated (tabular.rs:159-180): 1/n step size
     t = L.oracle_tabular_q_new(2, 2, 0.5, 0.0)
+    vals, cnts = np.zeros((2, 2), np.float64), np.zeros((2, 2), np.uint64)
     L.oracle_tabular_q_step_update(t, 0, 1, 4.0, O.TERMINATE, 0)
+    L.oracle_tabular_q_read(t, O.f64p(vals), O.u64p(cnts))
+    assert vals[0, 1] == 4.0 and cnts[0, 1] == 1  # first visit: weight 1
     L.oracle_tabular_q_step_update(t, 0, 1, 2.0, O.TERMINATE, 0)
+    L.oracle_tabular_q_read(t, O.f64p(vals), O.u64p(cnts))
+    assert vals[0, 1] == 3.0 and cnts[0, 1] == 2  # second visit: the running mean of 4 and 2
+    assert np.count_nonzero(vals) == 1
     L.oracle_tabular_q_free(t)
 
 
