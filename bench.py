@@ -41,9 +41,11 @@ def parse_args():
     ap.add_argument("--critic-steps", type=int, default=80)
     ap.add_argument("--max-episode-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", choices=("rccl", "gloo"), default=os.environ.get("RELEARN_BENCH_COMM", "rccl"),
-                    help="data-plane collective for N > 1: RCCL on the engine stream (default), or the host-staged "
-                         "fallback over the gloo control group (also taken when RCCL cannot be initialised)")
+    ap.add_argument("--comm", choices=("rccl", "ipc", "gloo"), default=os.environ.get("RELEARN_BENCH_COMM", "rccl"),
+                    help="data-plane collective for N > 1: RCCL on the engine stream (default); `ipc` = the library's "
+                         "single-launch all-reduce over peer-mapped mailboxes (self-tested at start-up, RCCL if the test "
+                         "fails); `gloo` = the host-staged fallback over the control group (also taken when RCCL cannot "
+                         "be initialised)")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="do not wrap launches in HIP events inside the timed region")
     ap.add_argument("--profile-steps", type=int, default=1,
@@ -81,6 +83,7 @@ def cpu_baseline(args):
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
+        "build": "gcc -O3 -ffp-contract=off -mavx2 -mfma -fopenmp (oracle/Makefile)",
         "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes), then single-threaded "
                   "GAE + TRPO + %d Adam steps; rollout %.2f s, update %.2f s" % (
                       cores, per_thread, steps, int(st.episodes), args.critic_steps,
@@ -122,6 +125,34 @@ def main():
     comm_kind = "none"
     if world > 1:
         comm_kind = args.comm
+        if comm_kind == "ipc":
+            # peer-mailbox transport: exchange the mailbox handles over the control group, map, and let every rank run
+            # the library's self-test; the job uses it only if ALL ranks pass (else RCCL, then gloo)
+            ok = 1
+            try:
+                mine = eng.comm_ipc_handle(world)
+            except ra.RelearnError as exc:
+                print("bench.py: rank %d: no mailbox (%s)" % (rank, exc), file=sys.stderr)
+                mine, ok = None, 0
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            if ok and all(h is not None for h in handles):
+                try:
+                    eng.comm_init_ipc(rank, world, handles)
+                    eng.comm_selftest()
+                except ra.RelearnError as exc:
+                    print("bench.py: rank %d: peer-mailbox collective unusable (%s)" % (rank, exc), file=sys.stderr)
+                    ok = 0
+            else:
+                ok = 0
+            agreed = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0:
+                dist.barrier()
+                eng.comm_destroy()
+                comm_kind = "rccl"
+                if rank == 0:
+                    print("bench.py: peer-mailbox collective not available on every rank, using RCCL", file=sys.stderr)
         if comm_kind == "rccl":
             # single-node job: RCCL's bootstrap sockets may use the loopback interface (the box may have no other)
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -335,6 +366,7 @@ def main():
                 "n_envs_total": args.envs, "n_envs_per_gpu": n_local, "horizon": T, "hidden": H,
                 "critic_steps": args.critic_steps,
                 "parallelism": "env-sharded x%d + %s" % (world, {"none": "no collective (one rank)", "rccl": "RCCL all-reduce",
+                                                               "ipc": "single-launch all-reduce over peer-mapped mailboxes",
                                                                "gloo": "host-staged all-reduce over gloo (fallback)"}[comm_kind]),
             },
             "roofline": roofline,

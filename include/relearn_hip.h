@@ -123,6 +123,18 @@ int32_t rl_comm_library_paths(char *rccl_out, size_t rccl_cap, char *hip_out, si
 int32_t rl_comm_unique_id(uint8_t id_out[128]);
 int32_t rl_comm_init(rl_engine *engine, int32_t rank, int32_t n_ranks, const uint8_t unique_id[128]);
 int32_t rl_comm_destroy(rl_engine *engine);
+/* Peer-mailbox transport for the same all-reduce (ranks = processes of ONE node): every rank owns a mailbox in its HBM,
+ * exports it (rl_comm_ipc_handle: a 64-byte hipIpcMemHandle; n_ranks <= 16), the caller gathers the handles of all ranks
+ * in rank order and hands them to rl_comm_init_ipc, which maps the peers' mailboxes.  An all-reduce is then ONE kernel
+ * per rank: publish into every peer's mailbox, wait for every peer's sequence number (bounded), add the rows in rank
+ * order — bit-identical replicas, no broadcast.  Vectors of <= 2048 floats (the feed-forward updates; recurrent modules
+ * keep RCCL).  A peer that never arrives makes the next synchronising call return RL_ERR_COMM.  Undone by
+ * rl_comm_destroy (all ranks, after a barrier of their own). */
+int32_t rl_comm_ipc_handle(rl_engine *engine, int32_t n_ranks, uint8_t handle_out[64]);
+int32_t rl_comm_init_ipc(rl_engine *engine, int32_t rank, int32_t n_ranks, const uint8_t *handles /* [n_ranks][64] */);
+/* Three all-reduces of known vectors through whatever collective is installed; RL_ERR_COMM when a sum is wrong or a
+ * peer does not arrive.  Collective: every rank calls it.  Lets a job agree that a transport works before relying on it. */
+int32_t rl_comm_selftest(rl_engine *engine);
 /* Host-staged collective for machines (or tests) without a usable RCCL communicator: for every all-reduce the library
  * copies the vector to the host, calls `fn(ctx, buf, count)` — which must sum `buf` element-wise over all ranks in place
  * (a gloo / MPI all-reduce, for instance) and return 0 — and copies the result back.  Same arithmetic contract as

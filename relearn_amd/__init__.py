@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "rl_abi_version", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
     "rl_last_error", "rl_engine_info", "rl_engine_set_kernel_variant", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
     "rl_comm_available", "rl_comm_library_paths", "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy", "rl_comm_init_host",
+    "rl_comm_ipc_handle", "rl_comm_init_ipc", "rl_comm_selftest",
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
@@ -211,6 +212,22 @@ class Engine(_Handle):
     def comm_init(self, rank, n_ranks, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         _check(lib().rl_comm_init(self.h, C.c_int32(rank), C.c_int32(n_ranks), buf), self.h)
+
+    def comm_ipc_handle(self, n_ranks):
+        """this rank's mailbox for the peer-mailbox collective, as 64 bytes to hand to the other ranks"""
+        buf = (C.c_uint8 * 64)()
+        _check(lib().rl_comm_ipc_handle(self.h, C.c_int32(n_ranks), buf), self.h)
+        return bytes(buf)
+
+    def comm_init_ipc(self, rank, n_ranks, handles):
+        """`handles`: the comm_ipc_handle() bytes of all ranks, in rank order"""
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == 64 * n_ranks
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(lib().rl_comm_init_ipc(self.h, C.c_int32(rank), C.c_int32(n_ranks), buf), self.h)
+
+    def comm_selftest(self):
+        _check(lib().rl_comm_selftest(self.h), self.h)
 
     def comm_destroy(self):
         _check(lib().rl_comm_destroy(self.h), self.h)

@@ -159,6 +159,14 @@ static void loopback_allreduce(rl_engine *e, float *d_buf, size_t count) {
 }
 
 void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
+  if (e->ipc_active) {
+    if (!ipc_allreduce_fits(e, count))
+      throw RlError(RL_ERR_UNSUPPORTED, "the peer-mailbox collective carries vectors of <= 2048 floats (feed-forward "
+                                        "modules); use the RCCL transport for larger ones");
+    ProfScope ps(e, RL_K_ALLREDUCE);
+    ipc_allreduce(e, d_buf, count);
+    return;
+  }
   if (e->loopback) {
     ProfScope ps(e, RL_K_ALLREDUCE);
     loopback_allreduce(e, d_buf, count);
@@ -246,6 +254,7 @@ static void engine_teardown(rl_engine *e) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
   if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+  ipc_teardown(e);
   prof_drain(e);
   for (auto ev : e->prof_event_pool) (void)hipEventDestroy(ev);
   if (e->pinned) (void)hipHostFree(e->pinned);
@@ -262,6 +271,7 @@ int32_t rl_engine_sync(rl_engine *e) {
     // also drain anything a collective library queued on streams of its own
     RL_HIP_CHECK(hipSetDevice(e->device));
     RL_HIP_CHECK(hipDeviceSynchronize());
+    ipc_check(e);
   });
 }
 
@@ -418,6 +428,32 @@ int32_t rl_comm_init_host(rl_engine *e, int32_t rank, int32_t n_ranks, rl_host_a
   });
 }
 
+int32_t rl_comm_selftest(rl_engine *e) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    const uint32_t count = 1030;  // the longest vector of the feed-forward updates
+    std::vector<float> h(count);
+    float *d = dalloc<float>(count);
+    try {
+      for (int round = 0; round < 3; ++round) {
+        for (uint32_t i = 0; i < count; ++i) h[i] = (float)((e->rank + 1) * (int)(i % 7 + 1 + round));
+        h2d(e, d, h.data(), count * sizeof(float));
+        rl_allreduce_sum_f32(e, d, count);
+        d2h(e, h.data(), d, count * sizeof(float));
+        ipc_check(e);
+        const int tri = e->n_ranks * (e->n_ranks + 1) / 2;
+        for (uint32_t i = 0; i < count; ++i)
+          if (h[i] != (float)(tri * (int)(i % 7 + 1 + round)))
+            throw RlError(RL_ERR_COMM, "collective self-test: wrong sum at element " + std::to_string(i));
+      }
+    } catch (...) {
+      dfree(d);
+      throw;
+    }
+    dfree(d);
+  });
+}
+
 int32_t rl_comm_destroy(rl_engine *e) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
@@ -429,6 +465,11 @@ int32_t rl_comm_destroy(rl_engine *e) {
       e->comm = nullptr;
     }
     e->loopback = nullptr;  // groups live for the life of the process (test facility)
+    if (e->ipc_box) {
+      sync(e);
+      ipc_teardown(e);
+    }
+    e->ipc_active = false;
     e->rank = 0;
     e->n_ranks = 1;
   });

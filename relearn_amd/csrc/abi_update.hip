@@ -146,6 +146,7 @@ int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg,
     launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
     TrpoStateDev h;
     d2h(e, &h, traj->trpo, sizeof(h));
+    ipc_check(e);
     stats->entropy = (double)h.entropy;
     stats->step_size = h.step_size;
     stats->loss_initial = (double)h.loss0;
@@ -307,7 +308,12 @@ static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64
                              float *losses_out) {
   RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
   uint64_t Bt = b_total(traj);
-  const bool fused = critic->kind == RL_MODULE_MLP && !traj->eng->has_collective();
+  // no separate all-reduce between the reduction and the (elementwise) optimiser step: one rank, or the peer-mailbox
+  // transport, whose exchange runs inside the reduction launch
+  const rl_engine *eng = traj->eng;
+  const bool mailbox = eng->ipc_active && !eng->comm && !eng->loopback && !eng->host_allreduce &&
+                       ipc_allreduce_fits(eng, critic->P + 4);
+  const bool fused = critic->kind == RL_MODULE_MLP && (!eng->has_collective() || mailbox);
   for (uint64_t k = 0; k < opt_steps; ++k) {
     if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
       uint32_t rowsA, rowsB;
@@ -321,6 +327,7 @@ static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64
   if (stats || losses_out) {
     std::vector<float> h(opt_steps ? opt_steps : 1);
     if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
+    ipc_check(traj->eng);
     if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
     if (stats) {
       stats->steps = opt_steps;

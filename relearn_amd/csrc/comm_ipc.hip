@@ -1,0 +1,119 @@
+// comm_ipc.hip — a single-launch all-reduce for the <= 8 KiB vectors of the update (gradients, Fisher-vector products,
+// line-search scalars) over peer-mapped mailboxes: every rank owns a mailbox in its own HBM, maps the mailboxes of its
+// peers (hipIpcOpenMemHandle: the ranks are processes of one node; over xGMI the mapping is a peer-to-peer window), and
+// an all-reduce is ONE kernel per rank —
+//   publish   my 64-column chunk of the vector goes into slot `seq & 1` of MY row in EVERY rank's mailbox (plain stores
+//             into the peer windows), then one release store of the sequence number per (peer, chunk);
+//   wait      until the sequence number has arrived from every rank for my chunk (bounded spin, acquire loads);
+//   sum       the n_ranks rows of my own mailbox in RANK ORDER — every rank adds the same numbers in the same order, so
+//             the replicas stay bit-identical without a broadcast.
+// Two slots are enough: a rank cannot start collective k + 2 (which reuses the slot of k) before it has seen every
+// peer's flag of k + 1, and a peer raises that flag only after it has finished reading k.
+// This replaces the `Vec<buffer>` hand-off of the reference's threads (src/simulation/train.rs:180) for the multi-GPU
+// configuration; RCCL (abi.hip) stays the default transport — its small-message latency is what this path avoids.
+// Every spin is bounded: a peer that never arrives sets the engine's error word and the wave leaves the loop.
+#include "abi_internal.hpp"
+#include "comm_ipc.hpp"
+
+namespace {
+
+// one workgroup (one wave) per 64-column chunk
+__global__ void __launch_bounds__(IPC_CHUNK) k_ipc_allreduce(float *__restrict__ vec, uint32_t count, IpcPeers peers) {
+  const uint32_t chunk = blockIdx.x, p = chunk * IPC_CHUNK + threadIdx.x;
+  const float mine = p < count ? vec[p] : 0.0f;
+  const float s = ipc_exchange_chunk(peers, chunk, threadIdx.x, mine);
+  if (p < count) vec[p] = s;
+}
+
+}  // namespace
+
+bool ipc_allreduce_fits(const rl_engine *e, size_t count) { return e->ipc_box != nullptr && count <= IPC_CAP; }
+
+void ipc_allreduce(rl_engine *e, float *d_buf, size_t count) {
+  const IpcPeers peers = ipc_peers_next(e);
+  hipLaunchKernelGGL(k_ipc_allreduce, dim3((unsigned)((count + IPC_CHUNK - 1) / IPC_CHUNK)), dim3(IPC_CHUNK), 0,
+                     e->stream, d_buf, (uint32_t)count, peers);
+}
+
+void ipc_check(rl_engine *e) {
+  if (e->ipc_box == nullptr) return;
+  int32_t err = 0;
+  d2h(e, &err, e->ipc_err, sizeof(err));
+  if (err != 0)
+    throw RlError(RL_ERR_COMM, "peer-mailbox all-reduce: rank " + std::to_string(err - 1) + " never arrived");
+}
+
+void ipc_teardown(rl_engine *e) {
+  for (int r = 0; r < RL_IPC_MAX_RANKS; ++r) {
+    if (e->ipc_peer[r] != nullptr && r != e->ipc_rank_of_box) (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
+    e->ipc_peer[r] = nullptr;
+  }
+  if (e->ipc_box) (void)hipFree(e->ipc_box);
+  if (e->ipc_err) (void)hipFree(e->ipc_err);
+  e->ipc_box = nullptr;
+  e->ipc_err = nullptr;
+  e->ipc_seq = 0;
+}
+
+extern "C" {
+
+int32_t rl_comm_ipc_handle(rl_engine *e, int32_t n_ranks, uint8_t handle_out[64]) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && handle_out, "NULL argument");
+    RL_REQUIRE(n_ranks >= 1 && n_ranks <= RL_IPC_MAX_RANKS, "n_ranks out of range for the mailbox collective");
+    RL_REQUIRE(!e->has_collective(), "communicator already initialised");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    if (e->ipc_box == nullptr) {
+      const size_t bytes = ipc_box_words((uint32_t)n_ranks) * sizeof(float);
+      void *p = nullptr;
+      // fine-grained: peers' stores and this device's loads of the mailbox are coherent without cache maintenance
+      RL_HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+      e->ipc_box = (float *)p;
+      e->ipc_box_ranks = n_ranks;
+      RL_HIP_CHECK(hipMemsetAsync(p, 0, bytes, e->stream));
+      e->ipc_err = dalloc<int32_t>(1);
+      RL_HIP_CHECK(hipMemsetAsync(e->ipc_err, 0, sizeof(int32_t), e->stream));
+      sync(e);
+    }
+    RL_REQUIRE(e->ipc_box_ranks == n_ranks, "the mailbox was sized for another number of ranks");
+    hipIpcMemHandle_t h;
+    RL_HIP_CHECK(hipIpcGetMemHandle(&h, e->ipc_box));
+    std::memcpy(handle_out, &h, 64);
+  });
+}
+
+int32_t rl_comm_init_ipc(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t *handles) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e && handles, "NULL argument");
+    RL_REQUIRE(n_ranks >= 1 && n_ranks <= RL_IPC_MAX_RANKS && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
+    RL_REQUIRE(!e->has_collective(), "communicator already initialised");
+    RL_REQUIRE(e->ipc_box != nullptr && e->ipc_box_ranks == n_ranks, "call rl_comm_ipc_handle first (same n_ranks)");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    try {
+      for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) {
+          e->ipc_peer[r] = e->ipc_box;
+          continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * 64, 64);
+        void *p = nullptr;
+        RL_HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        e->ipc_peer[r] = (float *)p;
+      }
+    } catch (...) {
+      for (int r = 0; r < n_ranks; ++r) {
+        if (r != rank && e->ipc_peer[r]) (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
+        e->ipc_peer[r] = nullptr;
+      }
+      throw;
+    }
+    e->ipc_rank_of_box = rank;
+    e->ipc_active = true;
+    e->rank = rank;
+    e->n_ranks = n_ranks;
+  });
+}
+
+}  // extern "C"

@@ -104,6 +104,8 @@ struct TrpoStateDev {
 struct RcclApi;  // dlopen'ed entry points (comm.cpp)
 struct LoopbackGroup;
 
+constexpr int RL_IPC_MAX_RANKS = 16;
+
 struct rl_engine {
   int device = -1;
   hipStream_t stream = nullptr;
@@ -122,8 +124,18 @@ struct rl_engine {
   rl_host_allreduce_fn host_allreduce = nullptr;  // host-staged collective (rl_comm_init_host)
   void *host_allreduce_ctx = nullptr;
   std::vector<float> host_allreduce_buf;
+  // peer-mailbox collective (comm_ipc.hip): own mailbox (fine-grained HBM), the peers' mailboxes mapped through IPC
+  // handles, the sequence number of the last collective, a device word a timed-out wait sets
+  float *ipc_box = nullptr;
+  float *ipc_peer[RL_IPC_MAX_RANKS] = {nullptr};
+  int32_t *ipc_err = nullptr;
+  uint32_t ipc_seq = 0;
+  int ipc_box_ranks = 0, ipc_rank_of_box = -1;
+  bool ipc_active = false;
   // any collective between a reduction and its consumer?  (false: the two may be fused into one launch)
-  bool has_collective() const { return comm != nullptr || loopback != nullptr || host_allreduce != nullptr; }
+  bool has_collective() const {
+    return comm != nullptr || loopback != nullptr || host_allreduce != nullptr || ipc_active;
+  }
   int rank = 0, n_ranks = 1;
   // host pinned scratch for small readbacks
   void *pinned = nullptr;
@@ -232,5 +244,10 @@ struct ProfScope {
   ~ProfScope();
 };
 
-// comm.cpp
+// abi.hip
 void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count);
+// comm_ipc.hip
+bool ipc_allreduce_fits(const rl_engine *e, size_t count);
+void ipc_allreduce(rl_engine *e, float *d_buf, size_t count);
+void ipc_check(rl_engine *e);  // throws RL_ERR_COMM when a wait of an earlier collective timed out
+void ipc_teardown(rl_engine *e);

@@ -14,6 +14,7 @@
 // Reference semantics followed: src/torch/agents/policies/trpo.rs:97-164,
 // src/torch/optimizers/conjugate_gradient.rs:115-403, src/torch/distributions/categorical.rs:29-77,
 // src/torch/agents/critics/opt.rs:100-126, src/torch/optimizers/coptimizer.rs:13-26.
+#include "comm_ipc.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
@@ -545,6 +546,10 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
 // k_reduce followed by the Adam update of the 64 entries each workgroup has just reduced (Adam is elementwise, so
 // no second launch is needed when no all-reduce sits between the two: single-rank runs).  Same arithmetic as
 // k_reduce + k_adam_step; `step` is the 1-based step index, tracked by the host.
+// XCHG: with several ranks on the peer-mailbox transport, wave 0 exchanges the 64 reduced columns of the workgroup (one
+// chunk of the collective, comm_ipc.hpp) between the reduction and the optimiser step — the multi-rank critic loop stays
+// at two launches per step
+template <bool XCHG>
 __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__ slabA, uint32_t nbA, uint32_t P,
                                                       const double *__restrict__ slabB, uint32_t nbB,
                                                       float *__restrict__ vec, float *__restrict__ params,
@@ -552,7 +557,7 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
                                                       uint64_t *step_ptr, uint64_t step, float neg_step_size,
                                                       float sqrt_bc2, double beta1, double beta2, double eps,
                                                       double weight_decay, double inv_B,
-                                                      float *__restrict__ loss_out) {
+                                                      float *__restrict__ loss_out, IpcPeers peers) {
   __shared__ double part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 64 + lane;
@@ -568,11 +573,13 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
   else if (p < P + 4) acc = column_partial(slabB, nbB, 4, p - P, w);
   part[w][lane] = acc;
   __syncthreads();
-  if (w != 0 || p >= P + 4) return;
+  if (w != 0) return;
   double t = part[0][lane];
 #pragma unroll
   for (int k = 1; k < 16; ++k) t = t + part[k][lane];
-  const float gsum = (float)t;
+  float gsum = (float)t;
+  if (XCHG) gsum = ipc_exchange_chunk(peers, blockIdx.x, (uint32_t)lane, p < P + 4 ? gsum : 0.0f);  // all 64 lanes
+  if (p >= P + 4) return;
   vec[p] = gsum;
   if (p == 0) *step_ptr = step;
   if (p >= P) {
@@ -714,11 +721,21 @@ void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t ro
   uint32_t P = (uint32_t)opt->mod->P;
   float neg_step_size, sqrt_bc2;
   adam_next_step(opt, &neg_step_size, &sqrt_bc2);
-  hipLaunchKernelGGL(k_reduce_adam, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
-                     traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
-                     opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
-                     opt->cfg.weight_decay, 1.0 / (double)B_total,
-                     loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr);
+  rl_engine *e = traj->eng;
+  float *loss_out = loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr;
+  if (e->ipc_active) {
+    ProfScope pa(e, RL_K_ALLREDUCE);  // counted as a collective as well: the exchange runs inside this launch
+    const IpcPeers peers = ipc_peers_next(e);
+    hipLaunchKernelGGL(k_reduce_adam<true>, dim3(cdiv(P + 4, 64)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
+                       traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
+                       opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
+                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, peers);
+  } else {
+    hipLaunchKernelGGL(k_reduce_adam<false>, dim3(cdiv(P + 4, 64)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
+                       traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
+                       opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
+                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, IpcPeers{});
+  }
 }
 
 void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_total) {

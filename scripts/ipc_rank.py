@@ -1,0 +1,65 @@
+"""One rank of a multi-PROCESS job over the peer-mailbox collective (rl_comm_init_ipc), all ranks on device 0 — the
+functional rehearsal a one-GPU box allows: IPC handles of one device map into other processes exactly like peer windows
+do.  Handles are exchanged through files in `dir`.   usage: ipc_rank.py <rank> <world> <dir> [n_total] [T]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import relearn_amd as ra  # noqa: E402
+
+rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+n_total = int(sys.argv[4]) if len(sys.argv) > 4 else 512
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 48
+
+
+def wait_for(paths, what, limit=120.0):
+    t0 = time.time()
+    while not all(os.path.exists(p) for p in paths):
+        if time.time() - t0 > limit:
+            sys.exit("rank %d: timed out waiting for %s" % (rank, what))
+        time.sleep(0.02)
+
+
+eng = ra.Engine(0)
+if world > 1:
+    h = eng.comm_ipc_handle(world)
+    tmp = os.path.join(d, "h%d.tmp" % rank)
+    open(tmp, "wb").write(h)
+    os.rename(tmp, os.path.join(d, "h%d.bin" % rank))
+    files = [os.path.join(d, "h%d.bin" % r) for r in range(world)]
+    wait_for(files, "the peers' mailbox handles")
+    eng.comm_init_ipc(rank, world, [open(f, "rb").read() for f in files])
+    eng.comm_selftest()
+n = n_total // world
+env = ra.CartPoleEnv(eng, n, max_steps=30, lane_offset=rank * n, seed_env=0, seed_actor=1)
+pol, cri = ra.Mlp(eng, 5, 128, 2), ra.Mlp(eng, 5, 128, 1)
+pol.init(2)
+cri.init(3)
+opt = ra.Adam(cri)
+traj = ra.Trajectory(eng, n, T, 5)
+out = {}
+eng.profile_enable(True)
+for period in range(2):
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    if period == 0:
+        out["action"] = traj.read(ra.TRAJ_ACTION)
+        out["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
+    st = ra.trpo_update(pol, traj)
+    cs, losses = ra.critic_update(cri, opt, traj, 6, want_losses=True)
+    out["policy%d" % period] = pol.get_params()
+    out["critic%d" % period] = cri.get_params()
+    out["losses%d" % period] = losses
+    out["trpo%d" % period] = np.array([st.loss_initial, st.entropy, st.step_size, st.cg_iterations, st.status])
+eng.sync()
+out["allreduce_launches"] = np.array([eng.profile_read()["allreduce"][1]])
+np.savez(os.path.join(d, "out%d_of_%d.npz" % (rank, world)), **out)
+if world > 1:
+    # nobody unmaps a mailbox a peer may still be writing to
+    open(os.path.join(d, "done%d" % rank), "w").close()
+    wait_for([os.path.join(d, "done%d" % r) for r in range(world)], "the peers to finish")
+    eng.comm_destroy()
+print("rank %d of %d ok" % (rank, world))

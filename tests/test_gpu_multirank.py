@@ -177,6 +177,15 @@ def test_bench_as_two_processes_over_the_host_collective():
     assert "gloo" in two["config"]["parallelism"] and two["cpu_baseline"] is None
     assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] * 1e-3 - 2048 * 32) < 1e-6 * 2048 * 32
     assert two["phases"]["allreduce"]["launches_per_step"] >= 5 + 11 + 2
+    # the same launch with the peer-mailbox transport (both ranks map each other's mailbox on the one device)
+    ipc = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "ipc"})
+    assert "mailboxes" in ipc["config"]["parallelism"], ipc["_stderr"][-1500:]
+    assert ipc["phases"]["allreduce"]["launches_per_step"] >= 5 + 11 + 2
+    for other in (two, ipc):
+        a, b = one["last_update"], other["last_update"]
+        assert a["trpo_status"] == b["trpo_status"]
+        assert abs(a["entropy"] - b["entropy"]) < 5e-3
+        assert abs(a["critic_loss_last"] - b["critic_loss_last"]) < 5e-2 * a["critic_loss_last"]
     a, b = one["last_update"], two["last_update"]
     assert a["trpo_status"] == b["trpo_status"]
     # one period of training with the f32 sums in another order: TRPO's CG amplifies rounding-level differences of the
@@ -211,3 +220,50 @@ def test_rccl_is_bound_next_to_the_hip_runtime_in_use(order):
     assert bound, text[-1500:]
     rccl, hip = (kv.split("=", 1)[1] for kv in bound[0].split()[1:3])
     assert rccl and hip and os.path.realpath(os.path.dirname(rccl)) == os.path.realpath(os.path.dirname(hip)), bound
+
+
+def test_two_processes_over_the_peer_mailbox_collective(tmp_path):
+    """rl_comm_init_ipc: two PROCESSES on this box's one GPU exchange their mailbox handles and run sharded updates
+    through the single-launch all-reduce (scripts/ipc_rank.py); the library's self-test passes on both, both end with
+    identical replicas, and the job agrees with the one-process run like the in-process loopback group does."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "ipc_rank.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(world):
+        procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(tmp_path)], cwd=root, env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+                 for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=200)
+            except subprocess.TimeoutExpired:
+                import signal
+                for q in procs:
+                    try:
+                        os.killpg(q.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+                raise AssertionError("ipc_rank.py (world %d) did not finish within 200 s" % world)
+            outs.append(o.decode())
+        for p, o in zip(procs, outs):
+            assert p.returncode == 0, o[-2000:]
+        return [dict(np.load(os.path.join(str(tmp_path), "out%d_of_%d.npz" % (r, world)))) for r in range(world)]
+
+    single = run(1)[0]
+    double = run(2)
+    assert single["allreduce_launches"][0] == 0
+    assert double[0]["allreduce_launches"][0] == double[1]["allreduce_launches"][0] > 2 * (1 + 11 + 1 + 6)
+    for period in range(2):
+        assert np.array_equal(double[0]["policy%d" % period], double[1]["policy%d" % period])
+        assert np.array_equal(double[0]["critic%d" % period], double[1]["critic%d" % period])
+    assert np.array_equal(np.concatenate([double[0]["action"], double[1]["action"]], axis=1), single["action"])
+    assert np.array_equal(np.concatenate([double[0]["adv"], double[1]["adv"]], axis=1), single["adv"])
+    a, b = double[0]["trpo0"], single["trpo0"]
+    assert abs(a[0] - b[0]) < 1e-6 and abs(a[1] - b[1]) < 1e-6 and a[3] == b[3] and a[4] == b[4]
+    assert abs(a[2] - b[2]) < 1e-1 * b[2]  # CG-amplified rounding, see test_two_ranks_equal_one_rank
+    assert np.max(np.abs(double[0]["losses0"] - single["losses0"]) / single["losses0"]) < 1e-5
+    assert np.mean(np.abs(double[0]["critic0"] - single["critic0"]) < 2e-5) > 0.97
