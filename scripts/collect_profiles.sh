@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the round's evidence on a GPU box into gpurun_out/prof_<tag>/ (copy what is to be judged into profiles/):
+#   bench lines at 65,536 / 8,192 / 4,096 lanes, the rocprofv3 --kernel-trace --stats summary of the bench command,
+#   and the PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE) over one period of the hot path.
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+TAG="${1:-r02}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
+OUT="gpurun_out/prof_$TAG"
+rm -rf "$OUT" && mkdir -p "$OUT"
+python3 bench.py > "$OUT/bench_65536.json" 2> "$OUT/bench_65536.err" || echo "bench 65536 failed"
+python3 bench.py --envs 8192 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_8192.json" 2> "$OUT/bench_8192.err" || echo "bench 8192 failed"
+python3 bench.py --envs 4096 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_4096.json" 2> "$OUT/bench_4096.err" || echo "bench 4096 failed"
+for n in 65536 8192 4096; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$n" -- python3 bench.py --envs $n --steps 3 --warmup 1 --no-cpu-baseline \
+    > "$OUT/bench_under_rocprof_$n.json" 2> "$OUT/stats_$n.log" || echo "rocprof stats $n failed"
+done
+bash scripts/pmc_passes.sh "${TAG}_65536" scripts/path_once.py 65536 1 80 > "$OUT/pmc_65536.log" 2>&1 || echo "pmc failed"
+cp "gpurun_out/pmc/${TAG}_65536/summary.json" "$OUT/pmc_65536_summary.json" 2>/dev/null
+find "$OUT" -name "*kernel_stats.csv" | head
+echo "collect_profiles done"
