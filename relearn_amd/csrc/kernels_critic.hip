@@ -99,12 +99,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     return o;
   };
 
-#ifdef RL_CRITIC_STAGGER
-  if (wave >= CRITIC_WAVES / 2) __builtin_amdgcn_s_sleep(RL_CRITIC_STAGGER);  // the two waves of a SIMD out of phase
-#endif
   TileOp op = load_tile(wave_id);
   for (size_t g = wave_id; g < n_tiles; g += n_waves) {
-    const TileOp next = load_tile(g + n_waves);  // global loads run one tile ahead
+    const TileOp next = load_tile(g + n_waves);  // global loads run one tile ahead (two: measured, no gain)
     Frag fa[3];
     bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
     // ---- forward, one hidden tile at a time, software-pipelined: the matrix pipe works on hidden tile t + 1 while the

@@ -580,8 +580,11 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
   const size_t n_tiles = (B + 31) / 32;
   const size_t wave_id = (size_t)blockIdx.x * V2_WAVES + wave, n_waves = (size_t)gridDim.x * V2_WAVES;
   int since_flush = 0;
+  // per lane: features 2 hf, 2 hf + 1 and 4 of sample n, and the per-sample scalars the pass needs (log pi_0 of both
+  // actions; advantage and action) — all requested one tile ahead
   struct TileOp {
-    float xa, xb, xc;
+    float xa, xb, xc, l0, l1, adv;
+    int act;
     bool valid;
   };
   // branch-free (padding lanes read sample B - 1 and are zeroed): the loads of tile i + 1 stay in flight across tile i
@@ -592,6 +595,19 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     const size_t sc = o.valid ? sidx : B - 1;
     const float xa = tr.obs[(size_t)(2 * hf) * plane + sc], xb = tr.obs[(size_t)(2 * hf + 1) * plane + sc];
     const float xc = tr.obs[(size_t)4 * plane + sc];
+    o.l0 = o.l1 = o.adv = 0.0f;
+    o.act = 0;
+    if (MODE != PASS_INIT) {  // log pi_0 (written by PASS_INIT, read by the others)
+      const float l0 = lp0[sc], l1 = lp0[B + sc];
+      o.l0 = o.valid ? l0 : 0.0f;
+      o.l1 = o.valid ? l1 : 0.0f;
+    }
+    if (!JVP) {
+      const float adv = tr.adv[sc];
+      const int act = (int)tr.action[sc];
+      o.adv = o.valid ? adv : 0.0f;
+      o.act = o.valid ? act : 0;
+    }
     o.xa = o.valid ? xa : 0.0f;
     o.xb = o.valid ? xb : 0.0f;
     o.xc = o.valid ? xc : 0.0f;
@@ -655,22 +671,17 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
     float dz0 = 0.0f, dz1 = 0.0f;
     if (JVP) {
       const float delta = s0 + tb2d;
-      float p0 = 0.0f, p1 = 0.0f;
-      if (op.valid) {
-        p0 = rl_expf(lp0[sidx]);
-        p1 = rl_expf(lp0[B + sidx]);
-      }
+      const float p0 = rl_expf(op.l0), p1 = rl_expf(op.l1);
       dz0 = op.valid ? (p0 * p1) * delta * inv_B : 0.0f;
       dz1 = -dz0;
     } else {
       float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
-      const float adv = op.valid ? tr.adv[sidx] : 0.0f;
-      const int act = op.valid ? (int)tr.action[sidx] : 0;
+      const float adv = op.adv;
+      const int act = op.act;
       log_softmax_lane<2>(z, lp);
       if (MODE == PASS_PPO) {
         // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
-        float l0a = 0.0f;
-        if (op.valid) l0a = lp0[(size_t)act * B + sidx];
+        const float l0a = act == 0 ? op.l0 : op.l1;
         const float lpa = act == 0 ? lp[0] : lp[1];
         const float ratio = rl_expf(lpa - l0a);
         const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
@@ -702,11 +713,7 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)
           sum2 += (double)(lpa * adv);
         }
       } else {  // PASS_EVAL
-        float l00 = 0.0f, l01 = 0.0f;
-        if (op.valid) {
-          l00 = lp0[sidx];
-          l01 = lp0[B + sidx];
-        }
+        const float l00 = op.l0, l01 = op.l1;
         const float lpa = act == 0 ? lp[0] : lp[1];
         const float l0a = act == 0 ? l00 : l01;
         const float ratio = rl_expf(lpa - l0a);
