@@ -72,6 +72,28 @@ __device__ __forceinline__ void split3(float v, uint32_t &p0, uint32_t &p1, uint
 }
 __device__ __forceinline__ uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
 
+// the value of lane (l & 31) and of lane (l & 31) + 32 in every lane: one v_permlane32_swap (VALU) instead of a
+// ds_bpermute round trip
+__device__ __forceinline__ void both_halves(float v, float &lo, float &hi) {
+  // the instruction swaps the upper half of its first operand with the lower half of its second: fed the same value
+  // twice (in two registers), the first ends up holding the lower half's values in both halves, the second the upper
+  // half's.  (Inline asm: the builtin's second result is mis-modelled by this compiler when both inputs are one value;
+  // the s_nop covers the VALU-write -> permlane-read wait state the compiler would insert.)
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+
+// sum of 16 consecutive floats of a transposed LDS row, as four interleaved chains joined pairwise (a short dependent
+// chain instead of a 16-long one)
+__device__ __forceinline__ float row_sum16(const float *row) {
+  float a[4] = {row[0], row[1], row[2], row[3]};
+#pragma unroll
+  for (int c = 4; c < 16; ++c) a[c & 3] = a[c & 3] + row[c];
+  return (a[0] + a[1]) + (a[2] + a[3]);
+}
+
 union Frag {
   bf16x8 v;
   uint32_t u[4];

@@ -130,17 +130,15 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
     bt::wave_lds_fence();
-    float part = 0.0f;
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) part = part + Ysh[wave][n][hf * 16 + cc];
+    float part = bt::row_sum16(&Ysh[wave][n][hf * 16]);
     {  // the linear half of relu: this half's inputs of sample n
       float lin = lv[0] * op.xa;
       lin = __builtin_fmaf(lv[1], op.xb, lin);
       lin = __builtin_fmaf(lv[2], hf == 0 ? op.xc : 1.0f, lin);
       part = part + lin;
     }
-    const float other = __shfl_xor(part, 32, 64);
-    const float p0 = hf == 0 ? part : other, p1 = hf == 0 ? other : part;
+    float p0, p1;
+    bt::both_halves(part, p0, p1);
     const float y = 0.5f * (p0 + p1) + b2;
     const float d = y - op.tgt;
     const float dy = op.valid ? d * two_over_B : 0.0f;

@@ -573,13 +573,12 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
     bt::wave_lds_fence();
-    float part = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) part = part + Ysh[wave][n][hf * 16 + c];
+    float part = bt::row_sum16(&Ysh[wave][n][hf * 16]);
     part = part + lin;
-    const float other = __shfl_xor(part, 32, 64);
+    float p0, p1;
+    bt::both_halves(part, p0, p1);
     bt::wave_lds_fence();
-    return hf == 0 ? part + other : other + part;
+    return p0 + p1;
   };
 
   const size_t n_tiles = (B + 31) / 32;
