@@ -227,23 +227,39 @@ __device__ inline uint64_t agent_u64(const AgentKey &key, uint64_t word_pos) {
 }
 
 // Uniform::new(0usize, n).sample(rng) for the draw `v`, then Episodes::get (replay.rs:154-165)
-__device__ inline EpisodePick pick_episode(const ReplayDev &rp, uint32_t lane, uint64_t v) {
+// the fields of a lane's ring the pick needs (constant during an update: a workgroup may cache them)
+struct LaneMeta {
+  uint32_t n_eps, eh, head;  // stored episodes; ring index of the oldest (reduced mod E); first stored step
+};
+__device__ inline LaneMeta lane_meta(const ReplayDev &rp, uint32_t lane) {
+  return LaneMeta{rp.ep_count[lane], rp.ep_head[lane] % rp.E, rp.head[lane]};  // ep_head counts up without wrapping
+}
+
+__device__ inline EpisodePick pick_episode(const ReplayDev &rp, uint32_t lane, const LaneMeta &lm, uint64_t v) {
   EpisodePick p{0, 0, false, false};
-  const uint64_t n = rp.ep_count[lane];
+  const uint64_t n = lm.n_eps;
   if (n == 0) {
     p.empty = true;  // Uniform::new(0, 0) panics in the reference
     return p;
   }
-  const uint64_t ints_to_reject = (0ull - n) % n;  // (u64::MAX - range + 1) % range
-  const uint64_t zone = ~0ull - ints_to_reject;
   const uint64_t lo = v * n, hi = __umul64hi(v, n);
-  if (lo > zone) {
-    p.rejected = true;
-    return p;
+  if (lo > ~0ull - n) {  // ints_to_reject < n: only then can the draw fall outside the zone (the 64-bit division
+                         // stays off the common path)
+    const uint64_t ints_to_reject = (0ull - n) % n;  // (u64::MAX - range + 1) % range
+    const uint64_t zone = ~0ull - ints_to_reject;
+    if (lo > zone) {
+      p.rejected = true;
+      return p;
+    }
   }
-  const uint32_t idx = (uint32_t)hi, eh = rp.ep_head[lane];
-  const uint32_t end = rp.ep_end[(size_t)((eh + idx) % rp.E) * rp.N + lane];
-  const uint32_t start = idx == 0 ? rp.head[lane] : rp.ep_end[(size_t)((eh + idx - 1) % rp.E) * rp.N + lane];
+  const uint32_t idx = (uint32_t)hi, eh = lm.eh;
+  // ring index (eh + idx) mod E: eh < E and idx < n <= E, one conditional subtraction
+  const uint32_t r1 = eh + idx, r0 = r1 - 1;
+  const uint32_t s1 = r1 >= rp.E ? r1 - rp.E : r1, s0 = (idx != 0 && r0 >= rp.E) ? r0 - rp.E : r0;
+  const uint32_t head = lm.head;
+  const uint32_t end = rp.ep_end[(size_t)s1 * rp.N + lane];
+  const uint32_t prev = rp.ep_end[(size_t)(idx != 0 ? s0 : s1) * rp.N + lane];  // unconditional: both loads in flight
+  const uint32_t start = idx == 0 ? head : prev;
   p.start = start;
   p.len = end - start;
   if (p.len == 0 || p.len > rp.C) p.empty = true;  // corrupt bookkeeping: never loop on it
@@ -251,7 +267,30 @@ __device__ inline EpisodePick pick_episode(const ReplayDev &rp, uint32_t lane, u
 }
 
 constexpr int SAMPLE_BLOCK = 1024;
+constexpr int SAMPLE_CPT = 5;                            // candidates per thread and pass (consecutive)
+constexpr int SAMPLE_CHUNK = SAMPLE_BLOCK * SAMPLE_CPT;  // 5,120: a 100 k-step minibatch of CartPole episodes is one pass
+constexpr int SAMPLE_BLOCKS = SAMPLE_CHUNK / 8 + 1;      // ChaCha blocks a pass can touch (8 draws of 2 words per block)
 
+// inclusive prefix sum of one value per thread over the workgroup (wave shuffles, then the 16 wave totals)
+__device__ inline uint32_t block_inclusive_scan(uint32_t v, uint32_t *wave_tot, uint32_t tid) {
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)v, d, 64);
+    if (lane >= (uint32_t)d) v += up;
+  }
+  if (lane == 63) wave_tot[wave] = v;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int w = 0; w < SAMPLE_BLOCK / 64; ++w) base += w < (int)wave ? wave_tot[w] : 0u;
+  __syncthreads();  // wave_tot is reused by the next scan
+  return base + v;
+}
+
+constexpr int SAMPLE_META_LANES = 4096;  // up to this many lanes the ring fields are cached in LDS (48 KB)
+
+template <bool META_LDS>
 __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, AgentKey key, uint64_t *agent_pos,
                                                              uint32_t minibatch_steps, uint32_t max_eps,
                                                              uint32_t *__restrict__ ep_lane,
@@ -259,15 +298,31 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
                                                              uint32_t *__restrict__ ep_len,
                                                              uint32_t *__restrict__ ep_off, DqnCountsDev *counts,
                                                              int sequential, uint32_t n_batches) {
-  __shared__ uint32_t scan[SAMPLE_BLOCK];
-  __shared__ int s_flag[2];  // [0] rejected draw in this chunk, [1] empty buffer
+  __shared__ uint32_t words[SAMPLE_BLOCKS * 16];  // the pass's stretch of the agent's stream, one ChaCha block per thread
+  __shared__ uint32_t wave_tot[SAMPLE_BLOCK / 64];
+  __shared__ int s_flag[2];  // [0] rejected draw in this pass, [1] empty buffer
+  __shared__ uint32_t s_last[2];  // episodes and steps the pass takes
+  __shared__ uint64_t s_pos;      // stream position after a sequential replay (known to thread 0 only)
+  __shared__ uint32_t meta[META_LDS ? 3 * SAMPLE_META_LANES : 3];
   const uint32_t tid = threadIdx.x;
+  if (META_LDS)
+    for (uint32_t l = tid; l < rp.N; l += SAMPLE_BLOCK) {
+      const LaneMeta lm = lane_meta(rp, l);
+      meta[3 * l] = lm.n_eps;
+      meta[3 * l + 1] = lm.eh;
+      meta[3 * l + 2] = lm.head;
+    }
+  auto meta_of = [&](uint32_t l) {
+    return META_LDS ? LaneMeta{meta[3 * l], meta[3 * l + 1], meta[3 * l + 2]} : lane_meta(rp, l);
+  };
+  const int rp_error = *rp.error != 0 ? 1 : 0;
+  uint64_t pos_now = *agent_pos;  // carried in registers from minibatch to minibatch
   // `n_batches` consecutive minibatches in one launch (the draws of minibatch b + 1 continue where b stopped);
   // minibatch b writes its lists at offset b * max_eps and its counts at counts[b]
   for (uint32_t batch = 0; batch < n_batches; ++batch, ep_lane += max_eps, ep_start += max_eps, ep_len += max_eps,
                 ep_off += max_eps, ++counts) {
-  __syncthreads();  // the previous minibatch's final position is visible
-  const uint64_t pos0 = *(volatile uint64_t *)agent_pos;
+  __syncthreads();  // (first minibatch: the cached ring fields are in place)
+  const uint64_t pos0 = pos_now;
   uint32_t total = 0;   // steps taken so far
   uint32_t n_eps = 0;   // episodes taken so far
   uint64_t draws = 0;   // u64 draws consumed so far
@@ -275,14 +330,33 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
   int err = 0;
   while (!done && !fallback) {
     if (tid < 2) s_flag[tid] = 0;
+    // the stream words of candidates [draws, draws + CHUNK): word positions [first, first + 2 CHUNK)
+    const uint64_t first = pos0 + 2 * draws, block0 = first >> 4;
+    const uint32_t skew = (uint32_t)(first & 15);
+    const uint32_t lane0 = (uint32_t)(draws % rp.N);
+    if (tid < (uint32_t)SAMPLE_BLOCKS) {
+      uint32_t w[16];
+      rl_chacha_block(key.w, block0 + tid, 0, 4, w);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) words[tid * 16 + k] = w[k];
+    }
     __syncthreads();
-    const uint64_t j = draws + tid;
-    const uint32_t lane = (uint32_t)(j % rp.N);
-    const EpisodePick p = pick_episode(rp, lane, agent_u64(key, pos0 + 2 * j));
-    if (p.rejected) s_flag[0] = 1;
-    if (p.empty) s_flag[1] = 1;
-    scan[tid] = p.len;
-    __syncthreads();
+    EpisodePick p[SAMPLE_CPT];
+    uint32_t lanes[SAMPLE_CPT], mine = 0;
+    bool rej = false, empty = false;
+#pragma unroll
+    for (int c = 0; c < SAMPLE_CPT; ++c) {
+      const uint32_t jl = tid * SAMPLE_CPT + c;
+      lanes[c] = (lane0 + jl) % rp.N;  // = (draws + jl) mod N without a 64-bit division per candidate
+      const uint32_t wi = skew + 2 * jl;
+      p[c] = pick_episode(rp, lanes[c], meta_of(lanes[c]), ((uint64_t)words[wi + 1] << 32) | words[wi]);
+      rej |= p[c].rejected;
+      empty |= p[c].empty;
+      mine += p[c].len;
+    }
+    if (rej) s_flag[0] = 1;
+    if (empty) s_flag[1] = 1;
+    const uint32_t incl = block_inclusive_scan(mine, wave_tot, tid);  // (its barriers publish s_flag)
     if (s_flag[1]) {
       err = 2;
       break;
@@ -291,32 +365,36 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
       fallback = true;
       break;
     }
-    // inclusive prefix sum of the chunk's episode lengths
-    for (int d = 1; d < SAMPLE_BLOCK; d <<= 1) {
-      const uint32_t add = tid >= (uint32_t)d ? scan[tid - d] : 0;
-      __syncthreads();
-      scan[tid] += add;
-      __syncthreads();
+    uint32_t before = total + incl - mine, took = 0;
+#pragma unroll
+    for (int c = 0; c < SAMPLE_CPT; ++c) {
+      const bool take = before < minibatch_steps;
+      const uint32_t slot = n_eps + tid * SAMPLE_CPT + c;
+      if (take && slot < max_eps) {
+        ep_lane[slot] = lanes[c];
+        ep_start[slot] = p[c].start;
+        ep_len[slot] = p[c].len;
+        ep_off[slot] = before;
+      }
+      took += take ? 1u : 0u;
+      before += take ? p[c].len : 0u;
     }
-    const uint32_t before = total + scan[tid] - p.len;
-    const bool take = before < minibatch_steps;
-    if (take && n_eps + tid < max_eps) {
-      ep_lane[n_eps + tid] = lane;
-      ep_start[n_eps + tid] = p.start;
-      ep_len[n_eps + tid] = p.len;
-      ep_off[n_eps + tid] = before;
+    // lengths are >= 1, so the taken candidates are a prefix of the pass (candidate 0 always belongs to it: the loop
+    // would have ended otherwise); the thread that holds the prefix's last candidate publishes its size and steps
+    const bool next_takes = tid + 1 < (uint32_t)SAMPLE_BLOCK && total + incl < minibatch_steps;
+    if (took > 0 && !(took == (uint32_t)SAMPLE_CPT && next_takes)) {
+      s_last[0] = tid * SAMPLE_CPT + took;
+      s_last[1] = before - total;
     }
-    const uint32_t n_take = __syncthreads_count(take);
-    if (n_take < SAMPLE_BLOCK) {
-      const uint32_t taken_steps = n_take == 0 ? 0 : scan[n_take - 1];
-      total += taken_steps;
-      n_eps += n_take;
-      draws += n_take + 1;  // plus the refused candidate
+    __syncthreads();
+    const uint32_t taken = s_last[0];
+    total += s_last[1];
+    n_eps += taken;
+    if (taken < (uint32_t)SAMPLE_CHUNK) {
+      draws += taken + 1;  // plus the refused candidate
       done = true;
     } else {
-      total += scan[SAMPLE_BLOCK - 1];
-      n_eps += SAMPLE_BLOCK;
-      draws += SAMPLE_BLOCK;
+      draws += SAMPLE_CHUNK;
     }
     __syncthreads();
   }
@@ -328,7 +406,7 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
       const uint32_t lane = (uint32_t)(cand % rp.N);
       EpisodePick p;
       for (;;) {
-        p = pick_episode(rp, lane, agent_u64(key, pos));
+        p = pick_episode(rp, lane, meta_of(lane), agent_u64(key, pos));
         pos += 2;
         if (!p.rejected) break;
       }
@@ -348,26 +426,34 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
       n_eps += 1;
       cand += 1;
     }
-    *agent_pos = pos;
-  } else if (tid == 0 && err == 0) {
-    *agent_pos = pos0 + 2 * draws;
+    s_pos = pos;
+  }
+  if (fallback) {  // (uniform)
+    __syncthreads();
+    pos_now = s_pos;  // thread 0's err / n_eps / total are the minibatch's; the others only need the position
+  } else if (err == 0) {
+    pos_now = pos0 + 2 * draws;
   }
   if (tid == 0) {
     counts->n_eps = n_eps;
     counts->n_steps = total;
-    counts->error = err != 0 ? err : (*rp.error != 0 ? 1 : 0);
+    counts->error = err != 0 ? err : rp_error;
     counts->pad = 0;
-    __threadfence_block();
   }
   }
+  if (tid == 0) *agent_pos = pos_now;
 }
 
 void launch_dqn_sample(rl_engine *eng, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
                        uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,
                        uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential, uint32_t n_batches) {
   ProfScope ps(eng, RL_K_SMALL);
-  hipLaunchKernelGGL(k_dqn_sample, dim3(1), dim3(SAMPLE_BLOCK), 0, eng->stream, rp, key, d_agent_pos,
-                     minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential, n_batches);
+  if (rp.N <= (uint32_t)SAMPLE_META_LANES)
+    hipLaunchKernelGGL(k_dqn_sample<true>, dim3(1), dim3(SAMPLE_BLOCK), 0, eng->stream, rp, key, d_agent_pos,
+                       minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential, n_batches);
+  else
+    hipLaunchKernelGGL(k_dqn_sample<false>, dim3(1), dim3(SAMPLE_BLOCK), 0, eng->stream, rp, key, d_agent_pos,
+                       minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential, n_batches);
 }
 
 static inline uint32_t cdiv_d(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }

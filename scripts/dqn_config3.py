@@ -36,6 +36,15 @@ ms_first = eng.timer_end()
 out = {"lanes": N, "buffer_capacity_per_lane": int(cfg.buffer_capacity), "first_collect_steps": first_T * N,
        "first_collect_ms": ms_first, "first_collect_steps_per_s": first_T * N / ms_first * 1e3}
 st = dqn.update()  # warm-up
+# device time of an update without the per-kernel profiling events
+t_plain = 0.0
+for it in range(updates):
+    dqn.collect(rest_T, want_stats=False)
+    eng.timer_begin()
+    st = dqn.update()
+    t_plain += eng.timer_end()
+out["update_ms"] = t_plain / updates
+out["trained_samples_per_s"] = int(st.last_minibatch_steps) * int(cfg.opt_steps_per_update) / (t_plain / updates) * 1e3
 eng.profile_enable(True)
 eng.profile_read(reset=True)
 t_collect = t_update = 0.0
@@ -51,9 +60,8 @@ wall = time.time() - wall0
 prof = eng.profile_read(reset=True)
 out.update({
     "updates": updates, "collect_steps_per_update": rest_T * N, "collect_ms": t_collect / updates,
-    "update_ms": t_update / updates, "opt_steps_per_update": int(cfg.opt_steps_per_update),
+    "update_ms_with_profiling": t_update / updates, "opt_steps_per_update": int(cfg.opt_steps_per_update),
     "minibatch_steps": int(st.last_minibatch_steps), "minibatch_episodes": int(st.last_minibatch_episodes),
-    "trained_samples_per_s": int(st.last_minibatch_steps) * int(cfg.opt_steps_per_update) / (t_update / updates) * 1e3,
     "wall_s_per_update_with_profiling": wall / updates,
     "loss_first": st.loss_first, "loss_last": st.loss_last, "exploration_rate": dqn.exploration_rate(),
     "kernel_ms_per_update": {k: v[0] / updates for k, v in prof.items() if v[1]},
