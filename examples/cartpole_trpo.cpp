@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
 
     const std::string path = out_dir + "/actor.cbor";
     std::printf("Saving actor to \"%s\"\n", path.c_str());
-    const std::vector<uint8_t> doc = actor_to_cbor(env, agent->actor(ActorMode::Evaluation));
+    const std::vector<uint8_t> doc = actor_to_cbor(env, agent->policy_module());  // the evaluation actor's state is the policy module
     std::ofstream(path, std::ios::binary).write((const char *)doc.data(), (std::streamsize)doc.size());
     std::printf("To evaluate the actor run\n%s %s\n", argv[0], path.c_str());
     return 0;

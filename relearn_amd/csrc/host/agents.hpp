@@ -5,6 +5,9 @@
 //   EnvStructure / Environment     src/envs/mod.rs:76-127,165-193     -> CartPoleLanes, ChainLanes (vectorised)
 //   BuildModule, MlpConfig, GruMlpConfig   src/torch/modules/mod.rs:14, ff/mlp.rs:13-34   -> MlpConfig, GruMlpConfig
 //   BuildAgent / Agent / Actor / BatchUpdate / ActorMode   src/agents/mod.rs:48-59,101-114,144,167-215
+//   Policy, Critic, Optimizer, TrustRegionOptimizer (abstract; Trpo / Ppo / Reinforce, ValuesOpt / RewardToGo,
+//   AdamOptimizer, ConjugateGradientOptimizer implement them)   src/torch/agents/policies/mod.rs:21-53,
+//   critics/mod.rs:20-99, src/torch/optimizers/mod.rs:25-92
 //   ActorCriticConfig / ActorCriticAgent   src/torch/agents/actor_critic.rs:20-136,176-211
 //   TrpoConfig / PpoConfig / ReinforceConfig   src/torch/agents/policies/{trpo,ppo,reinforce}.rs
 //   ValuesOptConfig / RewardToGoConfig       src/torch/agents/critics/{opt,rtg}.rs
@@ -23,7 +26,9 @@
 #include <vector>
 
 #include "../../../include/relearn_hip.h"
+#include "../../../include/rl_detmath.h"
 #include "logging.hpp"
+#include "prng.hpp"
 
 namespace relearn {
 
@@ -255,18 +260,44 @@ struct ChainLstmMlpConfig {
   }
 };
 
+// ---------------------------------------------------------------- optimizers (src/torch/optimizers/mod.rs:25-92)
+// `Optimizer` (first-order: backward_step) and `TrustRegionOptimizer` (trust_region_backward_step) are the reference's
+// two optimizer traits; the update loops that drive them live in the library, so an implementation here hands the
+// library what it needs: the device optimizer state, or the trust-region solver's settings.
+class Optimizer {
+ public:
+  virtual ~Optimizer() = default;
+  virtual rl_adam *handle() const = 0;  // device state of the rule (moments, step count)
+};
+class TrustRegionOptimizer {
+ public:
+  virtual ~TrustRegionOptimizer() = default;
+  // fill the solver's part of a trust-region step (the caller sets the constraint bound)
+  virtual void configure(rl_trpo_config &c) const = 0;
+};
+
+class AdamOptimizer final : public Optimizer {  // COptimizer over torch's Adam (optimizers/coptimizer.rs:16-110)
+ public:
+  AdamOptimizer(Module &m, Engine &eng, const rl_adam_config &c) { check(rl_adam_create(m.handle(), &c, &h_), eng.handle()); }
+  ~AdamOptimizer() override { rl_adam_destroy(h_); }
+  AdamOptimizer(const AdamOptimizer &) = delete;
+  AdamOptimizer &operator=(const AdamOptimizer &) = delete;
+  rl_adam *handle() const override { return h_; }
+
+ private:
+  rl_adam *h_ = nullptr;
+};
+
 struct AdamConfig {  // optimizers/coptimizer.rs:136-156
   double learning_rate = 1e-3, beta1 = 0.9, beta2 = 0.999, weight_decay = 0.0;
-  rl_adam *build_optimizer(Module &m, Engine &eng) const {
+  std::unique_ptr<Optimizer> build_optimizer(Module &m, Engine &eng) const {  // BuildOptimizer::build_optimizer
     rl_adam_config c;
     check(rl_adam_config_default(&c));
     c.learning_rate = learning_rate;
     c.beta1 = beta1;
     c.beta2 = beta2;
     c.weight_decay = weight_decay;
-    rl_adam *o = nullptr;
-    check(rl_adam_create(m.handle(), &c, &o), eng.handle());
-    return o;
+    return std::unique_ptr<Optimizer>(new AdamOptimizer(m, eng, c));
   }
 };
 
@@ -295,16 +326,130 @@ class DeviceHistory {
 };
 
 // ---------------------------------------------------------------- policies and critics
+struct ConjugateGradientOptimizerConfig;
+class ConjugateGradientOptimizer final : public TrustRegionOptimizer {  // conjugate_gradient.rs:67-260
+ public:
+  ConjugateGradientOptimizer(uint64_t iterations, uint64_t max_backtracks, double backtrack_ratio, double hpv_reg_coeff,
+                             bool accept_violation)
+      : iterations_(iterations), max_backtracks_(max_backtracks), backtrack_ratio_(backtrack_ratio),
+        hpv_reg_coeff_(hpv_reg_coeff), accept_violation_(accept_violation) {}
+  void configure(rl_trpo_config &c) const override {
+    c.iterations = iterations_;
+    c.max_backtracks = max_backtracks_;
+    c.backtrack_ratio = backtrack_ratio_;
+    c.hpv_reg_coeff = hpv_reg_coeff_;
+    c.accept_violation = accept_violation_ ? 1 : 0;
+  }
+
+ private:
+  uint64_t iterations_, max_backtracks_;
+  double backtrack_ratio_, hpv_reg_coeff_;
+  bool accept_violation_;
+};
 struct ConjugateGradientOptimizerConfig {  // conjugate_gradient.rs:41-65
   uint64_t iterations = 10, max_backtracks = 15;
   double backtrack_ratio = 0.8, hpv_reg_coeff = 1e-5;
   bool accept_violation = false;
+  std::unique_ptr<TrustRegionOptimizer> build_optimizer() const {
+    return std::unique_ptr<TrustRegionOptimizer>(
+        new ConjugateGradientOptimizer(iterations, max_backtracks, backtrack_ratio, hpv_reg_coeff, accept_violation));
+  }
 };
+
+enum class PolicyKind { Trpo, Ppo, Reinforce };
+
+// Policy (src/torch/agents/policies/mod.rs:21-53): a module and the rule that improves it from a history whose
+// advantages are in place.  `update` logs what the reference's implementation logs, under the caller's scope.
+class Policy {
+ public:
+  virtual ~Policy() = default;
+  virtual PolicyKind kind() const = 0;
+  virtual void update(DeviceHistory &history, StatsLogger &logger) = 0;
+  Module &module() { return *module_; }  // AsModule::as_module
+  int32_t last_status() const { return last_status_; }  // OptimizerStepError of the last update, RL_OPT_OK otherwise
+
+ protected:
+  Policy(Engine &eng, std::unique_ptr<Module> m) : eng_(eng), module_(std::move(m)) {}
+  Engine &eng_;
+  std::unique_ptr<Module> module_;
+  int32_t last_status_ = RL_OPT_OK;
+};
+
+class Trpo final : public Policy {  // policies/trpo.rs:63-164
+ public:
+  Trpo(Engine &eng, std::unique_ptr<Module> m, std::unique_ptr<TrustRegionOptimizer> opt, double max_policy_step_kl)
+      : Policy(eng, std::move(m)), optimizer_(std::move(opt)) {
+    check(rl_trpo_config_default(&cfg_));
+    optimizer_->configure(cfg_);
+    cfg_.max_policy_step_kl = max_policy_step_kl;
+  }
+  PolicyKind kind() const override { return PolicyKind::Trpo; }
+  void update(DeviceHistory &history, StatsLogger &logger) override {
+    rl_trpo_stats st{};
+    check(rl_trpo_update(module_->handle(), history.handle(), &cfg_, &st), eng_.handle());  // OptimizerNanError: the
+                                                                                           // reference panics (trpo.rs:154-162)
+    logger.log_scalar("entropy", st.entropy);                  // trpo.rs:119
+    logger.log_scalar("step_size", st.step_size);              // conjugate_gradient.rs:164
+    logger.log_scalar("loss_initial", st.loss_initial);        // :200
+    if (st.num_backtracks >= 0) {
+      logger.log_scalar("num_backtracks", (double)st.num_backtracks);  // :219
+      logger.log_scalar("step_scale", st.step_scale);                  // :220
+    }
+    logger.log_scalar("loss_final", st.loss_final);            // :225
+    logger.log_scalar("constraint_val_final", st.constraint_val_final);  // :226
+    last_status_ = st.status;  // OptimizerStepError::{LossNotImproving, ConstraintViolated}: warn and continue
+  }
+
+ private:
+  std::unique_ptr<TrustRegionOptimizer> optimizer_;
+  rl_trpo_config cfg_{};
+};
+
+class Ppo final : public Policy {  // policies/ppo.rs:63-137
+ public:
+  Ppo(Engine &eng, std::unique_ptr<Module> m, std::unique_ptr<Optimizer> opt, uint64_t opt_steps_per_update,
+      double clip_distance)
+      : Policy(eng, std::move(m)), optimizer_(std::move(opt)) {
+    cfg_.opt_steps_per_update = opt_steps_per_update;
+    cfg_.clip_distance = clip_distance;
+  }
+  PolicyKind kind() const override { return PolicyKind::Ppo; }
+  void update(DeviceHistory &history, StatsLogger &logger) override {
+    rl_policy_opt_stats st{};
+    check(rl_ppo_update(module_->handle(), optimizer_->handle(), history.handle(), &cfg_, &st, nullptr), eng_.handle());
+    logger.log_scalar("entropy", st.entropy);  // ppo.rs:114 (ToLog::NoAbsLoss: no final loss)
+  }
+
+ private:
+  std::unique_ptr<Optimizer> optimizer_;
+  rl_ppo_config cfg_{};
+};
+
+class Reinforce final : public Policy {  // policies/reinforce.rs:40-90
+ public:
+  Reinforce(Engine &eng, std::unique_ptr<Module> m, std::unique_ptr<Optimizer> opt)
+      : Policy(eng, std::move(m)), optimizer_(std::move(opt)) {}
+  PolicyKind kind() const override { return PolicyKind::Reinforce; }
+  void update(DeviceHistory &history, StatsLogger &logger) override {
+    rl_policy_opt_stats st{};
+    check(rl_reinforce_update(module_->handle(), optimizer_->handle(), history.handle(), &st), eng_.handle());
+    logger.log_scalar("loss", st.loss_first);
+    logger.log_scalar("entropy", st.entropy);  // reinforce.rs:84
+  }
+
+ private:
+  std::unique_ptr<Optimizer> optimizer_;
+};
+
 template <typename MB = MlpConfig>
 struct TrpoConfig {  // policies/trpo.rs:18-41
   MB policy_fn_config;
   ConjugateGradientOptimizerConfig optimizer_config;
   double max_policy_step_kl = 0.01;
+  std::unique_ptr<Policy> build_policy(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
+    return std::unique_ptr<Policy>(new Trpo(eng, policy_fn_config.build_module(eng, in_dim, out_dim, seed),
+                                            optimizer_config.build_optimizer(), max_policy_step_kl));
+  }
 };
 template <typename MB = MlpConfig>
 struct PpoConfig {  // policies/ppo.rs:13-41
@@ -312,13 +457,80 @@ struct PpoConfig {  // policies/ppo.rs:13-41
   AdamConfig optimizer_config;
   uint64_t opt_steps_per_update = 10;
   double clip_distance = 0.2;
+  std::unique_ptr<Policy> build_policy(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
+    std::unique_ptr<Module> m = policy_fn_config.build_module(eng, in_dim, out_dim, seed);
+    std::unique_ptr<Optimizer> o = optimizer_config.build_optimizer(*m, eng);
+    return std::unique_ptr<Policy>(new Ppo(eng, std::move(m), std::move(o), opt_steps_per_update, clip_distance));
+  }
 };
 template <typename MB = MlpConfig>
 struct ReinforceConfig {  // policies/reinforce.rs
   MB policy_fn_config;
   AdamConfig optimizer_config;
+  std::unique_ptr<Policy> build_policy(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
+    std::unique_ptr<Module> m = policy_fn_config.build_module(eng, in_dim, out_dim, seed);
+    std::unique_ptr<Optimizer> o = optimizer_config.build_optimizer(*m, eng);
+    return std::unique_ptr<Policy>(new Reinforce(eng, std::move(m), std::move(o)));
+  }
 };
+
+// Critic (src/torch/agents/critics/mod.rs:20-99): turns a history into per-step advantages for the policy and
+// improves itself from the same history afterwards.
+class Critic {
+ public:
+  virtual ~Critic() = default;
+  virtual void advantages(DeviceHistory &history) = 0;                    // Critic::advantages
+  virtual void update(DeviceHistory &history, StatsLogger &logger) = 0;   // Critic::update
+  virtual Module *module() { return nullptr; }                            // a critic may have no trainable state
+  virtual double discount_factor() const = 0;
+};
+
 enum class StepValueTarget { RewardToGo, OneStepTd };  // critics/mod.rs:203-215 (default RewardToGo)
+
+class ValuesOpt final : public Critic {  // critics/opt.rs:41-126
+ public:
+  ValuesOpt(Engine &eng, std::unique_ptr<Module> m, std::unique_ptr<Optimizer> opt, double discount_factor,
+            double gae_lambda, StepValueTarget target, uint64_t opt_steps_per_update)
+      : eng_(eng), module_(std::move(m)), optimizer_(std::move(opt)), gamma_((float)discount_factor),
+        lambda_(gae_lambda), target_(target), steps_(opt_steps_per_update) {}
+  void advantages(DeviceHistory &history) override {
+    check(rl_gae(history.handle(), module_->handle(), gamma_, (float)lambda_), eng_.handle());
+  }
+  void update(DeviceHistory &history, StatsLogger &logger) override {
+    // ValuesOpt::update (critics/opt.rs:100-126): targets once under no-grad, then n_backward_steps
+    rl_critic_stats cs{};
+    rl_values_opt_config vc{};
+    vc.opt_steps_per_update = steps_;
+    vc.target = target_ == StepValueTarget::OneStepTd ? RL_VALUE_TARGET_ONE_STEP_TD : RL_VALUE_TARGET_REWARD_TO_GO;
+    vc.discount_factor = gamma_;
+    check(rl_values_opt_update(module_->handle(), optimizer_->handle(), history.handle(), &vc, &cs, nullptr), eng_.handle());
+    logger.log_scalar("loss", cs.loss_last);  // n_backward_steps, ToLog::All (torch/agents/mod.rs:68-70)
+  }
+  Module *module() override { return module_.get(); }
+  double discount_factor() const override { return gamma_; }
+
+ private:
+  Engine &eng_;
+  std::unique_ptr<Module> module_;
+  std::unique_ptr<Optimizer> optimizer_;
+  float gamma_;
+  double lambda_;
+  StepValueTarget target_;
+  uint64_t steps_;
+};
+
+class RewardToGo final : public Critic {  // critics/rtg.rs:22-40
+ public:
+  RewardToGo(Engine &eng, double discount_factor) : eng_(eng), gamma_((float)discount_factor) {}
+  void advantages(DeviceHistory &history) override { check(rl_reward_to_go(history.handle(), gamma_), eng_.handle()); }
+  void update(DeviceHistory &, StatsLogger &) override {}  // RewardToGo::update does nothing
+  double discount_factor() const override { return gamma_; }
+
+ private:
+  Engine &eng_;
+  float gamma_;
+};
+
 template <typename MB = MlpConfig>
 struct ValuesOptConfig {  // critics/opt.rs:13-37
   MB state_value_fn_config;
@@ -327,98 +539,109 @@ struct ValuesOptConfig {  // critics/opt.rs:13-37
   StepValueTarget target = StepValueTarget::RewardToGo;
   uint64_t opt_steps_per_update = 80;
   double max_discount_factor = 0.99;
+  std::unique_ptr<Critic> build_critic(Engine &eng, uint32_t in_dim, double env_discount_factor, uint64_t seed) const {
+    std::unique_ptr<Module> m = state_value_fn_config.build_module(eng, in_dim, 1, seed);
+    std::unique_ptr<Optimizer> o = optimizer_config.build_optimizer(*m, eng);
+    const double g = env_discount_factor < max_discount_factor ? env_discount_factor : max_discount_factor;  // opt.rs:73
+    return std::unique_ptr<Critic>(new ValuesOpt(eng, std::move(m), std::move(o), g, gae_lambda, target, opt_steps_per_update));
+  }
 };
-struct RewardToGoConfig {};  // critics/rtg.rs
+struct RewardToGoConfig {  // critics/rtg.rs:14-20
+  std::unique_ptr<Critic> build_critic(Engine &eng, uint32_t, double env_discount_factor, uint64_t) const {
+    return std::unique_ptr<Critic>(new RewardToGo(eng, env_discount_factor));
+  }
+};
 
-enum class PolicyKind { Trpo, Ppo, Reinforce };
+// ---------------------------------------------------------------- Actor (src/agents/mod.rs:101-114)
+// `act(episode_state, observation, rng) -> action`, one observation at a time.  The batched rollouts are the fast
+// path (`ActorCriticAgent::collect`); this is the reference's per-step interface for a caller that steps its own
+// environment.  The random state belongs to the caller, as in the reference.
+class Actor {
+ public:
+  virtual ~Actor() = default;
+  virtual uint32_t act(const std::vector<float> &observation_features, Prng &rng) = 0;
+};
+
+// PolicyActor (policies/actor.rs:30-56) over a feed-forward policy module: logits from the device module,
+// Categorical::new (log_softmax) and the inverse-CDF draw of the rollouts (`log_probs.exp().multinomial(1)` with an
+// explicit uniform from `rng`; same arithmetic as device_fns.hpp, include/rl_detmath.h).  With `rng` at word t of
+// stream `lane` of the env's actor seed this returns exactly the action the device rollout takes for that lane and
+// step.  Recurrent modules carry their episode state on the device: they act through the rollouts only.
+class PolicyActor final : public Actor {
+ public:
+  PolicyActor(Engine &eng, Module &policy_module, uint32_t in_dim, uint32_t n_actions)
+      : eng_(eng), module_(policy_module), in_dim_(in_dim), n_actions_(n_actions) {}
+  uint32_t act(const std::vector<float> &x, Prng &rng) override {
+    if (x.size() != in_dim_) throw Error(RL_ERR_INVALID_ARGUMENT, "observation has the wrong number of features");
+    std::vector<float> z(n_actions_), lp(n_actions_);
+    check(rl_mlp_forward(module_.handle(), x.data(), 1, z.data()), eng_.handle());
+    float m = z[0];
+    for (uint32_t a = 1; a < n_actions_; ++a)
+      if (z[a] > m) m = z[a];
+    float s = 0.0f;
+    for (uint32_t a = 0; a < n_actions_; ++a) s += rl_expf(z[a] - m);
+    const float ls = rl_logf(s);
+    for (uint32_t a = 0; a < n_actions_; ++a) lp[a] = (z[a] - m) - ls;
+    const float u = rng.gen_f32();
+    float cum = 0.0f;
+    for (uint32_t a = 0; a + 1 < n_actions_; ++a) {
+      cum += rl_expf(lp[a]);
+      if (u < cum) return a;
+    }
+    return n_actions_ - 1;  // the last index absorbs rounding
+  }
+
+ private:
+  Engine &eng_;
+  Module &module_;
+  uint32_t in_dim_, n_actions_;
+};
+
 template <typename P, typename C>
 struct ActorCriticConfig;
 
-// ActorCriticAgent (actor_critic.rs:72-136) over device modules; `batch_update` follows batch_update_slice
+// ActorCriticAgent (actor_critic.rs:72-136) over a Policy and a Critic; `batch_update` follows batch_update_slice
 // (actor_critic.rs:176-211): advantages, policy update, critic update, with the reference's metric names.
 class ActorCriticAgent {
  public:
-  ~ActorCriticAgent() {
-    rl_adam_destroy(policy_opt_);
-    rl_adam_destroy(critic_opt_);
+  Policy &policy() { return *policy_; }
+  Critic &critic() { return *critic_; }
+  Module &policy_module() { return policy_->module(); }
+  Module *critic_module() { return critic_->module(); }
+  // Agent::actor(mode): the policy module is the actor's state (both modes sample from the policy's distribution,
+  // policies/mod.rs:42-53); the returned actor acts one observation at a time, `collect` is the batched form
+  std::unique_ptr<Actor> actor(ActorMode) {
+    return std::unique_ptr<Actor>(new PolicyActor(eng_, policy_->module(), obs_dim_, n_actions_));
   }
-  Module &policy_module() { return *policy_; }
-  Module *critic_module() { return critic_.get(); }
-  // Agent::actor(mode): the policy module is the actor's state; rollouts sample, evaluation is the host's business
-  Module &actor(ActorMode) { return *policy_; }
   DeviceHistory buffer(uint64_t horizon) const { return DeviceHistory(eng_, n_lanes_, horizon, obs_dim_); }
 
   // BatchUpdate::batch_update
   void batch_update(DeviceHistory &history, StatsLogger &logger) {
     log_elapsed(logger, "adv_est_time", [&] {
-      if (critic_) check(rl_gae(history.handle(), critic_->handle(), gamma_, (float)gae_lambda_), eng_.handle());
-      else check(rl_reward_to_go(history.handle(), gamma_), eng_.handle());
+      critic_->advantages(history);
       eng_.sync();
     });
     ScopedLogger pl(logger, "policy");
-    log_elapsed(pl, "update_time", [&] { update_policy(history, pl); eng_.sync(); });
+    log_elapsed(pl, "update_time", [&] { policy_->update(history, pl); eng_.sync(); });
     ScopedLogger cl(logger, "critic");
-    log_elapsed(cl, "update_time", [&] {
-      if (!critic_) return;  // RewardToGo::update does nothing
-      rl_critic_stats cs{};
-      // ValuesOpt::update (critics/opt.rs:100-126): targets once under no-grad, then n_backward_steps
-      rl_values_opt_config vc{};
-      vc.opt_steps_per_update = critic_steps_;
-      vc.target = critic_target_ == StepValueTarget::OneStepTd ? RL_VALUE_TARGET_ONE_STEP_TD : RL_VALUE_TARGET_REWARD_TO_GO;
-      vc.discount_factor = gamma_;
-      check(rl_values_opt_update(critic_->handle(), critic_opt_, history.handle(), &vc, &cs, nullptr), eng_.handle());
-      cl.log_scalar("loss", cs.loss_last);  // n_backward_steps, ToLog::All (torch/agents/mod.rs:68-70)
-    });
+    log_elapsed(cl, "update_time", [&] { critic_->update(history, cl); });
   }
 
   // one data-collection pass of every lane with the current policy (train.rs:124-158's thread fan-out)
-  void collect(EnvLanes &env, DeviceHistory &history) { check(rl_rollout(env.handle(), policy_->handle(), history.handle()), eng_.handle()); }
+  void collect(EnvLanes &env, DeviceHistory &history) {
+    check(rl_rollout(env.handle(), policy_->module().handle(), history.handle()), eng_.handle());
+  }
+  int32_t last_status() const { return policy_->last_status(); }
 
  private:
   template <typename P, typename C>
   friend struct ActorCriticConfig;
   ActorCriticAgent(Engine &eng) : eng_(eng) {}
-  void update_policy(DeviceHistory &history, StatsLogger &logger) {
-    if (kind_ == PolicyKind::Trpo) {
-      rl_trpo_stats st{};
-      const int32_t rc = rl_trpo_update(policy_->handle(), history.handle(), &trpo_, &st);
-      if (rc == RL_ERR_OPT_NAN) check(rc, eng_.handle());  // the reference panics here (trpo.rs:154-162)
-      check(rc, eng_.handle());
-      logger.log_scalar("entropy", st.entropy);                  // trpo.rs:119
-      logger.log_scalar("step_size", st.step_size);              // conjugate_gradient.rs:164
-      logger.log_scalar("loss_initial", st.loss_initial);        // :200
-      if (st.num_backtracks >= 0) {
-        logger.log_scalar("num_backtracks", (double)st.num_backtracks);  // :219
-        logger.log_scalar("step_scale", st.step_scale);                  // :220
-      }
-      logger.log_scalar("loss_final", st.loss_final);            // :225
-      logger.log_scalar("constraint_val_final", st.constraint_val_final);  // :226
-      last_status_ = st.status;  // OptimizerStepError::{LossNotImproving, ConstraintViolated}: warn and continue
-    } else if (kind_ == PolicyKind::Ppo) {
-      rl_policy_opt_stats st{};
-      check(rl_ppo_update(policy_->handle(), policy_opt_, history.handle(), &ppo_, &st, nullptr), eng_.handle());
-      logger.log_scalar("entropy", st.entropy);  // ppo.rs:114 (ToLog::NoAbsLoss: no final loss)
-    } else {
-      rl_policy_opt_stats st{};
-      check(rl_reinforce_update(policy_->handle(), policy_opt_, history.handle(), &st), eng_.handle());
-      logger.log_scalar("loss", st.loss_first);
-      logger.log_scalar("entropy", st.entropy);  // reinforce.rs:84
-    }
-  }
   Engine &eng_;
-  std::unique_ptr<Module> policy_, critic_;
-  rl_adam *policy_opt_ = nullptr, *critic_opt_ = nullptr;
-  PolicyKind kind_ = PolicyKind::Trpo;
-  rl_trpo_config trpo_{};
-  rl_ppo_config ppo_{};
-  uint64_t critic_steps_ = 80, n_lanes_ = 0;
-  uint32_t obs_dim_ = 0;
-  float gamma_ = 0.99f;
-  double gae_lambda_ = 0.95;
-  StepValueTarget critic_target_ = StepValueTarget::RewardToGo;
-
- public:
-  int32_t last_status_ = RL_OPT_OK;
+  std::unique_ptr<Policy> policy_;
+  std::unique_ptr<Critic> critic_;
+  uint64_t n_lanes_ = 0;
+  uint32_t obs_dim_ = 0, n_actions_ = 0;
 };
 
 template <typename P, typename C>
@@ -432,48 +655,10 @@ struct ActorCriticConfig {  // actor_critic.rs:20-45
     std::unique_ptr<ActorCriticAgent> a(new ActorCriticAgent(eng));
     a->n_lanes_ = env.num_lanes();
     a->obs_dim_ = env.num_observation_features();
-    a->policy_ = policy_config.policy_fn_config.build_module(eng, env.num_observation_features(), env.num_actions(), seed);
-    build_policy(*a, policy_config, eng);
-    build_critic(*a, critic_config, env, eng, seed + 1);
+    a->n_actions_ = env.num_actions();
+    a->policy_ = policy_config.build_policy(eng, env.num_observation_features(), env.num_actions(), seed);
+    a->critic_ = critic_config.build_critic(eng, env.num_observation_features(), env.discount_factor(), seed + 1);
     return a;
-  }
-
- private:
-  template <typename MB>
-  static void build_policy(ActorCriticAgent &a, const TrpoConfig<MB> &c, Engine &) {
-    a.kind_ = PolicyKind::Trpo;
-    check(rl_trpo_config_default(&a.trpo_));
-    a.trpo_.iterations = c.optimizer_config.iterations;
-    a.trpo_.max_backtracks = c.optimizer_config.max_backtracks;
-    a.trpo_.backtrack_ratio = c.optimizer_config.backtrack_ratio;
-    a.trpo_.hpv_reg_coeff = c.optimizer_config.hpv_reg_coeff;
-    a.trpo_.accept_violation = c.optimizer_config.accept_violation ? 1 : 0;
-    a.trpo_.max_policy_step_kl = c.max_policy_step_kl;
-  }
-  template <typename MB>
-  static void build_policy(ActorCriticAgent &a, const PpoConfig<MB> &c, Engine &eng) {
-    a.kind_ = PolicyKind::Ppo;
-    a.ppo_.opt_steps_per_update = c.opt_steps_per_update;
-    a.ppo_.clip_distance = c.clip_distance;
-    a.policy_opt_ = c.optimizer_config.build_optimizer(*a.policy_, eng);
-  }
-  template <typename MB>
-  static void build_policy(ActorCriticAgent &a, const ReinforceConfig<MB> &c, Engine &eng) {
-    a.kind_ = PolicyKind::Reinforce;
-    a.policy_opt_ = c.optimizer_config.build_optimizer(*a.policy_, eng);
-  }
-  template <typename MB>
-  static void build_critic(ActorCriticAgent &a, const ValuesOptConfig<MB> &c, EnvLanes &env, Engine &eng, uint64_t seed) {
-    a.critic_ = c.state_value_fn_config.build_module(eng, env.num_observation_features(), 1, seed);
-    a.critic_opt_ = c.optimizer_config.build_optimizer(*a.critic_, eng);
-    a.critic_steps_ = c.opt_steps_per_update;
-    a.gae_lambda_ = c.gae_lambda;
-    a.critic_target_ = c.target;
-    const double g = env.discount_factor() < c.max_discount_factor ? env.discount_factor() : c.max_discount_factor;
-    a.gamma_ = (float)g;  // critics/opt.rs:73
-  }
-  static void build_critic(ActorCriticAgent &a, const RewardToGoConfig &, EnvLanes &env, Engine &, uint64_t) {
-    a.gamma_ = (float)env.discount_factor();  // critics/rtg.rs:14-20
   }
 };
 
@@ -496,10 +681,7 @@ std::unique_ptr<DqnAgent> build_dqn_agent(const DqnConfig<VB> &c, EnvLanes &env,
 
 class DqnAgent {
  public:
-  ~DqnAgent() {
-    rl_dqn_destroy(dqn_);
-    rl_adam_destroy(opt_);
-  }
+  ~DqnAgent() { rl_dqn_destroy(dqn_); }  // before the optimizer and the module it refers to
   Module &action_value_fn() { return *q_; }
   struct Bound { uint64_t min_steps, slack_steps; };
   Bound min_update_size() const {  // dqn.rs:207-209
@@ -537,7 +719,7 @@ class DqnAgent {
   explicit DqnAgent(Engine &eng) : eng_(eng) {}
   Engine &eng_;
   std::unique_ptr<Module> q_;
-  rl_adam *opt_ = nullptr;
+  std::unique_ptr<Optimizer> opt_;
   rl_dqn *dqn_ = nullptr;
   uint64_t n_lanes_ = 0, global_steps_ = 0;
 };
@@ -565,7 +747,7 @@ std::unique_ptr<DqnAgent> build_dqn_agent(const DqnConfig<VB> &c, EnvLanes &env,
   d.update_rest = c.update_rest;
   d.discount_factor = (float)env.discount_factor();
   std::memcpy(d.agent_key, agent_key, sizeof(d.agent_key));
-  check(rl_dqn_create(env.handle(), a->q_->handle(), a->opt_, &d, &a->dqn_), eng.handle());
+  check(rl_dqn_create(env.handle(), a->q_->handle(), a->opt_->handle(), &d, &a->dqn_), eng.handle());
   return a;
 }
 

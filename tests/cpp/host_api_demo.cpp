@@ -92,6 +92,34 @@ int main() {
       log.scalars["global_steps"] = (double)agent->global_steps();
       dump("dqn", log, checksum(agent->action_value_fn().parameters()), 0.0, true);
     }
+    {  // Actor::act, one observation at a time: the scalar actor repeats the device rollout's choices when its Prng
+       // stands at word t of stream `lane` of the env's actor seed
+      const uint64_t n = 64, T = 6, seed_actor = 21;
+      CartPoleLanes env(eng, n, 500, StepLimit::Visible, /*seed_env=*/20, seed_actor);
+      ActorCriticConfig<TrpoConfig<MlpConfig>, RewardToGoConfig> cfg;
+      auto agent = cfg.build_agent(env, 22);
+      DeviceHistory history = agent->buffer(T);
+      agent->collect(env, history);
+      eng.sync();
+      std::vector<float> obs(5 * (T + 1) * n);
+      std::vector<uint8_t> act(T * n);
+      check(rl_traj_read(history.handle(), RL_TRAJ_OBS, obs.data(), obs.size() * sizeof(float)), eng.handle());
+      check(rl_traj_read(history.handle(), RL_TRAJ_ACTION, act.data(), act.size()), eng.handle());
+      std::unique_ptr<Actor> actor = agent->actor(ActorMode::Training);
+      uint64_t checked = 0, mismatches = 0;
+      for (uint64_t t = 0; t < T; ++t)
+        for (uint64_t lane = 0; lane < n; lane += 7) {
+          Prng rng = Prng::seed_from_u64(seed_actor);
+          rng.set_stream(lane);
+          rng.set_word_pos(t);
+          std::vector<float> x(5);
+          for (int d = 0; d < 5; ++d) x[d] = obs[(d * (T + 1) + t) * n + lane];
+          mismatches += actor->act(x, rng) != act[t * n + lane];
+          ++checked;
+        }
+      std::printf(", \"actor\": {\"checked\": %llu, \"mismatches\": %llu}\n", (unsigned long long)checked,
+                  (unsigned long long)mismatches);
+    }
     std::printf("}\n");
     // error behaviour: an unsupported module shape is a BuildAgentError
     try {

@@ -31,7 +31,10 @@ def test_cpp_host_api_compiles_and_links():
     assert os.path.exists(exe)
     hdr = open(os.path.join(ROOT, "relearn_amd", "csrc", "host", "agents.hpp")).read()
     for name in ("BuildAgentError", "StatsLogger", "ActorCriticConfig", "TrpoConfig", "PpoConfig", "ValuesOptConfig",
-                 "DqnConfig", "batch_update", "build_agent", "train_batched", "ActorMode"):
+                 "DqnConfig", "batch_update", "build_agent", "train_batched", "ActorMode", "class Policy", "class Critic",
+                 "class Optimizer", "class TrustRegionOptimizer", "class Actor", "class PolicyActor",
+                 "class Trpo final : public Policy", "class ValuesOpt final : public Critic",
+                 "class ConjugateGradientOptimizer final : public TrustRegionOptimizer"):
         assert name in hdr
 
 
@@ -121,6 +124,8 @@ def test_cpp_host_api_matches_the_ctypes_path(engine):
     assert d["scalars"]["loss"] == ust.loss_last and d["scalars"]["exploration_rate"] == rate
     assert d["scalars"]["global_steps"] == ust.global_steps == steps
     assert d["counters"] == {"sim/ep/count": eps, "sim/step/count": steps}
+    # ---- Actor::act on single observations repeats the batched rollout's actions (same stream words, same arithmetic)
+    assert out["actor"]["checked"] == 6 * 10 and out["actor"]["mismatches"] == 0
 
 
 def build_example():
