@@ -72,6 +72,9 @@ void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 // teacher-forced forward: d_out [A][T][n]; d_succ (may be NULL) [A][T][n]; d_act (may be NULL) activation record
 void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,
                             const int32_t *d_skip = nullptr);
+// kernels_seq_train.hip: the GRU chain's training passes with the recurrence on the bf16 matrix pipe
+void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
+void launch_gru_train_recur_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip);
 void launch_seq_gae(rl_traj *traj, float gamma, float lambda);
 void launch_seq_value_targets(rl_traj *traj, float gamma);  // one-step TD targets from traj->seq.out / succ -> d.tgt  // reads traj->seq.out / succ (plane 0)
 void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi,

@@ -927,6 +927,12 @@ void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, floa
   hipLaunchKernelGGL((k_gru_seq_forward<5, AA, CELL>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d, \
                      mod->d_params, d_out, d_succ, d_act, d_skip)
   const bool lstm = mod->kind == RL_MODULE_LSTM_MLP;
+  // training forward of the GRU chain (activation record, no successor evaluations): the bf16-pipe kernels of
+  // kernels_seq_train.hip; kernel variant 1 keeps the f32 cell for A/B runs
+  if (!lstm && d_act != nullptr && d_succ == nullptr && traj->eng->kernel_variant != 1) {
+    launch_gru_train_forward(traj, mod, d_out, d_act, d_skip);
+    return;
+  }
   if (mod->out_dim == 2) {
     if (lstm) FWD(2, LstmCell16);
     else FWD(2, GruCell16);

@@ -664,16 +664,22 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   const bool lstm = mod->kind == RL_MODULE_LSTM_MLP;
   {
     ProfScope ps(e, RL_K_BACKWARD);
-    if (lstm) {
+    const bool split_head = lstm || e->kernel_variant != 1;  // the head's backward as its own block-parallel kernel
+    if (split_head) {
       const uint32_t grid = blocks < 2048 ? blocks : 2048;
+      const int NG = lstm ? 4 : 3;
       if (mod->out_dim == 2)
-        hipLaunchKernelGGL(k_seq_head_backward<2>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, 4,
+        hipLaunchKernelGGL(k_seq_head_backward<2>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, NG,
                            traj->dz, q.act, q.dpre, q.tiles, blocks, d_skip);
       else
-        hipLaunchKernelGGL(k_seq_head_backward<1>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, 4,
+        hipLaunchKernelGGL(k_seq_head_backward<1>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, NG,
                            traj->dz, q.act, q.dpre, q.tiles, blocks, d_skip);
+    }
+    if (lstm) {
       hipLaunchKernelGGL(k_lstm_bptt, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5,
                          (int)mod->out_dim, q.act, q.dpre, d_skip);
+    } else if (split_head) {
+      launch_gru_train_recur_backward(traj, mod, d_skip);  // kernels_seq_train.hip: the recurrence on the bf16 pipe
     } else if (mod->out_dim == 2) {
       hipLaunchKernelGGL(k_gru_bptt<2>, dim3(q.tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, traj->dz,
                          q.act, q.dpre, d_skip);
