@@ -1109,7 +1109,8 @@ void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
   if (training && q.P < mod->P) {
     dfree(q.wg_slab);
     q.wg_slab = nullptr;
-    q.wg_slab = dalloc<float>((size_t)q.chunks * mod->P);
+    // + the rows of the head kernel (head columns) and of the backward recurrence (one per tile, input-side columns)
+    q.wg_slab = dalloc<float>((size_t)(q.chunks + (q.tiles > RL_SEQ_HEAD_ROWS ? q.tiles : RL_SEQ_HEAD_ROWS)) * mod->P);
     q.P = mod->P;
     // the P-sized vectors of the update workspace grow with the module
     if (t->Pmax < mod->P) {

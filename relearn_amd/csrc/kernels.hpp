@@ -74,7 +74,10 @@ void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, floa
                             const int32_t *d_skip = nullptr);
 // kernels_seq_train.hip: the GRU chain's training passes with the recurrence on the bf16 matrix pipe
 void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
+void launch_gru_train_head_backward(rl_traj *traj, const rl_mlp *mod, float *d_slab, const int32_t *d_skip);
 void launch_gru_train_recur_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip);
+void launch_gru_train_wgrad(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip);
+constexpr uint32_t RL_SEQ_HEAD_ROWS = 512;  // rows of head-gradient partials behind the weight-gradient kernel's chunks
 void launch_seq_gae(rl_traj *traj, float gamma, float lambda);
 void launch_seq_value_targets(rl_traj *traj, float gamma);  // one-step TD targets from traj->seq.out / succ -> d.tgt  // reads traj->seq.out / succ (plane 0)
 void launch_seq_policy_dlogits(rl_traj *traj, int mode, uint64_t B_total, float clip_lo, float clip_hi,

@@ -609,13 +609,28 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
 }
 
 // rows of f32 partials -> one f32 vector, accumulated in f64 in a fixed order: 64 columns per workgroup, the rows dealt
-// round-robin to 16 thread groups (eight loads in flight each), the 16 partial sums added in group order
-__global__ void __launch_bounds__(1024) k_seq_reduce(const float *__restrict__ slab, uint32_t rows, uint32_t P,
-                                                     float *__restrict__ vec) {
+// round-robin to 16 thread groups (eight loads in flight each), the 16 partial sums added in group order.  The columns
+// may come from different producers: segment s covers columns [col0, col1) with `rows` rows of P floats at `base`.
+struct SeqReduceSegs {
+  static constexpr int MAX = 8;
+  int n;
+  uint32_t col0[MAX], col1[MAX], rows[MAX];
+  const float *base[MAX];
+};
+__global__ void __launch_bounds__(1024) k_seq_reduce(SeqReduceSegs segs, uint32_t P, float *__restrict__ vec) {
   __shared__ double part[16][64];
   const uint32_t c = threadIdx.x & 63, grp = threadIdx.x >> 6, p = blockIdx.x * 64 + c;
+  const float *__restrict__ slab = nullptr;
+  uint32_t rows = 0;
+#pragma unroll
+  for (int k = 0; k < SeqReduceSegs::MAX; ++k)
+    if (k < segs.n && p >= segs.col0[k] && p < segs.col1[k]) {
+      slab = segs.base[k];
+      rows = segs.rows[k];
+    }
   double s = 0.0;
-  if (p < P) {
+  const bool live = slab != nullptr;
+  if (live) {
     uint32_t r = grp;
     for (; r + 7 * 16 < rows; r += 8 * 16) {
       float v[8];
@@ -628,7 +643,7 @@ __global__ void __launch_bounds__(1024) k_seq_reduce(const float *__restrict__ s
   }
   part[grp][c] = s;
   __syncthreads();
-  if (grp == 0 && p < P) {
+  if (grp == 0 && live) {
     double t = part[0][c];
 #pragma unroll
     for (int q = 1; q < 16; ++q) t += part[q][c];
@@ -662,10 +677,13 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   const SeqDev &q = traj->seq;
   uint32_t P = (uint32_t)mod->P, blocks = traj->d.T * q.tiles;
   const bool lstm = mod->kind == RL_MODULE_LSTM_MLP;
+  const bool gru_head = !lstm && e->kernel_variant != 1;  // kernels_seq_train.hip
   {
     ProfScope ps(e, RL_K_BACKWARD);
     const bool split_head = lstm || e->kernel_variant != 1;  // the head's backward as its own block-parallel kernel
-    if (split_head) {
+    if (gru_head) {
+      launch_gru_train_head_backward(traj, mod, q.wg_slab + (size_t)q.chunks * P, d_skip);  // + the head's weight gradients
+    } else if (split_head) {
       const uint32_t grid = blocks < 2048 ? blocks : 2048;
       const int NG = lstm ? 4 : 3;
       if (mod->out_dim == 2)
@@ -697,6 +715,8 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
       if (lstm) {
         WG(2, 4, 0, 2, true);
         WG(2, 4, 2, 2, false);
+      } else if (gru_head) {
+        launch_gru_train_wgrad(traj, mod, d_skip);
       } else {
         WG(2, 3, 0, 3, true);
       }
@@ -704,6 +724,8 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
       if (lstm) {
         WG(1, 4, 0, 2, true);
         WG(1, 4, 2, 2, false);
+      } else if (gru_head) {
+        launch_gru_train_wgrad(traj, mod, d_skip);
       } else {
         WG(1, 3, 0, 3, true);
       }
@@ -712,6 +734,28 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   }
   {
     ProfScope ps(e, RL_K_REDUCE);
-    hipLaunchKernelGGL(k_seq_reduce, dim3(cdiv_s(P, 64)), dim3(1024), 0, e->stream, q.wg_slab, q.chunks, P, traj->vec);
+    SeqReduceSegs segs{};
+    auto seg = [&](uint32_t c0, uint32_t c1, const float *base, uint32_t rows) {
+      segs.col0[segs.n] = c0;
+      segs.col1[segs.n] = c1;
+      segs.base[segs.n] = base;
+      segs.rows[segs.n] = rows;
+      segs.n += 1;
+    };
+    if (gru_head) {
+      // kernels_seq_train.hip: W_hh, the r / z rows of W_ih and b_ih, and b_hh from the weight-gradient kernel's rows;
+      // the n rows of W_ih and b_ih from the backward recurrence's rows (one per tile); the head from the head kernel's
+      const uint32_t oWhh = 3 * GH * 5, obih = oWhh + 3 * GH * GH, obhh = obih + 3 * GH, oW1 = obhh + 3 * GH;
+      const float *extra = q.wg_slab + (size_t)q.chunks * P;
+      seg(0, 2 * GH * 5, q.wg_slab, q.chunks);
+      seg(2 * GH * 5, oWhh, extra, q.tiles);
+      seg(oWhh, obih + 2 * GH, q.wg_slab, q.chunks);
+      seg(obih + 2 * GH, obhh, extra, q.tiles);
+      seg(obhh, oW1, q.wg_slab, q.chunks);
+      seg(oW1, P, extra, RL_SEQ_HEAD_ROWS);
+    } else {
+      seg(0, P, q.wg_slab, q.chunks);
+    }
+    hipLaunchKernelGGL(k_seq_reduce, dim3(cdiv_s(P, 64)), dim3(1024), 0, e->stream, segs, P, traj->vec);
   }
 }

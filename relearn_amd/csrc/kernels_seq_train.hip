@@ -288,11 +288,14 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 //   d h_prev = dh z + W_hh[r]^T d pre_r + W_hh[z]^T d pre_z + W_hh[n]^T d gh_n          (K = 384 on the matrix pipe)
 // and writes the four per-step arrays the weight-gradient GEMMs read.
 __global__ void __launch_bounds__(W16 * 64, 2)
-    k_gru_recur_bwd(TrajDev tr, const float *__restrict__ params, int D, int A, const float *__restrict__ act,
-                    float *__restrict__ dpre, const int32_t *__restrict__ skip) {
+    k_gru_recur_bwd(TrajDev tr, const float *__restrict__ params, int A, const float *__restrict__ act,
+                    float *__restrict__ dpre, float *__restrict__ slab, uint32_t P,
+                    const int32_t *__restrict__ skip) {
+  constexpr int D = 5;
   constexpr int KB = 3 * GH / 32, KBL = 3;  // k-blocks of the K = 384 product; the last KBL keep their weights in LDS
   __shared__ __attribute__((aligned(16))) unsigned short gP[3][TL][GROW];  // gate gradients as pieces, [sample][gate unit]
   __shared__ uint4 wTS[KBL][3][W16][64];  // 72 KB: 36 registers the budget does not have
+  __shared__ float xS[2][TL][8];          // observation features by step parity (the input side's weight gradients)
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
@@ -317,7 +320,16 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   struct StepIn {
     f32x4 r[2], z[2], n[2], ghn[2], hp[2], da1[2];
     uint32_t end[2];  // four flag bytes
+    float x;          // threads < TL * D: feature (tid / TL) of sample (tid % TL) of the step BEFORE (published a step
+                      // ahead, so that the sums need no barrier of their own)
   };
+  // input side of the n gate (dW_ih[n], db_ih[n]) for this lane's unit: sums of d pre_n over its eight samples of every
+  // step — d pre_n exists only here (the hidden side stores d pre_n r), so it never goes to HBM; the other gates' input
+  // side equals their hidden side and is summed where those arrays are staged (k_gru_wgrad_bf16)
+  float dwin[D], dbin = 0.0f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) dwin[d] = 0.0f;
+  const size_t plane = (size_t)(T + 1) * N;
   const uint32_t lo = (uint32_t)(j * TL + 4 * g4);  // + 16 mt: first of the lane's four contiguous samples (32-bit
                                                     // offsets from a uniform block base: no 64-bit address registers)
   auto load = [&](StepIn &in, uint32_t t) {
@@ -335,18 +347,25 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       in.da1[mt] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + o);
       in.end[mt] = *reinterpret_cast<const uint32_t *>(tr.flag + ((size_t)t * N + lane0) + (uint32_t)(16 * mt + 4 * g4));
     }
+    if (threadIdx.x < TL * D && t > 0)
+      in.x = tr.obs[(size_t)(threadIdx.x / TL) * plane + (size_t)(t - 1) * N + lane0 + (threadIdx.x % TL)];
   };
   StepIn in;
+  if (threadIdx.x < TL * D)
+    xS[(T - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] =
+        tr.obs[(size_t)(threadIdx.x / TL) * plane + (size_t)(T - 1) * N + lane0 + (threadIdx.x % TL)];
   load(in, T - 1);
+  __syncthreads();
   f32x4 dhc[2];
   dhc[0] = dhc[1] = (f32x4){0, 0, 0, 0};
   for (uint32_t t = T; t-- > 0;) {
     float *__restrict__ db = dpre + ((size_t)t * tiles + tile) * DPRE_ARR * GH * TL;
     f32x4 acc[2];  // d h_prev: starts as the direct term dh z, then the K = 384 product is added (two interleaved
                    // chains keep the matrix pipe at full rate)
+    if (threadIdx.x < TL * D && t > 0) xS[(t - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] = in.x;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      f32x4 grv, gzv, dpnv, gnrv;
+      f32x4 grv, gzv, gnrv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = 16 * mt + 4 * g4 + i;
@@ -360,8 +379,10 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         grv[i] = dr * rr * (1.0f - rr);
         gzv[i] = dzg * zz * (1.0f - zz);
         gnrv[i] = dpn * rr;
-        dpnv[i] = dpn;
         acc[mt][i] = dh * zz;
+        dbin += dpn;
+#pragma unroll
+        for (int d = 0; d < D; ++d) dwin[d] = __builtin_fmaf(dpn, xS[t & 1][m][d], dwin[d]);
         const float gv[3] = {grv[i], gzv[i], gnrv[i]};
 #pragma unroll
         for (int gte = 0; gte < 3; ++gte) {
@@ -375,8 +396,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       const uint32_t o = lo + 16 * mt;
       *reinterpret_cast<f32x4 *>(db + (uint32_t)(0 * GH * TL) + o) = grv;
       *reinterpret_cast<f32x4 *>(db + (uint32_t)(1 * GH * TL) + o) = gzv;
-      *reinterpret_cast<f32x4 *>(db + (uint32_t)(2 * GH * TL) + o) = dpnv;
-      *reinterpret_cast<f32x4 *>(db + (uint32_t)(3 * GH * TL) + o) = gnrv;
+      *reinterpret_cast<f32x4 *>(db + (uint32_t)(3 * GH * TL) + o) = gnrv;  // (array 2, d pre_n, stays on chip)
     }
     if (t > 0) load(in, t - 1);  // lands under the products below
     __syncthreads();  // the image of step t is complete
@@ -407,6 +427,319 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     dhc[1] = acc[1];
     __syncthreads();  // every wave has read the image: step t - 1 may overwrite it
   }
+  // ---- this tile's row of partials: the n gate's rows of W_ih and b_ih (the four lane groups of a wave hold
+  // different samples of the same unit)
+  float *__restrict__ out = slab + (size_t)tile * P;
+  const size_t obih = (size_t)3 * GH * D + (size_t)3 * GH * GH;
+  auto over_groups = [](float v) {
+    v = v + __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+  };
+  const int row = 2 * GH + j;
+  dbin = over_groups(dbin);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float v = over_groups(dwin[d]);
+    if (g4 == 0) out[(size_t)row * D + d] = v;
+  }
+  if (g4 == 0) out[obih + row] = dbin;
+}
+
+// ---------------------------------------------------------------- head backward, all blocks in parallel, with the
+// head's own weight gradients.  Per (step, tile) block:
+//   d u_pre = [u > 0] W2^T dz                       (VALU; kept in LDS, never written to HBM)
+//   d relu(h') = [relu(h') > 0] W1^T d u_pre        (matrix cores)  -> dpre[DPRE_DA1], the backward recurrence's input
+//   dW1 += d u_pre^T relu(h')  (matrix cores, contraction over the block's 32 samples),  db1 += d u_pre,
+//   dW2 += dz^T u,  db2 += dz                       (VALU)
+// so the weight-gradient kernel of the recurrence reads neither u, relu(h') nor d u_pre.  A workgroup walks blocks
+// blk = blockIdx.x, + gridDim.x, ... and writes one row of f32 partials (head columns only) for the f64 reduction.
+constexpr int HLS = TL + 20;  // LDS row stride (floats) of the [unit][sample] operand images: 16-byte aligned rows, and
+                              // 16 consecutive rows at a fixed column hit 16 different banks (52 r mod 64)
+template <int A>
+__global__ void __launch_bounds__(W16 * 64, 2)
+    k_gru_head_backward(TrajDev tr, const float *__restrict__ params, int D, const float *__restrict__ dz,
+                        const float *__restrict__ act, float *__restrict__ dpre, float *__restrict__ slab, uint32_t P,
+                        uint32_t tiles, uint32_t blocks, const int32_t *__restrict__ skip) {
+  __shared__ __attribute__((aligned(16))) float bufA[GH][HLS];  // relu(h'), [unit][sample]
+  __shared__ __attribute__((aligned(16))) float bufU[GH][HLS];  // d u_pre,  [unit][sample]
+  __shared__ float dzS[2][TL];
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
+  const uint32_t N = tr.n, T = tr.T;
+  const size_t B = (size_t)T * N;
+  const GruParams g = gru_params(params, D, A);
+  float w1T[MH / 4], w2c[A];
+#pragma unroll
+  for (int ks = 0; ks < MH / 4; ++ks) w1T[ks] = g.W1[(size_t)(4 * ks + g4) * GH + j];
+#pragma unroll
+  for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
+  f32x4 accw[GH / 16];  // dW1[16 wave + 4 g4 + i][16 nt + n16]
+#pragma unroll
+  for (int nt = 0; nt < GH / 16; ++nt) accw[nt] = (f32x4){0, 0, 0, 0};
+  float db1 = 0.0f, dw2[A], db2 = 0.0f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) dw2[a] = 0.0f;
+  const uint32_t lo = (uint32_t)(j * TL + 4 * g4);
+  f32x4 a1n[2], un[2];
+  float dzn = 0.0f;
+  auto fetch = [&](uint32_t blk) {
+    const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_A1 * GH * TL) + lo + 16 * mt);
+      un[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_U * GH * TL) + lo + 16 * mt);
+    }
+    if (wave == 0 && lane < A * TL) {  // lane = (output a = lane >> 5, sample lane & 31)
+      const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
+      dzn = dz[(size_t)(lane >> 5) * B + (size_t)t * N + lane0 + (lane & 31)];
+    }
+  };
+  if (blockIdx.x < blocks) fetch(blockIdx.x);
+  for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
+    float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
+    __syncthreads();  // the previous block's readers of the LDS images are done
+    if (wave == 0 && lane < A * TL) {
+      dzS[lane >> 5][lane & 31] = dzn;
+      db2 += dzn;
+    }
+    f32x4 a1c[2], uc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      a1c[mt] = a1n[mt];
+      uc[mt] = un[mt];
+      *reinterpret_cast<f32x4 *>(&bufA[j][16 * mt + 4 * g4]) = a1c[mt];
+    }
+    __syncthreads();  // dz of the block is visible
+    if (blk + gridDim.x < blocks) fetch(blk + gridDim.x);  // the next block's operands land under this block's products
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 duv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * mt + 4 * g4 + i;
+        float du = 0.0f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          du = __builtin_fmaf(dzS[a][m], w2c[a], du);
+          dw2[a] = __builtin_fmaf(dzS[a][m], uc[mt][i], dw2[a]);
+        }
+        du = uc[mt][i] > 0.0f ? du : 0.0f;
+        db1 += du;
+        duv[i] = du;
+      }
+      *reinterpret_cast<f32x4 *>(&bufU[j][16 * mt + 4 * g4]) = duv;
+    }
+    __syncthreads();
+    // d relu(h') = W1^T d u_pre: two half-chains per M-tile
+    f32x4 acc1[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc1[mt][0] = acc1[mt][1] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < MH / 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc1[mt][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufU[4 * ks + g4][16 * mt + n16], w1T[ks],
+                                                                acc1[mt][ks & 1], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      f32x4 dav;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dav[i] = a1c[mt][i] > 0.0f ? acc1[mt][0][i] + acc1[mt][1][i] : 0.0f;
+      *reinterpret_cast<f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + lo + 16 * mt) = dav;
+    }
+    // dW1[row][col] += sum over the samples of d u_pre[row][m] relu(h')[col][m]: A rows = this wave's 16 units
+#pragma unroll
+    for (int ks = 0; ks < TL / 4; ++ks) {
+      const float av = bufU[j][4 * ks + g4];
+#pragma unroll
+      for (int nt = 0; nt < GH / 16; ++nt)
+        accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bufA[16 * nt + n16][4 * ks + g4], accw[nt], 0, 0, 0);
+    }
+  }
+  // ---- this workgroup's row of partials (head columns)
+  const size_t oW1 = (size_t)3 * GH * D + (size_t)3 * GH * GH + 6 * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH,
+               ob2 = oW2 + (size_t)A * MH;
+  float *__restrict__ out = slab + (size_t)blockIdx.x * P;
+#pragma unroll
+  for (int nt = 0; nt < GH / 16; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[oW1 + (size_t)(16 * wave + 4 * g4 + i) * GH + 16 * nt + n16] = accw[nt][i];
+  // the four lane groups of a wave hold different samples of the same units
+  db1 = db1 + __shfl_xor(db1, 16, 64);
+  db1 = db1 + __shfl_xor(db1, 32, 64);
+  if (g4 == 0) out[ob1 + j] = db1;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    float v = dw2[a] + __shfl_xor(dw2[a], 16, 64);
+    v = v + __shfl_xor(v, 32, 64);
+    if (g4 == 0) out[oW2 + (size_t)a * MH + j] = v;
+  }
+  if (wave == 0) {
+    float v = lane < A * TL ? db2 : 0.0f;  // half a of the wave holds the per-sample-slot sums of output a
+#pragma unroll
+    for (int s2 = 16; s2 > 0; s2 >>= 1) v += __shfl_xor(v, s2, 64);
+    if ((lane & 31) == 0 && (lane >> 5) < A) out[ob2 + (lane >> 5)] = v;
+  }
+}
+
+// ---------------------------------------------------------------- weight gradients of the recurrence
+// dW_hh[g][k] = sum over (step, lane) of d gh_g . h_prev_k   (g over the 384 gate units: d pre_r, d pre_z, d pre_n r)
+// with the SAMPLE as the contraction index: the records are [unit][lane] rows, so eight consecutive samples of a row
+// are one operand fragment — no transposition.  A workgroup walks a contiguous run of (step, tile) blocks; per block
+// every element is split into its three bf16 pieces ONCE (each thread stages 1/512 of the block) and parked in LDS in
+// operand layout; wave w accumulates output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles,
+// 2 x 9 issues of v_mfma_f32_32x32x16_bf16 per tile and block.  dW_ih, db_ih and db_hh are sums the staging threads
+// keep for the rows they stage (a thread stages the same rows in every block).  One row of f32 partials per
+// workgroup (columns of the recurrent parameters only; the head's come from k_gru_head_backward).
+constexpr int WROW = TL + 8;  // halfwords per row of the [row][sample] piece images: 80-byte rows, 16-byte operand reads
+                              // of 16 consecutive rows hit 64 different banks
+template <int D>
+__global__ void __launch_bounds__(W16 * 64, 2)
+    k_gru_wgrad_bf16(TrajDev tr, const float *__restrict__ act, const float *__restrict__ dpre,
+                     float *__restrict__ slab, uint32_t P, uint32_t tiles, uint32_t blocks, uint32_t blocks_per_chunk,
+                     const int32_t *__restrict__ skip) {
+  __shared__ __attribute__((aligned(16))) unsigned short AP[3][3 * GH][WROW];  // d gh pieces
+  __shared__ __attribute__((aligned(16))) unsigned short BP[3][GH][WROW];      // h_prev pieces
+  __shared__ float xS[TL][8];
+  if (skip != nullptr && *skip != 0) return;
+  const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
+  const int n = lane & 31, hf = lane >> 5;
+  const int nt = wave & 3, mset = wave >> 2;
+  bt::f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // staging: 16-byte piece f = q + 512 i of the three gate arrays (i = 0..5: array i >> 1, row (q >> 3) + 64 (i & 1),
+  // samples 4 (q & 7) .. + 3); h_prev: pieces q and q + 512 (rows (q >> 3) and (q >> 3) + 64)
+  const int srow = q >> 3, scol = 4 * (q & 7);
+  // sums the staging thread keeps for the rows it stages: db_hh (all gates; = db_ih for r and z) and dW_ih of r and z
+  float dwih[2][2][D], dbh[3][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) dbh[g3][h] = 0.0f;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+      for (int d = 0; d < D; ++d) dwih[g2][h][d] = 0.0f;
+  }
+  const uint32_t N = tr.n, T = tr.T;
+  const size_t plane = (size_t)(T + 1) * N;
+  float xn = 0.0f;
+  const uint32_t b0 = blockIdx.x * blocks_per_chunk;
+  const uint32_t b1 = b0 + blocks_per_chunk < blocks ? b0 + blocks_per_chunk : blocks;
+  f32x4 gA[3][2], hB[2];
+  auto fetch = [&](uint32_t blk) {
+    const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
+    const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t o = (uint32_t)((srow + 64 * h) * TL + scol);
+      gA[0][h] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(0 * GH * TL) + o);
+      gA[1][h] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(1 * GH * TL) + o);
+      gA[2][h] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(3 * GH * TL) + o);  // hidden side of the n gate
+      hB[h] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
+    }
+    if (q < TL * D) {  // feature q / TL of sample q % TL
+      const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
+      xn = tr.obs[(size_t)(q / TL) * plane + (size_t)t * N + lane0 + (q % TL)];
+    }
+  };
+  // four samples of one row -> their pieces, 8 bytes into each of the three piece images ([3][rows][WROW], contiguous)
+  auto park = [&](unsigned short (*img)[WROW], int rows, int row, const f32x4 &v) {
+    uint32_t p[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bt::split3(v[i], p[i][0], p[i][1], p[i][2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint64_t w = (uint64_t)bt::pk(p[0][c], p[1][c]) | ((uint64_t)bt::pk(p[2][c], p[3][c]) << 32);
+      *reinterpret_cast<uint64_t *>(&img[c * rows + row][scol]) = w;
+    }
+  };
+  if (b0 < b1) fetch(b0);
+  for (uint32_t blk = b0; blk < b1; ++blk) {
+    __syncthreads();  // the previous block's operand reads are done
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) park(AP[0], 3 * GH, g3 * GH + srow + 64 * h, gA[g3][h]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) park(BP[0], GH, srow + 64 * h, hB[h]);
+    if (q < TL * D) xS[q % TL][q / TL] = xn;
+    f32x4 gi[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      gi[0][h] = gA[0][h];
+      gi[1][h] = gA[1][h];
+#pragma unroll
+      for (int g3 = 0; g3 < 3; ++g3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dbh[g3][h] += gA[g3][h][i];
+    }
+    __syncthreads();
+    if (blk + 1 < b1) fetch(blk + 1);  // lands under this block's products
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int d = 0; d < D; ++d) dwih[g2][h][d] = __builtin_fmaf(gi[g2][h][i], xS[scol + i][d], dwih[g2][h][d]);
+    // products: contraction over the block's 32 samples in two halves of 16
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      Frag fb[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        fb[c].x = *reinterpret_cast<const uint4 *>(&BP[c][32 * nt + n][16 * half + 8 * hf]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        Frag fa[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          fa[c].x = *reinterpret_cast<const uint4 *>(&AP[c][192 * mset + 32 * i + n][16 * half + 8 * hf]);
+#pragma unroll
+        for (int pa = 2; pa >= 0; --pa)
+#pragma unroll
+          for (int pb = 2; pb >= 0; --pb)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa].v, fb[pb].v, acc[i], 0, 0, 0);
+      }
+    }
+  }
+  // ---- this workgroup's row of partials (recurrent columns)
+  float *__restrict__ out = slab + (size_t)blockIdx.x * P;
+  const size_t oWhh = (size_t)3 * GH * D;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      out[oWhh + (size_t)(192 * mset + 32 * i + acc_row(r, hf)) * GH + 32 * nt + n] = acc[i][r];
+  // the eight threads q & 7 of a row hold its partial sums over different samples
+  const size_t obih = oWhh + (size_t)3 * GH * GH, obhh = obih + 3 * GH;
+  auto over8 = [](float v) {
+    v = v + __shfl_xor(v, 1, 64);
+    v = v + __shfl_xor(v, 2, 64);
+    return v + __shfl_xor(v, 4, 64);
+  };
+#pragma unroll
+  for (int g3 = 0; g3 < 3; ++g3)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = g3 * GH + srow + 64 * h;
+      const float vb = over8(dbh[g3][h]);
+      if ((q & 7) == 0) {
+        out[obhh + row] = vb;
+        if (g3 < 2) out[obih + row] = vb;  // (the n gate's input side comes from the backward recurrence)
+      }
+      if (g3 < 2) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const float v = over8(dwih[g3][h][d]);
+          if ((q & 7) == 0) out[(size_t)row * D + d] = v;
+        }
+      }
+    }
 }
 
 }  // namespace
@@ -429,9 +762,34 @@ void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, fl
                        d_act, d_out, tiles, blocks, d_skip);
 }
 
-// backward recurrence of the GRU chain (after k_seq_head_backward has left d u_pre and d relu(h') in seq.dpre)
+// head backward of the GRU chain with the head's weight gradients: rows [0, RL_SEQ_HEAD_ROWS) of `d_slab`
+void launch_gru_train_head_backward(rl_traj *traj, const rl_mlp *mod, float *d_slab, const int32_t *d_skip) {
+  const SeqDev &q = traj->seq;
+  const uint32_t blocks = traj->d.T * q.tiles, grid = blocks < RL_SEQ_HEAD_ROWS ? blocks : RL_SEQ_HEAD_ROWS;
+  if (grid < RL_SEQ_HEAD_ROWS)  // rows no workgroup writes
+    RL_HIP_CHECK(hipMemsetAsync(d_slab + (size_t)grid * mod->P, 0, (size_t)(RL_SEQ_HEAD_ROWS - grid) * mod->P * sizeof(float),
+                                traj->eng->stream));
+  if (mod->out_dim == 2)
+    hipLaunchKernelGGL(k_gru_head_backward<2>, dim3(grid), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params,
+                       5, traj->dz, q.act, q.dpre, d_slab, (uint32_t)mod->P, q.tiles, blocks, d_skip);
+  else
+    hipLaunchKernelGGL(k_gru_head_backward<1>, dim3(grid), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params,
+                       5, traj->dz, q.act, q.dpre, d_slab, (uint32_t)mod->P, q.tiles, blocks, d_skip);
+}
+
+// weight gradients of the recurrent parameters: rows [0, chunks) of seq.wg_slab, columns [0, W1)
+void launch_gru_train_wgrad(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip) {
+  const SeqDev &q = traj->seq;
+  const uint32_t blocks = traj->d.T * q.tiles;
+  hipLaunchKernelGGL(k_gru_wgrad_bf16<5>, dim3(q.chunks), dim3(W16 * 64), 0, traj->eng->stream, traj->d, q.act, q.dpre,
+                     q.wg_slab, (uint32_t)mod->P, q.tiles, blocks, q.blocks_per_chunk, d_skip);
+}
+
+// backward recurrence of the GRU chain (after the head's backward has left d relu(h') in seq.dpre)
 void launch_gru_train_recur_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip) {
   const SeqDev &q = traj->seq;
-  hipLaunchKernelGGL(k_gru_recur_bwd, dim3(q.tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params, 5,
-                     (int)mod->out_dim, q.act, q.dpre, d_skip);
+  // its W_ih / b_ih / b_hh partials: one row per tile behind the weight-gradient kernel's rows (the head kernel uses
+  // the head columns of the same rows)
+  hipLaunchKernelGGL(k_gru_recur_bwd, dim3(q.tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params,
+                     (int)mod->out_dim, q.act, q.dpre, q.wg_slab + (size_t)q.chunks * mod->P, (uint32_t)mod->P, d_skip);
 }

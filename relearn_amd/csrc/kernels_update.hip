@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
                                                   double beta1, double beta2, double eps, double weight_decay,
                                                   const float *__restrict__ loss_sum, double inv_B,
                                                   float *__restrict__ loss_out) {
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     *step_ptr = step;
     if (loss_out) *loss_out = (float)((double)(*loss_sum) * inv_B);
   }
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
   float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   float epsf = (float)eps;
   float wd = (float)weight_decay;
-  for (uint32_t i = threadIdx.x; i < P; i += SB) {
+  for (uint32_t i = blockIdx.x * SB + threadIdx.x; i < P; i += gridDim.x * SB) {  // (elementwise: any grid)
     float g = grad[i];
     if (weight_decay != 0.0) g = g + wd * params[i];
     float mi = m[i] * b1 + omb1 * g;
@@ -743,7 +743,7 @@ void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_tot
   uint32_t P = (uint32_t)opt->mod->P;
   float neg_step_size, sqrt_bc2;
   adam_next_step(opt, &neg_step_size, &sqrt_bc2);
-  hipLaunchKernelGGL(k_adam_step, dim3(1), dim3(SB), 0, traj->eng->stream, opt->mod->d_params, traj->vec, opt->d_m,
+  hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, traj->eng->stream, opt->mod->d_params, traj->vec, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, traj->vec + P, 1.0 / (double)B_total,
                      loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr);
@@ -754,7 +754,7 @@ void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
   uint32_t P = (uint32_t)opt->mod->P;
   float neg_step_size, sqrt_bc2;
   adam_next_step(opt, &neg_step_size, &sqrt_bc2);
-  hipLaunchKernelGGL(k_adam_step, dim3(1), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
+  hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr);
 }
