@@ -32,6 +32,9 @@ namespace {
 
 using bt::Frag;
 
+#ifndef RL_SEQ_VALU_PER_MFMA
+#define RL_SEQ_VALU_PER_MFMA 5
+#endif
 constexpr int HROW = GH + 8;      // halfwords per row of a [sample][unit] piece image: 272-byte rows, so the 16-byte
                                   // operand reads of 16 consecutive samples start 4 banks apart
 constexpr int GROW = 3 * GH + 8;  // the backward's [sample][gate unit] rows (784 bytes: the same property)
@@ -54,6 +57,41 @@ __device__ __forceinline__ f32x4 mfma9(const Frag (&a)[3], const Frag (&b)[3], f
 #pragma unroll
     for (int q = 2; q >= 0; --q) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p].v, b[q].v, acc, 0, 0, 0);
   return acc;
+}
+
+// Gate functions of the training forward.  The vector ALU bounds this kernel (0.73 busy, profiles/): the gate
+// arithmetic is written for instruction count — e^y through v_exp_f32 (one quarter-rate instruction instead of a
+// 14-instruction range reduction and polynomial), quotients through v_rcp_f32 and one Newton step (6 instructions
+// instead of the 10 of an IEEE division) — and without branches (a branch ends the basic block, and the scheduler
+// interleaves matrix and vector instructions only inside one).  Each result is within 2 ulp of rl_sigmoidf / rl_tanhf
+// (include/rl_detmath.h), which stay in the rollout and evaluation kernels: those are compared bit for bit with the
+// oracle, the training passes within f32 tolerances.
+__device__ __forceinline__ float exp_nonpos_fast(float y) {  // e^y, y <= 0
+  return __builtin_amdgcn_exp2f(y * 1.4426950216e+00f);      // (flushes to 0 below 2^-126: the callers add 1)
+}
+__device__ __forceinline__ float quot_fast(float n, float d) {  // n / d for d in [1, 2]
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  const float q = n * r;
+  return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+__device__ __forceinline__ float sigmoid_sel(float x) {
+  const float t = exp_nonpos_fast(x < 0.0f ? x : -x);
+  return quot_fast(x < 0.0f ? t : 1.0f, 1.0f + t);
+}
+__device__ __forceinline__ float tanh_sel(float x) {
+  const float ax = x < 0.0f ? -x : x;
+  const float x2 = ax * ax;
+  float p = -8.8632355e-03f;
+  p = __builtin_fmaf(x2, p, 2.1869488e-02f);
+  p = __builtin_fmaf(x2, p, -5.3968254e-02f);
+  p = __builtin_fmaf(x2, p, 1.3333334e-01f);
+  p = __builtin_fmaf(x2, p, -3.3333334e-01f);
+  const float small = __builtin_fmaf(ax, x2 * p, ax);
+  const float t = exp_nonpos_fast(-2.0f * ax);
+  const float big = quot_fast(1.0f - t, 1.0f + t);
+  const float y = ax < 0.25f ? small : big;
+  return rl_f32_from_bits(rl_f32_bits(y) | (rl_f32_bits(x) & 0x80000000u));  // odd; NaN in, NaN out
 }
 
 // ---------------------------------------------------------------- forward recurrence
@@ -130,30 +168,30 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     for (int gte = 0; gte < 3; ++gte)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) acc[gte][mt] = (f32x4){bhh[gte], bhh[gte], bhh[gte], bhh[gte]};
-    // operand reads one (k-block, M-tile) ahead of the products, and no further (the scheduler would otherwise
-    // hoist more reads than the register budget holds)
-    auto frags = [&](int it, Frag (&a)[3]) {
-      const int kb = it >> 1, mt = it & 1;
+    // The barrier keeps the two waves of a SIMD in step, so matrix and vector work overlap only INSIDE a wave: the
+    // products of M-tile 1 are issued between the gate arithmetic of M-tile 0 (one basic block, the scheduler
+    // interleaves them); operand reads run one k-block ahead of the products.
+    auto products = [&](int mt) {
+      auto frags = [&](int kb, Frag (&a)[3]) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[p].x = *reinterpret_cast<const uint4 *>(&hP[cur][p][16 * mt + n16][32 * kb + 8 * g4]);
+        for (int p = 0; p < 3; ++p)
+          a[p].x = *reinterpret_cast<const uint4 *>(&hP[cur][p][16 * mt + n16][32 * kb + 8 * g4]);
+      };
+      Frag fa[2][3];
+      frags(0, fa[0]);
+#pragma unroll
+      for (int kb = 0; kb < GH / 32; ++kb) {
+        if (kb + 1 < GH / 32) frags(kb + 1, fa[(kb + 1) & 1]);
+        Frag wn[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wn[q].x = wnS[kb][q][wave][lane];
+#pragma unroll
+        for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma9(fa[kb & 1], wf[gte][kb], acc[gte][mt]);
+        acc[2][mt] = mfma9(fa[kb & 1], wn, acc[2][mt]);
+      }
     };
-    Frag fa[2][3];
-    frags(0, fa[0]);
-#pragma unroll
-    for (int it = 0; it < 2 * (GH / 32); ++it) {
-      if (it + 1 < 2 * (GH / 32)) frags(it + 1, fa[(it + 1) & 1]);
-      Frag wn[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) wn[q].x = wnS[it >> 1][q][wave][lane];
-#pragma unroll
-      for (int gte = 0; gte < 2; ++gte) acc[gte][it & 1] = mfma9(fa[it & 1], wf[gte][it >> 1], acc[gte][it & 1]);
-      acc[2][it & 1] = mfma9(fa[it & 1], wn, acc[2][it & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     float *__restrict__ store = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    auto gates = [&](int mt) {
       // (uniform block base + 32-bit lane offsets: the addresses stay out of the vector registers)
       const uint32_t row = (uint32_t)(j * TL + 16 * mt + 4 * g4);
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_GHN * GH * TL) + row) = acc[2][mt];
@@ -178,10 +216,10 @@ __global__ void __launch_bounds__(W16 * 64, 2)
           for (int d = 0; d < D; ++d) v = __builtin_fmaf(xS[cur][m][d], wih[gte][d], v);
           gi[gte] = v;
         }
-        const float rr = rl_sigmoidf(acc[0][mt][i] + gi[0]);
-        const float zz = rl_sigmoidf(acc[1][mt][i] + gi[1]);
+        const float rr = sigmoid_sel(acc[0][mt][i] + gi[0]);
+        const float zz = sigmoid_sel(acc[1][mt][i] + gi[1]);
         const float rn = acc[2][mt][i] * rr;
-        const float nn = rl_tanhf(gi[2] + rn);
+        const float nn = tanh_sel(gi[2] + rn);
         const float dn = hown[r] - nn;
         const float hz = dn * zz;
         const float hv = hz + nn;
@@ -198,11 +236,27 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         hP[nxt][1][m][j] = (unsigned short)p1;
         hP[nxt][2][m][j] = (unsigned short)p2;
       }
+#ifndef RL_EXP_NO_FWD_STORES
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_R * GH * TL) + row) = rv;
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_Z * GH * TL) + row) = zv;
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_N * GH * TL) + row) = nv;
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
+#else
+      if (rv[0] + zv[1] + nv[2] + av[3] == 1234.5f) store[row] = 0.0f;
+#endif
+    };
+    products(0);
+    __builtin_amdgcn_sched_barrier(0);
+    products(1);
+    gates(0);
+    // the order asked of the scheduler for this region: one matrix instruction, then a few vector instructions, ...
+#pragma unroll
+    for (int k = 0; k < (GH / 32) * 27; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, RL_SEQ_VALU_PER_MFMA, 0);  // VALU
     }
+    __builtin_amdgcn_sched_barrier(0);
+    gates(1);
     if (io_lane && t + 1 < T) publish(nxt);
     __syncthreads();  // one barrier per step: the images of step t + 1 are complete, those of step t are free
   }
