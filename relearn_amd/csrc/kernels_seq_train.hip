@@ -263,14 +263,14 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 }
 
 // ---------------------------------------------------------------- head forward, all (step, tile) blocks in parallel
-// u = relu(b1 + W1 relu(h')) on the matrix cores (A operand: the recorded relu(h') block, [unit][lane] rows = the
-// [k][m] layout of a 16x16x4 A operand), recorded for the backward; out_a = b2_a + sum_q u_q W2[a][q] as 8 partial
-// sums of 16 terms per (sample, output), joined by a shuffle tree.
+// u = relu(b1 + W1 relu(h')) on the bf16 pipe (A operand: the recorded relu(h') block, split into its pieces and laid
+// out [sample][unit] in LDS; B: this wave's 16 rows of W1 as register fragments), recorded for the backward;
+// out_a = b2_a + sum_q u_q W2[a][q] as 8 partial sums of 16 terms per (sample, output), joined by a shuffle tree.
 template <int A>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_seq_head_forward(TrajDev tr, const float *__restrict__ params, int D, int NG, float *__restrict__ act,
                        float *__restrict__ out, uint32_t tiles, uint32_t blocks, const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) float bufA[GH][TLS];
+  __shared__ __attribute__((aligned(16))) unsigned short aK[3][TL][HROW];
   __shared__ float uS[TL][MH + 1];
   __shared__ float w2S[2][MH];
   if (skip != nullptr && *skip != 0) return;
@@ -278,38 +278,57 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const GruParams g = seq_params(params, D, A, NG);
-  float w1[GH / 4];
+  Frag w1f[GH / 32][3];  // W1[j][32 kb + 8 g4 + 0..7]
 #pragma unroll
-  for (int ks = 0; ks < GH / 4; ++ks) w1[ks] = g.W1[(size_t)j * GH + 4 * ks + g4];
+  for (int kb = 0; kb < GH / 32; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = g.W1[(size_t)j * GH + 32 * kb + 8 * g4 + i];
+    frags_of8(v, w1f[kb]);
+  }
   const float b1 = g.b1[j];
   for (int q = threadIdx.x; q < A * MH; q += W16 * 64) w2S[q / MH][q % MH] = g.W2[q];
   const int hs = 4 * wave + g4, ha = (lane >> 3) & 1, hc = lane & 7;  // head: sample, output, 16-term chunk
   const float b2v = ha < A ? g.b2[ha] : 0.0f;
-  const size_t lo = (size_t)j * TL + 4 * g4;
+  const uint32_t lo = (uint32_t)(j * TL + 4 * g4);
   f32x4 a1n[2];
   auto fetch = [&](uint32_t blk) {
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
-      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + lo + 16 * mt);
+      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_A1 * GH * TL) + lo + 16 * mt);
   };
   if (blockIdx.x < blocks) fetch(blockIdx.x);
   for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
     const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
     float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
-    __syncthreads();  // the previous block's readers of bufA / uS are done
+    __syncthreads();  // the previous block's readers of aK / uS are done
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4 *>(&bufA[j][16 * mt + 4 * g4]) = a1n[mt];
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t p0, p1, p2;
+        bt::split3(a1n[mt][i], p0, p1, p2);
+        const int m = 16 * mt + 4 * g4 + i;
+        aK[0][m][j] = (unsigned short)p0;
+        aK[1][m][j] = (unsigned short)p1;
+        aK[2][m][j] = (unsigned short)p2;
+      }
     if (blk + gridDim.x < blocks) fetch(blk + gridDim.x);  // the next block's operand lands under this block's products
     __syncthreads();
     f32x4 acc1[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) acc1[mt] = (f32x4){b1, b1, b1, b1};
 #pragma unroll
-    for (int ks = 0; ks < GH / 4; ++ks)
+    for (int kb = 0; kb < GH / 32; ++kb)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[4 * ks + g4][16 * mt + n16], w1[ks], acc1[mt], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt) {
+        Frag fa[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          fa[c].x = *reinterpret_cast<const uint4 *>(&aK[c][16 * mt + n16][32 * kb + 8 * g4]);
+        acc1[mt] = mfma9(fa, w1f[kb], acc1[mt]);
+      }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       f32x4 uv;
@@ -319,7 +338,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         uS[acc16_row(mt, i, g4)][j] = u;
         uv[i] = u;
       }
-      *reinterpret_cast<f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + 16 * mt) = uv;
+      *reinterpret_cast<f32x4 *>(ab + (uint32_t)(ACT_U * GH * TL) + lo + 16 * mt) = uv;
     }
     __syncthreads();
     float part = 0.0f;
@@ -501,21 +520,27 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 
 // ---------------------------------------------------------------- head backward, all blocks in parallel, with the
 // head's own weight gradients.  Per (step, tile) block:
-//   d u_pre = [u > 0] W2^T dz                       (VALU; kept in LDS, never written to HBM)
-//   d relu(h') = [relu(h') > 0] W1^T d u_pre        (matrix cores)  -> dpre[DPRE_DA1], the backward recurrence's input
-//   dW1 += d u_pre^T relu(h')  (matrix cores, contraction over the block's 32 samples),  db1 += d u_pre,
-//   dW2 += dz^T u,  db2 += dz                       (VALU)
+//   d u_pre = [u > 0] W2^T dz                       (VALU; stays on chip)
+//   d relu(h') = [relu(h') > 0] d u_pre W1          (contraction over the 128 units of u: K = 128 x 9 piece pairs)
+//                                                   -> dpre[DPRE_DA1], the backward recurrence's input
+//   dW1 += d u_pre^T relu(h')                       (contraction over the block's 32 samples: one issue per tile and pair)
+//   db1 += d u_pre,  dW2 += dz^T u,  db2 += dz      (VALU)
+// Both products run on the bf16 pipe with exact three-piece operands (the f32 form kept this kernel at 0.68 of the f32
+// matrix rate with the VALU blocked under it).  Three piece images per block in LDS:
+//   uJ [sample][unit]  d u_pre with the unit contiguous  (A operand of the first product)
+//   uM [unit][sample]  d u_pre with the sample contiguous (A operand of the second)
+//   aM [unit][sample]  relu(h')                           (B operand of the second)
 // so the weight-gradient kernel of the recurrence reads neither u, relu(h') nor d u_pre.  A workgroup walks blocks
 // blk = blockIdx.x, + gridDim.x, ... and writes one row of f32 partials (head columns only) for the f64 reduction.
-constexpr int HLS = TL + 20;  // LDS row stride (floats) of the [unit][sample] operand images: 16-byte aligned rows, and
-                              // 16 consecutive rows at a fixed column hit 16 different banks (52 r mod 64)
 template <int A>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_head_backward(TrajDev tr, const float *__restrict__ params, int D, const float *__restrict__ dz,
                         const float *__restrict__ act, float *__restrict__ dpre, float *__restrict__ slab, uint32_t P,
                         uint32_t tiles, uint32_t blocks, const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) float bufA[GH][HLS];  // relu(h'), [unit][sample]
-  __shared__ __attribute__((aligned(16))) float bufU[GH][HLS];  // d u_pre,  [unit][sample]
+  constexpr int MROW = TL + 8;  // halfwords per row of the [unit][sample] images (80-byte rows)
+  __shared__ __attribute__((aligned(16))) unsigned short uJ[3][TL][HROW];
+  __shared__ __attribute__((aligned(16))) unsigned short uM[3][MH][MROW];
+  __shared__ __attribute__((aligned(16))) unsigned short aM[3][GH][MROW];
   __shared__ float dzS[2][TL];
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -523,9 +548,15 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const uint32_t N = tr.n, T = tr.T;
   const size_t B = (size_t)T * N;
   const GruParams g = gru_params(params, D, A);
-  float w1T[MH / 4], w2c[A];
+  Frag w1f[MH / 32][3];  // B operand of d relu(h'): W1[32 kb + 8 g4 + 0..7][j] (rows: units of u; column: this lane's k)
 #pragma unroll
-  for (int ks = 0; ks < MH / 4; ++ks) w1T[ks] = g.W1[(size_t)(4 * ks + g4) * GH + j];
+  for (int kb = 0; kb < MH / 32; ++kb) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = g.W1[(size_t)(32 * kb + 8 * g4 + i) * GH + j];
+    frags_of8(v, w1f[kb]);
+  }
+  float w2c[A];
 #pragma unroll
   for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
   f32x4 accw[GH / 16];  // dW1[16 wave + 4 g4 + i][16 nt + n16]
@@ -549,6 +580,16 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       dzn = dz[(size_t)(lane >> 5) * B + (size_t)t * N + lane0 + (lane & 31)];
     }
   };
+  // four consecutive samples of this lane's unit -> 8 bytes of each piece image [unit][sample]
+  auto park4 = [&](unsigned short (*img)[MH][MROW], int col, const f32x4 &v) {
+    uint32_t p[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bt::split3(v[i], p[i][0], p[i][1], p[i][2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      *reinterpret_cast<uint64_t *>(&img[c][j][col]) =
+          (uint64_t)bt::pk(p[0][c], p[1][c]) | ((uint64_t)bt::pk(p[2][c], p[3][c]) << 32);
+  };
   if (blockIdx.x < blocks) fetch(blockIdx.x);
   for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
     float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
@@ -562,7 +603,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     for (int mt = 0; mt < 2; ++mt) {
       a1c[mt] = a1n[mt];
       uc[mt] = un[mt];
-      *reinterpret_cast<f32x4 *>(&bufA[j][16 * mt + 4 * g4]) = a1c[mt];
+      park4(aM, 16 * mt + 4 * g4, a1c[mt]);
     }
     __syncthreads();  // dz of the block is visible
     if (blk + gridDim.x < blocks) fetch(blk + gridDim.x);  // the next block's operands land under this block's products
@@ -581,34 +622,47 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         du = uc[mt][i] > 0.0f ? du : 0.0f;
         db1 += du;
         duv[i] = du;
+        uint32_t p0, p1, p2;
+        bt::split3(du, p0, p1, p2);
+        uJ[0][m][j] = (unsigned short)p0;
+        uJ[1][m][j] = (unsigned short)p1;
+        uJ[2][m][j] = (unsigned short)p2;
       }
-      *reinterpret_cast<f32x4 *>(&bufU[j][16 * mt + 4 * g4]) = duv;
+      park4(uM, 16 * mt + 4 * g4, duv);
     }
     __syncthreads();
-    // d relu(h') = W1^T d u_pre: two half-chains per M-tile
-    f32x4 acc1[2][2];
+    // d relu(h')[m][k = j] = sum over the units q of d u_pre[m][q] W1[q][k]
+    f32x4 acc1[2];
+    acc1[0] = acc1[1] = (f32x4){0, 0, 0, 0};
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc1[mt][0] = acc1[mt][1] = (f32x4){0, 0, 0, 0};
+    for (int kb = 0; kb < MH / 32; ++kb)
 #pragma unroll
-    for (int ks = 0; ks < MH / 4; ++ks)
+      for (int mt = 0; mt < 2; ++mt) {
+        Frag fa[3];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        acc1[mt][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bufU[4 * ks + g4][16 * mt + n16], w1T[ks],
-                                                                acc1[mt][ks & 1], 0, 0, 0);
+        for (int c = 0; c < 3; ++c)
+          fa[c].x = *reinterpret_cast<const uint4 *>(&uJ[c][16 * mt + n16][32 * kb + 8 * g4]);
+        acc1[mt] = mfma9(fa, w1f[kb], acc1[mt]);
+      }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       f32x4 dav;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dav[i] = a1c[mt][i] > 0.0f ? acc1[mt][0][i] + acc1[mt][1][i] : 0.0f;
+      for (int i = 0; i < 4; ++i) dav[i] = a1c[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
       *reinterpret_cast<f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + lo + 16 * mt) = dav;
     }
-    // dW1[row][col] += sum over the samples of d u_pre[row][m] relu(h')[col][m]: A rows = this wave's 16 units
+    // dW1[row][col] += sum over the 32 samples of d u_pre[row][m] relu(h')[col][m]: A rows = this wave's 16 units
+    {
+      Frag fa[3];
 #pragma unroll
-    for (int ks = 0; ks < TL / 4; ++ks) {
-      const float av = bufU[j][4 * ks + g4];
+      for (int c = 0; c < 3; ++c) fa[c].x = *reinterpret_cast<const uint4 *>(&uM[c][j][8 * g4]);
 #pragma unroll
-      for (int nt = 0; nt < GH / 16; ++nt)
-        accw[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bufA[16 * nt + n16][4 * ks + g4], accw[nt], 0, 0, 0);
+      for (int nt = 0; nt < GH / 16; ++nt) {
+        Frag fb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&aM[c][16 * nt + n16][8 * g4]);
+        accw[nt] = mfma9(fa, fb, accw[nt]);
+      }
     }
   }
   // ---- this workgroup's row of partials (head columns)
