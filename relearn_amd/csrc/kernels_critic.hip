@@ -85,13 +85,15 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     bool valid;
   };
   // branch-free (padding lanes read sample B - 1 and are zeroed): the loads of tile i + 1 stay in flight across tile i
+  // (32-bit element offsets from the uniform base pointers: a launch covers < 2^30 samples, checked by the launcher)
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
   auto load_tile = [&](size_t g) {
     TileOp o;
-    const size_t sidx = g * 32 + n;
-    o.valid = g < n_tiles && sidx < B;
-    const size_t sc = o.valid ? sidx : B - 1;
-    const float xa = tr.obs[(size_t)(2 * hf) * plane + sc], xb = tr.obs[(size_t)(2 * hf + 1) * plane + sc];
-    const float xc = tr.obs[(size_t)4 * plane + sc], tg = tr.tgt[sc];
+    const uint32_t sidx = (uint32_t)g * 32u + (uint32_t)n;
+    o.valid = g < n_tiles && sidx < B32;
+    const uint32_t sc = o.valid ? sidx : B32 - 1;
+    const float xa = tr.obs[(uint32_t)(2 * hf) * plane32 + sc], xb = tr.obs[(uint32_t)(2 * hf + 1) * plane32 + sc];
+    const float xc = tr.obs[4u * plane32 + sc], tg = tr.tgt[sc];
     o.xa = o.valid ? xa : 0.0f;
     o.xb = o.valid ? xb : 0.0f;
     o.xc = o.valid ? xc : 0.0f;
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 // ---------------------------------------------------------------- launcher
 bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
+  if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
   // persistent grid: one fat workgroup per CU (fewer, fatter workgroups = fewer slab rows for the reduction that follows

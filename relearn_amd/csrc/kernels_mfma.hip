@@ -592,17 +592,19 @@ __global__ void __launch_bounds__(WAVES * 64)
     bool valid;
   };
   // branch-free (padding lanes read sample B - 1 and are zeroed): the loads of tile i + 1 stay in flight across tile i
+  // (32-bit element offsets from the uniform base pointers: a launch covers < 2^30 samples, checked by the launcher)
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
   auto load_tile = [&](size_t g) {
     TileOp o;
-    const size_t sidx = g * 32 + n;
-    o.valid = g < n_tiles && sidx < B;
-    const size_t sc = o.valid ? sidx : B - 1;
-    const float xa = tr.obs[(size_t)(2 * hf) * plane + sc], xb = tr.obs[(size_t)(2 * hf + 1) * plane + sc];
-    const float xc = tr.obs[(size_t)4 * plane + sc];
+    const uint32_t sidx = (uint32_t)g * 32u + (uint32_t)n;
+    o.valid = g < n_tiles && sidx < B32;
+    const uint32_t sc = o.valid ? sidx : B32 - 1;
+    const float xa = tr.obs[(uint32_t)(2 * hf) * plane32 + sc], xb = tr.obs[(uint32_t)(2 * hf + 1) * plane32 + sc];
+    const float xc = tr.obs[4u * plane32 + sc];
     o.l0 = o.l1 = o.adv = 0.0f;
     o.act = 0;
     if (MODE != PASS_INIT) {  // log pi_0 (written by PASS_INIT, read by the others)
-      const float l0 = lp0[sc], l1 = lp0[B + sc];
+      const float l0 = lp0[sc], l1 = lp0[B32 + sc];
       o.l0 = o.valid ? l0 : 0.0f;
       o.l1 = o.valid ? l1 : 0.0f;
     }
@@ -834,6 +836,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
+  if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernels
   ProfScope ps(traj->eng, mode == PASS_JVP ? RL_K_POLICY_FVP : RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
