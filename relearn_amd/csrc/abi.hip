@@ -494,6 +494,16 @@ int32_t rl_cartpole_params_default(rl_cartpole_params *p) {
   });
 }
 
+// every device allocation of an env handle (also the clean-up of a failed rl_env_create)
+static void env_release_device(rl_env *env) {
+  void *ptrs[] = {env->st.x, env->st.xdot, env->st.th, env->st.thdot, env->st.nv_pos, env->st.steps_remaining,
+                  env->st.reset_count, env->d_actions, env->d_flag, env->d_reward, env->d_obs, env->d_term_obs};
+  for (void *p : ptrs) dfree(p);
+  env->st = EnvStateDev{};
+  env->d_actions = env->d_flag = nullptr;
+  env->d_reward = env->d_obs = env->d_term_obs = nullptr;
+}
+
 int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
   return guarded(e, [&] {
     RL_REQUIRE(e && cfg && out, "NULL argument");
@@ -545,6 +555,7 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     d.chain_size = 5;
     d.mem_actions = cfg->kind == RL_ENV_MEMORY ? (uint32_t)mem_actions : 0u;
     size_t n = cfg->n_lanes;
+    try {
     env->st.x = dalloc<double>(n);
     env->st.xdot = dalloc<double>(n);
     env->st.th = dalloc<double>(n);
@@ -565,6 +576,10 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     RL_HIP_CHECK(hipMemsetAsync(env->d_term_obs, 0, n * env->D * sizeof(float), e->stream));
     launch_env_reset(env.get());
     sync(e);
+    } catch (...) {  // (unique_ptr frees the host struct only)
+      env_release_device(env.get());
+      throw;
+    }
     e->live_handles += 1;
     *out = env.release();
   });
@@ -574,18 +589,7 @@ int32_t rl_env_destroy(rl_env *env) {
   if (!env) return RL_OK;
   (void)hipSetDevice(env->eng->device);
   (void)hipStreamSynchronize(env->eng->stream);
-  dfree(env->st.x);
-  dfree(env->st.xdot);
-  dfree(env->st.th);
-  dfree(env->st.thdot);
-  dfree(env->st.nv_pos);
-  dfree(env->st.steps_remaining);
-  dfree(env->st.reset_count);
-  dfree(env->d_actions);
-  dfree(env->d_flag);
-  dfree(env->d_reward);
-  dfree(env->d_obs);
-  dfree(env->d_term_obs);
+  env_release_device(env);
   rl_engine *eng = env->eng;
   delete env;
   engine_release_child(eng);

@@ -67,6 +67,31 @@ static void replay_free(ReplayDev &r) {
   r = ReplayDev{};
 }
 
+// every device allocation of a DQN handle (also the clean-up of a failed rl_dqn_create)
+static void dqn_release_device(rl_dqn *q) {
+  replay_free(q->rp);
+  void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags};
+  for (void *p : ptrs) dfree(p);
+  q->d_agent_pos = nullptr;
+  q->d_ep_lane = q->d_ep_start = q->d_ep_len = q->d_ep_off = nullptr;
+  q->d_counts = nullptr;
+  q->d_flags = nullptr;
+  if (q->mb) rl_traj_destroy(q->mb);
+  q->mb = nullptr;
+}
+
+// With several ranks a failure must be raised on ALL of them: a rank that throws before a collective leaves its peers
+// blocked in it.  One float travels through the update workspace; true when any rank reports a failure.
+static bool dqn_any_rank_failed(rl_dqn *q, bool local_failure) {
+  rl_engine *e = q->eng;
+  if (e->n_ranks <= 1) return local_failure;
+  float flag = local_failure ? 1.0f : 0.0f;
+  h2d(e, q->mb->vec, &flag, sizeof(flag));
+  rl_allreduce_sum_f32(e, q->mb->vec, 1);
+  d2h(e, &flag, q->mb->vec, sizeof(flag));
+  return flag > 0.0f;
+}
+
 int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_config *cfg, rl_dqn **out) {
   return guarded(env ? env->eng : nullptr, [&] {
     RL_REQUIRE(env && qnet && opt && cfg && out, "NULL argument");
@@ -94,6 +119,7 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     q->opt = opt;
     q->cfg = *cfg;
     q->cfg.episode_capacity = E;
+    try {
     q->rp = replay_alloc(e, (uint32_t)N, (uint32_t)cfg->buffer_capacity, (uint32_t)E, env->D);
     q->d_agent_pos = dalloc<uint64_t>(1);
     RL_HIP_CHECK(hipMemsetAsync(q->d_agent_pos, 0, 8, e->stream));
@@ -110,6 +136,10 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, nb * sizeof(DqnCountsDev), e->stream));
     q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
     sync(e);
+    } catch (...) {  // (unique_ptr frees the host struct only)
+      dqn_release_device(q.get());
+      throw;
+    }
     e->live_handles += 1;
     *out = q.release();
   });
@@ -119,10 +149,7 @@ int32_t rl_dqn_destroy(rl_dqn *q) {
   if (!q) return RL_OK;
   (void)hipSetDevice(q->eng->device);
   (void)hipStreamSynchronize(q->eng->stream);
-  replay_free(q->rp);
-  void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags};
-  for (void *p : ptrs) dfree(p);
-  rl_traj_destroy(q->mb);
+  dqn_release_device(q);
   rl_engine *eng = q->eng;
   delete q;
   engine_release_child(eng);
@@ -176,7 +203,9 @@ int32_t rl_dqn_collect(rl_dqn *q, uint64_t horizon, rl_dqn_collect_stats *stats)
     q->last_horizon = horizon;
     int32_t err = 0;
     d2h(e, &err, q->rp.error, sizeof(err));
-    if (err != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full: an episode outgrew the lane capacity");
+    if (dqn_any_rank_failed(q, err != 0))
+      throw RlError(RL_ERR_BUFFER_FULL, err != 0 ? "replay buffer full: an episode outgrew the lane capacity"
+                                                 : "replay buffer full on another rank");
     if (stats) {
       std::vector<uint8_t> fl(horizon * N);
       d2h(e, fl.data(), q->d_flags, fl.size());
@@ -205,13 +234,28 @@ static void dqn_draw_minibatches(rl_dqn *q, int sequential, uint32_t n_batches, 
                     q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, sequential, n_batches);
   counts.resize(n_batches);
   d2h(e, counts.data(), q->d_counts, n_batches * sizeof(DqnCountsDev));
+  // local validation first, the verdict only after every rank has reported (a rank that throws here alone would leave
+  // its peers blocked in the count all-reduce below)
+  int32_t code = RL_OK;
+  const char *what = "";
   for (const DqnCountsDev &c : counts) {
-    if (c.error == 2)
-      throw RlError(RL_ERR_INVALID_ARGUMENT, "minibatch sampling from a lane without a complete episode");
-    if (c.error != 0) throw RlError(RL_ERR_BUFFER_FULL, "replay buffer full");
-    RL_REQUIRE(c.n_eps <= q->max_eps && c.n_steps <= q->max_steps_mb, "minibatch exceeds its workspace");
-    RL_REQUIRE(c.n_steps > 0, "empty minibatch");
+    if (code != RL_OK) break;
+    if (c.error == 2) {
+      code = RL_ERR_INVALID_ARGUMENT;
+      what = "minibatch sampling from a lane without a complete episode";
+    } else if (c.error != 0) {
+      code = RL_ERR_BUFFER_FULL;
+      what = "replay buffer full";
+    } else if (c.n_eps > q->max_eps || c.n_steps > q->max_steps_mb) {
+      code = RL_ERR_INVALID_ARGUMENT;
+      what = "minibatch exceeds its workspace";
+    } else if (c.n_steps == 0) {
+      code = RL_ERR_INVALID_ARGUMENT;
+      what = "empty minibatch";
+    }
   }
+  if (dqn_any_rank_failed(q, code != RL_OK))
+    throw RlError(code != RL_OK ? code : RL_ERR_COMM, code != RL_OK ? what : "minibatch sampling failed on another rank");
   // the loss is a mean over all ranks' samples: sum the per-rank counts (two 16-bit halves each, exact in f32)
   totals.resize(n_batches);
   for (uint32_t k = 0; k < n_batches; ++k) totals[k] = counts[k].n_steps;
