@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 2
+#define RL_ABI_VERSION 3
 
 /* ---------------------------------------------------------------------------------------------
  * Status codes.  The non-generic ones mirror the reference's error enums:
@@ -65,7 +65,7 @@ enum { RL_SUCC_CONTINUE = 0, RL_SUCC_TERMINATE = 1, RL_SUCC_INTERRUPT = 2 };
 enum { RL_OPT_OK = 0, RL_OPT_LOSS_NOT_IMPROVING = 1, RL_OPT_CONSTRAINT_VIOLATED = 2, RL_OPT_NAN_LOSS = 3,
        RL_OPT_NAN_CONSTRAINT = 4 };
 /* env kinds / step-limit wrappers (src/envs/cartpole.rs, chain.rs, wrappers/step_limit.rs:13,97) */
-enum { RL_ENV_CARTPOLE = 0, RL_ENV_CHAIN = 1, RL_ENV_MEMORY = 2 };
+enum { RL_ENV_CARTPOLE = 0, RL_ENV_CHAIN = 1, RL_ENV_MEMORY = 2, RL_ENV_BANDIT = 3 };
 enum { RL_LIMIT_NONE = 0, RL_LIMIT_LATENT = 1, RL_LIMIT_VISIBLE = 2 };
 
 typedef struct rl_engine rl_engine;
@@ -171,6 +171,10 @@ typedef struct {
    * env takes any).  0 / 0 = (2, 3).  Episodes last history_len + 1 steps; the only random draw is
    * `gen_range(0..num_actions)` in initial_state, taken sequentially from the lane's env stream. */
   uint64_t memory_num_actions, memory_history_len;
+  /* RL_ENV_BANDIT: DeterministicBandit::from_values([v0, v1]) (src/envs/bandits.rs:109-116; Bandit::step :66-77): one
+   * state, reward = the chosen arm's value, every step terminates, discount factor 1, no step limit.  The singleton
+   * observation is presented as one-hot(5) of state 0 (its one constant feature padded to the kernels' five inputs). */
+  double bandit_values[2];
 } rl_env_config;
 
 int32_t rl_env_create(rl_engine *engine, const rl_env_config *cfg, rl_env **out);

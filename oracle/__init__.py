@@ -112,7 +112,8 @@ class ChainLanes(C.Structure):
                 ("seed_env", C.c_uint64), ("seed_actor", C.c_uint64), ("n_lanes", C.c_uint64),
                 ("lane_offset", C.c_uint64), ("state", C.POINTER(C.c_uint64)),
                 ("steps_remaining", C.POINTER(C.c_uint64)), ("reset_count", C.POINTER(C.c_uint64)),
-                ("initial", C.POINTER(C.c_uint64)), ("env_pos", C.POINTER(C.c_uint64)), ("t_global", C.c_uint64)]
+                ("initial", C.POINTER(C.c_uint64)), ("env_pos", C.POINTER(C.c_uint64)), ("t_global", C.c_uint64),
+                ("bandit", C.c_int), ("bandit_values", C.c_double * 2)]
 
 
 class Lanes(C.Structure):
@@ -359,6 +360,8 @@ def _declare(L):
     L.oracle_memory_lanes_new.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                                           C.c_uint64, C.c_uint64]
     L.oracle_memory_lanes_new.restype = P(ChainLanes)
+    L.oracle_bandit_lanes_new.argtypes = [P(C.c_double), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.oracle_bandit_lanes_new.restype = P(ChainLanes)
     L.oracle_memory_lanes_get_extra.argtypes = [P(ChainLanes), P(C.c_uint64), P(C.c_uint64)]
     L.oracle_chain_lanes_free.argtypes = [P(ChainLanes)]
     L.oracle_chain_lanes_reset.argtypes = [P(ChainLanes)]
@@ -858,6 +861,17 @@ class ChainLaneSim:
         lib().oracle_chain_lanes_rollout_gru(self.ptr, shape, f32p(params), T, f32p(obs), u8p(action), f32p(reward),
                                              u8p(flag), f32p(term), threads)
         return dict(obs=obs, action=action, reward=reward, flag=flag, term_obs=term)
+
+
+class BanditLaneSim(ChainLaneSim):
+    """DeterministicBandit lanes (src/envs/bandits.rs:109-116): reward = the chosen arm's value, every step ends the
+    episode; observations are one-hot(5) of the single state."""
+
+    def __init__(self, n_lanes, values=(0.0, 1.0), lane_offset=0, seed_env=0, seed_actor=1):
+        v = (C.c_double * 2)(*values)
+        self.ptr = lib().oracle_bandit_lanes_new(v, n_lanes, lane_offset, seed_env, seed_actor)
+        self.n = n_lanes
+        self.D = int(lib().oracle_chain_lanes_obs_dim(self.ptr))
 
 
 class MemoryLaneSim(ChainLaneSim):

@@ -410,7 +410,15 @@ typedef struct {
   uint64_t *state, *steps_remaining, *reset_count;
   uint64_t *initial, *env_pos; /* MemoryGame only */
   uint64_t t_global;
+  /* DeterministicBandit (src/envs/bandits.rs:109-116): one state, reward = the arm's value, every step terminates */
+  int bandit;
+  double bandit_values[2];
 } oracle_chain_lanes;
+/* Lanes of DeterministicBandit::from_values([v0, v1]) (bandits.rs:66-77 step, :109-116).  The singleton observation
+ * is presented as one-hot(5) of state 0 — its one constant feature (NonEmptyFeatures) padded to the five inputs the
+ * device kernels are built for; the discount factor is 1 (bandits.rs:52-54). */
+oracle_chain_lanes *oracle_bandit_lanes_new(const double *values, uint64_t n_lanes, uint64_t lane_offset,
+                                            uint64_t seed_env, uint64_t seed_actor);
 oracle_chain_lanes *oracle_memory_lanes_new(uint64_t num_actions, uint64_t history_len, int limit_kind,
                                             uint64_t max_steps, uint64_t n_lanes, uint64_t lane_offset,
                                             uint64_t seed_env, uint64_t seed_actor);

@@ -151,6 +151,16 @@ oracle_chain_lanes *oracle_memory_lanes_new(uint64_t num_actions, uint64_t histo
   return l;
 }
 
+oracle_chain_lanes *oracle_bandit_lanes_new(const double *values, uint64_t n_lanes, uint64_t lane_offset,
+                                            uint64_t seed_env, uint64_t seed_actor) {
+  oracle_chain_lanes *l = oracle_chain_lanes_new(5, ORACLE_LIMIT_NONE, 0, n_lanes, lane_offset, seed_env, seed_actor);
+  l->env.discount_factor = 1.0; /* bandits.rs:52-54 */
+  l->bandit = 1;
+  l->bandit_values[0] = values[0];
+  l->bandit_values[1] = values[1];
+  return l;
+}
+
 void oracle_chain_lanes_free(oracle_chain_lanes *l) {
   if (!l) return;
   free(l->state);
@@ -217,7 +227,10 @@ static int chain_lane_step(oracle_chain_lanes *l, uint64_t i, int action, oracle
                            float *reward, float *term_f) {
   double r;
   int succ;
-  if (l->memory.num_actions) {
+  if (l->bandit) { /* Bandit::step (bandits.rs:66-77): Deterministic::sample draws nothing */
+    r = l->bandit_values[action];
+    succ = ORACLE_TERMINATE;
+  } else if (l->memory.num_actions) {
     succ = oracle_memory_step(&l->memory, &l->state[i], l->initial[i], (uint64_t)action, &r);
   } else {
     oracle_prng_set_word_pos(env_rng, word);

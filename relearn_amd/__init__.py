@@ -24,7 +24,7 @@ ERR_INVALID_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_BUILD_AGENT, ERR_BUILD_ENV = 1
 ERR_BUFFER_FULL, ERR_PACKING, ERR_COMM, ERR_OPT_NAN, ERR_UNSUPPORTED = 6, 7, 8, 9, 10
 SUCC_CONTINUE, SUCC_TERMINATE, SUCC_INTERRUPT = 0, 1, 2
 OPT_OK, OPT_LOSS_NOT_IMPROVING, OPT_CONSTRAINT_VIOLATED, OPT_NAN_LOSS, OPT_NAN_CONSTRAINT = range(5)
-ENV_CARTPOLE, ENV_CHAIN, ENV_MEMORY = 0, 1, 2
+ENV_CARTPOLE, ENV_CHAIN, ENV_MEMORY, ENV_BANDIT = 0, 1, 2, 3
 LIMIT_NONE, LIMIT_LATENT, LIMIT_VISIBLE = 0, 1, 2
 (TRAJ_OBS, TRAJ_ACTION, TRAJ_REWARD, TRAJ_FLAG, TRAJ_TERM_OBS, TRAJ_VALUES, TRAJ_ADVANTAGES,
  TRAJ_RETURNS, TRAJ_TARGETS) = range(9)
@@ -77,7 +77,7 @@ class EnvConfig(C.Structure):
     _fields_ = [("kind", C.c_int32), ("limit_kind", C.c_int32), ("max_steps", C.c_uint64), ("n_lanes", C.c_uint64),
                 ("lane_offset", C.c_uint64), ("seed_env", C.c_uint64), ("seed_actor", C.c_uint64),
                 ("cartpole", CartPoleParams), ("chain_size", C.c_uint64), ("memory_num_actions", C.c_uint64),
-                ("memory_history_len", C.c_uint64)]
+                ("memory_history_len", C.c_uint64), ("bandit_values", C.c_double * 2)]
 
 
 class TrpoConfig(C.Structure):
@@ -378,6 +378,31 @@ class ChainEnv(_Handle):
         """(state index, steps_remaining, reset_count) per lane"""
         st, _, rem, rc = CartPoleEnv.get_state(self)
         return st[0].astype(np.uint64), rem, rc
+
+
+class BanditEnv(ChainEnv):
+    """N DeterministicBandit lanes (src/envs/bandits.rs:109-116) — `DeterministicBandit::from_values([v0, v1])`: every step
+    is a whole episode, the reward is the chosen arm's value.  Observations: one-hot(5) of the single state."""
+
+    def __init__(self, engine, n_lanes, values=(0.0, 1.0), lane_offset=0, seed_env=0, seed_actor=1):
+        self.eng = engine
+        cfg = EnvConfig()
+        cfg.kind = ENV_BANDIT
+        cfg.limit_kind = LIMIT_NONE
+        cfg.n_lanes = n_lanes
+        cfg.lane_offset = lane_offset
+        cfg.seed_env = seed_env
+        cfg.seed_actor = seed_actor
+        cfg.cartpole = cartpole_params_default()
+        cfg.bandit_values[0], cfg.bandit_values[1] = values
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _check(lib().rl_env_create(engine.h, C.byref(cfg), C.byref(self.h)), engine.h)
+        _register(self)
+        self.n = n_lanes
+        d, a = C.c_uint32(), C.c_uint32()
+        _check(lib().rl_env_dims(self.h, C.byref(d), C.byref(a)), engine.h)
+        self.D, self.A = d.value, a.value
 
 
 class MemoryEnv(ChainEnv):

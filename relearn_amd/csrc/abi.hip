@@ -508,7 +508,8 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
   return guarded(e, [&] {
     RL_REQUIRE(e && cfg && out, "NULL argument");
     *out = nullptr;
-    if (cfg->kind != RL_ENV_CARTPOLE && cfg->kind != RL_ENV_CHAIN && cfg->kind != RL_ENV_MEMORY)
+    if (cfg->kind != RL_ENV_CARTPOLE && cfg->kind != RL_ENV_CHAIN && cfg->kind != RL_ENV_MEMORY &&
+        cfg->kind != RL_ENV_BANDIT)
       throw RlError(RL_ERR_BUILD_ENV, "unknown env kind");
     const uint64_t mem_actions = cfg->memory_num_actions ? cfg->memory_num_actions : 2;
     const uint64_t mem_history = cfg->memory_num_actions || cfg->memory_history_len ? cfg->memory_history_len : 3;
@@ -524,7 +525,9 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     env->eng = e;
     env->cfg = *cfg;
     env->kind = cfg->kind;
-    if (cfg->kind == RL_ENV_CHAIN || cfg->kind == RL_ENV_MEMORY)
+    if (cfg->kind == RL_ENV_BANDIT && cfg->limit_kind != RL_LIMIT_NONE)
+      throw RlError(RL_ERR_BUILD_ENV, "bandit lanes take no step limit (every step ends the episode)");
+    if (cfg->kind == RL_ENV_CHAIN || cfg->kind == RL_ENV_MEMORY || cfg->kind == RL_ENV_BANDIT)
       env->D = 5 + (cfg->limit_kind == RL_LIMIT_VISIBLE ? 1 : 0);  // one-hot(5) [+ remaining]
     else
       env->D = cfg->limit_kind == RL_LIMIT_VISIBLE ? 5 : 4;
@@ -554,6 +557,9 @@ int32_t rl_env_create(rl_engine *e, const rl_env_config *cfg, rl_env **out) {
     d.limit_kind = cfg->limit_kind;
     d.chain_size = 5;
     d.mem_actions = cfg->kind == RL_ENV_MEMORY ? (uint32_t)mem_actions : 0u;
+    d.bandit = cfg->kind == RL_ENV_BANDIT ? 1u : 0u;
+    d.bandit_r[0] = (float)cfg->bandit_values[0];  // Reward -> f32 feedback, as every env's reward record
+    d.bandit_r[1] = (float)cfg->bandit_values[1];
     size_t n = cfg->n_lanes;
     try {
     env->st.x = dalloc<double>(n);

@@ -41,6 +41,8 @@ struct CartPoleDev {
   int32_t limit_kind;
   uint32_t chain_size;   // RL_ENV_CHAIN / RL_ENV_MEMORY: number of states = one-hot width
   uint32_t mem_actions;  // RL_ENV_MEMORY: num_actions (0 selects Chain in the shared lane code)
+  uint32_t bandit;       // RL_ENV_BANDIT: != 0; reward = bandit_r[action], every step terminates
+  float bandit_r[2];
 };
 
 struct EnvStateDev {

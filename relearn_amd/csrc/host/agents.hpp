@@ -193,6 +193,31 @@ class MemoryGameLanes : public EnvLanes {
   }
 };
 
+// `DeterministicBandit::from_values([v0, v1])` x n_lanes (src/envs/bandits.rs:109-116): every step is an episode,
+// reward = the chosen arm's value, discount factor 1.0 (bandits.rs:52-54).  The environment of the reference's universal
+// agent test (`train_deterministic_bandit`, src/agents/testing.rs:14-64).
+class DeterministicBanditLanes : public EnvLanes {
+ public:
+  DeterministicBanditLanes(Engine &eng, uint64_t n_lanes, double value0 = 0.0, double value1 = 1.0,
+                           uint64_t seed_env = 0, uint64_t seed_actor = 1, uint64_t lane_offset = 0)
+      : EnvLanes(eng, config(n_lanes, value0, value1, seed_env, seed_actor, lane_offset), 1.0) {}
+
+ private:
+  static rl_env_config config(uint64_t n, double v0, double v1, uint64_t se, uint64_t sa, uint64_t off) {
+    rl_env_config c{};
+    c.kind = RL_ENV_BANDIT;
+    c.limit_kind = RL_LIMIT_NONE;
+    c.n_lanes = n;
+    c.lane_offset = off;
+    c.seed_env = se;
+    c.seed_actor = sa;
+    check(rl_cartpole_params_default(&c.cartpole));
+    c.bandit_values[0] = v0;
+    c.bandit_values[1] = v1;
+    return c;
+  }
+};
+
 // ---------------------------------------------------------------- modules (BuildModule)
 class Module {
  public:

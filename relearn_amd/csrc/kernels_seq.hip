@@ -93,6 +93,10 @@ __device__ __forceinline__ void chain_reset(const CartPoleDev &c, ChainLane &s, 
 // env-stream word for this global step (Chain's slip draw)
 __device__ __forceinline__ int chain_step(const CartPoleDev &c, ChainLane &s, int action, uint32_t word,
                                           float &reward) {
+  if (c.bandit) {  // Bandit::step (bandits.rs:66-77): Deterministic::sample draws nothing
+    reward = c.bandit_r[action];
+    return RL_SUCC_TERMINATE;
+  }
   if (c.mem_actions) {
     if (s.state == c.chain_size - 1) {  // the last of num_actions + history_len states: the answer step
       reward = (uint32_t)action == s.initial ? 1.0f : -1.0f;

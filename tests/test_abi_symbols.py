@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     missing = [s for s in decl if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(ra.ABI_SYMBOLS) == decl, set(ra.ABI_SYMBOLS) ^ set(decl)
-    assert lib.rl_abi_version() == 2
+    assert lib.rl_abi_version() == 3
 
 
 def test_every_entry_point_cites_the_reference():
@@ -89,7 +89,7 @@ def test_integration_doc_binds_every_symbol():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     declared = sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", header)))
     assert [s for s in declared if "fn %s(" % s not in doc] == []
-    for field in ("chain_size", "memory_num_actions", "memory_history_len"):  # rl_env_config's latest fields
+    for field in ("chain_size", "memory_num_actions", "memory_history_len", "bandit_values"):  # rl_env_config's latest fields
         assert field in doc
 
 
