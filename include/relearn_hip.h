@@ -209,6 +209,15 @@ int32_t rl_env_set_state(rl_env *env, const double *state4, const int32_t *nv_po
  * (src/torch/modules/ff/mlp.rs:25-69); parameters are exchanged in the reference's flat order
  * (kernel [out][in] then bias per layer: ff/linear.rs:108-110, torch/utils.rs:10-22). */
 int32_t rl_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t hidden, uint32_t out_dim, rl_mlp **out);
+/* MlpConfig { hidden_sizes: Vec<usize>, .. } (src/torch/modules/ff/mlp.rs:13-34): in_dim -> hidden_sizes[0] -> ... ->
+ * out_dim with ReLU between the layers; parameters flat as [W, b] per layer in layer order.  `n_hidden` in [0, 4],
+ * every width in [1, 256], in_dim in {4, 5}, out_dim in {1, 2}; other shapes -> RL_ERR_BUILD_AGENT.  One hidden layer
+ * of at most 128 units is rl_mlp_create (the fused kernels every BASELINE configuration runs on); any other shape runs
+ * per-layer kernels (relearn_amd/csrc/kernels_general.hip: the general path, not the fast one) behind the same entry
+ * points — rollouts, GAE, TRPO / PPO / REINFORCE and critic updates, row-wise forward, actor serialisation; DQN takes
+ * single-hidden-layer modules only. */
+int32_t rl_mlp_create_layers(rl_engine *engine, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
+                             uint32_t out_dim, rl_mlp **out);
 int32_t rl_mlp_destroy(rl_mlp *mlp);
 int32_t rl_mlp_num_params(const rl_mlp *mlp, uint64_t *n);
 /* Linear::new Glorot-uniform init (ff/linear.rs:54-68) from the engine-defined stream ChaCha8(seed) */

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
-    "rl_mlp_create", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_params_get", "rl_params_set",
+    "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_params_get", "rl_params_set",
     "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
@@ -486,10 +486,17 @@ class Mlp(_Handle):
     """`MlpConfig{hidden_sizes:[H], activation: Relu}.build_module(in, out)`; flat params in reference order."""
 
     def __init__(self, engine, in_dim, hidden, out_dim):
+        """`hidden`: the width of the single hidden layer, or MlpConfig's `hidden_sizes` as a list (any number of layers:
+        shapes other than one layer of <= 128 units run the general per-layer kernels)"""
         self.eng = engine
         self.h = C.c_void_p()
-        _check(lib().rl_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(hidden), C.c_uint32(out_dim),
-                                   C.byref(self.h)), engine.h)
+        if isinstance(hidden, (list, tuple)):
+            sizes = (C.c_uint32 * max(len(hidden), 1))(*hidden)
+            _check(lib().rl_mlp_create_layers(engine.h, C.c_uint32(in_dim), sizes, C.c_uint32(len(hidden)),
+                                              C.c_uint32(out_dim), C.byref(self.h)), engine.h)
+        else:
+            _check(lib().rl_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(hidden), C.c_uint32(out_dim),
+                                       C.byref(self.h)), engine.h)
         _register(self)
         n = C.c_uint64()
         _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)

@@ -722,7 +722,39 @@ int32_t rl_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t hidden, uint32_t o
     m->in_dim = in_dim;
     m->hidden = hidden;
     m->out_dim = out_dim;
+    m->widths[0] = hidden;
     m->P = (uint64_t)hidden * in_dim + hidden + (uint64_t)out_dim * hidden + out_dim;
+    m->d_params = dalloc<float>(m->P);
+    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+    sync(e);
+    e->live_handles += 1;
+    *out = m.release();
+  });
+}
+
+int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
+                             uint32_t out_dim, rl_mlp **out) {
+  // one hidden layer of at most 128 units: the fused kernels
+  if (e && out && hidden_sizes && n_hidden == 1 && hidden_sizes[0] <= 128)
+    return rl_mlp_create(e, in_dim, hidden_sizes[0], out_dim, out);
+  return guarded(e, [&] {
+    RL_REQUIRE(e && out && (hidden_sizes || n_hidden == 0), "NULL argument");
+    *out = nullptr;
+    bool ok = (in_dim == 4 || in_dim == 5) && (out_dim == 1 || out_dim == 2) && n_hidden <= RL_MLP_MAX_HIDDEN;
+    for (uint32_t l = 0; ok && l < n_hidden; ++l) ok = hidden_sizes[l] >= 1 && hidden_sizes[l] <= RL_MLP_MAX_WIDTH;
+    if (!ok)
+      throw RlError(RL_ERR_BUILD_AGENT, "supported MLP shapes: in_dim in {4,5}, at most 4 hidden layers of 1..256 units, "
+                                        "out_dim in {1,2}");
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    std::unique_ptr<rl_mlp> m(new rl_mlp());
+    m->eng = e;
+    m->in_dim = in_dim;
+    m->hidden = 0;  // no fused kernel takes this module
+    m->out_dim = out_dim;
+    m->n_hidden = n_hidden;
+    for (uint32_t l = 0; l < n_hidden; ++l) m->widths[l] = hidden_sizes[l];
+    m->general = true;
+    m->P = m->layer_offset(m->n_layers());
     m->d_params = dalloc<float>(m->P);
     RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
     sync(e);
@@ -873,10 +905,9 @@ int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
       widx += 1;
       return u;
     };
-    uint32_t dims[2][2] = {{m->in_dim, m->hidden}, {m->hidden, m->out_dim}};
     size_t k = 0;
-    for (int l = 0; l < 2; ++l) {
-      uint32_t in = dims[l][0], out = dims[l][1];
+    for (uint32_t l = 0; l < m->n_layers(); ++l) {  // (one hidden layer: [in, hidden], [hidden, out] as before)
+      uint32_t in = m->fan_in(l), out = m->fan_out(l);
       float lim = (float)std::sqrt(3.0 * (2.0 / ((double)(in + 1) + (double)out)));
       size_t cnt = (size_t)in * out + out;
       for (size_t i = 0; i < cnt; ++i) {
@@ -919,7 +950,20 @@ int32_t rl_mlp_forward(rl_mlp *m, const float *rows, uint64_t n_rows, float *out
     float *d_in = dalloc<float>(soa.size()), *d_out = dalloc<float>(res.size());
     try {
       h2d(e, d_in, soa.data(), soa.size() * sizeof(float));
-      launch_mlp_forward_host_rows(m, d_in, n_rows, d_out);
+      if (m->general) {
+        rl_traj scratch{};  // (only the workspace of the per-layer kernels is used)
+        scratch.eng = e;
+        try {
+          launch_gen_forward(&scratch, m, d_in, n_rows, n_rows, d_out);
+          sync(e);
+        } catch (...) {
+          gen_free(&scratch);
+          throw;
+        }
+        gen_free(&scratch);
+      } else {
+        launch_mlp_forward_host_rows(m, d_in, n_rows, d_out);
+      }
       d2h(e, res.data(), d_out, res.size() * sizeof(float));
     } catch (...) {
       dfree(d_in);
@@ -1056,6 +1100,7 @@ int32_t rl_traj_destroy(rl_traj *t) {
                   t->losses, t->trpo, t->td};
   for (void *p : ptrs) dfree(p);
   seq_free(t);
+  gen_free(t);
   rl_engine *eng = t->eng;
   delete t;
   engine_release_child(eng);
@@ -1164,6 +1209,10 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     RL_REQUIRE(env->eng == traj->eng && env->eng == policy->eng, "handles belong to different engines");
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
+    if (policy->general) {  // any hidden_sizes: one launch sequence per step, either env family (advances t_global)
+      launch_gen_rollout(env, policy, traj);
+      return;
+    }
     if (rl_module_is_recurrent(policy->kind)) {
       seq_ensure(traj, policy, false);
       launch_rollout_gru(env, policy, traj);
@@ -1183,6 +1232,11 @@ int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
     if (rl_module_is_recurrent(critic->kind)) {
       seq_ensure(traj, critic, false);
       launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
+      launch_seq_gae(traj, gamma, lambda);
+      return;
+    }
+    if (critic->general) {  // values and successor values as arrays, then the array-fed scan of the recurrent path
+      launch_gen_values(traj, critic);
       launch_seq_gae(traj, gamma, lambda);
       return;
     }

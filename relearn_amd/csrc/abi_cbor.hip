@@ -84,29 +84,39 @@ static TensorDefView cbor_parse_tensor_def(const cbor::Value &t) {
 }
 
 // Mlp { layers, activation, output_activation } over `p` = [W1, b1, W2, b2] (ff/mlp.rs:45-50, ff/linear.rs:43-50)
-static void cbor_mlp(cbor::Writer &w, const float *p, int64_t in, int64_t hid, int64_t out) {
+// (`widths`: in, hidden sizes ..., out)
+static void cbor_mlp_layers(cbor::Writer &w, const float *p, const std::vector<int64_t> &widths) {
   w.map(3);
   w.key("layers");
-  w.array(2);
-  const int64_t dims[2][2] = {{in, hid}, {hid, out}};
-  for (int l = 0; l < 2; ++l) {
+  w.array(widths.size() - 1);
+  for (size_t l = 0; l + 1 < widths.size(); ++l) {
+    const int64_t in = widths[l], out = widths[l + 1];
     w.map(2);
     w.key("kernel");
-    cbor_tensor(w, p, {dims[l][1], dims[l][0]});
-    p += dims[l][0] * dims[l][1];
+    cbor_tensor(w, p, {out, in});
+    p += in * out;
     w.key("bias");
-    cbor_tensor(w, p, {dims[l][1]});
-    p += dims[l][1];
+    cbor_tensor(w, p, {out});
+    p += out;
   }
   w.key("activation");
   w.text("Relu");
   w.key("output_activation");
   w.text("Identity");
 }
+static void cbor_mlp(cbor::Writer &w, const float *p, int64_t in, int64_t hid, int64_t out) {
+  cbor_mlp_layers(w, p, {in, hid, out});
+}
+static std::vector<int64_t> mlp_widths(const rl_mlp *m) {
+  std::vector<int64_t> v{(int64_t)m->in_dim};
+  for (uint32_t l = 0; l < m->n_hidden; ++l) v.push_back((int64_t)m->widths[l]);
+  v.push_back((int64_t)m->out_dim);
+  return v;
+}
 
 static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<float> &p) {
   if (m->kind == RL_MODULE_MLP) {
-    cbor_mlp(w, p.data(), m->in_dim, m->hidden, m->out_dim);
+    cbor_mlp_layers(w, p.data(), mlp_widths(m));
     return;
   }
   // Gru and Lstm are both RnnBase<impl> (seq/rnn/gru.rs:17, lstm.rs:12): the same document, gate rows 3H or 4H
@@ -215,21 +225,25 @@ static void cbor_read_tensor(const cbor::Value &t, std::initializer_list<int64_t
   std::memcpy(dst, v.data->data(), v.data->size());
 }
 
-static float *cbor_read_mlp(const cbor::Value &m, int64_t in, int64_t hid, int64_t out, float *dst) {
+static float *cbor_read_mlp_layers(const cbor::Value &m, const std::vector<int64_t> &widths, float *dst) {
   RL_REQUIRE(m.at("activation").s == "Relu" && m.at("output_activation").s == "Identity",
              "CBOR module: only Relu hidden / Identity output activations are built");
   const cbor::Value &layers = m.at("layers");
-  RL_REQUIRE(layers.kind == cbor::Value::ARRAY && layers.items.size() == 2, "CBOR module: expected one hidden layer");
-  const int64_t dims[2][2] = {{in, hid}, {hid, out}};
-  for (int l = 0; l < 2; ++l) {
+  RL_REQUIRE(layers.kind == cbor::Value::ARRAY && layers.items.size() + 1 == widths.size(),
+             "CBOR module: the number of layers does not match the module");
+  for (size_t l = 0; l + 1 < widths.size(); ++l) {
+    const int64_t in = widths[l], out = widths[l + 1];
     const cbor::Value &lin = *layers.items[l];
-    cbor_read_tensor(lin.at("kernel"), {dims[l][1], dims[l][0]}, dst);
-    dst += dims[l][0] * dims[l][1];
+    cbor_read_tensor(lin.at("kernel"), {out, in}, dst);
+    dst += in * out;
     RL_REQUIRE(lin.at("bias").kind == cbor::Value::MAP, "CBOR module: layers without bias are not built");
-    cbor_read_tensor(lin.at("bias"), {dims[l][1]}, dst);
-    dst += dims[l][1];
+    cbor_read_tensor(lin.at("bias"), {out}, dst);
+    dst += out;
   }
   return dst;
+}
+static float *cbor_read_mlp(const cbor::Value &m, int64_t in, int64_t hid, int64_t out, float *dst) {
+  return cbor_read_mlp_layers(m, {in, hid, out}, dst);
 }
 
 int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
@@ -240,7 +254,7 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
     std::vector<float> p(module->P);
     float *end;
     if (module->kind == RL_MODULE_MLP) {
-      end = cbor_read_mlp(mod, module->in_dim, module->hidden, module->out_dim, p.data());
+      end = cbor_read_mlp_layers(mod, mlp_widths(module), p.data());
     } else {
       const int64_t H = module->gru_hidden, D = module->in_dim, GHR = (int64_t)rl_module_gates(module->kind) * H;
       RL_REQUIRE(mod.at("activation").s == "Relu", "CBOR module: Chain activation must be Relu");

@@ -101,6 +101,8 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     RL_REQUIRE(opt->mod == qnet, "optimizer does not belong to the action-value module");
     RL_REQUIRE(qnet->in_dim == env->D && qnet->out_dim == env->A, "action-value module does not match the env");
     RL_REQUIRE(env->A == 2, "DQN kernels are built for 2-action envs");
+    if (qnet->general || rl_module_is_recurrent(qnet->kind))
+      throw RlError(RL_ERR_BUILD_AGENT, "DQN is built for action-value modules with one hidden layer of at most 128 units");
     RL_REQUIRE(cfg->target == RL_DQN_TARGET_REWARD_TO_GO || cfg->target == RL_DQN_TARGET_ONE_STEP_TD, "bad target");
     RL_REQUIRE(cfg->minibatch_steps > 0 && cfg->minibatch_steps < (1ull << 30), "bad minibatch_steps");
     RL_REQUIRE(cfg->buffer_capacity > 0 && cfg->buffer_capacity < (1ull << 31), "bad buffer_capacity");

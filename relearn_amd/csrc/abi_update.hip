@@ -377,6 +377,9 @@ int32_t rl_values_opt_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, const 
       seq_ensure(traj, critic, false);
       launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
       launch_seq_value_targets(traj, cfg->discount_factor);
+    } else if (critic->general) {
+      launch_gen_values(traj, critic);
+      launch_seq_value_targets(traj, cfg->discount_factor);
     } else {
       launch_values(traj, critic);
       launch_value_targets(traj, critic, cfg->discount_factor);

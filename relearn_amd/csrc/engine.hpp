@@ -168,6 +168,9 @@ enum { RL_MODULE_MLP = 0, RL_MODULE_GRU_MLP = 1, RL_MODULE_LSTM_MLP = 2 };
 inline bool rl_module_is_recurrent(int kind) { return kind == RL_MODULE_GRU_MLP || kind == RL_MODULE_LSTM_MLP; }
 inline uint64_t rl_module_gates(int kind) { return kind == RL_MODULE_LSTM_MLP ? 4 : 3; }  // RnnImpl::GATES_MULTIPLE
 
+constexpr uint32_t RL_MLP_MAX_HIDDEN = 4;   // hidden layers of a general MlpConfig
+constexpr uint32_t RL_MLP_MAX_WIDTH = 256;  // widest hidden layer
+
 struct rl_mlp {
   rl_engine *eng;
   uint32_t in_dim, hidden, out_dim;  // GRU_MLP: hidden = the MLP's hidden width
@@ -175,6 +178,27 @@ struct rl_mlp {
   float *d_params = nullptr;
   int kind = RL_MODULE_MLP;
   uint32_t gru_hidden = 0;
+  // MlpConfig::hidden_sizes (ff/mlp.rs:13-34).  `general`: a shape the fused single-hidden-layer kernels do not cover
+  // (no hidden layer, several, or one wider than 128) — it runs the per-layer kernels of kernels_general.hip; then
+  // `hidden` is 0, which keeps every fused launcher away.
+  uint32_t n_hidden = 1;
+  uint32_t widths[RL_MLP_MAX_HIDDEN] = {0, 0, 0, 0};
+  bool general = false;
+  // layer l (0 .. n_hidden; the last one is the output layer): fan-in, fan-out, offset of its kernel in the flat
+  // parameter vector ([W, b] per layer, the reference's order)
+  uint32_t n_layers() const { return n_hidden + 1; }
+  uint32_t fan_in(uint32_t l) const { return l == 0 ? in_dim : widths[l - 1]; }
+  uint32_t fan_out(uint32_t l) const { return l == n_hidden ? out_dim : widths[l]; }
+  uint64_t layer_offset(uint32_t l) const {
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < l; ++i) o += (uint64_t)fan_in(i) * fan_out(i) + fan_out(i);
+    return o;
+  }
+  uint32_t hidden_units() const {
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < n_hidden; ++i) s += widths[i];
+    return s;
+  }
 };
 
 // workspace of the recurrent path, attached to a trajectory on first use (tiles of 32 lanes)
@@ -186,6 +210,14 @@ struct SeqDev {
   float *wg_slab = nullptr; // [chunks][P] partial weight gradients (f32)
   uint32_t tiles = 0, chunks = 0, blocks_per_chunk = 0;
   uint64_t P = 0;
+};
+
+// workspace of the general-MLP path (kernels_general.hip), attached to a trajectory on first use
+struct GenDev {
+  float *act = nullptr, *tact = nullptr;  // [hidden units][rows]: activations of the last forward, their tangents
+  float *delta = nullptr;                 // [2][widest layer][rows]: backward deltas (ping-pong)
+  float *z = nullptr, *tz = nullptr;      // [2][rows]: outputs and tangent outputs
+  uint64_t cap_act = 0, cap_tact = 0, cap_delta = 0, cap_z = 0, cap_tz = 0;
 };
 
 struct rl_adam {
@@ -214,6 +246,7 @@ struct rl_traj {
   uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbC = 0, Pmax = 0, max_losses = 0;
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
+  GenDev gen;
 };
 
 struct rl_dqn {

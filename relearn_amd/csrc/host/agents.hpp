@@ -243,11 +243,17 @@ class Module {
   uint64_t n_ = 0;
 };
 
-struct MlpConfig {  // MlpConfig::default: hidden_sizes [128], Relu (ff/mlp.rs:25-34)
-  uint32_t hidden_size = 128;
+struct MlpConfig {  // MlpConfig { hidden_sizes, activation: Relu, output_activation: Identity } (ff/mlp.rs:13-34)
+  std::vector<uint32_t> hidden_sizes{128};  // MlpConfig::default; any list of up to four widths <= 256 builds
+  // width of the single hidden layer (the recurrent chains take exactly one)
+  uint32_t single_hidden_size() const {
+    if (hidden_sizes.size() != 1) throw BuildAgentError(RL_ERR_BUILD_AGENT, "the chain's MLP takes one hidden layer");
+    return hidden_sizes[0];
+  }
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_mlp_create(eng.handle(), in_dim, hidden_size, out_dim, &h), eng.handle());
+    check(rl_mlp_create_layers(eng.handle(), in_dim, hidden_sizes.data(), (uint32_t)hidden_sizes.size(), out_dim, &h),
+          eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     check(rl_mlp_init(h, seed), eng.handle());
     return m;
@@ -259,7 +265,7 @@ struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mo
   MlpConfig second_config;
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_gru_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.hidden_size, out_dim, &h), eng.handle());
+    check(rl_gru_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.single_hidden_size(), out_dim, &h), eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     check(rl_mlp_init(h, seed), eng.handle());
     return m;
@@ -278,7 +284,7 @@ struct ChainLstmMlpConfig {
   MlpConfig second_config;
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_lstm_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.hidden_size, out_dim, &h), eng.handle());
+    check(rl_lstm_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.single_hidden_size(), out_dim, &h), eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     check(rl_mlp_init(h, seed), eng.handle());
     return m;

@@ -72,6 +72,16 @@ void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj);
 // teacher-forced forward: d_out [A][T][n]; d_succ (may be NULL) [A][T][n]; d_act (may be NULL) activation record
 void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,
                             const int32_t *d_skip = nullptr);
+// kernels_general.hip: MLPs of any hidden_sizes (per-layer kernels; rl_mlp::general)
+void gen_ensure(rl_traj *t, const rl_mlp *m, uint64_t rows, bool tangent, bool backward);
+void gen_free(rl_traj *t);
+void launch_gen_forward(rl_traj *t, const rl_mlp *m, const float *x, size_t x_stride, uint64_t rows, float *out);
+void launch_gen_policy_pass(rl_traj *t, const rl_mlp *m, int mode, const float *d_tangent, uint64_t B_total,
+                            const int32_t *d_skip, float clip_lo, float clip_hi);
+void launch_gen_critic_fwd(rl_traj *t, const rl_mlp *m, uint64_t B_total);
+void launch_gen_backward(rl_traj *t, const rl_mlp *m, const int32_t *d_skip);
+void launch_gen_values(rl_traj *t, const rl_mlp *critic);  // -> seq.out / seq.succ (plane 0)
+void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t);
 // kernels_seq_train.hip: the GRU chain's training passes with the recurrence on the bf16 matrix pipe
 void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
 void launch_gru_train_head_backward(rl_traj *traj, const rl_mlp *mod, float *d_slab, const int32_t *d_skip);

@@ -1,0 +1,490 @@
+// kernels_general.hip — MLPs of any `MlpConfig.hidden_sizes` (src/torch/modules/ff/mlp.rs:13-34): no hidden layer,
+// several, or one wider than 128 units.  The fused kernels of this library (kernels_critic.hip, kernels_mfma.hip,
+// kernels_rollout.hip) are built for ONE hidden layer of at most 128 units — every BASELINE configuration; any other
+// shape takes this path: per-layer kernels over [unit][sample] activation planes in a workspace attached to the
+// trajectory.  It is the general path, not the fast one (f32 VALU products, one launch per layer).
+//   k_gen_dense    Y = act(b + W X) for 64 samples per workgroup (X tile in LDS, weights through wave-uniform loads,
+//                  four output units per pass); with a tangent: tY = act'(.) (W tX + V X + vb)   (forward-mode, for
+//                  the Fisher-vector product of TRPO, conjugate_gradient.rs:262-339)
+//   k_gen_delta    dX = [X > 0] W^T dY                                   (backward through a hidden layer)
+//   k_gen_wgrad    dW = dY X^T, db = sum dY over a chunk of samples, f64 partials into the slab rows k_reduce sums
+//   k_gen_*_terms  the per-sample loss terms and d loss / d output from the stored outputs (the arithmetic of
+//                  k_policy_pass / k_critic_fwd, kernels_update.hip)
+// Every dot product is `acc = bias; acc = fma(x_k, w_k, acc)`, k ascending (the convention of this library's first
+// layers); sums over samples are f32 within 64 samples and f64 above, like the fused kernels.
+// The launchers at the end plug into the module-generic seams: launch_policy_pass / launch_critic_fwd /
+// launch_mlp_backward (kernels_update.hip), values for GAE and TD targets, row-wise forward, and a step-by-step
+// rollout over the standalone env kernels.
+#include "abi_internal.hpp"
+#include "policy_terms.hpp"
+
+namespace {
+
+constexpr int GT = 64;  // samples per workgroup tile
+
+static inline uint32_t cdiv_g(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+struct DenseArgs {
+  const float *X, *tX;    // [K][.] inputs (rows `xs` / `txs` floats apart), tangent inputs (TANGENT)
+  size_t xs, txs;
+  const float *W, *b;     // [N][K], [N]
+  const float *V, *vb;    // tangent parameters (TANGENT)
+  float *Y, *tY;          // [N][.] outputs (rows `ys` floats apart; tY rows too)
+  size_t ys;
+  size_t S;               // samples
+  int K, N;
+  const int32_t *skip;
+};
+
+template <bool RELU, bool TANGENT>
+__global__ void __launch_bounds__(256) k_gen_dense(DenseArgs a) {
+  extern __shared__ float sm[];  // Xs[K][GT] (+ tXs[K][GT])
+  if (a.skip != nullptr && *a.skip != 0) return;
+  const int s = threadIdx.x & (GT - 1);
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave: its units share scalar weight loads
+  const size_t s0 = (size_t)blockIdx.x * GT;
+  float *Xs = sm, *tXs = sm + (size_t)a.K * GT;
+  for (int idx = threadIdx.x; idx < a.K * GT; idx += 256) {
+    const int k = idx >> 6, ss = idx & (GT - 1);
+    const bool in = s0 + ss < a.S;
+    Xs[idx] = in ? a.X[(size_t)k * a.xs + s0 + ss] : 0.0f;
+    if (TANGENT) tXs[idx] = (in && a.tX != nullptr) ? a.tX[(size_t)k * a.txs + s0 + ss] : 0.0f;
+  }
+  __syncthreads();
+  const bool live = s0 + s < a.S;
+  for (int n0 = 4 * g; n0 < a.N; n0 += 16) {
+    float acc[4], tacc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + u < a.N ? n0 + u : a.N - 1;
+      acc[u] = a.b[n];
+      tacc[u] = TANGENT ? a.vb[n] : 0.0f;
+    }
+    for (int k = 0; k < a.K; ++k) {
+      const float xv = Xs[k * GT + s];
+      const float tv = TANGENT ? tXs[k * GT + s] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u < a.N ? n0 + u : a.N - 1;
+        acc[u] = __builtin_fmaf(xv, a.W[(size_t)n * a.K + k], acc[u]);
+        if (TANGENT) {
+          tacc[u] = __builtin_fmaf(tv, a.W[(size_t)n * a.K + k], tacc[u]);
+          tacc[u] = __builtin_fmaf(xv, a.V[(size_t)n * a.K + k], tacc[u]);
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (n0 + u < a.N) {
+          const bool on = !RELU || acc[u] > 0.0f;
+          a.Y[(size_t)(n0 + u) * a.ys + s0 + s] = on ? acc[u] : 0.0f;
+          if (TANGENT) a.tY[(size_t)(n0 + u) * a.ys + s0 + s] = on ? tacc[u] : 0.0f;
+        }
+    }
+  }
+}
+
+// dX[k][s] = [X[k][s] > 0] sum_n W[n][k] dY[n][s]
+__global__ void __launch_bounds__(256) k_gen_delta(const float *__restrict__ dY, size_t dys, int N,
+                                                   const float *__restrict__ W, int K, const float *__restrict__ X,
+                                                   float *__restrict__ dX, size_t S, const int32_t *__restrict__ skip) {
+  extern __shared__ float sm[];  // dYs[N][GT]
+  if (skip != nullptr && *skip != 0) return;
+  const int s = threadIdx.x & (GT - 1);
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t s0 = (size_t)blockIdx.x * GT;
+  for (int idx = threadIdx.x; idx < N * GT; idx += 256) {
+    const int n = idx >> 6, ss = idx & (GT - 1);
+    sm[idx] = s0 + ss < S ? dY[(size_t)n * dys + s0 + ss] : 0.0f;
+  }
+  __syncthreads();
+  if (s0 + s >= S) return;
+  for (int k0 = 4 * g; k0 < K; k0 += 16) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = 0; n < N; ++n) {
+      const float dv = sm[n * GT + s];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u < K ? k0 + u : K - 1;
+        acc[u] = __builtin_fmaf(dv, W[(size_t)n * K + k], acc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + u < K) {
+        const size_t o = (size_t)(k0 + u) * S + s0 + s;
+        dX[o] = X[o] > 0.0f ? acc[u] : 0.0f;
+      }
+  }
+}
+
+// dW[n][k] = sum_s dY[n][s] X[k][s], db[n] = sum_s dY[n][s] over the samples [chunk * c, chunk * (c + 1)) of slab row c:
+// a workgroup owns a 16 x 16 tile of (n, k); f32 within a 64-sample tile, f64 over the chunk
+__global__ void __launch_bounds__(256) k_gen_wgrad(const float *__restrict__ dY, size_t dys, int N,
+                                                   const float *__restrict__ X, size_t xs, int K, size_t S,
+                                                   uint32_t chunk, double *__restrict__ slab, uint32_t P,
+                                                   uint32_t offW, uint32_t offB, const int32_t *__restrict__ skip) {
+  __shared__ float dYs[16][GT + 1], Xs[16][GT + 1];
+  if (skip != nullptr && *skip != 0) return;
+  const int tiles_k = (K + 15) / 16;
+  const int tn0 = 16 * (int)(blockIdx.x / tiles_k), tk0 = 16 * (int)(blockIdx.x % tiles_k);
+  const int tn = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  const size_t c0 = (size_t)blockIdx.y * chunk, c1 = c0 + chunk < S ? c0 + chunk : S;
+  double accw = 0.0, accb = 0.0;
+  for (size_t s0 = c0; s0 < c1; s0 += GT) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * GT; idx += 256) {
+      const int r = idx >> 6, ss = idx & (GT - 1);
+      const bool in = s0 + ss < c1;
+      dYs[r][ss] = (in && tn0 + r < N) ? dY[(size_t)(tn0 + r) * dys + s0 + ss] : 0.0f;
+      Xs[r][ss] = (in && tk0 + r < K) ? X[(size_t)(tk0 + r) * xs + s0 + ss] : 0.0f;
+    }
+    __syncthreads();
+    float w = 0.0f, b = 0.0f;
+#pragma unroll 8
+    for (int ss = 0; ss < GT; ++ss) {
+      w = __builtin_fmaf(dYs[tn][ss], Xs[tk][ss], w);
+      b = b + dYs[tn][ss];
+    }
+    accw += (double)w;
+    accb += (double)b;
+  }
+  double *__restrict__ row = slab + (size_t)blockIdx.y * P;
+  if (tn0 + tn < N && tk0 + tk < K) row[offW + (size_t)(tn0 + tn) * K + tk0 + tk] = accw;
+  if (tk0 == 0 && tk == 0 && tn0 + tn < N) row[offB + tn0 + tn] = accb;
+}
+
+// per-sample policy terms from stored logits (and tangent logits): the arithmetic of k_policy_pass
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gen_policy_terms(TrajDev tr, const float *__restrict__ z,
+                                                          const float *__restrict__ tz, float *__restrict__ lp0,
+                                                          float *__restrict__ dz, double *__restrict__ slabB,
+                                                          float inv_B, const int32_t *__restrict__ skip, float clip_lo,
+                                                          float clip_hi) {
+  __shared__ double red[256];
+  if (skip != nullptr && *skip != 0) return;
+  const size_t B = (size_t)tr.T * tr.n;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) {
+    const float zz[2] = {z[b], z[B + b]};
+    const float tt[2] = {MODE == PASS_JVP ? tz[b] : 0.0f, MODE == PASS_JVP ? tz[B + b] : 0.0f};
+    policy_sample_terms<MODE>(zz, tt, (int)tr.action[b], MODE == PASS_JVP ? 0.0f : tr.adv[b], b, B, lp0, dz, inv_B, clip_lo,
+                              clip_hi, s0, s1, s2);
+  }
+  if (MODE != PASS_JVP) {
+    double t0 = block_sum<256>(s0, red);
+    double t1 = block_sum<256>(s1, red);
+    double t2 = block_sum<256>(s2, red);
+    if (threadIdx.x == 0) {
+      slabB[blockIdx.x * 4 + 0] = t0;
+      slabB[blockIdx.x * 4 + 1] = t1;
+      slabB[blockIdx.x * 4 + 2] = t2;
+      slabB[blockIdx.x * 4 + 3] = 0.0;
+    }
+  }
+}
+
+// critic: d = V - target, dz = 2 d / B, loss partial = sum d^2 (k_critic_fwd)
+__global__ void __launch_bounds__(256) k_gen_critic_terms(TrajDev tr, const float *__restrict__ v,
+                                                          float *__restrict__ dz, double *__restrict__ slabB,
+                                                          float two_over_B) {
+  __shared__ double red[256];
+  const size_t B = (size_t)tr.T * tr.n;
+  double s0 = 0.0;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) {
+    const float d = v[b] - tr.tgt[b];
+    dz[b] = d * two_over_B;
+    s0 += (double)(d * d);
+  }
+  double t0 = block_sum<256>(s0, red);
+  if (threadIdx.x == 0) {
+    slabB[blockIdx.x * 4 + 0] = t0;
+    slabB[blockIdx.x * 4 + 1] = 0.0;
+    slabB[blockIdx.x * 4 + 2] = 0.0;
+    slabB[blockIdx.x * 4 + 3] = 0.0;
+  }
+}
+
+// successor values of cut episodes for k_seq_gae / the TD targets: V(term_obs) after an Interrupt, V(obs[T]) for a lane
+// the horizon cuts, 0 elsewhere (eval_extended_state_values, critics/mod.rs:116-131)
+__global__ void __launch_bounds__(256) k_gen_successor_values(TrajDev tr, const float *__restrict__ v_term,
+                                                              const float *__restrict__ v_last,
+                                                              float *__restrict__ succ) {
+  const size_t B = (size_t)tr.T * tr.n;
+  const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t t = (uint32_t)(b / tr.n), i = (uint32_t)(b % tr.n);
+  const int f = tr.flag[b];
+  float s = 0.0f;
+  if (f == RL_SUCC_INTERRUPT) s = v_term[b];
+  else if (f == RL_SUCC_CONTINUE && t == tr.T - 1) s = v_last[i];
+  succ[b] = s;
+}
+
+// PolicyActor::act for one step of every lane from stored logits: Categorical::new + the inverse-CDF draw with word
+// `word` of the lane's actor stream (the fused rollouts' arithmetic, kernels_rollout.hip)
+__global__ void __launch_bounds__(256) k_gen_sample_actions(CartPoleDev c, const float *__restrict__ z, uint32_t n,
+                                                            uint64_t word, uint8_t *__restrict__ actions) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16];
+  rl_chacha_block(c.key_actor, word >> 4, c.lane_offset + i, 4, w);
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k == (int)(word & 15)) v = w[k];
+  const float u = rl_u32_to_unit_f32(v);
+  const float zz[2] = {z[i], z[n + i]};
+  float lp[2];
+  log_softmax_lane<2>(zz, lp);
+  actions[i] = (uint8_t)categorical_sample_lane<2>(lp, u);
+}
+
+// one step's record: the observation the step started from, then what the env's step kernel left in its buffers
+__global__ void __launch_bounds__(256) k_gen_record_obs(TrajDev tr, const float *__restrict__ obs, uint32_t t) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= tr.n) return;
+  const size_t plane = (size_t)(tr.T + 1) * tr.n;
+  for (uint32_t d = 0; d < tr.D; ++d) tr.obs[d * plane + (size_t)t * tr.n + i] = obs[(size_t)d * tr.n + i];
+}
+__global__ void __launch_bounds__(256) k_gen_record_step(TrajDev tr, const uint8_t *__restrict__ actions,
+                                                         const float *__restrict__ reward,
+                                                         const uint8_t *__restrict__ flag,
+                                                         const float *__restrict__ term_obs, uint32_t t) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= tr.n) return;
+  const size_t o = (size_t)t * tr.n + i;
+  tr.action[o] = actions[i];
+  tr.reward[o] = reward[i];
+  tr.flag[o] = flag[i];
+  if (flag[i] == RL_SUCC_INTERRUPT)
+    for (uint32_t d = 0; d < tr.D; ++d) tr.term_obs[(size_t)d * tr.T * tr.n + o] = term_obs[(size_t)d * tr.n + i];
+}
+
+template <bool RELU, bool TANGENT>
+void dense(rl_engine *e, const DenseArgs &a) {
+  const size_t lds = (size_t)a.K * GT * sizeof(float) * (TANGENT ? 2 : 1);
+  if (lds > 64 * 1024) {  // (once per instantiation: the tangent tiles of a 256-wide layer need 128 KB)
+    static bool raised = false;
+    if (!raised) {
+      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_dense<RELU, TANGENT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((k_gen_dense<RELU, TANGENT>), dim3(cdiv_g(a.S, GT)), dim3(256), lds, e->stream, a);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- workspace
+// activation planes [hidden unit][rows], tangent planes, two delta planes of the widest layer, outputs and tangent
+// outputs [2][rows]; grown on demand
+void gen_ensure(rl_traj *t, const rl_mlp *m, uint64_t rows, bool tangent, bool backward) {
+  GenDev &g = t->gen;
+  const uint64_t units = m->hidden_units() ? m->hidden_units() : 1;
+  uint32_t wmax = 1;
+  for (uint32_t l = 0; l < m->n_hidden; ++l) wmax = m->widths[l] > wmax ? m->widths[l] : wmax;
+  auto grow = [&](float *&p, uint64_t &cap, uint64_t need) {
+    if (cap >= need) return;
+    dfree(p);
+    p = nullptr;
+    cap = 0;
+    p = dalloc<float>(need);
+    cap = need;
+  };
+  grow(g.act, g.cap_act, units * rows);
+  grow(g.z, g.cap_z, 2 * rows);
+  if (tangent) {
+    grow(g.tact, g.cap_tact, units * rows);
+    grow(g.tz, g.cap_tz, 2 * rows);
+  }
+  if (backward) grow(g.delta, g.cap_delta, 2ull * wmax * rows);
+  // the P-sized vectors and the slab of the update workspace grow with the module (training passes only)
+  if (backward && t->Pmax < m->P) {
+    for (float **p : {&t->vec, &t->cg_x, &t->cg_r, &t->cg_p, &t->prev_params, &t->descent}) {
+      dfree(*p);
+      *p = nullptr;
+    }
+    dfree(t->slabA);
+    t->slabA = nullptr;
+    t->Pmax = (uint32_t)m->P;
+    t->vec = dalloc<float>(t->Pmax + 4);
+    t->cg_x = dalloc<float>(t->Pmax);
+    t->cg_r = dalloc<float>(t->Pmax);
+    t->cg_p = dalloc<float>(t->Pmax);
+    t->prev_params = dalloc<float>(t->Pmax);
+    t->descent = dalloc<float>(t->Pmax);
+    uint32_t rowsA = t->nbA;
+    if (t->nbV2 > rowsA) rowsA = t->nbV2;
+    if (t->nbC > rowsA) rowsA = t->nbC;
+    t->slabA = dalloc<double>((size_t)rowsA * t->Pmax);
+  }
+}
+
+void gen_free(rl_traj *t) {
+  GenDev &g = t->gen;
+  for (float *p : {g.act, g.tact, g.delta, g.z, g.tz}) dfree(p);
+  g = GenDev{};
+}
+
+// ---------------------------------------------------------------- forward (+ tangent) over `rows` samples
+// x: [in_dim][.] rows `xs` apart; activations into g.act (and g.tact); outputs [out][rows] into `out` (and `tout`)
+static void gen_forward_impl(rl_traj *t, const rl_mlp *m, const float *x, size_t xs, uint64_t rows, float *out,
+                             const float *tangent, float *tout, const int32_t *skip) {
+  rl_engine *e = t->eng;
+  GenDev &g = t->gen;
+  const float *in = x, *tin = nullptr;
+  size_t in_stride = xs;
+  uint64_t unit0 = 0;
+  for (uint32_t l = 0; l < m->n_layers(); ++l) {
+    const bool last = l == m->n_hidden;
+    const uint64_t off = m->layer_offset(l);
+    DenseArgs a{};
+    a.X = in;
+    a.xs = in_stride;
+    a.tX = tin;
+    a.txs = rows;
+    a.K = (int)m->fan_in(l);
+    a.N = (int)m->fan_out(l);
+    a.W = m->d_params + off;
+    a.b = a.W + (size_t)a.N * a.K;
+    a.V = tangent ? tangent + off : nullptr;
+    a.vb = tangent ? a.V + (size_t)a.N * a.K : nullptr;
+    a.Y = last ? out : g.act + unit0 * rows;
+    a.tY = last ? tout : g.tact + unit0 * rows;
+    a.ys = rows;
+    a.S = rows;
+    a.skip = skip;
+    if (tangent) {
+      if (last) dense<false, true>(e, a);
+      else dense<true, true>(e, a);
+    } else {
+      if (last) dense<false, false>(e, a);
+      else dense<true, false>(e, a);
+    }
+    if (!last) {
+      in = g.act + unit0 * rows;
+      tin = tangent ? g.tact + unit0 * rows : nullptr;
+      in_stride = rows;
+      unit0 += m->widths[l];
+    }
+  }
+}
+
+void launch_gen_forward(rl_traj *t, const rl_mlp *m, const float *x, size_t xs, uint64_t rows, float *out) {
+  gen_ensure(t, m, rows, false, false);
+  gen_forward_impl(t, m, x, xs, rows, out, nullptr, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------- the v1 seams (kernels_update.hip)
+void launch_gen_policy_pass(rl_traj *t, const rl_mlp *m, int mode, const float *d_tangent, uint64_t B_total,
+                            const int32_t *d_skip, float clip_lo, float clip_hi) {
+  const uint64_t B = t->B;
+  const bool jvp = mode == PASS_JVP;
+  gen_ensure(t, m, B, jvp, true);
+  GenDev &g = t->gen;
+  const size_t plane = (size_t)(t->d.T + 1) * t->d.n;
+  gen_forward_impl(t, m, t->d.obs, plane, B, g.z, jvp ? d_tangent : nullptr, jvp ? g.tz : nullptr, d_skip);
+  float inv_B = 1.0f / (float)B_total;
+  if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
+  dim3 grid(t->nbB), blk(256);
+#define TERMS(MM)                                                                                                \
+  hipLaunchKernelGGL((k_gen_policy_terms<MM>), grid, blk, 0, t->eng->stream, t->d, g.z, g.tz, t->lp0, t->dz, t->slabB, \
+                     inv_B, d_skip, clip_lo, clip_hi)
+  if (mode == PASS_INIT) TERMS(PASS_INIT);
+  else if (mode == PASS_EVAL) TERMS(PASS_EVAL);
+  else if (mode == PASS_DQN) TERMS(PASS_DQN);
+  else if (mode == PASS_PPO) TERMS(PASS_PPO);
+  else TERMS(PASS_JVP);
+#undef TERMS
+}
+
+void launch_gen_critic_fwd(rl_traj *t, const rl_mlp *m, uint64_t B_total) {
+  const uint64_t B = t->B;
+  gen_ensure(t, m, B, false, true);
+  GenDev &g = t->gen;
+  const size_t plane = (size_t)(t->d.T + 1) * t->d.n;
+  gen_forward_impl(t, m, t->d.obs, plane, B, g.z, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_gen_critic_terms, dim3(t->nbB), dim3(256), 0, t->eng->stream, t->d, g.z, t->dz, t->slabB,
+                     2.0f / (float)B_total);
+}
+
+// backward from t->dz ([out][B]) through the activations of the last forward: slab rows [0, nbA) x P
+void launch_gen_backward(rl_traj *t, const rl_mlp *m, const int32_t *d_skip) {
+  rl_engine *e = t->eng;
+  GenDev &g = t->gen;
+  const uint64_t B = t->B;
+  const size_t plane = (size_t)(t->d.T + 1) * t->d.n;
+  const uint32_t P = (uint32_t)m->P;
+  const float *dY = t->dz;
+  uint64_t unit_hi = m->hidden_units();
+  uint32_t wmax = 1;
+  for (uint32_t l = 0; l < m->n_hidden; ++l) wmax = m->widths[l] > wmax ? m->widths[l] : wmax;
+  for (uint32_t l = m->n_layers(); l-- > 0;) {
+    const int K = (int)m->fan_in(l), N = (int)m->fan_out(l);
+    const uint64_t off = m->layer_offset(l);
+    const float *X;
+    size_t xs;
+    if (l == 0) {
+      X = t->d.obs;
+      xs = plane;
+    } else {
+      unit_hi -= m->widths[l - 1];
+      X = g.act + unit_hi * B;
+      xs = B;
+    }
+    const uint32_t tiles = (uint32_t)(((N + 15) / 16) * ((K + 15) / 16));
+    hipLaunchKernelGGL(k_gen_wgrad, dim3(tiles, t->nbA), dim3(256), 0, e->stream, dY, (size_t)B, N, X, xs, K, (size_t)B,
+                       t->bwd_chunk, t->slabA, P, (uint32_t)off, (uint32_t)(off + (uint64_t)N * K), d_skip);
+    if (l > 0) {
+      float *dX = g.delta + (size_t)(l & 1) * wmax * B;
+      hipLaunchKernelGGL(k_gen_delta, dim3(cdiv_g(B, GT)), dim3(256), (size_t)N * GT * sizeof(float), e->stream, dY,
+                         (size_t)B, N, m->d_params + off, K, X, dX, (size_t)B, d_skip);
+      dY = dX;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- values for GAE / TD targets
+// seq.out[0] <- V(obs[t]) for t < T, seq.succ[0] <- successor values of cut episodes (the layout launch_seq_gae and
+// launch_seq_value_targets read)
+void launch_gen_values(rl_traj *t, const rl_mlp *critic) {
+  const uint64_t n = t->d.n, T = t->d.T, B = T * n;
+  SeqDev &q = t->seq;
+  if (q.out == nullptr) {
+    q.out = dalloc<float>(2 * B);
+    q.succ = dalloc<float>(2 * B);
+  }
+  gen_ensure(t, critic, B, false, false);
+  GenDev &g = t->gen;
+  const size_t plane = (size_t)(T + 1) * n;
+  // V(term_obs[t][lane]) for every (t, lane) (only the interrupted ones are used), V(obs[T][lane]), then V(obs[t])
+  gen_forward_impl(t, critic, t->d.term_obs, (size_t)B, B, g.z, nullptr, nullptr, nullptr);
+  gen_forward_impl(t, critic, t->d.obs + (size_t)T * n, plane, n, g.z + B, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_gen_successor_values, dim3(cdiv_g(B, 256)), dim3(256), 0, t->eng->stream, t->d, g.z, g.z + B,
+                     q.succ);
+  gen_forward_impl(t, critic, t->d.obs, plane, B, q.out, nullptr, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------- rollout, one launch sequence per step
+// observe -> policy forward -> sample -> env step -> record, over the standalone env kernels (either env family)
+void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t) {
+  rl_engine *e = env->eng;
+  const uint32_t n = t->d.n, T = t->d.T;
+  gen_ensure(t, policy, n, false, false);
+  GenDev &g = t->gen;
+  const dim3 grid(cdiv_g(n, 256)), blk(256);
+  launch_env_observe(env, env->d_obs);
+  for (uint32_t step = 0; step < T; ++step) {
+    hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, step);
+    gen_forward_impl(t, policy, env->d_obs, (size_t)n, n, g.z, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_gen_sample_actions, grid, blk, 0, e->stream, env->dev, g.z, n, env->t_global, env->d_actions);
+    launch_env_step(env);  // leaves reward, flag, the next observation and the interrupted successor in the env's buffers
+    env->t_global += 1;
+    hipLaunchKernelGGL(k_gen_record_step, grid, blk, 0, e->stream, t->d, env->d_actions, env->d_reward, env->d_flag,
+                       env->d_term_obs, step);
+  }
+  hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, T);
+}

@@ -17,6 +17,7 @@
 #include "comm_ipc.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
+#include "policy_terms.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -71,83 +72,12 @@ __global__ void __launch_bounds__(256) k_policy_pass(TrajDev tr, const float *__
           dzt[a] = __builtin_fmaf(h, tW2[a * H + j], dzt[a]);
         }
       }
-      float lp[A], p[A];
-      log_softmax_lane<A>(z, lp);
-      float pdz = 0.0f;
-#pragma unroll
-      for (int a = 0; a < A; ++a) {
-        p[a] = rl_expf(lp[a]);
-        pdz = __builtin_fmaf(p[a], dzt[a], pdz);
-      }
-#pragma unroll
-      for (int a = 0; a < A; ++a) dz[(size_t)a * B + b] = p[a] * (dzt[a] - pdz) * inv_B;
+      policy_sample_terms<MODE>(z, dzt, act, 0.0f, b, B, lp0, dz, inv_B, clip_lo, clip_hi, s0, s1, s2);
     } else {
-      float z[A], lp[A];
+      float z[A];
       mlp_forward_lane<D, A>(params, H, x, z);
-      float adv = tr.adv[b];
-      if (MODE == PASS_DQN) {
-        // action_values.gather(-1, actions).mse_loss(targets, Mean) + backward (dqn.rs:316-326); inv_B = 2 / B
-        float dq = (act == 0 ? z[0] : z[1]) - adv;
-        float g = dq * inv_B;
-        dz[b] = act == 0 ? g : 0.0f;
-        dz[B + b] = act == 1 ? g : 0.0f;
-        s0 += (double)(dq * dq);
-        continue;
-      }
-      log_softmax_lane<A>(z, lp);
-      if (MODE == PASS_PPO) {
-        // clipped surrogate of Ppo::update (policies/ppo.rs:124-137) and its torch-autograd gradient: minimum()
-        // splits a tie between its arguments, clamp() passes the gradient inside [lo, hi] (bounds included)
-        float l0a = lp0[(size_t)act * B + b];
-        float lpa = act == 0 ? lp[0] : lp[1];
-        float ratio = rl_expf(lpa - l0a);
-        float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
-        float u1 = ratio * adv, u2 = clipped * adv;
-        bool inside = ratio >= clip_lo && ratio <= clip_hi;
-        float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
-        float c = -(gr * ratio) * inv_B;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-          float ind = a == act ? 1.0f : 0.0f;
-          dz[(size_t)a * B + b] = c * (ind - rl_expf(lp[a]));
-        }
-        s0 += (double)(u1 < u2 ? u1 : u2);
-        continue;
-      }
-      if (MODE == PASS_INIT) {
-        float lpa = act == 0 ? lp[0] : lp[1];
-        s2 += (double)(lpa * adv);
-        float ratio = rl_expf(lpa - lpa);
-        float c = -(ratio * adv) * inv_B;
-        float ent = 0.0f;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-          float pa = rl_expf(lp[a]);
-          float ind = a == act ? 1.0f : 0.0f;
-          lp0[(size_t)a * B + b] = lp[a];
-          dz[(size_t)a * B + b] = c * (ind - pa);
-          float cl = lp[a] < -FLT_MAX ? -FLT_MAX : lp[a];
-          ent += cl * pa;
-        }
-        s0 += (double)(ratio * adv);
-        s1 += (double)(-ent);
-      } else {  // PASS_EVAL
-        float l0[A];
-#pragma unroll
-        for (int a = 0; a < A; ++a) l0[a] = lp0[(size_t)a * B + b];
-        float lpa = act == 0 ? lp[0] : lp[1];
-        float l0a = act == 0 ? l0[0] : l0[1];
-        float ratio = rl_expf(lpa - l0a);
-        float kl = 0.0f;
-#pragma unroll
-        for (int a = 0; a < A; ++a) {
-          float rel = l0[a] - lp[a];
-          if (rel < -FLT_MAX) rel = -FLT_MAX;
-          kl += rel * rl_expf(l0[a]);
-        }
-        s0 += (double)(ratio * adv);
-        s1 += (double)kl;
-      }
+      const float none[A] = {0.0f, 0.0f};
+      policy_sample_terms<MODE>(z, none, act, tr.adv[b], b, B, lp0, dz, inv_B, clip_lo, clip_hi, s0, s1, s2);
     }
   }
   if (MODE != PASS_JVP) {
@@ -605,6 +535,7 @@ void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const flo
                         const int32_t *d_skip, float clip_lo, float clip_hi) {
   ProfScope ps(traj->eng, RL_K_POLICY_PASS);
   RL_REQUIRE(policy->out_dim == 2, "policy pass: only 2-action categorical policies are built");
+  if (policy->general) return launch_gen_policy_pass(traj, policy, mode, d_tangent, B_total, d_skip, clip_lo, clip_hi);
   float inv_B = 1.0f / (float)B_total;
   dim3 g(traj->nbB), b(256);
   hipStream_t s = traj->eng->stream;
@@ -631,6 +562,7 @@ void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const flo
 
 void launch_critic_fwd(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
   ProfScope ps(traj->eng, RL_K_CRITIC_FWD);
+  if (critic->general) return launch_gen_critic_fwd(traj, critic, B_total);
   float two_over_B = 2.0f / (float)B_total;
   dim3 g(traj->nbB), b(256);
   if (traj->d.D == 5)
@@ -643,6 +575,7 @@ void launch_critic_fwd(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
 
 void launch_mlp_backward(rl_traj *traj, const rl_mlp *mlp, const int32_t *d_skip) {
   ProfScope ps(traj->eng, RL_K_BACKWARD);
+  if (mlp->general) return launch_gen_backward(traj, mlp, d_skip);
   RL_REQUIRE(mlp->hidden <= 128, "backward kernel v1 supports hidden <= 128");
   dim3 g(traj->nbA), b(128);
   size_t plane = (size_t)(traj->d.T + 1) * traj->d.n;

@@ -90,7 +90,20 @@ int main() {
         agent->batch_update(log);
       }
       log.scalars["global_steps"] = (double)agent->global_steps();
-      dump("dqn", log, checksum(agent->action_value_fn().parameters()), 0.0, true);
+      dump("dqn", log, checksum(agent->action_value_fn().parameters()), 0.0, false);
+    }
+    {  // MlpConfig { hidden_sizes: [64, 64] }: the general per-layer path behind the same agent configuration
+      CartPoleLanes env(eng, 128, 500, StepLimit::Visible, 7, 8);
+      ActorCriticConfig<TrpoConfig<MlpConfig>, ValuesOptConfig<MlpConfig>> cfg;
+      cfg.policy_config.policy_fn_config.hidden_sizes = {64, 64};
+      cfg.critic_config.state_value_fn_config.hidden_sizes = {64, 64};
+      cfg.critic_config.opt_steps_per_update = 3;
+      auto agent = cfg.build_agent(env, 9);
+      if (agent->policy_module().num_parameters() != 5 * 64 + 64 + 64 * 64 + 64 + 64 * 2 + 2) return 3;
+      DeviceHistory history = agent->buffer(16);
+      RecordingLogger log;
+      train_batched(*agent, env, history, 1, log);
+      dump("trpo_two_layers", log, checksum(agent->policy_module().parameters()), checksum(agent->critic_module()->parameters()), false);
     }
     {  // Actor::act, one observation at a time: the scalar actor repeats the device rollout's choices when its Prng
        // stands at word t of stream `lane` of the env's actor seed
@@ -117,14 +130,14 @@ int main() {
           mismatches += actor->act(x, rng) != act[t * n + lane];
           ++checked;
         }
-      std::printf(", \"actor\": {\"checked\": %llu, \"mismatches\": %llu}\n", (unsigned long long)checked,
+      std::printf("\"actor\": {\"checked\": %llu, \"mismatches\": %llu}\n", (unsigned long long)checked,
                   (unsigned long long)mismatches);
     }
     std::printf("}\n");
     // error behaviour: an unsupported module shape is a BuildAgentError
     try {
       MlpConfig bad;
-      bad.hidden_size = 4096;
+      bad.hidden_sizes = {4096};
       bad.build_module(eng, 5, 2, 0);
       return 2;
     } catch (const BuildAgentError &) {

@@ -1,0 +1,237 @@
+"""MLPs of any `MlpConfig.hidden_sizes` (src/torch/modules/ff/mlp.rs:13-34) through the C ABI: shapes the fused
+single-hidden-layer kernels do not cover run the per-layer kernels of relearn_amd/csrc/kernels_general.hip.  The checker
+here is an f64 NumPy restatement of the same network (forward, backward, forward-mode tangents) around the oracle's
+array-fed pieces (loss terms from logits, GAE / TD targets from value arrays); the env side of the step-by-step rollout
+is replayed through the oracle's lanes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+import relearn_amd as ra
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [[], [64, 64], [256], [32, 16, 8], [130], [200, 3, 256, 17]]
+
+
+def layers(in_dim, hidden, out_dim):
+    w = [in_dim] + list(hidden) + [out_dim]
+    return list(zip(w[:-1], w[1:]))
+
+
+def unflatten(p, in_dim, hidden, out_dim):
+    out, k = [], 0
+    for fi, fo in layers(in_dim, hidden, out_dim):
+        W = p[k:k + fi * fo].reshape(fo, fi)
+        k += fi * fo
+        b = p[k:k + fo]
+        k += fo
+        out.append((W.astype(np.float64), b.astype(np.float64)))
+    assert k == p.size
+    return out
+
+
+def forward64(net, x):
+    """x [rows][in] -> (outputs [rows][out], activations per hidden layer)"""
+    acts, h = [], x.astype(np.float64)
+    for i, (W, b) in enumerate(net):
+        h = h @ W.T + b
+        if i + 1 < len(net):
+            h = np.maximum(h, 0.0)
+            acts.append(h)
+    return h, acts
+
+
+def backward64(net, x, acts, dz):
+    """gradient of sum(dz * outputs) w.r.t. the flat parameters"""
+    grads, d = [], dz
+    inputs = [x.astype(np.float64)] + acts
+    for i in reversed(range(len(net))):
+        W, _ = net[i]
+        grads.append((d.T @ inputs[i], d.sum(axis=0)))
+        if i > 0:
+            d = (d @ W) * (acts[i - 1] > 0)
+    return np.concatenate([np.concatenate([gw.ravel(), gb]) for gw, gb in reversed(grads)])
+
+
+def jvp64(net, tnet, x):
+    h, th = x.astype(np.float64), np.zeros_like(x, dtype=np.float64)
+    for i, ((W, b), (V, vb)) in enumerate(zip(net, tnet)):
+        th = th @ W.T + h @ V.T + vb
+        h = h @ W.T + b
+        if i + 1 < len(net):
+            th = th * (h > 0)
+            h = np.maximum(h, 0.0)
+    return h, th
+
+
+def make(engine, in_dim, hidden, out_dim, seed):
+    m = ra.Mlp(engine, in_dim, hidden, out_dim)
+    m.init(seed)
+    return m
+
+
+@pytest.mark.parametrize("hidden", SHAPES)
+def test_shapes_init_and_forward(engine, hidden):
+    rng = np.random.default_rng(1)
+    for in_dim, out_dim in ((5, 2), (4, 1)):
+        m = make(engine, in_dim, hidden, out_dim, 7)
+        assert m.P == sum(fi * fo + fo for fi, fo in layers(in_dim, hidden, out_dim))
+        p = m.get_params()
+        k = 0
+        for fi, fo in layers(in_dim, hidden, out_dim):  # Linear::new: Uniform(+-sqrt(6 / (fan_in + 1 + fan_out)))
+            lim = np.float32(np.sqrt(3.0 * (2.0 / ((fi + 1) + fo))))
+            blk = p[k:k + fi * fo + fo]
+            k += fi * fo + fo
+            assert np.abs(blk).max() <= lim and (blk.size < 50 or np.abs(blk).max() > 0.8 * lim)
+        assert np.array_equal(p, make(engine, in_dim, hidden, out_dim, 7).get_params())
+        x = rng.normal(size=(300, in_dim)).astype(np.float32)
+        want, _ = forward64(unflatten(p, in_dim, hidden, out_dim), x)
+        got = m.forward(x)
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+def test_unsupported_shapes_are_refused(engine):
+    for hidden in ([300], [8] * 5, [0]):
+        with pytest.raises(ra.RelearnError):
+            ra.Mlp(engine, 5, hidden, 2)
+    q = ra.Mlp(engine, 5, [64, 64], 2)
+    env = ra.CartPoleEnv(engine, 64)
+    with pytest.raises(ra.RelearnError):  # DQN: single-hidden-layer modules only
+        ra.Dqn(env, q, ra.Adam(q), ra.dqn_config_default())
+
+
+def collect(engine, pol, n=96, T=12, seed=3):
+    env = ra.CartPoleEnv(engine, n, max_steps=9, seed_env=seed, seed_actor=seed + 1)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    return env, traj
+
+
+@pytest.mark.parametrize("hidden", [[64, 64], [130], []])
+def test_rollout_step_by_step(engine, hidden):
+    """the env side of the recorded trajectory replays bit for bit through the oracle's lanes; every recorded action is
+    the inverse-CDF draw of the policy's distribution with the lane's actor word (compared wherever the uniform is not
+    within 1e-5 of the boundary: the logits are checked to f32 tolerance, not bit for bit)"""
+    n, T = 96, 12
+    pol = make(engine, 5, hidden, 2, 11)
+    env, traj = collect(engine, pol, n, T)
+    got = traj.read_all()
+    sim = O.LaneSim(n, max_steps=9, seed_env=3, seed_actor=4)
+    assert np.array_equal(got["obs"][:, 0, :], sim.observe())
+    for t in range(T):
+        reward, flag, obs, term = sim.step(got["action"][t])
+        assert np.array_equal(got["reward"][t], reward) and np.array_equal(got["flag"][t], flag), t
+        assert np.array_equal(got["obs"][:, t + 1, :], obs), t
+        m = flag == O.INTERRUPT
+        assert np.array_equal(got["term_obs"][:, t, m], term[:, m])
+    assert (got["flag"] != O.CONTINUE).any()
+    net = unflatten(pol.get_params(), 5, hidden, 2)
+    r = O.Prng()
+    checked = 0
+    for t in range(T):
+        z, _ = forward64(net, got["obs"][:, t, :].T)
+        p0 = 1.0 / (1.0 + np.exp(z[:, 1] - z[:, 0]))
+        for i in range(n):
+            O.lib().oracle_prng_seed_from_u64(C.byref(r), 4)
+            O.lib().oracle_prng_set_stream(C.byref(r), i)
+            O.lib().oracle_prng_set_word_pos(C.byref(r), t)
+            u = O.lib().oracle_prng_gen_f32(C.byref(r))
+            if abs(u - p0[i]) > 1e-5:
+                assert got["action"][t, i] == (0 if u < p0[i] else 1), (t, i)
+                checked += 1
+    assert checked > 0.99 * n * T
+    # a second rollout continues the lanes and the streams
+    ra.rollout(env, pol, traj)
+    assert np.array_equal(traj.read_all()["obs"][:, 0, :], sim.observe())
+
+
+@pytest.mark.parametrize("hidden", [[64, 64], [256], [32, 16, 8], []])
+def test_gradients_and_fisher_vector_products(engine, hidden):
+    pol, cri = make(engine, 5, hidden, 2, 21), make(engine, 5, hidden, 1, 22)
+    _, traj = collect(engine, pol)
+    ra.gae(traj, cri, 0.99, 0.95)
+    tr = traj.read_all()
+    n, T = tr["action"].shape[1], tr["action"].shape[0]
+    B = n * T
+    x = tr["obs"][:, :T, :].reshape(5, B).T
+    # ---- values, advantages, returns: the oracle's array-fed scan on f64 values
+    cnet = unflatten(cri.get_params(), 5, hidden, 1)
+    v = forward64(cnet, x)[0][:, 0]
+    assert np.allclose(traj.read(ra.TRAJ_VALUES)[:T].reshape(-1), v, rtol=2e-5, atol=2e-6)
+    adv, rtg = traj.read(ra.TRAJ_ADVANTAGES).reshape(-1), traj.read(ra.TRAJ_RETURNS).reshape(-1)
+    assert np.isfinite(adv).all() and np.abs(adv).max() > 0
+    # ---- policy gradient: loss = -mean(A log pi(a)) at ratio 1 (Trpo / Reinforce closure)
+    pnet = unflatten(pol.get_params(), 5, hidden, 2)
+    z, acts = forward64(pnet, x)
+    lp = z - np.log(np.exp(z - z.max(axis=1, keepdims=True)).sum(axis=1, keepdims=True)) - z.max(axis=1, keepdims=True)
+    p = np.exp(lp)
+    a = tr["action"].reshape(-1).astype(np.int64)
+    onehot = np.eye(2)[a]
+    dz = -(adv[:, None].astype(np.float64)) * (onehot - p) / B
+    want = backward64(pnet, x, acts, dz)
+    got, loss = ra.policy_gradient(pol, traj)[:2]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-5 * scale + 1e-9
+    # ---- critic gradient: mean((V - returns)^2)
+    dv = (2.0 * (v - rtg.astype(np.float64)) / B)[:, None]
+    _, cacts = forward64(cnet, x)
+    cwant = backward64(cnet, x, cacts, dv)
+    cgot = ra.critic_gradient(cri, traj)[0]
+    assert np.abs(cgot - cwant).max() <= 2e-5 * np.abs(cwant).max() + 1e-9
+    # ---- Fisher-vector product: J^T (diag(p) - p p^T) J v / B + reg v
+    rng = np.random.default_rng(5)
+    vec = rng.normal(size=pol.P).astype(np.float32)
+    tnet = unflatten(vec, 5, hidden, 2)
+    _, tz = jvp64(pnet, tnet, x)
+    mz = p * (tz - (p * tz).sum(axis=1, keepdims=True)) / B
+    fwant = backward64(pnet, x, acts, mz) + 1e-5 * vec.astype(np.float64)
+    fgot = ra.policy_fvp(pol, traj, vec, 1e-5)
+    assert np.abs(fgot - fwant).max() <= 5e-5 * np.abs(fwant).max() + 1e-9
+
+
+@pytest.mark.parametrize("hidden", [[64, 64], [130]])
+def test_updates_run_and_improve(engine, hidden):
+    pol, cri = make(engine, 5, hidden, 2, 31), make(engine, 5, hidden, 1, 32)
+    env = ra.CartPoleEnv(engine, 256, max_steps=500, seed_env=1, seed_actor=2)
+    traj = ra.Trajectory(engine, 256, 32, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    st = ra.trpo_update(pol, traj)
+    assert st.status == ra.OPT_OK and 0 < st.constraint_val_final <= 0.01 and st.loss_final < st.loss_initial
+    cs, losses = ra.critic_update(cri, ra.Adam(cri), traj, 8, want_losses=True)
+    assert losses[-1] < losses[0]
+    vcfg = ra.values_opt_config_default()
+    vcfg.opt_steps_per_update, vcfg.target, vcfg.discount_factor = 3, ra.VALUE_TARGET_ONE_STEP_TD, 0.99
+    vs, vl = ra.values_opt_update(cri, ra.Adam(cri), traj, vcfg, want_losses=True)
+    assert np.isfinite(vl).all()
+    ppo = ra.ppo_config_default()
+    ppo.opt_steps_per_update = 3
+    ps, pl = ra.ppo_update(pol, ra.Adam(pol), traj, ppo, want_losses=True)
+    assert pl[-1] < pl[0]
+    ra.reinforce_update(pol, ra.Adam(pol), traj)
+    # actor serialisation round trip (Mlp { layers: [...] })
+    doc = ra.actor_to_cbor(env, pol)
+    twin = ra.Mlp(engine, 5, hidden, 2)
+    ra.module_from_cbor(twin, doc)
+    assert np.array_equal(twin.get_params(), pol.get_params())
+
+
+def test_two_hidden_layers_learn_cartpole(engine):
+    """the behavioural check of tests/test_gpu_learning.py on MlpConfig { hidden_sizes: [64, 64] }"""
+    n, T = 1024, 64
+    env = ra.CartPoleEnv(engine, n, max_steps=500, seed_env=0, seed_actor=1)
+    pol, cri = make(engine, 5, [64, 64], 2, 2), make(engine, 5, [64, 64], 1, 3)
+    copt = ra.Adam(cri)
+    traj = ra.Trajectory(engine, n, T, 5)
+    lengths = []
+    for _ in range(14):
+        ra.rollout(env, pol, traj)
+        ends = (traj.read(ra.TRAJ_FLAG) != 0).sum()
+        lengths.append(n * T / max(ends, 1))
+        ra.gae(traj, cri, 0.99, 0.95)
+        ra.trpo_update(pol, traj)
+        ra.critic_update(cri, copt, traj, 20)
+    assert lengths[0] < 40 and lengths[-1] > 2.5 * lengths[0], lengths

@@ -124,6 +124,19 @@ def test_cpp_host_api_matches_the_ctypes_path(engine):
     assert d["scalars"]["loss"] == ust.loss_last and d["scalars"]["exploration_rate"] == rate
     assert d["scalars"]["global_steps"] == ust.global_steps == steps
     assert d["counters"] == {"sim/ep/count": eps, "sim/step/count": steps}
+    # ---- MlpConfig { hidden_sizes: [64, 64] } for policy and critic: the general per-layer path
+    env2 = ra.CartPoleEnv(engine, 128, max_steps=500, seed_env=7, seed_actor=8)
+    p2, c2 = ra.Mlp(engine, 5, [64, 64], 2), ra.Mlp(engine, 5, [64, 64], 1)
+    p2.init(9)
+    c2.init(10)
+    t2 = ra.Trajectory(engine, 128, 16, 5)
+    ra.rollout(env2, p2, t2)
+    ra.gae(t2, c2, 0.99, 0.95)
+    st2 = ra.trpo_update(p2, t2)
+    ra.critic_update(c2, ra.Adam(c2), t2, 3)
+    g2 = out["trpo_two_layers"]
+    assert g2["policy_checksum"] == checksum(p2.get_params()) and g2["critic_checksum"] == checksum(c2.get_params())
+    assert g2["scalars"]["policy/step_size"] == st2.step_size
     # ---- Actor::act on single observations repeats the batched rollout's actions (same stream words, same arithmetic)
     assert out["actor"]["checked"] == 6 * 10 and out["actor"]["mismatches"] == 0
 
