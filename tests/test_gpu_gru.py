@@ -170,6 +170,24 @@ def test_critic_gradient_through_time(engine):
     assert abs(loss_d - (d * d).mean()) <= 1e-5 * (d * d).mean()
 
 
+def test_bf16_pipe_training_passes_agree_with_the_f32_kernels(engine):
+    """the two builds of the GRU chain's training passes — recurrence on the bf16 matrix pipe with exact three-piece
+    products (kernels_seq_train.hip, the default) and round 1's f32 kernels (engine kernel variant 1) — give the same
+    gradients and Fisher-vector products up to the order of their f32 sums"""
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    v = np.random.default_rng(9).normal(size=pol.P).astype(np.float32)
+    got = {}
+    for variant in (0, 1):
+        engine.set_kernel_variant(variant)
+        try:
+            got[variant] = (ra.policy_gradient(pol, traj)[0], ra.critic_gradient(cri, traj)[0],
+                            ra.policy_fvp(pol, traj, v, 0.0))
+        finally:
+            engine.set_kernel_variant(0)
+    for a, b in zip(got[0], got[1]):
+        assert np.abs(a).max() > 0 and rel_err(a, b.astype(np.float64)) < GRAD_RTOL
+
+
 def oracle_ppo_loop(p, want, ocfg, steps, clip):
     p = p.copy()
     st = L.oracle_adam_new(len(p))
