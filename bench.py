@@ -359,7 +359,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
+    # replicas must still be bit-identical after the timed region: every rank applied the same all-reduced vectors
+    # (whatever the transport).  A rank whose parameters differ invalidates the run.
+    replicas_identical = None
     if dist is not None:
+        import hashlib
+        mine = hashlib.sha256(policy.get_params().tobytes() + critic.get_params().tobytes()).hexdigest()
+        digests = [None] * world
+        dist.all_gather_object(digests, mine)
+        replicas_identical = all(d == digests[0] for d in digests)
+        if not replicas_identical:
+            print("bench.py: rank %d: replicas diverged under the %s collective: %s" % (rank, comm_kind, digests),
+                  file=sys.stderr, flush=True)
         dist.barrier()
     if rank == 0:
         st = last["trpo"]
@@ -391,6 +402,7 @@ def main():
             "roofline_env_step": env_step,
             "cpu_baseline": cpu,
             "phases": phases,
+            "replicas_identical": replicas_identical,
             "last_update": {"trpo_status": st.status, "num_backtracks": st.num_backtracks,
                             "kl": st.constraint_val_final, "entropy": st.entropy,
                             "critic_loss_first": last["critic"].loss_first,

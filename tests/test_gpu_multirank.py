@@ -181,6 +181,7 @@ def test_bench_as_two_processes_over_the_host_collective():
     ipc = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "ipc"})
     assert "mailboxes" in ipc["config"]["parallelism"], ipc["_stderr"][-1500:]
     assert ipc["phases"]["allreduce"]["launches_per_step"] >= 5 + 11 + 2
+    assert one["replicas_identical"] is None and two["replicas_identical"] is True and ipc["replicas_identical"] is True
     for other in (two, ipc):
         a, b = one["last_update"], other["last_update"]
         assert a["trpo_status"] == b["trpo_status"]
