@@ -60,7 +60,35 @@ __global__ void __launch_bounds__(256) k_gen_dense(DenseArgs a) {
       acc[u] = a.b[n];
       tacc[u] = TANGENT ? a.vb[n] : 0.0f;
     }
-    for (int k = 0; k < a.K; ++k) {
+    // eight consecutive k at a time: a unit's eight weights are contiguous (one wide wave-uniform load each), the sums
+    // stay k-ascending fma chains
+    int k = 0;
+    for (; k + 8 <= a.K; k += 8) {
+      float w[4][8], v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u < a.N ? n0 + u : a.N - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          w[u][q] = a.W[(size_t)n * a.K + k + q];
+          v[u][q] = TANGENT ? a.V[(size_t)n * a.K + k + q] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float xv = Xs[(k + q) * GT + s];
+        const float tv = TANGENT ? tXs[(k + q) * GT + s] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u] = __builtin_fmaf(xv, w[u][q], acc[u]);
+          if (TANGENT) {
+            tacc[u] = __builtin_fmaf(tv, w[u][q], tacc[u]);
+            tacc[u] = __builtin_fmaf(xv, v[u][q], tacc[u]);
+          }
+        }
+      }
+    }
+    for (; k < a.K; ++k) {
       const float xv = Xs[k * GT + s];
       const float tv = TANGENT ? tXs[k * GT + s] : 0.0f;
 #pragma unroll
@@ -102,7 +130,21 @@ __global__ void __launch_bounds__(256) k_gen_delta(const float *__restrict__ dY,
   if (s0 + s >= S) return;
   for (int k0 = 4 * g; k0 < K; k0 += 16) {
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int n = 0; n < N; ++n) {
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {  // (W[n][k0 .. k0 + 3] are contiguous: one wide wave-uniform load per row)
+      float w[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[q][u] = W[(size_t)(n + q) * K + (k0 + u < K ? k0 + u : K - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float dv = sm[(n + q) * GT + s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_fmaf(dv, w[q][u], acc[u]);
+      }
+    }
+    for (; n < N; ++n) {
       const float dv = sm[n * GT + s];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -120,39 +162,74 @@ __global__ void __launch_bounds__(256) k_gen_delta(const float *__restrict__ dY,
 }
 
 // dW[n][k] = sum_s dY[n][s] X[k][s], db[n] = sum_s dY[n][s] over the samples [chunk * c, chunk * (c + 1)) of slab row c:
-// a workgroup owns a 16 x 16 tile of (n, k); f32 within a 64-sample tile, f64 over the chunk
+// a workgroup owns a 64 x 64 tile of (n, k), a thread a 4 x 4 block of it (8 LDS reads per 16 fma); f32 within a
+// 32-sample tile, f64 over the chunk
+constexpr int WT = 32;  // samples per staged tile
 __global__ void __launch_bounds__(256) k_gen_wgrad(const float *__restrict__ dY, size_t dys, int N,
                                                    const float *__restrict__ X, size_t xs, int K, size_t S,
                                                    uint32_t chunk, double *__restrict__ slab, uint32_t P,
                                                    uint32_t offW, uint32_t offB, const int32_t *__restrict__ skip) {
-  __shared__ float dYs[16][GT + 1], Xs[16][GT + 1];
+  __shared__ float dYs[WT][64 + 4], Xs[WT][64 + 4];  // [sample][row]: a thread's four rows are one 16-byte read
   if (skip != nullptr && *skip != 0) return;
-  const int tiles_k = (K + 15) / 16;
-  const int tn0 = 16 * (int)(blockIdx.x / tiles_k), tk0 = 16 * (int)(blockIdx.x % tiles_k);
-  const int tn = threadIdx.x >> 4, tk = threadIdx.x & 15;
+  const int tiles_k = (K + 63) / 64;
+  const int tn0 = 64 * (int)(blockIdx.x / tiles_k), tk0 = 64 * (int)(blockIdx.x % tiles_k);
+  const int tn = 4 * (threadIdx.x >> 4), tk = 4 * (threadIdx.x & 15);
   const size_t c0 = (size_t)blockIdx.y * chunk, c1 = c0 + chunk < S ? c0 + chunk : S;
-  double accw = 0.0, accb = 0.0;
-  for (size_t s0 = c0; s0 < c1; s0 += GT) {
+  double accw[4][4], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accw[i][j] = 0.0;
+  }
+  for (size_t s0 = c0; s0 < c1; s0 += WT) {
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 16 * GT; idx += 256) {
-      const int r = idx >> 6, ss = idx & (GT - 1);
+    for (int idx = threadIdx.x; idx < 64 * WT; idx += 256) {  // coalesced over the samples of a row
+      const int r = idx / WT, ss = idx % WT;
       const bool in = s0 + ss < c1;
-      dYs[r][ss] = (in && tn0 + r < N) ? dY[(size_t)(tn0 + r) * dys + s0 + ss] : 0.0f;
-      Xs[r][ss] = (in && tk0 + r < K) ? X[(size_t)(tk0 + r) * xs + s0 + ss] : 0.0f;
+      dYs[ss][r] = (in && tn0 + r < N) ? dY[(size_t)(tn0 + r) * dys + s0 + ss] : 0.0f;
+      Xs[ss][r] = (in && tk0 + r < K) ? X[(size_t)(tk0 + r) * xs + s0 + ss] : 0.0f;
     }
     __syncthreads();
-    float w = 0.0f, b = 0.0f;
-#pragma unroll 8
-    for (int ss = 0; ss < GT; ++ss) {
-      w = __builtin_fmaf(dYs[tn][ss], Xs[tk][ss], w);
-      b = b + dYs[tn][ss];
+    float w[4][4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      b[i] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[i][j] = 0.0f;
     }
-    accw += (double)w;
-    accb += (double)b;
+#pragma unroll 4
+    for (int ss = 0; ss < WT; ++ss) {
+      float d[4], x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d[i] = dYs[ss][tn + i];
+        x[i] = Xs[ss][tk + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        b[i] = b[i] + d[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[i][j] = __builtin_fmaf(d[i], x[j], w[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      accb[i] += (double)b[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accw[i][j] += (double)w[i][j];
+    }
   }
   double *__restrict__ row = slab + (size_t)blockIdx.y * P;
-  if (tn0 + tn < N && tk0 + tk < K) row[offW + (size_t)(tn0 + tn) * K + tk0 + tk] = accw;
-  if (tk0 == 0 && tk == 0 && tn0 + tn < N) row[offB + tn0 + tn] = accb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = tn0 + tn + i;
+    if (n >= N) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tk0 + tk + j < K) row[offW + (size_t)n * K + tk0 + tk + j] = accw[i][j];
+    if (tk0 == 0 && tk == 0) row[offB + n] = accb[i];
+  }
 }
 
 // per-sample policy terms from stored logits (and tangent logits): the arithmetic of k_policy_pass
@@ -435,7 +512,7 @@ void launch_gen_backward(rl_traj *t, const rl_mlp *m, const int32_t *d_skip) {
       X = g.act + unit_hi * B;
       xs = B;
     }
-    const uint32_t tiles = (uint32_t)(((N + 15) / 16) * ((K + 15) / 16));
+    const uint32_t tiles = (uint32_t)(((N + 63) / 64) * ((K + 63) / 64));
     hipLaunchKernelGGL(k_gen_wgrad, dim3(tiles, t->nbA), dim3(256), 0, e->stream, dY, (size_t)B, N, X, xs, K, (size_t)B,
                        t->bwd_chunk, t->slabA, P, (uint32_t)off, (uint32_t)(off + (uint64_t)N * K), d_skip);
     if (l > 0) {
