@@ -148,6 +148,27 @@ def test_rollout_step_by_step(engine, hidden):
     assert np.array_equal(traj.read_all()["obs"][:, 0, :], sim.observe())
 
 
+def test_rollout_on_the_index_env_lanes(engine):
+    """the step-by-step rollout over the Chain lanes' standalone kernels (slip draws from the lane's env stream by global
+    step): replayed bit for bit through the oracle's lanes, over two trajectories"""
+    n, T = 64, 25
+    pol = make(engine, 5, [32, 32], 2, 13)
+    env = ra.ChainEnv(engine, n, max_steps=9, seed_env=5, seed_actor=6)
+    sim = O.ChainLaneSim(n, max_steps=9, seed_env=5, seed_actor=6)
+    traj = ra.Trajectory(engine, n, T, 5)
+    for _ in range(2):
+        ra.rollout(env, pol, traj)
+        got = traj.read_all()
+        assert np.array_equal(got["obs"][:, 0, :], sim.observe())
+        for t in range(T):
+            reward, flag, obs, term = sim.step(got["action"][t])
+            assert np.array_equal(got["reward"][t], reward) and np.array_equal(got["flag"][t], flag), t
+            assert np.array_equal(got["obs"][:, t + 1, :], obs), t
+            m = flag == O.INTERRUPT
+            assert np.array_equal(got["term_obs"][:, t, m], term[:, m])
+        assert (got["flag"] == O.INTERRUPT).any() and (got["action"] == 1).any() and (got["action"] == 0).any()
+
+
 @pytest.mark.parametrize("hidden", [[64, 64], [256], [32, 16, 8], []])
 def test_gradients_and_fisher_vector_products(engine, hidden):
     pol, cri = make(engine, 5, hidden, 2, 21), make(engine, 5, hidden, 1, 22)
