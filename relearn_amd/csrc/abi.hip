@@ -1144,8 +1144,8 @@ void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
   RL_REQUIRE(t->d.D == 5 && mod->in_dim == 5, "recurrent path: built for 5 observation features");
   SeqDev &q = t->seq;
   uint64_t n = t->d.n, T = t->d.T;
+  q.tiles = (uint32_t)(n / 32);  // (the output planes may already exist: the general-MLP path shares them)
   if (q.out == nullptr) {
-    q.tiles = (uint32_t)(n / 32);
     q.out = dalloc<float>(2 * T * n);
     q.succ = dalloc<float>(2 * T * n);
   }

@@ -218,6 +218,7 @@ struct GenDev {
   float *delta = nullptr;                 // [2][widest layer][rows]: backward deltas (ping-pong)
   float *z = nullptr, *tz = nullptr;      // [2][rows]: outputs and tangent outputs
   uint64_t cap_act = 0, cap_tact = 0, cap_delta = 0, cap_z = 0, cap_tz = 0;
+  uint64_t cap_slabA = 0;                 // doubles in the trajectory's slabA once this path has regrown it
 };
 
 struct rl_adam {

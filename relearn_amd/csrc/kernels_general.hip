@@ -378,14 +378,13 @@ void gen_ensure(rl_traj *t, const rl_mlp *m, uint64_t rows, bool tangent, bool b
     grow(g.tz, g.cap_tz, 2 * rows);
   }
   if (backward) grow(g.delta, g.cap_delta, 2ull * wmax * rows);
-  // the P-sized vectors and the slab of the update workspace grow with the module (training passes only)
+  // the P-sized vectors and the slab of the update workspace grow with the module (training passes only).  The slab is
+  // tracked on its own: the recurrent path grows the vectors too, but keeps its partials elsewhere
   if (backward && t->Pmax < m->P) {
     for (float **p : {&t->vec, &t->cg_x, &t->cg_r, &t->cg_p, &t->prev_params, &t->descent}) {
       dfree(*p);
       *p = nullptr;
     }
-    dfree(t->slabA);
-    t->slabA = nullptr;
     t->Pmax = (uint32_t)m->P;
     t->vec = dalloc<float>(t->Pmax + 4);
     t->cg_x = dalloc<float>(t->Pmax);
@@ -393,10 +392,20 @@ void gen_ensure(rl_traj *t, const rl_mlp *m, uint64_t rows, bool tangent, bool b
     t->cg_p = dalloc<float>(t->Pmax);
     t->prev_params = dalloc<float>(t->Pmax);
     t->descent = dalloc<float>(t->Pmax);
+  }
+  if (backward) {
     uint32_t rowsA = t->nbA;
     if (t->nbV2 > rowsA) rowsA = t->nbV2;
     if (t->nbC > rowsA) rowsA = t->nbC;
-    t->slabA = dalloc<double>((size_t)rowsA * t->Pmax);
+    const uint64_t fused_P = 128 * 5 + 128 + 2 * 128 + 2;  // what traj_alloc sized the slab for
+    const uint64_t need = (uint64_t)rowsA * (m->P > fused_P ? m->P : fused_P);
+    if (m->P > fused_P && g.cap_slabA < need) {
+      dfree(t->slabA);
+      t->slabA = nullptr;
+      g.cap_slabA = 0;
+      t->slabA = dalloc<double>(need);
+      g.cap_slabA = need;
+    }
   }
 }
 

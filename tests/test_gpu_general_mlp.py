@@ -256,3 +256,22 @@ def test_two_hidden_layers_learn_cartpole(engine):
         ra.trpo_update(pol, traj)
         ra.critic_update(cri, copt, traj, 20)
     assert lengths[0] < 40 and lengths[-1] > 2.5 * lengths[0], lengths
+
+
+def test_recurrent_policy_with_a_general_critic_on_one_trajectory(engine):
+    """the two paths share the trajectory's value planes: a GRU policy and an MlpConfig { hidden_sizes: [32, 32] }
+    critic take turns on the same handle"""
+    n, T = 64, 20
+    env = ra.ChainEnv(engine, n, max_steps=9, seed_env=1, seed_actor=2)
+    pol, cri = ra.GruMlp(engine, 5, 2), make(engine, 5, [32, 32], 1, 5)
+    pol.init(4)
+    traj = ra.Trajectory(engine, n, T, 5)
+    for _ in range(2):
+        ra.rollout(env, pol, traj)
+        ra.gae(traj, cri, 0.95, 0.9)          # general critic first: allocates the shared planes
+        cfg = ra.ppo_config_default()
+        cfg.opt_steps_per_update = 2
+        st, losses = ra.ppo_update(pol, ra.Adam(pol), traj, cfg, want_losses=True)
+        assert np.isfinite(losses).all()
+        cs, cl = ra.critic_update(cri, ra.Adam(cri), traj, 3, want_losses=True)
+        assert cl[-1] < cl[0]
