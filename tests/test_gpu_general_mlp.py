@@ -275,3 +275,25 @@ def test_recurrent_policy_with_a_general_critic_on_one_trajectory(engine):
         assert np.isfinite(losses).all()
         cs, cl = ra.critic_update(cri, ra.Adam(cri), traj, 3, want_losses=True)
         assert cl[-1] < cl[0]
+
+
+def test_fused_modules_are_untouched_by_a_general_module_on_the_same_trajectory(engine):
+    """a general policy regrows the trajectory's update workspace; the fused critic update that follows on the same
+    handle gives bit for bit what it gives on a handle no general module has touched"""
+    n, T = 256, 32
+    results = []
+    for with_general in (False, True):
+        env = ra.CartPoleEnv(engine, n, max_steps=50, seed_env=8, seed_actor=9)
+        beh, cri = make(engine, 5, 128, 2, 1), make(engine, 5, 128, 1, 2)
+        traj = ra.Trajectory(engine, n, T, 5)
+        ra.rollout(env, beh, traj)
+        ra.gae(traj, cri, 0.99, 0.95)
+        if with_general:
+            big = make(engine, 5, [200, 200], 2, 3)
+            st = ra.trpo_update(big, traj)
+            assert st.status == ra.OPT_OK
+        ra.critic_update(cri, ra.Adam(cri), traj, 5)
+        st = ra.trpo_update(beh, traj)
+        results.append((cri.get_params(), beh.get_params(), st.step_size))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    assert results[0][2] == results[1][2]
