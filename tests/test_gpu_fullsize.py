@@ -174,3 +174,14 @@ def test_config5_rollout_slices_and_update(engine):
     cfg.opt_steps_per_update = 3
     st, losses = ra.ppo_update(pol, ra.Adam(pol), traj, cfg, want_losses=True)
     assert losses[-1] < losses[0] and 0.0 < st.entropy <= np.log(2.0) + 1e-6
+    # the two builds of the training passes (recurrence on the bf16 matrix pipe with exact three-piece products — the
+    # default — and the f32 kernels, engine kernel variant 1) agree at full size: 1.64 M sample-steps per gradient
+    grads = {}
+    for variant in (0, 1):
+        engine.set_kernel_variant(variant)
+        try:
+            grads[variant] = (ra.policy_gradient(pol, traj)[0], ra.critic_gradient(cri, traj)[0])
+        finally:
+            engine.set_kernel_variant(0)
+    for a, b in zip(grads[0], grads[1]):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0 and rel_err(a, b) < 1e-4, rel_err(a, b)
