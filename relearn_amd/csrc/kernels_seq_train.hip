@@ -17,12 +17,17 @@
 // workgroup barriers and a 128-deep product less on the critical path of every step:
 //   k_gru_recur_fwd      t = 0 .. T-1: gates by MFMA, cell on the VALU; records r, z, n, gh_n, h_prev, relu(h')
 //   k_seq_head_forward   u = relu(W1 relu(h') + b1) (recorded), out = W2 u + b2          (all blocks in parallel)
-//   k_seq_head_backward  d u_pre, d relu(h')                  (kernels_seq_bwd.hip; all blocks in parallel)
-//   k_gru_recur_bwd      t = T-1 .. 0: d gates on the VALU, d h_prev = sum_g W_hh[g]^T d gh_g by MFMA
+//   k_gru_head_backward  d u_pre (on chip), d relu(h'), and the head's own weight gradients  (all blocks in parallel)
+//   k_gru_recur_bwd      t = T-1 .. 0: d gates on the VALU, d h_prev = sum_g W_hh[g]^T d gh_g by MFMA; the n gate's
+//                        input-side sums
+//   k_gru_wgrad_bf16     dW_hh with the sample as contraction index; db_hh and the r / z input-side sums
 // Ownership is the rollout cell's: eight waves per tile of 32 lanes, wave w owns units [16w, 16w+16); accumulator
 // register i of lane l is (sample 16 mt + 4 (l >> 4) + i, unit 16 w + (l & 15)) for both MFMA shapes, so the records
-// keep their layout ([unit][lane] rows, seq_common.hpp) and the weight-gradient GEMMs read them unchanged.
-// Register budget per wave: 3 gates x 4 k-blocks x 3 pieces x 4 = 144 weight registers, 24 accumulators.
+// keep their layout ([unit][lane] rows, seq_common.hpp).
+// Register budget per wave: a gate's W_hh fragments are 4 k-blocks x 3 pieces x 4 = 48 registers; two gates (forward)
+// or nine of the twelve k-blocks (backward) stay in registers, the rest waits in LDS — the 256-register budget of two
+// waves per SIMD does not hold 144 fragment registers next to the accumulators, the prefetched record of the next
+// step and the gate arithmetic.
 // Reference: gru_cell (src/torch/modules/seq/rnn/gru.rs:30-39), Chain (modules/chain.rs:127-186), and what libtorch's
 // autograd does for loss.backward() on them (src/torch/optimizers/coptimizer.rs:13-26).
 #include "bf16_tile.hpp"
@@ -59,8 +64,8 @@ __device__ __forceinline__ f32x4 mfma9(const Frag (&a)[3], const Frag (&b)[3], f
   return acc;
 }
 
-// Gate functions of the training forward.  The vector ALU bounds this kernel (0.73 busy, profiles/): the gate
-// arithmetic is written for instruction count — e^y through v_exp_f32 (one quarter-rate instruction instead of a
+// Gate functions of the training forward.  The vector ALU bounded this kernel (0.73 busy with rl_sigmoidf / rl_tanhf,
+// 0.52 with these; profiles/r02_pmc_gru_config5_summary.json): the gate arithmetic is written for instruction count — e^y through v_exp_f32 (one quarter-rate instruction instead of a
 // 14-instruction range reduction and polynomial), quotients through v_rcp_f32 and one Newton step (6 instructions
 // instead of the 10 of an IEEE division) — and without branches (a branch ends the basic block, and the scheduler
 // interleaves matrix and vector instructions only inside one).  Each result is within 2 ulp of rl_sigmoidf / rl_tanhf
