@@ -37,9 +37,7 @@ namespace {
 
 using bt::Frag;
 
-#ifndef RL_SEQ_VALU_PER_MFMA
-#define RL_SEQ_VALU_PER_MFMA 5
-#endif
+constexpr int VALU_PER_MFMA = 5;  // vector instructions the schedule of the forward places between two matrix instructions
 constexpr int HROW = GH + 8;      // halfwords per row of a [sample][unit] piece image: 272-byte rows, so the 16-byte
                                   // operand reads of 16 consecutive samples start 4 banks apart
 constexpr int GROW = 3 * GH + 8;  // the backward's [sample][gate unit] rows (784 bytes: the same property)
@@ -241,24 +239,21 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         hP[nxt][1][m][j] = (unsigned short)p1;
         hP[nxt][2][m][j] = (unsigned short)p2;
       }
-#ifndef RL_EXP_NO_FWD_STORES
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_R * GH * TL) + row) = rv;
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_Z * GH * TL) + row) = zv;
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_N * GH * TL) + row) = nv;
       *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
-#else
-      if (rv[0] + zv[1] + nv[2] + av[3] == 1234.5f) store[row] = 0.0f;
-#endif
     };
     products(0);
     __builtin_amdgcn_sched_barrier(0);
     products(1);
     gates(0);
-    // the order asked of the scheduler for this region: one matrix instruction, then a few vector instructions, ...
+    // the order asked of the scheduler for this region (the 108 products of M-tile 1, the gate arithmetic of M-tile 0):
+    // one matrix instruction, then a few vector instructions, ...
 #pragma unroll
     for (int k = 0; k < (GH / 32) * 27; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, RL_SEQ_VALU_PER_MFMA, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
     }
     __builtin_amdgcn_sched_barrier(0);
     gates(1);
