@@ -794,7 +794,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int d = 0; d < D; ++d) dwih[g2][h][d] = __builtin_fmaf(gi[g2][h][i], xS[scol + i][d], dwih[g2][h][d]);
-    // products: contraction over the block's 32 samples in two halves of 16
+    // products: contraction over the block's 32 samples in two halves of 16.  Two tiles at a time, their nine products
+    // interleaved: consecutive matrix instructions then write different accumulators (back-to-back products into ONE
+    // 32x32 accumulator wait for each other: the pipe was 0.55 busy)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       Frag fb[3];
@@ -802,16 +804,20 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       for (int c = 0; c < 3; ++c)
         fb[c].x = *reinterpret_cast<const uint4 *>(&BP[c][32 * nt + n][16 * half + 8 * hf]);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        Frag fa[3];
+      for (int i = 0; i < 6; i += 2) {
+        Frag fa[2][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          fa[c].x = *reinterpret_cast<const uint4 *>(&AP[c][192 * mset + 32 * i + n][16 * half + 8 * hf]);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[c][192 * mset + 32 * (i + u) + n][16 * half + 8 * hf]);
 #pragma unroll
         for (int pa = 2; pa >= 0; --pa)
 #pragma unroll
           for (int pb = 2; pb >= 0; --pb)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa].v, fb[pb].v, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              acc[i + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][pa].v, fb[pb].v, acc[i + u], 0, 0, 0);
       }
     }
   }
