@@ -694,22 +694,26 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // ---------------------------------------------------------------- weight gradients of the recurrence
 // dW_hh[g][k] = sum over (step, lane) of d gh_g . h_prev_k   (g over the 384 gate units: d pre_r, d pre_z, d pre_n r)
 // with the SAMPLE as the contraction index: the records are [unit][lane] rows, so eight consecutive samples of a row
-// are one operand fragment — no transposition.  A workgroup walks a contiguous run of (step, tile) blocks; per block
-// every element is split into its three bf16 pieces ONCE (each thread stages 1/512 of the block) and parked in LDS in
-// operand layout; wave w accumulates output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles,
-// 2 x 9 issues of v_mfma_f32_32x32x16_bf16 per tile and block.  dW_ih, db_ih and db_hh are sums the staging threads
-// keep for the rows they stage (a thread stages the same rows in every block).  One row of f32 partials per
-// workgroup (columns of the recurrent parameters only; the head's come from k_gru_head_backward).
-constexpr int WROW = TL + 8;  // halfwords per row of the [row][sample] piece images: 80-byte rows, 16-byte operand reads
-                              // of 16 consecutive rows hit 64 different banks
+// are one operand fragment — no transposition.  A workgroup walks a contiguous run of (step, tile) blocks in HALF
+// blocks of 16 samples.  Every element is split into its three bf16 pieces ONCE (each thread stages 1/512 of a half)
+// and parked in LDS in operand layout, in one of two buffers: the pieces of half h + 1 are produced (VALU) between the
+// matrix instructions of half h (the schedule is asked for explicitly: with one buffer per block, or with the two
+// phases merely adjacent in program order, they took turns — matrix pipe 0.55 busy, VALU 0.34).  Wave w accumulates
+// output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles, 9 issues of
+// v_mfma_f32_32x32x16_bf16 per tile and half, two tiles interleaved.  db_hh, and dW_ih / db_ih of the r and z gates
+// (their input side equals their hidden side), are sums the staging threads keep for the rows they stage (thread q
+// stages row q >> 2 of every gate in every half); the n gate's input side comes from the backward recurrence.  One row
+// of f32 partials per workgroup (columns of the recurrent parameters only; the head's come from k_gru_head_backward).
+constexpr int WROW = 16 + 8;  // halfwords per row of the [row][16 samples] piece images: 48-byte rows, the 16-byte
+                              // operand reads of 16 consecutive rows hit 64 different banks
 template <int D>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_wgrad_bf16(TrajDev tr, const float *__restrict__ act, const float *__restrict__ dpre,
                      float *__restrict__ slab, uint32_t P, uint32_t tiles, uint32_t blocks, uint32_t blocks_per_chunk,
                      const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) unsigned short AP[3][3 * GH][WROW];  // d gh pieces
-  __shared__ __attribute__((aligned(16))) unsigned short BP[3][GH][WROW];      // h_prev pieces
-  __shared__ float xS[TL][8];
+  __shared__ __attribute__((aligned(16))) unsigned short AP[2][3][3 * GH][WROW];  // d gh pieces, by half parity
+  __shared__ __attribute__((aligned(16))) unsigned short BP[2][3][GH][WROW];      // h_prev pieces
+  __shared__ float xS[2][TL][8];                                                  // observations, by block parity
   if (skip != nullptr && *skip != 0) return;
   const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
   const int n = lane & 31, hf = lane >> 5;
@@ -717,43 +721,43 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   bt::f32x16 acc[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // staging: 16-byte piece f = q + 512 i of the three gate arrays (i = 0..5: array i >> 1, row (q >> 3) + 64 (i & 1),
-  // samples 4 (q & 7) .. + 3); h_prev: pieces q and q + 512 (rows (q >> 3) and (q >> 3) + 64)
-  const int srow = q >> 3, scol = 4 * (q & 7);
-  // sums the staging thread keeps for the rows it stages: db_hh (all gates; = db_ih for r and z) and dW_ih of r and z
-  float dwih[2][2][D], dbh[3][2];
+  // staging of a half: thread q takes the 16-byte piece (row q >> 2, samples 4 (q & 3) .. + 3 of the half) of each of
+  // the three gate arrays and of h_prev
+  const int srow = q >> 2, scol = 4 * (q & 3);
+  float dwih[2][D], dbh[3];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int g3 = 0; g3 < 3; ++g3) dbh[g3] = 0.0f;
 #pragma unroll
-    for (int g3 = 0; g3 < 3; ++g3) dbh[g3][h] = 0.0f;
+  for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2)
-#pragma unroll
-      for (int d = 0; d < D; ++d) dwih[g2][h][d] = 0.0f;
-  }
+    for (int d = 0; d < D; ++d) dwih[g2][d] = 0.0f;
   const uint32_t N = tr.n, T = tr.T;
   const size_t plane = (size_t)(T + 1) * N;
-  float xn = 0.0f;
   const uint32_t b0 = blockIdx.x * blocks_per_chunk;
   const uint32_t b1 = b0 + blocks_per_chunk < blocks ? b0 + blocks_per_chunk : blocks;
-  f32x4 gA[3][2], hB[2];
-  auto fetch = [&](uint32_t blk) {
+  const uint32_t n_half = 2 * (b1 - b0);
+  // register stages of the global loads: half h lands in slot h & 1, two halves before its pieces are produced
+  struct Slot {
+    f32x4 g[3], hB;
+    float xn;
+  };
+  Slot slot[2];
+  slot[0].xn = slot[1].xn = 0.0f;
+  auto fetch = [&](uint32_t h, Slot &sl) {  // half h of the chunk: block b0 + h / 2, samples 16 (h & 1) .. + 15
+    const uint32_t blk = b0 + (h >> 1);
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t o = (uint32_t)((srow + 64 * h) * TL + scol);
-      gA[0][h] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(0 * GH * TL) + o);
-      gA[1][h] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(1 * GH * TL) + o);
-      gA[2][h] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(3 * GH * TL) + o);  // hidden side of the n gate
-      hB[h] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
-    }
-    if (q < TL * D) {  // feature q / TL of sample q % TL
-      const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
-      xn = tr.obs[(size_t)(q / TL) * plane + (size_t)t * N + lane0 + (q % TL)];
+    const uint32_t o = (uint32_t)(srow * TL + 16 * (h & 1) + scol);
+    sl.g[0] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(0 * GH * TL) + o);
+    sl.g[1] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(1 * GH * TL) + o);
+    sl.g[2] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(3 * GH * TL) + o);  // hidden side of the n gate
+    sl.hB = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
+    if ((h & 1) == 0 && q < TL * D && blk + 1 < b1) {  // feature q / TL of sample q % TL of the NEXT block (its sums
+      const uint32_t t = (blk + 1) / tiles, lane0 = ((blk + 1) % tiles) * TL;  // run while its pieces are produced)
+      sl.xn = tr.obs[(size_t)(q / TL) * plane + (size_t)t * N + lane0 + (q % TL)];
     }
   };
-  // four samples of one row -> their pieces, 8 bytes into each of the three piece images ([3][rows][WROW], contiguous)
+  // four samples of one row -> their pieces, 8 bytes into each of the three piece images of a buffer
   auto park = [&](unsigned short (*img)[WROW], int rows, int row, const f32x4 &v) {
     uint32_t p[4][3];
 #pragma unroll
@@ -764,62 +768,79 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       *reinterpret_cast<uint64_t *>(&img[c * rows + row][scol]) = w;
     }
   };
-  if (b0 < b1) fetch(b0);
-  for (uint32_t blk = b0; blk < b1; ++blk) {
-    __syncthreads();  // the previous block's operand reads are done
+  // park half h (in `sl`) into LDS buffer h & 1, and add it to the sums of the rows this thread stages (the block's x
+  // was published two halves ago)
+  auto stage = [&](uint32_t h, const Slot &sl) {
+    const int buf = (int)(h & 1);
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) park(AP[buf][0], 3 * GH, g3 * GH + srow, sl.g[g3]);
+    park(BP[buf][0], GH, srow, sl.hB);
+    if ((h & 1) == 0 && q < TL * D) xS[((h >> 1) + 1) & 1][q % TL][q / TL] = sl.xn;  // x of the next block
+    const int xb = (int)((h >> 1) & 1);
 #pragma unroll
     for (int g3 = 0; g3 < 3; ++g3)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) park(AP[0], 3 * GH, g3 * GH + srow + 64 * h, gA[g3][h]);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) park(BP[0], GH, srow + 64 * h, hB[h]);
-    if (q < TL * D) xS[q % TL][q / TL] = xn;
-    f32x4 gi[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      gi[0][h] = gA[0][h];
-      gi[1][h] = gA[1][h];
-#pragma unroll
-      for (int g3 = 0; g3 < 3; ++g3)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dbh[g3][h] += gA[g3][h][i];
-    }
-    __syncthreads();
-    if (blk + 1 < b1) fetch(blk + 1);  // lands under this block's products
+      for (int i = 0; i < 4; ++i) dbh[g3] += sl.g[g3][i];
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int d = 0; d < D; ++d)
+          dwih[g2][d] = __builtin_fmaf(sl.g[g2][i], xS[xb][16 * (h & 1) + scol + i][d], dwih[g2][d]);
+  };
+  auto products = [&](int buf) {  // contraction over the 16 samples of the half in buffer `buf`, two tiles interleaved
+    Frag fb[3];
 #pragma unroll
-          for (int d = 0; d < D; ++d) dwih[g2][h][d] = __builtin_fmaf(gi[g2][h][i], xS[scol + i][d], dwih[g2][h][d]);
-    // products: contraction over the block's 32 samples in two halves of 16.  Two tiles at a time, their nine products
-    // interleaved: consecutive matrix instructions then write different accumulators (back-to-back products into ONE
-    // 32x32 accumulator wait for each other: the pipe was 0.55 busy)
+    for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&BP[buf][c][32 * nt + n][8 * hf]);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      Frag fb[3];
+    for (int i = 0; i < 6; i += 2) {
+      Frag fa[2][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        fb[c].x = *reinterpret_cast<const uint4 *>(&BP[c][32 * nt + n][16 * half + 8 * hf]);
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int i = 0; i < 6; i += 2) {
-        Frag fa[2][3];
+        for (int c = 0; c < 3; ++c)
+          fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[buf][c][192 * mset + 32 * (i + u) + n][8 * hf]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+      for (int pa = 2; pa >= 0; --pa)
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[c][192 * mset + 32 * (i + u) + n][16 * half + 8 * hf]);
+        for (int pb = 2; pb >= 0; --pb)
 #pragma unroll
-        for (int pa = 2; pa >= 0; --pa)
-#pragma unroll
-          for (int pb = 2; pb >= 0; --pb)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-              acc[i + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][pa].v, fb[pb].v, acc[i + u], 0, 0, 0);
-      }
+          for (int u = 0; u < 2; ++u)
+            acc[i + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][pa].v, fb[pb].v, acc[i + u], 0, 0, 0);
     }
+  };
+  // one half: the pieces (and sums) of the NEXT half from slot `sl` into the other buffer, the fetch of the half after
+  // that into the slot just freed, and the 54 products of this half — issued as one region, one matrix instruction then
+  // a few vector instructions
+  auto half_step = [&](uint32_t h, Slot &sl, int buf) {
+    if (h + 1 < n_half) stage(h + 1, sl);
+    if (h + 3 < n_half) fetch(h + 3, sl);
+    products(buf);
+#pragma unroll
+    for (int k = 0; k < 54; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // buffer `buf` is free for half h + 2, the other buffer holds half h + 1
+  };
+  // n_half is even (whole blocks)
+  if (n_half > 0) {
+    if (q < TL * D) {  // x of the first block
+      const uint32_t t = b0 / tiles, lane0 = (b0 % tiles) * TL;
+      xS[0][q % TL][q / TL] = tr.obs[(size_t)(q / TL) * plane + (size_t)t * N + lane0 + (q % TL)];
+    }
+    fetch(0, slot[0]);
+    fetch(1, slot[1]);
+    __syncthreads();
+    stage(0, slot[0]);
+    if (n_half > 2) fetch(2, slot[0]);
+  }
+  __syncthreads();
+  for (uint32_t h = 0; h < n_half; h += 2) {
+    half_step(h, slot[1], 0);
+    half_step(h + 1, slot[0], 1);
   }
   // ---- this workgroup's row of partials (recurrent columns)
   float *__restrict__ out = slab + (size_t)blockIdx.x * P;
@@ -829,31 +850,28 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       out[oWhh + (size_t)(192 * mset + 32 * i + acc_row(r, hf)) * GH + 32 * nt + n] = acc[i][r];
-  // the eight threads q & 7 of a row hold its partial sums over different samples
+  // the four threads q & 3 of a row hold its partial sums over different samples
   const size_t obih = oWhh + (size_t)3 * GH * GH, obhh = obih + 3 * GH;
-  auto over8 = [](float v) {
+  auto over4 = [](float v) {
     v = v + __shfl_xor(v, 1, 64);
-    v = v + __shfl_xor(v, 2, 64);
-    return v + __shfl_xor(v, 4, 64);
+    return v + __shfl_xor(v, 2, 64);
   };
 #pragma unroll
-  for (int g3 = 0; g3 < 3; ++g3)
+  for (int g3 = 0; g3 < 3; ++g3) {
+    const int row = g3 * GH + srow;
+    const float vb = over4(dbh[g3]);
+    if ((q & 3) == 0) {
+      out[obhh + row] = vb;
+      if (g3 < 2) out[obih + row] = vb;  // (the n gate's input side comes from the backward recurrence)
+    }
+    if (g3 < 2) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = g3 * GH + srow + 64 * h;
-      const float vb = over8(dbh[g3][h]);
-      if ((q & 7) == 0) {
-        out[obhh + row] = vb;
-        if (g3 < 2) out[obih + row] = vb;  // (the n gate's input side comes from the backward recurrence)
-      }
-      if (g3 < 2) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const float v = over8(dwih[g3][h][d]);
-          if ((q & 7) == 0) out[(size_t)row * D + d] = v;
-        }
+      for (int d = 0; d < D; ++d) {
+        const float v = over4(dwih[g3][d]);
+        if ((q & 3) == 0) out[(size_t)row * D + d] = v;
       }
     }
+  }
 }
 
 }  // namespace
