@@ -1,13 +1,13 @@
 // kernels_seq_train.hip — the GRU chain's training passes (the 90 gradient evaluations of a period in BASELINE.json
-// configs[4]) with the recurrence on the bf16 matrix pipe, every product exact.
+// configs[4]) with the recurrence on the bf16 matrix pipe, products from three-piece splits at f32 accuracy.
 //
 // What the hardware dictates (scripts/probe/pipe_overlap.hip, mfma16x32_bf16.hip): the f32 MFMAs of the rollout's cell
 // occupy the vector ALU, so the gates' products and their sigmoid / tanh arithmetic add up (38 k cycles per step and
 // SIMD against 16 k of matrix work); v_mfma_f32_16x16x32_bf16 runs beside vector work.  An f32 value is the exact sum
 // of three bf16 pieces (bf16_tile.hpp) and a product of two bf16 numbers is exact in the f32 accumulator, so
-//   h W^T = sum over the nine piece pairs (h_p, W_q)
-// costs 9 bf16 issues of 16 cycles where the f32 form costs 8 issues of 32 cycles for the same 32 values of k — and
-// leaves the VALU to the gate arithmetic.  The accumulation order differs from the rollout's sequential fma chain
+//   h W^T = sum over the piece pairs (h_p, W_q)
+// — the six pairs that matter at f32 accuracy, PIECE_ORDER below — costs 6 bf16 issues of 16 cycles where the f32 form
+// costs 8 issues of 32 cycles for the same 32 values of k, and leaves the VALU to the gate arithmetic.  The accumulation order differs from the rollout's sequential fma chain
 // (which stays on the f32 kernels of kernels_seq.hip: rollouts, values and GAE are bit-exact with the oracle); the
 // training passes are compared with the f64 oracle within f32 tolerances (tests/test_gpu_gru.py), like every
 // gradient in this library.
@@ -37,7 +37,15 @@ namespace {
 
 using bt::Frag;
 
-constexpr int VALU_PER_MFMA = 5;  // vector instructions the schedule of the forward places between two matrix instructions
+// An f32 value is the exact sum of three bf16 pieces (round to nearest: |p1| <= 2^-9 |v|, |p2| <= 2^-18 |v|).  Of the
+// nine piece pairs of a product a b the six with p + q < 3 are multiplied; the other three together are below
+// 2^-26 |a||b|, a quarter of the rounding of ONE f32 product, and under the f32 accumulator's own rounding they do not
+// change a single bit of the gradients the tests look at (tests/test_gpu_gru.py::test_piece_products_keep_f32_accuracy:
+// the same distance from the f64 oracle as with all nine, 6.7e-8 / 2.9e-8 of max |g|; the f32 fma kernels: 4.7e-8 /
+// 1.8e-8).  PIECE_ORDER 5 multiplies all nine.
+constexpr int PIECE_ORDER = 3;
+constexpr int PIECE_PAIRS = PIECE_ORDER == 3 ? 6 : PIECE_ORDER == 4 ? 8 : 9;
+constexpr int VALU_PER_MFMA = 45 / PIECE_PAIRS;  // vector instructions the schedule of the forward places between two matrix instructions
 constexpr int HROW = GH + 8;      // halfwords per row of a [sample][unit] piece image: 272-byte rows, so the 16-byte
                                   // operand reads of 16 consecutive samples start 4 banks apart
 constexpr int GROW = 3 * GH + 8;  // the backward's [sample][gate unit] rows (784 bytes: the same property)
@@ -53,12 +61,13 @@ __device__ __forceinline__ void frags_of8(const float (&v)[8], Frag (&f)[3]) {
     for (int h = 0; h < 4; ++h) f[q].u[h] = bt::pk(p[2 * h][q], p[2 * h + 1][q]);
 }
 
-// acc += sum over the nine piece pairs of a (3 fragments of A) and b (3 fragments of B)
-__device__ __forceinline__ f32x4 mfma9(const Frag (&a)[3], const Frag (&b)[3], f32x4 acc) {
+// acc += sum over the piece pairs (p + q < PIECE_ORDER) of a (3 fragments of A) and b (3 fragments of B)
+__device__ __forceinline__ f32x4 mfma_pieces(const Frag (&a)[3], const Frag (&b)[3], f32x4 acc) {
 #pragma unroll
   for (int p = 2; p >= 0; --p)  // small terms first
 #pragma unroll
-    for (int q = 2; q >= 0; --q) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p].v, b[q].v, acc, 0, 0, 0);
+    for (int q = 2; q >= 0; --q)
+      if (p + q < PIECE_ORDER) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p].v, b[q].v, acc, 0, 0, 0);
   return acc;
 }
 
@@ -189,8 +198,8 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
         for (int q = 0; q < 3; ++q) wn[q].x = wnS[kb][q][wave][lane];
 #pragma unroll
-        for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma9(fa[kb & 1], wf[gte][kb], acc[gte][mt]);
-        acc[2][mt] = mfma9(fa[kb & 1], wn, acc[2][mt]);
+        for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma_pieces(fa[kb & 1], wf[gte][kb], acc[gte][mt]);
+        acc[2][mt] = mfma_pieces(fa[kb & 1], wn, acc[2][mt]);
       }
     };
     float *__restrict__ store = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
@@ -251,7 +260,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     // the order asked of the scheduler for this region (the 108 products of M-tile 1, the gate arithmetic of M-tile 0):
     // one matrix instruction, then a few vector instructions, ...
 #pragma unroll
-    for (int k = 0; k < (GH / 32) * 27; ++k) {
+    for (int k = 0; k < (GH / 32) * 3 * PIECE_PAIRS; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
     }
@@ -327,7 +336,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           fa[c].x = *reinterpret_cast<const uint4 *>(&aK[c][16 * mt + n16][32 * kb + 8 * g4]);
-        acc1[mt] = mfma9(fa, w1f[kb], acc1[mt]);
+        acc1[mt] = mfma_pieces(fa, w1f[kb], acc1[mt]);
       }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -487,12 +496,12 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     for (int it = 0; it < 2 * KB; ++it) {
       if (it + 1 < 2 * KB) frags(it + 1, fa[(it + 1) & 1]);
       if ((it >> 1) < KB - KBL) {
-        acc[it & 1] = mfma9(fa[it & 1], wT[(it >> 1) < KB - KBL ? (it >> 1) : 0], acc[it & 1]);
+        acc[it & 1] = mfma_pieces(fa[it & 1], wT[(it >> 1) < KB - KBL ? (it >> 1) : 0], acc[it & 1]);
       } else {
         Frag wl[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) wl[q].x = wTS[(it >> 1) - (KB - KBL)][q][wave][lane];
-        acc[it & 1] = mfma9(fa[it & 1], wl, acc[it & 1]);
+        acc[it & 1] = mfma_pieces(fa[it & 1], wl, acc[it & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -521,7 +530,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // ---------------------------------------------------------------- head backward, all blocks in parallel, with the
 // head's own weight gradients.  Per (step, tile) block:
 //   d u_pre = [u > 0] W2^T dz                       (VALU; stays on chip)
-//   d relu(h') = [relu(h') > 0] d u_pre W1          (contraction over the 128 units of u: K = 128 x 9 piece pairs)
+//   d relu(h') = [relu(h') > 0] d u_pre W1          (contraction over the 128 units of u, times the piece pairs)
 //                                                   -> dpre[DPRE_DA1], the backward recurrence's input
 //   dW1 += d u_pre^T relu(h')                       (contraction over the block's 32 samples: one issue per tile and pair)
 //   db1 += d u_pre,  dW2 += dz^T u,  db2 += dz      (VALU)
@@ -642,7 +651,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           fa[c].x = *reinterpret_cast<const uint4 *>(&uJ[c][16 * mt + n16][32 * kb + 8 * g4]);
-        acc1[mt] = mfma9(fa, w1f[kb], acc1[mt]);
+        acc1[mt] = mfma_pieces(fa, w1f[kb], acc1[mt]);
       }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -661,7 +670,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         Frag fb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&aM[c][16 * nt + n16][8 * g4]);
-        accw[nt] = mfma9(fa, fb, accw[nt]);
+        accw[nt] = mfma_pieces(fa, fb, accw[nt]);
       }
     }
   }
@@ -699,7 +708,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // and parked in LDS in operand layout, in one of two buffers: the pieces of half h + 1 are produced (VALU) between the
 // matrix instructions of half h (the schedule is asked for explicitly: with one buffer per block, or with the two
 // phases merely adjacent in program order, they took turns — matrix pipe 0.55 busy, VALU 0.34).  Wave w accumulates
-// output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles, 9 issues of
+// output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles, PIECE_PAIRS issues of
 // v_mfma_f32_32x32x16_bf16 per tile and half, two tiles interleaved.  db_hh, and dW_ih / db_ih of the r and z gates
 // (their input side equals their hidden side), are sums the staging threads keep for the rows they stage (thread q
 // stages row q >> 2 of every gate in every half); the n gate's input side comes from the backward recurrence.  One row
@@ -807,7 +816,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         for (int pb = 2; pb >= 0; --pb)
 #pragma unroll
           for (int u = 0; u < 2; ++u)
-            acc[i + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][pa].v, fb[pb].v, acc[i + u], 0, 0, 0);
+            if (pa + pb < PIECE_ORDER) acc[i + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u][pa].v, fb[pb].v, acc[i + u], 0, 0, 0);
     }
   };
   // one half: the pieces (and sums) of the NEXT half from slot `sl` into the other buffer, the fetch of the half after
@@ -818,9 +827,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     if (h + 3 < n_half) fetch(h + 3, sl);
     products(buf);
 #pragma unroll
-    for (int k = 0; k < 54; ++k) {
+    for (int k = 0; k < 6 * PIECE_PAIRS; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, 36 / PIECE_PAIRS, 0);  // VALU
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // buffer `buf` is free for half h + 2, the other buffer holds half h + 1

@@ -188,6 +188,29 @@ def test_bf16_pipe_training_passes_agree_with_the_f32_kernels(engine):
         assert np.abs(a).max() > 0 and rel_err(a, b.astype(np.float64)) < GRAD_RTOL
 
 
+def test_piece_products_keep_f32_accuracy(engine):
+    """the bf16 pipe multiplies the piece pairs (p, q) with p + q < 3 of the three-piece splits — six of nine; the
+    dropped pairs are below 2^-26 |a||b| per term, a quarter of the rounding of one f32 product — so its gradients
+    must sit as close to the f64 oracle's as those of the f32 kernels (sequential fma chains) do"""
+    pol, cri, traj, want, _, _ = setup_update(engine)
+    g64 = {"policy": policy_grad_f64(pol.get_params(), want)}
+    v, _ = O.gru_seq_forward(CS, cri.get_params(), want, f64=True, want_succ=False)
+    d = v - want["rtg"].astype(np.float64)[None]
+    g64["critic"] = O.gru_seq_backward(CS, cri.get_params(), want, 2.0 * d / v[0].size, f64=True)
+    err = {}
+    for variant in (0, 1):
+        engine.set_kernel_variant(variant)
+        try:
+            err[variant] = {"policy": rel_err(ra.policy_gradient(pol, traj)[0], g64["policy"]),
+                            "critic": rel_err(ra.critic_gradient(cri, traj)[0], g64["critic"])}
+        finally:
+            engine.set_kernel_variant(0)
+    print("relative error against f64 (bf16 pieces, f32 kernels):", err)
+    for k in ("policy", "critic"):
+        assert err[0][k] < GRAD_RTOL
+        assert err[0][k] < 2.0 * err[1][k] + 1e-7, err
+
+
 def oracle_ppo_loop(p, want, ocfg, steps, clip):
     p = p.copy()
     st = L.oracle_adam_new(len(p))
