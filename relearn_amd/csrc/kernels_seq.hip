@@ -319,7 +319,7 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
       av[i] = hv > 0.0f ? hv : 0.0f;
     }
     if (store != nullptr) {
-      float *__restrict__ row = store + (size_t)j * TL + 16 * mt + 4 * g4;
+      float *__restrict__ row = store + rec_at(j, 16 * mt + 4 * g4);
       *reinterpret_cast<f32x4 *>(row + (size_t)ACT_R * GH * TL) = rv;
       *reinterpret_cast<f32x4 *>(row + (size_t)ACT_Z * GH * TL) = zv;
       *reinterpret_cast<f32x4 *>(row + (size_t)ACT_N * GH * TL) = nv;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
       uv[i] = u;
     }
     if (store != nullptr)
-      *reinterpret_cast<f32x4 *>(store + (size_t)ACT_U * GH * TL + (size_t)j * TL + 16 * mt + 4 * g4) = uv;
+      *reinterpret_cast<f32x4 *>(store + (size_t)ACT_U * GH * TL + rec_at(j, 16 * mt + 4 * g4)) = uv;
   }
   __syncthreads();
   if (wave == 0 && (lane >> 5) < A) {
@@ -458,7 +458,7 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
       tv[i] = tc;
     }
     if (store != nullptr) {
-      float *__restrict__ row = store + (size_t)j * TL + 16 * mt + 4 * g4;
+      float *__restrict__ row = store + rec_at(j, 16 * mt + 4 * g4);
       *reinterpret_cast<f32x4 *>(row + (size_t)LACT_I * GH * TL) = iv;
       *reinterpret_cast<f32x4 *>(row + (size_t)LACT_F * GH * TL) = fv;
       *reinterpret_cast<f32x4 *>(row + (size_t)LACT_G * GH * TL) = gv;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
       uv[i] = u;
     }
     if (store != nullptr)
-      *reinterpret_cast<f32x4 *>(store + (size_t)ACT_U * GH * TL + (size_t)j * TL + 16 * mt + 4 * g4) = uv;
+      *reinterpret_cast<f32x4 *>(store + (size_t)ACT_U * GH * TL + rec_at(j, 16 * mt + 4 * g4)) = uv;
   }
   __syncthreads();
   if (wave == 0 && (lane >> 5) < A) {

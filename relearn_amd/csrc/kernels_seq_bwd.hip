@@ -138,12 +138,12 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
     f32x4 u[2], a1[2], r[2], z[2], n[2], ghn[2], hp[2], dzv[A][2];
     uint32_t end[2];  // four flag bytes
   };
-  const size_t lo = (size_t)j * TL + 4 * g4;  // + 16 mt: first of the lane's four contiguous samples
+  const size_t lo = rec_at(j, 4 * g4);  // + 16 mt: first of the lane's four contiguous samples
   auto load_u = [&](StepIn &in, uint32_t t) {
     const float *__restrict__ ab = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      in.u[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + 16 * mt);
+      in.u[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + REC_HALF * mt);
 #pragma unroll
       for (int a = 0; a < A; ++a)
         in.dzv[a][mt] = *reinterpret_cast<const f32x4 *>(dz + (size_t)a * B + (size_t)t * N + lane0 + 16 * mt + 4 * g4);
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
     const float *__restrict__ ab = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const size_t o = lo + 16 * mt;
+      const size_t o = lo + REC_HALF * mt;
       in.a1[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + o);
       in.r[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_R * GH * TL + o);
       in.z[mt] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_Z * GH * TL + o);
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
         bufU[j][16 * mt + 4 * g4 + i] = du;
         duv[i] = du;
       }
-      *reinterpret_cast<f32x4 *>(db + (size_t)4 * GH * TL + lo + 16 * mt) = duv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)4 * GH * TL + lo + REC_HALF * mt) = duv;
     }
     uint32_t endw[2] = {in.end[0], in.end[1]};
     if (t > 0) load_u(in, t - 1);  // consumed at the top of the next step
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_bptt(TrajDev tr, const floa
         bufG[1][j][m] = gzv[i];
         bufG[2][j][m] = gnrv[i];
       }
-      const size_t o = lo + 16 * mt;
+      const size_t o = lo + REC_HALF * mt;
       *reinterpret_cast<f32x4 *>(db + (size_t)0 * GH * TL + o) = grv;
       *reinterpret_cast<f32x4 *>(db + (size_t)1 * GH * TL + o) = gzv;
       *reinterpret_cast<f32x4 *>(db + (size_t)2 * GH * TL + o) = dpnv;
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_seq_head_backward(TrajDev tr, c
   for (int ks = 0; ks < MH / 4; ++ks) w1T[ks] = g.W1[(size_t)(4 * ks + g4) * GH + j];
 #pragma unroll
   for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
-  const size_t lo = (size_t)j * TL + 4 * g4;
+  const size_t lo = rec_at(j, 4 * g4);
   for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
     const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_seq_head_backward(TrajDev tr, c
     __syncthreads();  // the previous block's readers of bufU are done
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const f32x4 uv = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + 16 * mt);
+      const f32x4 uv = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_U * GH * TL + lo + REC_HALF * mt);
       f32x4 dzv[A], duv;
 #pragma unroll
       for (int a = 0; a < A; ++a)
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_seq_head_backward(TrajDev tr, c
         bufU[j][16 * mt + 4 * g4 + i] = du;
         duv[i] = du;
       }
-      *reinterpret_cast<f32x4 *>(db + (size_t)DPRE_DU * GH * TL + lo + 16 * mt) = duv;
+      *reinterpret_cast<f32x4 *>(db + (size_t)DPRE_DU * GH * TL + lo + REC_HALF * mt) = duv;
     }
     __syncthreads();
     f32x4 acc1[2][2];
@@ -313,11 +313,11 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_seq_head_backward(TrajDev tr, c
                                                                 acc1[mt][ks & 1], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + lo + 16 * mt);
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + lo + REC_HALF * mt);
       f32x4 dav;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dav[i] = a1[i] > 0.0f ? acc1[mt][0][i] + acc1[mt][1][i] : 0.0f;
-      *reinterpret_cast<f32x4 *>(db + (size_t)DPRE_DA1 * GH * TL + lo + 16 * mt) = dav;
+      *reinterpret_cast<f32x4 *>(db + (size_t)DPRE_DA1 * GH * TL + lo + REC_HALF * mt) = dav;
     }
   }
 }
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_lstm_bptt(TrajDev tr, const flo
   for (int gte = 0; gte < 4; ++gte)
 #pragma unroll
     for (int ks = 0; ks < GH / 4; ++ks) whhT[gte][ks] = g.Whh[(size_t)(gte * GH + 4 * ks + g4) * GH + j];
-  const size_t lo = (size_t)j * TL + 4 * g4;
+  const size_t lo = rec_at(j, 4 * g4);
   f32x4 dhc[2], dcc[2];
   dhc[0] = dhc[1] = dcc[0] = dcc[1] = (f32x4){0, 0, 0, 0};
   for (uint32_t t = T; t-- > 0;) {
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_lstm_bptt(TrajDev tr, const flo
     float *__restrict__ db = dpre + ((size_t)t * tiles + tile) * DPRE_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const size_t o = lo + 16 * mt;
+      const size_t o = lo + REC_HALF * mt;
       const f32x4 iv = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_I * GH * TL + o);
       const f32x4 fv = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_F * GH * TL + o);
       const f32x4 gv = *reinterpret_cast<const f32x4 *>(ab + (size_t)LACT_G * GH * TL + o);
@@ -478,7 +478,8 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int f = threadIdx.x + 256 * i;
-        *reinterpret_cast<f32x4 *>(&aS[a][f >> 3][4 * (f & 7)]) = stg[a][i];
+        // (record layout [half][unit][16], seq_common.hpp: float 4 f is unit (f & 511) >> 2, sample 16 (f >> 9) + 4 (f & 3))
+        *reinterpret_cast<f32x4 *>(&aS[a][(f & 511) >> 2][16 * (f >> 9) + 4 * (f & 3)]) = stg[a][i];
       }
     if (wave == 0 && lane < TL) {
 #pragma unroll
@@ -491,7 +492,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_wgrad(TrajDev tr, const float *_
     f32x4 hp4[4], a14[4], dpnv[4], uv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const size_t o = (size_t)j * TL + 16 * hf + 4 * q;
+      const size_t o = rec_at(j, 16 * hf + 4 * q);
       hp4[q] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_HPREV * GH * TL + o);
       a14[q] = *reinterpret_cast<const f32x4 *>(ab + (size_t)ACT_A1 * GH * TL + o);
       dpnv[q] = *reinterpret_cast<const f32x4 *>(db + (size_t)2 * GH * TL + o);

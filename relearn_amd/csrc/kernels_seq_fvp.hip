@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_tangent_pre(TrajDev tr, const fl
       for (int r = 0; r < 16; ++r) acc[gte][r] = w.bhh[gte];
 #pragma unroll
     for (int ks = 0; ks < GH / 2; ++ks) {
-      const float a = ab[(size_t)ACT_HPREV * GH * TL + (2 * ks + hf) * TL + n];
+      const float a = ab[(size_t)ACT_HPREV * GH * TL + rec_at(2 * ks + hf, n)];
 #pragma unroll
       for (int gte = 0; gte < 3; ++gte)
         acc[gte] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w.whh[gte][ks], acc[gte], 0, 0, 0);
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_tangent_pre(TrajDev tr, const fl
         for (int d = 0; d < D; ++d) q = __builtin_fmaf(xS[m][d], w.wih[gte][d], q);
         gi[gte] = q;
       }
-      const size_t o = (size_t)j * TL + m;
+      const size_t o = rec_at(j, m);
       sb[(size_t)0 * GH * TL + o] = acc[0][r] + gi[0];  // static part of d(gh_r + gi_r)
       sb[(size_t)1 * GH * TL + o] = acc[1][r] + gi[1];
       sb[(size_t)2 * GH * TL + o] = gi[2];              // d gi_n
@@ -76,14 +76,14 @@ __global__ void __launch_bounds__(256, 1) k_gru_tangent_pre(TrajDev tr, const fl
     for (int r = 0; r < 16; ++r) acc1[r] = w.b1;
 #pragma unroll
     for (int ks = 0; ks < GH / 2; ++ks)
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + (2 * ks + hf) * TL + n], w.w1[ks],
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + rec_at(2 * ks + hf, n)], w.w1[ks],
                                                   acc1, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sb[(size_t)4 * GH * TL + (size_t)j * TL + acc_row(r, hf)] = acc1[r];
+    for (int r = 0; r < 16; ++r) sb[(size_t)4 * GH * TL + rec_at(j, acc_row(r, hf))] = acc1[r];
     if (wave == 0 && hf < A) {
       float z = vb2;
 #pragma unroll 8
-      for (int q = 0; q < MH; ++q) z = __builtin_fmaf(ab[(size_t)ACT_U * GH * TL + q * TL + n], v2S[hf][q], z);
+      for (int q = 0; q < MH; ++q) z = __builtin_fmaf(ab[(size_t)ACT_U * GH * TL + rec_at(q, n)], v2S[hf][q], z);
       out_stat[((size_t)hf * T + t) * N + lane0 + n] = z;
     }
   }
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_tangent_rec(TrajDev tr, const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = acc_row(r, hf);
-      const size_t o = (size_t)j * TL + m;
+      const size_t o = rec_at(j, m);
       const float rr = ab[(size_t)ACT_R * GH * TL + o], zz = ab[(size_t)ACT_Z * GH * TL + o];
       const float nn = ab[(size_t)ACT_N * GH * TL + o], ghn = ab[(size_t)ACT_GHN * GH * TL + o];
       const float hp = ab[(size_t)ACT_HPREV * GH * TL + o], a1 = ab[(size_t)ACT_A1 * GH * TL + o];
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, 1) k_gru_tangent_rec(TrajDev tr, const fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = acc_row(r, hf);
-      const size_t o = (size_t)j * TL + m;
+      const size_t o = rec_at(j, m);
       const float u = ab[(size_t)ACT_U * GH * TL + o];
       udS[m][j] = u > 0.0f ? acc1[r] + sb[(size_t)4 * GH * TL + o] : 0.0f;
     }
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const f
       for (int r = 0; r < 16; ++r) acc[gte][r] = bhh[gte];
 #pragma unroll
     for (int ks = 0; ks < GH / 2; ++ks) {
-      const float a = ab[(size_t)ACT_HPREV * GH * TL + (2 * ks + hf) * TL + n];
+      const float a = ab[(size_t)ACT_HPREV * GH * TL + rec_at(2 * ks + hf, n)];
 #pragma unroll
       for (int gte = 0; gte < 4; ++gte)
         acc[gte] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, whh[gte][ks], acc[gte], 0, 0, 0);
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = acc_row(r, hf);
-      const size_t o = (size_t)j * TL + m;
+      const size_t o = rec_at(j, m);
 #pragma unroll
       for (int gte = 0; gte < 4; ++gte) {
         float q = bih[gte];
@@ -250,14 +250,14 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const f
     for (int r = 0; r < 16; ++r) acc1[r] = vb1;
 #pragma unroll
     for (int ks = 0; ks < GH / 2; ++ks)
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + (2 * ks + hf) * TL + n], w1[ks], acc1,
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + rec_at(2 * ks + hf, n)], w1[ks], acc1,
                                                   0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sb[(size_t)4 * GH * TL + (size_t)j * TL + acc_row(r, hf)] = acc1[r];
+    for (int r = 0; r < 16; ++r) sb[(size_t)4 * GH * TL + rec_at(j, acc_row(r, hf))] = acc1[r];
     if (wave == 0 && hf < A) {
       float z = vb2;
 #pragma unroll 8
-      for (int q = 0; q < MH; ++q) z = __builtin_fmaf(ab[(size_t)ACT_U * GH * TL + q * TL + n], v2S[hf][q], z);
+      for (int q = 0; q < MH; ++q) z = __builtin_fmaf(ab[(size_t)ACT_U * GH * TL + rec_at(q, n)], v2S[hf][q], z);
       out_stat[((size_t)hf * T + t) * N + lane0 + n] = z;
     }
   }
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_rec(TrajDev tr, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = acc_row(r, hf);
-      const size_t o = (size_t)j * TL + m;
+      const size_t o = rec_at(j, m);
       const float ig = ab[(size_t)LACT_I * GH * TL + o], fg = ab[(size_t)LACT_F * GH * TL + o];
       const float gg = ab[(size_t)LACT_G * GH * TL + o], og = ab[(size_t)LACT_O * GH * TL + o];
       const float cp = ab[(size_t)LACT_CPREV * GH * TL + o], tc = ab[(size_t)LACT_TC * GH * TL + o];
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_rec(TrajDev tr, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = acc_row(r, hf);
-      const size_t o = (size_t)j * TL + m;
+      const size_t o = rec_at(j, m);
       const float u = ab[(size_t)ACT_U * GH * TL + o];
       udS[m][j] = u > 0.0f ? acc1[r] + sb[(size_t)4 * GH * TL + o] : 0.0f;
     }

@@ -45,10 +45,41 @@ using bt::Frag;
 // 1.8e-8).  PIECE_ORDER 5 multiplies all nine.
 constexpr int PIECE_ORDER = 3;
 constexpr int PIECE_PAIRS = PIECE_ORDER == 3 ? 6 : PIECE_ORDER == 4 ? 8 : 9;
-constexpr int VALU_PER_MFMA = 45 / PIECE_PAIRS;  // vector instructions the schedule of the forward places between two matrix instructions
-constexpr int HROW = GH + 8;      // halfwords per row of a [sample][unit] piece image: 272-byte rows, so the 16-byte
-                                  // operand reads of 16 consecutive samples start 4 banks apart
-constexpr int GROW = 3 * GH + 8;  // the backward's [sample][gate unit] rows (784 bytes: the same property)
+constexpr int VALU_PER_MFMA = 4;  // vector instructions the forward's schedule places after each matrix instruction  // vector instructions the schedule of the forward places between two matrix instructions
+// Piece images [sample][unit] in LDS: rows of GH halfwords (256 bytes — the width of the LDS), the 16-byte chunk c of
+// row m stored at chunk (c + img_rot(m)) & 15.  A ds_read_b128 is served in four groups of sixteen lanes that are NOT
+// contiguous ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: MI355X_MICROARCH.md, LDS).  The operand read of lane
+// (n16, g4) — row n16, chunk 4 kb + g4 — is conflict-free when the rows' rotations are even and differ within rows
+// {0-3, 12-15} and within rows {4-11}.  The padded 272-byte rows this file had before cost every such read twice its
+// cycles (0.23 - 0.54 of all LDS cycles were bank conflicts: profiles/r02_pmc_gru_config5_summary.json, with the head
+// forward's LDS busy 0.7 of the time).  The rotation keeps the piece writes (lane = unit, lane group = sample)
+// conflict-free as well.  scripts/lds_conflicts.py evaluates every pattern used here under the banking rules.
+__device__ __forceinline__ int img_rot(int m) { return 4 * (m & 3) + 2 * ((m >> 2) & 1); }
+// halfword index of (sample m, unit k) in a [TL][GH] image (k a multiple of 8: the start of an operand chunk)
+__device__ __forceinline__ int img_at(int m, int k) { return m * GH + ((k + 8 * img_rot(m)) & (GH - 1)); }
+// The backward recurrence has no registers for rotated offsets (one per k-block of a row): its [sample][3 GH] rows
+// are padded by 32 bytes instead — row m starts 2 m chunks into the LDS width, which gives the operand reads the same
+// property with linear addresses; its piece writes pay for it (lanes l and l + 16 write rows four apart, 25 x 128
+// bytes: two cycles instead of one).
+constexpr int GROW = 3 * GH + 16;
+// Piece images [unit][sample] (the sample is the contraction index): 64-byte rows of TL halfwords, chunk c of row r
+// (the eight samples 4 c .. 4 c + 3, 16 + 4 c .. 16 + 4 c + 3: the two accumulator quadruples of ONE lane, so a lane
+// parks a row's chunk with one 16-byte write; both operands of the product use the same order) stored at chunk
+// c ^ ((r >> 1) & 3): reads (lane = row, lane group = chunk) and writes (the same pattern) are conflict-free.
+__device__ __forceinline__ int timg_at(int r, int c) { return r * TL + 8 * (c ^ ((r >> 1) & 3)); }
+
+// sum over the 16 lanes of a DPP row (lanes 16 q .. 16 q + 15), in every one of them: vector-ALU lane moves, no LDS
+template <int CTRL>
+__device__ __forceinline__ float dpp_lanes(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum16(float v) {
+  v += dpp_lanes<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_lanes<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_lanes<0x141>(v);  // row_half_mirror: the other quad of the eight
+  v += dpp_lanes<0x140>(v);  // row_mirror: the other eight
+  return v;
+}
 
 // eight consecutive values of k -> the three operand fragments of their exact bf16 pieces
 __device__ __forceinline__ void frags_of8(const float (&v)[8], Frag (&f)[3]) {
@@ -111,8 +142,8 @@ template <int D>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_recur_fwd(TrajDev tr, const float *__restrict__ params, int A, float *__restrict__ act,
                     const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) unsigned short hP[2][3][TL][HROW];  // h as pieces, [sample][unit], by step parity
-  __shared__ float xS[2][TL][8];
+  __shared__ __attribute__((aligned(16))) unsigned short hP[3][TL * GH];  // h as pieces, [sample][unit] (img_at)
+  __shared__ float xS[2][TL][9];  // (9: the four samples a wave reads at once are 4 rows apart — 144 bytes, not 128)
   __shared__ int endS[2][TL];
   __shared__ float wiS[3][D + 1][GH];
   __shared__ uint4 wnS[GH / 32][3][W16][64];  // the n gate's W_hh fragments (96 KB): 48 registers the budget does not have
@@ -148,7 +179,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     const int gte = q / ((D + 1) * GH), d = (q / GH) % (D + 1), u = q % GH;
     wiS[gte][d][u] = d < D ? g.Wih[(size_t)(gte * GH + u) * D + d] : g.bih[gte * GH + u];
   }
-  for (int q = threadIdx.x; q < (int)(sizeof(hP) / 4); q += W16 * 64) reinterpret_cast<uint32_t *>(hP)[q] = 0u;
+  for (int q = threadIdx.x; q < (int)(sizeof(hP) / 4); q += W16 * 64) reinterpret_cast<uint32_t *>(&hP[0][0])[q] = 0u;
   float hown[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) hown[r] = 0.0f;
@@ -172,116 +203,134 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     publish(0);
   }
   __syncthreads();
-  for (uint32_t t = 0; t < T; ++t) {
-    const int cur = (int)(t & 1), nxt = cur ^ 1;
-    if (io_lane && t + 1 < T) fetch(t + 1);  // lands under the products
-    f32x4 acc[3][2];
+  // A step is two phases with a barrier after each, and in both the matrix pipe and the vector ALU work side by side:
+  //   phase 1: products of M-tile 1 (step t)       | gate arithmetic of M-tile 0 (step t) -> rows 0-15 of h(t+1)
+  //   phase 2: products of M-tile 0 (step t + 1)   | gate arithmetic of M-tile 1 (step t) -> rows 16-31 of h(t+1)
+  // (the products of an M-tile need its 16 samples of ALL units, i.e. that M-tile's gate arithmetic of every wave, and
+  // nothing of the other M-tile).  The barrier keeps the two waves of a SIMD in the same phase, so the overlap has to
+  // come from INSIDE a wave: each phase is one basic block, and the scheduler is asked to place a few vector
+  // instructions after every matrix instruction.  (One phase per step — both M-tiles' products, then both M-tiles'
+  // gates with M-tile 1's products between M-tile 0's — left the first products and the last gates uncovered: VALU
+  // busy 0.52 + matrix pipe 0.48 added up to the step time.)  Rows of the image are rewritten only after the barrier
+  // that follows their last read, so one image serves.
+  f32x4 acc[3][2];
+  auto start = [&](int mt) {
 #pragma unroll
-    for (int gte = 0; gte < 3; ++gte)
+    for (int gte = 0; gte < 3; ++gte) acc[gte][mt] = (f32x4){bhh[gte], bhh[gte], bhh[gte], bhh[gte]};
+  };
+  // operand reads run one k-block ahead of the products
+  auto products = [&](int mt) {
+    auto frags = [&](int kb, Frag (&a)[3]) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[gte][mt] = (f32x4){bhh[gte], bhh[gte], bhh[gte], bhh[gte]};
-    // The barrier keeps the two waves of a SIMD in step, so matrix and vector work overlap only INSIDE a wave: the
-    // products of M-tile 1 are issued between the gate arithmetic of M-tile 0 (one basic block, the scheduler
-    // interleaves them); operand reads run one k-block ahead of the products.
-    auto products = [&](int mt) {
-      auto frags = [&](int kb, Frag (&a)[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          a[p].x = *reinterpret_cast<const uint4 *>(&hP[cur][p][16 * mt + n16][32 * kb + 8 * g4]);
-      };
-      Frag fa[2][3];
-      frags(0, fa[0]);
-#pragma unroll
-      for (int kb = 0; kb < GH / 32; ++kb) {
-        if (kb + 1 < GH / 32) frags(kb + 1, fa[(kb + 1) & 1]);
-        Frag wn[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) wn[q].x = wnS[kb][q][wave][lane];
-#pragma unroll
-        for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma_pieces(fa[kb & 1], wf[gte][kb], acc[gte][mt]);
-        acc[2][mt] = mfma_pieces(fa[kb & 1], wn, acc[2][mt]);
-      }
+      for (int p = 0; p < 3; ++p)
+        a[p].x = *reinterpret_cast<const uint4 *>(&hP[p][img_at(16 * mt + n16, 32 * kb + 8 * g4)]);
     };
+    Frag fa[2][3];
+    frags(0, fa[0]);
+#pragma unroll
+    for (int kb = 0; kb < GH / 32; ++kb) {
+      if (kb + 1 < GH / 32) frags(kb + 1, fa[(kb + 1) & 1]);
+      Frag wn[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wn[q].x = wnS[kb][q][wave][lane];
+#pragma unroll
+      for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma_pieces(fa[kb & 1], wf[gte][kb], acc[gte][mt]);
+      acc[2][mt] = mfma_pieces(fa[kb & 1], wn, acc[2][mt]);
+    }
+  };
+  auto gates = [&](int mt, uint32_t t) {
+    const int cur = (int)(t & 1);
     float *__restrict__ store = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
-    auto gates = [&](int mt) {
-      // (uniform block base + 32-bit lane offsets: the addresses stay out of the vector registers)
-      const uint32_t row = (uint32_t)(j * TL + 16 * mt + 4 * g4);
-      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_GHN * GH * TL) + row) = acc[2][mt];
-      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_HPREV * GH * TL) + row) =
-          (f32x4){hown[4 * mt], hown[4 * mt + 1], hown[4 * mt + 2], hown[4 * mt + 3]};
-      float wih[3][D], bih[3];
+    // (uniform block base + 32-bit lane offsets: the addresses stay out of the vector registers)
+    const uint32_t row = rec_at(j, 16 * mt + 4 * g4);
+    *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_GHN * GH * TL) + row) = acc[2][mt];
+    *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_HPREV * GH * TL) + row) =
+        (f32x4){hown[4 * mt], hown[4 * mt + 1], hown[4 * mt + 2], hown[4 * mt + 3]};
+    float wih[3][D], bih[3];
+#pragma unroll
+    for (int gte = 0; gte < 3; ++gte) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) wih[gte][d] = wiS[gte][d][j];
+      bih[gte] = wiS[gte][D][j];
+    }
+    f32x4 rv, zv, nv, av;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = acc16_row(mt, i, g4), r = 4 * mt + i;
+      float gi[3];
 #pragma unroll
       for (int gte = 0; gte < 3; ++gte) {
+        float v = bih[gte];
 #pragma unroll
-        for (int d = 0; d < D; ++d) wih[gte][d] = wiS[gte][d][j];
-        bih[gte] = wiS[gte][D][j];
+        for (int d = 0; d < D; ++d) v = __builtin_fmaf(xS[cur][m][d], wih[gte][d], v);
+        gi[gte] = v;
       }
-      f32x4 rv, zv, nv, av;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = acc16_row(mt, i, g4), r = 4 * mt + i;
-        float gi[3];
-#pragma unroll
-        for (int gte = 0; gte < 3; ++gte) {
-          float v = bih[gte];
-#pragma unroll
-          for (int d = 0; d < D; ++d) v = __builtin_fmaf(xS[cur][m][d], wih[gte][d], v);
-          gi[gte] = v;
-        }
-        const float rr = sigmoid_sel(acc[0][mt][i] + gi[0]);
-        const float zz = sigmoid_sel(acc[1][mt][i] + gi[1]);
-        const float rn = acc[2][mt][i] * rr;
-        const float nn = tanh_sel(gi[2] + rn);
-        const float dn = hown[r] - nn;
-        const float hz = dn * zz;
-        const float hv = hz + nn;
-        rv[i] = rr;
-        zv[i] = zz;
-        nv[i] = nn;
-        av[i] = hv > 0.0f ? hv : 0.0f;
-        // the state the next step starts from: zero after an episode end (SeqPacked restarts per episode)
-        const float hn = endS[cur][m] != 0 ? 0.0f : hv;
-        hown[r] = hn;
-        uint32_t p0, p1, p2;
-        bt::split3(hn, p0, p1, p2);
-        hP[nxt][0][m][j] = (unsigned short)p0;
-        hP[nxt][1][m][j] = (unsigned short)p1;
-        hP[nxt][2][m][j] = (unsigned short)p2;
-      }
-      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_R * GH * TL) + row) = rv;
-      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_Z * GH * TL) + row) = zv;
-      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_N * GH * TL) + row) = nv;
-      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
-    };
-    products(0);
-    __builtin_amdgcn_sched_barrier(0);
-    products(1);
-    gates(0);
-    // the order asked of the scheduler for this region (the 108 products of M-tile 1, the gate arithmetic of M-tile 0):
-    // one matrix instruction, then a few vector instructions, ...
+      const float rr = sigmoid_sel(acc[0][mt][i] + gi[0]);
+      const float zz = sigmoid_sel(acc[1][mt][i] + gi[1]);
+      const float rn = acc[2][mt][i] * rr;
+      const float nn = tanh_sel(gi[2] + rn);
+      const float dn = hown[r] - nn;
+      const float hz = dn * zz;
+      const float hv = hz + nn;
+      rv[i] = rr;
+      zv[i] = zz;
+      nv[i] = nn;
+      av[i] = hv > 0.0f ? hv : 0.0f;
+      // the state the next step starts from: zero after an episode end (SeqPacked restarts per episode)
+      const float hn = endS[cur][m] != 0 ? 0.0f : hv;
+      hown[r] = hn;
+      uint32_t p0, p1, p2;
+      bt::split3(hn, p0, p1, p2);
+      hP[0][img_at(m, j)] = (unsigned short)p0;
+      hP[1][img_at(m, j)] = (unsigned short)p1;
+      hP[2][img_at(m, j)] = (unsigned short)p2;
+    }
+    *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_R * GH * TL) + row) = rv;
+    *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_Z * GH * TL) + row) = zv;
+    *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_N * GH * TL) + row) = nv;
+    *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
+  };
+  auto interleave = [&]() {  // the order asked of the scheduler for a phase: one matrix instruction, a few vector ones
 #pragma unroll
     for (int k = 0; k < (GH / 32) * 3 * PIECE_PAIRS; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
     }
     __builtin_amdgcn_sched_barrier(0);
-    gates(1);
-    if (io_lane && t + 1 < T) publish(nxt);
-    __syncthreads();  // one barrier per step: the images of step t + 1 are complete, those of step t are free
+  };
+  start(0);
+  products(0);  // (h = 0: the biases)
+  for (uint32_t t = 0; t < T; ++t) {
+    if (io_lane && t + 1 < T) fetch(t + 1);  // lands under the products
+    __builtin_amdgcn_sched_barrier(0);
+    start(1);
+    products(1);
+    gates(0, t);
+    interleave();
+    __syncthreads();  // rows 0-15 of h(t+1) are complete; every wave has read rows 16-31 of h(t)
+    if (t + 1 < T) {
+      start(0);
+      products(0);
+      gates(1, t);
+      interleave();
+      if (io_lane) publish((int)((t + 1) & 1));
+    } else {
+      gates(1, t);
+    }
+    __syncthreads();  // rows 16-31 of h(t+1) and the inputs of step t + 1 are complete; rows 0-15 have been read
   }
 }
 
 // ---------------------------------------------------------------- head forward, all (step, tile) blocks in parallel
 // u = relu(b1 + W1 relu(h')) on the bf16 pipe (A operand: the recorded relu(h') block, split into its pieces and laid
 // out [sample][unit] in LDS; B: this wave's 16 rows of W1 as register fragments), recorded for the backward;
-// out_a = b2_a + sum_q u_q W2[a][q] as 8 partial sums of 16 terms per (sample, output), joined by a shuffle tree.
+// out_a = b2_a + sum_q u_q W2[a][q]: the 16 units of a wave summed across its lanes (DPP), the eight waves through LDS.
 template <int A>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_seq_head_forward(TrajDev tr, const float *__restrict__ params, int D, int NG, float *__restrict__ act,
                        float *__restrict__ out, uint32_t tiles, uint32_t blocks, const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) unsigned short aK[3][TL][HROW];
-  __shared__ float uS[TL][MH + 1];
-  __shared__ float w2S[2][MH];
+  __shared__ __attribute__((aligned(16))) unsigned short aK[3][TL * GH];  // relu(h') as pieces (img_at)
+  __shared__ float vS[2][W16][TL];  // per output, wave and sample: the wave's 16 terms of W2 u
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
@@ -296,22 +345,24 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     frags_of8(v, w1f[kb]);
   }
   const float b1 = g.b1[j];
-  for (int q = threadIdx.x; q < A * MH; q += W16 * 64) w2S[q / MH][q % MH] = g.W2[q];
-  const int hs = 4 * wave + g4, ha = (lane >> 3) & 1, hc = lane & 7;  // head: sample, output, 16-term chunk
+  float w2c[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) w2c[a] = g.W2[a * MH + j];
+  const int ha = (int)threadIdx.x / TL, hm = (int)threadIdx.x % TL;  // threads < A TL: output, sample
   const float b2v = ha < A ? g.b2[ha] : 0.0f;
-  const uint32_t lo = (uint32_t)(j * TL + 4 * g4);
+  const uint32_t lo = rec_at(j, 4 * g4);
   f32x4 a1n[2];
   auto fetch = [&](uint32_t blk) {
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
-      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_A1 * GH * TL) + lo + 16 * mt);
+      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_A1 * GH * TL) + lo + REC_HALF * mt);
   };
   if (blockIdx.x < blocks) fetch(blockIdx.x);
   for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
     const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
     float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
-    __syncthreads();  // the previous block's readers of aK / uS are done
+    __syncthreads();  // the previous block's readers of aK / vS are done
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -319,9 +370,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         uint32_t p0, p1, p2;
         bt::split3(a1n[mt][i], p0, p1, p2);
         const int m = 16 * mt + 4 * g4 + i;
-        aK[0][m][j] = (unsigned short)p0;
-        aK[1][m][j] = (unsigned short)p1;
-        aK[2][m][j] = (unsigned short)p2;
+        aK[0][img_at(m, j)] = (unsigned short)p0;
+        aK[1][img_at(m, j)] = (unsigned short)p1;
+        aK[2][img_at(m, j)] = (unsigned short)p2;
       }
     if (blk + gridDim.x < blocks) fetch(blk + gridDim.x);  // the next block's operand lands under this block's products
     __syncthreads();
@@ -335,7 +386,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         Frag fa[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          fa[c].x = *reinterpret_cast<const uint4 *>(&aK[c][16 * mt + n16][32 * kb + 8 * g4]);
+          fa[c].x = *reinterpret_cast<const uint4 *>(&aK[c][img_at(16 * mt + n16, 32 * kb + 8 * g4)]);
         acc1[mt] = mfma_pieces(fa, w1f[kb], acc1[mt]);
       }
 #pragma unroll
@@ -344,21 +395,22 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float u = acc1[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
-        uS[acc16_row(mt, i, g4)][j] = u;
         uv[i] = u;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          const float part = sum16(u * w2c[a]);
+          if (n16 == 0) vS[a][wave][acc16_row(mt, i, g4)] = part;
+        }
       }
-      *reinterpret_cast<f32x4 *>(ab + (uint32_t)(ACT_U * GH * TL) + lo + 16 * mt) = uv;
+      *reinterpret_cast<f32x4 *>(ab + (uint32_t)(ACT_U * GH * TL) + lo + REC_HALF * mt) = uv;
     }
     __syncthreads();
-    float part = 0.0f;
     if (ha < A) {
+      float v = b2v;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) part = __builtin_fmaf(uS[hs][16 * hc + q], w2S[ha][16 * hc + q], part);
+      for (int w = 0; w < W16; ++w) v += vS[ha][w][hm];
+      out[((size_t)ha * T + t) * N + lane0 + hm] = v;
     }
-    part = part + __shfl_xor(part, 1, 64);
-    part = part + __shfl_xor(part, 2, 64);
-    part = part + __shfl_xor(part, 4, 64);
-    if (hc == 0 && ha < A) out[((size_t)ha * T + t) * N + lane0 + hs] = part + b2v;
   }
 }
 
@@ -377,7 +429,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   constexpr int KB = 3 * GH / 32, KBL = 3;  // k-blocks of the K = 384 product; the last KBL keep their weights in LDS
   __shared__ __attribute__((aligned(16))) unsigned short gP[3][TL][GROW];  // gate gradients as pieces, [sample][gate unit]
   __shared__ uint4 wTS[KBL][3][W16][64];  // 72 KB: 36 registers the budget does not have
-  __shared__ float xS[2][TL][8];          // observation features by step parity (the input side's weight gradients)
+  __shared__ float xS[2][TL][9];          // observation features by step parity (the input side's weight gradients)
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
@@ -412,7 +464,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
   for (int d = 0; d < D; ++d) dwin[d] = 0.0f;
   const size_t plane = (size_t)(T + 1) * N;
-  const uint32_t lo = (uint32_t)(j * TL + 4 * g4);  // + 16 mt: first of the lane's four contiguous samples (32-bit
+  const uint32_t lo = rec_at(j, 4 * g4);  // + 16 mt: first of the lane's four contiguous samples (32-bit
                                                     // offsets from a uniform block base: no 64-bit address registers)
   auto load = [&](StepIn &in, uint32_t t) {
     const size_t blk = (size_t)t * tiles + tile;
@@ -420,7 +472,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     const float *__restrict__ db = dpre + blk * DPRE_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const uint32_t o = lo + 16 * mt;
+      const uint32_t o = lo + REC_HALF * mt;
       in.r[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_R * GH * TL) + o);
       in.z[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_Z * GH * TL) + o);
       in.n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_N * GH * TL) + o);
@@ -475,7 +527,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
           gP[2][m][gte * GH + j] = (unsigned short)p2;
         }
       }
-      const uint32_t o = lo + 16 * mt;
+      const uint32_t o = lo + REC_HALF * mt;
       *reinterpret_cast<f32x4 *>(db + (uint32_t)(0 * GH * TL) + o) = grv;
       *reinterpret_cast<f32x4 *>(db + (uint32_t)(1 * GH * TL) + o) = gzv;
       *reinterpret_cast<f32x4 *>(db + (uint32_t)(3 * GH * TL) + o) = gnrv;  // (array 2, d pre_n, stays on chip)
@@ -546,10 +598,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_head_backward(TrajDev tr, const float *__restrict__ params, int D, const float *__restrict__ dz,
                         const float *__restrict__ act, float *__restrict__ dpre, float *__restrict__ slab, uint32_t P,
                         uint32_t tiles, uint32_t blocks, const int32_t *__restrict__ skip) {
-  constexpr int MROW = TL + 8;  // halfwords per row of the [unit][sample] images (80-byte rows)
-  __shared__ __attribute__((aligned(16))) unsigned short uJ[3][TL][HROW];
-  __shared__ __attribute__((aligned(16))) unsigned short uM[3][MH][MROW];
-  __shared__ __attribute__((aligned(16))) unsigned short aM[3][GH][MROW];
+  __shared__ __attribute__((aligned(16))) unsigned short uJ[3][TL * GH];  // img_at
+  __shared__ __attribute__((aligned(16))) unsigned short uM[3][MH * TL];  // timg_at
+  __shared__ __attribute__((aligned(16))) unsigned short aM[3][GH * TL];  // timg_at
   __shared__ float dzS[2][TL];
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -574,30 +625,33 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   float db1 = 0.0f, dw2[A], db2 = 0.0f;
 #pragma unroll
   for (int a = 0; a < A; ++a) dw2[a] = 0.0f;
-  const uint32_t lo = (uint32_t)(j * TL + 4 * g4);
+  const uint32_t lo = rec_at(j, 4 * g4);
   f32x4 a1n[2], un[2];
   float dzn = 0.0f;
   auto fetch = [&](uint32_t blk) {
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_A1 * GH * TL) + lo + 16 * mt);
-      un[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_U * GH * TL) + lo + 16 * mt);
+      a1n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_A1 * GH * TL) + lo + REC_HALF * mt);
+      un[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_U * GH * TL) + lo + REC_HALF * mt);
     }
     if (wave == 0 && lane < A * TL) {  // lane = (output a = lane >> 5, sample lane & 31)
       const uint32_t t = blk / tiles, lane0 = (blk % tiles) * TL;
       dzn = dz[(size_t)(lane >> 5) * B + (size_t)t * N + lane0 + (lane & 31)];
     }
   };
-  // four consecutive samples of this lane's unit -> 8 bytes of each piece image [unit][sample]
-  auto park4 = [&](unsigned short (*img)[MH][MROW], int col, const f32x4 &v) {
-    uint32_t p[4][3];
+  // this lane's eight samples of unit j (its two accumulator quadruples) -> chunk g4 of row j of each piece image
+  auto park8 = [&](unsigned short (*img)[MH * TL], const f32x4 &v0, const f32x4 &v1) {
+    uint32_t p[8][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bt::split3(v[i], p[i][0], p[i][1], p[i][2]);
+    for (int i = 0; i < 4; ++i) {
+      bt::split3(v0[i], p[i][0], p[i][1], p[i][2]);
+      bt::split3(v1[i], p[4 + i][0], p[4 + i][1], p[4 + i][2]);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      *reinterpret_cast<uint64_t *>(&img[c][j][col]) =
-          (uint64_t)bt::pk(p[0][c], p[1][c]) | ((uint64_t)bt::pk(p[2][c], p[3][c]) << 32);
+      *reinterpret_cast<uint4 *>(&img[c][timg_at(j, g4)]) =
+          make_uint4(bt::pk(p[0][c], p[1][c]), bt::pk(p[2][c], p[3][c]), bt::pk(p[4][c], p[5][c]), bt::pk(p[6][c], p[7][c]));
   };
   if (blockIdx.x < blocks) fetch(blockIdx.x);
   for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
@@ -612,13 +666,13 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     for (int mt = 0; mt < 2; ++mt) {
       a1c[mt] = a1n[mt];
       uc[mt] = un[mt];
-      park4(aM, 16 * mt + 4 * g4, a1c[mt]);
     }
+    park8(aM, a1c[0], a1c[1]);
     __syncthreads();  // dz of the block is visible
     if (blk + gridDim.x < blocks) fetch(blk + gridDim.x);  // the next block's operands land under this block's products
+    f32x4 duv[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      f32x4 duv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = 16 * mt + 4 * g4 + i;
@@ -630,15 +684,15 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         }
         du = uc[mt][i] > 0.0f ? du : 0.0f;
         db1 += du;
-        duv[i] = du;
+        duv[mt][i] = du;
         uint32_t p0, p1, p2;
         bt::split3(du, p0, p1, p2);
-        uJ[0][m][j] = (unsigned short)p0;
-        uJ[1][m][j] = (unsigned short)p1;
-        uJ[2][m][j] = (unsigned short)p2;
+        uJ[0][img_at(m, j)] = (unsigned short)p0;
+        uJ[1][img_at(m, j)] = (unsigned short)p1;
+        uJ[2][img_at(m, j)] = (unsigned short)p2;
       }
-      park4(uM, 16 * mt + 4 * g4, duv);
     }
+    park8(uM, duv[0], duv[1]);
     __syncthreads();
     // d relu(h')[m][k = j] = sum over the units q of d u_pre[m][q] W1[q][k]
     f32x4 acc1[2];
@@ -650,7 +704,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
         Frag fa[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          fa[c].x = *reinterpret_cast<const uint4 *>(&uJ[c][16 * mt + n16][32 * kb + 8 * g4]);
+          fa[c].x = *reinterpret_cast<const uint4 *>(&uJ[c][img_at(16 * mt + n16, 32 * kb + 8 * g4)]);
         acc1[mt] = mfma_pieces(fa, w1f[kb], acc1[mt]);
       }
 #pragma unroll
@@ -658,18 +712,18 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       f32x4 dav;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dav[i] = a1c[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
-      *reinterpret_cast<f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + lo + 16 * mt) = dav;
+      *reinterpret_cast<f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + lo + REC_HALF * mt) = dav;
     }
     // dW1[row][col] += sum over the 32 samples of d u_pre[row][m] relu(h')[col][m]: A rows = this wave's 16 units
     {
       Frag fa[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) fa[c].x = *reinterpret_cast<const uint4 *>(&uM[c][j][8 * g4]);
+      for (int c = 0; c < 3; ++c) fa[c].x = *reinterpret_cast<const uint4 *>(&uM[c][timg_at(j, g4)]);
 #pragma unroll
       for (int nt = 0; nt < GH / 16; ++nt) {
         Frag fb[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&aM[c][16 * nt + n16][8 * g4]);
+        for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&aM[c][timg_at(16 * nt + n16, g4)]);
         accw[nt] = mfma_pieces(fa, fb, accw[nt]);
       }
     }
@@ -713,16 +767,18 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // (their input side equals their hidden side), are sums the staging threads keep for the rows they stage (thread q
 // stages row q >> 2 of every gate in every half); the n gate's input side comes from the backward recurrence.  One row
 // of f32 partials per workgroup (columns of the recurrent parameters only; the head's come from k_gru_head_backward).
-constexpr int WROW = 16 + 8;  // halfwords per row of the [row][16 samples] piece images: 48-byte rows, the 16-byte
-                              // operand reads of 16 consecutive rows hit 64 different banks
+// [row][16 samples] piece images: 32-byte rows, the two 16-byte chunks of rows 8 .. 15 (mod 16) swapped — operand reads
+// (lane = row, upper half-wave = upper chunk) and the staging writes (four lanes per row) are conflict-free
+// (scripts/lds_conflicts.py; the padded 48-byte rows before cost the writes twice their cycles)
+__device__ __forceinline__ int wimg_at(int row, int hw) { return row * 16 + (hw ^ (((row >> 3) & 1) << 3)); }
 template <int D>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_wgrad_bf16(TrajDev tr, const float *__restrict__ act, const float *__restrict__ dpre,
                      float *__restrict__ slab, uint32_t P, uint32_t tiles, uint32_t blocks, uint32_t blocks_per_chunk,
                      const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) unsigned short AP[2][3][3 * GH][WROW];  // d gh pieces, by half parity
-  __shared__ __attribute__((aligned(16))) unsigned short BP[2][3][GH][WROW];      // h_prev pieces
-  __shared__ float xS[2][TL][8];                                                  // observations, by block parity
+  __shared__ __attribute__((aligned(16))) unsigned short AP[2][3][3 * GH * 16];  // d gh pieces, by half parity (wimg_at)
+  __shared__ __attribute__((aligned(16))) unsigned short BP[2][3][GH * 16];      // h_prev pieces
+  __shared__ float xS[2][TL][9];  // observations, by block parity (9: samples 4 rows apart on different banks)
   if (skip != nullptr && *skip != 0) return;
   const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
   const int n = lane & 31, hf = lane >> 5;
@@ -756,7 +812,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     const uint32_t blk = b0 + (h >> 1);
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
-    const uint32_t o = (uint32_t)(srow * TL + 16 * (h & 1) + scol);
+    const uint32_t o = rec_at(srow, 16 * (int)(h & 1) + scol);
     sl.g[0] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(0 * GH * TL) + o);
     sl.g[1] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(1 * GH * TL) + o);
     sl.g[2] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(3 * GH * TL) + o);  // hidden side of the n gate
@@ -767,14 +823,14 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     }
   };
   // four samples of one row -> their pieces, 8 bytes into each of the three piece images of a buffer
-  auto park = [&](unsigned short (*img)[WROW], int rows, int row, const f32x4 &v) {
+  auto park = [&](auto &img, int row, const f32x4 &v) {
     uint32_t p[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bt::split3(v[i], p[i][0], p[i][1], p[i][2]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const uint64_t w = (uint64_t)bt::pk(p[0][c], p[1][c]) | ((uint64_t)bt::pk(p[2][c], p[3][c]) << 32);
-      *reinterpret_cast<uint64_t *>(&img[c * rows + row][scol]) = w;
+      *reinterpret_cast<uint64_t *>(&img[c][wimg_at(row, scol)]) = w;
     }
   };
   // park half h (in `sl`) into LDS buffer h & 1, and add it to the sums of the rows this thread stages (the block's x
@@ -782,8 +838,8 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   auto stage = [&](uint32_t h, const Slot &sl) {
     const int buf = (int)(h & 1);
 #pragma unroll
-    for (int g3 = 0; g3 < 3; ++g3) park(AP[buf][0], 3 * GH, g3 * GH + srow, sl.g[g3]);
-    park(BP[buf][0], GH, srow, sl.hB);
+    for (int g3 = 0; g3 < 3; ++g3) park(AP[buf], g3 * GH + srow, sl.g[g3]);
+    park(BP[buf], srow, sl.hB);
     if ((h & 1) == 0 && q < TL * D) xS[((h >> 1) + 1) & 1][q % TL][q / TL] = sl.xn;  // x of the next block
     const int xb = (int)((h >> 1) & 1);
 #pragma unroll
@@ -801,7 +857,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   auto products = [&](int buf) {  // contraction over the 16 samples of the half in buffer `buf`, two tiles interleaved
     Frag fb[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&BP[buf][c][32 * nt + n][8 * hf]);
+    for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&BP[buf][c][wimg_at(32 * nt + n, 8 * hf)]);
 #pragma unroll
     for (int i = 0; i < 6; i += 2) {
       Frag fa[2][3];
@@ -809,7 +865,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[buf][c][192 * mset + 32 * (i + u) + n][8 * hf]);
+          fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[buf][c][wimg_at(192 * mset + 32 * (i + u) + n, 8 * hf)]);
 #pragma unroll
       for (int pa = 2; pa >= 0; --pa)
 #pragma unroll

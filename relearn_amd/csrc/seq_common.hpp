@@ -18,6 +18,13 @@ constexpr int TLS = TL + 16;  // LDS row stride of the [k][m] operand buffers re
 //   LSTM record: i, f, g, o, h_prev, relu(h'), u, c_prev, tanh(c')         backward: d pre_i, d pre_f, d pre_g, d pre_o, d u_pre, d relu(h')
 constexpr int SEQ_ARR = RL_SEQ_ACT_ARRAYS;
 constexpr int DPRE_ARR = RL_SEQ_DPRE_ARRAYS;
+// Inside one [GH][TL] record array the two M-tiles (samples 0-15, 16-31) are separate halves, [half][unit][16]: the four
+// samples of an M-tile a lane owns are 16 bytes, and the 16 units of a wave make 1 KB contiguous per store instruction —
+// full 128-byte lines.  ([unit][32] rows made every store 16 segments of 64 bytes, the other half of each line written
+// a phase later: the training forward then sat on its record stores at 3.3 TB/s — with the stores removed it ran in
+// 1.0 ms instead of 1.5.)
+constexpr int REC_HALF = GH * 16;  // floats per half of a record array
+__host__ __device__ constexpr uint32_t rec_at(int j, int m) { return (uint32_t)((m >> 4) * REC_HALF + j * 16 + (m & 15)); }
 enum { ACT_R = 0, ACT_Z = 1, ACT_N = 2, ACT_GHN = 3, ACT_HPREV = 4, ACT_A1 = 5, ACT_U = 6 };
 enum { LACT_I = 0, LACT_F = 1, LACT_G = 2, LACT_O = 3, LACT_CPREV = 7, LACT_TC = 8 };  // 4, 5, 6 as above
 enum { DPRE_DU = 4, DPRE_DA1 = 5 };
