@@ -225,17 +225,15 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       for (int p = 0; p < 3; ++p)
         a[p].x = *reinterpret_cast<const uint4 *>(&hP[p][img_at(16 * mt + n16, 32 * kb + 8 * g4)]);
     };
-    Frag fa[2][3];
-    frags(0, fa[0]);
 #pragma unroll
     for (int kb = 0; kb < GH / 32; ++kb) {
-      if (kb + 1 < GH / 32) frags(kb + 1, fa[(kb + 1) & 1]);
-      Frag wn[3];
+      Frag fa[3], wn[3];
+      frags(kb, fa);
 #pragma unroll
       for (int q = 0; q < 3; ++q) wn[q].x = wnS[kb][q][wave][lane];
 #pragma unroll
-      for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma_pieces(fa[kb & 1], wf[gte][kb], acc[gte][mt]);
-      acc[2][mt] = mfma_pieces(fa[kb & 1], wn, acc[2][mt]);
+      for (int gte = 0; gte < 2; ++gte) acc[gte][mt] = mfma_pieces(fa, wf[gte][kb], acc[gte][mt]);
+      acc[2][mt] = mfma_pieces(fa, wn, acc[2][mt]);
     }
   };
   auto gates = [&](int mt, uint32_t t) {
@@ -290,11 +288,14 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_N * GH * TL) + row) = nv;
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
   };
-  auto interleave = [&]() {  // the order asked of the scheduler for a phase: one matrix instruction, a few vector ones
+  // the order asked of the scheduler for a phase: one matrix instruction, a few vector ones (PHASE: the two phases share
+  // a basic block, and groups of one sync id are matched against the whole block)
+  auto interleave = [&](auto phase) {
+    constexpr int PHASE = decltype(phase)::value;
 #pragma unroll
     for (int k = 0; k < (GH / 32) * 3 * PIECE_PAIRS; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, PHASE);              // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, PHASE);  // VALU
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -304,19 +305,21 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     if (io_lane && t + 1 < T) fetch(t + 1);  // lands under the products
     __builtin_amdgcn_sched_barrier(0);
     start(1);
-    products(1);
     gates(0, t);
-    interleave();
+    products(1);
+    interleave(std::integral_constant<int, 0>{});
     __syncthreads();  // rows 0-15 of h(t+1) are complete; every wave has read rows 16-31 of h(t)
-    if (t + 1 < T) {
+    // (the branch, always taken, gives phase 2 a basic block of its own: with both phases in one block the scheduler
+    // honoured the requested order for one of them only)
+    int taken;
+    asm volatile("s_mov_b32 %0, 1" : "=s"(taken));
+    if (taken != 0) {
       start(0);
-      products(0);
+      products(0);  // (after the last step: products nobody reads — a branch on t here would split the phase's block)
       gates(1, t);
-      interleave();
-      if (io_lane) publish((int)((t + 1) & 1));
-    } else {
-      gates(1, t);
+      interleave(std::integral_constant<int, 1>{});
     }
+    if (io_lane && t + 1 < T) publish((int)((t + 1) & 1));
     __syncthreads();  // rows 16-31 of h(t+1) and the inputs of step t + 1 are complete; rows 0-15 have been read
   }
 }
@@ -778,7 +781,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
                      const int32_t *__restrict__ skip) {
   __shared__ __attribute__((aligned(16))) unsigned short AP[2][3][3 * GH * 16];  // d gh pieces, by half parity (wimg_at)
   __shared__ __attribute__((aligned(16))) unsigned short BP[2][3][GH * 16];      // h_prev pieces
-  __shared__ float xS[2][TL][9];  // observations, by block parity (9: samples 4 rows apart on different banks)
+  __shared__ float xS[2][TL][17];  // observations, by block parity: thread q holds column q / TL of sample q % TL (the
+                                   // columns >= D are padding: every thread writes, no branch; 17: samples 4 rows apart
+                                   // on different banks)
   if (skip != nullptr && *skip != 0) return;
   const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
   const int n = lane & 31, hf = lane >> 5;
@@ -808,7 +813,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   };
   Slot slot[2];
   slot[0].xn = slot[1].xn = 0.0f;
-  auto fetch = [&](uint32_t h, Slot &sl) {  // half h of the chunk: block b0 + h / 2, samples 16 (h & 1) .. + 15
+  // half h of the chunk: block b0 + h / 2, samples 16 (h & 1) .. + 15.  `steady`: the block after it exists as well (no
+  // branch then: a branch would end the basic block the products and the staging arithmetic are interleaved in)
+  auto fetch = [&](uint32_t h, Slot &sl, bool steady) {
     const uint32_t blk = b0 + (h >> 1);
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
@@ -817,9 +824,10 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     sl.g[1] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(1 * GH * TL) + o);
     sl.g[2] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(3 * GH * TL) + o);  // hidden side of the n gate
     sl.hB = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
-    if ((h & 1) == 0 && q < TL * D && blk + 1 < b1) {  // feature q / TL of sample q % TL of the NEXT block (its sums
-      const uint32_t t = (blk + 1) / tiles, lane0 = ((blk + 1) % tiles) * TL;  // run while its pieces are produced)
-      sl.xn = tr.obs[(size_t)(q / TL) * plane + (size_t)t * N + lane0 + (q % TL)];
+    if ((h & 1) == 0 && (steady || blk + 1 < b1)) {  // feature q / TL of sample q % TL of the NEXT block (its sums run
+      const uint32_t t = (blk + 1) / tiles, lane0 = ((blk + 1) % tiles) * TL;  // while its pieces are produced)
+      const int xf = q / TL < D ? q / TL : D - 1;  // (threads beyond the D features load a value nobody reads)
+      sl.xn = tr.obs[(size_t)xf * plane + (size_t)t * N + lane0 + (q % TL)];
     }
   };
   // four samples of one row -> their pieces, 8 bytes into each of the three piece images of a buffer
@@ -840,7 +848,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
     for (int g3 = 0; g3 < 3; ++g3) park(AP[buf], g3 * GH + srow, sl.g[g3]);
     park(BP[buf], srow, sl.hB);
-    if ((h & 1) == 0 && q < TL * D) xS[((h >> 1) + 1) & 1][q % TL][q / TL] = sl.xn;  // x of the next block
+    if ((h & 1) == 0) xS[((h >> 1) + 1) & 1][q % TL][q / TL] = sl.xn;  // x of the next block
     const int xb = (int)((h >> 1) & 1);
 #pragma unroll
     for (int g3 = 0; g3 < 3; ++g3)
@@ -878,34 +886,46 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   // one half: the pieces (and sums) of the NEXT half from slot `sl` into the other buffer, the fetch of the half after
   // that into the slot just freed, and the 54 products of this half — issued as one region, one matrix instruction then
   // a few vector instructions
-  auto half_step = [&](uint32_t h, Slot &sl, int buf) {
-    if (h + 1 < n_half) stage(h + 1, sl);
-    if (h + 3 < n_half) fetch(h + 3, sl);
-    products(buf);
-#pragma unroll
-    for (int k = 0; k < 6 * PIECE_PAIRS; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 36 / PIECE_PAIRS, 0);  // VALU
+  // The two waves of a SIMD (w and w + 4) take the two jobs of a half in opposite order, so that at any time one of them
+  // feeds the matrix pipe and the other the vector ALU.  (Asking the scheduler to interleave the two jobs inside each wave
+  // did not survive this loop's shape: the listing showed all matrix instructions in one run, and matrix pipe 0.55 +
+  // VALU 0.34 added up to the time.)
+  auto half_step = [&](uint32_t h, Slot &sl, int buf, bool steady) {
+    if (wave < W16 / 2) {
+      if (steady || h + 1 < n_half) stage(h + 1, sl);
+      if (steady || h + 3 < n_half) fetch(h + 3, sl, steady);
+      __builtin_amdgcn_sched_barrier(0);
+      products(buf);
+    } else {
+      products(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      if (steady || h + 1 < n_half) stage(h + 1, sl);
+      if (steady || h + 3 < n_half) fetch(h + 3, sl, steady);
     }
-    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // buffer `buf` is free for half h + 2, the other buffer holds half h + 1
   };
   // n_half is even (whole blocks)
   if (n_half > 0) {
-    if (q < TL * D) {  // x of the first block
+    {  // x of the first block
       const uint32_t t = b0 / tiles, lane0 = (b0 % tiles) * TL;
-      xS[0][q % TL][q / TL] = tr.obs[(size_t)(q / TL) * plane + (size_t)t * N + lane0 + (q % TL)];
+      const int xf = q / TL < D ? q / TL : D - 1;
+      xS[0][q % TL][q / TL] = tr.obs[(size_t)xf * plane + (size_t)t * N + lane0 + (q % TL)];
     }
-    fetch(0, slot[0]);
-    fetch(1, slot[1]);
+    fetch(0, slot[0], false);
+    fetch(1, slot[1], false);
     __syncthreads();
     stage(0, slot[0]);
-    if (n_half > 2) fetch(2, slot[0]);
+    if (n_half > 2) fetch(2, slot[0], false);
   }
   __syncthreads();
-  for (uint32_t h = 0; h < n_half; h += 2) {
-    half_step(h, slot[1], 0);
-    half_step(h + 1, slot[0], 1);
+  uint32_t h = 0;
+  for (; h + 6 < n_half; h += 2) {  // steady state: every half up to h + 4, and the block after it, exist
+    half_step(h, slot[1], 0, true);
+    half_step(h + 1, slot[0], 1, true);
+  }
+  for (; h < n_half; h += 2) {
+    half_step(h, slot[1], 0, false);
+    half_step(h + 1, slot[0], 1, false);
   }
   // ---- this workgroup's row of partials (recurrent columns)
   float *__restrict__ out = slab + (size_t)blockIdx.x * P;
