@@ -55,7 +55,7 @@ out = {"lanes": N, "horizon": T, "env_steps_per_period": steps, **acc, "period_m
        "flop_per_pass": {"forward": fwd_flop, "bptt": bwd_flop, "wgrad": wg_flop}}
 # per gradient evaluation (90 per period: 10 PPO + 80 critic): the three passes' device time by kernel class, their
 # f32-equivalent rate against the f32 matrix peak (157.3 TFLOP/s) and the rate the bf16 pipe actually executes
-# (every f32 product = 9 bf16 products of exact pieces) against its dense peak (2,500 TFLOP/s)
+# (every f32 product = 6 bf16 products of pieces: PIECE_PAIRS in kernels_seq_train.hip) against its dense peak (2,500 TFLOP/s)
 k = out["kernel_ms_per_period"]
 n_grad = 10 + critic_steps
 dw1_flop = 2.0 * 128 * 128 * steps  # the head's weight gradient is accumulated by the head's backward kernel
@@ -67,6 +67,6 @@ for name, (cls, flop) in passes.items():
         ms = k[cls] / n_grad
         out["gradient_passes"][name] = {
             "ms": ms, "f32_equivalent_tflops": flop / ms / 1e9, "frac_of_f32_mfma_peak": flop / ms / 1e9 / 157.3,
-            "executed_bf16_tflops": 9 * flop / ms / 1e9, "frac_of_bf16_mfma_peak": 9 * flop / ms / 1e9 / 2500.0}
+            "executed_bf16_tflops": 6 * flop / ms / 1e9, "frac_of_bf16_mfma_peak": 6 * flop / ms / 1e9 / 2500.0}
 out["ms_per_gradient"] = sum(v["ms"] for v in out["gradient_passes"].values()) + (k.get("reduce", 0) + k.get("small", 0)) / n_grad
 print(json.dumps(out))
