@@ -44,15 +44,52 @@ def img_rot(m):  # rotation of row m of a [sample][128 units] image, in 16-byte 
     return 4 * (m & 3) + 2 * ((m >> 2) & 1)
 
 
+def patterns():
+    """(name, kind, cycles, conflict-free cycles) of every LDS access pattern of kernels_seq_train.hip's piece images"""
+    out = []
+
+    def img(m, k):  # img_at: byte address of (sample m, unit k) in a [TL][GH] image
+        return 2 * (m * 128 + ((k + 8 * img_rot(m)) & 127))
+
+    def timg(r, c):  # timg_at: byte address of chunk c of row r of a [unit][TL] image
+        return 2 * (r * 32 + 8 * (c ^ ((r >> 1) & 3)))
+
+    def wimg(row, hw):  # wimg_at
+        return 2 * (row * 16 + (hw ^ (((row >> 3) & 1) << 3)))
+
+    for mt in range(2):
+        for kb in range(4):
+            out.append((f"[sample][unit] operand read, M-tile {mt}, k-block {kb}", "read_b128",
+                        cycles("read_b128", lambda l: img(16 * mt + (l & 15), 32 * kb + 8 * (l >> 4))), 4))
+        for i in range(4):
+            for w in (0, 5):
+                out.append((f"[sample][unit] piece write, M-tile {mt}, sample slot {i}, wave {w}", "write_b16",
+                            cycles("write_b16", lambda l: img(16 * mt + 4 * (l >> 4) + i, 16 * w + (l & 15))), 2))
+    for nt in range(8):
+        out.append((f"[unit][sample] operand read, unit tile {nt}", "read_b128",
+                    cycles("read_b128", lambda l: timg(16 * nt + (l & 15), l >> 4)), 4))
+    # backward recurrence: padded rows of 3 GH + 16 halfwords
+    for kb in (0, 5, 11):
+        out.append((f"backward [sample][3 GH + 16] operand read, k-block {kb}", "read_b128",
+                    cycles("read_b128", lambda l: 2 * ((l & 15) * 400 + 32 * kb + 8 * (l >> 4))), 4))
+    # weight gradients: lane = row (32), upper half-wave = upper chunk; staging: four lanes per row, 8 bytes each
+    out.append(("weight-gradient [row][16] operand read", "read_b128",
+                cycles("read_b128", lambda l: wimg(l & 31, 8 * (l >> 5))), 4))
+    out.append(("weight-gradient [row][16] staging write", "write_b64",
+                cycles("write_b64", lambda l: wimg(l >> 2, 4 * (l & 3))), 4))
+    return out
+
+
 def report():
-    GH = 128
-    for name, row_bytes, rot in (("padded 272-byte rows (round 2 until now)", 272, lambda m: 0),
-                                 ("256-byte rows, chunk rotation", 256, img_rot)):
+    for name, row_bytes, rot in (("padded 272-byte rows (before)", 272, lambda m: 0),
+                                 ("256-byte rows, chunk rotation (img_at)", 256, img_rot)):
         def elem(m, k):  # byte address of (sample m, unit k)
             return m * row_bytes + (2 * k + 16 * rot(m)) % 256
         rd = cycles("read_b128", lambda l: elem(l & 15, 32 * 1 + 8 * (l >> 4)))
         wr = cycles("write_b16", lambda l: elem(4 * (l >> 4) + 1, 16 * 3 + (l & 15)))
-        print(f"[sample][unit] image, {name}: A-fragment read {rd} cycles (4 = free), piece write {wr} (2 = free)")
+        print(f"[sample][unit] image, {name}: operand read {rd} cycles (4 = free), piece write {wr} (2 = free)")
+    for name, kind, got, free in patterns():
+        print(f"{name}: {kind} {got} cycles ({free} = free)")
 
 
 if __name__ == "__main__":
