@@ -190,7 +190,12 @@ __device__ __forceinline__ void mlp_forward_lane(const float *__restrict__ param
 
 // The same forward with the parameters parked in LDS as one 8-float record per hidden unit {W1[j][0..D), pad, b1[j],
 // W2[0][j], W2[1][j]} (two 16-byte broadcast reads per unit instead of a stream of scalar loads); `pk` also holds b2
-// behind the H records.
+// behind the H records.  Four floats of padding follow every eight records: the G threads of a row read records
+// 16 / G units apart at once, and 8 units = 256 bytes is the width of the LDS — without the padding threads g and
+// g + G / 2 (G = 2: the two threads of every row) hit the same banks with different addresses on every read (the 64k-lane
+// rollout measured SQ_LDS_BANK_CONFLICT at 0.49 of its LDS cycles, LDS busy 0.67 of the time).
+constexpr int MLP_PK_FLOATS = 8 * 128 + 4 * 16 + 4;  // records + padding of 128 hidden units, b2
+__host__ __device__ constexpr int mlp_pk_at(int j) { return 8 * j + 4 * (j >> 3); }  // first float of unit j's record
 template <int D>
 __device__ __forceinline__ void mlp_pack_lds(float *__restrict__ pk, const float *__restrict__ params, int H, int tid,
                                              int nthreads) {
@@ -201,15 +206,15 @@ __device__ __forceinline__ void mlp_pack_lds(float *__restrict__ pk, const float
   for (int q = tid; q < 8 * H + 2; q += nthreads) {
     float v = 0.0f;
     if (q >= 8 * H) {
-      v = b2[q - 8 * H];
-    } else {
-      const int j = q >> 3, k = q & 7;
-      if (k < D) v = W1[j * D + k];
-      else if (k == 5) v = b1[j];
-      else if (k == 6) v = W2[j];
-      else if (k == 7) v = W2[H + j];
+      pk[mlp_pk_at(H) + (q - 8 * H)] = b2[q - 8 * H];
+      continue;
     }
-    pk[q] = v;
+    const int j = q >> 3, k = q & 7;
+    if (k < D) v = W1[j * D + k];
+    else if (k == 5) v = b1[j];
+    else if (k == 6) v = W2[j];
+    else if (k == 7) v = W2[H + j];
+    pk[mlp_pk_at(j) + k] = v;
   }
 }
 
@@ -222,8 +227,8 @@ __device__ __forceinline__ void mlp_units_lds(const float *__restrict__ pk, int 
   float4 lo[NB], hi[NB];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
-    lo[u] = *reinterpret_cast<const float4 *>(pk + 8 * (j0 + u));
-    hi[u] = *reinterpret_cast<const float4 *>(pk + 8 * (j0 + u) + 4);
+    lo[u] = *reinterpret_cast<const float4 *>(pk + mlp_pk_at(j0 + u));
+    hi[u] = *reinterpret_cast<const float4 *>(pk + mlp_pk_at(j0 + u) + 4);
   }
   float acc[NB];
 #pragma unroll
@@ -275,7 +280,7 @@ __device__ __forceinline__ void mlp_forward_group_lds(const float *__restrict__ 
     float s = c[a][0];
 #pragma unroll
     for (int m = 1; m < G; m *= 2) s = s + __shfl_xor(s, m, 64);  // a + b == b + a bit for bit: both partners agree
-    z[a] = s + pk[8 * H + a];
+    z[a] = s + pk[mlp_pk_at(H) + a];
   }
 }
 

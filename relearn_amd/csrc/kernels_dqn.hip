@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
                                                                 uint64_t p_int, int always_explore,
                                                                 uint8_t *__restrict__ flags_out) {
   __shared__ uint32_t words[16 * BLOCK];
-  __shared__ __attribute__((aligned(16))) float pk[8 * 128 + 4];  // the Q-network, one 8-float record per hidden unit
+  __shared__ __attribute__((aligned(16))) float pk[MLP_PK_FLOATS];  // the Q-network, one 8-float record per hidden unit
   const uint32_t n = rp.N;
   mlp_pack_lds<D>(pk, qnet, H, threadIdx.x, BLOCK);
   __syncthreads();

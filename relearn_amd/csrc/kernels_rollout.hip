@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
                                                             const float *__restrict__ policy, int H,
                                                             uint64_t t_global) {
   __shared__ uint32_t actor_words[16 * BLOCK];
-  __shared__ __attribute__((aligned(16))) float pk[8 * 128 + 4];  // the policy, one 8-float record per hidden unit
+  __shared__ __attribute__((aligned(16))) float pk[MLP_PK_FLOATS];  // the policy, one 8-float record per hidden unit
   const uint32_t n = tr.n, T = tr.T;
   mlp_pack_lds<D>(pk, policy, H, threadIdx.x, BLOCK);
   __syncthreads();
