@@ -213,10 +213,11 @@ __global__ void __launch_bounds__(256) k_chain_step(CartPoleDev c, EnvStateDev s
 }
 
 // LDS of the forward kernels
+constexpr int LSTM_KS_LDS = 15;  // k-steps (of GH / 4 = 32) of the LSTM's o gate whose W_hh operands wait in LDS
 template <bool WITH_W1>
 struct SeqFwdSharedT {
   float hT[2][GH][TLS];     // recurrent state, [k][m], double-buffered
-  float uS[TL][MH + 1];     // MLP hidden activations, [m][j]
+  float uS[WITH_W1 ? 1 : TL][MH + 1];  // MLP hidden activations, [m][j] (LSTM: in the state buffer the step has finished reading)
   float xS[TL][8];          // observation features of the current step
   float w2S[2][MH];
   float outS[2][TL];
@@ -226,6 +227,10 @@ struct SeqFwdSharedT {
   // LSTM only: the MLP's first layer as MFMA B operands, [wave][k-step][lane] (its four gate matrices fill the
   // register budget the GRU spends on three gates + this layer)
   float w1S[WITH_W1 ? 8 : 1][WITH_W1 ? GH / 4 : 1][WITH_W1 ? 64 : 1];
+  // LSTM only: what else the register file does not hold next to four gates' W_hh operands — the first LSTM_KS_LDS
+  // k-steps of the o gate's operands, [wave][k-step][lane], and the input projection with both biases, [gate][row][unit]
+  float whS[WITH_W1 ? 8 : 1][WITH_W1 ? LSTM_KS_LDS : 1][WITH_W1 ? 64 : 1];
+  float wiS[WITH_W1 ? 4 : 1][WITH_W1 ? 7 : 1][WITH_W1 ? GH : 1];  // rows 0..D-1: W_ih[.][d]; row 5: b_ih; row 6: b_hh
 };
 using SeqFwdShared = SeqFwdSharedT<false>;
 using LstmFwdShared = SeqFwdSharedT<true>;
@@ -381,9 +386,9 @@ __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights
 // with every pre-activation = (b_hh + W_hh h) + (b_ih + W_ih x), the same fma chains as the GRU's r and z gates.
 template <int D>
 struct LstmFwdWeights16 {
-  float whh[4][GH / 4];
-  float wih[4][D];
-  float bih[4], bhh[4], b1;
+  float whh[3][GH / 4];                 // gates i, f, g
+  float whh_o[GH / 4 - LSTM_KS_LDS];    // gate o, k-steps LSTM_KS_LDS .. (the first ones: LstmFwdShared::whS)
+  float b1;
 };
 
 template <int D>
@@ -394,11 +399,18 @@ __device__ __forceinline__ void lstm_load_weights16(LstmFwdWeights16<D> &w, cons
   for (int gte = 0; gte < 4; ++gte) {
     const int row = gte * GH + j;
 #pragma unroll
-    for (int ks = 0; ks < GH / 4; ++ks) w.whh[gte][ks] = g.Whh[(size_t)row * GH + 4 * ks + g4];
+    for (int ks = 0; ks < GH / 4; ++ks) {
+      const float v = g.Whh[(size_t)row * GH + 4 * ks + g4];
+      if (gte < 3) w.whh[gte < 3 ? gte : 0][ks] = v;
+      else if (ks >= LSTM_KS_LDS) w.whh_o[ks >= LSTM_KS_LDS ? ks - LSTM_KS_LDS : 0] = v;
+      else sh.whS[wave][ks < LSTM_KS_LDS ? ks : 0][lane] = v;
+    }
+    if (g4 == 0) {  // one lane group per unit fills the shared input projection
 #pragma unroll
-    for (int d = 0; d < D; ++d) w.wih[gte][d] = g.Wih[(size_t)row * D + d];
-    w.bih[gte] = g.bih[row];
-    w.bhh[gte] = g.bhh[row];
+      for (int d = 0; d < D; ++d) sh.wiS[gte][d][j] = g.Wih[(size_t)row * D + d];
+      sh.wiS[gte][5][j] = g.bih[row];
+      sh.wiS[gte][6][j] = g.bhh[row];
+    }
   }
   for (int ks = 0; ks < GH / 4; ++ks) sh.w1S[wave][ks][lane] = g.W1[(size_t)j * GH + 4 * ks + g4];
   w.b1 = g.b1[j];
@@ -413,15 +425,21 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
 #pragma unroll
   for (int gte = 0; gte < 4; ++gte)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc[gte][mt] = (f32x4){w.bhh[gte], w.bhh[gte], w.bhh[gte], w.bhh[gte]};
+    for (int mt = 0; mt < 2; ++mt) {
+      const float b = sh.wiS[gte][6][j];
+      acc[gte][mt] = (f32x4){b, b, b, b};
+    }
 #pragma unroll
   for (int ks = 0; ks < GH / 4; ++ks) {
+    const float wo = ks < LSTM_KS_LDS ? sh.whS[wave][ks < LSTM_KS_LDS ? ks : 0][lane]
+                                      : w.whh_o[ks >= LSTM_KS_LDS ? ks - LSTM_KS_LDS : 0];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const float a = sh.hT[cur][4 * ks + g4][16 * mt + n16];
 #pragma unroll
-      for (int gte = 0; gte < 4; ++gte)
+      for (int gte = 0; gte < 3; ++gte)
         acc[gte][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w.whh[gte][ks], acc[gte][mt], 0, 0, 0);
+      acc[3][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wo, acc[3][mt], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -433,9 +451,9 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
       float pre[4];
 #pragma unroll
       for (int gte = 0; gte < 4; ++gte) {
-        float v = w.bih[gte];
+        float v = sh.wiS[gte][5][j];
 #pragma unroll
-        for (int d = 0; d < D; ++d) v = __builtin_fmaf(sh.xS[m][d], w.wih[gte][d], v);
+        for (int d = 0; d < D; ++d) v = __builtin_fmaf(sh.xS[m][d], sh.wiS[gte][d][j], v);
         pre[gte] = acc[gte][mt][i] + v;
       }
       const float ig = rl_sigmoidf(pre[0]), fg = rl_sigmoidf(pre[1]), gg = rl_tanhf(pre[2]), og = rl_sigmoidf(pre[3]);
@@ -470,6 +488,10 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
     }
   }
   __syncthreads();
+  // every wave has read h(t) by now: its buffer holds the MLP's hidden activations [m][j] until the next step's gates
+  // write h(t+2) there (after the workgroup barrier that ends this step)
+  float *__restrict__ uS = &sh.hT[cur][0][0];
+  static_assert(TL * (MH + 1) <= GH * TLS, "the head's activations fit the state buffer");
   f32x4 acc1[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) acc1[mt] = (f32x4){w.b1, w.b1, w.b1, w.b1};
@@ -490,7 +512,7 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
     for (int i = 0; i < 4; ++i) {
       const int m = acc16_row(mt, i, g4);
       const float u = acc1[mt][i] > 0.0f ? acc1[mt][i] : 0.0f;
-      sh.uS[m][j] = u;
+      uS[m * (MH + 1) + j] = u;
       uv[i] = u;
     }
     if (store != nullptr)
@@ -501,7 +523,7 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
     const int n = lane & 31, hf = lane >> 5;
     float z = b2_mine;
 #pragma unroll 8
-    for (int q = 0; q < MH; ++q) z = __builtin_fmaf(sh.uS[n][q], sh.w2S[hf][q], z);
+    for (int q = 0; q < MH; ++q) z = __builtin_fmaf(uS[n * (MH + 1) + q], sh.w2S[hf][q], z);
     sh.outS[hf][n] = z;
   }
   // the head's outputs are read by lanes of wave 0 only (the env / io lanes): a caller that syncs the workgroup later
