@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const size_t plane = (size_t)(T + 1) * N;
   const uint32_t b0 = blockIdx.x * blocks_per_chunk;
   const uint32_t b1 = b0 + blocks_per_chunk < blocks ? b0 + blocks_per_chunk : blocks;
-  const uint32_t n_half = 2 * (b1 - b0);
+  const uint32_t n_half = b1 > b0 ? 2 * (b1 - b0) : 0;  // (a chunk past the end writes a row of zeros)
   // register stages of the global loads: half h lands in slot h & 1, two halves before its pieces are produced
   struct Slot {
     f32x4 g[3], hB;
