@@ -7,8 +7,8 @@
 // of three bf16 pieces (bf16_tile.hpp) and a product of two bf16 numbers is exact in the f32 accumulator, so
 //   h W^T = sum over the piece pairs (h_p, W_q)
 // — the six pairs that matter at f32 accuracy, PIECE_ORDER below — costs 6 bf16 issues of 16 cycles where the f32 form
-// costs 8 issues of 32 cycles for the same 32 values of k, and leaves the VALU to the gate arithmetic.  The accumulation order differs from the rollout's sequential fma chain
-// (which stays on the f32 kernels of kernels_seq.hip: rollouts, values and GAE are bit-exact with the oracle); the
+// costs 8 issues of 32 cycles for the same 32 values of k, and leaves the VALU to the gate arithmetic.  The accumulation
+// order differs from the rollout's sequential fma chain (which stays on the f32 kernels of kernels_seq.hip: rollouts, values and GAE are bit-exact with the oracle); the
 // training passes are compared with the f64 oracle within f32 tolerances (tests/test_gpu_gru.py), like every
 // gradient in this library.
 //
@@ -22,8 +22,8 @@
 //                        input-side sums
 //   k_gru_wgrad_bf16     dW_hh with the sample as contraction index; db_hh and the r / z input-side sums
 // Ownership is the rollout cell's: eight waves per tile of 32 lanes, wave w owns units [16w, 16w+16); accumulator
-// register i of lane l is (sample 16 mt + 4 (l >> 4) + i, unit 16 w + (l & 15)) for both MFMA shapes, so the records
-// keep their layout ([unit][lane] rows, seq_common.hpp).
+// register i of lane l is (sample 16 mt + 4 (l >> 4) + i, unit 16 w + (l & 15)) for both MFMA shapes: a lane's four
+// samples of an M-tile are 16 contiguous bytes of a record array ([half][unit][16], rec_at in seq_common.hpp).
 // Register budget per wave: a gate's W_hh fragments are 4 k-blocks x 3 pieces x 4 = 48 registers; two gates (forward)
 // or nine of the twelve k-blocks (backward) stay in registers, the rest waits in LDS — the 256-register budget of two
 // waves per SIMD does not hold 144 fragment registers next to the accumulators, the prefetched record of the next

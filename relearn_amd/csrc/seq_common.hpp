@@ -12,7 +12,7 @@ constexpr int MH = 128;      // MLP hidden width (MlpConfig::default)
 constexpr int TL = 32;       // lanes per tile
 constexpr int TLS = TL + 16;  // LDS row stride of the [k][m] operand buffers read as 16x16x4 A operands: the four
                               // k-rows of an instruction start 48 floats apart = banks 0 / 48 / 32 / 16: no conflict
-// Per (step, tile) block the training forward records SEQ_ARR [unit][lane] arrays and the backward DPRE_ARR (the strides
+// Per (step, tile) block the training forward records SEQ_ARR arrays of GH x TL floats and the backward DPRE_ARR (the strides
 // are those of the LSTM, the larger of the two cells; kernels.hpp: RL_SEQ_ACT_ARRAYS / RL_SEQ_DPRE_ARRAYS).
 //   GRU  record: r, z, n, gh_n, h_prev, relu(h'), u                        backward: d pre_r, d pre_z, d pre_n, d pre_n * r, d u_pre
 //   LSTM record: i, f, g, o, h_prev, relu(h'), u, c_prev, tanh(c')         backward: d pre_i, d pre_f, d pre_g, d pre_o, d u_pre, d relu(h')
