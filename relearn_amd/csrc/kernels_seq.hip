@@ -271,7 +271,7 @@ __device__ __forceinline__ void seq_load_weights16(SeqFwdWeights16<D> &w, const 
 
 // One cell + head evaluation for the tile.  Reads the state from sh.hT[cur] and `hown`, writes the new state to
 // sh.hT[cur ^ 1] and `hnew`; the head outputs land in sh.outS (valid after the function returns: it ends with a
-// barrier).  `store` != nullptr: record the 7 activation arrays of this (t, tile) block ([unit][lane] rows: a lane's
+// barrier).  `store` != nullptr: record the 7 activation arrays of this (t, tile) block ([half][unit][16] arrays, rec_at: a lane's
 // four samples of an M-tile are contiguous, one 16-byte store per array and M-tile).
 template <int D, int A, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void seq_cell16(SeqFwdShared &sh, const SeqFwdWeights16<D> &w, int cur,

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_seq_critic_dvalues(TrajDev tr, const fl
 // multiplied pass through LDS ([128][33] per vector: d u_pre, then the three gate vectors side by side, so a step
 // needs two workgroup barriers).  The sums over k run as independent MFMA chains (two half-chains per M-tile for
 // W1^T, one chain per gate and M-tile for W_hh^T), added at the end: the matrix pipe stays busy instead of waiting
-// for one accumulator.  A lane's four samples of an M-tile are contiguous in the record ([unit][lane] rows), so every
+// for one accumulator.  A lane's four samples of an M-tile are contiguous in the record ([half][unit][16] arrays, rec_at), so every
 // record access is one 16-byte load / store; the record of step t-1 is requested as soon as step t has consumed its
 // own, and lands under the gate products.  Writes the five per-step arrays the weight-gradient GEMMs read.
 // (Gradients are compared with the oracle within fp32 tolerances, tests/test_gpu_gru.py: the order of these sums is
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_lstm_bptt(TrajDev tr, const flo
 // ---------------------------------------------------------------- weight-gradient GEMMs
 // dW_hh = sum dgh (x) h_prev [384 x 128], dW1 = sum du (x) relu(h') [128 x 128] on the matrix cores with the
 // sample index as the MFMA k dimension (k-pair (ks, hf) <-> sample m = 16 hf + ks, so every operand is 16
-// consecutive floats of a [unit][32] row); dW_ih, the biases and dW2 on the VALU.  A workgroup accumulates a
+// consecutive floats of a [unit][16] row of a record half); dW_ih, the biases and dW2 on the VALU.  A workgroup accumulates a
 // contiguous run of (t, tile) blocks in f32 and writes one row of partials; k_seq_reduce sums the rows in f64.
 // The four A-operand arrays of a block (d gh_r, d gh_z, d gh_n, d u_pre: every wave needs all 512 rows) are fetched
 // ONCE per workgroup with fully coalesced 16-byte loads into registers while the previous block's products run, then

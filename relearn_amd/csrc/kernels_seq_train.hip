@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 
 // ---------------------------------------------------------------- weight gradients of the recurrence
 // dW_hh[g][k] = sum over (step, lane) of d gh_g . h_prev_k   (g over the 384 gate units: d pre_r, d pre_z, d pre_n r)
-// with the SAMPLE as the contraction index: the records are [unit][lane] rows, so eight consecutive samples of a row
+// with the SAMPLE as the contraction index: the records are [half][unit][16] arrays, so eight consecutive samples of a row
 // are one operand fragment — no transposition.  A workgroup walks a contiguous run of (step, tile) blocks in HALF
 // blocks of 16 samples.  Every element is split into its three bf16 pieces ONCE (each thread stages 1/512 of a half)
 // and parked in LDS in operand layout, in one of two buffers: the pieces of half h + 1 are produced (VALU) between the
