@@ -762,10 +762,10 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // with the SAMPLE as the contraction index: the records are [half][unit][16] arrays, so eight consecutive samples of a row
 // are one operand fragment — no transposition.  A workgroup walks a contiguous run of (step, tile) blocks in HALF
 // blocks of 16 samples.  Every element is split into its three bf16 pieces ONCE (each thread stages 1/512 of a half)
-// and parked in LDS in operand layout, in one of two buffers: the pieces of half h + 1 are produced (VALU) between the
-// matrix instructions of half h (the schedule is asked for explicitly: with one buffer per block, or with the two
-// phases merely adjacent in program order, they took turns — matrix pipe 0.55 busy, VALU 0.34).  Wave w accumulates
-// output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles, PIECE_PAIRS issues of
+// and parked in LDS in operand layout, in one of two buffers: the pieces of half h + 1 are produced (VALU) while the
+// matrix pipe works on half h — the two waves of a SIMD take the two jobs in opposite order (half_step below; with one
+// buffer per block, or both waves in the same order, the jobs took turns: matrix pipe 0.55 busy, VALU 0.34).  Wave w
+// accumulates output rows [192 (w >> 2), + 192) x columns [32 (w & 3), + 32): six 32x32 tiles, PIECE_PAIRS issues of
 // v_mfma_f32_32x32x16_bf16 per tile and half, two tiles interleaved.  db_hh, and dW_ih / db_ih of the r and z gates
 // (their input side equals their hidden side), are sums the staging threads keep for the rows they stage (thread q
 // stages row q >> 2 of every gate in every half); the n gate's input side comes from the backward recurrence.  One row
