@@ -324,12 +324,14 @@ static void launch_rollout_g(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
 
 void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
-  // threads per lane: up to two waves per SIMD (the launch is bound by the latency of a step, not by throughput).
-  // Measured, 128 steps, ms: 65,536 lanes 0.77 / 0.70 / 0.78 for G = 1 / 2 / 4; 16,384 lanes 0.42 / 0.41 / 0.51 for
-  // G = 4 / 8 / 16; 4,096 lanes 0.41 / 0.35 / 0.29 for G = 4 / 8 / 16 (profiles/r02_rollout_group_sweep.txt)
+  // threads per lane: up to two waves per SIMD for groups of at most four threads, one wave per SIMD for wider groups
+  // (the launch is bound by the latency of a step; the wider the group, the more of a step every thread repeats).
+  // Measured, 128 steps, ms for G = 1 / 2 / 4 / 8 / 16 (profiles/r02_rollout_group_sweep.txt): 65,536 lanes 0.78 /
+  // 0.71 / 0.84 / 1.25 / 2.21; 32,768: 0.82 / 0.56 / 0.54 / 0.69 / 1.06; 16,384: 0.76 / 0.57 / 0.43 / 0.44 / 0.60;
+  // 8,192: 0.75 / 0.53 / 0.44 / 0.35 / 0.38; 4,096: 0.75 / 0.53 / 0.41 / 0.36 / 0.30
   const uint64_t simds = 4ull * (uint64_t)env->eng->prop.multiProcessorCount, n = env->cfg.n_lanes;
   int G = 1;
-  while (G < 16 && n * (uint64_t)(2 * G) <= 2 * simds * 64) G *= 2;
+  while (G < 16 && n * (uint64_t)(2 * G) <= (2 * G >= 8 ? 1 : 2) * simds * 64) G *= 2;
   if (const char *o = std::getenv("RELEARN_ROLLOUT_G")) G = std::atoi(o);  // measurement override
 #define ROLL(DD)                                                   \
   switch (G) {                                                     \
