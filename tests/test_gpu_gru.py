@@ -170,6 +170,24 @@ def test_critic_gradient_through_time(engine):
     assert abs(loss_d - (d * d).mean()) <= 1e-5 * (d * d).mean()
 
 
+@pytest.mark.parametrize("n,T,max_steps", [(32, 1, 9), (32, 2, 1), (96, 7, 3), (160, 3, 2), (2048, 20, 4), (2048, 50, 7)],
+                         ids=["one-tile-one-step", "every-step-ends", "three-tiles", "five-tiles", "two-blocks-per-chunk",
+                              "steady-state-chunks"])
+def test_gradients_through_time_at_edge_shapes(engine, n, T, max_steps):
+    """shapes at the edges of the training kernels' loops: a single (step, tile) block, episodes that end at every
+    step, tile counts that are not a power of two, and enough blocks (1,280 and 3,200) for the weight-gradient
+    kernel's chunks to hold two blocks and to reach the branch-free steady state of its loop"""
+    pol, cri, traj, want, _, _ = setup_update(engine, n=n, T=T, max_steps=max_steps)
+    g_pol = ra.policy_gradient(pol, traj)[0]
+    assert rel_err(g_pol, policy_grad_f64(pol.get_params(), want)) < GRAD_RTOL
+    p = cri.get_params()
+    g_cri, loss_d = ra.critic_gradient(cri, traj)
+    v, _ = O.gru_seq_forward(CS, p, want, f64=True, want_succ=False)
+    d = v - want["rtg"].astype(np.float64)[None]
+    assert rel_err(g_cri, O.gru_seq_backward(CS, p, want, 2.0 * d / v[0].size, f64=True)) < GRAD_RTOL
+    assert abs(loss_d - (d * d).mean()) <= 1e-5 * max((d * d).mean(), 1e-12)
+
+
 def test_bf16_pipe_training_passes_agree_with_the_f32_kernels(engine):
     """the two builds of the GRU chain's training passes — recurrence on the bf16 matrix pipe with exact three-piece
     products (kernels_seq_train.hip, the default) and round 1's f32 kernels (engine kernel variant 1) — give the same
