@@ -148,6 +148,19 @@ def test_critic_gradient_through_time(engine):
     assert abs(loss_d - (d * d).mean()) <= 1e-5 * (d * d).mean()
 
 
+@pytest.mark.parametrize("n,T,max_steps", [(32, 1, 9), (32, 2, 1), (96, 7, 3), (2048, 12, 4)],
+                         ids=["one-tile-one-step", "every-step-ends", "three-tiles", "two-blocks-per-chunk"])
+def test_critic_gradient_at_edge_shapes(engine, n, T, max_steps):
+    """the LSTM chain's forward record, BPTT and weight-gradient kernels at the edges of their loops"""
+    pol, cri, traj, want, _, _ = setup_update(engine, n=n, T=T, max_steps=max_steps)
+    p = cri.get_params()
+    g_d, loss_d = ra.critic_gradient(cri, traj)
+    v, _ = O.gru_seq_forward(CS, p, want, f64=True, want_succ=False)
+    d = v - want["rtg"].astype(np.float64)[None]
+    assert rel_err(g_d, O.gru_seq_backward(CS, p, want, 2.0 * d / v[0].size, f64=True)) < GRAD_RTOL
+    assert abs(loss_d - (d * d).mean()) <= 1e-5 * max((d * d).mean(), 1e-12)
+
+
 def test_ppo_and_critic_updates(engine):
     pol, cri, traj, want, acfg, ocfg = setup_update(engine)
     p0 = pol.get_params().copy()
