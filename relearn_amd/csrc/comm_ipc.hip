@@ -2,13 +2,14 @@
 // line-search scalars) over peer-mapped mailboxes: every rank owns a mailbox in its own HBM, maps the mailboxes of its
 // peers (hipIpcOpenMemHandle: the ranks are processes of one node; over xGMI the mapping is a peer-to-peer window), and
 // an all-reduce is ONE kernel per rank —
-//   publish   my 64-column chunk of the vector goes into slot `seq & 1` of MY row in EVERY rank's mailbox (plain stores
-//             into the peer windows), then one release store of the sequence number per (peer, chunk);
-//   wait      until the sequence number has arrived from every rank for my chunk (bounded spin, acquire loads);
-//   sum       the n_ranks rows of my own mailbox in RANK ORDER — every rank adds the same numbers in the same order, so
-//             the replicas stay bit-identical without a broadcast.
-// Two slots are enough: a rank cannot start collective k + 2 (which reuses the slot of k) before it has seen every
-// peer's flag of k + 1, and a peer raises that flag only after it has finished reading k.
+//   publish   my 64-column chunk of the vector goes into slot `seq & 1` of MY row in EVERY rank's mailbox, every element
+//             as one 64-bit word {sequence number, float bits} (relaxed system-scope atomic stores into the peer windows);
+//   gather    every lane polls ITS column in the n_ranks rows of its own mailbox until the word carries this collective's
+//             sequence number (bounded spin), and adds the values in RANK ORDER — every rank adds the same numbers in the
+//             same order, so the replicas stay bit-identical without a broadcast.
+// No flag and no fence: a word is complete or absent.  Two slots are enough: a rank cannot start collective k + 2 (which
+// reuses the slot of k) before it has read every peer's words of k + 1, and a peer writes those only after it has
+// finished reading k.
 // This replaces the `Vec<buffer>` hand-off of the reference's threads (src/simulation/train.rs:180) for the multi-GPU
 // configuration; RCCL (abi.hip) stays the default transport — its small-message latency is what this path avoids.
 // Every spin is bounded: a peer that never arrives sets the engine's error word and the wave leaves the loop.
@@ -65,7 +66,7 @@ int32_t rl_comm_ipc_handle(rl_engine *e, int32_t n_ranks, uint8_t handle_out[64]
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     RL_HIP_CHECK(hipSetDevice(e->device));
     if (e->ipc_box == nullptr) {
-      const size_t bytes = ipc_box_words((uint32_t)n_ranks) * sizeof(float);
+      const size_t bytes = ipc_box_bytes((uint32_t)n_ranks);
       void *p = nullptr;
       // fine-grained: peers' stores and this device's loads of the mailbox are coherent without cache maintenance
       RL_HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
