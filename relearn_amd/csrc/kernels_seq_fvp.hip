@@ -188,13 +188,16 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const f
                                                              const int32_t *__restrict__ skip) {
   __shared__ float xS[TL][8];
   __shared__ float v2S[2][MH];
+  // the MLP layer's tangent operands, [k-step][thread] (read back by the thread that wrote them): the four gates' 256
+  // operand registers leave no room for these 64 next to the accumulators — the kernel spilt 45 registers with them
+  __shared__ float w1S[GH / 2][256];
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, hf = lane >> 5, j = 32 * wave + n;
   const uint32_t N = tr.n, T = tr.T;
   const size_t plane = (size_t)(T + 1) * N;
   const GruParams v = seq_params(tangent, D, A, 4);
-  float whh[4][GH / 2], w1[GH / 2], wih[4][D], bih[4], bhh[4];
+  float whh[4][GH / 2], wih[4][D], bih[4], bhh[4];
 #pragma unroll
   for (int gte = 0; gte < 4; ++gte) {
     const int row = gte * GH + j;
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const f
     bhh[gte] = v.bhh[row];
   }
 #pragma unroll
-  for (int ks = 0; ks < GH / 2; ++ks) w1[ks] = v.W1[(size_t)j * GH + 2 * ks + hf];
+  for (int ks = 0; ks < GH / 2; ++ks) w1S[ks][threadIdx.x] = v.W1[(size_t)j * GH + 2 * ks + hf];
   const float vb1 = v.b1[j];
   for (int q = threadIdx.x; q < A * MH; q += 256) v2S[q / MH][q % MH] = v.W2[q];
   const float vb2 = hf < A ? v.b2[hf] : 0.0f;
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(256, 1) k_lstm_tangent_pre(TrajDev tr, const f
     for (int r = 0; r < 16; ++r) acc1[r] = vb1;
 #pragma unroll
     for (int ks = 0; ks < GH / 2; ++ks)
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + rec_at(2 * ks + hf, n)], w1[ks], acc1,
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(size_t)ACT_A1 * GH * TL + rec_at(2 * ks + hf, n)], w1S[ks][threadIdx.x], acc1,
                                                   0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) sb[(size_t)4 * GH * TL + rec_at(j, acc_row(r, hf))] = acc1[r];
