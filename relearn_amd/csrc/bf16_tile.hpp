@@ -170,171 +170,30 @@ __device__ __forceinline__ void pack_mask_now(const float (&gm)[16], Frag (&ga)[
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(ga[s].u[i]));
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Output layer on the matrix pipe (round 3).  With g_sj = relu'(pre_sj) and h_sj = g_sj pre_sj,
-//   sum_j w_j h_sj = sum_k x~_sk q_sk,   q_sk = sum_j g_sj (w_j W~1[j][k])
-// — the same kind of masked sum as the backward, contracted over the hidden unit instead of the sample: 18 piece
-// columns (three exact bf16 pieces of each of the six products w_j W~1[j][k], rounded to f32 once), 8 issues per tile
-// instead of one VALU fma per (sample, unit) plus a 32 x 32 LDS transpose of partial sums.  Any weight matrix that is
-// linear in the inputs works the same way (the Fisher-vector product's tangent logits use Z of kernels_mfma.hip).
-//
-// What an instruction costs (scripts/probe/slot_cost.hip, profiles/r03_slot_cost.txt): the waves of a SIMD share ONE
-// issue port — a vector instruction takes ~4 cycles of it, a matrix instruction 8 (and 32 of the matrix pipe), an LDS
-// instruction 14-25; a second wave per SIMD adds no issue capacity.  So everything a tile needs goes through registers
-// and the matrix pipe, nothing through LDS:
-//   * the contraction of the output layer runs over the forward tile's LANE index, so the packed mask is transposed —
-//     by the matrix pipe itself: mask^T = mask^T . I with the packed mask as A operand (sum over its row index, no lane
-//     movement) and an identity selection as B (ident_frags): 2 issues per hidden tile, exact 0 / 1 results with the
-//     SAMPLE on the lane, packed by 8 conversions into the B operands of q^T[c][s] = sum_j Wp^T[c][j] mask^T[j][s].
-//     (Through LDS — ds_write_b64 + ds_read_b64_tr_b16, built and measured first, scripts/probe/cvt_clamp_tr.hip — the
-//     same transpose is 32 LDS instructions per tile: ~690 issue cycles against 190.)
-//   * the pieces of u_sk = g_s x~_sk reach the backward's B operand (sample in the registers, column on the lane) the
-//     same way: each sample lane packs its nine pieces as an A operand, a selection matrix (sel_frags) routes slot k to
-//     piece column n: 2 issues + 8 conversions instead of 9 ds_write_b16 + 2 ds_read2_b64.
-//
-// relu' itself: the forward weights are scaled by 2^96 (exact: a power of two), so the accumulator holds 2^96 pre and
-// v_cvt_pk_bf16_f32 with the clamp bit turns two of them into packed 0/1 masks in ONE instruction: 1 for
-// pre >= 2^-96, 0 for pre <= 0 (NaN -> 0).  (A non-zero sum of exact products below 2^-96 would give a fractional
-// mask; the f32 accumulation of terms of ordinary size cannot produce one.)  pre itself is no longer needed anywhere.
-constexpr float FWD_SCALE = 0x1p96f;
-constexpr int L2_KS = 8;  // k-steps of the output-layer product (128 hidden units / 16)
-
-// `after` is not used by the instruction: it orders the statement behind the instruction that produced it (below)
+// relu' in half an instruction per value (round 3).  The forward weights are scaled by 2^96 (exact: a power of two), so
+// the accumulator holds 2^96 pre, and v_cvt_pk_bf16_f32 with the VOP3 clamp bit turns two of them into packed 0 / 1
+// masks in ONE instruction: 1 for pre >= 2^-96, 0 for pre <= 0 (NaN -> 0; scripts/probe/cvt_clamp_tr.hip).  A non-zero
+// sum of exact products below 2^-96 would give a fractional mask; the f32 accumulation of terms of ordinary size cannot
+// produce one.  Whatever else reads the accumulator multiplies by 2^-96 (folded into a constant operand: exact).
+// The compiler's hazard recogniser does not look into inline asm, and a matrix instruction's result registers must not
+// be read (or overwritten) by a vector instruction before the required wait states have passed (no hardware
+// interlock): the first reader of the tile is therefore a real instruction — the clamp of element 0, which the
+// conversion's own clamp leaves unchanged — and every asm statement takes its result as an extra operand, so all of
+// them follow it in program order, behind the wait states the compiler inserted for it.
+constexpr float FWD_SCALE = 0x1p96f, FWD_UNSCALE = 0x1p-96f;
 __device__ __forceinline__ uint32_t mask_pair(float lo, float hi, float after) {
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(lo), "v"(hi), "v"(after));
   return r;
 }
-// relu' of a (scaled) forward tile, packed as the two A operands of the backward.
-// The compiler's hazard recogniser does not look into inline asm, and a matrix instruction's result registers must not
-// be read (or overwritten) by a vector instruction before the required wait states have passed (no hardware interlock):
-// the first reader of the tile is therefore a real instruction — the clamp of element 0, which the conversion's own
-// clamp leaves unchanged — and every asm statement takes its result as an extra operand, so all of them follow it in
-// program order, behind the wait states the compiler inserted for it.
-__device__ __forceinline__ float mask_first(const f32x16 &c) { return __builtin_amdgcn_fmed3f(c[0], 0.0f, 1.0f); }
-// half s (registers 8 s .. 8 s + 7) of the tile
-__device__ __forceinline__ void mask_half(const f32x16 &c, float first, int s, Frag &g) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) g.u[i] = mask_pair(s + i == 0 ? first : c[8 * s + 2 * i], c[8 * s + 2 * i + 1], first);
-}
+// relu' of a scaled forward tile, packed as the two A operands of the backward
 __device__ __forceinline__ void mask_tile(const f32x16 &c, Frag (&ga)[2]) {
-  const float first = mask_first(c);
-  mask_half(c, first, 0, ga[0]);
-  mask_half(c, first, 1, ga[1]);
-}
-
-// An accumulator tile X (rows in the registers, column on the lane) packed as the operand of a product that sums over
-// X's ROW index: element e of lane half h of k-step s is row acc_row(s, h, e) of X — the order every operand that meets
-// such a fragment in a product has to follow.
-__device__ __forceinline__ constexpr int acc_row(int s, int h, int e) { return 16 * s + 8 * (e >> 2) + 4 * h + (e & 3); }
-__device__ __forceinline__ void pack_acc(const f32x16 &x, Frag (&f)[2]) {
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[s].u[i] = pack_bf16(x[8 * s + 2 * i], x[8 * s + 2 * i + 1]);
-}
-// B operand of  X^T = X^T . I  for a packed 32 x 32 tile X given as A operand: I[k][n] = [row of slot k == n]
-__device__ __forceinline__ void ident_frags(int lane, Frag (&id)[2]) {
-  const int n = lane & 31, hh = lane >> 5;
+  const float first = __builtin_amdgcn_fmed3f(c[0], 0.0f, 1.0f);
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      id[s].u[i] = pk(acc_row(s, hh, 2 * i) == n ? 0x3F80u : 0u, acc_row(s, hh, 2 * i + 1) == n ? 0x3F80u : 0u);
-}
-// The pieces of u = g x~ as an A operand: lane (sample, hf) holds its nine pieces (three of each of its inputs
-// 2 hf, 2 hf + 1 and 4 + hf) in slots 0..7 of k-step 0 and slot 0 of k-step 1 of its half ...
-struct Pieces3 {
-  uint32_t p[3];
-};
-__device__ __forceinline__ Pieces3 split3v(float v) {
-  Pieces3 r;
-  split3(v, r.p[0], r.p[1], r.p[2]);
-  return r;
-}
-// three exact splits side by side, stage by stage: three independent dependency chains, so that a single wave's
-// in-order stream issues them at the full vector rate, and a stage fits the shadow of one matrix instruction
-struct Split3x3 {
-  float v[3], r[3];
-  uint32_t p0[3], p1[3], p2[3];
-  __device__ __forceinline__ void st0() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) p0[i] = pack_bf16(v[i], 0.0f);
-  }
-  __device__ __forceinline__ void st1() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r[i] = v[i] - bf16_bits_to_f32(p0[i]);
-  }
-  __device__ __forceinline__ void st2() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) p1[i] = pack_bf16(r[i], 0.0f);
-  }
-  __device__ __forceinline__ void st3() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r[i] = r[i] - bf16_bits_to_f32(p1[i]);
-  }
-  __device__ __forceinline__ void st4() {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) p2[i] = pack_bf16(r[i], 0.0f);
-  }
-  __device__ __forceinline__ Pieces3 get(int i) const { return Pieces3{{p0[i], p1[i], p2[i]}}; }
-};
-__device__ __forceinline__ void piece_operand(const Pieces3 &a, const Pieces3 &b, const Pieces3 &c, Frag (&pa)[2]) {
-  pa[0].u[0] = pk(a.p[0], a.p[1]);
-  pa[0].u[1] = pk(a.p[2], b.p[0]);
-  pa[0].u[2] = pk(b.p[1], b.p[2]);
-  pa[0].u[3] = pk(c.p[0], c.p[1]);
-  pa[1].u[0] = c.p[2];
-  pa[1].u[1] = pa[1].u[2] = pa[1].u[3] = 0u;
-}
-// ... and the selection matrix that routes slot (k-step, half, e) to its piece column pcol(k) + p (B operand, built
-// once per launch): the product is the piece image U[sample][column] as an accumulator tile, packed by pack_acc into
-// the B operands of the backward
-__device__ __forceinline__ void sel_frags(int lane, Frag (&sel)[2]) {
-  const int n = lane & 31, hh = lane >> 5;
-  auto col = [&](int i) {  // piece i = 3 q + p of this half's input slot q
-    const int q = i / 3, p = i % 3;
-    return (q == 0 ? 6 * hh : (q == 1 ? 6 * hh + 3 : (hh == 0 ? 12 : 16))) + p;
-  };
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sel[0].u[i] = pk(col(2 * i) == n ? 0x3F80u : 0u, col(2 * i + 1) == n ? 0x3F80u : 0u);
-  sel[1].u[0] = col(8) == n ? 0x3F80u : 0u;
-  sel[1].u[1] = sel[1].u[2] = sel[1].u[3] = 0u;
-}
-
-// Row of the output-layer product's A operand (= accumulator row of q^T) that holds piece p of input k: lane half
-// hf_out = the half whose lanes own input k (k = 0, 1, 4 -> 0; 2, 3, 5 -> 1), register 3 i + p with i the input's slot
-// in that half (the slots of input_frags: 2 hf, 2 hf + 1, 4 + hf).
-// Cooperative build of the A-operand fragments of the weight matrix Wp[j][k] = val(j, k), k = 0..5, in LDS, lane-linear
-// per k-step (img[ks][lane]): element e of lane (row c = lane & 31, hh = lane >> 5) of k-step ks = 2 t + u = the piece of
-// Wp[32 t + acc_row(u, hh, e)][k] that row c holds (the hidden-unit order of the transposed masks), or 0 for a row that
-// holds none.  Every thread of the workgroup calls it; the caller synchronises before the first l2_frag.
-template <typename F>
-__device__ __forceinline__ void l2_build(uint4 (*img)[64], int tid, int nthreads, F val) {
-  for (int idx = tid; idx < L2_KS * 64; idx += nthreads) {
-    const int ks = idx >> 6, ln = idx & 63, m = ln & 31, hh = ln >> 5;
-    const int hf_out = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3), i = r / 3, p = r % 3;
-    const int k = i < 2 ? 2 * hf_out + i : 4 + hf_out;
-    uint32_t h[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      uint32_t q0, q1, q2;
-      split3(val(32 * (ks >> 1) + acc_row(ks & 1, hh, e), k), q0, q1, q2);
-      h[e] = r < 9 ? (p == 0 ? q0 : (p == 1 ? q1 : q2)) : 0u;
-    }
-    img[ks][ln] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
-  }
-}
-__device__ __forceinline__ Frag l2_frag(const uint4 (*img)[64], int ks, int lane) {
-  Frag f;
-  f.x = img[ks][lane];
-  return f;
-}
-// sum_k x~_k q_k over this half's three inputs (a, b and c = x_4 or the bias input) from the q^T accumulator; the
-// other half's part comes through both_halves
-__device__ __forceinline__ float l2_dot(const f32x16 &q, float xa, float xb, float xc) {
-  const float sa = (q[0] + q[1]) + q[2], sb = (q[3] + q[4]) + q[5], sc = (q[6] + q[7]) + q[8];
-  return __builtin_fmaf(xc, sc, __builtin_fmaf(xb, sb, xa * sa));
+      ga[s].u[i] = mask_pair(s + i == 0 ? first : c[8 * s + 2 * i], c[8 * s + 2 * i + 1], first);
 }
 
 __device__ __forceinline__ constexpr int pcol(int k) { return k < 5 ? 3 * k : 16; }
@@ -365,30 +224,6 @@ __device__ __forceinline__ void piece_frags(const unsigned short (*ubf)[UROW], i
       ub[s].q[0] = *reinterpret_cast<const uint64_t *>(&ubf[n][16 * s + 4 * hf]);
       ub[s].q[1] = *reinterpret_cast<const uint64_t *>(&ubf[n][16 * s + 8 + 4 * hf]);
     }
-  }
-}
-
-// input_frags from already split features (a, c: features 2 hf, 2 hf + 1; e: feature 4), one fragment at a time — for
-// kernels that place the steps by hand between matrix instructions
-__device__ __forceinline__ void input_frags_pack(const Pieces3 &a, const Pieces3 &c, const Pieces3 &e, bool valid, int hf,
-                                                 int i, Frag &f) {
-  const uint32_t one = valid ? 0x3F80u : 0u;
-  const uint32_t x0 = hf == 0 ? e.p[0] : e.p[2], x1 = hf == 0 ? e.p[1] : one;
-  if (i == 0) {
-    f.u[0] = pk(a.p[0], a.p[0]);
-    f.u[1] = pk(a.p[0], a.p[1]);
-    f.u[2] = pk(a.p[1], a.p[1]);
-    f.u[3] = pk(a.p[2], a.p[2]);
-  } else if (i == 1) {
-    f.u[0] = pk(a.p[2], c.p[0]);
-    f.u[1] = pk(c.p[0], c.p[0]);
-    f.u[2] = pk(c.p[1], c.p[1]);
-    f.u[3] = pk(c.p[1], c.p[2]);
-  } else {
-    f.u[0] = pk(c.p[2], c.p[2]);
-    f.u[1] = pk(x0, x0);
-    f.u[2] = pk(x0, x1);
-    f.u[3] = pk(x1, x1);
   }
 }
 

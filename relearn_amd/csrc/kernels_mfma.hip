@@ -516,31 +516,36 @@ __global__ void __launch_bounds__(WAVES * 64)
     for (int p = lane; p < PIMG_M; p += 64) acc64[p] = 0.0;
 
   Frag fw[NT][3];
-  float w2v[NT][A];
-  float lv[A][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+  // Only the DIFFERENCE of the two logits enters a two-way log-softmax (it is shift-invariant), so the output layer is
+  // one chain with the differenced weights w2d = W2[0] - W2[1]; the passes agree with each other because all of them
+  // (and log pi_0, stored by PASS_INIT) use this form.  The rollout's bit-exact forward is device_fns.hpp, not this.
+  float w2d[NT];
+  float lvd[3] = {0.0f, 0.0f, 0.0f};  // the linear half of relu (bf16_tile.hpp) for the differenced logit
   float tb2d = 0.0f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = t * 32 + n;
     const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
-    bt::weight_frags(wa, wb, w4, bj, hf, fw[t]);
+    // gradient / evaluation passes: the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp) and
+    // the |pre| chain takes the scale back out through w2d (both exact); the Fisher-vector pass needs relu' as an f32
+    // factor and keeps the unscaled forward
+    const float sc = JVP ? 1.0f : bt::FWD_SCALE;
+    bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
     if (FW_LDS && wave == t) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) Fw[t * 3 + i][lane] = fw[t][i].x;
     }
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      w2v[t][a] = W2[a * H + j];
-      if (!JVP) {
-        lv[a][0] = __builtin_fmaf(w2v[t][a], wa, lv[a][0]);
-        lv[a][1] = __builtin_fmaf(w2v[t][a], wb, lv[a][1]);
-        lv[a][2] = __builtin_fmaf(w2v[t][a], hf == 0 ? w4 : bj, lv[a][2]);
-      }
+    const float wd = W2[j] - W2[H + j];
+    if (!JVP) {
+      lvd[0] = __builtin_fmaf(wd, wa, lvd[0]);
+      lvd[1] = __builtin_fmaf(wd, wb, lvd[1]);
+      lvd[2] = __builtin_fmaf(wd, hf == 0 ? w4 : bj, lvd[2]);
     }
+    w2d[t] = bt::FWD_UNSCALE * wd;
     if (JVP && wave == t) {  // waves 0..3 build the fragments of Z for hidden tile t = wave
       const float *__restrict__ V1 = tangent, *__restrict__ vb1 = V1 + H * D, *__restrict__ V2 = vb1 + H;
-      const float w2d = w2v[t][0] - w2v[t][1], t2d = V2[j] - V2[H + j];
-      auto zmix = [&](float v, float w) { return __builtin_fmaf(t2d, w, w2d * v); };
+      const float t2d = V2[j] - V2[H + j];
+      auto zmix = [&](float v, float w) { return __builtin_fmaf(t2d, w, wd * v); };
       Frag fz[3];
       bt::weight_frags(zmix(V1[j * D + 2 * hf], wa), zmix(V1[j * D + 2 * hf + 1], wb), zmix(V1[j * D + 4], w4),
                        zmix(vb1[j], bj), hf, fz);
@@ -554,13 +559,11 @@ __global__ void __launch_bounds__(WAVES * 64)
     tb2d = vb2[0] - vb2[1];
   } else {
 #pragma unroll
-    for (int a = 0; a < A; ++a)
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) lv[a][q] = lv[a][q] + __shfl_xor(lv[a][q], m, 64);
+      for (int m = 1; m < 32; m <<= 1) lvd[q] = lvd[q] + __shfl_xor(lvd[q], m, 64);
   }
-  const float b2_0 = b2[0], b2_1 = b2[1];
+  const float b2d = b2[0] - b2[1];
   bt::f32x16 dm[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dm[t] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -627,12 +630,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     Frag fa[3];
     bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
     Frag ga[NT][2];
-    float y0[16], y1[16];
+    float y0[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      y0[r] = 0.0f;
-      y1[r] = 0.0f;
-    }
+    for (int r = 0; r < 16; ++r) y0[r] = 0.0f;
     auto fwd = [&](int t) {
       if (FW_LDS) {
         Frag f[3];
@@ -660,28 +660,22 @@ __global__ void __launch_bounds__(WAVES * 64)
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pre = c[r], apre = __builtin_fabsf(pre);
-          y0[r] = __builtin_fmaf(apre, w2v[t][0], y0[r]);
-          y1[r] = __builtin_fmaf(apre, w2v[t][1], y1[r]);
-          if (BWD) gm[r] = __builtin_amdgcn_fmed3f(pre * big, 0.0f, 1.0f);
-        }
+        for (int r = 0; r < 16; ++r) y0[r] = __builtin_fmaf(__builtin_fabsf(c[r]), w2d[t], y0[r]);
       }
-      if (BWD) bt::pack_mask_now(gm, ga[t]);
+      if (BWD) {
+        if (JVP) bt::pack_mask_now(gm, ga[t]);
+        else bt::mask_tile(c, ga[t]);  // relu'(pre): one conversion per two values
+      }
       c = cn;
     }
-    float s0, s1 = 0.0f;
+    float s0;
     if (JVP) {
       s0 = lane_sum(y0, 0.0f);
     } else {
-      const float x3 = hf == 0 ? op.xc : 1.0f;
-      float lin0 = lv[0][0] * op.xa, lin1 = lv[1][0] * op.xa;
-      lin0 = __builtin_fmaf(lv[0][1], op.xb, lin0);
-      lin1 = __builtin_fmaf(lv[1][1], op.xb, lin1);
-      lin0 = __builtin_fmaf(lv[0][2], x3, lin0);
-      lin1 = __builtin_fmaf(lv[1][2], x3, lin1);
-      s0 = 0.5f * lane_sum(y0, lin0);
-      s1 = 0.5f * lane_sum(y1, lin1);
+      float lin = lvd[0] * op.xa;
+      lin = __builtin_fmaf(lvd[1], op.xb, lin);
+      lin = __builtin_fmaf(lvd[2], hf == 0 ? op.xc : 1.0f, lin);
+      s0 = 0.5f * lane_sum(y0, lin);
     }
     // ---- per-sample math on the owner lanes (lane n and n + 32 both hold sample n)
     float dz0 = 0.0f, dz1 = 0.0f;
@@ -691,7 +685,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       dz0 = op.valid ? (p0 * p1) * delta * inv_B : 0.0f;
       dz1 = -dz0;
     } else {
-      float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
+      float z[2] = {s0 + b2d, 0.0f}, lp[2];
       const float adv = op.adv;
       const int act = op.act;
       log_softmax_lane<2>(z, lp);
@@ -857,7 +851,7 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   else {
     // the evaluation pass has no backward state: with the weight fragments in LDS it fits twelve waves per CU (152
     // VGPRs) — 0.155 ms per launch at 8.4 M samples against 0.206 ms at eight (sixteen waves: 17 spills, no gain)
-    constexpr int EVAL_WAVES = 12;
+    constexpr int EVAL_WAVES = 16;
     hipLaunchKernelGGL((k_policy_bf16<PASS_EVAL, EVAL_WAVES, true>), g, dim3(EVAL_WAVES * 64), 0, s, traj->d,
                        policy->d_params, d_tangent, traj->lp0, traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi);
   }
