@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 3
+#define RL_ABI_VERSION 4
 
 /* ---------------------------------------------------------------------------------------------
  * Status codes.  The non-generic ones mirror the reference's error enums:
@@ -204,20 +204,39 @@ int32_t rl_env_get_state(rl_env *env, double *state4, int32_t *nv_pos, uint64_t 
 int32_t rl_env_set_state(rl_env *env, const double *state4, const int32_t *nv_pos, const uint64_t *steps_remaining,
                          const uint64_t *reset_count);
 
+/* Test hook for the random streams (Prng = ChaCha8Rng used as a counter-based generator, src/lib.rs:68):
+ * `n_words` consecutive 32-bit words, starting at word `first_word`, of ChaCha8Rng::seed_from_u64(seed) with
+ * set_stream(stream), computed ON THE DEVICE by the block function the rollouts, resets and env steps draw from
+ * (include/rl_chacha.h as compiled for gfx950).  tests/test_gpu_chacha_independent.py compares them with a from-scratch
+ * implementation (RFC 7539 quarter round, 8 rounds; rand_core's PCG32 seed expansion) that shares no code with the
+ * library or the oracle. */
+int32_t rl_debug_stream_words(rl_engine *engine, uint64_t seed, uint64_t stream, uint64_t first_word, uint32_t n_words,
+                              uint32_t *words_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Modules.  `MlpConfig::build_module` with one hidden layer, ReLU, identity output
  * (src/torch/modules/ff/mlp.rs:25-69); parameters are exchanged in the reference's flat order
  * (kernel [out][in] then bias per layer: ff/linear.rs:108-110, torch/utils.rs:10-22). */
 int32_t rl_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t hidden, uint32_t out_dim, rl_mlp **out);
-/* MlpConfig { hidden_sizes: Vec<usize>, .. } (src/torch/modules/ff/mlp.rs:13-34): in_dim -> hidden_sizes[0] -> ... ->
- * out_dim with ReLU between the layers; parameters flat as [W, b] per layer in layer order.  `n_hidden` in [0, 4],
- * every width in [1, 256], in_dim in {4, 5}, out_dim in {1, 2}; other shapes -> RL_ERR_BUILD_AGENT.  One hidden layer
- * of at most 128 units is rl_mlp_create (the fused kernels every BASELINE configuration runs on); any other shape runs
- * per-layer kernels (relearn_amd/csrc/kernels_general.hip: the general path, not the fast one) behind the same entry
- * points — rollouts, GAE, TRPO / PPO / REINFORCE and critic updates, row-wise forward, actor serialisation; DQN takes
- * single-hidden-layer modules only. */
+/* Activation (src/torch/modules/ff/activation.rs:11-20,85-92): the unit variants of the reference's enum, in its
+ * declaration order.  Sigmoid and tanh are the engine's deterministic ones (include/rl_detmath.h, within 2.5 ulp of
+ * libm), shared with the oracle like every transcendental of the bit-exact paths. */
+typedef enum {
+  RL_ACT_IDENTITY = 0,
+  RL_ACT_RELU = 1,
+  RL_ACT_SIGMOID = 2,
+  RL_ACT_TANH = 3
+} rl_activation;
+/* MlpConfig { hidden_sizes, activation, output_activation, .. } (src/torch/modules/ff/mlp.rs:13-34,139-151): in_dim ->
+ * hidden_sizes[0] -> ... -> out_dim with `activation` after every hidden layer and `output_activation` on the output;
+ * parameters flat as [W, b] per layer in layer order.  `n_hidden` in [0, 4], every width in [1, 256], in_dim in {4, 5},
+ * out_dim in {1, 2}, activations from rl_activation; anything else -> RL_ERR_BUILD_AGENT.  One hidden layer of at most
+ * 128 units with the reference's defaults (Relu, Identity) is rl_mlp_create — the fused kernels every BASELINE
+ * configuration runs on, which are built for exactly that; any other shape or activation runs per-layer kernels
+ * (relearn_amd/csrc/kernels_general.hip: the general path, not the fast one) behind the same entry points — rollouts,
+ * GAE, TRPO / PPO / REINFORCE and critic updates, row-wise forward, actor serialisation; DQN takes fused modules only. */
 int32_t rl_mlp_create_layers(rl_engine *engine, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
-                             uint32_t out_dim, rl_mlp **out);
+                             uint32_t out_dim, int32_t activation, int32_t output_activation, rl_mlp **out);
 int32_t rl_mlp_destroy(rl_mlp *mlp);
 int32_t rl_mlp_num_params(const rl_mlp *mlp, uint64_t *n);
 /* Linear::new Glorot-uniform init (ff/linear.rs:54-68) from the engine-defined stream ChaCha8(seed) */

@@ -259,6 +259,8 @@ def _declare(L):
     L.oracle_mlp_init.argtypes = [MlpShape, C.c_uint64, P(C.c_float)]
     L.oracle_mlp_forward_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_float)]
     L.oracle_mlp_forward_batch_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
+    L.oracle_mlp_layers_forward_f32.argtypes = [C.c_uint32, P(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                                P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
 
     L.oracle_log_softmax_f32.argtypes = [P(C.c_float), C.c_uint32, P(C.c_float), C.c_int]
     L.oracle_categorical_sample_u.argtypes = [P(C.c_float), C.c_uint32, C.c_float, C.c_int]
@@ -459,6 +461,20 @@ def mlp_forward_batch(shape, params, x):
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.zeros((x.shape[0], shape.out_dim), dtype=np.float32)
     lib().oracle_mlp_forward_batch_f32(shape, f32p(params), f32p(x), x.shape[0], f32p(out))
+    return out
+
+
+ACTIVATIONS = ["Identity", "Relu", "Sigmoid", "Tanh"]  # the reference enum's declaration order (ff/activation.rs:11-20)
+
+
+def mlp_layers_forward(in_dim, hidden, out_dim, params, x, activation="Relu", output_activation="Identity"):
+    """Mlp::forward for any hidden_sizes / activations (oracle_mlp_layers_forward_f32); x [rows][in] -> [rows][out]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros((x.shape[0], out_dim), dtype=np.float32)
+    hs = (C.c_uint32 * max(len(hidden), 1))(*hidden)
+    lib().oracle_mlp_layers_forward_f32(in_dim, hs, len(hidden), out_dim, ACTIVATIONS.index(activation),
+                                        ACTIVATIONS.index(output_activation), f32p(np.ascontiguousarray(params, dtype=np.float32)),
+                                        f32p(x), x.shape[0], f32p(out))
     return out
 
 

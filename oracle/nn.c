@@ -310,3 +310,46 @@ void oracle_reinforce_update_f32(oracle_mlp_shape s, float *params, oracle_adam_
   free(lp);
   free(g);
 }
+
+/* ------------------------------------------------------------------ MLPs of any hidden_sizes and activations
+ * Mlp::forward (src/torch/modules/ff/mlp.rs:139-151): every hidden Linear followed by `activation`, the last Linear by
+ * `output_activation`; Activation::forward (ff/activation.rs:85-92): identity / relu / sigmoid / tanh.  Parameters flat
+ * as [kernel [out][in], bias [out]] per layer (ff/linear.rs:108-110).  Dot products in the engine's order, `acc = bias;
+ * acc = fma(x_k, w_k, acc)`, k ascending; sigmoid / tanh are the engine's deterministic ones (include/rl_detmath.h) —
+ * so the f32 version is what the device's per-layer kernels must reproduce bit for bit.  `act`, `out_act`: 0 Identity,
+ * 1 Relu, 2 Sigmoid, 3 Tanh (the reference enum's declaration order).  x: [rows][in_dim]; out: [rows][out_dim]. */
+static float layers_act_f32(int act, float x) {
+  switch (act) {
+    case 1: return x > 0.0f ? x : 0.0f;
+    case 2: return rl_sigmoidf(x);
+    case 3: return rl_tanhf(x);
+    default: return x;
+  }
+}
+void oracle_mlp_layers_forward_f32(uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden, uint32_t out_dim,
+                                   int act, int out_act, const float *params, const float *x, uint64_t rows,
+                                   float *out) {
+  float a[256], b[256];
+  for (uint64_t r = 0; r < rows; ++r) {
+    const float *in = x + r * in_dim;
+    uint32_t K = in_dim;
+    const float *p = params;
+    float *cur = a, *nxt = b;
+    for (uint32_t l = 0; l <= n_hidden; ++l) {
+      const uint32_t N = l == n_hidden ? out_dim : hidden_sizes[l];
+      const float *W = p, *bias = p + (uint64_t)N * K;
+      float *dst = l == n_hidden ? out + r * out_dim : cur;
+      for (uint32_t n = 0; n < N; ++n) {
+        float acc = bias[n];
+        for (uint32_t k = 0; k < K; ++k) acc = __builtin_fmaf(in[k], W[(uint64_t)n * K + k], acc);
+        dst[n] = layers_act_f32(l == n_hidden ? out_act : act, acc);
+      }
+      p = bias + N;
+      in = dst;
+      K = N;
+      float *t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+  }
+}

@@ -187,6 +187,11 @@ uint64_t oracle_mlp_num_params(oracle_mlp_shape s);
 void oracle_mlp_init(oracle_mlp_shape s, uint64_t seed, float *params);
 void oracle_mlp_forward_f32(oracle_mlp_shape s, const float *params, const float *x, float *out);
 void oracle_mlp_forward_batch_f32(oracle_mlp_shape s, const float *params, const float *x, uint64_t n, float *out);
+/* Mlp::forward for any hidden_sizes (<= 256 wide) and activations (ff/mlp.rs:139-151, ff/activation.rs:85-92); act codes
+ * 0 Identity, 1 Relu, 2 Sigmoid, 3 Tanh; x [rows][in_dim] -> out [rows][out_dim]; the engine's fma order and detmath */
+void oracle_mlp_layers_forward_f32(uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden, uint32_t out_dim,
+                                   int act, int out_act, const float *params, const float *x, uint64_t rows,
+                                   float *out);
 
 /* ---------------------------------------------------------------- Categorical (src/torch/distributions/categorical.rs) */
 void oracle_log_softmax_f32(const float *z, uint32_t n, float *lp, int use_libm);

@@ -34,7 +34,7 @@ KERNEL_CLASSES = ["env_step", "rollout", "values", "gae", "policy_pass", "backwa
 
 # every symbol include/relearn_hip.h declares (checked by tests/test_abi_symbols.py against the header)
 ABI_SYMBOLS = [
-    "rl_abi_version", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
+    "rl_abi_version", "rl_debug_stream_words", "rl_device_count", "rl_engine_create", "rl_engine_destroy", "rl_engine_sync",
     "rl_last_error", "rl_engine_info", "rl_engine_set_kernel_variant", "rl_timer_begin", "rl_timer_end", "rl_profile_enable", "rl_profile_read",
     "rl_comm_available", "rl_comm_library_paths", "rl_comm_unique_id", "rl_comm_init", "rl_comm_destroy", "rl_comm_init_host",
     "rl_comm_ipc_handle", "rl_comm_init_ipc", "rl_comm_selftest",
@@ -188,6 +188,13 @@ class Engine(_Handle):
         cus = C.c_int32()
         _check(lib().rl_engine_info(self.h, name, C.c_size_t(256), arch, C.c_size_t(256), C.byref(cus)), self.h)
         return name.value.decode(), arch.value.decode(), cus.value
+
+    def stream_words(self, seed, stream, first_word, n_words):
+        """raw 32-bit words of the engine's ChaCha8 stream (seed, stream), computed on the device (test hook)"""
+        out = np.zeros(n_words, dtype=np.uint32)
+        _check(lib().rl_debug_stream_words(self.h, C.c_uint64(seed), C.c_uint64(stream), C.c_uint64(first_word),
+                                           C.c_uint32(n_words), out.ctypes.data_as(C.c_void_p)), self.h)
+        return out
 
     def set_kernel_variant(self, variant):
         _check(lib().rl_engine_set_kernel_variant(self.h, C.c_int32(variant)), self.h)
@@ -482,18 +489,26 @@ class LstmMlp(GruMlp):
         self.in_dim, self.hidden, self.out_dim, self.gru_hidden = in_dim, mlp_hidden, out_dim, lstm_hidden
 
 
+ACTIVATIONS = ["Identity", "Relu", "Sigmoid", "Tanh"]  # rl_activation, in the reference enum's order
+
+
 class Mlp(_Handle):
     """`MlpConfig{hidden_sizes:[H], activation: Relu}.build_module(in, out)`; flat params in reference order."""
 
-    def __init__(self, engine, in_dim, hidden, out_dim):
+    def __init__(self, engine, in_dim, hidden, out_dim, activation="Relu", output_activation="Identity"):
         """`hidden`: the width of the single hidden layer, or MlpConfig's `hidden_sizes` as a list (any number of layers:
-        shapes other than one layer of <= 128 units run the general per-layer kernels)"""
+        shapes other than one layer of <= 128 units, and activations other than Relu / Identity, run the general
+        per-layer kernels); activations by the reference's variant names (ff/activation.rs:11-20)"""
         self.eng = engine
         self.h = C.c_void_p()
-        if isinstance(hidden, (list, tuple)):
+        self.activation, self.output_activation = activation, output_activation
+        if isinstance(hidden, (list, tuple)) or (activation, output_activation) != ("Relu", "Identity"):
+            hidden = list(hidden) if isinstance(hidden, (list, tuple)) else [hidden]
             sizes = (C.c_uint32 * max(len(hidden), 1))(*hidden)
             _check(lib().rl_mlp_create_layers(engine.h, C.c_uint32(in_dim), sizes, C.c_uint32(len(hidden)),
-                                              C.c_uint32(out_dim), C.byref(self.h)), engine.h)
+                                              C.c_uint32(out_dim), C.c_int32(ACTIVATIONS.index(activation)),
+                                              C.c_int32(ACTIVATIONS.index(output_activation)), C.byref(self.h)),
+                   engine.h)
         else:
             _check(lib().rl_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(hidden), C.c_uint32(out_dim),
                                        C.byref(self.h)), engine.h)

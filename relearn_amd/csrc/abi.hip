@@ -625,6 +625,36 @@ int32_t rl_env_observe(rl_env *env, float *obs_out) {
   });
 }
 
+// one thread per word: block = word / 16 of the stream, the word's position in it
+__global__ void k_debug_stream_words(AgentKey key, uint64_t stream, uint64_t first_word, uint32_t n_words,
+                                     uint32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_words) return;
+  const uint64_t w = first_word + i;
+  uint32_t words[16];
+  rl_chacha_block(key.w, w >> 4, stream, 4, words);
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v = (uint32_t)(w & 15) == (uint32_t)k ? words[k] : v;
+  out[i] = v;
+}
+
+int32_t rl_debug_stream_words(rl_engine *engine, uint64_t seed, uint64_t stream, uint64_t first_word, uint32_t n_words,
+                              uint32_t *words_out) {
+  return guarded(engine, [&] {
+    RL_REQUIRE(engine && words_out, "NULL argument");
+    RL_REQUIRE(n_words > 0 && n_words <= (1u << 20), "n_words must be in [1, 2^20]");
+    AgentKey key;
+    rl_seed_from_u64(seed, key.w);
+    uint32_t *d = dalloc<uint32_t>(n_words);
+    hipLaunchKernelGGL(k_debug_stream_words, dim3((n_words + 255) / 256), dim3(256), 0, engine->stream, key, stream,
+                       first_word, n_words, d);
+    RL_HIP_CHECK(hipGetLastError());
+    d2h(engine, words_out, d, (size_t)n_words * sizeof(uint32_t));
+    dfree(d);
+  });
+}
+
 int32_t rl_env_upload_actions(rl_env *env, const uint8_t *actions) {
   return guarded(env ? env->eng : nullptr, [&] {
     RL_REQUIRE(env && actions, "NULL argument");
@@ -733,9 +763,10 @@ int32_t rl_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t hidden, uint32_t o
 }
 
 int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
-                             uint32_t out_dim, rl_mlp **out) {
-  // one hidden layer of at most 128 units: the fused kernels
-  if (e && out && hidden_sizes && n_hidden == 1 && hidden_sizes[0] <= 128)
+                             uint32_t out_dim, int32_t activation, int32_t output_activation, rl_mlp **out) {
+  // one hidden layer of at most 128 units, Relu inside and Identity on the output: the fused kernels
+  if (e && out && hidden_sizes && n_hidden == 1 && hidden_sizes[0] <= 128 && activation == RL_ACT_RELU &&
+      output_activation == RL_ACT_IDENTITY)
     return rl_mlp_create(e, in_dim, hidden_sizes[0], out_dim, out);
   return guarded(e, [&] {
     RL_REQUIRE(e && out && (hidden_sizes || n_hidden == 0), "NULL argument");
@@ -745,6 +776,10 @@ int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidd
     if (!ok)
       throw RlError(RL_ERR_BUILD_AGENT, "supported MLP shapes: in_dim in {4,5}, at most 4 hidden layers of 1..256 units, "
                                         "out_dim in {1,2}");
+    if (activation < RL_ACT_IDENTITY || activation > RL_ACT_TANH || output_activation < RL_ACT_IDENTITY ||
+        output_activation > RL_ACT_TANH)
+      throw RlError(RL_ERR_BUILD_AGENT, "activation / output_activation must be one of rl_activation "
+                                        "(Identity, Relu, Sigmoid, Tanh)");
     RL_HIP_CHECK(hipSetDevice(e->device));
     std::unique_ptr<rl_mlp> m(new rl_mlp());
     m->eng = e;
@@ -754,6 +789,8 @@ int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidd
     m->n_hidden = n_hidden;
     for (uint32_t l = 0; l < n_hidden; ++l) m->widths[l] = hidden_sizes[l];
     m->general = true;
+    m->act = activation;
+    m->out_act = output_activation;
     m->P = m->layer_offset(m->n_layers());
     m->d_params = dalloc<float>(m->P);
     RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));

@@ -85,7 +85,10 @@ static TensorDefView cbor_parse_tensor_def(const cbor::Value &t) {
 
 // Mlp { layers, activation, output_activation } over `p` = [W1, b1, W2, b2] (ff/mlp.rs:45-50, ff/linear.rs:43-50)
 // (`widths`: in, hidden sizes ..., out)
-static void cbor_mlp_layers(cbor::Writer &w, const float *p, const std::vector<int64_t> &widths) {
+// unit variants of `Activation` as serde writes them: the variant's name (ff/activation.rs:11-20)
+static const char *const kActivationNames[4] = {"Identity", "Relu", "Sigmoid", "Tanh"};
+static void cbor_mlp_layers(cbor::Writer &w, const float *p, const std::vector<int64_t> &widths, int act = RL_ACT_RELU,
+                            int out_act = RL_ACT_IDENTITY) {
   w.map(3);
   w.key("layers");
   w.array(widths.size() - 1);
@@ -100,9 +103,9 @@ static void cbor_mlp_layers(cbor::Writer &w, const float *p, const std::vector<i
     p += out;
   }
   w.key("activation");
-  w.text("Relu");
+  w.text(kActivationNames[act]);
   w.key("output_activation");
-  w.text("Identity");
+  w.text(kActivationNames[out_act]);
 }
 static void cbor_mlp(cbor::Writer &w, const float *p, int64_t in, int64_t hid, int64_t out) {
   cbor_mlp_layers(w, p, {in, hid, out});
@@ -116,7 +119,7 @@ static std::vector<int64_t> mlp_widths(const rl_mlp *m) {
 
 static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<float> &p) {
   if (m->kind == RL_MODULE_MLP) {
-    cbor_mlp_layers(w, p.data(), mlp_widths(m));
+    cbor_mlp_layers(w, p.data(), mlp_widths(m), m->act, m->out_act);
     return;
   }
   // Gru and Lstm are both RnnBase<impl> (seq/rnn/gru.rs:17, lstm.rs:12): the same document, gate rows 3H or 4H
@@ -225,9 +228,10 @@ static void cbor_read_tensor(const cbor::Value &t, std::initializer_list<int64_t
   std::memcpy(dst, v.data->data(), v.data->size());
 }
 
-static float *cbor_read_mlp_layers(const cbor::Value &m, const std::vector<int64_t> &widths, float *dst) {
-  RL_REQUIRE(m.at("activation").s == "Relu" && m.at("output_activation").s == "Identity",
-             "CBOR module: only Relu hidden / Identity output activations are built");
+static float *cbor_read_mlp_layers(const cbor::Value &m, const std::vector<int64_t> &widths, float *dst,
+                                   int act = RL_ACT_RELU, int out_act = RL_ACT_IDENTITY) {
+  RL_REQUIRE(m.at("activation").s == kActivationNames[act] && m.at("output_activation").s == kActivationNames[out_act],
+             "CBOR module: the document's activations are not the module's");
   const cbor::Value &layers = m.at("layers");
   RL_REQUIRE(layers.kind == cbor::Value::ARRAY && layers.items.size() + 1 == widths.size(),
              "CBOR module: the number of layers does not match the module");
@@ -254,7 +258,7 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
     std::vector<float> p(module->P);
     float *end;
     if (module->kind == RL_MODULE_MLP) {
-      end = cbor_read_mlp_layers(mod, mlp_widths(module), p.data());
+      end = cbor_read_mlp_layers(mod, mlp_widths(module), p.data(), module->act, module->out_act);
     } else {
       const int64_t H = module->gru_hidden, D = module->in_dim, GHR = (int64_t)rl_module_gates(module->kind) * H;
       RL_REQUIRE(mod.at("activation").s == "Relu", "CBOR module: Chain activation must be Relu");

@@ -184,6 +184,8 @@ struct rl_mlp {
   uint32_t n_hidden = 1;
   uint32_t widths[RL_MLP_MAX_HIDDEN] = {0, 0, 0, 0};
   bool general = false;
+  // MlpConfig::activation / output_activation (rl_activation); the fused kernels are built for Relu / Identity
+  int act = 1, out_act = 0;
   // layer l (0 .. n_hidden; the last one is the output layer): fan-in, fan-out, offset of its kernel in the flat
   // parameter vector ([W, b] per layer, the reference's order)
   uint32_t n_layers() const { return n_hidden + 1; }

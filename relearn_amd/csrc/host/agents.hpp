@@ -243,8 +243,12 @@ class Module {
   uint64_t n_ = 0;
 };
 
-struct MlpConfig {  // MlpConfig { hidden_sizes, activation: Relu, output_activation: Identity } (ff/mlp.rs:13-34)
+enum class Activation { Identity = RL_ACT_IDENTITY, Relu = RL_ACT_RELU, Sigmoid = RL_ACT_SIGMOID, Tanh = RL_ACT_TANH };
+
+struct MlpConfig {  // MlpConfig { hidden_sizes, activation, output_activation } (ff/mlp.rs:13-34)
   std::vector<uint32_t> hidden_sizes{128};  // MlpConfig::default; any list of up to four widths <= 256 builds
+  Activation activation = Activation::Relu;             // between the hidden layers (ff/activation.rs:11-27)
+  Activation output_activation = Activation::Identity;  // on the output
   // width of the single hidden layer (the recurrent chains take exactly one)
   uint32_t single_hidden_size() const {
     if (hidden_sizes.size() != 1) throw BuildAgentError(RL_ERR_BUILD_AGENT, "the chain's MLP takes one hidden layer");
@@ -252,7 +256,8 @@ struct MlpConfig {  // MlpConfig { hidden_sizes, activation: Relu, output_activa
   }
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_mlp_create_layers(eng.handle(), in_dim, hidden_sizes.data(), (uint32_t)hidden_sizes.size(), out_dim, &h),
+    check(rl_mlp_create_layers(eng.handle(), in_dim, hidden_sizes.data(), (uint32_t)hidden_sizes.size(), out_dim,
+                               (int32_t)activation, (int32_t)output_activation, &h),
           eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     check(rl_mlp_init(h, seed), eng.handle());

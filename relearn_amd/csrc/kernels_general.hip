@@ -6,7 +6,10 @@
 //   k_gen_dense    Y = act(b + W X) for 64 samples per workgroup (X tile in LDS, weights through wave-uniform loads,
 //                  four output units per pass); with a tangent: tY = act'(.) (W tX + V X + vb)   (forward-mode, for
 //                  the Fisher-vector product of TRPO, conjugate_gradient.rs:262-339)
-//   k_gen_delta    dX = [X > 0] W^T dY                                   (backward through a hidden layer)
+//   k_gen_delta    dX = act'(.) W^T dY                                   (backward through a hidden layer)
+//   act is MlpConfig::activation for the hidden layers and ::output_activation for the last one (ff/mlp.rs:139-151,
+//   ff/activation.rs:85-92: Identity, Relu, Sigmoid, Tanh); the derivative is taken from the stored OUTPUT of the
+//   layer (relu: [y > 0], sigmoid: y (1 - y), tanh: 1 - y^2), so no pre-activation is kept
 //   k_gen_wgrad    dW = dY X^T, db = sum dY over a chunk of samples, f64 partials into the slab rows k_reduce sums
 //   k_gen_*_terms  the per-sample loss terms and d loss / d output from the stored outputs (the arithmetic of
 //                  k_policy_pass / k_critic_fwd, kernels_update.hip)
@@ -15,6 +18,9 @@
 // The launchers at the end plug into the module-generic seams: launch_policy_pass / launch_critic_fwd /
 // launch_mlp_backward (kernels_update.hip), values for GAE and TD targets, row-wise forward, and a step-by-step
 // rollout over the standalone env kernels.
+#include <mutex>
+#include <set>
+
 #include "abi_internal.hpp"
 #include "policy_terms.hpp"
 
@@ -23,6 +29,20 @@ namespace {
 constexpr int GT = 64;  // samples per workgroup tile
 
 static inline uint32_t cdiv_g(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// Activation::forward (ff/activation.rs:85-92) and its derivative in terms of the output y
+__device__ __forceinline__ float act_apply(int act, float x) {
+  if (act == RL_ACT_RELU) return x > 0.0f ? x : 0.0f;
+  if (act == RL_ACT_SIGMOID) return rl_sigmoidf(x);
+  if (act == RL_ACT_TANH) return rl_tanhf(x);
+  return x;
+}
+__device__ __forceinline__ float act_slope(int act, float y) {
+  if (act == RL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == RL_ACT_SIGMOID) return y * (1.0f - y);
+  if (act == RL_ACT_TANH) return 1.0f - y * y;
+  return 1.0f;
+}
 
 struct DenseArgs {
   const float *X, *tX;    // [K][.] inputs (rows `xs` / `txs` floats apart), tangent inputs (TANGENT)
@@ -33,10 +53,11 @@ struct DenseArgs {
   size_t ys;
   size_t S;               // samples
   int K, N;
+  int act;                // rl_activation of this layer (wave-uniform)
   const int32_t *skip;
 };
 
-template <bool RELU, bool TANGENT>
+template <bool TANGENT>
 __global__ void __launch_bounds__(256) k_gen_dense(DenseArgs a) {
   extern __shared__ float sm[];  // Xs[K][GT] (+ tXs[K][GT])
   if (a.skip != nullptr && *a.skip != 0) return;
@@ -105,18 +126,19 @@ __global__ void __launch_bounds__(256) k_gen_dense(DenseArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (n0 + u < a.N) {
-          const bool on = !RELU || acc[u] > 0.0f;
-          a.Y[(size_t)(n0 + u) * a.ys + s0 + s] = on ? acc[u] : 0.0f;
-          if (TANGENT) a.tY[(size_t)(n0 + u) * a.ys + s0 + s] = on ? tacc[u] : 0.0f;
+          const float y = act_apply(a.act, acc[u]);
+          a.Y[(size_t)(n0 + u) * a.ys + s0 + s] = y;
+          if (TANGENT) a.tY[(size_t)(n0 + u) * a.ys + s0 + s] = act_slope(a.act, y) * tacc[u];
         }
     }
   }
 }
 
-// dX[k][s] = [X[k][s] > 0] sum_n W[n][k] dY[n][s]
+// dX[k][s] = act'(X[k][s]) sum_n W[n][k] dY[n][s]   (X: the stored outputs of the layer below, `act` its activation)
 __global__ void __launch_bounds__(256) k_gen_delta(const float *__restrict__ dY, size_t dys, int N,
                                                    const float *__restrict__ W, int K, const float *__restrict__ X,
-                                                   float *__restrict__ dX, size_t S, const int32_t *__restrict__ skip) {
+                                                   float *__restrict__ dX, size_t S, int act,
+                                                   const int32_t *__restrict__ skip) {
   extern __shared__ float sm[];  // dYs[N][GT]
   if (skip != nullptr && *skip != 0) return;
   const int s = threadIdx.x & (GT - 1);
@@ -156,7 +178,7 @@ __global__ void __launch_bounds__(256) k_gen_delta(const float *__restrict__ dY,
     for (int u = 0; u < 4; ++u)
       if (k0 + u < K) {
         const size_t o = (size_t)(k0 + u) * S + s0 + s;
-        dX[o] = X[o] > 0.0f ? acc[u] : 0.0f;
+        dX[o] = act_slope(act, X[o]) * acc[u];
       }
   }
 }
@@ -339,18 +361,27 @@ __global__ void __launch_bounds__(256) k_gen_record_step(TrajDev tr, const uint8
     for (uint32_t d = 0; d < tr.D; ++d) tr.term_obs[(size_t)d * tr.T * tr.n + o] = term_obs[(size_t)d * tr.n + i];
 }
 
-template <bool RELU, bool TANGENT>
+// d loss / d (pre-activation of the output layer) = d loss / d output * act'(output)   (output_activation != Identity)
+__global__ void __launch_bounds__(256) k_gen_output_slope(float *__restrict__ dz, const float *__restrict__ z, size_t count,
+                                                          int act, const int32_t *__restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dz[i] = dz[i] * act_slope(act, z[i]);
+}
+
+template <bool TANGENT>
 void dense(rl_engine *e, const DenseArgs &a) {
   const size_t lds = (size_t)a.K * GT * sizeof(float) * (TANGENT ? 2 : 1);
-  if (lds > 64 * 1024) {  // (once per instantiation: the tangent tiles of a 256-wide layer need 128 KB)
-    static bool raised = false;
-    if (!raised) {
-      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_dense<RELU, TANGENT>),
+  if (lds > 64 * 1024) {  // the tangent tiles of a 256-wide layer need 128 KB: raised once per device and instantiation
+    static std::mutex mu;
+    static std::set<int> raised;
+    std::lock_guard<std::mutex> lock(mu);
+    if (raised.insert(e->device).second)
+      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_dense<TANGENT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      raised = true;
-    }
   }
-  hipLaunchKernelGGL((k_gen_dense<RELU, TANGENT>), dim3(cdiv_g(a.S, GT)), dim3(256), lds, e->stream, a);
+  hipLaunchKernelGGL((k_gen_dense<TANGENT>), dim3(cdiv_g(a.S, GT)), dim3(256), lds, e->stream, a);
+  RL_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace
@@ -443,13 +474,9 @@ static void gen_forward_impl(rl_traj *t, const rl_mlp *m, const float *x, size_t
     a.ys = rows;
     a.S = rows;
     a.skip = skip;
-    if (tangent) {
-      if (last) dense<false, true>(e, a);
-      else dense<true, true>(e, a);
-    } else {
-      if (last) dense<false, false>(e, a);
-      else dense<true, false>(e, a);
-    }
+    a.act = last ? m->out_act : m->act;
+    if (tangent) dense<true>(e, a);
+    else dense<false>(e, a);
     if (!last) {
       in = g.act + unit0 * rows;
       tin = tangent ? g.tact + unit0 * rows : nullptr;
@@ -485,6 +512,14 @@ void launch_gen_policy_pass(rl_traj *t, const rl_mlp *m, int mode, const float *
   else if (mode == PASS_PPO) TERMS(PASS_PPO);
   else TERMS(PASS_JVP);
 #undef TERMS
+  RL_HIP_CHECK(hipGetLastError());
+  if (m->out_act != RL_ACT_IDENTITY && mode != PASS_EVAL) {
+    // the loss terms above are functions of the module's OUTPUTS: one more factor back to the output layer's
+    // pre-activation (the forward-mode pass has applied the same slope to the tangent outputs already)
+    const size_t count = (size_t)m->out_dim * B;
+    hipLaunchKernelGGL(k_gen_output_slope, dim3(cdiv_g(count, 256)), dim3(256), 0, t->eng->stream, t->dz, g.z, count,
+                       m->out_act, d_skip);
+  }
 }
 
 void launch_gen_critic_fwd(rl_traj *t, const rl_mlp *m, uint64_t B_total) {
@@ -495,6 +530,10 @@ void launch_gen_critic_fwd(rl_traj *t, const rl_mlp *m, uint64_t B_total) {
   gen_forward_impl(t, m, t->d.obs, plane, B, g.z, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_gen_critic_terms, dim3(t->nbB), dim3(256), 0, t->eng->stream, t->d, g.z, t->dz, t->slabB,
                      2.0f / (float)B_total);
+  RL_HIP_CHECK(hipGetLastError());
+  if (m->out_act != RL_ACT_IDENTITY)
+    hipLaunchKernelGGL(k_gen_output_slope, dim3(cdiv_g(B, 256)), dim3(256), 0, t->eng->stream, t->dz, g.z, (size_t)B,
+                       m->out_act, (const int32_t *)nullptr);
 }
 
 // backward from t->dz ([out][B]) through the activations of the last forward: slab rows [0, nbA) x P
@@ -527,10 +566,11 @@ void launch_gen_backward(rl_traj *t, const rl_mlp *m, const int32_t *d_skip) {
     if (l > 0) {
       float *dX = g.delta + (size_t)(l & 1) * wmax * B;
       hipLaunchKernelGGL(k_gen_delta, dim3(cdiv_g(B, GT)), dim3(256), (size_t)N * GT * sizeof(float), e->stream, dY,
-                         (size_t)B, N, m->d_params + off, K, X, dX, (size_t)B, d_skip);
+                         (size_t)B, N, m->d_params + off, K, X, dX, (size_t)B, m->act, d_skip);
       dY = dX;
     }
   }
+  RL_HIP_CHECK(hipGetLastError());
 }
 
 // ---------------------------------------------------------------- values for GAE / TD targets

@@ -33,42 +33,51 @@ def unflatten(p, in_dim, hidden, out_dim):
     return out
 
 
-def forward64(net, x):
-    """x [rows][in] -> (outputs [rows][out], activations per hidden layer)"""
+def act64(name, pre):
+    """Activation::forward (ff/activation.rs:85-92) -> (output, derivative)"""
+    if name == "Relu":
+        return np.maximum(pre, 0.0), (pre > 0).astype(np.float64)
+    if name == "Sigmoid":
+        y = 1.0 / (1.0 + np.exp(-pre))
+        return y, y * (1.0 - y)
+    if name == "Tanh":
+        y = np.tanh(pre)
+        return y, 1.0 - y * y
+    return pre, np.ones_like(pre)
+
+
+def forward64(net, x, act="Relu", out_act="Identity"):
+    """x [rows][in] -> (outputs [rows][out], per layer (layer outputs, slopes))"""
     acts, h = [], x.astype(np.float64)
     for i, (W, b) in enumerate(net):
-        h = h @ W.T + b
-        if i + 1 < len(net):
-            h = np.maximum(h, 0.0)
-            acts.append(h)
+        h, slope = act64(act if i + 1 < len(net) else out_act, h @ W.T + b)
+        acts.append((h, slope))
     return h, acts
 
 
 def backward64(net, x, acts, dz):
     """gradient of sum(dz * outputs) w.r.t. the flat parameters"""
-    grads, d = [], dz
-    inputs = [x.astype(np.float64)] + acts
+    grads, d = [], dz * acts[-1][1]
+    inputs = [x.astype(np.float64)] + [h for h, _ in acts[:-1]]
     for i in reversed(range(len(net))):
         W, _ = net[i]
         grads.append((d.T @ inputs[i], d.sum(axis=0)))
         if i > 0:
-            d = (d @ W) * (acts[i - 1] > 0)
+            d = (d @ W) * acts[i - 1][1]
     return np.concatenate([np.concatenate([gw.ravel(), gb]) for gw, gb in reversed(grads)])
 
 
-def jvp64(net, tnet, x):
+def jvp64(net, tnet, x, act="Relu", out_act="Identity"):
     h, th = x.astype(np.float64), np.zeros_like(x, dtype=np.float64)
     for i, ((W, b), (V, vb)) in enumerate(zip(net, tnet)):
         th = th @ W.T + h @ V.T + vb
-        h = h @ W.T + b
-        if i + 1 < len(net):
-            th = th * (h > 0)
-            h = np.maximum(h, 0.0)
+        h, slope = act64(act if i + 1 < len(net) else out_act, h @ W.T + b)
+        th = th * slope
     return h, th
 
 
-def make(engine, in_dim, hidden, out_dim, seed):
-    m = ra.Mlp(engine, in_dim, hidden, out_dim)
+def make(engine, in_dim, hidden, out_dim, seed, act="Relu", out_act="Identity"):
+    m = ra.Mlp(engine, in_dim, hidden, out_dim, act, out_act)
     m.init(seed)
     return m
 
@@ -91,6 +100,65 @@ def test_shapes_init_and_forward(engine, hidden):
         want, _ = forward64(unflatten(p, in_dim, hidden, out_dim), x)
         got = m.forward(x)
         assert np.allclose(got, want, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("hidden,act,out_act", [([64, 64], "Tanh", "Identity"), ([32, 16, 8], "Sigmoid", "Tanh"),
+                                                ([128], "Sigmoid", "Identity"), ([100], "Identity", "Sigmoid"),
+                                                ([], "Relu", "Tanh"), ([256, 3], "Relu", "Identity")])
+def test_forward_with_activations_is_bit_exact_against_the_oracle(engine, hidden, act, out_act):
+    """the per-layer kernels' forward — fma order, the shared deterministic sigmoid / tanh — reproduces
+    oracle_mlp_layers_forward_f32 (Mlp::forward, ff/mlp.rs:139-151) bit for bit"""
+    rng = np.random.default_rng(4)
+    for in_dim, out_dim in ((5, 2), (4, 1)):
+        m = make(engine, in_dim, hidden, out_dim, 9, act, out_act)
+        x = (3.0 * rng.normal(size=(257, in_dim))).astype(np.float32)
+        want = O.mlp_layers_forward(in_dim, hidden, out_dim, m.get_params(), x, act, out_act)
+        assert np.array_equal(m.forward(x), want)
+        ref, _ = forward64(unflatten(m.get_params(), in_dim, hidden, out_dim), x, act, out_act)
+        assert np.allclose(want, ref, rtol=2e-5, atol=2e-6)  # and the oracle agrees with the f64 restatement
+
+
+def test_actor_documents_carry_the_activation_variants(engine):
+    """Mlp { layers, activation, output_activation } (ff/mlp.rs:45-50): unit variants as serde writes them — their names"""
+    from cbor_ref import decode
+    env = ra.CartPoleEnv(engine, 64)
+    for act, out_act in (("Tanh", "Identity"), ("Sigmoid", "Tanh"), ("Relu", "Identity")):
+        pol = make(engine, 5, [24, 12], 2, 5, act, out_act)
+        doc = ra.actor_to_cbor(env, pol)
+        def find(v):  # the Mlp map inside the actor document
+            if isinstance(v, dict):
+                if "activation" in v and "layers" in v:
+                    return v
+                v = list(v.values())
+            if isinstance(v, (list, tuple)):
+                for item in v:
+                    hit = find(item)
+                    if hit is not None:
+                        return hit
+            return None
+        mod = find(decode(bytes(doc)))
+        assert mod is not None and mod["activation"] == act and mod["output_activation"] == out_act
+        assert len(mod["layers"]) == 3
+        twin = ra.Mlp(engine, 5, [24, 12], 2, act, out_act)
+        ra.module_from_cbor(twin, doc)
+        assert np.array_equal(twin.get_params(), pol.get_params())
+        other = ra.Mlp(engine, 5, [24, 12], 2, "Relu" if act != "Relu" else "Tanh", out_act)
+        with pytest.raises(ra.RelearnError):  # a document of other activations is not this module's
+            ra.module_from_cbor(other, doc)
+
+
+def test_invalid_activations_are_refused(engine):
+    sizes = (C.c_uint32 * 1)(64)
+    h = C.c_void_p()
+    for a, o in ((4, 0), (-1, 0), (1, 7)):
+        code = ra.lib().rl_mlp_create_layers(engine.h, C.c_uint32(5), sizes, C.c_uint32(1), C.c_uint32(2), C.c_int32(a),
+                                             C.c_int32(o), C.byref(h))
+        assert code == ra.ERR_BUILD_AGENT and not h
+    # the reference's defaults on one hidden layer of <= 128 units are the fused module, anything else the general one
+    q = ra.Mlp(engine, 5, [64], 2, "Tanh", "Identity")
+    env = ra.CartPoleEnv(engine, 64)
+    with pytest.raises(ra.RelearnError):  # DQN: fused modules only
+        ra.Dqn(env, q, ra.Adam(q), ra.dqn_config_default())
 
 
 def test_unsupported_shapes_are_refused(engine):
@@ -169,9 +237,16 @@ def test_rollout_on_the_index_env_lanes(engine):
         assert (got["flag"] == O.INTERRUPT).any() and (got["action"] == 1).any() and (got["action"] == 0).any()
 
 
-@pytest.mark.parametrize("hidden", [[64, 64], [256], [32, 16, 8], []])
-def test_gradients_and_fisher_vector_products(engine, hidden):
-    pol, cri = make(engine, 5, hidden, 2, 21), make(engine, 5, hidden, 1, 22)
+# MlpConfig.activation / output_activation (ff/mlp.rs:18-21, ff/activation.rs:11-20): the reference's defaults on every
+# shape, then every other variant on the hidden layers and on the output
+ACT_CASES = [(h, "Relu", "Identity") for h in ([64, 64], [256], [32, 16, 8], [])] + [
+    ([64, 64], "Tanh", "Identity"), ([32, 16, 8], "Sigmoid", "Identity"), ([48], "Identity", "Identity"),
+    ([64, 64], "Relu", "Tanh"), ([40, 24], "Tanh", "Sigmoid"), ([128], "Tanh", "Identity"), ([], "Relu", "Tanh")]
+
+
+@pytest.mark.parametrize("hidden,act,out_act", ACT_CASES)
+def test_gradients_and_fisher_vector_products(engine, hidden, act, out_act):
+    pol, cri = make(engine, 5, hidden, 2, 21, act, out_act), make(engine, 5, hidden, 1, 22, act, out_act)
     _, traj = collect(engine, pol)
     ra.gae(traj, cri, 0.99, 0.95)
     tr = traj.read_all()
@@ -180,13 +255,13 @@ def test_gradients_and_fisher_vector_products(engine, hidden):
     x = tr["obs"][:, :T, :].reshape(5, B).T
     # ---- values, advantages, returns: the oracle's array-fed scan on f64 values
     cnet = unflatten(cri.get_params(), 5, hidden, 1)
-    v = forward64(cnet, x)[0][:, 0]
+    v = forward64(cnet, x, act, out_act)[0][:, 0]
     assert np.allclose(traj.read(ra.TRAJ_VALUES)[:T].reshape(-1), v, rtol=2e-5, atol=2e-6)
     adv, rtg = traj.read(ra.TRAJ_ADVANTAGES).reshape(-1), traj.read(ra.TRAJ_RETURNS).reshape(-1)
     assert np.isfinite(adv).all() and np.abs(adv).max() > 0
     # ---- policy gradient: loss = -mean(A log pi(a)) at ratio 1 (Trpo / Reinforce closure)
     pnet = unflatten(pol.get_params(), 5, hidden, 2)
-    z, acts = forward64(pnet, x)
+    z, acts = forward64(pnet, x, act, out_act)
     lp = z - np.log(np.exp(z - z.max(axis=1, keepdims=True)).sum(axis=1, keepdims=True)) - z.max(axis=1, keepdims=True)
     p = np.exp(lp)
     a = tr["action"].reshape(-1).astype(np.int64)
@@ -198,7 +273,7 @@ def test_gradients_and_fisher_vector_products(engine, hidden):
     assert np.abs(got - want).max() <= 2e-5 * scale + 1e-9
     # ---- critic gradient: mean((V - returns)^2)
     dv = (2.0 * (v - rtg.astype(np.float64)) / B)[:, None]
-    _, cacts = forward64(cnet, x)
+    _, cacts = forward64(cnet, x, act, out_act)
     cwant = backward64(cnet, x, cacts, dv)
     cgot = ra.critic_gradient(cri, traj)[0]
     assert np.abs(cgot - cwant).max() <= 2e-5 * np.abs(cwant).max() + 1e-9
@@ -206,7 +281,7 @@ def test_gradients_and_fisher_vector_products(engine, hidden):
     rng = np.random.default_rng(5)
     vec = rng.normal(size=pol.P).astype(np.float32)
     tnet = unflatten(vec, 5, hidden, 2)
-    _, tz = jvp64(pnet, tnet, x)
+    _, tz = jvp64(pnet, tnet, x, act, out_act)
     mz = p * (tz - (p * tz).sum(axis=1, keepdims=True)) / B
     fwant = backward64(pnet, x, acts, mz) + 1e-5 * vec.astype(np.float64)
     fgot = ra.policy_fvp(pol, traj, vec, 1e-5)
