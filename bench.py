@@ -26,9 +26,17 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+PMC_SUMMARY = "r03_pmc_65536_summary.json"  # profiles/: counter passes of the build named inside (scripts/pmc_summary.py)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA peak = f32 vector peak
 BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def lib_sha16():
+    """identity of the kernel library this process runs (what the committed counter summaries are matched against)"""
+    import hashlib
+    import relearn_amd as ra
+    return hashlib.sha256(open(ra.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def parse_args():
@@ -255,56 +263,92 @@ def main():
 
     # ---- roofline of the dominant kernel: k_critic_step_mfma (class "critic_fused") -------------------------
     # One launch = forward + MSE loss + backward of the 5-128-1 critic over every sample of the rank.
-    # Algorithmic flops per sample: 3 x critic forward = 3 x 2 x (5*128 + 128*1) = 4608.
+    # The kernel's contractions run on the bf16 matrix pipe as EXACT three-piece splits (relearn_amd/csrc/bf16_tile.hpp:
+    # every product exact, f32 accumulation — f32-equivalent arithmetic), so the roof it sits under is the dense bf16 MFMA
+    # peak and `achieved` counts the flop that pipe EXECUTES: 48 contraction slots x 128 units forward + 32 piece columns
+    # x 128 units backward, 2 flop each = 20,480 per sample.  The algorithmic f32 rate (3 x critic forward =
+    # 4,608 flop per sample) is reported beside it as `f32_equivalent_TFLOPs`, never as a fraction of a roof.
     roofline = None
     roofline_policy = None
     phases = None
+
+    def counters(prefix):
+        """counter evidence of a kernel from the committed PMC summary (separate rocprofv3 --pmc passes over
+        scripts/path_once.py, scripts/pmc_passes.sh), with the build it was taken from"""
+        tpath = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+        out = {"traffic": None, "valu_busy_frac": None, "mfma_busy_frac": None, "valu_issue_frac": None,
+               "source": {"file": "profiles/" + PMC_SUMMARY, "kind": "committed rocprofv3 PMC summary, not measured in this run",
+                          "applies": False}}
+        if not (os.path.exists(tpath) and args.envs // world == 65536 and T == 128):
+            out["source"]["why_not"] = "no summary for this lane count / horizon"
+            return out
+        summary = json.load(open(tpath))
+        out["source"]["collected_from_lib_sha16"] = summary.get("lib_sha16")
+        out["source"]["this_lib_sha16"] = lib_sha16()
+        out["source"]["applies"] = summary.get("lib_sha16") == lib_sha16()
+        for kname, row in summary.get("kernels", {}).items():
+            if kname.startswith(prefix):
+                out["traffic"] = row.get("hbm_bytes_per_launch")
+                out["valu_busy_frac"], out["mfma_busy_frac"] = row.get("valu_busy_frac"), row.get("mfma_busy_frac")
+                if row.get("SQ_INSTS_VALU") and row.get("SQ_BUSY_CU_CYCLES"):
+                    # vector instructions x 4 issue cycles against the SIMD cycles of the launch (4 SIMDs per busy CU cycle)
+                    out["valu_issue_frac"] = 4.0 * row["SQ_INSTS_VALU"] / (4.0 * row["SQ_BUSY_CU_CYCLES"])
+        return out
+
     if prof is not None:
         flop_c = 3 * 2 * (5 * H + H * 1)
         cf_ms, cf_n = prof["critic_fused"]
-        if cf_n == 0:  # v1 kernels (hidden != 128): the separate forward + backward pair
+        fused = cf_n > 0
+        if not fused:  # v1 kernels (hidden != 128): the separate forward + backward pair on the vector unit
             cf_ms = prof["critic_fwd"][0] + prof["backward"][0]
             cf_n = prof["critic_fwd"][1]
-        achieved = flop_c * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
-        # counter evidence of the dominant kernel (separate rocprofv3 --pmc passes over scripts/path_once.py with this
-        # build, scripts/pmc_passes.sh; profiles/README.md): HBM bytes per launch, VALU and matrix-pipe busy fractions
-        traffic = valu_busy = mfma_busy = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_65536_summary.json")
-        if os.path.exists(tpath) and args.envs // world == 65536 and T == 128:
-            for kname, row in json.load(open(tpath)).get("kernels", {}).items():
-                if kname.startswith("k_critic_step_mfma"):
-                    traffic = row.get("hbm_bytes_per_launch")
-                    valu_busy, mfma_busy = row.get("valu_busy_frac"), row.get("mfma_busy_frac")
-        # what the matrix pipe executes per sample: 48 contraction slots x 128 units forward, 32 piece columns x 128
-        # units backward, 2 flop each — bf16 products of exact three-piece splits (relearn_amd/csrc/bf16_tile.hpp)
+        algorithmic = flop_c * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
         bf16_flop = 2 * (48 * H + 32 * H)
         executed = bf16_flop * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
-        roofline = {
-            "kernel": "k_critic_step_mfma", "bound": "valu", "achieved": achieved, "peak": F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS, "traffic": traffic,
-            "valu_busy_frac": valu_busy, "mfma_busy_frac": mfma_busy,
-            "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1),
-            "algorithmic_flop_per_sample": flop_c, "samples_per_launch": B_local,
-            "executed_bf16_TFLOPs": executed, "executed_frac_of_bf16_dense_peak": executed / BF16_PEAK_TFLOPS,
-            "note": "achieved = ALGORITHMIC f32 flop (4608 per sample: 3 x critic forward) / launch time, peak = the f32 "
-                    "MFMA = packed f32 vector peak.  The kernel's GEMM-shaped parts run on the bf16 matrix pipe as EXACT "
-                    "three-piece splits (every product exact, f32 accumulation; no reduced precision), so the algorithmic "
-                    "f32 rate is not capped by the f32 peak: frac may exceed 1.  What binds the kernel is VALU issue "
-                    "(valu_busy_frac; relu', masks, piece splits, the 128 -> 1 layer), not the matrix pipe "
-                    "(mfma_busy_frac; executed bf16 rate given against the 2.5 PFLOP/s dense bf16 peak) and not HBM "
-                    "(traffic, bytes per launch).  Per-rank figures.",
-        }
+        ctr = counters("k_critic_step_mfma")
+        if fused:
+            roofline = {
+                "kernel": "k_critic_step_mfma", "bound": "mfma", "achieved": executed, "peak": BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": executed / BF16_PEAK_TFLOPS, "traffic": ctr["traffic"],
+                "executed_bf16_flop_per_sample": bf16_flop,
+                "f32_equivalent_TFLOPs": algorithmic, "algorithmic_flop_per_sample": flop_c,
+                "valu_issue_frac": ctr["valu_issue_frac"], "valu_busy_frac": ctr["valu_busy_frac"],
+                "mfma_busy_frac": ctr["mfma_busy_frac"], "source": ctr["source"],
+                "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1), "samples_per_launch": B_local,
+                "note": "achieved = flop the bf16 matrix pipe executes (20,480 per sample: exact three-piece splits of "
+                        "f32 operands, f32 accumulation) / launch time, peak = dense bf16 MFMA.  What keeps the pipe "
+                        "from its peak is not HBM (traffic = bytes per launch, 1.0x the algorithmic 24 B per sample) but "
+                        "the SIMD's shared issue port (a vector instruction ~4 cycles, a matrix instruction 8, an LDS "
+                        "instruction 14-25: profiles/r03_slot_cost.txt) and per-tile latency chains at two waves per "
+                        "SIMD (DESIGN 5.3); valu_issue_frac / *_busy_frac are counter-derived (see source).  Per-rank "
+                        "figures.",
+            }
+        else:
+            roofline = {
+                "kernel": "k_critic_fwd + k_mlp_backward (v1, vector unit)", "bound": "mfma", "achieved": algorithmic,
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": algorithmic / F32_PEAK_TFLOPS, "traffic": None,
+                "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1), "samples_per_launch": B_local,
+                "algorithmic_flop_per_sample": flop_c,
+                "note": "hidden != 128: the first-generation f32 kernels; achieved = algorithmic f32 flop against the f32 "
+                        "vector / MFMA peak",
+            }
         tot = sum(v[0] for v in prof.values())
         phases = {k: {"ms_per_step": v[0] / prof_steps, "launches_per_step": v[1] / prof_steps,
                       "share": (v[0] / tot if tot > 0 else 0.0)} for k, v in prof.items() if v[1]}
         fv_ms, fv_n = prof.get("policy_fvp", (0.0, 0))
         if fv_n:
-            # Fisher-vector product launch of the fused policy kernel: forward + tangent forward + 2x backward of
-            # the 5-128-2 MLP = 4 x 2 x (5*128 + 128*2) = 7168 algorithmic flop per sample
+            # Fisher-vector product launch of the fused policy kernel.  Algorithmic: forward + tangent forward + 2x
+            # backward of the 5-128-2 MLP = 4 x 2 x (5*128 + 128*2) = 7,168 f32 flop per sample.  Executed on the bf16
+            # pipe: forward 48 slots + tangent forward 48 slots + backward 32 columns, x 128 units x 2 = 32,768.
             flop_p = 4 * 2 * (5 * H + H * 2)
             ach = flop_p * B_local * fv_n / (fv_ms * 1e-3) / 1e12
-            roofline_policy = {"kernel": "k_policy_bf16<PASS_JVP>", "bound": "valu", "achieved": ach,
-                               "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_PEAK_TFLOPS,
+            exe = 2 * (48 + 48 + 32) * H * B_local * fv_n / (fv_ms * 1e-3) / 1e12
+            pc = counters("void k_policy_bf16<2")
+            roofline_policy = {"kernel": "k_policy_bf16<PASS_JVP>", "bound": "mfma", "achieved": exe,
+                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exe / BF16_PEAK_TFLOPS,
+                               "traffic": pc["traffic"], "f32_equivalent_TFLOPs": ach,
+                               "valu_issue_frac": pc["valu_issue_frac"], "valu_busy_frac": pc["valu_busy_frac"],
+                               "mfma_busy_frac": pc["mfma_busy_frac"], "source": pc["source"],
                                "launches": int(fv_n), "avg_launch_us": 1e3 * fv_ms / fv_n,
                                "algorithmic_flop_per_sample": flop_p, "samples_per_launch": B_local}
         pf_ms, pf_n = prof["policy_fused"]
@@ -372,6 +416,16 @@ def main():
             print("bench.py: rank %d: replicas diverged under the %s collective: %s" % (rank, comm_kind, digests),
                   file=sys.stderr, flush=True)
         dist.barrier()
+    # what the collective cost each rank (launches and time per period), so that a scaling run explains itself
+    allreduce_per_rank = None
+    if dist is not None:
+        mine = None
+        if prof is not None and prof.get("allreduce", (0.0, 0))[1]:
+            ar_ms, ar_n = prof["allreduce"]
+            mine = {"rank": rank, "launches_per_step": ar_n / prof_steps, "us_per_launch": 1e3 * ar_ms / ar_n,
+                    "ms_per_step": ar_ms / prof_steps}
+        allreduce_per_rank = [None] * world
+        dist.all_gather_object(allreduce_per_rank, mine)
     if rank == 0:
         st = last["trpo"]
         out = {
@@ -403,11 +457,15 @@ def main():
             "cpu_baseline": cpu,
             "phases": phases,
             "replicas_identical": replicas_identical,
+            "allreduce_per_rank": allreduce_per_rank,
             "last_update": {"trpo_status": st.status, "num_backtracks": st.num_backtracks,
                             "kl": st.constraint_val_final, "entropy": st.entropy,
                             "critic_loss_first": last["critic"].loss_first,
                             "critic_loss_last": last["critic"].loss_last},
         }
+        if replicas_identical is False:  # an invalid run has no headline number
+            out["value"] = None
+            out["invalid"] = "the ranks' parameter replicas differ after the timed region"
         print(json.dumps(out))
     if dist is not None:
         try:
@@ -416,6 +474,8 @@ def main():
             print("bench.py: rank %d: comm_destroy: %s" % (rank, exc), file=sys.stderr)
         dist.barrier()
         dist.destroy_process_group()
+    if replicas_identical is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -428,23 +428,42 @@ int32_t rl_comm_init_host(rl_engine *e, int32_t rank, int32_t n_ranks, rl_host_a
   });
 }
 
+// Every rank sends pseudo-random payloads that every rank can recompute: small integers, so that the expected sum is
+// exact in f32 whatever order a transport adds in.  240 rounds x {2048, 1030, 901, 64, 4} elements: on the mailbox
+// transport that is every one of the 32 chunks, both slots many times over, sequence numbers running — a torn or stale
+// 64-bit word, or a lost store, shows up as a wrong element.
+static inline int32_t selftest_payload(uint32_t round, uint32_t rank, uint32_t i) {
+  uint64_t z = ((uint64_t)round << 40) ^ ((uint64_t)rank << 32) ^ (uint64_t)i;
+  z += 0x9E3779B97F4A7C15ull;  // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (int32_t)(z & 0xFFFF) - 32768;
+}
+
 int32_t rl_comm_selftest(rl_engine *e) {
   return guarded(e, [&] {
     RL_REQUIRE(e, "engine is NULL");
-    const uint32_t count = 1030;  // the longest vector of the feed-forward updates
-    std::vector<float> h(count);
-    float *d = dalloc<float>(count);
+    const uint32_t sizes[5] = {2048, 1030, 901, 64, 4};  // IPC_CAP; policy gradient + scalars; critic; one chunk; scalars
+    std::vector<float> h(2048);
+    float *d = dalloc<float>(2048);
     try {
-      for (int round = 0; round < 3; ++round) {
-        for (uint32_t i = 0; i < count; ++i) h[i] = (float)((e->rank + 1) * (int)(i % 7 + 1 + round));
+      for (uint32_t round = 0; round < 240; ++round) {
+        const uint32_t count = sizes[round % 5];
+        for (uint32_t i = 0; i < count; ++i) h[i] = (float)selftest_payload(round, (uint32_t)e->rank, i);
         h2d(e, d, h.data(), count * sizeof(float));
         rl_allreduce_sum_f32(e, d, count);
-        d2h(e, h.data(), d, count * sizeof(float));
-        ipc_check(e);
-        const int tri = e->n_ranks * (e->n_ranks + 1) / 2;
-        for (uint32_t i = 0; i < count; ++i)
-          if (h[i] != (float)(tri * (int)(i % 7 + 1 + round)))
-            throw RlError(RL_ERR_COMM, "collective self-test: wrong sum at element " + std::to_string(i));
+        if (round % 16 == 15 || round == 239) {  // (between checks the collectives run back to back, as in an update)
+          d2h(e, h.data(), d, count * sizeof(float));
+          ipc_check(e);
+          for (uint32_t i = 0; i < count; ++i) {
+            int32_t want = 0;
+            for (int r = 0; r < e->n_ranks; ++r) want += selftest_payload(round, (uint32_t)r, i);
+            if (h[i] != (float)want)
+              throw RlError(RL_ERR_COMM, "collective self-test: wrong sum at element " + std::to_string(i) + " of round " +
+                                             std::to_string(round));
+          }
+        }
       }
     } catch (...) {
       dfree(d);

@@ -48,12 +48,17 @@ struct TensorDefView {
   const std::string *data = nullptr;
 };
 
-// the reader is strict about what serde's derived Deserialize accepts from serde_cbor's writer: five fields, known
-// variant names, native byte order (`From<&TensorDef> for Tensor` asserts it, serialize.rs:110-114), consistent sizes
+// the reader accepts what serde's derived Deserialize accepts: the five fields of the struct in ANY order (a map is
+// keyed, not positional), each exactly once, known variant names, native byte order (`From<&TensorDef> for Tensor`
+// asserts it, serialize.rs:110-114), consistent sizes
 static TensorDefView cbor_parse_tensor_def(const cbor::Value &t) {
-  static const char *const order[5] = {"kind", "shape", "requires_grad", "byte_order", "data"};
+  static const char *const names[5] = {"kind", "shape", "requires_grad", "byte_order", "data"};
   RL_REQUIRE(t.kind == cbor::Value::MAP && t.fields.size() == 5, "CBOR tensor: expected the five TensorDef fields");
-  for (int i = 0; i < 5; ++i) RL_REQUIRE(t.fields[i].first == order[i], "CBOR tensor: unexpected field order");
+  for (int i = 0; i < 5; ++i) {
+    int seen = 0;
+    for (const auto &f : t.fields) seen += f.first == names[i];
+    RL_REQUIRE(seen == 1, "CBOR tensor: every TensorDef field exactly once");
+  }
   TensorDefView v;
   const cbor::Value &k = t.at("kind");
   RL_REQUIRE(k.kind == cbor::Value::TEXT, "CBOR tensor: kind must be a unit variant name");
@@ -71,6 +76,8 @@ static TensorDefView cbor_parse_tensor_def(const cbor::Value &t) {
     const int64_t d = it->as_int();
     RL_REQUIRE(d >= 0, "CBOR tensor: negative extent");
     v.shape.push_back(d);
+    // the element count must stay a count: [2^32, 2^32] would wrap to 0 and pass the length check with empty data
+    RL_REQUIRE(d == 0 || count <= (uint64_t(1) << 40) / (uint64_t)d, "CBOR tensor: the shape's element count overflows");
     count *= (uint64_t)d;
   }
   const cbor::Value &rg = t.at("requires_grad");

@@ -393,6 +393,7 @@ int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float
     check_critic(critic, traj);
     RL_REQUIRE(grad_out, "grad_out is NULL");
     uint32_t P = (uint32_t)critic->P;
+    traj->d.tgt = traj->d.rtg;  // the documented loss: MSE against RL_TRAJ_RETURNS, whatever targets an update left behind
     run_critic_gradient(critic, traj);
     std::vector<float> h(P + 4);
     d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));

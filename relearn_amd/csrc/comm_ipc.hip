@@ -12,7 +12,17 @@
 // finished reading k.
 // This replaces the `Vec<buffer>` hand-off of the reference's threads (src/simulation/train.rs:180) for the multi-GPU
 // configuration; RCCL (abi.hip) stays the default transport — its small-message latency is what this path avoids.
-// Every spin is bounded: a peer that never arrives sets the engine's error word and the wave leaves the loop.
+// Every wait is bounded in wall-clock time (30 s by default, RELEARN_IPC_TIMEOUT_MS; rank skew — a first-launch code
+// object load, a host stall, a profiler — is far below that): a peer that never arrives sets the engine's STICKY error
+// word, the wave returns before it stores anything (no stale sum reaches the vector, the parameters or the optimiser
+// state), every later collective fails fast without publishing, and the host raises RL_ERR_COMM at its next
+// synchronising call.
+// EXPERIMENTAL: the protocol has run between processes sharing one GPU (IPC handles of one device map like peer windows)
+// and never across xGMI; rl_comm_init_ipc checks what it can for mailboxes on other devices (peer access, native
+// atomics), the self-test hammers both slots and every chunk with random payloads, but 8-byte store atomicity and
+// visibility through a real peer window are unverified on this pool.  RCCL is the default transport.
+#include <cstdlib>
+
 #include "abi_internal.hpp"
 #include "comm_ipc.hpp"
 
@@ -22,7 +32,8 @@ namespace {
 __global__ void __launch_bounds__(IPC_CHUNK) k_ipc_allreduce(float *__restrict__ vec, uint32_t count, IpcPeers peers) {
   const uint32_t chunk = blockIdx.x, p = chunk * IPC_CHUNK + threadIdx.x;
   const float mine = p < count ? vec[p] : 0.0f;
-  const float s = ipc_exchange_chunk(peers, chunk, threadIdx.x, mine);
+  float s;
+  if (!ipc_exchange_chunk(peers, chunk, threadIdx.x, mine, s)) return;  // failed: vec keeps the local values
   if (p < count) vec[p] = s;
 }
 
@@ -65,7 +76,7 @@ int32_t rl_comm_ipc_handle(rl_engine *e, int32_t n_ranks, uint8_t handle_out[64]
     RL_REQUIRE(!e->has_collective(), "communicator already initialised");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
     RL_HIP_CHECK(hipSetDevice(e->device));
-    if (e->ipc_box == nullptr) {
+    if (e->ipc_box == nullptr) try {
       const size_t bytes = ipc_box_bytes((uint32_t)n_ranks);
       void *p = nullptr;
       // fine-grained: peers' stores and this device's loads of the mailbox are coherent without cache maintenance
@@ -76,6 +87,15 @@ int32_t rl_comm_ipc_handle(rl_engine *e, int32_t n_ranks, uint8_t handle_out[64]
       e->ipc_err = dalloc<int32_t>(1);
       RL_HIP_CHECK(hipMemsetAsync(e->ipc_err, 0, sizeof(int32_t), e->stream));
       sync(e);
+      uint64_t ms = IPC_TIMEOUT_MS_DEFAULT;
+      if (const char *env = std::getenv("RELEARN_IPC_TIMEOUT_MS")) {
+        const long long v = std::atoll(env);
+        if (v > 0) ms = (uint64_t)v;
+      }
+      e->ipc_timeout_ticks = ms * 100000ull;  // s_memrealtime counts at 100 MHz
+    } catch (...) {  // all or nothing: a retry must not find a mailbox without its error word
+      ipc_teardown(e);
+      throw;
     }
     RL_REQUIRE(e->ipc_box_ranks == n_ranks, "the mailbox was sized for another number of ranks");
     hipIpcMemHandle_t h;
@@ -102,6 +122,18 @@ int32_t rl_comm_init_ipc(rl_engine *e, int32_t rank, int32_t n_ranks, const uint
         void *p = nullptr;
         RL_HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
         e->ipc_peer[r] = (float *)p;
+        // a mailbox on ANOTHER device is reached through a peer window: the protocol needs peer access and 64-bit
+        // stores that land as one unit (native atomics over the link); refuse the transport otherwise
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device != e->device) {
+          int can = 0, atomics = 0;
+          RL_HIP_CHECK(hipDeviceCanAccessPeer(&can, e->device, attr.device));
+          if (can) (void)hipDeviceGetP2PAttribute(&atomics, hipDevP2PAttrNativeAtomicSupported, e->device, attr.device);
+          if (!can || !atomics)
+            throw RlError(RL_ERR_COMM, "peer-mailbox transport: device " + std::to_string(e->device) +
+                                           (can ? " has no native atomics to device " : " cannot access device ") +
+                                           std::to_string(attr.device) + " (use RCCL)");
+        }
       }
     } catch (...) {
       for (int r = 0; r < n_ranks; ++r) {

@@ -9,7 +9,7 @@
 constexpr uint32_t IPC_CAP = 2048;             // floats per vector (the MLP updates need <= 1030)
 constexpr uint32_t IPC_CHUNK = 64;             // columns per exchanging wave
 constexpr uint32_t IPC_CHUNKS = IPC_CAP / IPC_CHUNK;
-constexpr uint32_t IPC_SPIN_LIMIT = 1u << 24;  // polls of ~1 us before a wait gives up
+constexpr uint64_t IPC_TIMEOUT_MS_DEFAULT = 30000;  // wall-clock bound of one wait (RELEARN_IPC_TIMEOUT_MS overrides it)
 
 // layout of one mailbox (receiver-owned): words[sender][slot][IPC_CAP], one 64-bit word per vector element =
 // {sequence number of the collective : 32 | the float's bits : 32}
@@ -21,7 +21,8 @@ inline size_t ipc_box_bytes(uint32_t n_ranks) { return (size_t)n_ranks * 2 * IPC
 struct IpcPeers {
   float *box[RL_IPC_MAX_RANKS];  // box[r] = rank r's mailbox as seen from this process (box[rank] = the own one)
   uint32_t rank, n_ranks, seq;
-  int32_t *err;
+  int32_t *err;                  // sticky error word of the engine: 0, or 1 + the rank that never arrived
+  uint64_t timeout_ticks;        // bound of one wait in ticks of the constant 100 MHz counter (s_memrealtime)
 };
 
 inline IpcPeers ipc_peers_next(rl_engine *e) {  // the descriptor of the engine's NEXT collective
@@ -32,6 +33,7 @@ inline IpcPeers ipc_peers_next(rl_engine *e) {  // the descriptor of the engine'
   p.n_ranks = (uint32_t)e->n_ranks;
   p.seq = e->ipc_seq;
   p.err = e->ipc_err;
+  p.timeout_ticks = e->ipc_timeout_ticks;
   return p;
 }
 
@@ -41,7 +43,13 @@ inline IpcPeers ipc_peers_next(rl_engine *e) {  // the descriptor of the engine'
 // stores, a system-scope release fence, one flag per chunk, an acquire fence — cost 26 us per collective with two
 // processes on one GPU: on this part a release / acquire fence at device or system scope writes back and invalidates
 // the L2 of the XCD)
-__device__ __forceinline__ float ipc_exchange_chunk(const IpcPeers &pe, uint32_t chunk, uint32_t l, float mine) {
+// Returns false — for the WHOLE wave, and then `sum` is not to be used: the caller returns before it stores anything —
+// when the engine's error word is already set (an earlier collective failed: every later one fails fast, nothing is
+// published) or when a peer's word has not arrived within the wall-clock bound.  A timeout sets the error word and
+// stays set; the host raises RL_ERR_COMM at its next synchronising call (ipc_check).
+__device__ __forceinline__ bool ipc_exchange_chunk(const IpcPeers &pe, uint32_t chunk, uint32_t l, float mine,
+                                                   float &sum) {
+  if (__hip_atomic_load(pe.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;  // wave-uniform
   const uint32_t slot = pe.seq & 1u, p = chunk * IPC_CHUNK + l;
   const uint64_t word = ((uint64_t)pe.seq << 32) | (uint64_t)__builtin_bit_cast(uint32_t, mine);
   // publish: my row in every mailbox (the own one included)
@@ -50,21 +58,28 @@ __device__ __forceinline__ float ipc_exchange_chunk(const IpcPeers &pe, uint32_t
                        __HIP_MEMORY_SCOPE_SYSTEM);
   // gather: this column from every rank's row of the own mailbox, in rank order
   const uint64_t *own = reinterpret_cast<const uint64_t *>(pe.box[pe.rank]);
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   float s = 0.0f;
+  int32_t missing = 0;  // 1 + the first rank whose word this lane gave up on
   for (uint32_t r = 0; r < pe.n_ranks; ++r) {
     const uint64_t *q = own + ipc_word_off(r, slot) + p;
     uint64_t w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t spins = 0;
+    uint32_t polls = 0;
     while ((uint32_t)(w >> 32) != pe.seq) {  // (a slot is rewritten two collectives later, after this read: header of comm_ipc.hip)
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > IPC_SPIN_LIMIT) {
-        atomicExch(pe.err, (int32_t)(1 + r));  // which rank never arrived (1-based)
+      if ((++polls & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > pe.timeout_ticks) {
+        missing = (int32_t)(1 + r);
         break;
       }
       w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (missing != 0) break;
     const float v = __builtin_bit_cast(float, (uint32_t)w);
     s = r == 0 ? v : s + v;
   }
-  return s;
+  sum = s;
+  // the decision is the wave's, not the lane's: one late word fails the whole chunk, nobody stores a partial sum
+  const bool ok = __builtin_amdgcn_ballot_w64(missing != 0) == 0;
+  if (!ok && missing != 0) atomicCAS(pe.err, 0, missing);  // first failure wins and stays
+  return ok;
 }

@@ -132,6 +132,7 @@ struct rl_engine {
   float *ipc_peer[RL_IPC_MAX_RANKS] = {nullptr};
   int32_t *ipc_err = nullptr;
   uint32_t ipc_seq = 0;
+  uint64_t ipc_timeout_ticks = 0;  // bound of one mailbox wait, 100 MHz ticks (RELEARN_IPC_TIMEOUT_MS)
   int ipc_box_ranks = 0, ipc_rank_of_box = -1;
   bool ipc_active = false;
   // any collective between a reduction and its consumer?  (false: the two may be fused into one launch)

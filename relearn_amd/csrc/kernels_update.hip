@@ -508,7 +508,11 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
 #pragma unroll
   for (int k = 1; k < 16; ++k) t = t + part[k][lane];
   float gsum = (float)t;
-  if (XCHG) gsum = ipc_exchange_chunk(peers, blockIdx.x, (uint32_t)lane, p < P + 4 ? gsum : 0.0f);  // all 64 lanes
+  if (XCHG) {  // all 64 lanes; a failed exchange (sticky error word, comm_ipc.hpp) leaves vec, params and moments alone
+    float total;
+    if (!ipc_exchange_chunk(peers, blockIdx.x, (uint32_t)lane, p < P + 4 ? gsum : 0.0f, total)) return;
+    gsum = total;
+  }
   if (p >= P + 4) return;
   vec[p] = gsum;
   if (p == 0) *step_ptr = step;

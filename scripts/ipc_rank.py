@@ -1,6 +1,8 @@
 """One rank of a multi-PROCESS job over the peer-mailbox collective (rl_comm_init_ipc), all ranks on device 0 — the
 functional rehearsal a one-GPU box allows: IPC handles of one device map into other processes exactly like peer windows
-do.  Handles are exchanged through files in `dir`.   usage: ipc_rank.py <rank> <world> <dir> [n_total] [T]"""
+do.  Handles are exchanged through files in `dir`.   usage: ipc_rank.py <rank> <world> <dir> [n_total] [T] [desert]
+`desert`: the last rank leaves right after the communicator exists; the others must see RL_ERR_COMM within the wait
+bound (RELEARN_IPC_TIMEOUT_MS), with their parameters and optimiser state untouched, and fail fast afterwards."""
 import os
 import sys
 import time
@@ -13,6 +15,7 @@ import relearn_amd as ra  # noqa: E402
 rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 n_total = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 T = int(sys.argv[5]) if len(sys.argv) > 5 else 48
+desert = len(sys.argv) > 6 and sys.argv[6] == "desert"
 
 
 def wait_for(paths, what, limit=120.0):
@@ -32,6 +35,43 @@ if world > 1:
     files = [os.path.join(d, "h%d.bin" % r) for r in range(world)]
     wait_for(files, "the peers' mailbox handles")
     eng.comm_init_ipc(rank, world, [open(f, "rb").read() for f in files])
+    if desert:
+        if rank == world - 1:
+            # stay mapped (nobody writes into freed memory) but never take part in a collective
+            open(os.path.join(d, "deserted"), "w").close()
+            wait_for([os.path.join(d, "seen%d" % r) for r in range(world - 1)], "the others to notice")
+            print("rank %d of %d deserted" % (rank, world))
+            sys.exit(0)
+        wait_for([os.path.join(d, "deserted")], "the deserter")
+        cri = ra.Mlp(eng, 5, 128, 1)
+        cri.init(3)
+        opt = ra.Adam(cri)
+        env = ra.CartPoleEnv(eng, 64, max_steps=30, lane_offset=rank * 64)
+        pol = ra.Mlp(eng, 5, 128, 2)
+        pol.init(2)
+        traj = ra.Trajectory(eng, 64, 16, 5)
+        ra.rollout(env, pol, traj)
+        ra.gae(traj, cri, 0.99, 0.95)
+        before = cri.get_params()
+        t0 = time.time()
+        try:
+            ra.critic_update(cri, opt, traj, 3)
+            eng.sync()
+            sys.exit("rank %d: the update with a missing peer did not fail" % rank)
+        except ra.RelearnError as err:
+            assert err.code == ra.ERR_COMM, err
+        first = time.time() - t0
+        assert np.array_equal(cri.get_params(), before), "a failed exchange must not step the parameters"
+        t0 = time.time()
+        try:
+            eng.comm_selftest()
+            sys.exit("rank %d: a collective after the failure did not fail" % rank)
+        except ra.RelearnError as err:
+            assert err.code == ra.ERR_COMM, err
+        again = time.time() - t0
+        print("rank %d of %d saw the timeout after %.2f s, then failed fast in %.3f s" % (rank, world, first, again))
+        open(os.path.join(d, "seen%d" % rank), "w").close()
+        sys.exit(0)
     eng.comm_selftest()
 n = n_total // world
 env = ra.CartPoleEnv(eng, n, max_steps=30, lane_offset=rank * n, seed_env=0, seed_actor=1)

@@ -56,7 +56,11 @@ cal = calib()
 passes = {p: load(os.path.join(root, p)) for p in ("sq_a", "sq_b", "fetch", "write")}
 dur = durations(os.path.join(root, "sq_a"))
 kernels = sorted({k for agg, _ in passes.values() for k in agg})
-summary = {"calibration": cal, "kernels": {}}
+import hashlib
+_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "relearn_amd", "librelearn_hip.so")
+summary = {"calibration": cal, "kernels": {},
+           # the build these counters belong to: bench.py reports them only as applying when it runs the same library
+           "lib_sha16": hashlib.sha256(open(_lib, "rb").read()).hexdigest()[:16] if os.path.exists(_lib) else None}
 for k in kernels:
     if k.startswith("__amd") or "fillBuffer" in k:
         continue

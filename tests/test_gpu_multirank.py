@@ -223,48 +223,86 @@ def test_rccl_is_bound_next_to_the_hip_runtime_in_use(order):
     assert rccl and hip and os.path.realpath(os.path.dirname(rccl)) == os.path.realpath(os.path.dirname(hip)), bound
 
 
-def test_two_processes_over_the_peer_mailbox_collective(tmp_path):
-    """rl_comm_init_ipc: two PROCESSES on this box's one GPU exchange their mailbox handles and run sharded updates
-    through the single-launch all-reduce (scripts/ipc_rank.py); the library's self-test passes on both, both end with
-    identical replicas, and the job agrees with the one-process run like the in-process loopback group does."""
+def _run_ipc_ranks(tmp_path, world, extra=(), env_extra=None, limit=200):
+    """`world` processes of scripts/ipc_rank.py on this box's one GPU, handle files in a directory of their own"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "scripts", "ipc_rank.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    d = os.path.join(str(tmp_path), "world%d%s" % (world, "_".join(extra)))
+    os.makedirs(d)
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), d] + list(extra), cwd=root, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            import signal
+            for q in procs:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+            raise AssertionError("ipc_rank.py (world %d) did not finish within %d s" % (world, limit))
+        outs.append(o.decode())
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+    return d, outs
 
-    def run(world):
-        procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(tmp_path)], cwd=root, env=env,
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
-                 for r in range(world)]
-        outs = []
-        for p in procs:
-            try:
-                o, _ = p.communicate(timeout=200)
-            except subprocess.TimeoutExpired:
-                import signal
-                for q in procs:
-                    try:
-                        os.killpg(q.pid, signal.SIGKILL)
-                    except ProcessLookupError:
-                        pass
-                raise AssertionError("ipc_rank.py (world %d) did not finish within 200 s" % world)
-            outs.append(o.decode())
-        for p, o in zip(procs, outs):
-            assert p.returncode == 0, o[-2000:]
-        return [dict(np.load(os.path.join(str(tmp_path), "out%d_of_%d.npz" % (r, world)))) for r in range(world)]
 
-    single = run(1)[0]
-    double = run(2)
-    assert single["allreduce_launches"][0] == 0
-    assert double[0]["allreduce_launches"][0] == double[1]["allreduce_launches"][0] > 2 * (1 + 11 + 1 + 6)
-    for period in range(2):
-        assert np.array_equal(double[0]["policy%d" % period], double[1]["policy%d" % period])
-        assert np.array_equal(double[0]["critic%d" % period], double[1]["critic%d" % period])
-    assert np.array_equal(np.concatenate([double[0]["action"], double[1]["action"]], axis=1), single["action"])
-    assert np.array_equal(np.concatenate([double[0]["adv"], double[1]["adv"]], axis=1), single["adv"])
-    a, b = double[0]["trpo0"], single["trpo0"]
+def _ipc_results(tmp_path, world):
+    d, _ = _run_ipc_ranks(tmp_path, world)
+    return [dict(np.load(os.path.join(d, "out%d_of_%d.npz" % (r, world)))) for r in range(world)]
+
+
+def _check_sharded_against_single(ranks, single):
+    world = len(ranks)
+    assert len({int(r["allreduce_launches"][0]) for r in ranks}) == 1
+    assert ranks[0]["allreduce_launches"][0] > 2 * (1 + 11 + 1 + 6)
+    for period in range(2):  # every rank ends every update with the same replica, bit for bit
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0]["policy%d" % period], r["policy%d" % period])
+            assert np.array_equal(ranks[0]["critic%d" % period], r["critic%d" % period])
+    assert np.array_equal(np.concatenate([r["action"] for r in ranks], axis=1), single["action"])
+    assert np.array_equal(np.concatenate([r["adv"] for r in ranks], axis=1), single["adv"])
+    a, b = ranks[0]["trpo0"], single["trpo0"]
     assert abs(a[0] - b[0]) < 1e-6 and abs(a[1] - b[1]) < 1e-6 and a[3] == b[3] and a[4] == b[4]
     assert abs(a[2] - b[2]) < 1e-1 * b[2]  # CG-amplified rounding, see test_two_ranks_equal_one_rank
-    assert np.max(np.abs(double[0]["losses0"] - single["losses0"]) / single["losses0"]) < 1e-5
-    assert np.mean(np.abs(double[0]["critic0"] - single["critic0"]) < 2e-5) > 0.97
+    assert np.max(np.abs(ranks[0]["losses0"] - single["losses0"]) / single["losses0"]) < 1e-5
+    assert np.mean(np.abs(ranks[0]["critic0"] - single["critic0"]) < 2e-5) > 0.97
+    assert world >= 2
+
+
+def test_two_processes_over_the_peer_mailbox_collective(tmp_path):
+    """rl_comm_init_ipc: two PROCESSES on this box's one GPU exchange their mailbox handles and run sharded updates
+    through the single-launch all-reduce (scripts/ipc_rank.py); the library's self-test (240 rounds of random payloads
+    over every chunk and both slots) passes on both, both end with identical replicas, and the job agrees with the
+    one-process run like the in-process loopback group does."""
+    single = _ipc_results(tmp_path, 1)[0]
+    assert single["allreduce_launches"][0] == 0
+    _check_sharded_against_single(_ipc_results(tmp_path, 2), single)
+
+
+def test_four_processes_over_the_peer_mailbox_collective(tmp_path):
+    """the same with FOUR ranks: four rows per mailbox, sums of four terms in rank order, slot reuse with three peers
+    that may each be a collective ahead or behind (VERDICT round 2, next 8 i)"""
+    single = _ipc_results(tmp_path, 1)[0]
+    _check_sharded_against_single(_ipc_results(tmp_path, 4), single)
+
+
+def test_a_missing_peer_fails_the_mailbox_collective_without_touching_the_replica(tmp_path):
+    """A rank that never joins a collective: the others' waits end at the wall-clock bound (here 1.5 s), the exchange
+    returns before anything is stored — the critic's parameters are bit-identical to what they were —, the engine's
+    error word is sticky (the next collective fails in milliseconds, not after another bound), and both surface as
+    RL_ERR_COMM (comm_ipc.hpp)."""
+    _, outs = _run_ipc_ranks(tmp_path, 3, extra=("512", "48", "desert"), env_extra={"RELEARN_IPC_TIMEOUT_MS": "1500"},
+                             limit=120)
+    assert "deserted" in outs[2]
+    for o in outs[:2]:
+        assert "saw the timeout" in o, o[-1500:]
+        secs = float(o.split("saw the timeout after ")[1].split(" s")[0])
+        fast = float(o.split("failed fast in ")[1].split(" s")[0])
+        assert 1.0 < secs < 30.0 and fast < 1.0, o[-500:]

@@ -41,6 +41,7 @@ def test_one_step_td_targets_and_update_mlp(engine, variant):
         cfg = ra.values_opt_config_default()
         cfg.opt_steps_per_update, cfg.target, cfg.discount_factor = steps, ra.VALUE_TARGET_ONE_STEP_TD, 0.97
         opt = ra.Adam(critic)
+        ra.gae(traj, critic, 0.97, 0.95)  # RL_TRAJ_RETURNS of the initial critic (used at the end of this test)
         st, losses_d = ra.values_opt_update(critic, opt, traj, cfg, want_losses=True)
         # targets: computed once from the critic as it stood BEFORE the first step (tch::no_grad, opt.rs:101-104)
         td_o = O.lanes_one_step_targets(CS, cp, want, np.float32(0.97))
@@ -60,6 +61,16 @@ def test_one_step_td_targets_and_update_mlp(engine, variant):
         assert np.allclose(losses_d, losses_o, rtol=1e-4)
         assert np.abs(critic.get_params() - c_o).max() < 2e-5 + 1e-3 * steps * 1e-3
         assert st.steps == steps and losses_d[-1] < losses_d[0]
+        # rl_critic_gradient is the MSE against RL_TRAJ_RETURNS whatever targets the last update regressed on
+        # (the target pointer used to stay on the TD targets)
+        c_now = critic.get_params()
+        g_d, loss_d = ra.critic_gradient(critic, traj)
+        _, _, rtg_o = O.lanes_gae(CS, cp, want, 0.97, 0.95)
+        g_o = np.zeros_like(c_now)
+        lo = C.c_float()
+        L.oracle_critic_grad_f32(CS, O.f32p(c_now), O.f32p(x), O.f32p(np.ascontiguousarray(rtg_o.reshape(-1))), len(a),
+                                 O.f32p(g_o), C.byref(lo))
+        assert np.abs(g_d - g_o).max() <= 1e-5 * np.abs(g_o).max() and abs(loss_d - lo.value) <= 1e-5 * lo.value
     finally:
         engine.set_kernel_variant(0)
 

@@ -49,9 +49,14 @@ def test_reader_refuses_what_serde_refuses():
     assert ra.tensor_def_from_cbor(encode(good)) == ("Float", [2], True, bytes(8))
     for bad in (dict(good, kind="Float32"), dict(good, byte_order="BigEndian"), dict(good, byte_order="Native"),
                 dict(good, data=bytes(7)), dict(good, shape=[-2]), dict(good, requires_grad=1),
-                {k: good[k] for k in ("shape", "kind", "requires_grad", "byte_order", "data")},
+                dict(good, shape=[1 << 32, 1 << 32], data=b""),  # the element count must not wrap to 0
+                dict(good, shape=[1 << 62, 4], data=b""),
                 {k: good[k] for k in ("kind", "shape", "requires_grad", "byte_order")}):
         with pytest.raises(ra.RelearnError):
             ra.tensor_def_from_cbor(encode(bad))
     with pytest.raises(ra.RelearnError):
         ra.tensor_def_from_cbor(encode(good)[:-1])
+    # a map is keyed, not positional: serde's derived Deserialize takes the fields in any order
+    for order in (("shape", "kind", "requires_grad", "byte_order", "data"),
+                  ("data", "byte_order", "requires_grad", "shape", "kind")):
+        assert ra.tensor_def_from_cbor(encode({k: good[k] for k in order})) == ("Float", [2], True, bytes(8))
