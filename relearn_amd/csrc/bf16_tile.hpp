@@ -196,6 +196,54 @@ __device__ __forceinline__ void mask_tile(const f32x16 &c, Frag (&ga)[2]) {
       ga[s].u[i] = mask_pair(s + i == 0 ? first : c[8 * s + 2 * i], c[8 * s + 2 * i + 1], first);
 }
 
+// The pieces of u = g x~ from the sample lanes to the backward's B operand (sample in the registers, piece column on
+// the lane) WITHOUT LDS (round 3; an LDS instruction costs 14-25 cycles of the SIMD's issue port and the write -> read
+// round trip sits in every tile's dependency chain: scripts/probe/slot_cost.hip): each sample lane packs its nine pieces
+// as an A operand — slots 0..7 of k-step 0 and slot 0 of k-step 1 of its half — and a selection matrix (B operand, built
+// once per launch) routes slot (k-step, half, e) to piece column pcol(k) + p: two matrix instructions give the piece
+// image U[sample][column] as an accumulator tile (every entry one exact piece times 1), and eight conversions pack it
+// in the row order of relu' tiles (pack_mask).
+struct Pieces3 {
+  uint32_t p[3];
+};
+__device__ __forceinline__ Pieces3 split3v(float v) {
+  Pieces3 r;
+  split3(v, r.p[0], r.p[1], r.p[2]);
+  return r;
+}
+__device__ __forceinline__ void piece_operand(const Pieces3 &a, const Pieces3 &b, const Pieces3 &c, Frag (&pa)[2]) {
+  pa[0].u[0] = pk(a.p[0], a.p[1]);
+  pa[0].u[1] = pk(a.p[2], b.p[0]);
+  pa[0].u[2] = pk(b.p[1], b.p[2]);
+  pa[0].u[3] = pk(c.p[0], c.p[1]);
+  pa[1].u[0] = c.p[2];
+  pa[1].u[1] = pa[1].u[2] = pa[1].u[3] = 0u;
+}
+__device__ __forceinline__ void sel_frags(int lane, Frag (&sel)[2]) {
+  const int n = lane & 31, hh = lane >> 5;
+  auto col = [&](int i) {  // piece i = 3 q + p of this half's input slot q (inputs 2 hh, 2 hh + 1, 4 + hh)
+    const int q = i / 3, p = i % 3;
+    return (q == 0 ? 6 * hh : (q == 1 ? 6 * hh + 3 : (hh == 0 ? 12 : 16))) + p;
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sel[0].u[i] = pk(col(2 * i) == n ? 0x3F80u : 0u, col(2 * i + 1) == n ? 0x3F80u : 0u);
+  sel[1].u[0] = col(8) == n ? 0x3F80u : 0u;
+  sel[1].u[1] = sel[1].u[2] = sel[1].u[3] = 0u;
+}
+// B operands of the backward from g and this lane's inputs (xa, xb: features 2 hf, 2 hf + 1; xc: feature 4)
+__device__ __forceinline__ void piece_frags_mfma(float g, float xa, float xb, float xc, int hf, const Frag (&sel)[2],
+                                                 Frag (&ub)[2]) {
+  Frag pa[2];
+  piece_operand(split3v(g * xa), split3v(g * xb), split3v(hf == 0 ? g * xc : g), pa);
+  f32x16 ut = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0].v, sel[0].v, ut, 0, 0, 0);
+  ut = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1].v, sel[1].v, ut, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ub[s].u[i] = pack_bf16(ut[8 * s + 2 * i], ut[8 * s + 2 * i + 1]);
+}
+
 __device__ __forceinline__ constexpr int pcol(int k) { return k < 5 ? 3 * k : 16; }
 
 // publish u[sample n][k] = g * x~_k for this lane's three k (half 0: k = 0, 1, 4; half 1: k = 2, 3 and 5, where

@@ -32,7 +32,6 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   constexpr int D = 5, H = 128, NT = bt::NT;
   constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] (slot 6 unused); then db2, loss
   __shared__ float Ysh[CRITIC_WAVES][32][33];
-  __shared__ __attribute__((aligned(8))) unsigned short Ubf[CRITIC_WAVES][bt::COLS][bt::UROW];
   __shared__ double Acc[CRITIC_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,6 +73,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   double loss64 = 0.0, db2_64 = 0.0;
   bt::wave_lds_fence();
 
+  Frag selb[2];  // piece-column selection (B operand of the routing product)
+  bt::sel_frags(lane, selb);
   const size_t n_tiles = (B + 31) / 32;
   const size_t wave_id = (size_t)blockIdx.x * CRITIC_WAVES + wave, n_waves = (size_t)gridDim.x * CRITIC_WAVES;
   int since_flush = 0;
@@ -101,7 +102,10 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 
   TileOp op = load_tile(wave_id);
   for (size_t g = wave_id; g < n_tiles; g += n_waves) {
-    const TileOp next = load_tile(g + n_waves);  // global loads run one tile ahead (two: measured, no gain)
+    // global loads run one tile ahead.  (Two tiles ahead — by register moves or by rotating three named buffers through
+    // a loop unrolled three times — is SLOWER, 0.237 against 0.220 ms per step, although a timing build without the
+    // loads runs in 0.197: what the loads cost is issue slots and address arithmetic, not exposed latency.)
+    const TileOp next = load_tile(g + n_waves);
     Frag fa[3];
     bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
     // ---- forward, one hidden tile at a time, software-pipelined: the matrix pipe works on hidden tile t + 1 while the
@@ -140,13 +144,12 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
       loss64 += (double)(d * d);
       db2_64 += (double)dy;
     }
-    // ---- backward: u[sample][k] = dy * x~_k as exact pieces, masked sum over the samples on the matrix pipe
-    bt::publish_pieces(Ubf[wave], dy, op.xa, op.xb, op.xc, n, hf);
-    bt::wave_lds_fence();
+    // ---- backward: u[sample][k] = dy * x~_k as exact pieces (routed to the piece columns by a selection product),
+    // masked sum over the samples on the matrix pipe
     Frag ub[2];
-    bt::piece_frags(Ubf[wave], n, hf, ub);
+    bt::piece_frags_mfma(dy, op.xa, op.xb, op.xc, hf, selb, ub);
     bt::backward(ga, ub, dm);
-    bt::wave_lds_fence();  // Ysh / Ubf are rewritten by the next tile
+    bt::wave_lds_fence();  // Ysh is rewritten by the next tile
     if (++since_flush == C_FLUSH) {
       since_flush = 0;
       bt::flush(dm, acc64, 7, n, hf);

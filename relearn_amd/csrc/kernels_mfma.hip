@@ -499,7 +499,6 @@ __global__ void __launch_bounds__(WAVES * 64)
   constexpr int IW = 7;              // f64 image slots per hidden unit (six columns)
   constexpr int PIMG_M = H * IW + 5; // then db2[0], db2[1], sum0, sum1, sum2
   __shared__ float Ysh[WAVES][32][33];
-  __shared__ __attribute__((aligned(8))) unsigned short Ubf[BWD ? WAVES : 1][bt::COLS][bt::UROW];
   __shared__ double Acc[WAVES][BWD ? PIMG_M : 4];
   __shared__ uint4 Fz[JVP ? NT * 3 : 1][64];  // piece fragments of Z (JVP): [tile * 3 + issue][lane]
   __shared__ uint4 Fw[FW_LDS ? NT * 3 : 1][64];  // FW_LDS: the weight fragments live in LDS, shared by the waves
@@ -564,6 +563,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       for (int m = 1; m < 32; m <<= 1) lvd[q] = lvd[q] + __shfl_xor(lvd[q], m, 64);
   }
   const float b2d = b2[0] - b2[1];
+  Frag selb[2];  // piece-column selection (B operand of the routing product, bf16_tile.hpp)
+  if (BWD) bt::sel_frags(lane, selb);
   bt::f32x16 dm[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dm[t] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -744,12 +745,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         db2_1 += (double)dz1;
       }
       // one channel: u[sample][k] = g * x~_k with g = (dz_0 - dz_1) / 2, masked sum over the samples on the matrix pipe
-      bt::publish_pieces(Ubf[wave], 0.5f * (dz0 - dz1), op.xa, op.xb, op.xc, n, hf);
-      bt::wave_lds_fence();
       Frag ub[2];
-      bt::piece_frags(Ubf[wave], n, hf, ub);
+      bt::piece_frags_mfma(0.5f * (dz0 - dz1), op.xa, op.xb, op.xc, hf, selb, ub);
       bt::backward(ga, ub, dm);
-      bt::wave_lds_fence();
       if (++since_flush == PB_FLUSH) {
         since_flush = 0;
         bt::flush(dm, acc64, IW, n, hf);
