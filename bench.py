@@ -303,7 +303,7 @@ def main():
             cf_ms = prof["critic_fwd"][0] + prof["backward"][0]
             cf_n = prof["critic_fwd"][1]
         algorithmic = flop_c * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
-        bf16_flop = 2 * (48 * H + 32 * H)
+        bf16_flop = 22 * 32768 // 32
         executed = bf16_flop * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
         ctr = counters("k_critic_step_mfma")
         if fused:
@@ -315,7 +315,7 @@ def main():
                 "valu_issue_frac": ctr["valu_issue_frac"], "valu_busy_frac": ctr["valu_busy_frac"],
                 "mfma_busy_frac": ctr["mfma_busy_frac"], "source": ctr["source"],
                 "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1), "samples_per_launch": B_local,
-                "note": "achieved = flop the bf16 matrix pipe executes (20,480 per sample: exact three-piece splits of "
+                "note": "achieved = flop the bf16 matrix pipe executes (22,528 per sample: exact three-piece splits of "
                         "f32 operands, f32 accumulation) / launch time, peak = dense bf16 MFMA.  What keeps the pipe "
                         "from its peak is not HBM (traffic = bytes per launch, 1.0x the algorithmic 24 B per sample) but "
                         "the SIMD's shared issue port (a vector instruction ~4 cycles, a matrix instruction 8, an LDS "
@@ -339,10 +339,11 @@ def main():
         if fv_n:
             # Fisher-vector product launch of the fused policy kernel.  Algorithmic: forward + tangent forward + 2x
             # backward of the 5-128-2 MLP = 4 x 2 x (5*128 + 128*2) = 7,168 f32 flop per sample.  Executed on the bf16
-            # pipe: forward 48 slots + tangent forward 48 slots + backward 32 columns, x 128 units x 2 = 32,768.
+            # pipe: 38 matrix instructions per 32-sample tile (12 forward, 8 transposing the relu' masks, 8 for the masked
+            # sum that gives the tangent logit, 2 routing pieces, 8 backward) x 32,768 flop = 38,912 per sample.
             flop_p = 4 * 2 * (5 * H + H * 2)
             ach = flop_p * B_local * fv_n / (fv_ms * 1e-3) / 1e12
-            exe = 2 * (48 + 48 + 32) * H * B_local * fv_n / (fv_ms * 1e-3) / 1e12
+            exe = (38 * 32768 // 32) * B_local * fv_n / (fv_ms * 1e-3) / 1e12
             pc = counters("void k_policy_bf16<2")
             roofline_policy = {"kernel": "k_policy_bf16<PASS_JVP>", "bound": "mfma", "achieved": exe,
                                "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exe / BF16_PEAK_TFLOPS,

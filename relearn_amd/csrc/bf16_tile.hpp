@@ -196,6 +196,76 @@ __device__ __forceinline__ void mask_tile(const f32x16 &c, Frag (&ga)[2]) {
       ga[s].u[i] = mask_pair(s + i == 0 ? first : c[8 * s + 2 * i], c[8 * s + 2 * i + 1], first);
 }
 
+// A sum over the hidden units weighted by relu' as a masked sum on the matrix pipe (round 3).  With g_sj = relu'(pre_sj),
+//   sum_j g_sj (x~_s . Z_j) = sum_k x~_sk q_sk,   q_sk = sum_j g_sj Z_jk
+// for any matrix Z that is linear in the inputs — the Fisher-vector product's tangent logit (kernels_mfma.hip) — is the
+// same kind of product as the backward, contracted over the hidden unit instead of the sample: 18 piece columns (three
+// exact bf16 pieces of each Z_jk), 8 issues per tile.  The contraction runs over the forward tile's LANE index, so the
+// packed mask is transposed first — by the matrix pipe itself: mask^T = mask^T . I with the packed mask as A operand (a
+// sum over its row index: no lane movement) and an identity selection as B, 2 issues per hidden tile, exact 0 / 1
+// results with the SAMPLE on the lane, packed by 8 conversions into the B operands of q^T[c][s] = sum_j Zp^T[c][j]
+// mask^T[j][s].  (The same transpose through LDS, ds_write_b64 + ds_read_b64_tr_b16, is 32 LDS instructions per tile,
+// ~690 issue cycles against ~190: scripts/probe/cvt_clamp_tr.hip, slot_cost.hip; measured in the critic step, where the
+// whole scheme came out even with the vector-unit output layer and was not kept: 208-214 us against 195.)
+constexpr int L2_KS = 8;  // k-steps of the product (128 hidden units / 16)
+// An accumulator tile X (rows in the registers, column on the lane) packed as the operand of a product that sums over
+// X's ROW index: element e of lane half h of k-step s is row acc_row(s, h, e) of X — the order every operand that meets
+// such a fragment in a product has to follow.
+__device__ __forceinline__ constexpr int acc_row(int s, int h, int e) { return 16 * s + 8 * (e >> 2) + 4 * h + (e & 3); }
+// B operand of  X^T = X^T . I  for a packed 32 x 32 tile X given as A operand: I[k][n] = [row of slot k == n]
+__device__ __forceinline__ void ident_frags(int lane, Frag (&id)[2]) {
+  const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      id[s].u[i] = pk(acc_row(s, hh, 2 * i) == n ? 0x3F80u : 0u, acc_row(s, hh, 2 * i + 1) == n ? 0x3F80u : 0u);
+}
+// Cooperative build of the A-operand fragments of Zp[j][k] = val(j, k), k = 0..5, in LDS, lane-linear per k-step
+// (img[ks][lane]: every ds_read_b128 of a wave is 1 KB contiguous).  Row c = lane & 31 of the operand (= accumulator
+// row of q^T) holds piece p of input k for c = row(3 i + p) of the lane half hf_out that owns input k (the slots of
+// input_frags: 2 hf, 2 hf + 1, 4 + hf), nothing otherwise; element e of lane (c, hh) of k-step ks = 2 t + u is that
+// piece of Zp[32 t + acc_row(u, hh, e)][k] — the hidden-unit order of the transposed masks.  Every thread of the
+// workgroup calls it; the caller synchronises before the first l2_frag.
+template <typename F>
+__device__ __forceinline__ void l2_build(uint4 (*img)[64], int tid, int nthreads, F val) {
+  for (int idx = tid; idx < L2_KS * 64; idx += nthreads) {
+    const int ks = idx >> 6, ln = idx & 63, m = ln & 31, hh = ln >> 5;
+    const int hf_out = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3), i = r / 3, p = r % 3;
+    const int k = i < 2 ? 2 * hf_out + i : 4 + hf_out;
+    uint32_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint32_t q0, q1, q2;
+      split3(val(32 * (ks >> 1) + acc_row(ks & 1, hh, e), k), q0, q1, q2);
+      h[e] = r < 9 ? (p == 0 ? q0 : (p == 1 ? q1 : q2)) : 0u;
+    }
+    img[ks][ln] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
+  }
+}
+// q^T += Zp^T mask^T for one hidden tile: transpose the packed mask (2 issues), pack it (8 conversions), 2 product issues
+__device__ __forceinline__ f32x16 masked_sum_tile(const Frag (&ga)[2], const Frag (&idb)[2], const uint4 (*img)[64],
+                                                  int t, int lane, f32x16 q) {
+  f32x16 gt = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  gt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0].v, idb[0].v, gt, 0, 0, 0);
+  gt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1].v, idb[1].v, gt, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    Frag mt, fz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mt.u[i] = pack_bf16(gt[8 * s + 2 * i], gt[8 * s + 2 * i + 1]);
+    fz.x = img[2 * t + s][lane];
+    q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz.v, mt.v, q, 0, 0, 0);
+  }
+  return q;
+}
+// sum_k x~_k q_k over this half's three inputs (a, b and c = x_4 or the bias input) from the q^T accumulator; the
+// other half's part comes through both_halves
+__device__ __forceinline__ float l2_dot(const f32x16 &q, float xa, float xb, float xc) {
+  const float sa = (q[0] + q[1]) + q[2], sb = (q[3] + q[4]) + q[5], sc = (q[6] + q[7]) + q[8];
+  return __builtin_fmaf(xc, sc, __builtin_fmaf(xb, sb, xa * sa));
+}
+
 // The pieces of u = g x~ from the sample lanes to the backward's B operand (sample in the registers, piece column on
 // the lane) WITHOUT LDS (round 3; an LDS instruction costs 14-25 cycles of the SIMD's issue port and the write -> read
 // round trip sits in every tile's dependency chain: scripts/probe/slot_cost.hip): each sample lane packs its nine pieces

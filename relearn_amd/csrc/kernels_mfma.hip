@@ -498,9 +498,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   constexpr bool JVP = MODE == PASS_JVP;
   constexpr int IW = 7;              // f64 image slots per hidden unit (six columns)
   constexpr int PIMG_M = H * IW + 5; // then db2[0], db2[1], sum0, sum1, sum2
-  __shared__ float Ysh[WAVES][32][33];
+  __shared__ float Ysh[JVP ? 1 : WAVES][32][33];
   __shared__ double Acc[WAVES][BWD ? PIMG_M : 4];
-  __shared__ uint4 Fz[JVP ? NT * 3 : 1][64];  // piece fragments of Z (JVP): [tile * 3 + issue][lane]
+  __shared__ uint4 Fz[JVP ? bt::L2_KS : 1][64];  // JVP: A operands of the masked sum over the hidden units (pieces of Z)
   __shared__ uint4 Fw[FW_LDS ? NT * 3 : 1][64];  // FW_LDS: the weight fragments live in LDS, shared by the waves
   if (skip != nullptr && *skip != 0) return;
 
@@ -525,10 +525,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   for (int t = 0; t < NT; ++t) {
     const int j = t * 32 + n;
     const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
-    // gradient / evaluation passes: the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp) and
-    // the |pre| chain takes the scale back out through w2d (both exact); the Fisher-vector pass needs relu' as an f32
-    // factor and keeps the unscaled forward
-    const float sc = JVP ? 1.0f : bt::FWD_SCALE;
+    // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain of the gradient /
+    // evaluation passes takes the scale back out through w2d (both exact); the Fisher-vector pass only needs the masks
+    const float sc = bt::FWD_SCALE;
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
     if (FW_LDS && wave == t) {
 #pragma unroll
@@ -541,16 +540,16 @@ __global__ void __launch_bounds__(WAVES * 64)
       lvd[2] = __builtin_fmaf(wd, hf == 0 ? w4 : bj, lvd[2]);
     }
     w2d[t] = bt::FWD_UNSCALE * wd;
-    if (JVP && wave == t) {  // waves 0..3 build the fragments of Z for hidden tile t = wave
-      const float *__restrict__ V1 = tangent, *__restrict__ vb1 = V1 + H * D, *__restrict__ V2 = vb1 + H;
-      const float t2d = V2[j] - V2[H + j];
-      auto zmix = [&](float v, float w) { return __builtin_fmaf(t2d, w, wd * v); };
-      Frag fz[3];
-      bt::weight_frags(zmix(V1[j * D + 2 * hf], wa), zmix(V1[j * D + 2 * hf + 1], wb), zmix(V1[j * D + 4], w4),
-                       zmix(vb1[j], bj), hf, fz);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Fz[t * 3 + i][lane] = fz[i].x;
-    }
+  }
+  if (JVP) {
+    // Z_jk = w2d_j V~1[j][k] + t2d_j W~1[j][k] (k = 5: the bias row): the tangent logit difference is
+    // sum_j relu'(pre_j) (x~ . Z_j) + (vb2_0 - vb2_1) = sum_k x~_k q_k + ..., q = the masked sum of Z's rows
+    const float *__restrict__ V1 = tangent, *__restrict__ vb1 = V1 + H * D, *__restrict__ V2 = vb1 + H;
+    bt::l2_build(Fz, (int)threadIdx.x, WAVES * 64, [&](int j, int k) {
+      const float wd = W2[j] - W2[H + j], t2d = V2[j] - V2[H + j];
+      const float w = k < D ? W1[j * D + k] : b1[j], v = k < D ? V1[j * D + k] : vb1[j];
+      return __builtin_fmaf(t2d, w, wd * v);
+    });
   }
   if (JVP || FW_LDS) __syncthreads();
   if (JVP) {
@@ -563,12 +562,12 @@ __global__ void __launch_bounds__(WAVES * 64)
       for (int m = 1; m < 32; m <<= 1) lvd[q] = lvd[q] + __shfl_xor(lvd[q], m, 64);
   }
   const float b2d = b2[0] - b2[1];
-  Frag selb[2];  // piece-column selection (B operand of the routing product, bf16_tile.hpp)
+  Frag selb[2], idb[2];  // piece-column selection, identity (B operands of the routing / transposing products)
   if (BWD) bt::sel_frags(lane, selb);
+  if (JVP) bt::ident_frags(lane, idb);
   bt::f32x16 dm[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dm[t] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const float big = 0x1p126f;
   double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
   bt::wave_lds_fence();
 
@@ -576,9 +575,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   // sample n in both halves
   auto lane_sum = [&](const float(&yp)[16], float lin) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
+    for (int r = 0; r < 16; ++r) Ysh[JVP ? 0 : wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
     bt::wave_lds_fence();
-    float part = bt::row_sum16(&Ysh[wave][n][hf * 16]);
+    float part = bt::row_sum16(&Ysh[JVP ? 0 : wave][n][hf * 16]);
     part = part + lin;
     float p0, p1;
     bt::both_halves(part, p0, p1);
@@ -634,6 +633,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     float y0[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) y0[r] = 0.0f;
+    bt::f32x16 q = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto fwd = [&](int t) {
       if (FW_LDS) {
         Frag f[3];
@@ -648,30 +648,19 @@ __global__ void __launch_bounds__(WAVES * 64)
     for (int t = 0; t < NT; ++t) {
       bt::f32x16 cn = c;
       if (t + 1 < NT) cn = fwd(t + 1);
-      float gm[16];
-      if (JVP) {
-        Frag fz[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) fz[i].x = Fz[t * 3 + i][lane];
-        const bt::f32x16 both = bt::layer1(fa, fz);  // x~ . Z_j for the tile's units
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          gm[r] = __builtin_amdgcn_fmed3f((float)c[r] * big, 0.0f, 1.0f);
-          y0[r] = __builtin_fmaf(gm[r], both[r], y0[r]);
-        }
-      } else {
+      if (!JVP) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) y0[r] = __builtin_fmaf(__builtin_fabsf(c[r]), w2d[t], y0[r]);
       }
-      if (BWD) {
-        if (JVP) bt::pack_mask_now(gm, ga[t]);
-        else bt::mask_tile(c, ga[t]);  // relu'(pre): one conversion per two values
-      }
+      if (BWD) bt::mask_tile(c, ga[t]);  // relu'(pre): one conversion per two values
+      if (JVP) q = bt::masked_sum_tile(ga[t], idb, Fz, t, lane, q);
       c = cn;
     }
     float s0;
     if (JVP) {
-      s0 = lane_sum(y0, 0.0f);
+      float p0, p1;
+      bt::both_halves(bt::l2_dot(q, op.xa, op.xb, hf == 0 ? op.xc : 1.0f), p0, p1);
+      s0 = p0 + p1;
     } else {
       float lin = lvd[0] * op.xa;
       lin = __builtin_fmaf(lvd[1], op.xb, lin);
