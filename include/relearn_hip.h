@@ -241,6 +241,24 @@ int32_t rl_mlp_destroy(rl_mlp *mlp);
 int32_t rl_mlp_num_params(const rl_mlp *mlp, uint64_t *n);
 /* Linear::new Glorot-uniform init (ff/linear.rs:54-68) from the engine-defined stream ChaCha8(seed) */
 int32_t rl_mlp_init(rl_mlp *mlp, uint64_t seed);
+/* LinearConfig { kernel_init, bias_init } (src/torch/modules/ff/linear.rs:13-33) with the reference's `Initializer`
+ * (src/torch/initializers.rs:8-64,152-176,328-364): Zeros; Constant(value); Uniform(scale): U(+-sqrt(3 var));
+ * Normal(scale): N(0, var); Orthogonal: QR of a normal [rows, cols] matrix (transposed when rows < cols), columns
+ * multiplied by the sign of R's diagonal.  var = VarianceScale::variance: Constant(value) | 1 / fan_in | 1 / fan_out |
+ * 2 / (fan_in + fan_out) with Linear::new's fan_in = in_dim + 1 for kernel AND bias and fan_out from the tensor's
+ * shape.  Feed-forward modules only; every layer uses the same pair, as MlpConfig::linear_config does.  The draws come
+ * from the engine's stream ChaCha8(seed), stream 0, in flat parameter order: one f32 per uniform element, Box-Muller
+ * on consecutive pairs for normal ones (libtorch's generator is never seeded by the reference).
+ * `bias_init` NULL (LinearConfig::bias_init = None: layers without a bias vector) -> RL_ERR_UNSUPPORTED: every kernel
+ * of this library folds the bias in as a sixth input.  rl_mlp_init(m, seed) = both Uniform(FanAvg), the default. */
+typedef enum { RL_INIT_ZEROS = 0, RL_INIT_CONSTANT = 1, RL_INIT_UNIFORM = 2, RL_INIT_NORMAL = 3, RL_INIT_ORTHOGONAL = 4 } rl_init_kind;
+typedef enum { RL_SCALE_CONSTANT = 0, RL_SCALE_FAN_IN = 1, RL_SCALE_FAN_OUT = 2, RL_SCALE_FAN_AVG = 3 } rl_variance_scale;
+typedef struct {
+  int32_t kind;   /* rl_init_kind */
+  int32_t scale;  /* rl_variance_scale, read by Uniform and Normal */
+  double value;   /* Constant(value); VarianceScale::Constant(value) */
+} rl_initializer;
+int32_t rl_mlp_init_with(rl_mlp *mlp, uint64_t seed, const rl_initializer *kernel_init, const rl_initializer *bias_init);
 int32_t rl_params_get(rl_mlp *mlp, float *host, uint64_t n);
 int32_t rl_params_set(rl_mlp *mlp, const float *host, uint64_t n);
 /* Forward::forward on host rows [n_rows][in_dim] -> [n_rows][out_dim] (test/utility path) */

@@ -259,6 +259,8 @@ def _declare(L):
     L.oracle_mlp_init.argtypes = [MlpShape, C.c_uint64, P(C.c_float)]
     L.oracle_mlp_forward_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), P(C.c_float)]
     L.oracle_mlp_forward_batch_f32.argtypes = [MlpShape, P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
+    L.oracle_mlp_layers_init.argtypes = [C.c_uint32, P(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int,
+                                         C.c_double, C.c_int, C.c_int, C.c_double, P(C.c_float)]
     L.oracle_mlp_layers_forward_f32.argtypes = [C.c_uint32, P(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                                 P(C.c_float), P(C.c_float), C.c_uint64, P(C.c_float)]
 
@@ -462,6 +464,21 @@ def mlp_forward_batch(shape, params, x):
     out = np.zeros((x.shape[0], shape.out_dim), dtype=np.float32)
     lib().oracle_mlp_forward_batch_f32(shape, f32p(params), f32p(x), x.shape[0], f32p(out))
     return out
+
+
+INIT_KINDS = ["Zeros", "Constant", "Uniform", "Normal", "Orthogonal"]  # Initializer (initializers.rs:8-21)
+SCALES = ["Constant", "FanIn", "FanOut", "FanAvg"]                          # VarianceScale (initializers.rs:40-62)
+
+
+def mlp_layers_init(in_dim, hidden, out_dim, seed, kernel_init=("Uniform", "FanAvg", 0.0), bias_init=("Uniform", "FanAvg", 0.0)):
+    """Linear::new for every layer with the given (kind, scale, value) initializers (oracle_mlp_layers_init)"""
+    P_ = sum(fi * fo + fo for fi, fo in zip([in_dim] + list(hidden), list(hidden) + [out_dim]))
+    p = np.zeros(P_, dtype=np.float32)
+    hs = (C.c_uint32 * max(len(hidden), 1))(*hidden)
+    lib().oracle_mlp_layers_init(in_dim, hs, len(hidden), out_dim, seed, INIT_KINDS.index(kernel_init[0]),
+                                 SCALES.index(kernel_init[1]), float(kernel_init[2]), INIT_KINDS.index(bias_init[0]),
+                                 SCALES.index(bias_init[1]), float(bias_init[2]), f32p(p))
+    return p
 
 
 ACTIVATIONS = ["Identity", "Relu", "Sigmoid", "Tanh"]  # the reference enum's declaration order (ff/activation.rs:11-20)

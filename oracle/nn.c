@@ -353,3 +353,99 @@ void oracle_mlp_layers_forward_f32(uint32_t in_dim, const uint32_t *hidden_sizes
     }
   }
 }
+
+/* ------------------------------------------------------------------ Linear::new with any Initializer
+ * LinearConfig { kernel_init, bias_init } (src/torch/modules/ff/linear.rs:13-33,54-68) for every layer of an MLP;
+ * Initializer / VarianceScale / TensorBuilder::build / init_orthogonal (src/torch/initializers.rs:8-64,67-83,152-176,
+ * 328-364).  kind: 0 Zeros, 1 Constant(value), 2 Uniform(scale), 3 Normal(scale), 4 Orthogonal; scale: 0
+ * Constant(value), 1 FanIn, 2 FanOut, 3 FanAvg; fan_in = in_dim + 1 for kernel and bias, fan_out = shape[0].
+ * The draw stream is the engine's (libtorch's generator is never seeded by the reference): ChaCha8(seed), stream 0, one
+ * gen::<f32>() per uniform element in flat order, Box-Muller on consecutive pairs for normal elements, orthogonal = QR by
+ * modified Gram-Schmidt applied twice in f64 (positive diagonal of R: the sign fold is the identity). */
+static void layers_normals(oracle_prng *r, size_t count, double *z) {
+  const double two_pi = 6.283185307179586;
+  for (size_t i = 0; i < count; i += 2) {
+    const double u1 = (double)oracle_prng_gen_f32(r), u2 = (double)oracle_prng_gen_f32(r);
+    double rho = sqrt(-2.0 * log(1.0 - u1)), sn, cs;
+    rl_sincos(two_pi * u2, &sn, &cs);
+    z[i] = rho * cs;
+    if (i + 1 < count) z[i + 1] = rho * sn;
+  }
+}
+static double layers_variance(int scale, double value, double fan_in, double fan_out) {
+  switch (scale) {
+    case 0: return value;
+    case 1: return 1.0 / fan_in;
+    case 2: return 1.0 / fan_out;
+    default: return 2.0 / (fan_in + fan_out);
+  }
+}
+static void layers_fill(oracle_prng *r, int kind, int scale, double value, float *dst, uint64_t rows, uint64_t cols,
+                        double fan_in) {
+  const size_t count = (size_t)rows * cols;
+  const double fan_out = (double)rows;
+  if (kind == 0) {
+    for (size_t i = 0; i < count; ++i) dst[i] = 0.0f;
+  } else if (kind == 1) {
+    for (size_t i = 0; i < count; ++i) dst[i] = (float)value;
+  } else if (kind == 2) {
+    const float lim = (float)sqrt(3.0 * layers_variance(scale, value, fan_in, fan_out));
+    for (size_t i = 0; i < count; ++i) {
+      float t = 2.0f * oracle_prng_gen_f32(r);
+      t = t - 1.0f;
+      dst[i] = t * lim;
+    }
+  } else {
+    double *z = (double *)malloc(sizeof(double) * (count + 1));
+    layers_normals(r, count, z);
+    if (kind == 3) {
+      const double sd = sqrt(layers_variance(scale, value, fan_in, fan_out));
+      for (size_t i = 0; i < count; ++i) dst[i] = (float)(sd * z[i]);
+    } else {
+      const int wide = rows < cols;
+      const uint64_t R = wide ? cols : rows, Cn = wide ? rows : cols;
+      double *a = (double *)malloc(sizeof(double) * (size_t)R * Cn);
+      for (uint64_t rr = 0; rr < rows; ++rr)
+        for (uint64_t c = 0; c < cols; ++c) {
+          const double v = z[(size_t)rr * cols + c];
+          if (wide) a[(size_t)rr * R + c] = v;
+          else a[(size_t)c * R + rr] = v;
+        }
+      for (uint64_t c = 0; c < Cn; ++c) {
+        double *v = a + (size_t)c * R;
+        for (int pass = 0; pass < 2; ++pass)
+          for (uint64_t q = 0; q < c; ++q) {
+            const double *w = a + (size_t)q * R;
+            double dot = 0.0;
+            for (uint64_t rr = 0; rr < R; ++rr) dot += w[rr] * v[rr];
+            for (uint64_t rr = 0; rr < R; ++rr) v[rr] -= dot * w[rr];
+          }
+        double nrm = 0.0;
+        for (uint64_t rr = 0; rr < R; ++rr) nrm += v[rr] * v[rr];
+        nrm = sqrt(nrm);
+        for (uint64_t rr = 0; rr < R; ++rr) v[rr] /= nrm;
+      }
+      for (uint64_t rr = 0; rr < rows; ++rr)
+        for (uint64_t c = 0; c < cols; ++c)
+          dst[(size_t)rr * cols + c] = (float)(wide ? a[(size_t)rr * R + c] : a[(size_t)c * R + rr]);
+      free(a);
+    }
+    free(z);
+  }
+}
+void oracle_mlp_layers_init(uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden, uint32_t out_dim,
+                            uint64_t seed, int k_kind, int k_scale, double k_value, int b_kind, int b_scale,
+                            double b_value, float *params) {
+  oracle_prng r;
+  oracle_prng_seed_from_u64(&r, seed);
+  uint32_t K = in_dim;
+  float *p = params;
+  for (uint32_t l = 0; l <= n_hidden; ++l) {
+    const uint32_t N = l == n_hidden ? out_dim : hidden_sizes[l];
+    layers_fill(&r, k_kind, k_scale, k_value, p, N, K, (double)K + 1.0);
+    p += (size_t)N * K;
+    layers_fill(&r, b_kind, b_scale, b_value, p, N, 1, (double)K + 1.0);
+    p += N;
+    K = N;
+  }
+}

@@ -187,6 +187,12 @@ uint64_t oracle_mlp_num_params(oracle_mlp_shape s);
 void oracle_mlp_init(oracle_mlp_shape s, uint64_t seed, float *params);
 void oracle_mlp_forward_f32(oracle_mlp_shape s, const float *params, const float *x, float *out);
 void oracle_mlp_forward_batch_f32(oracle_mlp_shape s, const float *params, const float *x, uint64_t n, float *out);
+/* Linear::new with LinearConfig { kernel_init, bias_init } for every layer (ff/linear.rs:54-68, initializers.rs): kinds 0
+ * Zeros, 1 Constant(value), 2 Uniform(scale), 3 Normal(scale), 4 Orthogonal; scales 0 Constant(value), 1 FanIn, 2 FanOut,
+ * 3 FanAvg; draws from the engine's init stream */
+void oracle_mlp_layers_init(uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden, uint32_t out_dim,
+                            uint64_t seed, int k_kind, int k_scale, double k_value, int b_kind, int b_scale,
+                            double b_value, float *params);
 /* Mlp::forward for any hidden_sizes (<= 256 wide) and activations (ff/mlp.rs:139-151, ff/activation.rs:85-92); act codes
  * 0 Identity, 1 Relu, 2 Sigmoid, 3 Tanh; x [rows][in_dim] -> out [rows][out_dim]; the engine's fma order and detmath */
 void oracle_mlp_layers_forward_f32(uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden, uint32_t out_dim,

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
-    "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_params_get", "rl_params_set",
+    "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_mlp_init_with", "rl_params_get", "rl_params_set",
     "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
@@ -490,6 +490,18 @@ class LstmMlp(GruMlp):
 
 
 ACTIVATIONS = ["Identity", "Relu", "Sigmoid", "Tanh"]  # rl_activation, in the reference enum's order
+INIT_KINDS = ["Zeros", "Constant", "Uniform", "Normal", "Orthogonal"]  # rl_init_kind
+VARIANCE_SCALES = ["Constant", "FanIn", "FanOut", "FanAvg"]             # rl_variance_scale
+
+
+class Initializer(C.Structure):
+    """rl_initializer"""
+    _fields_ = [("kind", C.c_int32), ("scale", C.c_int32), ("value", C.c_double)]
+
+    @staticmethod
+    def of(spec):
+        kind, scale, value = spec
+        return Initializer(INIT_KINDS.index(kind), VARIANCE_SCALES.index(scale), float(value))
 
 
 class Mlp(_Handle):
@@ -523,8 +535,17 @@ class Mlp(_Handle):
             lib().rl_mlp_destroy(self.h)
             self.h = C.c_void_p()
 
-    def init(self, seed):
-        _check(lib().rl_mlp_init(self.h, C.c_uint64(seed)), self.eng.h)
+    def init(self, seed, kernel_init=None, bias_init=None):
+        """Linear::new for every layer; `kernel_init` / `bias_init`: (kind, scale, value) with the reference's variant
+        names, e.g. ("Normal", "FanIn", 0.0), ("Constant", "Constant", 0.1), ("Orthogonal", "FanIn", 0.0); default
+        both Uniform(FanAvg)"""
+        if kernel_init is None and bias_init is None:
+            _check(lib().rl_mlp_init(self.h, C.c_uint64(seed)), self.eng.h)
+            return
+        default = ("Uniform", "FanAvg", 0.0)
+        k = Initializer.of(kernel_init or default)
+        b = Initializer.of(bias_init or default)
+        _check(lib().rl_mlp_init_with(self.h, C.c_uint64(seed), C.byref(k), C.byref(b)), self.eng.h)
 
     def get_params(self):
         p = np.zeros(self.P, dtype=np.float32)

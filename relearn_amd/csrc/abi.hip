@@ -937,6 +937,106 @@ int32_t rl_mlp_num_params(const rl_mlp *m, uint64_t *n) {
   });
 }
 
+// Linear::new for every layer of a feed-forward module (reference src/torch/modules/ff/linear.rs:54-68) with the
+// given initializers (initializers.rs:152-176: TensorBuilder::build; :67-83 VarianceScale::variance; :328-364
+// init_orthogonal).  Stream (engine-defined, libtorch's RNG is unseeded in the reference): ChaCha8(seed), stream 0, in
+// flat parameter order (kernel then bias per layer): one Standard f32 per uniform element, value = (2u - 1) * lim in
+// f32; normal elements by Box-Muller on consecutive draw pairs (an odd count leaves the pair's second value unused);
+// orthogonal kernels: QR of the normal matrix by modified Gram-Schmidt applied twice in f64 — positive diagonal of R,
+// so the sign fold of init_orthogonal is the identity.  Zeros / Constant draw nothing.
+static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit, const rl_initializer &binit) {
+  std::vector<float> h(m->P);
+  uint32_t key[8];
+  rl_seed_from_u64(seed, key);
+  uint32_t words[16];
+  uint64_t widx = 0;
+  auto next_f32 = [&]() {
+    if ((widx & 15) == 0) rl_chacha_block(key, widx >> 4, 0, 4, words);
+    float u = rl_u32_to_unit_f32(words[widx & 15]);
+    widx += 1;
+    return u;
+  };
+  auto normals = [&](size_t count, std::vector<double> &z) {
+    z.assign(count, 0.0);
+    const double two_pi = 6.283185307179586;
+    for (size_t i = 0; i < count; i += 2) {
+      const double u1 = (double)next_f32(), u2 = (double)next_f32();
+      double rho = std::sqrt(-2.0 * std::log(1.0 - u1)), sn, cs;
+      rl_sincos(two_pi * u2, &sn, &cs);
+      z[i] = rho * cs;
+      if (i + 1 < count) z[i + 1] = rho * sn;
+    }
+  };
+  auto variance = [](const rl_initializer &it, double fan_in, double fan_out) {
+    switch (it.scale) {
+      case RL_SCALE_CONSTANT: return it.value;
+      case RL_SCALE_FAN_IN: return 1.0 / fan_in;
+      case RL_SCALE_FAN_OUT: return 1.0 / fan_out;
+      default: return 2.0 / (fan_in + fan_out);
+    }
+  };
+  // one tensor of `rows` x `cols` elements (a bias: rows = out, cols = 1; fan_out = shape[0] either way,
+  // calculate_fan_in_and_fan_out, initializers.rs:90-103)
+  auto fill = [&](const rl_initializer &it, float *dst, uint64_t rows, uint64_t cols, double fan_in) {
+    const size_t count = (size_t)rows * cols;
+    const double fan_out = (double)rows;
+    if (it.kind == RL_INIT_ZEROS) {
+      for (size_t i = 0; i < count; ++i) dst[i] = 0.0f;
+    } else if (it.kind == RL_INIT_CONSTANT) {
+      for (size_t i = 0; i < count; ++i) dst[i] = (float)it.value;
+    } else if (it.kind == RL_INIT_UNIFORM) {
+      const float lim = (float)std::sqrt(3.0 * variance(it, fan_in, fan_out));
+      for (size_t i = 0; i < count; ++i) {
+        float t = 2.0f * next_f32();
+        t = t - 1.0f;
+        dst[i] = t * lim;
+      }
+    } else if (it.kind == RL_INIT_NORMAL) {
+      const double sd = std::sqrt(variance(it, fan_in, fan_out));
+      std::vector<double> z;
+      normals(count, z);
+      for (size_t i = 0; i < count; ++i) dst[i] = (float)(sd * z[i]);
+    } else {  // orthogonal: tall = the [rows, cols] matrix, transposed when it is wide
+      std::vector<double> z;
+      normals(count, z);
+      const bool wide = rows < cols;
+      const uint64_t R = wide ? cols : rows, Cn = wide ? rows : cols;  // tall matrix R x Cn, columns orthonormalised
+      std::vector<double> a((size_t)R * Cn);                           // column-major: a[c * R + r]
+      for (uint64_t r = 0; r < rows; ++r)
+        for (uint64_t c = 0; c < cols; ++c) {
+          const double v = z[(size_t)r * cols + c];
+          if (wide) a[(size_t)r * R + c] = v;  // tall[c][r] = flat[r][c]
+          else a[(size_t)c * R + r] = v;
+        }
+      for (uint64_t c = 0; c < Cn; ++c) {
+        double *v = a.data() + (size_t)c * R;
+        for (int pass = 0; pass < 2; ++pass)
+          for (uint64_t q = 0; q < c; ++q) {
+            const double *w = a.data() + (size_t)q * R;
+            double dot = 0.0;
+            for (uint64_t r = 0; r < R; ++r) dot += w[r] * v[r];
+            for (uint64_t r = 0; r < R; ++r) v[r] -= dot * w[r];
+          }
+        double nrm = 0.0;
+        for (uint64_t r = 0; r < R; ++r) nrm += v[r] * v[r];
+        nrm = std::sqrt(nrm);
+        for (uint64_t r = 0; r < R; ++r) v[r] /= nrm;
+      }
+      for (uint64_t r = 0; r < rows; ++r)
+        for (uint64_t c = 0; c < cols; ++c) dst[(size_t)r * cols + c] = (float)(wide ? a[(size_t)r * R + c] : a[(size_t)c * R + r]);
+    }
+  };
+  size_t k = 0;
+  for (uint32_t l = 0; l < m->n_layers(); ++l) {
+    const uint64_t in = m->fan_in(l), out = m->fan_out(l);
+    fill(kinit, h.data() + k, out, in, (double)(in + 1));  // kernel [out][in]
+    k += (size_t)in * out;
+    fill(binit, h.data() + k, out, 1, (double)(in + 1));   // bias [out]
+    k += out;
+  }
+  h2d(m->eng, m->d_params, h.data(), m->P * sizeof(float));
+}
+
 int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
   return guarded(m ? m->eng : nullptr, [&] {
     RL_REQUIRE(m, "mlp is NULL");
@@ -946,34 +1046,30 @@ int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
       h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
       return;
     }
-    // Linear::new (reference src/torch/modules/ff/linear.rs:54-68; initializers.rs:31-38,78-108,159-163):
-    // Uniform(+-sqrt(3 * 2 / (fan_in + fan_out))) with fan_in = in_dim + 1 for kernel and bias.
-    // Stream (engine-defined, libtorch's RNG is unseeded in the reference): ChaCha8(seed), stream 0,
-    // one Standard f32 per element in flat parameter order; value = (2u - 1) * lim in f32.
-    std::vector<float> h(m->P);
-    uint32_t key[8];
-    rl_seed_from_u64(seed, key);
-    uint32_t words[16];
-    uint64_t widx = 0;
-    auto next_f32 = [&]() {
-      if ((widx & 15) == 0) rl_chacha_block(key, widx >> 4, 0, 4, words);
-      float u = rl_u32_to_unit_f32(words[widx & 15]);
-      widx += 1;
-      return u;
-    };
-    size_t k = 0;
-    for (uint32_t l = 0; l < m->n_layers(); ++l) {  // (one hidden layer: [in, hidden], [hidden, out] as before)
-      uint32_t in = m->fan_in(l), out = m->fan_out(l);
-      float lim = (float)std::sqrt(3.0 * (2.0 / ((double)(in + 1) + (double)out)));
-      size_t cnt = (size_t)in * out + out;
-      for (size_t i = 0; i < cnt; ++i) {
-        float u = next_f32();
-        float t = 2.0f * u;
-        t = t - 1.0f;
-        h[k++] = t * lim;
+    const rl_initializer glorot{RL_INIT_UNIFORM, RL_SCALE_FAN_AVG, 0.0};
+    mlp_init_host(m, seed, glorot, glorot);
+  });
+}
+
+int32_t rl_mlp_init_with(rl_mlp *m, uint64_t seed, const rl_initializer *kernel_init, const rl_initializer *bias_init) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m && kernel_init, "NULL argument");
+    if (rl_module_is_recurrent(m->kind))
+      throw RlError(RL_ERR_UNSUPPORTED, "rl_mlp_init_with: feed-forward modules only (the recurrent chains use "
+                                        "RnnBaseConfig::default's initializers)");
+    if (bias_init == nullptr)
+      throw RlError(RL_ERR_UNSUPPORTED, "LinearConfig::bias_init = None (layers without a bias vector) is not built: the "
+                                        "kernels fold the bias in as an input");
+    for (const rl_initializer *i : {kernel_init, bias_init}) {
+      RL_REQUIRE(i->kind >= RL_INIT_ZEROS && i->kind <= RL_INIT_ORTHOGONAL, "unknown initializer kind");
+      if (i->kind == RL_INIT_UNIFORM || i->kind == RL_INIT_NORMAL) {
+        RL_REQUIRE(i->scale >= RL_SCALE_CONSTANT && i->scale <= RL_SCALE_FAN_AVG, "unknown variance scale");
+        RL_REQUIRE(i->scale != RL_SCALE_CONSTANT || i->value >= 0.0, "a variance must not be negative");
       }
     }
-    h2d(m->eng, m->d_params, h.data(), m->P * sizeof(float));
+    if (bias_init->kind == RL_INIT_ORTHOGONAL)  // init_orthogonal asserts shape.len() >= 2 (initializers.rs:331-334)
+      throw RlError(RL_ERR_INVALID_ARGUMENT, "tensor for orthogonal init must be at least 2D: not a bias initializer");
+    mlp_init_host(m, seed, *kernel_init, *bias_init);
   });
 }
 

@@ -13,6 +13,9 @@
 //   relu' values at once (bf16_tile.hpp).
 //   at the end  dL/dW1[j][k] = w2_j M[j][k],  dL/db1[j] = w2_j M[j][5],  dL/db2 = sum dy,
 //               dL/dW2[j] = sum_s dy_s h_sj = sum_k W~1[j][k] M[j][k]   (h_sj = [pre_sj > 0] W~1[j] . x~_s).
+// (The output layer as a masked sum on the matrix pipe — what the Fisher-vector pass gains 17 % from, kernels_mfma.hip —
+// loses here: 0.259 against 0.219 ms per step; this kernel has one |pre| chain to replace, not a second layer-1 product
+// with its LDS-resident operands, and 16 more matrix instructions per tile push it against the matrix pipe.)
 // Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2 x backward of the 5-128-1 MLP).
 #include "bf16_tile.hpp"
 #include "device_fns.hpp"

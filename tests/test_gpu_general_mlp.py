@@ -372,3 +372,63 @@ def test_fused_modules_are_untouched_by_a_general_module_on_the_same_trajectory(
         results.append((cri.get_params(), beh.get_params(), st.step_size))
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
     assert results[0][2] == results[1][2]
+
+
+# ---------------------------------------------------------------- LinearConfig { kernel_init, bias_init }
+INIT_CASES = [(("Zeros", "FanIn", 0.0), ("Constant", "Constant", 0.25)),
+              (("Uniform", "FanIn", 0.0), ("Uniform", "FanOut", 0.0)),
+              (("Uniform", "Constant", 0.01), ("Zeros", "FanIn", 0.0)),
+              (("Normal", "FanAvg", 0.0), ("Normal", "Constant", 1e-4)),
+              (("Orthogonal", "FanIn", 0.0), ("Zeros", "FanIn", 0.0)),
+              (("Normal", "FanIn", 0.0), ("Uniform", "FanAvg", 0.0))]
+
+
+@pytest.mark.parametrize("kinit,binit", INIT_CASES)
+def test_initializers_match_the_oracle_and_their_definitions(engine, kinit, binit):
+    """rl_mlp_init_with: every `Initializer` variant (src/torch/initializers.rs:8-21,152-176,328-364) with Linear::new's
+    fan_in = in + 1 (ff/linear.rs:54-68), bit for bit against oracle_mlp_layers_init, and against what the variants MEAN:
+    limits and variances from the shapes, orthonormal rows or columns (compared with numpy's QR of the same normals up
+    to the column signs the reference folds away)."""
+    for in_dim, hidden, out_dim in ((5, [128], 2), (5, [96, 200], 1), (4, [], 2)):
+        m = ra.Mlp(engine, in_dim, hidden if len(hidden) != 1 else hidden[0], out_dim)
+        m.init(13, kinit, binit)
+        p = m.get_params()
+        assert np.array_equal(p, O.mlp_layers_init(in_dim, hidden, out_dim, 13, kinit, binit))
+        k = 0
+        for fi, fo in layers(in_dim, hidden, out_dim):
+            W, b = p[k:k + fi * fo].reshape(fo, fi), p[k + fi * fo:k + fi * fo + fo]
+            k += fi * fo + fo
+            for (kind, scale, value), t in ((kinit, W), (binit, b)):
+                var = {"Constant": value, "FanIn": 1.0 / (fi + 1), "FanOut": 1.0 / fo, "FanAvg": 2.0 / (fi + 1 + fo)}[scale]
+                if kind == "Zeros":
+                    assert not t.any()
+                elif kind == "Constant":
+                    assert (t == np.float32(value)).all()
+                elif kind == "Uniform":
+                    lim = np.float32(np.sqrt(3.0 * var))
+                    assert np.abs(t).max() <= lim and (t.size < 64 or np.abs(t).max() > 0.8 * lim)
+                    assert t.size < 2000 or abs(t.astype(np.float64).var() / var - 1.0) < 0.15
+                elif kind == "Normal":
+                    assert t.size < 2000 or abs(t.astype(np.float64).var() / var - 1.0) < 0.15
+                    assert t.size < 64 or np.abs(t).max() > 1.5 * np.sqrt(var)  # not a bounded distribution
+                else:
+                    Wd = W.astype(np.float64)
+                    gram = Wd @ Wd.T if fo <= fi else Wd.T @ Wd
+                    assert np.abs(gram - np.eye(gram.shape[0])).max() < 1e-5
+
+
+def test_initializer_argument_checks(engine):
+    m = ra.Mlp(engine, 5, 128, 2)
+    k = ra.Initializer.of(("Uniform", "FanAvg", 0.0))
+    assert ra.lib().rl_mlp_init_with(m.h, C.c_uint64(1), C.byref(k), None) == ra.ERR_UNSUPPORTED  # bias_init: None
+    with pytest.raises(ra.RelearnError):  # init_orthogonal needs two dimensions (initializers.rs:331-334)
+        m.init(1, ("Uniform", "FanAvg", 0.0), ("Orthogonal", "FanIn", 0.0))
+    bad = ra.Initializer(7, 0, 0.0)
+    assert ra.lib().rl_mlp_init_with(m.h, C.c_uint64(1), C.byref(bad), C.byref(k)) == ra.ERR_INVALID_ARGUMENT
+    g = ra.GruMlp(engine, 5, 2)  # the recurrent chains keep RnnBaseConfig::default's initializers
+    assert ra.lib().rl_mlp_init_with(g.h, C.c_uint64(1), C.byref(k), C.byref(k)) == ra.ERR_UNSUPPORTED
+    # the default pair is rl_mlp_init
+    a, b = ra.Mlp(engine, 5, 128, 2), ra.Mlp(engine, 5, 128, 2)
+    a.init(5)
+    b.init(5, ("Uniform", "FanAvg", 0.0), ("Uniform", "FanAvg", 0.0))
+    assert np.array_equal(a.get_params(), b.get_params())
