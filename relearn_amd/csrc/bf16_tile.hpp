@@ -71,6 +71,20 @@ __device__ __forceinline__ void split3(float v, uint32_t &p0, uint32_t &p1, uint
   p2 = pack_bf16(r2, 0.0f);
 }
 __device__ __forceinline__ uint32_t pk(uint32_t lo, uint32_t hi) { return lo | (hi << 16); }
+// The same split by TRUNCATION, for the per-tile paths (round 3): p0 = the top 16 bits of v, the residual is exact and
+// has at most 16 significant bits, p1 = its top 16 bits, what is left has at most 8 and IS the third piece — two ands and
+// two subtractions instead of three conversions, two shifts and two subtractions.  The pieces come out as f32 bit
+// patterns (bf16 bits in the HIGH half); pkh packs two of them with one byte permute.  (v = p0 + p1 + p2 exactly, as
+// with rounding; |p1| <= 2^-7 |v| here, so this form is for the kernels that multiply ALL nine piece pairs.)
+__device__ __forceinline__ void split3t(float v, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+  p0 = __builtin_bit_cast(uint32_t, v) & 0xFFFF0000u;
+  const float r1 = v - __builtin_bit_cast(float, p0);
+  p1 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+  p2 = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, p1));
+}
+__device__ __forceinline__ uint32_t pkh(uint32_t lo, uint32_t hi) {  // element 0 = lo's piece, element 1 = hi's
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
 
 // the value of lane (l & 31) and of lane (l & 31) + 32 in every lane: one v_permlane32_swap (VALU) instead of a
 // ds_bpermute round trip
@@ -126,23 +140,23 @@ __device__ __forceinline__ void weight_frags(float wa, float wb, float w4, float
 // sample)
 __device__ __forceinline__ void input_frags(float xa, float xb, float xc, bool valid, int hf, Frag (&f)[3]) {
   uint32_t a0, a1, a2, c0, c1, c2, e0, e1, e2;
-  split3(xa, a0, a1, a2);
-  split3(xb, c0, c1, c2);
-  split3(xc, e0, e1, e2);
-  const uint32_t one = valid ? 0x3F80u : 0u;
+  split3t(xa, a0, a1, a2);
+  split3t(xb, c0, c1, c2);
+  split3t(xc, e0, e1, e2);
+  const uint32_t one = valid ? 0x3F800000u : 0u;
   const uint32_t x0 = hf == 0 ? e0 : e2, x1 = hf == 0 ? e1 : one;
-  f[0].u[0] = pk(a0, a0);
-  f[0].u[1] = pk(a0, a1);
-  f[0].u[2] = pk(a1, a1);
-  f[0].u[3] = pk(a2, a2);
-  f[1].u[0] = pk(a2, c0);
-  f[1].u[1] = pk(c0, c0);
-  f[1].u[2] = pk(c1, c1);
-  f[1].u[3] = pk(c1, c2);
-  f[2].u[0] = pk(c2, c2);
-  f[2].u[1] = pk(x0, x0);
-  f[2].u[2] = pk(x0, x1);
-  f[2].u[3] = pk(x1, x1);
+  f[0].u[0] = pkh(a0, a0);
+  f[0].u[1] = pkh(a0, a1);
+  f[0].u[2] = pkh(a1, a1);
+  f[0].u[3] = pkh(a2, a2);
+  f[1].u[0] = pkh(a2, c0);
+  f[1].u[1] = pkh(c0, c0);
+  f[1].u[2] = pkh(c1, c1);
+  f[1].u[3] = pkh(c1, c2);
+  f[2].u[0] = pkh(c2, c2);
+  f[2].u[1] = pkh(x0, x0);
+  f[2].u[2] = pkh(x0, x1);
+  f[2].u[3] = pkh(x1, x1);
 }
 
 // pre-activations of one 32-unit hidden tile for the wave's 32 samples
@@ -276,17 +290,17 @@ __device__ __forceinline__ float l2_dot(const f32x16 &q, float xa, float xb, flo
 struct Pieces3 {
   uint32_t p[3];
 };
-__device__ __forceinline__ Pieces3 split3v(float v) {
+__device__ __forceinline__ Pieces3 split3v(float v) {  // (truncating split: pieces in the high halves)
   Pieces3 r;
-  split3(v, r.p[0], r.p[1], r.p[2]);
+  split3t(v, r.p[0], r.p[1], r.p[2]);
   return r;
 }
 __device__ __forceinline__ void piece_operand(const Pieces3 &a, const Pieces3 &b, const Pieces3 &c, Frag (&pa)[2]) {
-  pa[0].u[0] = pk(a.p[0], a.p[1]);
-  pa[0].u[1] = pk(a.p[2], b.p[0]);
-  pa[0].u[2] = pk(b.p[1], b.p[2]);
-  pa[0].u[3] = pk(c.p[0], c.p[1]);
-  pa[1].u[0] = c.p[2];
+  pa[0].u[0] = pkh(a.p[0], a.p[1]);
+  pa[0].u[1] = pkh(a.p[2], b.p[0]);
+  pa[0].u[2] = pkh(b.p[1], b.p[2]);
+  pa[0].u[3] = pkh(c.p[0], c.p[1]);
+  pa[1].u[0] = c.p[2] >> 16;
   pa[1].u[1] = pa[1].u[2] = pa[1].u[3] = 0u;
 }
 __device__ __forceinline__ void sel_frags(int lane, Frag (&sel)[2]) {
