@@ -74,6 +74,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 #pragma unroll
   for (int t = 0; t < NT; ++t) dm[t] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double loss64 = 0.0, db2_64 = 0.0;
+  float loss32 = 0.0f, db2_32 = 0.0f;  // per-lane f32 partials over one flush period (<= 64 tiles), then f64: the two levels
+                                         // of every sum over samples here
   bt::wave_lds_fence();
 
   Frag selb[2];  // piece-column selection (B operand of the routing product)
@@ -144,8 +146,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     const float d = y - op.tgt;
     const float dy = op.valid ? d * two_over_B : 0.0f;
     if (hf == 0 && op.valid) {
-      loss64 += (double)(d * d);
-      db2_64 += (double)dy;
+      loss32 = __builtin_fmaf(d, d, loss32);
+      db2_32 = db2_32 + dy;
     }
     // ---- backward: u[sample][k] = dy * x~_k as exact pieces (routed to the piece columns by a selection product),
     // masked sum over the samples on the matrix pipe
@@ -156,10 +158,15 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     if (++since_flush == C_FLUSH) {
       since_flush = 0;
       bt::flush(dm, acc64, 7, n, hf);
+      loss64 += (double)loss32;
+      db2_64 += (double)db2_32;
+      loss32 = db2_32 = 0.0f;
     }
     op = next;
   }
   bt::flush(dm, acc64, 7, n, hf);
+  loss64 += (double)loss32;
+  db2_64 += (double)db2_32;
   // loss / db2: reduce over the 32 owner lanes of the wave (f64 moved as two 32-bit halves)
   auto xlane = [](double v, int mask) {
     uint64_t bits = rl_f64_bits(v);
