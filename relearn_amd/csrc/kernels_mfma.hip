@@ -568,7 +568,18 @@ __global__ void __launch_bounds__(WAVES * 64)
   bt::f32x16 dm[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) dm[t] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
+  double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums ...
+  // ... fed through per-lane f32 partials over one flush period (PB_FLUSH tiles): the two levels of every sum over
+  // samples in this library, and a conversion + an f64 addition less per sum and tile
+  float s0f = 0.0f, s1f = 0.0f, s2f = 0.0f, d0f = 0.0f, d1f = 0.0f;
+  auto fold = [&]() {
+    sum0 += (double)s0f;
+    sum1 += (double)s1f;
+    sum2 += (double)s2f;
+    db2_0 += (double)d0f;
+    db2_1 += (double)d1f;
+    s0f = s1f = s2f = d0f = d1f = 0.0f;
+  };
   bt::wave_lds_fence();
 
   // sum over the 32 source lanes of 16 per-lane partials (+ this half's linear part): LDS transpose, the result for
@@ -691,7 +702,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         const float cc = -(gr * ratio) * inv_B;
         dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - rl_expf(lp[0])) : 0.0f;
         dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - rl_expf(lp[1])) : 0.0f;
-        if (op.valid && hf == 0) sum0 += (double)(u1 < u2 ? u1 : u2);
+        if (op.valid && hf == 0) s0f = s0f + (u1 < u2 ? u1 : u2);
       } else if (MODE == PASS_INIT) {
         if (op.valid && hf == 0) {
           lp0[sidx] = lp[0];
@@ -708,9 +719,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         float ent = cl0 * pa0;
         ent += cl1 * pa1;
         if (op.valid && hf == 0) {
-          sum0 += (double)(ratio * adv);
-          sum1 += (double)(-ent);
-          sum2 += (double)(lpa * adv);
+          s0f = __builtin_fmaf(ratio, adv, s0f);
+          s1f = s1f - ent;
+          s2f = __builtin_fmaf(lpa, adv, s2f);
         }
       } else {  // PASS_EVAL
         const float l00 = op.l0, l01 = op.l1;
@@ -723,15 +734,15 @@ __global__ void __launch_bounds__(WAVES * 64)
         float kl = rel0 * rl_expf(l00);
         kl += rel1 * rl_expf(l01);
         if (op.valid && hf == 0) {
-          sum0 += (double)(ratio * adv);
-          sum1 += (double)kl;
+          s0f = __builtin_fmaf(ratio, adv, s0f);
+          s1f = s1f + kl;
         }
       }
     }
     if (BWD) {
       if (hf == 0) {
-        db2_0 += (double)dz0;
-        db2_1 += (double)dz1;
+        d0f = d0f + dz0;
+        d1f = d1f + dz1;
       }
       // one channel: u[sample][k] = g * x~_k with g = (dz_0 - dz_1) / 2, masked sum over the samples on the matrix pipe
       Frag ub[2];
@@ -740,11 +751,16 @@ __global__ void __launch_bounds__(WAVES * 64)
       if (++since_flush == PB_FLUSH) {
         since_flush = 0;
         bt::flush(dm, acc64, IW, n, hf);
+        fold();
       }
+    } else if (++since_flush == PB_FLUSH) {
+      since_flush = 0;
+      fold();
     }
     op = next;
   }
   if (BWD) bt::flush(dm, acc64, IW, n, hf);
+  fold();
   auto xlane = [](double v, int mask) {
     uint64_t bits = rl_f64_bits(v);
     uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
