@@ -484,6 +484,39 @@ __global__ void __launch_bounds__(V2_WAVES * 64, 2)  // (three waves per SIMD: 3
 // src/torch/optimizers/conjugate_gradient.rs:262-339), Ppo::update (policies/ppo.rs:124-137), Categorical
 // (src/torch/distributions/categorical.rs).
 // ================================================================================================
+// Transcendentals of the update passes: v_exp_f32 / v_log_f32 (base 2, about one ulp) with the base change as a
+// multiplication — 2-3 instructions instead of the ~25 of rl_expf / rl_logf (include/rl_detmath.h).  The deterministic
+// versions stay where results are compared bit for bit with the oracle (rollouts, values, GAE, targets); these passes
+// are compared with the f64 oracle within f32 tolerances, and they agree with each other because log pi_0 (stored by
+// PASS_INIT) and every later log pi come from the same code.  (Counter evidence: the evaluation pass ran at VALU busy
+// 0.96, the gradient pass issued 2.2 x the critic step's vector instructions: profiles/r03_pmc_65536_summary.json.)
+__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// The two-way softmax of the logits {zd, 0} from ONE exponential: t = exp(-|zd|) (the rounding of the argument's base
+// change is carried through: hi + lo = -|zd| log2 e to ~2^-48), r = 1 / (1 + t) (reciprocal + one Newton step), the
+// probabilities r and t r — they sum to one within an ulp, so the two logit gradients stay antisymmetric, which two
+// independent exponentials are not (measured: a 1.4e-6 relative bias in db2) — and lse = max(zd, 0) + log(1 + t).
+struct SoftPair {
+  float lp[2], p[2];
+};
+__device__ __forceinline__ SoftPair soft_pair(float zd) {
+  const float ax = -__builtin_fabsf(zd);
+  const float hi = ax * 1.4426950408889634f;
+  const float lo = __builtin_fmaf(ax, 1.4426950408889634f, -hi) + ax * 1.925963033500343e-08f;  // log2 e = hi part + 1.93e-8
+  const float e = __builtin_amdgcn_exp2f(hi);
+  const float t = __builtin_fmaf(e * lo, 0.6931471805599453f, e);
+  const float s1 = 1.0f + t;
+  float r = __builtin_amdgcn_rcpf(s1);
+  r = __builtin_fmaf(__builtin_fmaf(-s1, r, 1.0f), r, r);
+  const float big = r, small = t * r;
+  const float lse = __builtin_fmaxf(zd, 0.0f) + 0.6931471805599453f * __builtin_amdgcn_logf(s1);
+  SoftPair o;
+  o.lp[0] = zd - lse;
+  o.lp[1] = -lse;
+  o.p[0] = zd >= 0.0f ? big : small;
+  o.p[1] = zd >= 0.0f ? small : big;
+  return o;
+}
+
 constexpr int PB_FLUSH = 16;  // f32 -> f64 flush period in tiles (32 / 64: 2 % faster Fisher-vector products, measured; TRPO's
                               // CG wants the shorter f32 accumulation)
 
@@ -682,26 +715,26 @@ __global__ void __launch_bounds__(WAVES * 64)
     float dz0 = 0.0f, dz1 = 0.0f;
     if (JVP) {
       const float delta = s0 + tb2d;
-      const float p0 = rl_expf(op.l0), p1 = rl_expf(op.l1);
-      dz0 = op.valid ? (p0 * p1) * delta * inv_B : 0.0f;
+      const SoftPair old = soft_pair(op.l0 - op.l1);  // pi_0 from its stored log-probabilities
+      dz0 = op.valid ? (old.p[0] * old.p[1]) * delta * inv_B : 0.0f;
       dz1 = -dz0;
     } else {
-      float z[2] = {s0 + b2d, 0.0f}, lp[2];
       const float adv = op.adv;
       const int act = op.act;
-      log_softmax_lane<2>(z, lp);
+      const SoftPair sp = soft_pair(s0 + b2d);
+      const float(&lp)[2] = sp.lp;
       if (MODE == PASS_PPO) {
         // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
         const float l0a = act == 0 ? op.l0 : op.l1;
         const float lpa = act == 0 ? lp[0] : lp[1];
-        const float ratio = rl_expf(lpa - l0a);
+        const float ratio = fast_expf(lpa - l0a);
         const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
         const float u1 = ratio * adv, u2 = clipped * adv;
         const bool inside = ratio >= clip_lo && ratio <= clip_hi;
         const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
         const float cc = -(gr * ratio) * inv_B;
-        dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - rl_expf(lp[0])) : 0.0f;
-        dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - rl_expf(lp[1])) : 0.0f;
+        dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]) : 0.0f;
+        dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]) : 0.0f;
         if (op.valid && hf == 0) s0f = s0f + (u1 < u2 ? u1 : u2);
       } else if (MODE == PASS_INIT) {
         if (op.valid && hf == 0) {
@@ -709,9 +742,9 @@ __global__ void __launch_bounds__(WAVES * 64)
           lp0[B + sidx] = lp[1];
         }
         const float lpa = act == 0 ? lp[0] : lp[1];
-        const float ratio = rl_expf(lpa - lpa);
+        const float ratio = fast_expf(lpa - lpa);
         const float cc = -(ratio * adv) * inv_B;
-        const float pa0 = rl_expf(lp[0]), pa1 = rl_expf(lp[1]);
+        const float pa0 = sp.p[0], pa1 = sp.p[1];
         dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - pa0) : 0.0f;
         dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - pa1) : 0.0f;
         const float cl0 = lp[0] < -3.402823466e+38f ? -3.402823466e+38f : lp[0];
@@ -727,12 +760,13 @@ __global__ void __launch_bounds__(WAVES * 64)
         const float l00 = op.l0, l01 = op.l1;
         const float lpa = act == 0 ? lp[0] : lp[1];
         const float l0a = act == 0 ? l00 : l01;
-        const float ratio = rl_expf(lpa - l0a);
+        const float ratio = fast_expf(lpa - l0a);
         float rel0 = l00 - lp[0], rel1 = l01 - lp[1];
         if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
         if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
-        float kl = rel0 * rl_expf(l00);
-        kl += rel1 * rl_expf(l01);
+        const SoftPair old = soft_pair(l00 - l01);  // pi_0 from its stored log-probabilities
+        float kl = rel0 * old.p[0];
+        kl += rel1 * old.p[1];
         if (op.valid && hf == 0) {
           s0f = __builtin_fmaf(ratio, adv, s0f);
           s1f = s1f + kl;

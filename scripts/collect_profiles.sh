@@ -4,13 +4,15 @@
 #   and the PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE) over one period of the hot path.
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-TAG="${1:-r02}"
+TAG="${1:-r03}"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 OUT="gpurun_out/prof_$TAG"
 rm -rf "$OUT" && mkdir -p "$OUT"
 python3 bench.py > "$OUT/bench_65536.json" 2> "$OUT/bench_65536.err" || echo "bench 65536 failed"
-python3 bench.py --envs 8192 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_8192.json" 2> "$OUT/bench_8192.err" || echo "bench 8192 failed"
-python3 bench.py --envs 4096 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_4096.json" 2> "$OUT/bench_4096.err" || echo "bench 4096 failed"
+# one rank's share of the headline at 2 / 4 / 8 / 16 GPUs (the projection is built from these)
+for n in 32768 16384 8192 4096; do
+  python3 bench.py --envs $n --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_$n.json" 2> "$OUT/bench_$n.err" || echo "bench $n failed"
+done
 for n in 65536 8192 4096; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$n" -- python3 bench.py --envs $n --steps 3 --warmup 1 --no-cpu-baseline \
     > "$OUT/bench_under_rocprof_$n.json" 2> "$OUT/stats_$n.log" || echo "rocprof stats $n failed"
