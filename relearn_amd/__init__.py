@@ -793,6 +793,8 @@ class Dqn(_Handle):
         losses = np.zeros(max(K, 1), dtype=np.float32)
         _check(lib().rl_dqn_update(self.h, C.byref(st), losses.ctypes.data_as(C.c_void_p) if want_losses else None),
                self.eng.h)
+        if K:  # the update's last minibatch is the one minibatch_read / minibatch_gradient see now
+            self.n_eps, self.n_steps = int(st.last_minibatch_episodes), int(st.last_minibatch_steps)
         return (st, losses[:K]) if want_losses else st
 
     def replay_read(self, field):

@@ -39,11 +39,8 @@ static ReplayDev replay_alloc(rl_engine *e, uint32_t N, uint32_t C, uint32_t E, 
   r.E = E;
   r.D = D;
   size_t cn = (size_t)C * N;
-  r.obs = dalloc<float>(cn * D);
-  r.next_obs = dalloc<float>(cn * D);
-  r.action = dalloc<uint8_t>(cn);
-  r.reward = dalloc<float>(cn);
-  r.flag = dalloc<uint8_t>(cn);
+  r.rec = dalloc<ReplayRec>(cn);
+  r.next = dalloc<ReplayNext>(cn);
   r.head = dalloc<uint32_t>(N);
   r.count = dalloc<uint32_t>(N);
   r.ep_head = dalloc<uint32_t>(N);
@@ -56,26 +53,49 @@ static ReplayDev replay_alloc(rl_engine *e, uint32_t N, uint32_t C, uint32_t E, 
   for (uint32_t *p : zero_u32) RL_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)N * 4, e->stream));
   RL_HIP_CHECK(hipMemsetAsync(r.actor_pos, 0, (size_t)N * 8, e->stream));
   RL_HIP_CHECK(hipMemsetAsync(r.error, 0, 4, e->stream));
-  RL_HIP_CHECK(hipMemsetAsync(r.next_obs, 0, cn * D * 4, e->stream));
+  RL_HIP_CHECK(hipMemsetAsync(r.next, 0, cn * sizeof(ReplayNext), e->stream));
   return r;
 }
 
 static void replay_free(ReplayDev &r) {
-  void *ptrs[] = {r.obs,      r.next_obs, r.action, r.reward, r.flag,      r.head, r.count,
-                  r.ep_head,  r.ep_count, r.total,  r.ep_end, r.actor_pos, r.error};
+  void *ptrs[] = {r.rec, r.next, r.head, r.count, r.ep_head, r.ep_count, r.total, r.ep_end, r.actor_pos, r.error};
   for (void *p : ptrs) dfree(p);
   r = ReplayDev{};
+}
+
+// point the minibatch workspace back at its own sample arrays (an all-at-once update leaves it looking at its last
+// minibatch inside the big arrays)
+static void dqn_own_arrays(rl_dqn *q) {
+  if (!q->mb || !q->own_obs) return;
+  q->mb->d.obs = q->own_obs;
+  q->mb->d.adv = q->own_target;
+  q->mb->d.action = q->own_action;
 }
 
 // every device allocation of a DQN handle (also the clean-up of a failed rl_dqn_create)
 static void dqn_release_device(rl_dqn *q) {
   replay_free(q->rp);
-  void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags};
+  void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags,
+                  q->all_obs,     q->all_target, q->all_action};
   for (void *p : ptrs) dfree(p);
+  q->all_obs = q->all_target = nullptr;
+  q->all_action = nullptr;
+  if (q->draw_stream) {
+    (void)hipStreamSynchronize(q->draw_stream);
+    (void)hipStreamDestroy(q->draw_stream);
+  }
+  q->draw_stream = nullptr;
+  for (hipEvent_t ev : q->draw_events) (void)hipEventDestroy(ev);
+  q->draw_events.clear();
+  if (q->main_event) (void)hipEventDestroy(q->main_event);
+  q->main_event = nullptr;
+  if (q->h_counts) (void)hipHostFree(q->h_counts);
+  q->h_counts = nullptr;
   q->d_agent_pos = nullptr;
   q->d_ep_lane = q->d_ep_start = q->d_ep_len = q->d_ep_off = nullptr;
   q->d_counts = nullptr;
   q->d_flags = nullptr;
+  dqn_own_arrays(q);
   if (q->mb) rl_traj_destroy(q->mb);
   q->mb = nullptr;
 }
@@ -112,7 +132,7 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     if (cfg->exploration_kind == RL_SCHEDULE_LINEAR_ANNEALED)
       RL_REQUIRE(cfg->exploration_period > 0, "exploration_period must be positive");
     uint64_t N = env->cfg.n_lanes;
-    RL_REQUIRE(cfg->buffer_capacity * N * 46 < (200ull << 30), "replay store would not fit in HBM");
+    RL_REQUIRE(cfg->buffer_capacity * N * (sizeof(ReplayRec) + sizeof(ReplayNext)) < (200ull << 30), "replay store would not fit in HBM");
     RL_HIP_CHECK(hipSetDevice(e->device));
     std::unique_ptr<rl_dqn> q(new rl_dqn());
     q->eng = e;
@@ -137,6 +157,9 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     q->d_counts = dalloc<DqnCountsDev>(nb);
     RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, nb * sizeof(DqnCountsDev), e->stream));
     q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
+    q->own_obs = q->mb->d.obs;
+    q->own_target = q->mb->d.adv;
+    q->own_action = q->mb->d.action;
     sync(e);
     } catch (...) {  // (unique_ptr frees the host struct only)
       dqn_release_device(q.get());
@@ -226,36 +249,41 @@ static AgentKey dqn_key(const rl_dqn *q) {
   return k;
 }
 
+// the sampler's verdict on `n` minibatches: RL_OK, or the first failure and what it was
+static int32_t dqn_check_counts(const rl_dqn *q, const DqnCountsDev *counts, size_t n, const char **what) {
+  for (size_t i = 0; i < n; ++i) {
+    const DqnCountsDev &c = counts[i];
+    if (c.error == 2) {
+      *what = "minibatch sampling from a lane without a complete episode";
+      return RL_ERR_INVALID_ARGUMENT;
+    } else if (c.error != 0) {
+      *what = "replay buffer full";
+      return RL_ERR_BUFFER_FULL;
+    } else if (c.n_eps > q->max_eps || c.n_steps > q->max_steps_mb) {
+      *what = "minibatch exceeds its workspace";
+      return RL_ERR_INVALID_ARGUMENT;
+    } else if (c.n_steps == 0) {
+      *what = "empty minibatch";
+      return RL_ERR_INVALID_ARGUMENT;
+    }
+  }
+  return RL_OK;
+}
+
 // one sample_minibatch (dqn.rs:279-314): draw episodes, gather them, compute targets
 // draw the episode lists of `n_batches` consecutive minibatches (dqn.rs:280-291) in one launch and read back their
 // sizes: the draws do not depend on the network, so the whole update needs this one host round trip
 static void dqn_draw_minibatches(rl_dqn *q, int sequential, uint32_t n_batches, std::vector<DqnCountsDev> &counts,
                                  std::vector<uint64_t> &totals) {
   rl_engine *e = q->eng;
-  launch_dqn_sample(e, q->rp, dqn_key(q), q->d_agent_pos, (uint32_t)q->cfg.minibatch_steps, q->max_eps,
+  launch_dqn_sample(e, e->stream, q->rp, dqn_key(q), q->d_agent_pos, (uint32_t)q->cfg.minibatch_steps, q->max_eps,
                     q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, sequential, n_batches);
   counts.resize(n_batches);
   d2h(e, counts.data(), q->d_counts, n_batches * sizeof(DqnCountsDev));
   // local validation first, the verdict only after every rank has reported (a rank that throws here alone would leave
   // its peers blocked in the count all-reduce below)
-  int32_t code = RL_OK;
   const char *what = "";
-  for (const DqnCountsDev &c : counts) {
-    if (code != RL_OK) break;
-    if (c.error == 2) {
-      code = RL_ERR_INVALID_ARGUMENT;
-      what = "minibatch sampling from a lane without a complete episode";
-    } else if (c.error != 0) {
-      code = RL_ERR_BUFFER_FULL;
-      what = "replay buffer full";
-    } else if (c.n_eps > q->max_eps || c.n_steps > q->max_steps_mb) {
-      code = RL_ERR_INVALID_ARGUMENT;
-      what = "minibatch exceeds its workspace";
-    } else if (c.n_steps == 0) {
-      code = RL_ERR_INVALID_ARGUMENT;
-      what = "empty minibatch";
-    }
-  }
+  const int32_t code = dqn_check_counts(q, counts.data(), counts.size(), &what);
   if (dqn_any_rank_failed(q, code != RL_OK))
     throw RlError(code != RL_OK ? code : RL_ERR_COMM, code != RL_OK ? what : "minibatch sampling failed on another rank");
   // the loss is a mean over all ranks' samples: sum the per-rank counts (two 16-bit halves each, exact in f32)
@@ -277,6 +305,7 @@ static void dqn_draw_minibatches(rl_dqn *q, int sequential, uint32_t n_batches, 
 
 // gather minibatch `k` of the last draw and compute its targets (dqn.rs:293-314)
 static void dqn_build_minibatch(rl_dqn *q, uint32_t k, const DqnCountsDev &c, uint64_t total) {
+  dqn_own_arrays(q);
   q->last_n_eps = c.n_eps;
   q->last_n_steps = c.n_steps;
   q->last_total_steps = total;
@@ -305,7 +334,7 @@ static void dqn_gradient(rl_dqn *q, rl_adam *step_opt = nullptr, int loss_slot =
   rl_traj *mb = q->mb;
   uint32_t P = (uint32_t)q->qnet->P;
   uint32_t rowsA, rowsB;
-  if (q->eng->kernel_variant != 1 && launch_policy_v2(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr)) {
+  if (q->eng->kernel_variant == 0 && launch_dqn_step_bf16(mb, q->qnet, q->last_total_steps)) {
     rowsA = rowsB = mb->nbV2;
   } else {
     launch_policy_pass(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr);
@@ -330,13 +359,102 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
     // taken the same number of steps and the horizon rule drops none
     q->global_steps = q->steps_per_lane * (uint64_t)q->rp.N * (uint64_t)e->n_ranks;
     uint64_t K = q->cfg.opt_steps_per_update;
+    // Reward-to-go targets do not depend on the network: whole chunks of minibatches are gathered, targets included, in
+    // one launch each, and an optimisation step is a gradient launch and a reduction + Adam launch.  (One-step TD targets
+    // use the current network: those minibatches are still built one step at a time.)
+    const uint64_t D = q->rp.D, cap = q->max_steps_mb;
+    const bool all_at_once = K > 1 && q->cfg.target == RL_DQN_TARGET_REWARD_TO_GO && K * cap * (8 * D + 5) <= (8ull << 30);
+    if (all_at_once && !q->all_obs) {
+      q->all_obs = dalloc<float>(K * D * 2 * cap);
+      q->all_target = dalloc<float>(K * cap);
+      q->all_action = dalloc<uint8_t>(K * cap);
+    }
+    // The draws do not depend on the network either, but they are one sequential chain through the agent's Prng (12 us
+    // per minibatch on one CU).  One rank: the chain runs on a second stream in chunks of 2, 4, 8, ... minibatches
+    // while the main stream trains on the chunks already drawn — the draw is faster than the training, so only the first
+    // chunk is waited for.  (Several ranks agree on the counts through a collective first; per-kernel profiling keeps
+    // everything on the profiled stream.)
+    const bool pipelined = all_at_once && e->n_ranks == 1 && !e->profiling;
     std::vector<DqnCountsDev> counts;
     std::vector<uint64_t> totals;
-    if (K) dqn_draw_minibatches(q, 0, (uint32_t)K, counts, totals);
-    for (uint64_t k = 0; k < K; ++k) {
-      dqn_build_minibatch(q, (uint32_t)k, counts[k], totals[k]);
-      dqn_gradient(q, q->opt, (int)k);
+    std::vector<uint32_t> chunk_end;  // minibatches [chunk_end[c - 1], chunk_end[c]) form chunk c
+    if (pipelined) {
+      for (uint64_t first = 0, size = 2; first < K; first += size, size *= 2) chunk_end.push_back((uint32_t)(first + size < K ? first + size : K));
+      if (!q->draw_stream) RL_HIP_CHECK(hipStreamCreateWithFlags(&q->draw_stream, hipStreamNonBlocking));
+      if (!q->main_event) RL_HIP_CHECK(hipEventCreateWithFlags(&q->main_event, hipEventDisableTiming));
+      if (!q->h_counts) RL_HIP_CHECK(hipHostMalloc((void **)&q->h_counts, K * sizeof(DqnCountsDev), hipHostMallocDefault));
+      while (q->draw_events.size() < chunk_end.size()) {
+        hipEvent_t ev;
+        RL_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        q->draw_events.push_back(ev);
+      }
+      // the store is as the main stream's collection left it
+      RL_HIP_CHECK(hipEventRecord(q->main_event, e->stream));
+      RL_HIP_CHECK(hipStreamWaitEvent(q->draw_stream, q->main_event, 0));
+      for (size_t c = 0; c < chunk_end.size(); ++c) {
+        const uint32_t first = c ? chunk_end[c - 1] : 0, size = chunk_end[c] - first;
+        const size_t o = (size_t)first * q->max_eps;
+        launch_dqn_sample(e, q->draw_stream, q->rp, dqn_key(q), q->d_agent_pos, (uint32_t)q->cfg.minibatch_steps,
+                          q->max_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o, q->d_ep_off + o,
+                          q->d_counts + first, 0, size);
+        RL_HIP_CHECK(hipMemcpyAsync(q->h_counts + first, q->d_counts + first, size * sizeof(DqnCountsDev),
+                                    hipMemcpyDeviceToHost, q->draw_stream));
+        RL_HIP_CHECK(hipEventRecord(q->draw_events[c], q->draw_stream));
+      }
+      counts.resize(K);
+      totals.resize(K);
+    } else {
+      if (K) dqn_draw_minibatches(q, 0, (uint32_t)K, counts, totals);
+      chunk_end.push_back((uint32_t)K);
     }
+    rl_traj *mb = q->mb;
+    try {
+      for (size_t c = 0; c < chunk_end.size(); ++c) {
+        const uint32_t first = c ? chunk_end[c - 1] : 0, size = chunk_end[c] - first;
+        if (pipelined) {
+          RL_HIP_CHECK(hipEventSynchronize(q->draw_events[c]));
+          const char *what = "";
+          const int32_t code = dqn_check_counts(q, q->h_counts + first, size, &what);
+          if (code != RL_OK) throw RlError(code, what);
+          for (uint32_t k = first; k < first + size; ++k) {
+            counts[k] = q->h_counts[k];
+            totals[k] = counts[k].n_steps;
+          }
+        }
+        if (all_at_once && size) {
+          uint32_t widest = 0;
+          for (uint32_t k = first; k < first + size; ++k) widest = counts[k].n_eps > widest ? counts[k].n_eps : widest;
+          const size_t o = (size_t)first * q->max_eps;
+          launch_dqn_build_all(e, q->rp, size, widest, q->max_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o,
+                               q->d_ep_off + o, q->d_counts + first, q->all_obs + first * D * 2 * cap,
+                               (size_t)(D * 2 * cap), q->all_action + first * cap, q->all_target + first * cap,
+                               (size_t)cap, q->cfg.discount_factor);
+        }
+        for (uint64_t k = first; k < first + size; ++k) {
+          if (all_at_once) {
+            q->last_n_eps = counts[k].n_eps;
+            q->last_n_steps = counts[k].n_steps;
+            q->last_total_steps = totals[k];
+            q->last_batch_index = (uint32_t)k;
+            mb->d.n = counts[k].n_steps;
+            mb->d.T = 1;
+            traj_plan(mb, counts[k].n_steps);
+            mb->d.obs = q->all_obs + k * D * 2 * cap;
+            mb->d.action = q->all_action + k * cap;
+            mb->d.adv = q->all_target + k * cap;
+          } else {
+            dqn_build_minibatch(q, (uint32_t)k, counts[k], totals[k]);
+          }
+          dqn_gradient(q, q->opt, (int)k);
+        }
+      }
+    } catch (...) {
+      if (pipelined) (void)hipStreamSynchronize(q->draw_stream);  // the later chunks' draws still advance the agent's Prng
+      dqn_own_arrays(q);
+      q->last_n_eps = q->last_n_steps = 0;  // no minibatch to read after a failed update
+      throw;
+    }
+    // (after an all-at-once update `mb` keeps looking at the last minibatch: rl_dqn_minibatch_read / _gradient work)
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
     if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
@@ -354,6 +472,7 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
 static void replay_field(const rl_dqn *q, int32_t field, void **ptr, uint64_t *bytes) {
   const ReplayDev &r = q->rp;
   uint64_t N = r.N, C = r.C, E = r.E, D = r.D;
+  *ptr = nullptr;
   switch (field) {
     case RL_REPLAY_HEAD: *ptr = r.head; *bytes = N * 4; break;
     case RL_REPLAY_COUNT: *ptr = r.count; *bytes = N * 4; break;
@@ -361,11 +480,12 @@ static void replay_field(const rl_dqn *q, int32_t field, void **ptr, uint64_t *b
     case RL_REPLAY_EP_COUNT: *ptr = r.ep_count; *bytes = N * 4; break;
     case RL_REPLAY_TOTAL: *ptr = r.total; *bytes = N * 4; break;
     case RL_REPLAY_EP_END: *ptr = r.ep_end; *bytes = E * N * 4; break;
-    case RL_REPLAY_OBS: *ptr = r.obs; *bytes = D * C * N * 4; break;
-    case RL_REPLAY_NEXT_OBS: *ptr = r.next_obs; *bytes = D * C * N * 4; break;
-    case RL_REPLAY_ACTION: *ptr = r.action; *bytes = C * N; break;
-    case RL_REPLAY_REWARD: *ptr = r.reward; *bytes = C * N * 4; break;
-    case RL_REPLAY_FLAG: *ptr = r.flag; *bytes = C * N; break;
+    // step data lives in records (engine.hpp): *ptr stays NULL, the read goes through launch_replay_planes
+    case RL_REPLAY_OBS: *bytes = D * C * N * 4; break;
+    case RL_REPLAY_NEXT_OBS: *bytes = D * C * N * 4; break;
+    case RL_REPLAY_ACTION: *bytes = C * N; break;
+    case RL_REPLAY_REWARD: *bytes = C * N * 4; break;
+    case RL_REPLAY_FLAG: *bytes = C * N; break;
     case RL_REPLAY_ACTOR_POS: *ptr = r.actor_pos; *bytes = N * 8; break;
     case RL_REPLAY_LAST_FLAGS: *ptr = q->d_flags; *bytes = q->last_horizon * N; break;
     default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown replay field");
@@ -387,7 +507,21 @@ int32_t rl_dqn_replay_read(rl_dqn *q, int32_t field, void *host, uint64_t bytes)
     uint64_t need;
     replay_field(q, field, &p, &need);
     RL_REQUIRE(bytes == need, "byte count mismatch for replay field");
-    if (bytes) d2h(q->eng, host, p, bytes);
+    if (!bytes) return;
+    if (p) {
+      d2h(q->eng, host, p, bytes);
+      return;
+    }
+    RL_HIP_CHECK(hipSetDevice(q->eng->device));
+    void *planes = dalloc<uint8_t>(bytes);
+    try {
+      launch_replay_planes(q->eng, q->rp, field, planes);
+      d2h(q->eng, host, planes, bytes);
+    } catch (...) {
+      dfree(planes);
+      throw;
+    }
+    dfree(planes);
   });
 }
 

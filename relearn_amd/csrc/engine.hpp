@@ -66,14 +66,23 @@ struct TrajDev {
   uint32_t n, T, D;
 };
 
-// the DQN replay store: every lane is one ReplayBuffer (src/agents/buffers/replay.rs:11-27); step data in a
-// per-lane time ring `[C][N]` (lane fastest), bookkeeping per lane, see replay.hpp
+// the DQN replay store: every lane is one ReplayBuffer (src/agents/buffers/replay.rs:11-27), see replay.hpp for the
+// bookkeeping.  Step data: one 32-byte record per step, `[N][C]` with the ring slot fastest — the steps of an episode are
+// consecutive records (two runs where it wraps), so gathering a sampled episode reads whole lines.  (Feature planes
+// `[D][C][N]` cost one memory line per 4-byte element there: 8 lines per step, and the minibatch builder ran at 4 TB/s
+// of line traffic for 40 MB of samples.)
+struct alignas(32) ReplayRec {
+  float x[5];       // observation features (x[4] unused when D = 4)
+  float reward;
+  uint32_t af;      // action | successor code << 8
+  uint32_t pad;
+};
+struct alignas(32) ReplayNext {
+  float x[8];       // successor observation, meaningful where the step's successor code is INTERRUPT
+};
 struct ReplayDev {
-  float *obs;       // [D][C][N]
-  float *next_obs;  // [D][C][N] meaningful where flag == INTERRUPT
-  uint8_t *action;  // [C][N]
-  float *reward;    // [C][N]
-  uint8_t *flag;    // [C][N]
+  ReplayRec *rec;    // [N][C]
+  ReplayNext *next;  // [N][C]
   uint32_t *head, *count, *ep_head, *ep_count, *total;  // [N] LaneRing fields
   uint32_t *ep_end;     // [E][N] absolute one-past-the-end step index of each stored episode
   uint64_t *actor_pos;  // [N] word position of the lane's actor stream
@@ -268,6 +277,17 @@ struct rl_dqn {
   uint32_t max_eps = 0;
   uint64_t max_steps_mb = 0;         // sample capacity of the minibatch workspace
   rl_traj *mb = nullptr;             // minibatch workspace: T = 1, n = current minibatch size
+  // reward-to-go updates: the compact samples of ALL minibatches of an update, built in one launch (first update)
+  float *all_obs = nullptr, *all_target = nullptr;  // [K][D][2 * max_steps_mb], [K][max_steps_mb]
+  uint8_t *all_action = nullptr;                    // [K][max_steps_mb]
+  // ... drawn on a second stream in growing chunks while the main stream already trains on the earlier ones
+  hipStream_t draw_stream = nullptr;
+  std::vector<hipEvent_t> draw_events;
+  hipEvent_t main_event = nullptr;
+  DqnCountsDev *h_counts = nullptr;  // pinned, [K]
+  // ... `mb` then points into them (the last minibatch stays readable); its own arrays, for the one-at-a-time builder:
+  float *own_obs = nullptr, *own_target = nullptr;
+  uint8_t *own_action = nullptr;
   uint64_t global_steps = 0;         // as of the last update (dqn.rs:276)
   uint64_t steps_per_lane = 0;       // collected so far
   uint32_t last_n_eps = 0, last_n_steps = 0, last_batch_index = 0;

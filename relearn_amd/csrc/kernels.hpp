@@ -54,10 +54,16 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
 void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
                         int always_explore, uint8_t *d_flags);
 struct AgentKey { uint32_t w[8]; };
-void launch_dqn_sample(rl_engine *eng, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
+void launch_dqn_sample(rl_engine *eng, hipStream_t stream, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
                        uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,
                        uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential,
                        uint32_t n_batches = 1);
+void launch_dqn_build_all(rl_engine *eng, const ReplayDev &rp, uint32_t n_batches, uint32_t widest_eps, uint32_t max_eps,
+                          const uint32_t *d_lane, const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
+                          const DqnCountsDev *d_counts, float *d_obs, size_t obs_stride, uint8_t *d_action,
+                          float *d_target, size_t step_stride, float gamma);
+void launch_replay_planes(rl_engine *eng, const ReplayDev &rp, int field, void *d_out);
+bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total);
 void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,
                                 const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                                 float *d_obs, size_t out_plane, uint8_t *d_action, float *d_target, float gamma,

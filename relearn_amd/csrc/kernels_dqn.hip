@@ -4,9 +4,26 @@
 // Reference: DqnActor::act (src/torch/agents/dqn.rs:360-379), ReplayBuffer::write_step (src/agents/buffers/
 // replay.rs:89-115), DqnAgent::batch_update_slice_refs sample_minibatch (dqn.rs:280-314), StepValueTarget
 // (src/torch/agents/critics/mod.rs:203-229).
+#include <memory>
+
+#include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
 #include "replay.hpp"
+
+// one step record: two 16-byte accesses
+__device__ __forceinline__ ReplayRec rec_load(const ReplayRec *__restrict__ p) {
+  const uint4 a = reinterpret_cast<const uint4 *>(p)[0], b = reinterpret_cast<const uint4 *>(p)[1];
+  ReplayRec r;
+  r.x[0] = __uint_as_float(a.x), r.x[1] = __uint_as_float(a.y), r.x[2] = __uint_as_float(a.z), r.x[3] = __uint_as_float(a.w);
+  r.x[4] = __uint_as_float(b.x), r.reward = __uint_as_float(b.y), r.af = b.z, r.pad = b.w;
+  return r;
+}
+__device__ __forceinline__ void rec_store(ReplayRec *__restrict__ p, const ReplayRec &r) {
+  reinterpret_cast<uint4 *>(p)[0] = make_uint4(__float_as_uint(r.x[0]), __float_as_uint(r.x[1]), __float_as_uint(r.x[2]),
+                                               __float_as_uint(r.x[3]));
+  reinterpret_cast<uint4 *>(p)[1] = make_uint4(__float_as_uint(r.x[4]), __float_as_uint(r.reward), r.af, 0u);
+}
 
 struct DevEpEnds {
   uint32_t *base;  // [E][N]
@@ -65,7 +82,6 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
   LaneRing ring{rp.head[i], rp.count[i], rp.ep_head[i], rp.ep_count[i], rp.total[i]};
   DevEpEnds eps{rp.ep_end, n, i};
   LaneActorRng<BLOCK> rng{&words[threadIdx.x], c.key_actor, lane, rp.actor_pos[i], ~0ull};
-  const size_t plane = (size_t)rp.C * n;
   for (uint32_t t = 0; t < T; ++t) {
     float f[D];
     cp_features<D>(c, s, f);
@@ -97,16 +113,17 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
       *rp.error = 1;  // WriteExperienceError::Full: a single episode longer than the lane's capacity
       break;
     }
-    const size_t o = (size_t)(slot_abs % rp.C) * n + i;
+    const size_t o = (size_t)i * rp.C + slot_abs % rp.C;
+    ReplayRec rec;
 #pragma unroll
-    for (int d = 0; d < D; ++d) rp.obs[d * plane + o] = f[d];
-    rp.action[o] = (uint8_t)a;
-    rp.reward[o] = 1.0f;  // CartPole::step reward (cartpole.rs:140)
-    rp.flag[o] = (uint8_t)succ_rec;
+    for (int d = 0; d < 5; ++d) rec.x[d] = d < D ? f[d < D ? d : 0] : 0.0f;
+    rec.reward = 1.0f;  // CartPole::step reward (cartpole.rs:140)
+    rec.af = (uint32_t)a | (uint32_t)succ_rec << 8;
+    rec_store(rp.rec + o, rec);
     if (succ_rec == RL_SUCC_INTERRUPT) {
       cp_features<D>(c, s, f);
 #pragma unroll
-      for (int d = 0; d < D; ++d) rp.next_obs[d * plane + o] = f[d];
+      for (int d = 0; d < D; ++d) rp.next[o].x[d] = f[d];
     }
     flags_out[(size_t)t * n + i] = (uint8_t)succ_rec;
     if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, lane);
@@ -137,31 +154,32 @@ __global__ void __launch_bounds__(64) k_dqn_build_minibatch(ReplayDev rp, const 
   __shared__ float carry;
   const uint32_t e = blockIdx.x;
   const uint32_t lane = ep_lane[e], start = ep_start[e], len = ep_len[e], off = ep_offset[e];
-  const uint32_t n = rp.N;
-  const size_t plane = (size_t)rp.C * n;
+  const ReplayRec *__restrict__ ring = rp.rec + (size_t)lane * rp.C;
   for (uint32_t i = threadIdx.x; i < len; i += 64) {
-    const size_t o = (size_t)((start + i) % rp.C) * n + lane;
+    const uint32_t slot = (start + i) % rp.C;
+    const ReplayRec rec = rec_load(ring + slot);
 #pragma unroll
-    for (int d = 0; d < D; ++d) out_obs[d * out_plane + off + i] = rp.obs[d * plane + o];
-    out_action[off + i] = rp.action[o];
+    for (int d = 0; d < D; ++d) out_obs[d * out_plane + off + i] = rec.x[d];
+    out_action[off + i] = (uint8_t)(rec.af & 0xffu);
     if (one_step_td) {
-      const uint8_t fl = rp.flag[o];
+      const uint32_t fl = rec.af >> 8;
       float vnext = 0.0f;
       if (fl != RL_SUCC_TERMINATE) {
         float x[D], z[2];
         if (fl == RL_SUCC_INTERRUPT || i + 1 == len) {
+          const ReplayNext *__restrict__ nx = rp.next + (size_t)lane * rp.C + slot;
 #pragma unroll
-          for (int d = 0; d < D; ++d) x[d] = rp.next_obs[d * plane + o];
+          for (int d = 0; d < D; ++d) x[d] = nx->x[d];
         } else {
-          const size_t o1 = (size_t)((start + i + 1) % rp.C) * n + lane;
+          const ReplayRec r1 = rec_load(ring + (start + i + 1) % rp.C);
 #pragma unroll
-          for (int d = 0; d < D; ++d) x[d] = rp.obs[d * plane + o1];
+          for (int d = 0; d < D; ++d) x[d] = r1.x[d];
         }
         mlp_forward_lane<D, 2>(qnet, H, x, z);
         vnext = z[1] > z[0] ? z[1] : z[0];  // amax(-1)
       }
       const float dn = gamma * vnext;
-      out_target[off + i] = rp.reward[o] + dn;
+      out_target[off + i] = rec.reward + dn;
     }
   }
   if (one_step_td) return;
@@ -170,7 +188,7 @@ __global__ void __launch_bounds__(64) k_dqn_build_minibatch(ReplayDev rp, const 
   __syncthreads();
   for (uint32_t hi = len; hi > 0;) {
     const uint32_t lo = hi > 1024 ? hi - 1024 : 0, cnt = hi - lo;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 64) rew[i] = rp.reward[(size_t)((start + lo + i) % rp.C) * n + lane];
+    for (uint32_t i = threadIdx.x; i < cnt; i += 64) rew[i] = ring[(start + lo + i) % rp.C].reward;
     __syncthreads();
     if (threadIdx.x == 0) {
       float g = carry;
@@ -190,6 +208,59 @@ __global__ void __launch_bounds__(64) k_dqn_build_minibatch(ReplayDev rp, const 
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < cnt; i += 64) out_target[off + lo + i] = rew[i];
     __syncthreads();
+    hi = lo;
+  }
+}
+
+// All minibatches of an update in ONE launch (reward-to-go targets do not depend on the network, so nothing in an update
+// has to wait for them): one wave per sampled episode, blockIdx.y = minibatch.  Same arithmetic as the builder above
+// (G_t = r_t + gamma * G_{t+1}: multiply, then add), the scan runs on broadcast values of one 64-step chunk at a time,
+// last chunk first.  Minibatch b lands at obs + b * obs_stride (plane stride 2 * its step count: the T = 1 trajectory
+// layout the gradient kernels read), action / target + b * step_stride.
+constexpr int BUILD_ALL_WAVES = 4;
+template <int D>
+__global__ void __launch_bounds__(BUILD_ALL_WAVES * 64)
+    k_dqn_build_all(ReplayDev rp, const uint32_t *__restrict__ ep_lane, const uint32_t *__restrict__ ep_start,
+                    const uint32_t *__restrict__ ep_len, const uint32_t *__restrict__ ep_offset, uint32_t max_eps,
+                    const DqnCountsDev *__restrict__ counts, float *__restrict__ out_obs, size_t obs_stride,
+                    uint8_t *__restrict__ out_action, float *__restrict__ out_target, size_t step_stride, float gamma) {
+  const uint32_t b = blockIdx.y, lane = threadIdx.x & 63;
+  const uint32_t e = blockIdx.x * BUILD_ALL_WAVES + (threadIdx.x >> 6);
+  const uint32_t n_eps = counts[b].n_eps, n_steps = counts[b].n_steps;
+  if (e >= n_eps) return;
+  const size_t eo = (size_t)b * max_eps + e;
+  const uint32_t ln = ep_lane[eo], start = ep_start[eo], len = ep_len[eo], off = ep_offset[eo];
+  const size_t out_plane = (size_t)2 * n_steps;
+  const ReplayRec *__restrict__ ring = rp.rec + (size_t)ln * rp.C;
+  float *__restrict__ obs_b = out_obs + (size_t)b * obs_stride;
+  uint8_t *__restrict__ act_b = out_action + (size_t)b * step_stride;
+  float *__restrict__ tgt_b = out_target + (size_t)b * step_stride;
+  float g = 0.0f;
+  bool first = true;
+  for (uint32_t hi = len; hi > 0;) {
+    const uint32_t lo = hi > 64 ? hi - 64 : 0, cnt = hi - lo;
+    const bool mine = lane < cnt;
+    const uint32_t i = lo + (mine ? lane : 0);
+    const ReplayRec rec = rec_load(ring + (start + i) % rp.C);
+    const float rew = rec.reward;
+    float out = 0.0f;
+    for (uint32_t k = cnt; k-- > 0;) {  // (uniform trip count; every lane carries the same g)
+      const float r = __shfl(rew, (int)k, 64);
+      if (first) {
+        g = r;
+        first = false;
+      } else {
+        const float p = g * gamma;
+        g = r + p;
+      }
+      if (lane == k) out = g;
+    }
+    if (mine) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) obs_b[d * out_plane + off + i] = rec.x[d];
+      act_b[off + i] = (uint8_t)(rec.af & 0xffu);
+      tgt_b[off + i] = out;
+    }
     hi = lo;
   }
 }
@@ -444,16 +515,20 @@ __global__ void __launch_bounds__(SAMPLE_BLOCK) k_dqn_sample(ReplayDev rp, Agent
   if (tid == 0) *agent_pos = pos_now;
 }
 
-void launch_dqn_sample(rl_engine *eng, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
-                       uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,
-                       uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential, uint32_t n_batches) {
-  ProfScope ps(eng, RL_K_SMALL);
+// `stream`: the engine's stream, or the side stream an update draws its later minibatches on (not profiled there)
+void launch_dqn_sample(rl_engine *eng, hipStream_t stream, const ReplayDev &rp, const AgentKey &key,
+                       uint64_t *d_agent_pos, uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane,
+                       uint32_t *d_start, uint32_t *d_len, uint32_t *d_off, DqnCountsDev *d_counts, int sequential,
+                       uint32_t n_batches) {
+  std::unique_ptr<ProfScope> ps;
+  if (stream == eng->stream) ps.reset(new ProfScope(eng, RL_K_SMALL));
   if (rp.N <= (uint32_t)SAMPLE_META_LANES)
-    hipLaunchKernelGGL(k_dqn_sample<true>, dim3(1), dim3(SAMPLE_BLOCK), 0, eng->stream, rp, key, d_agent_pos,
+    hipLaunchKernelGGL(k_dqn_sample<true>, dim3(1), dim3(SAMPLE_BLOCK), 0, stream, rp, key, d_agent_pos,
                        minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential, n_batches);
   else
-    hipLaunchKernelGGL(k_dqn_sample<false>, dim3(1), dim3(SAMPLE_BLOCK), 0, eng->stream, rp, key, d_agent_pos,
+    hipLaunchKernelGGL(k_dqn_sample<false>, dim3(1), dim3(SAMPLE_BLOCK), 0, stream, rp, key, d_agent_pos,
                        minibatch_steps, max_eps, d_lane, d_start, d_len, d_off, d_counts, sequential, n_batches);
+  RL_HIP_CHECK(hipGetLastError());
 }
 
 static inline uint32_t cdiv_d(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
@@ -485,4 +560,276 @@ void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_
     hipLaunchKernelGGL(k_dqn_build_minibatch<4>, dim3(n_eps), dim3(64), 0, eng->stream, rp, d_lane, d_start, d_len,
                        d_off, d_obs, out_plane, d_action, d_target, gamma, one_step_td, qnet->d_params,
                        (int)qnet->hidden);
+}
+
+void launch_dqn_build_all(rl_engine *eng, const ReplayDev &rp, uint32_t n_batches, uint32_t widest_eps, uint32_t max_eps,
+                          const uint32_t *d_lane, const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
+                          const DqnCountsDev *d_counts, float *d_obs, size_t obs_stride, uint8_t *d_action,
+                          float *d_target, size_t step_stride, float gamma) {
+  ProfScope ps(eng, RL_K_VALUES);
+  if (n_batches == 0 || widest_eps == 0) return;
+  const dim3 grid(cdiv_d(widest_eps, BUILD_ALL_WAVES), n_batches), block(BUILD_ALL_WAVES * 64);
+  if (rp.D == 5)
+    hipLaunchKernelGGL(k_dqn_build_all<5>, grid, block, 0, eng->stream, rp, d_lane, d_start, d_len, d_off, max_eps,
+                       d_counts, d_obs, obs_stride, d_action, d_target, step_stride, gamma);
+  else
+    hipLaunchKernelGGL(k_dqn_build_all<4>, grid, block, 0, eng->stream, rp, d_lane, d_start, d_len, d_off, max_eps,
+                       d_counts, d_obs, obs_stride, d_action, d_target, step_stride, gamma);
+  RL_HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+// The DQN gradient on the bf16 matrix pipe: forward + MSE loss + backward of the 5-128-2 action-value MLP over one
+// minibatch — mean((Q(s)[a] - target)^2), dqn.rs:316-326 — with the tile machinery of bf16_tile.hpp (exact three-piece
+// products, f32 accumulation; kernels_critic.hip is the one-output version of this kernel).  The loss gradient reaches
+// the hidden layer through row a_s of the output weights, so the masked sums over the samples come in two channels,
+//   M_c[j][k] = sum_{s : a_s = c} [pre_sj > 0] g_s x~_sk,  g_s = 2 (Q(s)[a_s] - target_s) / B,
+// (36 piece columns: one more accumulator set than fits beside the forward at two waves per SIMD — the kernel runs four
+// waves per workgroup with the whole register file; a minibatch is ~3 tiles per wave, so latency, not issue, binds) and
+//   dW1[j][k] = W2[0][j] M_0[j][k] + W2[1][j] M_1[j][k],   db1[j] likewise with k = 5,
+//   dW2[c][j] = sum_k W~1[j][k] M_c[j][k],                  db2[c] = sum_{a_s = c} g_s.
+// The forward carries both output chains (relu through |x|, as in the critic step) and picks Q(s)[a_s] per sample.
+// ================================================================================================
+constexpr int DQN_WAVES = 4;
+constexpr int DQN_FLUSH = 16;  // f32 -> f64 flush period in tiles
+
+__global__ void __launch_bounds__(DQN_WAVES * 64)
+    k_dqn_step_bf16(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
+                    double *__restrict__ slabB, float two_over_B, uint32_t P) {
+  using bt::f32x16;
+  using bt::Frag;
+  constexpr int D = 5, H = 128, NT = bt::NT, A = 2;
+  constexpr int CH = H * 7;            // one channel's image: per hidden unit M[0..5] (slot 6 unused)
+  constexpr int IMG = A * CH + A + 1;  // two channels, db2[0], db2[1], loss
+  __shared__ float Ysh[DQN_WAVES][A][32][33];
+  __shared__ double Acc[DQN_WAVES][IMG];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, hf = lane >> 5;
+  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H,
+                           *__restrict__ b2 = W2 + A * H;
+  const size_t B = (size_t)tr.T * tr.n;
+  const size_t plane = (size_t)(tr.T + 1) * tr.n;
+  double *acc64 = Acc[wave];
+  for (int p = lane; p < IMG; p += 64) acc64[p] = 0.0;
+
+  Frag fw[NT][3];
+  float w2v[A][NT];
+  float lv[A][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};  // the linear half of relu, per output
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = t * 32 + n;
+    const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
+    const float sc = bt::FWD_SCALE;  // relu' by conversion (bf16_tile.hpp); the |pre| chains take the scale back out
+    bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const float w2 = W2[a * H + j];
+      lv[a][0] = __builtin_fmaf(w2, wa, lv[a][0]);
+      lv[a][1] = __builtin_fmaf(w2, wb, lv[a][1]);
+      lv[a][2] = __builtin_fmaf(w2, hf == 0 ? w4 : bj, lv[a][2]);
+      w2v[a][t] = bt::FWD_UNSCALE * w2;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) lv[a][q] = lv[a][q] + __shfl_xor(lv[a][q], m, 64);
+  const float b20 = b2[0], b21 = b2[1];
+  f32x16 dm[A][NT];
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dm[a][t] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double loss64 = 0.0, db64[A] = {0.0, 0.0};
+  float loss32 = 0.0f, db32[A] = {0.0f, 0.0f};
+  bt::wave_lds_fence();
+
+  Frag selb[2];
+  bt::sel_frags(lane, selb);
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t wave_id = (size_t)blockIdx.x * DQN_WAVES + wave, n_waves = (size_t)gridDim.x * DQN_WAVES;
+  int since_flush = 0;
+  struct TileOp {
+    float xa, xb, xc, tgt;
+    int act;
+    bool valid;
+  };
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
+  auto load_tile = [&](size_t g) {  // (branch-free: padding lanes read sample B - 1 and are zeroed)
+    TileOp o;
+    const uint32_t sidx = (uint32_t)g * 32u + (uint32_t)n;
+    o.valid = g < n_tiles && sidx < B32;
+    const uint32_t sc = o.valid ? sidx : B32 - 1;
+    const float xa = tr.obs[(uint32_t)(2 * hf) * plane32 + sc], xb = tr.obs[(uint32_t)(2 * hf + 1) * plane32 + sc];
+    const float xc = tr.obs[4u * plane32 + sc], tg = tr.adv[sc];  // (the minibatch workspace keeps its targets in `adv`)
+    const int act = (int)tr.action[sc];
+    o.xa = o.valid ? xa : 0.0f;
+    o.xb = o.valid ? xb : 0.0f;
+    o.xc = o.valid ? xc : 0.0f;
+    o.tgt = o.valid ? tg : 0.0f;
+    o.act = o.valid ? act : 0;
+    return o;
+  };
+  auto flush_all = [&]() {
+    bt::flush(dm[0], acc64, 7, n, hf);
+    bt::flush(dm[1], acc64 + CH, 7, n, hf);
+    loss64 += (double)loss32;
+    db64[0] += (double)db32[0];
+    db64[1] += (double)db32[1];
+    loss32 = db32[0] = db32[1] = 0.0f;
+  };
+
+  TileOp op = load_tile(wave_id);
+  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
+    const TileOp next = load_tile(g + n_waves);
+    Frag fa[3];
+    bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
+    Frag ga[NT][2];
+    float yp[A][16];
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yp[a][r] = 0.0f;
+    f32x16 c = bt::layer1(fa, fw[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 cn = c;
+      if (t + 1 < NT) cn = bt::layer1(fa, fw[t + 1]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ab = __builtin_fabsf(c[r]);
+        yp[0][r] = __builtin_fmaf(ab, w2v[0][t], yp[0][r]);
+        yp[1][r] = __builtin_fmaf(ab, w2v[1][t], yp[1][r]);
+      }
+      bt::mask_tile(c, ga[t]);
+      c = cn;
+    }
+    // both outputs: transpose the 16 partial sums per lane through LDS (row = sample, column = source lane)
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ysh[wave][a][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[a][r];
+    bt::wave_lds_fence();
+    float qv[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      float part = bt::row_sum16(&Ysh[wave][a][n][hf * 16]);
+      float lin = lv[a][0] * op.xa;
+      lin = __builtin_fmaf(lv[a][1], op.xb, lin);
+      lin = __builtin_fmaf(lv[a][2], hf == 0 ? op.xc : 1.0f, lin);
+      part = part + lin;
+      float p0, p1;
+      bt::both_halves(part, p0, p1);
+      qv[a] = 0.5f * (p0 + p1) + (a == 0 ? b20 : b21);
+    }
+    const float d = (op.act == 0 ? qv[0] : qv[1]) - op.tgt;
+    const float gq = op.valid ? d * two_over_B : 0.0f;
+    const float g0 = op.act == 0 ? gq : 0.0f, g1 = op.act == 0 ? 0.0f : gq;
+    if (hf == 0 && op.valid) {
+      loss32 = __builtin_fmaf(d, d, loss32);
+      db32[0] = db32[0] + g0;
+      db32[1] = db32[1] + g1;
+    }
+    Frag ub[2];
+    bt::piece_frags_mfma(g0, op.xa, op.xb, op.xc, hf, selb, ub);
+    bt::backward(ga, ub, dm[0]);
+    bt::piece_frags_mfma(g1, op.xa, op.xb, op.xc, hf, selb, ub);
+    bt::backward(ga, ub, dm[1]);
+    bt::wave_lds_fence();  // Ysh is rewritten by the next tile
+    if (++since_flush == DQN_FLUSH) {
+      since_flush = 0;
+      flush_all();
+    }
+    op = next;
+  }
+  flush_all();
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+  double l = hf == 0 ? loss64 : 0.0, s0 = hf == 0 ? db64[0] : 0.0, s1 = hf == 0 ? db64[1] : 0.0;
+#pragma unroll
+  for (int s = 16; s > 0; s >>= 1) {
+    l = l + xlane(l, s);
+    s0 = s0 + xlane(s0, s);
+    s1 = s1 + xlane(s1, s);
+  }
+  if (lane == 0) {
+    acc64[A * CH] = s0;
+    acc64[A * CH + 1] = s1;
+    acc64[A * CH + 2] = l;
+  }
+  __syncthreads();
+  auto tot = [&](int src) {
+    double s = Acc[0][src];
+#pragma unroll
+    for (int w = 1; w < DQN_WAVES; ++w) s = s + Acc[w][src];
+    return s;
+  };
+  for (uint32_t p = threadIdx.x; p < P; p += DQN_WAVES * 64) {
+    double s;
+    if (p < (uint32_t)(H * D)) {
+      const int j = p / D, k = p % D;
+      s = tot(j * 7 + k) * (double)W2[j] + tot(CH + j * 7 + k) * (double)W2[H + j];
+    } else if (p < (uint32_t)(H * D + H)) {
+      const int j = p - H * D;
+      s = tot(j * 7 + 5) * (double)W2[j] + tot(CH + j * 7 + 5) * (double)W2[H + j];
+    } else if (p < (uint32_t)(H * D + H + A * H)) {
+      const int q = p - H * D - H, a = q / H, j = q % H;
+      s = tot(a * CH + j * 7 + 5) * (double)b1[j];
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += tot(a * CH + j * 7 + k) * (double)W1[j * D + k];
+    } else {
+      s = tot(A * CH + (int)(p - (H * D + H + A * H)));
+    }
+    slabA[(size_t)blockIdx.x * P + p] = s;
+  }
+  if (threadIdx.x < 4) slabB[(size_t)blockIdx.x * 4 + threadIdx.x] = threadIdx.x == 0 ? tot(A * CH + 2) : 0.0;
+}
+
+// returns false when the kernel is not built for this shape (the caller falls back to the f32 passes)
+bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total) {
+  if (mb->d.D != 5 || qnet->hidden != 128 || qnet->out_dim != 2 || qnet->general) return false;
+  if ((uint64_t)(mb->d.T + 1) * mb->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
+  ProfScope ps(mb->eng, RL_K_POLICY_FUSED);
+  const uint64_t n_tiles = (mb->B + 31) / 32, cus = (uint64_t)mb->eng->prop.multiProcessorCount;
+  uint64_t nb = (n_tiles + DQN_WAVES - 1) / DQN_WAVES;
+  if (nb > cus) nb = cus;
+  mb->nbV2 = (uint32_t)nb;  // slab rows of this launch (the slabs are sized for any grid up to 8 x CUs)
+  hipLaunchKernelGGL(k_dqn_step_bf16, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, mb->d,
+                     qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P);
+  RL_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// rl_dqn_replay_read: the store's step data in the documented plane layouts ([D][C][N] features, [C][N] the rest; lane
+// fastest) out of the records — a test / inspection path
+__global__ void __launch_bounds__(256) k_replay_planes(ReplayDev rp, int field, void *__restrict__ out) {
+  const size_t cn = (size_t)rp.C * rp.N;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cn) return;
+  const uint32_t lane = (uint32_t)(idx % rp.N), slot = (uint32_t)(idx / rp.N);
+  const size_t o = (size_t)lane * rp.C + slot;
+  if (field == RL_REPLAY_OBS) {
+    for (uint32_t d = 0; d < rp.D; ++d) static_cast<float *>(out)[d * cn + idx] = rp.rec[o].x[d];
+  } else if (field == RL_REPLAY_NEXT_OBS) {
+    for (uint32_t d = 0; d < rp.D; ++d) static_cast<float *>(out)[d * cn + idx] = rp.next[o].x[d];
+  } else if (field == RL_REPLAY_ACTION) {
+    static_cast<uint8_t *>(out)[idx] = (uint8_t)(rp.rec[o].af & 0xffu);
+  } else if (field == RL_REPLAY_FLAG) {
+    static_cast<uint8_t *>(out)[idx] = (uint8_t)(rp.rec[o].af >> 8);
+  } else {
+    static_cast<float *>(out)[idx] = rp.rec[o].reward;
+  }
+}
+
+void launch_replay_planes(rl_engine *eng, const ReplayDev &rp, int field, void *d_out) {
+  const size_t cn = (size_t)rp.C * rp.N;
+  hipLaunchKernelGGL(k_replay_planes, dim3(cdiv_d(cn, 256)), dim3(256), 0, eng->stream, rp, field, d_out);
+  RL_HIP_CHECK(hipGetLastError());
 }

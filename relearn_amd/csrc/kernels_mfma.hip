@@ -1,469 +1,14 @@
-// kernels_mfma.hip — fused full-batch policy-gradient kernels built around the f32 MFMA (the critic step, same tile
-// machinery with its backward on the bf16 matrix pipe, lives in kernels_critic.hip).
-//
-// One wavefront owns a tile of 32 samples at a time.  Layer 1 of the MLP (x~ [32 x 6] times W~1^T [6 x 128],
-// bias folded in as the 6th input) is 4 x 3 issues of v_mfma_f32_32x32x2_f32 whose D layout puts
-//     the HIDDEN UNIT on the lane   (col  = lane & 31, one 32-unit tile per accumulator)
-//     the SAMPLE in the registers   (row  = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = 0..15).
-// That orientation is chosen for the BACKWARD pass: every gradient entry of hidden unit j is a sum over
-// samples, i.e. over registers and over time — never over lanes — so lane j keeps dW1[j][:], db1[j], dW2[:][j]
-// in its own registers for the whole launch (exactly one cross-half add at the very end).
-// The only cross-lane step is the forward's sum over hidden units (y_s = sum_j w2_j h_sj): 16 partial sums per
-// lane go through a per-wave LDS transpose (conflict-free, stride 33) and come back as one value per sample;
-// the sample-owning lanes then do the per-sample scalar math (loss, dL/dy) and publish dL/dy * x~ rows that
-// the backward reads as LDS broadcasts.
-//
-// f32 MFMA runs at the f32 vector rate (64 FLOP/clk/SIMD) on its own pipe, so layer 1 (and its recompute)
-// costs no VALU issue slots; the VALU does relu, the 128->A layer, masks and the gradient accumulation.
-// Accumulation is two-level: f32 over 4 tiles (64 samples per accumulator), f64 across tiles/waves/workgroups
-// (see kernels_update.hip for why f32 sums are not accurate enough for TRPO's CG).
-//
-// Reference semantics: ValuesOpt::update (src/torch/agents/critics/opt.rs:100-126): loss = mse_loss(V(obs),
-// targets, Mean); backward; the Adam step itself is k_adam_step (kernels_update.hip).
+// kernels_mfma.hip — the fused full-batch policy passes (gradient, Fisher-vector product, evaluation) of the 5-128-2
+// categorical policy on the bf16 matrix pipe.  The tile machinery is bf16_tile.hpp; the critic step (one output) is
+// kernels_critic.hip, the DQN gradient (two outputs, two backward channels) is k_dqn_step_bf16 in kernels_dqn.hip.
+// (Rounds 1-2 ran these passes on the f32 MFMA with the backward on the VALU; that kernel is gone — its last user was
+// the DQN gradient.)
 #include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-static inline uint32_t cdiv_u(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
-
-__device__ __forceinline__ void wave_lds_fence() {
-  // LDS operations of one wavefront execute in program order; what is needed is that the compiler keeps that
-  // order across lanes it cannot see a dependence between.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 constexpr int V2_WAVES = 8;        // policy kernels: one workgroup of eight waves per CU (two per SIMD)
-constexpr int V2_NT = 4;           // 32-unit hidden tiles (H = 128)
-constexpr int V2_FLUSH = 8;        // f32 -> f64 flush period in tiles (8 x 16 samples per accumulator)
 
-// ================================================================================================
-// Policy kernels (2-action categorical head).  Same tile machinery as the critic kernel; differences:
-//   - two output channels: the forward carries 2 x 16 partial sums and transposes them one after the other
-//     through the same LDS tile;
-//   - the backward accumulates M_a[j][k] = sum_s [pre_sj > 0] dz_sa x~_sk for a = 0, 1 (12 values per hidden
-//     unit); at the end  dW1[j][k] = sum_a W2[a][j] M_a[j][k],  db1[j] = sum_a W2[a][j] M_a[j][5],
-//     dW2[a][j] = sum_k W~1[j][k] M_a[j][k]  (because h_sj = [pre_sj > 0] W~1[j].x~_s),  db2[a] = sum_s dz_sa.
-// Two-action softmax heads (every mode except PASS_DQN): the logit gradient of anything that depends on the logits
-// only through log-softmax is antisymmetric, dz_1 = -dz_0 (the rows of the softmax Jacobian sum to zero), so
-//   M_0 = -M_1 = M_d := sum_s [pre_sj > 0] g_s x~_sk  with  g_s = (dz_s0 - dz_s1) / 2,
-//   dW1[j][k] = (W2[0][j] - W2[1][j]) M_d[j][k],  dW2[0][j] = -dW2[1][j] = sum_k W~1[j][k] M_d[j][k].
-// One channel of 6 columns instead of two: the backward then runs as VALU FMAs with lane = hidden unit, exactly
-// like the critic's (k_critic_step_mfma), at half the work.  db2 keeps its two exact per-channel sums.
-// Reference semantics: Trpo::update closure + HessianVectorProduct (src/torch/agents/policies/trpo.rs:97-146,
-// src/torch/optimizers/conjugate_gradient.rs:262-339) and Categorical (src/torch/distributions/categorical.rs).
-// ================================================================================================
-
-struct PolicyTile {
-  float a0, a1, a2;
-  bool valid;
-};
-
-template <int MODE>  // PASS_INIT (gradient), PASS_JVP (Fisher-vector product), PASS_EVAL (loss / KL only)
-__global__ void __launch_bounds__(V2_WAVES * 64, 2)  // (three waves per SIMD: 30 spills and 10 % slower, measured;
-                                                     // with layer 1 recomputed for the backward, 12 spills, 9 % slower;
-                                                     // recomputing only two of the four hidden tiles: 43 spills)
-    k_policy_mfma(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
-                  float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
-                  uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
-  constexpr int D = 5, H = 128, NT = V2_NT, A = 2;
-  constexpr bool ANTI = MODE != PASS_DQN;  // antisymmetric logit gradient: one backward channel on the VALU
-  constexpr int IW = ANTI ? 7 : 12;        // f64 image slots per hidden unit (one or two channels of six columns)
-  constexpr int PIMG_M = H * IW + 5;       // then db2[0], db2[1], sum0, sum1, sum2
-  __shared__ float Ysh[V2_WAVES][32][33];
-  __shared__ __attribute__((aligned(16))) float Ush[V2_WAVES][32][ANTI ? 8 : 12];
-  __shared__ double Acc[V2_WAVES][MODE == PASS_EVAL ? 4 : PIMG_M];
-  if (skip != nullptr && *skip != 0) return;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, hf = lane >> 5;
-  const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H,
-                           *__restrict__ b2 = W2 + A * H;
-  const size_t B = (size_t)tr.T * tr.n;
-  const size_t plane = (size_t)(tr.T + 1) * tr.n;
-  double *acc64 = Acc[wave];
-  if (MODE != PASS_EVAL)
-    for (int p = lane; p < PIMG_M; p += 64) acc64[p] = 0.0;
-
-  float wb[NT][3], w2v[NT][A];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int j = t * 32 + n;
-    wb[t][0] = W1[j * D + hf];
-    wb[t][1] = W1[j * D + 2 + hf];
-    wb[t][2] = hf == 0 ? W1[j * D + 4] : b1[j];
-#pragma unroll
-    for (int a = 0; a < A; ++a) w2v[t][a] = W2[a * H + j];
-  }
-  // tangent copies (PASS_JVP only)
-  float tb[NT][3], t2v[NT][A];
-  float tb2[A] = {0.0f, 0.0f};
-  if (MODE == PASS_JVP) {
-    const float *__restrict__ V1 = tangent, *__restrict__ vb1 = V1 + H * D, *__restrict__ V2 = vb1 + H,
-                             *__restrict__ vb2 = V2 + A * H;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int j = t * 32 + n;
-      tb[t][0] = V1[j * D + hf];
-      tb[t][1] = V1[j * D + 2 + hf];
-      tb[t][2] = hf == 0 ? V1[j * D + 4] : vb1[j];
-#pragma unroll
-      for (int a = 0; a < A; ++a) t2v[t][a] = V2[a * H + j];
-    }
-    tb2[0] = vb2[0];
-    tb2[1] = vb2[1];
-  }
-  float w2d[NT], t2d[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    w2d[t] = w2v[t][0] - w2v[t][1];
-    t2d[t] = MODE == PASS_JVP ? t2v[t][0] - t2v[t][1] : 0.0f;
-  }
-  const float b2_0 = b2[0], b2_1 = b2[1];
-  // backward accumulators on the matrix pipe (see k_critic_step_mfma): 12 columns = 3 feature groups of 4
-  f32x4 dacc[NT][3];
-  float md[NT][6];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int fg = 0; fg < 3; ++fg) dacc[t][fg] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) md[t][k] = 0.0f;
-  }
-  if (ANTI)  // columns 6, 7 of the U rows are read as float4 padding and never written
-    for (int p = lane; p < 32 * 8; p += 64) (&Ush[wave][0][0])[p] = 0.0f;
-  const float big = 0x1p126f;
-  double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, db2_0 = 0.0, db2_1 = 0.0;  // owner-lane f64 sums
-  wave_lds_fence();
-
-  auto flush = [&]() {
-    if (MODE == PASS_EVAL) return;
-    if (ANTI) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int j = t * 32 + n;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          float v = md[t][k] + __shfl_xor(md[t][k], 32, 64);
-          if (hf == 0) acc64[j * IW + k] += (double)v;
-          md[t][k] = 0.0f;
-        }
-      }
-      return;
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int fg = 0; fg < 3; ++fg)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = dacc[t][fg][i] + __shfl_xor(dacc[t][fg][i], 32, 64);
-          const int j = t * 32 + 4 * (n >> 2) + i, k = 4 * fg + (n & 3);
-          if (hf == 0) acc64[j * 12 + k] += (double)v;
-          dacc[t][fg][i] = 0.0f;
-        }
-  };
-  // sum over the 32 source lanes of 16 per-lane partials: LDS transpose, result for sample n in both halves
-  auto lane_sum = [&](const float(&yp)[16]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
-    wave_lds_fence();
-    float part = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) part = part + Ysh[wave][n][hf * 16 + c];
-    float other = __shfl_xor(part, 32, 64);
-    wave_lds_fence();
-    return hf == 0 ? part + other : other + part;
-  };
-
-  const size_t n_tiles = (B + 31) / 32;
-  const size_t wave_id = (size_t)blockIdx.x * V2_WAVES + wave, n_waves = (size_t)gridDim.x * V2_WAVES;
-  int since_flush = 0;
-  auto load_tile = [&](size_t g) {
-    PolicyTile o;
-    const size_t sidx = g * 32 + n;
-    o.a0 = o.a1 = o.a2 = 0.0f;
-    o.valid = g < n_tiles && sidx < B;
-    if (o.valid) {
-      o.a0 = tr.obs[(size_t)hf * plane + sidx];
-      o.a1 = tr.obs[(size_t)(2 + hf) * plane + sidx];
-      o.a2 = hf == 0 ? tr.obs[(size_t)4 * plane + sidx] : 1.0f;
-    }
-    return o;
-  };
-  PolicyTile op = load_tile(wave_id);
-  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
-    PolicyTile next = load_tile(g + n_waves);
-    const size_t sidx = g * 32 + n;
-    f32x16 acc[NT];
-    float y0[16], y1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      y0[r] = 0.0f;
-      y1[r] = 0.0f;
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0, wb[t][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1, wb[t][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a2, wb[t][2], c, 0, 0, 0);
-      if (MODE == PASS_JVP) {
-        // tangent pre-activation of the same tile, consumed immediately (16 live registers)
-        f32x16 tc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        tc = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a0, tb[t][0], tc, 0, 0, 0);
-        tc = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a1, tb[t][1], tc, 0, 0, 0);
-        tc = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a2, tb[t][2], tc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // Only the DIFFERENCE of the two tangent logits enters the Fisher metric of a 2-way softmax:
-          // (diag(p) - p p^T) dz = p0 p1 (dz_0 - dz_1) (1, -1).  One chain with the differenced output weights:
-          // dz_0 - dz_1 = sum_j ((W2[0][j] - W2[1][j]) dh_j + (V2[0][j] - V2[1][j]) h_j) + (vb2_0 - vb2_1)
-          // with dh_j = relu'(pre_j) t_j and h_j = relu'(pre_j) pre_j: one relu' factor for both terms, and the
-          // accumulator keeps `pre` (the backward's relu' reads its sign just as well as h's) — four VALU ops per
-          // (sample, unit) instead of five
-          const float pre = c[r];
-          const float gsel = __builtin_amdgcn_fmed3f(pre * big, 0.0f, 1.0f);
-          float both = tc[r] * w2d[t];
-          both = __builtin_fmaf(pre, t2d[t], both);
-          y0[r] = __builtin_fmaf(gsel, both, y0[r]);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int hb = __builtin_bit_cast(int, (float)c[r]);
-          hb = hb > 0 ? hb : 0;
-          float h = __builtin_bit_cast(float, hb);
-          c[r] = h;
-          y0[r] = __builtin_fmaf(h, w2v[t][0], y0[r]);
-          y1[r] = __builtin_fmaf(h, w2v[t][1], y1[r]);
-        }
-      }
-      acc[t] = c;
-    }
-    const float s0 = lane_sum(y0), s1 = MODE == PASS_JVP ? 0.0f : lane_sum(y1);
-    // ---- per-sample math on the owner lanes (lane n and n+32 both hold sample n)
-    float dz0 = 0.0f, dz1 = 0.0f;
-    if (MODE == PASS_JVP) {
-      const float delta = s0 + (tb2[0] - tb2[1]);
-      float p0 = 0.0f, p1 = 0.0f;
-      if (op.valid) {
-        p0 = rl_expf(lp0[sidx]);
-        p1 = rl_expf(lp0[B + sidx]);
-      }
-      dz0 = op.valid ? (p0 * p1) * delta * inv_B : 0.0f;
-      dz1 = -dz0;
-    } else {
-      float z[2] = {s0 + b2_0, s1 + b2_1}, lp[2];
-      const float adv = op.valid ? tr.adv[sidx] : 0.0f;
-      const int act = op.valid ? (int)tr.action[sidx] : 0;
-      if (MODE == PASS_DQN) {
-        // MSE on the taken action's value against the target held in `adv` (dqn.rs:316-326); inv_B = 2 / B
-        const float dq = (act == 0 ? z[0] : z[1]) - adv;
-        const float g = op.valid ? dq * inv_B : 0.0f;
-        dz0 = act == 0 ? g : 0.0f;
-        dz1 = act == 1 ? g : 0.0f;
-        if (op.valid && hf == 0) sum0 += (double)(dq * dq);
-      } else if (MODE == PASS_PPO) {
-        // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
-        log_softmax_lane<2>(z, lp);
-        float l0a = 0.0f;
-        if (op.valid) l0a = lp0[(size_t)act * B + sidx];
-        const float lpa = act == 0 ? lp[0] : lp[1];
-        const float ratio = rl_expf(lpa - l0a);
-        const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
-        const float u1 = ratio * adv, u2 = clipped * adv;
-        const bool inside = ratio >= clip_lo && ratio <= clip_hi;
-        const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
-        const float c = -(gr * ratio) * inv_B;
-        dz0 = op.valid ? c * ((act == 0 ? 1.0f : 0.0f) - rl_expf(lp[0])) : 0.0f;
-        dz1 = op.valid ? c * ((act == 1 ? 1.0f : 0.0f) - rl_expf(lp[1])) : 0.0f;
-        if (op.valid && hf == 0) sum0 += (double)(u1 < u2 ? u1 : u2);
-      } else {
-      log_softmax_lane<2>(z, lp);
-      if (MODE == PASS_INIT) {
-        if (op.valid && hf == 0) {
-          lp0[sidx] = lp[0];
-          lp0[B + sidx] = lp[1];
-        }
-        float lpa = act == 0 ? lp[0] : lp[1];
-        float ratio = rl_expf(lpa - lpa);
-        float c = -(ratio * adv) * inv_B;
-        float pa0 = rl_expf(lp[0]), pa1 = rl_expf(lp[1]);
-        dz0 = op.valid ? c * ((act == 0 ? 1.0f : 0.0f) - pa0) : 0.0f;
-        dz1 = op.valid ? c * ((act == 1 ? 1.0f : 0.0f) - pa1) : 0.0f;
-        float cl0 = lp[0] < -3.402823466e+38f ? -3.402823466e+38f : lp[0];
-        float cl1 = lp[1] < -3.402823466e+38f ? -3.402823466e+38f : lp[1];
-        float ent = cl0 * pa0;
-        ent += cl1 * pa1;
-        if (op.valid && hf == 0) {
-          sum0 += (double)(ratio * adv);
-          sum1 += (double)(-ent);
-          sum2 += (double)(lpa * adv);
-        }
-      } else {  // PASS_EVAL
-        float l00 = 0.0f, l01 = 0.0f;
-        if (op.valid) {
-          l00 = lp0[sidx];
-          l01 = lp0[B + sidx];
-        }
-        float lpa = act == 0 ? lp[0] : lp[1];
-        float l0a = act == 0 ? l00 : l01;
-        float ratio = rl_expf(lpa - l0a);
-        float rel0 = l00 - lp[0], rel1 = l01 - lp[1];
-        if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
-        if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
-        float kl = rel0 * rl_expf(l00);
-        kl += rel1 * rl_expf(l01);
-        if (op.valid && hf == 0) {
-          sum0 += (double)(ratio * adv);
-          sum1 += (double)kl;
-        }
-      }
-      }
-    }
-    if (MODE != PASS_EVAL) {
-      if (hf == 0) {
-        db2_0 += (double)dz0;
-        db2_1 += (double)dz1;
-      }
-      if (ANTI) {
-        // one channel: u[sample][k] = g * x~_k with g = (dz_0 - dz_1) / 2, then lane = hidden unit FMAs
-        const float gd = 0.5f * (dz0 - dz1);
-        Ush[wave][n][hf] = gd * op.a0;
-        Ush[wave][n][2 + hf] = gd * op.a1;
-        Ush[wave][n][4 + hf] = gd * op.a2;
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float4 *src = reinterpret_cast<const float4 *>(&Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0]);
-          const float4 lo = src[0], hi = src[1];
-          const float u[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) md[t][k] = __builtin_fmaf(gsel, u[k], md[t][k]);
-          }
-        }
-        wave_lds_fence();
-        if (++since_flush == V2_FLUSH) {
-          since_flush = 0;
-          flush();
-        }
-        op = next;
-        continue;
-      }
-      if constexpr (!ANTI) {
-      // publish u[sample][a*6 + k] = dz_a * x~_k
-      Ush[wave][n][hf] = dz0 * op.a0;
-      Ush[wave][n][2 + hf] = dz0 * op.a1;
-      Ush[wave][n][4 + hf] = dz0 * op.a2;
-      Ush[wave][n][6 + hf] = dz1 * op.a0;
-      Ush[wave][n][8 + hf] = dz1 * op.a1;
-      Ush[wave][n][10 + hf] = dz1 * op.a2;
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float *urow = &Ush[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][0];
-        const float ub0 = urow[lane & 3], ub1 = urow[4 + (lane & 3)], ub2 = urow[8 + (lane & 3)];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float gsel = __builtin_amdgcn_fmed3f((float)acc[t][r] * big, 0.0f, 1.0f);
-          dacc[t][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub0, dacc[t][0], 0, 0, 0);
-          dacc[t][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub1, dacc[t][1], 0, 0, 0);
-          dacc[t][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(gsel, ub2, dacc[t][2], 0, 0, 0);
-        }
-      }
-      wave_lds_fence();
-      if (++since_flush == V2_FLUSH) {
-        since_flush = 0;
-        flush();
-      }
-      }
-    }
-    op = next;
-  }
-  flush();
-  auto xlane = [](double v, int mask) {
-    uint64_t bits = rl_f64_bits(v);
-    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
-    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
-    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
-  };
-  double r0 = hf == 0 ? sum0 : 0.0, r1 = hf == 0 ? sum1 : 0.0, r2 = hf == 0 ? db2_0 : 0.0, r3 = hf == 0 ? db2_1 : 0.0;
-  double r4 = hf == 0 ? sum2 : 0.0;
-#pragma unroll
-  for (int s = 16; s > 0; s >>= 1) {
-    r0 = r0 + xlane(r0, s);
-    r1 = r1 + xlane(r1, s);
-    r2 = r2 + xlane(r2, s);
-    r3 = r3 + xlane(r3, s);
-    if (MODE == PASS_INIT) r4 = r4 + xlane(r4, s);
-  }
-  constexpr int TAIL = MODE == PASS_EVAL ? 0 : H * IW;
-  if (lane == 0) {
-    acc64[TAIL + 0] = r2;
-    acc64[TAIL + 1] = r3;
-    acc64[TAIL + 2] = r0;
-    acc64[TAIL + 3] = r1;
-    if (MODE == PASS_INIT) acc64[TAIL + 4] = r4;
-  }
-  __syncthreads();
-  auto tot = [&](int src) {
-    double s = Acc[0][src];
-#pragma unroll
-    for (int w = 1; w < V2_WAVES; ++w) s = s + Acc[w][src];
-    return s;
-  };
-  if (MODE != PASS_EVAL) {
-    for (uint32_t p = threadIdx.x; p < P; p += V2_WAVES * 64) {
-      double s = 0.0;
-      if (ANTI && p < (uint32_t)(H * D + H + A * H)) {
-        // M_0 = M_d, M_1 = -M_d
-        if (p < (uint32_t)(H * D)) {
-          int j = p / D, k = p % D;
-          s = tot(j * IW + k) * ((double)W2[j] - (double)W2[H + j]);
-        } else if (p < (uint32_t)(H * D + H)) {
-          int j = p - H * D;
-          s = tot(j * IW + 5) * ((double)W2[j] - (double)W2[H + j]);
-        } else {
-          int q = p - H * D - H, a = q / H, j = q % H;
-          s = tot(j * IW + 5) * (double)b1[j];
-#pragma unroll
-          for (int k = 0; k < D; ++k) s += tot(j * IW + k) * (double)W1[j * D + k];
-          if (a == 1) s = -s;
-        }
-      } else if (p < (uint32_t)(H * D)) {
-        int j = p / D, k = p % D;
-        s = tot(j * 12 + k) * (double)W2[j] + tot(j * 12 + 6 + k) * (double)W2[H + j];
-      } else if (p < (uint32_t)(H * D + H)) {
-        int j = p - H * D;
-        s = tot(j * 12 + 5) * (double)W2[j] + tot(j * 12 + 11) * (double)W2[H + j];
-      } else if (p < (uint32_t)(H * D + H + A * H)) {
-        int q = p - H * D - H, a = q / H, j = q % H;
-        s = tot(j * 12 + a * 6 + 5) * (double)b1[j];
-#pragma unroll
-        for (int k = 0; k < D; ++k) s += tot(j * 12 + a * 6 + k) * (double)W1[j * D + k];
-      } else {
-        s = tot(TAIL + (int)(p - (H * D + H + A * H)));
-      }
-      slabA[(size_t)blockIdx.x * P + p] = s;
-    }
-  }
-  if (threadIdx.x < 4) {
-    double v = 0.0;
-    if (MODE != PASS_JVP && threadIdx.x < 2) v = tot(TAIL + 2 + threadIdx.x);
-    if (MODE == PASS_INIT && threadIdx.x == 2) v = tot(TAIL + 4);
-    slabB[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
-  }
-}
-
-// ---------------------------------------------------------------- launcher
 // ================================================================================================
 // Policy passes on the bf16 matrix pipe (tile machinery: bf16_tile.hpp; every product exact, f32 accumulation).
 //   PASS_INIT / PASS_PPO   gradient of the (clipped) surrogate: forward, per-sample math, masked-sum backward
@@ -868,22 +413,18 @@ __global__ void __launch_bounds__(WAVES * 64)
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
+  if (mode == PASS_DQN) return false;  // k_dqn_step_bf16 (kernels_dqn.hip)
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernels
   ProfScope ps(traj->eng, mode == PASS_JVP ? RL_K_POLICY_FVP : RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
   hipStream_t s = traj->eng->stream;
   uint32_t P = (uint32_t)policy->P;
-#define PLAUNCH(MM)                                                                                              \
-  hipLaunchKernelGGL((k_policy_mfma<MM>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0, traj->slabA, \
-                     traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
 #define BLAUNCH(MM)                                                                                                  \
   hipLaunchKernelGGL((k_policy_bf16<MM, V2_WAVES>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0,       \
                      traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
-  if (mode == PASS_DQN) inv_B = 2.0f / (float)B_total;
   if (mode == PASS_INIT) BLAUNCH(PASS_INIT);
   else if (mode == PASS_JVP) BLAUNCH(PASS_JVP);
-  else if (mode == PASS_DQN) PLAUNCH(PASS_DQN);
   else if (mode == PASS_PPO) BLAUNCH(PASS_PPO);
   else {
     // the evaluation pass has no backward state: with the weight fragments in LDS it fits twelve waves per CU (152
@@ -892,7 +433,6 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
     hipLaunchKernelGGL((k_policy_bf16<PASS_EVAL, EVAL_WAVES, true>), g, dim3(EVAL_WAVES * 64), 0, s, traj->d,
                        policy->d_params, d_tangent, traj->lp0, traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi);
   }
-#undef PLAUNCH
 #undef BLAUNCH
   return true;
 }

@@ -189,6 +189,33 @@ def test_update_against_oracle(engine, variant, td):
     assert np.abs(dqn.qnet.get_params() - osim.qparams).max() < PARAM_ATOL
 
 
+def test_update_builds_all_minibatches_at_once(engine):
+    """Reward-to-go updates gather every minibatch of the update in one launch; the last one stays readable and is
+    bit-identical to the oracle's (the same bars as the one-at-a-time builder), episodes longer than a wave's 64-step
+    chunk included."""
+    dqn, osim = make(engine, n=192, capacity=400, minibatch=9000, opt_steps=5, max_steps=150, eps=("const", 0.9))
+    dqn.collect(330)
+    osim.collect(330, 0.9)
+    st, losses_d = dqn.update(want_losses=True)
+    for _ in range(4):
+        osim.sample()
+    lanes, starts, lens, ns = osim.sample()
+    assert lens.max() > 64 and st.last_minibatch_steps == ns and st.last_minibatch_episodes == len(lanes)
+    assert dqn.agent_rng_pos() == osim.agent_pos()
+    obs_o, act_o, tgt_o = osim.minibatch(lanes, starts, lens)
+    assert np.array_equal(dqn.minibatch_read(ra.MB_EP_LEN), lens)
+    assert np.array_equal(dqn.minibatch_read(ra.MB_OBS).T, obs_o)
+    assert np.array_equal(dqn.minibatch_read(ra.MB_ACTION), act_o.astype(np.uint8))
+    assert np.array_equal(dqn.minibatch_read(ra.MB_TARGET), tgt_o)
+    # and the one-at-a-time path takes the workspace back
+    ne, ns2 = dqn.minibatch_sample()
+    lanes, starts, lens, ns_o = osim.sample()
+    assert (ne, ns2) == (len(lanes), ns_o)
+    obs_o, act_o, tgt_o = osim.minibatch(lanes, starts, lens)
+    assert np.array_equal(dqn.minibatch_read(ra.MB_OBS).T, obs_o)
+    assert np.array_equal(dqn.minibatch_read(ra.MB_TARGET), tgt_o)
+
+
 def test_cartpole_dqn_learns_something(engine):
     """A few collect/update rounds of the whole loop: the loss falls and nothing is NaN.  (The reference's own DQN
     test, learns_deterministic_bandit at dqn.rs:391-414, needs the bandit env; this is the CartPole analogue.)"""
