@@ -1,111 +1,87 @@
-// Probe: cost of a device-wide barrier inside a persistent kernel on gfx950 (256 workgroups, one per CU), against the
-// gap between two dependent kernels in one stream.  Every spin loop is bounded, so the kernel always exits.
+// What does one optimisation step cost inside a persistent kernel?  256 workgroups (one per CU), per iteration: every
+// workgroup writes a 642-double slab row, grid barrier, every workgroup reduces 3 columns over the 256 rows and writes
+// 3 parameters, grid barrier, every workgroup reads the 642 parameters.   build: hipcc --offload-arch=gfx950 -O3 grid_barrier.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-struct Bar {
-  unsigned int count;
-  unsigned int gen;
-  unsigned int timeout;
-};
-
-__device__ __forceinline__ bool grid_barrier(Bar *b, unsigned int n_blocks, unsigned int &local_gen) {
+__device__ __forceinline__ bool grid_sync(unsigned *counter, unsigned target) {
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
-    const unsigned int target = local_gen + 1;
     __threadfence();
-    const unsigned int prev = __hip_atomic_fetch_add(&b->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == n_blocks - 1) {
-      __hip_atomic_store(&b->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&b->gen, target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      unsigned int spins = 0;
-      while (__hip_atomic_load(&b->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 22)) {
-          ok = false;
-          atomicAdd(&b->timeout, 1u);
-          break;
-        }
-      }
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_readcyclecounter() - t0 > 4000000000ull) { ok = false; break; }
     }
     __threadfence();
   }
-  local_gen += 1;
   __syncthreads();
   return ok;
 }
 
-__global__ void __launch_bounds__(768) k_persistent(Bar *b, int n_barriers, float *data, float *out) {
-  unsigned int gen = 0;
+template <int MODE>  // 0: barriers only; 1: + slab write / column reduce / param exchange
+__global__ void __launch_bounds__(512) k_loop(unsigned *counter, double *slab, float *params, int iters, float *out) {
+  const int P = 642, nwg = gridDim.x;
+  __shared__ float ps[648];
   float acc = 0.0f;
-  for (int i = 0; i < n_barriers; ++i) {
-    // a little memory traffic that must be visible across the barrier
-    if (threadIdx.x == 0) data[blockIdx.x] = (float)(i + 1);
-    if (!grid_barrier(b, gridDim.x, gen)) break;
-    acc += __builtin_nontemporal_load(&data[(blockIdx.x + 1) % gridDim.x]);
+  unsigned target = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 1) {
+      double *row = slab + ((size_t)(it & 1) * nwg + blockIdx.x) * P;
+      for (int p = threadIdx.x; p < P; p += 512) row[p] = (double)(ps[p] + it);
+    }
+    target += nwg;
+    if (!grid_sync(counter, target)) return;
+    if (MODE == 1) {
+      // columns 3 b .. 3 b + 2: 16 chains x 16 rows each, as k_reduce_adam sums them
+      const int c = threadIdx.x >> 4, w = threadIdx.x & 15, col = blockIdx.x * 3 + c;
+      if (c < 3 && col < P) {
+        const double *base = slab + (size_t)(it & 1) * nwg * P + col;
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (w + 16 * u) < nwg ? base[(size_t)(w + 16 * u) * P] : 0.0;
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a = a + v[u];
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t = t + __shfl(a, (threadIdx.x & ~15) + k, 64);
+        if (w == 0) params[(size_t)((it + 1) & 1) * 648 + col] = (float)t * 1e-9f;
+      }
+    }
+    target += nwg;
+    if (!grid_sync(counter, target)) return;
+    if (MODE == 1) {
+      for (int p = threadIdx.x; p < P; p += 512) ps[p] = params[(size_t)((it + 1) & 1) * 648 + p];
+      __syncthreads();
+      acc += ps[threadIdx.x % P];
+    }
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = acc;
-}
-
-__global__ void __launch_bounds__(768) k_tiny(float *data, int i) {
-  if (threadIdx.x == 0) data[blockIdx.x] = data[(blockIdx.x + 1) % gridDim.x] + (float)i;
+  if (out) out[blockIdx.x * 512 + threadIdx.x] = acc;
 }
 
 int main() {
-  hipDeviceProp_t prop;
-  (void)hipGetDeviceProperties(&prop, 0);
-  const int nb = prop.multiProcessorCount;
-  Bar *bar;
-  float *data, *out;
-  (void)hipMalloc(&bar, sizeof(Bar));
-  (void)hipMalloc(&data, nb * sizeof(float));
-  (void)hipMalloc(&out, nb * sizeof(float));
-  hipStream_t s;
-  (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  for (int threads : {256, 768}) {
-    for (int nbar : {1, 101, 1001}) {
-      (void)hipMemsetAsync(bar, 0, sizeof(Bar), s);
-      (void)hipMemsetAsync(data, 0, nb * sizeof(float), s);
-      void *args[] = {&bar, &nbar, &data, &out};
-      float ms = 0;
-      for (int rep = 0; rep < 2; ++rep) {
-        (void)hipMemsetAsync(bar, 0, sizeof(Bar), s);
-        (void)hipEventRecord(e0, s);
-        hipError_t rc = hipLaunchCooperativeKernel((void *)k_persistent, dim3(nb), dim3(threads), args, 0, s);
-        (void)hipEventRecord(e1, s);
-        (void)hipEventSynchronize(e1);
-        if (rc != hipSuccess) printf("cooperative launch failed: %s\n", hipGetErrorString(rc));
-        (void)hipEventElapsedTime(&ms, e0, e1);
-      }
-      Bar h;
-      std::vector<float> ho(nb);
-      (void)hipMemcpy(&h, bar, sizeof(Bar), hipMemcpyDeviceToHost);
-      (void)hipMemcpy(ho.data(), out, nb * sizeof(float), hipMemcpyDeviceToHost);
-      // expected: sum_{i=1..nbar} i
-      double want = 0.5 * nbar * (nbar + 1.0);
-      int bad = 0;
-      for (int i = 0; i < nb; ++i) bad += ho[i] != (float)want;
-      printf("persistent %d WGs x %d thr, %4d barriers: %.3f ms total, timeouts %u, wrong %d\n", nb, threads, nbar, ms,
-             h.timeout, bad);
+  const int nwg = 256, iters = 200;
+  unsigned *counter; double *slab; float *params, *out;
+  CK(hipMalloc(&counter, 4)); CK(hipMalloc(&slab, sizeof(double) * 2 * nwg * 642)); CK(hipMalloc(&params, 4 * 2 * 648));
+  CK(hipMalloc(&out, 4 * nwg * 512));
+  CK(hipMemset(params, 0, 4 * 2 * 648));
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int mode = 0; mode < 2; ++mode)
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemset(counter, 0, 4));
+      CK(hipEventRecord(a));
+      if (mode == 0) hipLaunchKernelGGL(k_loop<0>, dim3(nwg), dim3(512), 0, 0, counter, slab, params, iters, out);
+      else hipLaunchKernelGGL(k_loop<1>, dim3(nwg), dim3(512), 0, 0, counter, slab, params, iters, out);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b));
+      unsigned c; CK(hipMemcpy(&c, counter, 4, hipMemcpyDeviceToHost));
+      printf("mode %d: %.2f us per iteration (two barriers%s), counter %u of %u\n", mode, ms * 1e3 / iters,
+             mode ? " + slab write + 3-column reduce + parameter exchange" : "", c, 2u * nwg * iters);
     }
-  }
-  // dependent tiny kernels in one stream
-  for (int n : {100, 1000}) {
-    float ms = 0;
-    for (int rep = 0; rep < 2; ++rep) {
-      (void)hipEventRecord(e0, s);
-      for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_tiny, dim3(nb), dim3(768), 0, s, data, i);
-      (void)hipEventRecord(e1, s);
-      (void)hipEventSynchronize(e1);
-      (void)hipEventElapsedTime(&ms, e0, e1);
-    }
-    printf("%d dependent tiny launches: %.3f ms = %.2f us each\n", n, ms, 1e3 * ms / n);
-  }
   return 0;
 }
