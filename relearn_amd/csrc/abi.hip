@@ -1214,6 +1214,8 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   }
   t->slabA = dalloc<double>((size_t)rows * t->Pmax);
   t->slabB = dalloc<double>((size_t)rowsB * 4);
+  t->cap_slabA = (uint64_t)rows * t->Pmax;
+  t->cap_slabB = (uint64_t)rowsB * 4;
   t->vec = dalloc<float>(t->Pmax + 4);
   t->cg_x = dalloc<float>(t->Pmax);
   t->cg_r = dalloc<float>(t->Pmax);

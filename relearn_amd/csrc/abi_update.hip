@@ -71,7 +71,7 @@ static void run_policy_gradient(rl_mlp *policy, rl_traj *traj) {
   if (rl_module_is_recurrent(policy->kind)) return seq_policy_pass(policy, traj, PASS_INIT, true, 0.0f, 0.0f);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr)) {
-    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+    launch_reduce(traj, P, true, true, traj->last_rows, traj->last_rows);
   } else {
     launch_policy_pass(traj, policy, PASS_INIT, nullptr, b_total(traj), nullptr);
     launch_mlp_backward(traj, policy, nullptr);
@@ -85,7 +85,7 @@ static void run_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip
   if (rl_module_is_recurrent(policy->kind)) return seq_policy_eval(policy, traj, d_skip);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip)) {
-    launch_reduce(traj, P, false, true, traj->nbV2, traj->nbV2);
+    launch_reduce(traj, P, false, true, traj->last_rows, traj->last_rows);
   } else {
     launch_policy_pass(traj, policy, PASS_EVAL, nullptr, b_total(traj), d_skip);
     launch_reduce(traj, P, false, true, traj->nbA, traj->nbB);
@@ -98,7 +98,7 @@ static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, cons
   if (rl_module_is_recurrent(policy->kind)) return seq_policy_fvp(policy, traj, d_v, d_skip);
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 && launch_policy_v2(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip)) {
-    launch_reduce(traj, P, true, false, traj->nbV2, traj->nbV2);
+    launch_reduce(traj, P, true, false, traj->last_rows, traj->last_rows);
   } else {
     launch_policy_pass(traj, policy, PASS_JVP, d_v, b_total(traj), d_skip);
     launch_mlp_backward(traj, policy, d_skip);
@@ -286,7 +286,7 @@ static void check_critic(const rl_mlp *critic, const rl_traj *traj) {
 // per-workgroup partial sums of the critic's MSE gradient and loss -> slabA / slabB (feed-forward modules)
 static void critic_slabs(rl_mlp *critic, rl_traj *traj, uint32_t *rowsA, uint32_t *rowsB) {
   if (traj->eng->kernel_variant != 1 && launch_critic_step_v2(traj, critic, b_total(traj))) {
-    *rowsA = *rowsB = traj->nbC;
+    *rowsA = *rowsB = traj->last_rows;
   } else {
     launch_critic_fwd(traj, critic, b_total(traj));
     launch_mlp_backward(traj, critic, nullptr);
@@ -417,7 +417,7 @@ static void run_policy_ppo(rl_mlp *policy, rl_traj *traj, float lo, float hi) {
   uint32_t P = (uint32_t)policy->P;
   if (traj->eng->kernel_variant != 1 &&
       launch_policy_v2(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi)) {
-    launch_reduce(traj, P, true, true, traj->nbV2, traj->nbV2);
+    launch_reduce(traj, P, true, true, traj->last_rows, traj->last_rows);
   } else {
     launch_policy_pass(traj, policy, PASS_PPO, nullptr, b_total(traj), nullptr, lo, hi);
     launch_mlp_backward(traj, policy, nullptr);

@@ -230,7 +230,6 @@ struct GenDev {
   float *delta = nullptr;                 // [2][widest layer][rows]: backward deltas (ping-pong)
   float *z = nullptr, *tz = nullptr;      // [2][rows]: outputs and tangent outputs
   uint64_t cap_act = 0, cap_tact = 0, cap_delta = 0, cap_z = 0, cap_tz = 0;
-  uint64_t cap_slabA = 0;                 // doubles in the trajectory's slabA once this path has regrown it
 };
 
 struct rl_adam {
@@ -257,6 +256,8 @@ struct rl_traj {
   float *losses = nullptr;  // [max critic steps]
   TrpoStateDev *trpo = nullptr;
   uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbC = 0, Pmax = 0, max_losses = 0;
+  uint32_t last_rows = 0;   // slab rows the last fused pass (launch_policy_v2 / launch_critic_step_v2) wrote
+  uint64_t cap_slabA = 0, cap_slabB = 0;  // doubles allocated (traj_ensure_slabs grows them)
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
   GenDev gen;

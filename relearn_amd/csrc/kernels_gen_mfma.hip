@@ -1,0 +1,623 @@
+// kernels_gen_mfma.hip — the update passes of MLPs with SEVERAL hidden layers (MlpConfig.hidden_sizes, ff/mlp.rs:13-34;
+// any rl_activation) as one fused launch on the bf16 matrix pipe: forward, per-sample loss terms, backward and weight
+// gradients of one 32-sample tile per wave and iteration, no activation ever written to HBM.  (kernels_general.hip runs
+// the same passes as one launch per layer over [unit][sample] planes: 178 ms for a TRPO + critic period of two 64-unit
+// layers at 16,384 lanes, against 3 ms for the fused single-hidden-layer kernels.)
+//
+// Shapes: 1..3 hidden layers of at most 64 units (two 32-unit tiles; narrower layers are zero-padded), at most 7
+// inputs, at most 2 outputs.  Every matrix product is an exact-piece product: both factors are split into three bf16
+// pieces and the six piece pairs that matter are multiplied on v_mfma_f32_32x32x16_bf16 with f32 accumulation
+// (bf16_tile.hpp) — the weights by rounding (|p1| <= 2^-9 |w|, |p2| <= 2^-18 |w|), activations by truncation, deltas by
+// rounding, so the dropped pairs stay below 2^-24 of the product.
+//
+// Orientation: a tile of layer values X is an accumulator tile with the UNIT in the registers (row (r & 3) + 8 (r >> 2) +
+// 4 (lane >> 5)) and the SAMPLE on the lane (column lane & 31).
+//   chains   Z_{l+1}^T = W_{l+1} A_l^T  and  D_l^T = W_{l+1}^T D_{l+1}^T  contract over the row index of the tile that
+//            feeds them: the tile's registers, split and packed in place, ARE the B operand (bf16_tile.hpp's acc_row
+//            order); the weights are A operands, built once per launch in that order and parked in LDS.
+//   weight gradients  dW_l = D_l A_{l-1}^T contract over the SAMPLE — the lane index of both tiles.  Each is transposed on
+//            the matrix pipe first: X^T = X^T . I with the packed pieces of X as A operand and an identity selection as B
+//            (every entry one exact piece times one), packed by conversions: the unit on the lane, the samples in the
+//            registers, the operand layout of a product that sums over samples.  Bias gradients are one more column: a
+//            product with a one-hot column selector, all layers into one accumulator tile.
+// The weight-gradient accumulators live in registers (f32 over at most 64 tiles = 2,048 samples, the two-level scheme
+// of this library) and are added, as f64, to the wave's own slab row; k_reduce sums the rows.  One wave per SIMD: the
+// accumulators of a 64-64 network are 144 registers next to the activations and operand pieces.
+//
+// Reference semantics: the same as kernels_mfma.hip / kernels_critic.hip (Trpo / Ppo closures, ValuesOpt::update);
+// activations: ff/activation.rs:85-92.
+#include <mutex>
+#include <set>
+
+#include "abi_internal.hpp"
+#include "bf16_tile.hpp"
+#include "device_fns.hpp"
+#include "kernels.hpp"
+#include "policy_fast.hpp"
+
+namespace {
+
+using bt::f32x16;
+using bt::Frag;
+
+constexpr int GW = 2;          // 32-unit tiles per hidden layer
+constexpr int GWAVES = 4;      // waves per workgroup (one per SIMD, 512 registers each)
+constexpr int GM_FLUSH = 64;   // f32 -> f64 flush period in tiles
+constexpr int GM_MAX_IN = 7, GM_MAX_HIDDEN = 3;
+
+struct GmArgs {
+  const float *params;
+  int in_dim, out_dim, act, out_act;
+  int width[GM_MAX_HIDDEN];
+  uint32_t off[GM_MAX_HIDDEN + 1];  // parameter offset of layer l's weights [N][K]; its bias follows them
+  uint32_t P;
+};
+
+// fragment groups of the LDS weight image (three piece fragments each): forward layer 0 [ot], forward hidden layer l
+// [ot][ks], forward output [ks], backward hidden layer l [it][ks], backward output [it]
+constexpr int gm_fh(int l) { return GW + (l - 1) * 2 * GW * GW; }
+constexpr int gm_fo(int NL) { return GW + (NL - 1) * 2 * GW * GW; }
+constexpr int gm_bh(int NL, int l) { return gm_fo(NL) + 2 * GW + (l - 1) * 2 * GW * GW; }
+constexpr int gm_bo(int NL) { return gm_bh(NL, NL); }
+constexpr int gm_groups(int NL) { return gm_bo(NL) + GW; }
+constexpr size_t gm_lds_bytes(int NL) { return (size_t)gm_groups(NL) * 3 * 64 * 16 + (size_t)NL * 64 * 4; }
+
+__device__ __forceinline__ constexpr int urow(int r, int kb) { return (r & 3) + 8 * (r >> 2) + 4 * kb; }
+
+__device__ __forceinline__ float gm_act(int act, float x) {
+  if (act == RL_ACT_RELU) return __builtin_fmaxf(x, 0.0f);
+  if (act == RL_ACT_SIGMOID) return fast_sigmoidf(x);
+  if (act == RL_ACT_TANH) return fast_tanhf(x);
+  return x;
+}
+__device__ __forceinline__ float gm_slope(int act, float y) {
+  if (act == RL_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == RL_ACT_SIGMOID) return y * (1.0f - y);
+  if (act == RL_ACT_TANH) return __builtin_fmaf(-y, y, 1.0f);
+  return 1.0f;
+}
+__device__ __forceinline__ void gm_act_tile(int act, f32x16 &c) {
+  if (act == RL_ACT_IDENTITY) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = gm_act(act, c[r]);
+}
+
+// the B operand pieces of k-step q of an accumulator tile (registers 8 q .. 8 q + 7), by truncation (activations) ...
+__device__ __forceinline__ void pieces_trunc(const f32x16 &t, int q, Frag (&x)[3]) {
+  uint32_t p[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bt::split3t(t[8 * q + e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[c].u[i] = bt::pkh(p[c][2 * i], p[c][2 * i + 1]);
+}
+// ... and by rounding (deltas)
+__device__ __forceinline__ void pieces_round(const f32x16 &t, int q, Frag (&x)[3]) {
+  uint32_t p[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bt::split3(t[8 * q + e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[c].u[i] = bt::pk(p[c][2 * i], p[c][2 * i + 1]);
+}
+
+// acc += W X for one k-step: the six piece pairs that matter (w0 x0, w0 x1, w1 x0, w1 x1, w0 x2, w2 x0)
+__device__ __forceinline__ f32x16 prod6(f32x16 acc, const Frag (&w)[3], const Frag (&x)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0].v, x[0].v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0].v, x[1].v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1].v, x[0].v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1].v, x[1].v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0].v, x[2].v, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2].v, x[0].v, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 prod6_lds(f32x16 acc, const uint4 (*img)[64], int grp, int lane, const Frag (&x)[3]) {
+  Frag w[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) w[c].x = img[grp * 3 + c][lane];
+  return prod6(acc, w, x);
+}
+
+// X^T of a tile given as packed pieces xb[q][piece] (k-steps q < QS): the pieces of X^T as operands of a product that
+// sums over the SAMPLE, xt[sample k-step][piece]
+template <int QS>
+__device__ __forceinline__ void transpose_pieces(const Frag (&xb)[QS][3], const Frag (&idb)[2], Frag (&xt)[2][3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f32x16 d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < QS; ++q) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb[q][c].v, idb[q].v, d, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xt[s][c].u[i] = bt::pack_bf16(d[8 * s + 2 * i], d[8 * s + 2 * i + 1]);
+  }
+}
+
+// dW += D^T-pieces x A^T-pieces over both sample k-steps
+__device__ __forceinline__ f32x16 wgrad_tile(f32x16 acc, const Frag (&dt)[2][3], const Frag (&at)[2][3]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) acc = prod6(acc, dt[s], at[s]);
+  return acc;
+}
+// bias column: sum over the samples of D^T's three pieces into column `c` of the bias tile
+__device__ __forceinline__ f32x16 bias_tile(f32x16 acc, const Frag (&dt)[2][3], int c, int m) {
+  Frag e;
+  e.u[0] = e.u[1] = e.u[2] = e.u[3] = m == c ? 0x3F803F80u : 0u;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt[s][p].v, e.v, acc, 0, 0, 0);
+  return acc;
+}
+
+constexpr int GM_CRITIC = 100;  // mean((V - target)^2); the policy modes are PASS_INIT / PASS_PPO / PASS_EVAL (kernels.hpp)
+
+template <int MODE, int NL>
+__global__ void __launch_bounds__(GWAVES * 64)
+    k_gen_mfma(TrajDev tr, GmArgs g, float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB,
+               float inv_B, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
+  extern __shared__ uint4 gm_lds[];
+  uint4(*img)[64] = reinterpret_cast<uint4(*)[64]>(gm_lds);
+  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_groups(NL) * 3 * 64);  // [NL][64]: layers 1 .. NL
+  constexpr bool BWD = MODE != PASS_EVAL;
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, kb = lane >> 5;
+  auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
+  auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
+
+  // ---- the weight image: every fragment in the acc_row order of the tile it meets
+  for (int idx = threadIdx.x; idx < gm_groups(NL) * 64; idx += GWAVES * 64) {
+    const int grp = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float val = 0.0f;
+      if (grp < GW) {  // forward, layer 0: inputs 4 hh + e (e < 4), the bias as input `in_dim`
+        const int unit = grp * 32 + mm, k = bt::acc_row(0, hh, e);
+        const float *W = g.params + g.off[0];
+        if (unit < Nof(0)) {
+          if (k < g.in_dim) val = W[unit * g.in_dim + k];
+          else if (k == g.in_dim) val = W[Nof(0) * g.in_dim + unit];
+        }
+      } else if (grp < gm_fo(NL)) {  // forward, hidden layer l
+        const int rel = grp - GW, l = 1 + rel / (2 * GW * GW), r2 = rel % (2 * GW * GW), ot = r2 / (2 * GW), ks = r2 % (2 * GW);
+        const int unit = ot * 32 + mm, kin = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e);
+        if (unit < Nof(l) && kin < Kof(l)) val = g.params[g.off[l] + unit * Kof(l) + kin];
+      } else if (grp < gm_fo(NL) + 2 * GW) {  // forward, output layer
+        const int ks = grp - gm_fo(NL), kin = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e);
+        if (mm < g.out_dim && kin < Kof(NL)) val = g.params[g.off[NL] + mm * Kof(NL) + kin];
+      } else if (grp < gm_bo(NL)) {  // backward through hidden layer l: W_l^T
+        const int rel = grp - gm_fo(NL) - 2 * GW, l = 1 + rel / (2 * GW * GW), r2 = rel % (2 * GW * GW), it = r2 / (2 * GW),
+                  ks = r2 % (2 * GW);
+        const int kcol = it * 32 + mm, j = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e);
+        if (j < Nof(l) && kcol < Kof(l)) val = g.params[g.off[l] + j * Kof(l) + kcol];
+      } else {  // backward through the output layer
+        const int it = grp - gm_bo(NL), kcol = it * 32 + mm, j = bt::acc_row(0, hh, e);
+        if (j < g.out_dim && kcol < Kof(NL)) val = g.params[g.off[NL] + j * Kof(NL) + kcol];
+      }
+      v[e] = val;
+    }
+    uint32_t p[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bt::split3(v[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      img[grp * 3 + c][ln] = make_uint4(bt::pk(p[c][0], p[c][1]), bt::pk(p[c][2], p[c][3]), bt::pk(p[c][4], p[c][5]),
+                                        bt::pk(p[c][6], p[c][7]));
+  }
+  for (int idx = threadIdx.x; idx < NL * 64; idx += GWAVES * 64) {
+    const int l = 1 + idx / 64, u = idx % 64;
+    bias[idx] = u < Nof(l) ? g.params[g.off[l] + Nof(l) * Kof(l) + u] : 0.0f;
+  }
+  __syncthreads();
+
+  Frag idb[2];
+  bt::ident_frags(lane, idb);
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // weight-gradient accumulators: layer 0 [ot] (columns: inputs, then the bias), hidden [l - 1][ot][it], output [it]
+  // (rows: outputs), biases of layers >= 1 (column = (l - 1) GW + ot)
+  f32x16 dW0[GW], dWh[NL > 1 ? NL - 1 : 1][GW][GW], dWo[GW], dbt = zero16;
+#pragma unroll
+  for (int a = 0; a < GW; ++a) {
+    dW0[a] = zero16;
+    dWo[a] = zero16;
+#pragma unroll
+    for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l)
+#pragma unroll
+      for (int b = 0; b < GW; ++b) dWh[l][a][b] = zero16;
+  }
+  double sum64[3] = {0.0, 0.0, 0.0};
+  float sum32[3] = {0.0f, 0.0f, 0.0f};
+
+  const size_t B = (size_t)tr.T * tr.n;
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)((size_t)(tr.T + 1) * tr.n);
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t wave_id = (size_t)blockIdx.x * GWAVES + wave, n_waves = (size_t)gridDim.x * GWAVES;
+  double *__restrict__ row = slabA + wave_id * g.P;
+  bool first_flush = true;
+
+  // slab entry += tile entry, for the valid (output j, input k) of a weight tile / the bias columns
+  auto put = [&](uint32_t at, float v) {
+    if (first_flush) row[at] = (double)v;
+    else row[at] = row[at] + (double)v;
+  };
+  auto flush_w = [&](f32x16 &t, int l, int ot, int it) {
+    const int K = Kof(l), N = Nof(l), k = it * 32 + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = ot * 32 + urow(r, kb);
+      if (j < N) {
+        if (k < K) put(g.off[l] + (uint32_t)(j * K + k), t[r]);
+        else if (l == 0 && k == K) put(g.off[0] + (uint32_t)(N * K + j), t[r]);
+      }
+      t[r] = 0.0f;
+    }
+  };
+  auto flush_all = [&]() {
+#pragma unroll
+    for (int ot = 0; ot < GW; ++ot) flush_w(dW0[ot], 0, ot, 0);
+#pragma unroll
+    for (int l = 1; l < NL; ++l)
+#pragma unroll
+      for (int ot = 0; ot < GW; ++ot)
+#pragma unroll
+        for (int it = 0; it < GW; ++it) flush_w(dWh[l - 1][ot][it], l, ot, it);
+#pragma unroll
+    for (int it = 0; it < GW; ++it) flush_w(dWo[it], NL, 0, it);
+    {  // biases of layers 1 .. NL: column c = (l - 1) GW + ot
+      const int l = 1 + m / GW, ot = m % GW;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = ot * 32 + urow(r, kb);
+        if (l <= NL && (l < NL || ot == 0) && j < Nof(l)) put(g.off[l] + (uint32_t)(Nof(l) * Kof(l) + j), dbt[r]);
+        dbt[r] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      sum64[q] += (double)sum32[q];
+      sum32[q] = 0.0f;
+    }
+    first_flush = false;
+  };
+
+  struct TileIn {
+    float x[4], tgt, adv, l0, l1;
+    int act;
+    bool valid;
+  };
+  auto load_tile = [&](size_t t) {  // (branch-free: padding lanes read sample B - 1 and are zeroed)
+    TileIn o;
+    const uint32_t sidx = (uint32_t)t * 32u + (uint32_t)m;
+    o.valid = t < n_tiles && sidx < B32;
+    const uint32_t sc = o.valid ? sidx : B32 - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * kb + e;
+      float v = 0.0f;
+      if (k < g.in_dim) v = tr.obs[(uint32_t)k * plane32 + sc];
+      else if (k == g.in_dim) v = 1.0f;
+      o.x[e] = o.valid ? v : 0.0f;
+    }
+    o.tgt = o.adv = o.l0 = o.l1 = 0.0f;
+    o.act = 0;
+    if (MODE == GM_CRITIC) {
+      const float tg = tr.tgt[sc];
+      o.tgt = o.valid ? tg : 0.0f;
+    } else {
+      const float adv = tr.adv[sc];
+      const int act = (int)tr.action[sc];
+      o.adv = o.valid ? adv : 0.0f;
+      o.act = o.valid ? act : 0;
+      if (MODE != PASS_INIT) {
+        const float l0 = lp0[sc], l1 = lp0[B32 + sc];
+        o.l0 = o.valid ? l0 : 0.0f;
+        o.l1 = o.valid ? l1 : 0.0f;
+      }
+    }
+    return o;
+  };
+
+  int since_flush = 0;
+  TileIn op = load_tile(wave_id);
+  for (size_t t = wave_id; t < n_tiles; t += n_waves) {
+    const TileIn next = load_tile(t + n_waves);
+    // ---- forward
+    Frag xb0[1][3];
+    {
+      uint32_t p[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bt::split3t(op.x[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xb0[0][c].u[0] = bt::pkh(p[c][0], p[c][1]);
+        xb0[0][c].u[1] = bt::pkh(p[c][2], p[c][3]);
+        xb0[0][c].u[2] = xb0[0][c].u[3] = 0u;
+      }
+    }
+    f32x16 a[NL][GW];
+#pragma unroll
+    for (int ot = 0; ot < GW; ++ot) {
+      a[0][ot] = prod6_lds(zero16, img, ot, lane, xb0[0]);
+      gm_act_tile(g.act, a[0][ot]);
+    }
+    auto bias_rows = [&](int l, int ot) {  // accumulator initialised with the bias of its row's unit
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = bias[(l - 1) * 64 + ot * 32 + urow(r, kb)];
+      return c;
+    };
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+      Frag ab[GW][2][3];
+#pragma unroll
+      for (int it = 0; it < GW; ++it)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_trunc(a[l - 1][it], q, ab[it][q]);
+#pragma unroll
+      for (int ot = 0; ot < GW; ++ot) {
+        f32x16 c = bias_rows(l, ot);
+#pragma unroll
+        for (int ks = 0; ks < 2 * GW; ++ks) c = prod6_lds(c, img, gm_fh(l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
+        gm_act_tile(g.act, c);
+        a[l][ot] = c;
+      }
+    }
+    f32x16 zt = bias_rows(NL, 0);
+    {
+      Frag ab[GW][2][3];
+#pragma unroll
+      for (int it = 0; it < GW; ++it)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1][it], q, ab[it][q]);
+#pragma unroll
+      for (int ks = 0; ks < 2 * GW; ++ks) zt = prod6_lds(zt, img, gm_fo(NL) + ks, lane, ab[ks >> 1][ks & 1]);
+    }
+    // ---- per-sample terms on the lanes of half 0 (rows 0 and 1 of the output tile are the module's outputs)
+    const bool owner = kb == 0 && op.valid;
+    float d0 = 0.0f, d1 = 0.0f;  // d loss / d (pre-activation of output 0 / 1)
+    if (MODE == GM_CRITIC) {
+      const float v = gm_act(g.out_act, zt[0]);
+      const float d = v - op.tgt;
+      if (owner) {
+        sum32[0] = __builtin_fmaf(d, d, sum32[0]);
+        d0 = d * inv_B * gm_slope(g.out_act, v);  // inv_B = 2 / B here
+      }
+    } else {
+      const float y0 = gm_act(g.out_act, zt[0]), y1 = gm_act(g.out_act, zt[1]);
+      const SoftPair sp = soft_pair(y0 - y1);
+      const float adv = op.adv;
+      const int act = op.act;
+      const float lpa = act == 0 ? sp.lp[0] : sp.lp[1];
+      float g0 = 0.0f, g1 = 0.0f;  // d loss / d output
+      if (MODE == PASS_INIT) {
+        if (owner) {
+          const uint32_t sidx = (uint32_t)t * 32u + (uint32_t)m;
+          lp0[sidx] = sp.lp[0];
+          lp0[B32 + sidx] = sp.lp[1];
+        }
+        const float cc = -adv * inv_B;  // ratio = exp(lpa - lpa) = 1
+        g0 = cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]);
+        g1 = cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]);
+        const float cl0 = sp.lp[0] < -3.402823466e+38f ? -3.402823466e+38f : sp.lp[0];
+        const float cl1 = sp.lp[1] < -3.402823466e+38f ? -3.402823466e+38f : sp.lp[1];
+        float ent = cl0 * sp.p[0];
+        ent += cl1 * sp.p[1];
+        if (owner) {
+          sum32[0] = sum32[0] + adv;  // ratio * adv
+          sum32[1] = sum32[1] - ent;
+          sum32[2] = __builtin_fmaf(lpa, adv, sum32[2]);
+        }
+      } else if (MODE == PASS_PPO) {
+        // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
+        const float l0a = act == 0 ? op.l0 : op.l1;
+        const float ratio = fast_expf(lpa - l0a);
+        const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
+        const float u1 = ratio * adv, u2 = clipped * adv;
+        const bool inside = ratio >= clip_lo && ratio <= clip_hi;
+        const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
+        const float cc = -(gr * ratio) * inv_B;
+        g0 = cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]);
+        g1 = cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]);
+        if (owner) sum32[0] = sum32[0] + (u1 < u2 ? u1 : u2);
+      } else {  // PASS_EVAL: surrogate and KL(pi_0 || pi) of candidate parameters
+        const float l0a = act == 0 ? op.l0 : op.l1;
+        const float ratio = fast_expf(lpa - l0a);
+        float rel0 = op.l0 - sp.lp[0], rel1 = op.l1 - sp.lp[1];
+        if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
+        if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
+        const SoftPair old = soft_pair(op.l0 - op.l1);
+        float kl = rel0 * old.p[0];
+        kl += rel1 * old.p[1];
+        if (owner) {
+          sum32[0] = __builtin_fmaf(ratio, adv, sum32[0]);
+          sum32[1] = sum32[1] + kl;
+        }
+      }
+      if (owner) {
+        d0 = g0 * gm_slope(g.out_act, y0);
+        d1 = g1 * gm_slope(g.out_act, y1);
+      }
+    }
+    if (BWD) {
+      // ---- output layer: delta pieces (units 0 and 1 = elements 0 and 1 of half 0's k-step 0)
+      Frag dob[1][3];
+      {
+        uint32_t p0[3], p1[3];
+        bt::split3(d0, p0[0], p0[1], p0[2]);
+        bt::split3(d1, p1[0], p1[1], p1[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dob[0][c].u[0] = kb == 0 ? bt::pk(p0[c], p1[c]) : 0u;
+          dob[0][c].u[1] = dob[0][c].u[2] = dob[0][c].u[3] = 0u;
+        }
+      }
+      Frag dT[GW][2][3], aT[GW][2][3];  // transposed pieces: deltas of the layer in hand, activations below it
+      transpose_pieces<1>(dob, idb, dT[0]);
+      dbt = bias_tile(dbt, dT[0], (NL - 1) * GW, m);
+      f32x16 dl[GW];  // deltas of the hidden layer in hand
+#pragma unroll
+      for (int it = 0; it < GW; ++it) {
+        Frag ab[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1][it], q, ab[q]);
+        transpose_pieces<2>(ab, idb, aT[it]);
+        dWo[it] = wgrad_tile(dWo[it], dT[0], aT[it]);
+        f32x16 c = prod6_lds(zero16, img, gm_bo(NL) + it, lane, dob[0]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = c[r] * gm_slope(g.act, a[NL - 1][it][r]);
+        dl[it] = c;
+      }
+      // ---- hidden layers NL - 1 .. 1: weights between layer l - 1 and l
+#pragma unroll
+      for (int l = NL - 1; l >= 1; --l) {
+        Frag db[GW][2][3];
+#pragma unroll
+        for (int ot = 0; ot < GW; ++ot) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) pieces_round(dl[ot], q, db[ot][q]);
+          transpose_pieces<2>(db[ot], idb, dT[ot]);
+          dbt = bias_tile(dbt, dT[ot], (l - 1) * GW + ot, m);
+        }
+        f32x16 dn[GW];
+#pragma unroll
+        for (int it = 0; it < GW; ++it) {
+          Frag ab[2][3];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) pieces_trunc(a[l - 1][it], q, ab[q]);
+          transpose_pieces<2>(ab, idb, aT[it]);
+#pragma unroll
+          for (int ot = 0; ot < GW; ++ot) dWh[l - 1][ot][it] = wgrad_tile(dWh[l - 1][ot][it], dT[ot], aT[it]);
+          f32x16 c = zero16;
+#pragma unroll
+          for (int ks = 0; ks < 2 * GW; ++ks)
+            c = prod6_lds(c, img, gm_bh(NL, l) + it * 2 * GW + ks, lane, db[ks >> 1][ks & 1]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = c[r] * gm_slope(g.act, a[l - 1][it][r]);
+          dn[it] = c;
+        }
+#pragma unroll
+        for (int it = 0; it < GW; ++it) dl[it] = dn[it];
+      }
+      // ---- layer 0: inputs (and the bias input) against the deltas of hidden layer 0
+      transpose_pieces<1>(xb0, idb, aT[0]);
+#pragma unroll
+      for (int ot = 0; ot < GW; ++ot) {
+        Frag db[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_round(dl[ot], q, db[q]);
+        transpose_pieces<2>(db, idb, dT[ot]);
+        dW0[ot] = wgrad_tile(dW0[ot], dT[ot], aT[0]);
+      }
+    }
+    if (++since_flush == GM_FLUSH) {
+      since_flush = 0;
+      if (BWD) flush_all();
+      else
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          sum64[q] += (double)sum32[q];
+          sum32[q] = 0.0f;
+        }
+    }
+    op = next;
+  }
+  if (BWD) flush_all();
+  else
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sum64[q] += (double)sum32[q];
+  // the wave's scalar sums: over its 32 owner lanes
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double s = kb == 0 ? sum64[q] : 0.0;
+#pragma unroll
+    for (int sft = 16; sft > 0; sft >>= 1) s = s + xlane(s, sft);
+    sum64[q] = s;
+  }
+  if (lane == 0) {
+    double *sb = slabB + wave_id * 4;
+    sb[0] = sum64[0];
+    sb[1] = sum64[1];
+    sb[2] = sum64[2];
+    sb[3] = 0.0;
+  }
+}
+
+template <int MODE, int NL>
+void gm_launch(rl_traj *t, const GmArgs &g, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
+               float clip_hi) {
+  const size_t lds = gm_lds_bytes(NL);
+  {
+    static std::mutex mu;
+    static std::set<int> raised;
+    std::lock_guard<std::mutex> lock(mu);
+    if (raised.insert(t->eng->device).second)
+      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_mfma<MODE, NL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL((k_gen_mfma<MODE, NL>), dim3(nwg), dim3(GWAVES * 64), lds, t->eng->stream, t->d, g, t->lp0, t->slabA,
+                     t->slabB, inv_B, d_skip, clip_lo, clip_hi);
+  RL_HIP_CHECK(hipGetLastError());
+}
+
+template <int MODE>
+void gm_launch_nl(rl_traj *t, const GmArgs &g, int NL, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
+                  float clip_hi) {
+  if (NL == 1) gm_launch<MODE, 1>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (NL == 2) gm_launch<MODE, 2>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else gm_launch<MODE, 3>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+}
+
+}  // namespace
+
+// true when the module's passes run as fused matrix-pipe launches (kernel documentation above for the shapes)
+bool gen_mfma_fits(const rl_traj *t, const rl_mlp *m) {
+  if (!m->general || m->n_hidden < 1 || m->n_hidden > (uint32_t)GM_MAX_HIDDEN) return false;
+  if (m->in_dim > (uint32_t)GM_MAX_IN || m->out_dim > 2 || m->in_dim != t->d.D) return false;
+  for (uint32_t l = 0; l < m->n_hidden; ++l)
+    if (m->widths[l] > 32u * GW) return false;
+  if ((uint64_t)(t->d.T + 1) * t->d.n * m->in_dim >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
+  return true;
+}
+
+// mode: RL_GEN_CRITIC, PASS_INIT, PASS_PPO or PASS_EVAL.  Leaves one slab row per WAVE: t->last_rows rows of slabA
+// (gradient modes) and slabB.
+bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, uint64_t B_total, const int32_t *d_skip, float clip_lo,
+                     float clip_hi) {
+  if (!gen_mfma_fits(t, m)) return false;
+  if (mode != RL_GEN_CRITIC && mode != PASS_INIT && mode != PASS_PPO && mode != PASS_EVAL) return false;
+  if (mode != RL_GEN_CRITIC && m->out_dim != 2) return false;
+  if (mode == RL_GEN_CRITIC && m->out_dim != 1) return false;
+  GmArgs g{};
+  g.params = m->d_params;
+  g.in_dim = (int)m->in_dim;
+  g.out_dim = (int)m->out_dim;
+  g.act = m->act;
+  g.out_act = m->out_act;
+  for (uint32_t l = 0; l < m->n_hidden; ++l) g.width[l] = (int)m->widths[l];
+  for (uint32_t l = 0; l <= m->n_hidden; ++l) g.off[l] = (uint32_t)m->layer_offset(l);
+  g.P = (uint32_t)m->P;
+  const uint64_t n_tiles = (t->B + 31) / 32, cus = (uint64_t)t->eng->prop.multiProcessorCount;
+  uint64_t nwg = (n_tiles + GWAVES - 1) / GWAVES;
+  if (nwg > cus) nwg = cus;
+  t->last_rows = (uint32_t)(nwg * GWAVES);
+  gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
+  traj_ensure_slabs(t, t->last_rows, m->P, t->last_rows);
+  const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
+  const int NL = (int)m->n_hidden;
+  if (mode == RL_GEN_CRITIC) gm_launch_nl<GM_CRITIC>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (mode == PASS_INIT) gm_launch_nl<PASS_INIT>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (mode == PASS_PPO) gm_launch_nl<PASS_PPO>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else gm_launch_nl<PASS_EVAL>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  return true;
+}

@@ -428,15 +428,26 @@ void gen_ensure(rl_traj *t, const rl_mlp *m, uint64_t rows, bool tangent, bool b
     uint32_t rowsA = t->nbA;
     if (t->nbV2 > rowsA) rowsA = t->nbV2;
     if (t->nbC > rowsA) rowsA = t->nbC;
-    const uint64_t fused_P = 128 * 5 + 128 + 2 * 128 + 2;  // what traj_alloc sized the slab for
-    const uint64_t need = (uint64_t)rowsA * (m->P > fused_P ? m->P : fused_P);
-    if (m->P > fused_P && g.cap_slabA < need) {
-      dfree(t->slabA);
-      t->slabA = nullptr;
-      g.cap_slabA = 0;
-      t->slabA = dalloc<double>(need);
-      g.cap_slabA = need;
-    }
+    traj_ensure_slabs(t, rowsA, m->P, t->nbB > rowsA ? t->nbB : rowsA);
+  }
+}
+
+// room for `rowsA` slab rows of P partial sums and `rowsB` rows of four scalars (the partials of any pass are dead once
+// its reduction has run, so growing drops them)
+void traj_ensure_slabs(rl_traj *t, uint64_t rowsA, uint64_t P, uint64_t rowsB) {
+  if (t->cap_slabA < rowsA * P) {
+    dfree(t->slabA);
+    t->slabA = nullptr;
+    t->cap_slabA = 0;
+    t->slabA = dalloc<double>(rowsA * P);
+    t->cap_slabA = rowsA * P;
+  }
+  if (t->cap_slabB < rowsB * 4) {
+    dfree(t->slabB);
+    t->slabB = nullptr;
+    t->cap_slabB = 0;
+    t->slabB = dalloc<double>(rowsB * 4);
+    t->cap_slabB = rowsB * 4;
   }
 }
 

@@ -6,6 +6,7 @@
 #include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
+#include "policy_fast.hpp"
 
 constexpr int V2_WAVES = 8;        // policy kernels: one workgroup of eight waves per CU (two per SIMD)
 
@@ -29,39 +30,6 @@ constexpr int V2_WAVES = 8;        // policy kernels: one workgroup of eight wav
 // src/torch/optimizers/conjugate_gradient.rs:262-339), Ppo::update (policies/ppo.rs:124-137), Categorical
 // (src/torch/distributions/categorical.rs).
 // ================================================================================================
-// Transcendentals of the update passes: v_exp_f32 / v_log_f32 (base 2, about one ulp) with the base change as a
-// multiplication — 2-3 instructions instead of the ~25 of rl_expf / rl_logf (include/rl_detmath.h).  The deterministic
-// versions stay where results are compared bit for bit with the oracle (rollouts, values, GAE, targets); these passes
-// are compared with the f64 oracle within f32 tolerances, and they agree with each other because log pi_0 (stored by
-// PASS_INIT) and every later log pi come from the same code.  (Counter evidence: the evaluation pass ran at VALU busy
-// 0.96, the gradient pass issued 2.2 x the critic step's vector instructions: profiles/r03_pmc_65536_summary.json.)
-__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-// The two-way softmax of the logits {zd, 0} from ONE exponential: t = exp(-|zd|) (the rounding of the argument's base
-// change is carried through: hi + lo = -|zd| log2 e to ~2^-48), r = 1 / (1 + t) (reciprocal + one Newton step), the
-// probabilities r and t r — they sum to one within an ulp, so the two logit gradients stay antisymmetric, which two
-// independent exponentials are not (measured: a 1.4e-6 relative bias in db2) — and lse = max(zd, 0) + log(1 + t).
-struct SoftPair {
-  float lp[2], p[2];
-};
-__device__ __forceinline__ SoftPair soft_pair(float zd) {
-  const float ax = -__builtin_fabsf(zd);
-  const float hi = ax * 1.4426950408889634f;
-  const float lo = __builtin_fmaf(ax, 1.4426950408889634f, -hi) + ax * 1.925963033500343e-08f;  // log2 e = hi part + 1.93e-8
-  const float e = __builtin_amdgcn_exp2f(hi);
-  const float t = __builtin_fmaf(e * lo, 0.6931471805599453f, e);
-  const float s1 = 1.0f + t;
-  float r = __builtin_amdgcn_rcpf(s1);
-  r = __builtin_fmaf(__builtin_fmaf(-s1, r, 1.0f), r, r);
-  const float big = r, small = t * r;
-  const float lse = __builtin_fmaxf(zd, 0.0f) + 0.6931471805599453f * __builtin_amdgcn_logf(s1);
-  SoftPair o;
-  o.lp[0] = zd - lse;
-  o.lp[1] = -lse;
-  o.p[0] = zd >= 0.0f ? big : small;
-  o.p[1] = zd >= 0.0f ? small : big;
-  return o;
-}
-
 constexpr int PB_FLUSH = 16;  // f32 -> f64 flush period in tiles (32 / 64: 2 % faster Fisher-vector products, measured; TRPO's
                               // CG wants the shorter f32 accumulation)
 
@@ -412,11 +380,13 @@ __global__ void __launch_bounds__(WAVES * 64)
 // gradient (PASS_INIT), Fisher-vector product (PASS_JVP) or loss/KL evaluation (PASS_EVAL) in one launch
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
+  if (policy->general) return launch_gen_mfma(traj, policy, mode, B_total, d_skip, clip_lo, clip_hi);
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
   if (mode == PASS_DQN) return false;  // k_dqn_step_bf16 (kernels_dqn.hip)
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernels
   ProfScope ps(traj->eng, mode == PASS_JVP ? RL_K_POLICY_FVP : RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
+  traj->last_rows = traj->nbV2;
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
   hipStream_t s = traj->eng->stream;
   uint32_t P = (uint32_t)policy->P;
