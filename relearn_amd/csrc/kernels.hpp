@@ -88,10 +88,10 @@ void launch_gen_critic_fwd(rl_traj *t, const rl_mlp *m, uint64_t B_total);
 void launch_gen_backward(rl_traj *t, const rl_mlp *m, const int32_t *d_skip);
 void traj_ensure_slabs(rl_traj *t, uint64_t rowsA, uint64_t P, uint64_t rowsB);
 // kernels_gen_mfma.hip: the passes of a several-hidden-layer MLP as one fused matrix-pipe launch (false: shape not built)
-constexpr int RL_GEN_CRITIC = 100;  // mode: mean((V - target)^2); else PASS_INIT / PASS_PPO / PASS_EVAL
+constexpr int RL_GEN_CRITIC = 100;  // mode: mean((V - target)^2); else PASS_INIT / PASS_PPO / PASS_EVAL / PASS_JVP
 bool gen_mfma_fits(const rl_traj *t, const rl_mlp *m);
-bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, uint64_t B_total, const int32_t *d_skip, float clip_lo,
-                     float clip_hi);
+bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tangent, uint64_t B_total,
+                     const int32_t *d_skip, float clip_lo, float clip_hi);
 void launch_gen_values(rl_traj *t, const rl_mlp *critic);  // -> seq.out / seq.succ (plane 0)
 void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t);
 // kernels_seq_train.hip: the GRU chain's training passes with the recurrence on the bf16 matrix pipe

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 
 // ---------------------------------------------------------------- launcher
 bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total) {
-  if (critic->general) return launch_gen_mfma(traj, critic, RL_GEN_CRITIC, B_total, nullptr, 0.0f, 0.0f);
+  if (critic->general) return launch_gen_mfma(traj, critic, RL_GEN_CRITIC, nullptr, B_total, nullptr, 0.0f, 0.0f);
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);

@@ -46,7 +46,7 @@ constexpr int GM_FLUSH = 64;   // f32 -> f64 flush period in tiles
 constexpr int GM_MAX_IN = 7, GM_MAX_HIDDEN = 3;
 
 struct GmArgs {
-  const float *params;
+  const float *params, *tangent;  // tangent: PASS_JVP only, laid out like params
   int in_dim, out_dim, act, out_act;
   int width[GM_MAX_HIDDEN];
   uint32_t off[GM_MAX_HIDDEN + 1];  // parameter offset of layer l's weights [N][K]; its bias follows them
@@ -60,7 +60,12 @@ constexpr int gm_fo(int NL) { return GW + (NL - 1) * 2 * GW * GW; }
 constexpr int gm_bh(int NL, int l) { return gm_fo(NL) + 2 * GW + (l - 1) * 2 * GW * GW; }
 constexpr int gm_bo(int NL) { return gm_bh(NL, NL); }
 constexpr int gm_groups(int NL) { return gm_bo(NL) + GW; }
-constexpr size_t gm_lds_bytes(int NL) { return (size_t)gm_groups(NL) * 3 * 64 * 16 + (size_t)NL * 64 * 4; }
+// PASS_JVP: the forward fragments of the tangent parameters follow, in the same order (layer 0, hidden, output)
+constexpr int gm_fwd_groups(int NL) { return gm_fo(NL) + 2 * GW; }
+constexpr int gm_all_groups(int NL, bool jvp) { return gm_groups(NL) + (jvp ? gm_fwd_groups(NL) : 0); }
+constexpr size_t gm_lds_bytes(int NL, bool jvp) {
+  return (size_t)gm_all_groups(NL, jvp) * 3 * 64 * 16 + (size_t)NL * 64 * 4 * (jvp ? 2 : 1);
+}
 
 __device__ __forceinline__ constexpr int urow(int r, int kb) { return (r & 3) + 8 * (r >> 2) + 4 * kb; }
 
@@ -76,10 +81,31 @@ __device__ __forceinline__ float gm_slope(int act, float y) {
   if (act == RL_ACT_TANH) return __builtin_fmaf(-y, y, 1.0f);
   return 1.0f;
 }
+// a whole tile at a time: one (wave-uniform) branch per tile, straight-line code inside
 __device__ __forceinline__ void gm_act_tile(int act, f32x16 &c) {
-  if (act == RL_ACT_IDENTITY) return;
+  if (act == RL_ACT_RELU) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) c[r] = gm_act(act, c[r]);
+    for (int r = 0; r < 16; ++r) c[r] = __builtin_fmaxf(c[r], 0.0f);
+  } else if (act == RL_ACT_SIGMOID) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = fast_sigmoidf(c[r]);
+  } else if (act == RL_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = fast_tanhf(c[r]);
+  }
+}
+// c *= act'(.) given the layer's outputs y
+__device__ __forceinline__ void gm_slope_tile(int act, f32x16 &c, const f32x16 &y) {
+  if (act == RL_ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = y[r] > 0.0f ? c[r] : 0.0f;
+  } else if (act == RL_ACT_SIGMOID) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = c[r] * (y[r] * (1.0f - y[r]));
+  } else if (act == RL_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = c[r] * __builtin_fmaf(-y[r], y[r], 1.0f);
+  }
 }
 
 // the B operand pieces of k-step q of an accumulator tile (registers 8 q .. 8 q + 7), by truncation (activations) ...
@@ -161,46 +187,23 @@ __global__ void __launch_bounds__(GWAVES * 64)
                float inv_B, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   extern __shared__ uint4 gm_lds[];
   uint4(*img)[64] = reinterpret_cast<uint4(*)[64]>(gm_lds);
-  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_groups(NL) * 3 * 64);  // [NL][64]: layers 1 .. NL
+  constexpr bool JVP = MODE == PASS_JVP;
+  constexpr int TG = gm_groups(NL);  // first fragment group of the tangent parameters (JVP)
+  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_all_groups(NL, JVP) * 3 * 64);  // [NL][64]: layers 1 .. NL
+  float *tbias = bias + NL * 64;                                                               // (JVP) of the tangent
   constexpr bool BWD = MODE != PASS_EVAL;
   if (skip != nullptr && *skip != 0) return;
+#ifdef GM_FIXED_RELU
+  g.act = RL_ACT_RELU;
+  g.out_act = RL_ACT_IDENTITY;
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, kb = lane >> 5;
   auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
   auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
 
   // ---- the weight image: every fragment in the acc_row order of the tile it meets
-  for (int idx = threadIdx.x; idx < gm_groups(NL) * 64; idx += GWAVES * 64) {
-    const int grp = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float val = 0.0f;
-      if (grp < GW) {  // forward, layer 0: inputs 4 hh + e (e < 4), the bias as input `in_dim`
-        const int unit = grp * 32 + mm, k = bt::acc_row(0, hh, e);
-        const float *W = g.params + g.off[0];
-        if (unit < Nof(0)) {
-          if (k < g.in_dim) val = W[unit * g.in_dim + k];
-          else if (k == g.in_dim) val = W[Nof(0) * g.in_dim + unit];
-        }
-      } else if (grp < gm_fo(NL)) {  // forward, hidden layer l
-        const int rel = grp - GW, l = 1 + rel / (2 * GW * GW), r2 = rel % (2 * GW * GW), ot = r2 / (2 * GW), ks = r2 % (2 * GW);
-        const int unit = ot * 32 + mm, kin = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e);
-        if (unit < Nof(l) && kin < Kof(l)) val = g.params[g.off[l] + unit * Kof(l) + kin];
-      } else if (grp < gm_fo(NL) + 2 * GW) {  // forward, output layer
-        const int ks = grp - gm_fo(NL), kin = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e);
-        if (mm < g.out_dim && kin < Kof(NL)) val = g.params[g.off[NL] + mm * Kof(NL) + kin];
-      } else if (grp < gm_bo(NL)) {  // backward through hidden layer l: W_l^T
-        const int rel = grp - gm_fo(NL) - 2 * GW, l = 1 + rel / (2 * GW * GW), r2 = rel % (2 * GW * GW), it = r2 / (2 * GW),
-                  ks = r2 % (2 * GW);
-        const int kcol = it * 32 + mm, j = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e);
-        if (j < Nof(l) && kcol < Kof(l)) val = g.params[g.off[l] + j * Kof(l) + kcol];
-      } else {  // backward through the output layer
-        const int it = grp - gm_bo(NL), kcol = it * 32 + mm, j = bt::acc_row(0, hh, e);
-        if (j < g.out_dim && kcol < Kof(NL)) val = g.params[g.off[NL] + j * Kof(NL) + kcol];
-      }
-      v[e] = val;
-    }
+  auto put_group = [&](int grp, int ln, const float (&v)[8]) {
     uint32_t p[3][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bt::split3(v[e], p[0][e], p[1][e], p[2][e]);
@@ -208,11 +211,70 @@ __global__ void __launch_bounds__(GWAVES * 64)
     for (int c = 0; c < 3; ++c)
       img[grp * 3 + c][ln] = make_uint4(bt::pk(p[c][0], p[c][1]), bt::pk(p[c][2], p[c][3]), bt::pk(p[c][4], p[c][5]),
                                         bt::pk(p[c][6], p[c][7]));
-  }
-  for (int idx = threadIdx.x; idx < NL * 64; idx += GWAVES * 64) {
-    const int l = 1 + idx / 64, u = idx % 64;
-    bias[idx] = u < Nof(l) ? g.params[g.off[l] + Nof(l) * Kof(l) + u] : 0.0f;
-  }
+  };
+  // `src`: the parameters (forward and backward fragments from group 0) or the tangent (forward fragments from group TG)
+  auto build = [&](const float *__restrict__ src, int g0, bool with_backward, float *bias_out) {
+    // forward, layer 0 [ot]: inputs 4 hh + e (e < 4), the bias as input `in_dim`
+    for (int idx = threadIdx.x; idx < GW * 64; idx += GWAVES * 64) {
+      const int ot = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+      const int unit = ot * 32 + mm, N = Nof(0);
+      const float *W = src + g.off[0];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = bt::acc_row(0, hh, e);
+        v[e] = unit < N ? (k < g.in_dim ? W[unit * g.in_dim + k] : (k == g.in_dim ? W[N * g.in_dim + unit] : 0.0f)) : 0.0f;
+      }
+      put_group(g0 + ot, ln, v);
+    }
+    // forward [ot][ks] and backward [it][ks] through hidden layer l
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+      const int K = Kof(l), N = Nof(l);
+      const float *W = src + g.off[l];
+      for (int idx = threadIdx.x; idx < (with_backward ? 2 : 1) * 2 * GW * GW * 64; idx += GWAVES * 64) {
+        const int dir = idx / (2 * GW * GW * 64), r2 = (idx >> 6) % (2 * GW * GW), ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+        const int tile = r2 / (2 * GW), ks = r2 % (2 * GW);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int across = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e), own = tile * 32 + mm;
+          // forward: row = own output unit, column = input `across`; backward (W^T): row = own input, column = output
+          const int j = dir == 0 ? own : across, k = dir == 0 ? across : own;
+          v[e] = (j < N && k < K) ? W[j * K + k] : 0.0f;
+        }
+        put_group(g0 + (dir == 0 ? gm_fh(l) : gm_bh(NL, l)) + r2, ln, v);
+      }
+    }
+    {  // output layer: forward [ks], backward [it]
+      const int K = Kof(NL);
+      const float *W = src + g.off[NL];
+      for (int idx = threadIdx.x; idx < (with_backward ? 3 : 2) * GW * 64; idx += GWAVES * 64) {
+        const int q = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int j, k;
+          if (q < 2 * GW) {
+            j = mm;
+            k = 32 * (q >> 1) + bt::acc_row(q & 1, hh, e);
+          } else {
+            j = bt::acc_row(0, hh, e);
+            k = (q - 2 * GW) * 32 + mm;
+          }
+          v[e] = (j < g.out_dim && k < K) ? W[j * K + k] : 0.0f;
+        }
+        put_group(g0 + (q < 2 * GW ? gm_fo(NL) + q : gm_bo(NL) + (q - 2 * GW)), ln, v);
+      }
+    }
+#pragma unroll
+    for (int l = 1; l <= NL; ++l) {
+      const int N = Nof(l), K = Kof(l);
+      for (int u = threadIdx.x; u < 64; u += GWAVES * 64) bias_out[(l - 1) * 64 + u] = u < N ? src[g.off[l] + N * K + u] : 0.0f;
+    }
+  };
+  build(g.params, 0, true, bias);
+  if (JVP) build(g.tangent, TG, false, tbias);
   __syncthreads();
 
   Frag idb[2];
@@ -237,6 +299,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
   const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)((size_t)(tr.T + 1) * tr.n);
   const size_t n_tiles = (B + 31) / 32;
   const size_t wave_id = (size_t)blockIdx.x * GWAVES + wave, n_waves = (size_t)gridDim.x * GWAVES;
+  if (wave_id >= n_tiles) return;  // (no barrier below; the launcher counts slab rows for the waves that have tiles)
   double *__restrict__ row = slabA + wave_id * g.P;
   bool first_flush = true;
 
@@ -256,6 +319,9 @@ __global__ void __launch_bounds__(GWAVES * 64)
       }
       t[r] = 0.0f;
     }
+    // (the slab updates of one tile at a time: hoisting every load of the flush above the first store needs ~400 more
+    // registers than the kernel has)
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto flush_all = [&]() {
 #pragma unroll
@@ -268,15 +334,20 @@ __global__ void __launch_bounds__(GWAVES * 64)
         for (int it = 0; it < GW; ++it) flush_w(dWh[l - 1][ot][it], l, ot, it);
 #pragma unroll
     for (int it = 0; it < GW; ++it) flush_w(dWo[it], NL, 0, it);
-    {  // biases of layers 1 .. NL: column c = (l - 1) GW + ot
-      const int l = 1 + m / GW, ot = m % GW;
+    // biases of layers 1 .. NL: column c = (l - 1) GW + ot of the bias tile
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = ot * 32 + urow(r, kb);
-        if (l <= NL && (l < NL || ot == 0) && j < Nof(l)) put(g.off[l] + (uint32_t)(Nof(l) * Kof(l) + j), dbt[r]);
-        dbt[r] = 0.0f;
+    for (int l = 1; l <= NL; ++l) {
+      const int N = Nof(l), K = Kof(l), ot = m - (l - 1) * GW;
+      if (ot >= 0 && ot < (l < NL ? GW : 1)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = ot * 32 + urow(r, kb);
+          if (j < N) put(g.off[l] + (uint32_t)(N * K + j), dbt[r]);
+        }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dbt[r] = 0.0f;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       sum64[q] += (double)sum32[q];
@@ -308,7 +379,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
     if (MODE == GM_CRITIC) {
       const float tg = tr.tgt[sc];
       o.tgt = o.valid ? tg : 0.0f;
-    } else {
+    } else if (!JVP) {
       const float adv = tr.adv[sc];
       const int act = (int)tr.action[sc];
       o.adv = o.valid ? adv : 0.0f;
@@ -339,35 +410,54 @@ __global__ void __launch_bounds__(GWAVES * 64)
         xb0[0][c].u[2] = xb0[0][c].u[3] = 0u;
       }
     }
-    f32x16 a[NL][GW];
+    // (JVP: the tangent of every layer rides along, ta_l = act'(.) (W_l ta_{l-1} + V_l a_{l-1} + vb_l), ta_{-1} = 0 —
+    // forward-mode differentiation along the tangent parameters V, conjugate_gradient.rs:262-339)
+    f32x16 a[NL][GW], ta[GW];
 #pragma unroll
     for (int ot = 0; ot < GW; ++ot) {
       a[0][ot] = prod6_lds(zero16, img, ot, lane, xb0[0]);
       gm_act_tile(g.act, a[0][ot]);
+      if (JVP) {
+        ta[ot] = prod6_lds(zero16, img, TG + ot, lane, xb0[0]);
+        gm_slope_tile(g.act, ta[ot], a[0][ot]);
+      }
     }
-    auto bias_rows = [&](int l, int ot) {  // accumulator initialised with the bias of its row's unit
+    auto bias_rows = [&](const float *table, int l, int ot) {  // accumulator initialised with the bias of its row's unit
       f32x16 c;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = bias[(l - 1) * 64 + ot * 32 + urow(r, kb)];
+      for (int r = 0; r < 16; ++r) c[r] = table[(l - 1) * 64 + ot * 32 + urow(r, kb)];
       return c;
     };
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
-      Frag ab[GW][2][3];
+      Frag ab[GW][2][3], tb[JVP ? GW : 1][2][3];
 #pragma unroll
       for (int it = 0; it < GW; ++it)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) pieces_trunc(a[l - 1][it], q, ab[it][q]);
+        for (int q = 0; q < 2; ++q) {
+          pieces_trunc(a[l - 1][it], q, ab[it][q]);
+          if (JVP) pieces_trunc(ta[it], q, tb[it][q]);
+        }
 #pragma unroll
       for (int ot = 0; ot < GW; ++ot) {
-        f32x16 c = bias_rows(l, ot);
+        f32x16 c = bias_rows(bias, l, ot);
 #pragma unroll
         for (int ks = 0; ks < 2 * GW; ++ks) c = prod6_lds(c, img, gm_fh(l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
         gm_act_tile(g.act, c);
         a[l][ot] = c;
+        if (JVP) {
+          f32x16 tc = bias_rows(tbias, l, ot);
+#pragma unroll
+          for (int ks = 0; ks < 2 * GW; ++ks) {
+            tc = prod6_lds(tc, img, gm_fh(l) + ot * 2 * GW + ks, lane, tb[JVP ? ks >> 1 : 0][ks & 1]);
+            tc = prod6_lds(tc, img, TG + gm_fh(l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
+          }
+          gm_slope_tile(g.act, tc, c);
+          ta[ot] = tc;  // (the pieces of the previous layer's tangent are in tb already)
+        }
       }
     }
-    f32x16 zt = bias_rows(NL, 0);
+    f32x16 zt = bias_rows(bias, NL, 0), tzt = zero16;
     {
       Frag ab[GW][2][3];
 #pragma unroll
@@ -376,6 +466,16 @@ __global__ void __launch_bounds__(GWAVES * 64)
         for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1][it], q, ab[it][q]);
 #pragma unroll
       for (int ks = 0; ks < 2 * GW; ++ks) zt = prod6_lds(zt, img, gm_fo(NL) + ks, lane, ab[ks >> 1][ks & 1]);
+      if (JVP) {
+        tzt = bias_rows(tbias, NL, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2 * GW; ++ks) {
+          Frag tb[3];
+          pieces_trunc(ta[ks >> 1], ks & 1, tb);
+          tzt = prod6_lds(tzt, img, gm_fo(NL) + ks, lane, tb);
+          tzt = prod6_lds(tzt, img, TG + gm_fo(NL) + ks, lane, ab[ks >> 1][ks & 1]);
+        }
+      }
     }
     // ---- per-sample terms on the lanes of half 0 (rows 0 and 1 of the output tile are the module's outputs)
     const bool owner = kb == 0 && op.valid;
@@ -386,6 +486,17 @@ __global__ void __launch_bounds__(GWAVES * 64)
       if (owner) {
         sum32[0] = __builtin_fmaf(d, d, sum32[0]);
         d0 = d * inv_B * gm_slope(g.out_act, v);  // inv_B = 2 / B here
+      }
+    } else if (JVP) {
+      // Fisher metric of the categorical head on the tangent outputs: dz_a = p_a (ty_a - sum_b p_b ty_b) / B; two
+      // actions: dz_0 = -dz_1 = p_0 p_1 (ty_0 - ty_1) / B
+      const float y0 = gm_act(g.out_act, zt[0]), y1 = gm_act(g.out_act, zt[1]);
+      const float s0 = gm_slope(g.out_act, y0), s1 = gm_slope(g.out_act, y1);
+      const SoftPair sp = soft_pair(y0 - y1);
+      const float gz = (sp.p[0] * sp.p[1]) * (tzt[0] * s0 - tzt[1] * s1) * inv_B;
+      if (owner) {
+        d0 = gz * s0;
+        d1 = -gz * s1;
       }
     } else {
       const float y0 = gm_act(g.out_act, zt[0]), y1 = gm_act(g.out_act, zt[1]);
@@ -468,8 +579,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
         transpose_pieces<2>(ab, idb, aT[it]);
         dWo[it] = wgrad_tile(dWo[it], dT[0], aT[it]);
         f32x16 c = prod6_lds(zero16, img, gm_bo(NL) + it, lane, dob[0]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = c[r] * gm_slope(g.act, a[NL - 1][it][r]);
+        gm_slope_tile(g.act, c, a[NL - 1][it]);
         dl[it] = c;
       }
       // ---- hidden layers NL - 1 .. 1: weights between layer l - 1 and l
@@ -496,8 +606,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
 #pragma unroll
           for (int ks = 0; ks < 2 * GW; ++ks)
             c = prod6_lds(c, img, gm_bh(NL, l) + it * 2 * GW + ks, lane, db[ks >> 1][ks & 1]);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) c[r] = c[r] * gm_slope(g.act, a[l - 1][it][r]);
+          gm_slope_tile(g.act, c, a[l - 1][it]);
           dn[it] = c;
         }
 #pragma unroll
@@ -514,22 +623,22 @@ __global__ void __launch_bounds__(GWAVES * 64)
         dW0[ot] = wgrad_tile(dW0[ot], dT[ot], aT[0]);
       }
     }
-    if (++since_flush == GM_FLUSH) {
+    // one flush site (the accumulators stay in registers only if nothing out of line touches them): every GM_FLUSH
+    // tiles and after the wave's last tile
+    if (++since_flush == GM_FLUSH || t + n_waves >= n_tiles) {
       since_flush = 0;
-      if (BWD) flush_all();
-      else
+      if (BWD) {
+        flush_all();
+      } else {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
           sum64[q] += (double)sum32[q];
           sum32[q] = 0.0f;
         }
+      }
     }
     op = next;
   }
-  if (BWD) flush_all();
-  else
-#pragma unroll
-    for (int q = 0; q < 3; ++q) sum64[q] += (double)sum32[q];
   // the wave's scalar sums: over its 32 owner lanes
   auto xlane = [](double v, int mask) {
     uint64_t bits = rl_f64_bits(v);
@@ -556,7 +665,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
 template <int MODE, int NL>
 void gm_launch(rl_traj *t, const GmArgs &g, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
                float clip_hi) {
-  const size_t lds = gm_lds_bytes(NL);
+  const size_t lds = gm_lds_bytes(NL, MODE == PASS_JVP);
   {
     static std::mutex mu;
     static std::set<int> raised;
@@ -590,16 +699,19 @@ bool gen_mfma_fits(const rl_traj *t, const rl_mlp *m) {
   return true;
 }
 
-// mode: RL_GEN_CRITIC, PASS_INIT, PASS_PPO or PASS_EVAL.  Leaves one slab row per WAVE: t->last_rows rows of slabA
+// mode: RL_GEN_CRITIC, PASS_INIT, PASS_PPO, PASS_EVAL or PASS_JVP (with the tangent parameters).  Leaves one slab row per WAVE: t->last_rows rows of slabA
 // (gradient modes) and slabB.
-bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, uint64_t B_total, const int32_t *d_skip, float clip_lo,
-                     float clip_hi) {
+bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tangent, uint64_t B_total,
+                     const int32_t *d_skip, float clip_lo, float clip_hi) {
   if (!gen_mfma_fits(t, m)) return false;
-  if (mode != RL_GEN_CRITIC && mode != PASS_INIT && mode != PASS_PPO && mode != PASS_EVAL) return false;
+  if (mode != RL_GEN_CRITIC && mode != PASS_INIT && mode != PASS_PPO && mode != PASS_EVAL && mode != PASS_JVP) return false;
+  // the tangent's forward fragments next to the parameters': 114 KB of LDS for two hidden layers, too much for three
+  if (mode == PASS_JVP && (d_tangent == nullptr || gm_lds_bytes((int)m->n_hidden, true) > 160 * 1024)) return false;
   if (mode != RL_GEN_CRITIC && m->out_dim != 2) return false;
   if (mode == RL_GEN_CRITIC && m->out_dim != 1) return false;
   GmArgs g{};
   g.params = m->d_params;
+  g.tangent = d_tangent;
   g.in_dim = (int)m->in_dim;
   g.out_dim = (int)m->out_dim;
   g.act = m->act;
@@ -610,7 +722,7 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, uint64_t B_total, co
   const uint64_t n_tiles = (t->B + 31) / 32, cus = (uint64_t)t->eng->prop.multiProcessorCount;
   uint64_t nwg = (n_tiles + GWAVES - 1) / GWAVES;
   if (nwg > cus) nwg = cus;
-  t->last_rows = (uint32_t)(nwg * GWAVES);
+  t->last_rows = (uint32_t)(nwg * GWAVES < n_tiles ? nwg * GWAVES : n_tiles);  // one slab row per wave that has tiles
   gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
   traj_ensure_slabs(t, t->last_rows, m->P, t->last_rows);
   const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
@@ -618,6 +730,7 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, uint64_t B_total, co
   if (mode == RL_GEN_CRITIC) gm_launch_nl<GM_CRITIC>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   else if (mode == PASS_INIT) gm_launch_nl<PASS_INIT>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   else if (mode == PASS_PPO) gm_launch_nl<PASS_PPO>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (mode == PASS_JVP) gm_launch_nl<PASS_JVP>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   else gm_launch_nl<PASS_EVAL>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   return true;
 }

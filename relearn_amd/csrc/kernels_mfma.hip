@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 // gradient (PASS_INIT), Fisher-vector product (PASS_JVP) or loss/KL evaluation (PASS_EVAL) in one launch
 bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                       const int32_t *d_skip, float clip_lo, float clip_hi) {
-  if (policy->general) return launch_gen_mfma(traj, policy, mode, B_total, d_skip, clip_lo, clip_hi);
+  if (policy->general) return launch_gen_mfma(traj, policy, mode, d_tangent, B_total, d_skip, clip_lo, clip_hi);
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
   if (mode == PASS_DQN) return false;  // k_dqn_step_bf16 (kernels_dqn.hip)
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernels
