@@ -229,6 +229,7 @@ struct GenDev {
   float *act = nullptr, *tact = nullptr;  // [hidden units][rows]: activations of the last forward, their tangents
   float *delta = nullptr;                 // [2][widest layer][rows]: backward deltas (ping-pong)
   float *z = nullptr, *tz = nullptr;      // [2][rows]: outputs and tangent outputs
+  int32_t *no_interrupt = nullptr;        // != 0: the trajectory holds no Interrupt (the successor-value forward is skipped)
   uint64_t cap_act = 0, cap_tact = 0, cap_delta = 0, cap_z = 0, cap_tz = 0;
 };
 

@@ -321,6 +321,14 @@ __global__ void __launch_bounds__(256) k_gen_successor_values(TrajDev tr, const 
   succ[b] = s;
 }
 
+// *flag = 0 when any step of the trajectory ended in an Interrupt (the host sets it non-zero before the launch)
+__global__ void __launch_bounds__(256) k_gen_any_interrupt(TrajDev tr, int32_t *__restrict__ flag) {
+  const size_t B = (size_t)tr.T * tr.n;
+  bool any = false;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (size_t)gridDim.x * 256) any |= tr.flag[b] == RL_SUCC_INTERRUPT;
+  if (__any(any) && (threadIdx.x & 63) == 0) *flag = 0;
+}
+
 // PolicyActor::act for one step of every lane from stored logits: Categorical::new + the inverse-CDF draw with word
 // `word` of the lane's actor stream (the fused rollouts' arithmetic, kernels_rollout.hip)
 __global__ void __launch_bounds__(256) k_gen_sample_actions(CartPoleDev c, const float *__restrict__ z, uint32_t n,
@@ -359,6 +367,50 @@ __global__ void __launch_bounds__(256) k_gen_record_step(TrajDev tr, const uint8
   tr.flag[o] = flag[i];
   if (flag[i] == RL_SUCC_INTERRUPT)
     for (uint32_t d = 0; d < tr.D; ++d) tr.term_obs[(size_t)d * tr.T * tr.n + o] = term_obs[(size_t)d * tr.n + i];
+}
+
+// One CartPole step of every lane in ONE launch: PolicyActor::act from the stored logits (k_gen_sample_actions), the env
+// step (k_env_step, kernels_rollout.hip), the step's record and the next observation — into the trajectory (slot t + 1)
+// and into the env's observation buffer, where the next forward reads it.  The same values as the four launches it
+// replaces (sample, env step, record step, record observation): a per-step sequence is launch-bound, 7 launches of ~7 us.
+template <int D>
+__global__ void __launch_bounds__(256) k_gen_step_cartpole(CartPoleDev c, EnvStateDev st, TrajDev tr,
+                                                           const float *__restrict__ z, uint64_t word, uint32_t t,
+                                                           float *__restrict__ obs_next) {
+  const uint32_t n = tr.n, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16];
+  rl_chacha_block(c.key_actor, word >> 4, c.lane_offset + i, 4, w);
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k == (int)(word & 15)) v = w[k];
+  const float u = rl_u32_to_unit_f32(v);
+  const float zz[2] = {z[i], z[n + i]};
+  float lp[2];
+  log_softmax_lane<2>(zz, lp);
+  const int a = categorical_sample_lane<2>(lp, u);
+  LaneState s;
+  lane_load(st, i, s);
+  const int succ = cp_step(c, s, a);
+  const size_t o = (size_t)t * n + i, plane = (size_t)(tr.T + 1) * n;
+  tr.action[o] = (uint8_t)a;
+  tr.reward[o] = 1.0f;  // Reward(1.0) as f32
+  tr.flag[o] = (uint8_t)succ;
+  float f[D];
+  if (succ == RL_SUCC_INTERRUPT) {
+    cp_features<D>(c, s, f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * tr.T * n + o] = f[d];
+  }
+  if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, c.lane_offset + i);
+  cp_features<D>(c, s, f);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    obs_next[(size_t)d * n + i] = f[d];
+    tr.obs[d * plane + (size_t)(t + 1) * n + i] = f[d];
+  }
+  lane_store(st, i, s);
 }
 
 // d loss / d (pre-activation of the output layer) = d loss / d output * act'(output)   (output_activation != Identity)
@@ -454,6 +506,7 @@ void traj_ensure_slabs(rl_traj *t, uint64_t rowsA, uint64_t P, uint64_t rowsB) {
 void gen_free(rl_traj *t) {
   GenDev &g = t->gen;
   for (float *p : {g.act, g.tact, g.delta, g.z, g.tz}) dfree(p);
+  dfree(g.no_interrupt);
   g = GenDev{};
 }
 
@@ -597,8 +650,12 @@ void launch_gen_values(rl_traj *t, const rl_mlp *critic) {
   gen_ensure(t, critic, B, false, false);
   GenDev &g = t->gen;
   const size_t plane = (size_t)(T + 1) * n;
-  // V(term_obs[t][lane]) for every (t, lane) (only the interrupted ones are used), V(obs[T][lane]), then V(obs[t])
-  gen_forward_impl(t, critic, t->d.term_obs, (size_t)B, B, g.z, nullptr, nullptr, nullptr);
+  // V(term_obs[t][lane]) for every (t, lane) — only the interrupted ones are used, and the whole forward is skipped
+  // (device-side flag) when the trajectory holds none — V(obs[T][lane]), then V(obs[t])
+  if (!g.no_interrupt) g.no_interrupt = dalloc<int32_t>(1);
+  RL_HIP_CHECK(hipMemsetAsync(g.no_interrupt, 1, sizeof(int32_t), t->eng->stream));
+  hipLaunchKernelGGL(k_gen_any_interrupt, dim3(256), dim3(256), 0, t->eng->stream, t->d, g.no_interrupt);
+  gen_forward_impl(t, critic, t->d.term_obs, (size_t)B, B, g.z, nullptr, nullptr, g.no_interrupt);
   gen_forward_impl(t, critic, t->d.obs + (size_t)T * n, plane, n, g.z + B, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_gen_successor_values, dim3(cdiv_g(B, 256)), dim3(256), 0, t->eng->stream, t->d, g.z, g.z + B,
                      q.succ);
@@ -614,6 +671,22 @@ void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t) {
   GenDev &g = t->gen;
   const dim3 grid(cdiv_g(n, 256)), blk(256);
   launch_env_observe(env, env->d_obs);
+  if (env->kind == RL_ENV_CARTPOLE && policy->out_dim == 2 && e->kernel_variant != 1) {
+    // CartPole lanes: a step is the policy's layer launches and one launch for everything else
+    hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, 0u);
+    for (uint32_t step = 0; step < T; ++step) {
+      gen_forward_impl(t, policy, env->d_obs, (size_t)n, n, g.z, nullptr, nullptr, nullptr);
+      if (env->D == 5)
+        hipLaunchKernelGGL(k_gen_step_cartpole<5>, grid, blk, 0, e->stream, env->dev, env->st, t->d, g.z, env->t_global,
+                           step, env->d_obs);
+      else
+        hipLaunchKernelGGL(k_gen_step_cartpole<4>, grid, blk, 0, e->stream, env->dev, env->st, t->d, g.z, env->t_global,
+                           step, env->d_obs);
+      env->t_global += 1;
+    }
+    RL_HIP_CHECK(hipGetLastError());
+    return;
+  }
   for (uint32_t step = 0; step < T; ++step) {
     hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, step);
     gen_forward_impl(t, policy, env->d_obs, (size_t)n, n, g.z, nullptr, nullptr, nullptr);
