@@ -189,11 +189,13 @@ def test_update_against_oracle(engine, variant, td):
     assert np.abs(dqn.qnet.get_params() - osim.qparams).max() < PARAM_ATOL
 
 
-def test_update_builds_all_minibatches_at_once(engine):
-    """Reward-to-go updates gather every minibatch of the update in one launch; the last one stays readable and is
-    bit-identical to the oracle's (the same bars as the one-at-a-time builder), episodes longer than a wave's 64-step
-    chunk included."""
-    dqn, osim = make(engine, n=192, capacity=400, minibatch=9000, opt_steps=5, max_steps=150, eps=("const", 0.9))
+@pytest.mark.parametrize("limit", [ra.LIMIT_VISIBLE, ra.LIMIT_NONE], ids=["5-features", "4-features"])
+def test_update_builds_all_minibatches_at_once(engine, limit):
+    """Reward-to-go updates gather every minibatch of the update in one launch (and draw them on a second stream while
+    the first ones train); the last one stays readable and is bit-identical to the oracle's (the same bars as the
+    one-at-a-time builder), episodes longer than a wave's 64-step chunk included."""
+    dqn, osim = make(engine, n=192, capacity=400, minibatch=9000, opt_steps=5, max_steps=150, eps=("const", 0.9),
+                     limit=limit)
     dqn.collect(330)
     osim.collect(330, 0.9)
     st, losses_d = dqn.update(want_losses=True)

@@ -288,6 +288,60 @@ def test_gradients_and_fisher_vector_products(engine, hidden, act, out_act):
     assert np.abs(fgot - fwant).max() <= 5e-5 * np.abs(fwant).max() + 1e-9
 
 
+@pytest.mark.parametrize("hidden,act,out_act,n,T", [
+    ([64, 64], "Relu", "Identity", 3, 5), ([64, 64], "Tanh", "Identity", 700, 9), ([33], "Relu", "Identity", 65, 7),
+    ([32, 16, 8], "Sigmoid", "Tanh", 130, 20), ([17, 64], "Relu", "Sigmoid", 96, 12), ([64, 1, 64], "Tanh", "Identity", 50, 3)])
+def test_fused_matrix_passes_agree_with_the_layer_kernels(engine, hidden, act, out_act, n, T):
+    """Shapes the fused matrix-pipe launch takes (kernels_gen_mfma.hip: 1-3 hidden layers of at most 64 units) against
+    the per-layer f32 kernels (kernel variant 1) on the same trajectory: two implementations that share no code beyond
+    the activation definitions.  Sample counts below one tile, ragged last tiles, fewer tiles than waves; every pass:
+    gradient, loss / KL, Fisher-vector product, PPO steps, critic gradient and critic steps."""
+    pol, cri = make(engine, 5, hidden, 2, 41, act, out_act), make(engine, 5, hidden, 1, 42, act, out_act)
+    env = ra.CartPoleEnv(engine, n, max_steps=9, seed_env=5, seed_actor=6)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    p0, c0 = pol.get_params(), cri.get_params()
+    vec = np.random.default_rng(9).normal(size=pol.P).astype(np.float32)
+    moved = (p0 + 0.01 * vec).astype(np.float32)
+    got = {}
+    for variant in (0, 1):
+        engine.set_kernel_variant(variant)
+        try:
+            pol.set_params(p0)
+            cri.set_params(c0)
+            r = {"grad": ra.policy_gradient(pol, traj), "fvp": ra.policy_fvp(pol, traj, vec, 0.0),
+                 "cgrad": ra.critic_gradient(cri, traj)}
+            pol.set_params(moved)
+            r["loss_kl"] = ra.policy_loss_kl(pol, traj, p0)
+            pol.set_params(p0)
+            cfg = ra.ppo_config_default()
+            cfg.opt_steps_per_update = 3
+            r["ppo"] = ra.ppo_update(pol, ra.Adam(pol), traj, cfg, want_losses=True)[1]
+            r["ppo_params"] = pol.get_params()
+            r["critic"] = ra.critic_update(cri, ra.Adam(cri), traj, 3, want_losses=True)[1]
+            r["critic_params"] = cri.get_params()
+            got[variant] = r
+        finally:
+            engine.set_kernel_variant(0)
+    a, b = got[0], got[1]
+
+    def close(x, y, rel):
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        return np.abs(x - y).max() <= rel * max(np.abs(y).max(), 1e-30) + 1e-12
+
+    assert close(a["grad"][0], b["grad"][0], 2e-5) and close(a["grad"][1:], b["grad"][1:], 2e-5)  # gradient; loss, entropy
+    assert close(a["fvp"], b["fvp"], 5e-5)
+    assert close(a["cgrad"][0], b["cgrad"][0], 2e-5) and close(a["cgrad"][1], b["cgrad"][1], 2e-6)
+    assert abs(a["loss_kl"][0] - b["loss_kl"][0]) <= 2e-5 * abs(b["loss_kl"][0]) + 1e-7
+    assert abs(a["loss_kl"][1] - b["loss_kl"][1]) <= 2e-4 * abs(b["loss_kl"][1]) + 1e-8
+    assert close(a["ppo"], b["ppo"], 2e-5) and close(a["critic"], b["critic"], 2e-5)
+    # three Adam steps at lr 1e-3: the first step moves every parameter by ~lr whatever the gradient's size, so a
+    # gradient entry near zero can flip its step's sign between two f32 summation orders
+    assert np.abs(a["ppo_params"] - b["ppo_params"]).max() < 4e-3 and np.abs(a["critic_params"] - b["critic_params"]).max() < 4e-3
+    assert np.median(np.abs(a["critic_params"] - b["critic_params"])) < 1e-5
+
+
 @pytest.mark.parametrize("hidden", [[64, 64], [130]])
 def test_updates_run_and_improve(engine, hidden):
     pol, cri = make(engine, 5, hidden, 2, 31), make(engine, 5, hidden, 1, 32)
