@@ -19,5 +19,12 @@ for n in 65536 8192 4096; do
 done
 bash scripts/pmc_passes.sh "${TAG}_65536" scripts/path_once.py 65536 1 80 > "$OUT/pmc_65536.log" 2>&1 || echo "pmc failed"
 cp "gpurun_out/pmc/${TAG}_65536/summary.json" "$OUT/pmc_65536_summary.json" 2>/dev/null
+# the other configurations: DQN (config 3) with its kernel trace, GRU (config 5), the general MLP period and its passes
+python3 scripts/dqn_config3.py > "$OUT/dqn_config3.json" 2> "$OUT/dqn_config3.err" || echo "dqn failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dqn" -- python3 scripts/dqn_config3.py 4096 1221 3 \
+  > "$OUT/dqn_under_rocprof.json" 2> "$OUT/stats_dqn.log" || echo "rocprof dqn failed"
+python3 scripts/gru_config5.py > "$OUT/gru_config5.json" 2> "$OUT/gru_config5.err" || echo "gru failed"
+python3 scripts/general_mlp_period.py > "$OUT/general_mlp_period.json" 2> "$OUT/general_mlp_period.err" || echo "general failed"
+python3 scripts/gen_passes.py > "$OUT/general_mlp_passes.txt" 2>&1 || echo "gen passes failed"
 find "$OUT" -name "*kernel_stats.csv" | head
 echo "collect_profiles done"
