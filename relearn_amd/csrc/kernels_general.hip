@@ -421,6 +421,204 @@ __global__ void __launch_bounds__(256) k_gen_output_slope(float *__restrict__ dz
   if (i < count) dz[i] = dz[i] * act_slope(act, z[i]);
 }
 
+// ---------------------------------------------------------------- all layers of a forward in one workgroup
+// The arithmetic of k_gen_dense (acc = bias; acc = fma(x_k, w_k, acc), k ascending; act), layer after layer on one
+// 64-sample tile whose activations ping-pong between two LDS tiles: no activation plane in HBM and one launch for the
+// whole network.  A workgroup's four waves split a layer's output units, four units per pass over the inputs, eight
+// inputs per block of wave-uniform weight loads — k_gen_dense's inner loop.
+struct ChainNet {
+  const float *params;
+  int n_layers, act, out_act;
+  int K[RL_MLP_MAX_HIDDEN + 1], N[RL_MLP_MAX_HIDDEN + 1];
+  uint32_t off[RL_MLP_MAX_HIDDEN + 1];
+  int wmax;  // widest input of any layer (rows of an LDS tile)
+};
+
+// X: [wmax][GT] input tile (rows 0 .. K[0]); returns the tile that holds the module's outputs (rows 0 .. out_dim).
+// Every thread of the 256-thread workgroup calls it; barriers inside.
+__device__ __forceinline__ float *chain_forward_tile(const ChainNet &net, float *X, float *Y, int s, int g) {
+  float *in = X, *out = Y;
+  for (int l = 0; l < net.n_layers; ++l) {
+    const int K = net.K[l], N = net.N[l];
+    const float *__restrict__ W = net.params + net.off[l];
+    const float *__restrict__ b = W + (size_t)N * K;
+    const int act = l + 1 == net.n_layers ? net.out_act : net.act;
+    for (int n0 = 4 * g; n0 < N; n0 += 16) {
+      float acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = b[n0 + u < N ? n0 + u : N - 1];
+      int k = 0;
+      for (; k + 8 <= K; k += 8) {
+        float w[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n = n0 + u < N ? n0 + u : N - 1;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) w[u][q] = W[(size_t)n * K + k + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float xv = in[(k + q) * GT + s];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] = __builtin_fmaf(xv, w[u][q], acc[u]);
+        }
+      }
+      for (; k < K; ++k) {
+        const float xv = in[k * GT + s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_fmaf(xv, W[(size_t)(n0 + u < N ? n0 + u : N - 1) * K + k], acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (n0 + u < N) out[(n0 + u) * GT + s] = act_apply(act, acc[u]);
+    }
+    __syncthreads();
+    float *t = in;
+    in = out;
+    out = t;
+  }
+  return in;
+}
+
+// rows of [in_dim][.] inputs (feature k of row r at X[k * xs + r]) -> outputs Y[o * ys + r]
+__global__ void __launch_bounds__(256) k_gen_chain_rows(ChainNet net, const float *__restrict__ X, size_t xs, size_t rows,
+                                                        float *__restrict__ Y, size_t ys, int out_dim,
+                                                        const int32_t *__restrict__ skip) {
+  extern __shared__ float chain_lds[];  // [2][wmax][GT]
+  if (skip != nullptr && *skip != 0) return;
+  const int s = threadIdx.x & (GT - 1);
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t s0 = (size_t)blockIdx.x * GT;
+  float *t0 = chain_lds, *t1 = chain_lds + (size_t)net.wmax * GT;
+  for (int idx = threadIdx.x; idx < net.K[0] * GT; idx += 256) {
+    const int k = idx >> 6, ss = idx & (GT - 1);
+    t0[idx] = s0 + ss < rows ? X[(size_t)k * xs + s0 + ss] : 0.0f;
+  }
+  __syncthreads();
+  const float *z = chain_forward_tile(net, t0, t1, s, g);
+  for (int idx = threadIdx.x; idx < out_dim * GT; idx += 256) {
+    const int o = idx >> 6, ss = idx & (GT - 1);
+    if (s0 + ss < rows) Y[(size_t)o * ys + s0 + ss] = z[o * GT + ss];
+  }
+}
+
+// The fused rollout of kernels_rollout.hip (k_rollout_cartpole: T env-actor steps in one launch, lane state in registers
+// for the whole horizon, the 26 B/step trajectory record the only HBM traffic) for policies with any hidden_sizes: a
+// workgroup owns 64 lanes, its four waves share the policy forward of every step (chain_forward_tile), wave 0 keeps the
+// lanes: features, the actor's draw, the env step, the records.  The same observations, draws, actions and records as the
+// step-by-step launch sequence (tests/test_gpu_general_mlp.py replays them through the oracle's lanes bit for bit).
+template <int D>
+__global__ void __launch_bounds__(256) k_gen_rollout_cartpole(CartPoleDev c, EnvStateDev st, TrajDev tr, ChainNet net,
+                                                              uint64_t t_global) {
+  extern __shared__ float chain_lds[];  // [2][wmax][GT], then the actor words [16][GT]
+  const int s = threadIdx.x & (GT - 1);
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool keeper = g == 0;
+  float *t0 = chain_lds, *t1 = chain_lds + (size_t)net.wmax * GT;
+  uint32_t *actor_words = reinterpret_cast<uint32_t *>(chain_lds + (size_t)2 * net.wmax * GT);
+  const uint32_t n = tr.n, T = tr.T;
+  const uint32_t i = blockIdx.x * GT + (uint32_t)s;
+  const bool live = keeper && i < n;
+  const uint32_t il = i < n ? i : n - 1;
+  const uint64_t lane = c.lane_offset + il;
+  LaneState ls;
+  if (keeper) lane_load(st, il, ls);
+  const size_t plane = (size_t)(T + 1) * n;
+  uint64_t cur_block = ~0ull;
+  for (uint32_t t = 0; t < T; ++t) {
+    float f[D];
+    if (keeper) {
+      cp_features<D>(c, ls, f);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (live) tr.obs[d * plane + (size_t)t * n + il] = f[d];
+        t0[d * GT + s] = f[d];
+      }
+      const uint64_t blk = (t_global + t) >> 4;
+      if (blk != cur_block) {
+        uint32_t words[16];
+        rl_chacha_block(c.key_actor, blk, lane, 4, words);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) actor_words[k * GT + s] = words[k];
+        cur_block = blk;
+      }
+    }
+    __syncthreads();
+    const float *z = chain_forward_tile(net, t0, t1, s, g);  // (ends with a barrier)
+    if (keeper) {
+      const float u = rl_u32_to_unit_f32(actor_words[(uint32_t)((t_global + t) & 15) * GT + s]);
+      const float zz[2] = {z[s], z[GT + s]};
+      float lp[2];
+      log_softmax_lane<2>(zz, lp);
+      const int a = categorical_sample_lane<2>(lp, u);
+      const int succ = cp_step(c, ls, a);
+      const size_t o = (size_t)t * n + il;
+      if (live) {
+        tr.action[o] = (uint8_t)a;
+        tr.reward[o] = 1.0f;
+        tr.flag[o] = (uint8_t)succ;
+      }
+      if (succ == RL_SUCC_INTERRUPT) {
+        cp_features<D>(c, ls, f);
+        if (live) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) tr.term_obs[(size_t)d * T * n + o] = f[d];
+        }
+      }
+      if (succ != RL_SUCC_CONTINUE) cp_reset(c, ls, lane);
+    }
+    __syncthreads();  // the output tile is the next step's scratch
+  }
+  if (keeper) {
+    float f[D];
+    cp_features<D>(c, ls, f);
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) tr.obs[d * plane + (size_t)T * n + il] = f[d];
+      lane_store(st, il, ls);
+    }
+  }
+}
+
+// the module as a kernel argument; false when a layer is too wide for two LDS tiles (+ the actor words) of a workgroup
+bool chain_net(const rl_mlp *m, ChainNet *net) {
+  net->params = m->d_params;
+  net->n_layers = (int)m->n_layers();
+  net->act = m->act;
+  net->out_act = m->out_act;
+  int wmax = (int)m->in_dim;
+  for (uint32_t l = 0; l < m->n_layers(); ++l) {
+    net->K[l] = (int)m->fan_in(l);
+    net->N[l] = (int)m->fan_out(l);
+    net->off[l] = (uint32_t)m->layer_offset(l);
+    if (net->N[l] > wmax) wmax = net->N[l];
+  }
+  net->wmax = wmax;
+  return ((size_t)2 * wmax * GT + 16 * GT) * sizeof(float) <= 150 * 1024;
+}
+
+static void chain_lds_attr(rl_engine *e, const void *kern, size_t lds) {
+  if (lds <= 48 * 1024) return;
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  if (raised.insert({e->device, kern}).second)
+    RL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+}
+
+// Y[o][r] = module(X[.][r]) for `rows` rows in one launch; false: a layer too wide (the caller runs the layer kernels)
+bool launch_gen_chain_rows(rl_engine *e, const rl_mlp *m, const float *x, size_t xs, uint64_t rows, float *out, size_t ys,
+                           const int32_t *skip) {
+  ChainNet net;
+  if (!chain_net(m, &net) || rows == 0 || e->kernel_variant == 1) return false;
+  const size_t lds = (size_t)2 * net.wmax * GT * sizeof(float);
+  chain_lds_attr(e, reinterpret_cast<const void *>(&k_gen_chain_rows), lds);
+  hipLaunchKernelGGL(k_gen_chain_rows, dim3(cdiv_g(rows, GT)), dim3(256), lds, e->stream, net, x, xs, (size_t)rows, out, ys,
+                     (int)m->out_dim, skip);
+  RL_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 template <bool TANGENT>
 void dense(rl_engine *e, const DenseArgs &a) {
   const size_t lds = (size_t)a.K * GT * sizeof(float) * (TANGENT ? 2 : 1);
@@ -551,6 +749,7 @@ static void gen_forward_impl(rl_traj *t, const rl_mlp *m, const float *x, size_t
 }
 
 void launch_gen_forward(rl_traj *t, const rl_mlp *m, const float *x, size_t xs, uint64_t rows, float *out) {
+  if (launch_gen_chain_rows(t->eng, m, x, xs, rows, out, (size_t)rows, nullptr)) return;
   gen_ensure(t, m, rows, false, false);
   gen_forward_impl(t, m, x, xs, rows, out, nullptr, nullptr, nullptr);
 }
@@ -655,11 +854,15 @@ void launch_gen_values(rl_traj *t, const rl_mlp *critic) {
   if (!g.no_interrupt) g.no_interrupt = dalloc<int32_t>(1);
   RL_HIP_CHECK(hipMemsetAsync(g.no_interrupt, 1, sizeof(int32_t), t->eng->stream));
   hipLaunchKernelGGL(k_gen_any_interrupt, dim3(256), dim3(256), 0, t->eng->stream, t->d, g.no_interrupt);
-  gen_forward_impl(t, critic, t->d.term_obs, (size_t)B, B, g.z, nullptr, nullptr, g.no_interrupt);
-  gen_forward_impl(t, critic, t->d.obs + (size_t)T * n, plane, n, g.z + B, nullptr, nullptr, nullptr);
+  auto fwd = [&](const float *x, size_t xs, uint64_t rows, float *out, const int32_t *skip) {
+    if (!launch_gen_chain_rows(t->eng, critic, x, xs, rows, out, (size_t)rows, skip))
+      gen_forward_impl(t, critic, x, xs, rows, out, nullptr, nullptr, skip);
+  };
+  fwd(t->d.term_obs, (size_t)B, B, g.z, g.no_interrupt);
+  fwd(t->d.obs + (size_t)T * n, plane, n, g.z + B, nullptr);
   hipLaunchKernelGGL(k_gen_successor_values, dim3(cdiv_g(B, 256)), dim3(256), 0, t->eng->stream, t->d, g.z, g.z + B,
                      q.succ);
-  gen_forward_impl(t, critic, t->d.obs, plane, B, q.out, nullptr, nullptr, nullptr);
+  fwd(t->d.obs, plane, B, q.out, nullptr);
 }
 
 // ---------------------------------------------------------------- rollout, one launch sequence per step
@@ -669,6 +872,23 @@ void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t) {
   const uint32_t n = t->d.n, T = t->d.T;
   gen_ensure(t, policy, n, false, false);
   GenDev &g = t->gen;
+  ChainNet net;
+  if (env->kind == RL_ENV_CARTPOLE && policy->out_dim == 2 && e->kernel_variant == 0 && chain_net(policy, &net)) {
+    // CartPole lanes: all T steps in one launch
+    const size_t lds = ((size_t)2 * net.wmax * GT + 16 * GT) * sizeof(float);
+    if (env->D == 5) {
+      chain_lds_attr(e, reinterpret_cast<const void *>(&k_gen_rollout_cartpole<5>), lds);
+      hipLaunchKernelGGL(k_gen_rollout_cartpole<5>, dim3(cdiv_g(n, GT)), dim3(256), lds, e->stream, env->dev, env->st, t->d,
+                         net, env->t_global);
+    } else {
+      chain_lds_attr(e, reinterpret_cast<const void *>(&k_gen_rollout_cartpole<4>), lds);
+      hipLaunchKernelGGL(k_gen_rollout_cartpole<4>, dim3(cdiv_g(n, GT)), dim3(256), lds, e->stream, env->dev, env->st, t->d,
+                         net, env->t_global);
+    }
+    RL_HIP_CHECK(hipGetLastError());
+    env->t_global += T;
+    return;
+  }
   const dim3 grid(cdiv_g(n, 256)), blk(256);
   launch_env_observe(env, env->d_obs);
   if (env->kind == RL_ENV_CARTPOLE && policy->out_dim == 2 && e->kernel_variant != 1) {
