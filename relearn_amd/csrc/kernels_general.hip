@@ -435,15 +435,15 @@ struct ChainNet {
 };
 
 // X: [wmax][GT] input tile (rows 0 .. K[0]); returns the tile that holds the module's outputs (rows 0 .. out_dim).
-// Every thread of the 256-thread workgroup calls it; barriers inside.
-__device__ __forceinline__ float *chain_forward_tile(const ChainNet &net, float *X, float *Y, int s, int g) {
+// Every thread of the workgroup (`waves` waves, wave g takes the unit groups g, g + waves, ...) calls it; barriers inside.
+__device__ __forceinline__ float *chain_forward_tile(const ChainNet &net, float *X, float *Y, int s, int g, int waves = 4) {
   float *in = X, *out = Y;
   for (int l = 0; l < net.n_layers; ++l) {
     const int K = net.K[l], N = net.N[l];
     const float *__restrict__ W = net.params + net.off[l];
     const float *__restrict__ b = W + (size_t)N * K;
     const int act = l + 1 == net.n_layers ? net.out_act : net.act;
-    for (int n0 = 4 * g; n0 < N; n0 += 16) {
+    for (int n0 = 4 * g; n0 < N; n0 += 4 * waves) {
       float acc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[u] = b[n0 + u < N ? n0 + u : N - 1];
@@ -507,9 +507,12 @@ __global__ void __launch_bounds__(256) k_gen_chain_rows(ChainNet net, const floa
 // workgroup owns 64 lanes, its four waves share the policy forward of every step (chain_forward_tile), wave 0 keeps the
 // lanes: features, the actor's draw, the env step, the records.  The same observations, draws, actions and records as the
 // step-by-step launch sequence (tests/test_gpu_general_mlp.py replays them through the oracle's lanes bit for bit).
+// (sixteen waves per workgroup: the launch is T x the latency of one step, and a step's latency is the number of
+// weight blocks a wave walks through — one pass per layer at sixteen waves, four at four: 2.2 -> ? ms at 16,384 lanes)
+constexpr int ROLL_WAVES = 16;
 template <int D>
-__global__ void __launch_bounds__(256) k_gen_rollout_cartpole(CartPoleDev c, EnvStateDev st, TrajDev tr, ChainNet net,
-                                                              uint64_t t_global) {
+__global__ void __launch_bounds__(ROLL_WAVES * 64) k_gen_rollout_cartpole(CartPoleDev c, EnvStateDev st, TrajDev tr,
+                                                                          ChainNet net, uint64_t t_global) {
   extern __shared__ float chain_lds[];  // [2][wmax][GT], then the actor words [16][GT]
   const int s = threadIdx.x & (GT - 1);
   const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -544,7 +547,7 @@ __global__ void __launch_bounds__(256) k_gen_rollout_cartpole(CartPoleDev c, Env
       }
     }
     __syncthreads();
-    const float *z = chain_forward_tile(net, t0, t1, s, g);  // (ends with a barrier)
+    const float *z = chain_forward_tile(net, t0, t1, s, g, ROLL_WAVES);  // (ends with a barrier)
     if (keeper) {
       const float u = rl_u32_to_unit_f32(actor_words[(uint32_t)((t_global + t) & 15) * GT + s]);
       const float zz[2] = {z[s], z[GT + s]};
@@ -878,11 +881,11 @@ void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t) {
     const size_t lds = ((size_t)2 * net.wmax * GT + 16 * GT) * sizeof(float);
     if (env->D == 5) {
       chain_lds_attr(e, reinterpret_cast<const void *>(&k_gen_rollout_cartpole<5>), lds);
-      hipLaunchKernelGGL(k_gen_rollout_cartpole<5>, dim3(cdiv_g(n, GT)), dim3(256), lds, e->stream, env->dev, env->st, t->d,
+      hipLaunchKernelGGL(k_gen_rollout_cartpole<5>, dim3(cdiv_g(n, GT)), dim3(ROLL_WAVES * 64), lds, e->stream, env->dev, env->st, t->d,
                          net, env->t_global);
     } else {
       chain_lds_attr(e, reinterpret_cast<const void *>(&k_gen_rollout_cartpole<4>), lds);
-      hipLaunchKernelGGL(k_gen_rollout_cartpole<4>, dim3(cdiv_g(n, GT)), dim3(256), lds, e->stream, env->dev, env->st, t->d,
+      hipLaunchKernelGGL(k_gen_rollout_cartpole<4>, dim3(cdiv_g(n, GT)), dim3(ROLL_WAVES * 64), lds, e->stream, env->dev, env->st, t->d,
                          net, env->t_global);
     }
     RL_HIP_CHECK(hipGetLastError());
