@@ -818,43 +818,66 @@ __global__ void __launch_bounds__(64) k_seq_gae(TrajDev tr, const float *__restr
   const float disc = lambda * gamma;
   float adv_next = 0.0f, rtg_next = 0.0f, v_next = 0.0f;
   tr.values[(size_t)T * n + i] = succ[(size_t)(T - 1) * n + i];
-  for (uint32_t t = T; t-- > 0;) {
-    const size_t o = (size_t)t * n + i;
-    const uint8_t f = tr.flag[o];
-    const float r = tr.reward[o], v = values[o];
-    float vn;
-    bool ends;
-    if (f == RL_SUCC_TERMINATE) {
-      vn = 0.0f;
-      ends = true;
-    } else if (f == RL_SUCC_INTERRUPT || t == T - 1) {
-      vn = succ[o];
-      ends = true;
-    } else {
-      vn = v_next;
-      ends = false;
+  // the inputs of 16 steps are requested before the chain walks through them (k_gae_scan, kernels_rollout.hip: one
+  // memory round trip per 16 steps instead of one per step)
+  constexpr int AHEAD = 16;
+  const uint8_t *__restrict__ flag_in = tr.flag;
+  const float *__restrict__ reward_in = tr.reward;
+  for (uint32_t hi = T; hi > 0;) {
+    uint8_t fb[AHEAD];
+    float rb[AHEAD], vb[AHEAD], sb[AHEAD];
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) {
+      const size_t o = (size_t)(hi > (uint32_t)u ? hi - 1 - (uint32_t)u : 0u) * n + i;
+      fb[u] = flag_in[o];
+      rb[u] = reward_in[o];
+      vb[u] = values[o];
+      sb[u] = succ[o];
     }
-    const float dn = gamma * vn;
-    const float tmp = r + dn;
-    const float delta = tmp - v;
-    float a, g;
-    if (ends) {
-      a = delta;
-      g = r;
-    } else {
-      const float pa = adv_next * disc;
-      a = delta + pa;
-      const float pg = rtg_next * gamma;
-      g = r + pg;
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) {
+      if (hi > (uint32_t)u) {
+        const uint32_t t = hi - 1 - (uint32_t)u;
+        const size_t o = (size_t)t * n + i;
+        const uint8_t f = fb[u];
+        const float r = rb[u], v = vb[u];
+        float vn;
+        bool ends;
+        if (f == RL_SUCC_TERMINATE) {
+          vn = 0.0f;
+          ends = true;
+        } else if (f == RL_SUCC_INTERRUPT || t == T - 1) {
+          vn = sb[u];
+          ends = true;
+        } else {
+          vn = v_next;
+          ends = false;
+        }
+        const float dn = gamma * vn;
+        const float tmp = r + dn;
+        const float delta = tmp - v;
+        float a, g;
+        if (ends) {
+          a = delta;
+          g = r;
+        } else {
+          const float pa = adv_next * disc;
+          a = delta + pa;
+          const float pg = rtg_next * gamma;
+          g = r + pg;
+        }
+        tr.adv[o] = a;
+        tr.rtg[o] = g;
+        tr.values[o] = v;
+        adv_next = a;
+        rtg_next = g;
+        v_next = v;
+      }
     }
-    tr.adv[o] = a;
-    tr.rtg[o] = g;
-    tr.values[o] = v;
-    adv_next = a;
-    rtg_next = g;
-    v_next = v;
+    hi = hi > (uint32_t)AHEAD ? hi - AHEAD : 0u;
   }
 }
+
 
 // one_step_values (critics/mod.rs:139-150) with a recurrent critic: next values from the teacher-forced forward
 // (values [T][n]; succ [T][n] where an episode is cut), same selection rule as k_seq_gae; also mirrors the values
