@@ -4,8 +4,8 @@
 // the same passes as one launch per layer over [unit][sample] planes: 178 ms for a TRPO + critic period of two 64-unit
 // layers at 16,384 lanes, against 3 ms for the fused single-hidden-layer kernels.)
 //
-// Shapes: 1..3 hidden layers of at most 64 units (two 32-unit tiles; narrower layers are zero-padded), at most 7
-// inputs, at most 2 outputs.  Every matrix product is an exact-piece product: both factors are split into three bf16
+// Shapes: 1..3 hidden layers of at most 64 units (two 32-unit tiles; narrower layers are zero-padded) or one hidden layer
+// of at most 128 (four tiles: the same 144 accumulator registers), at most 7 inputs, at most 2 outputs.  Every matrix product is an exact-piece product: both factors are split into three bf16
 // pieces and the six piece pairs that matter are multiplied on v_mfma_f32_32x32x16_bf16 with f32 accumulation
 // (bf16_tile.hpp) — the weights by rounding (|p1| <= 2^-9 |w|, |p2| <= 2^-18 |w|), activations by truncation, deltas by
 // rounding, so the dropped pairs stay below 2^-24 of the product.
@@ -40,7 +40,6 @@ namespace {
 using bt::f32x16;
 using bt::Frag;
 
-constexpr int GW = 2;          // 32-unit tiles per hidden layer
 constexpr int GWAVES = 4;      // waves per workgroup (one per SIMD, 512 registers each)
 constexpr int GM_FLUSH = 64;   // f32 -> f64 flush period in tiles
 constexpr int GM_MAX_IN = 7, GM_MAX_HIDDEN = 3;
@@ -55,16 +54,17 @@ struct GmArgs {
 
 // fragment groups of the LDS weight image (three piece fragments each): forward layer 0 [ot], forward hidden layer l
 // [ot][ks], forward output [ks], backward hidden layer l [it][ks], backward output [it]
-constexpr int gm_fh(int l) { return GW + (l - 1) * 2 * GW * GW; }
-constexpr int gm_fo(int NL) { return GW + (NL - 1) * 2 * GW * GW; }
-constexpr int gm_bh(int NL, int l) { return gm_fo(NL) + 2 * GW + (l - 1) * 2 * GW * GW; }
-constexpr int gm_bo(int NL) { return gm_bh(NL, NL); }
-constexpr int gm_groups(int NL) { return gm_bo(NL) + GW; }
+// (GW = 32-unit tiles per hidden layer: 2 for up to three layers of at most 64 units, 4 for one layer of at most 128)
+constexpr int gm_fh(int GW, int l) { return GW + (l - 1) * 2 * GW * GW; }
+constexpr int gm_fo(int GW, int NL) { return GW + (NL - 1) * 2 * GW * GW; }
+constexpr int gm_bh(int GW, int NL, int l) { return gm_fo(GW, NL) + 2 * GW + (l - 1) * 2 * GW * GW; }
+constexpr int gm_bo(int GW, int NL) { return gm_bh(GW, NL, NL); }
+constexpr int gm_groups(int GW, int NL) { return gm_bo(GW, NL) + GW; }
 // PASS_JVP: the forward fragments of the tangent parameters follow, in the same order (layer 0, hidden, output)
-constexpr int gm_fwd_groups(int NL) { return gm_fo(NL) + 2 * GW; }
-constexpr int gm_all_groups(int NL, bool jvp) { return gm_groups(NL) + (jvp ? gm_fwd_groups(NL) : 0); }
-constexpr size_t gm_lds_bytes(int NL, bool jvp) {
-  return (size_t)gm_all_groups(NL, jvp) * 3 * 64 * 16 + (size_t)NL * 64 * 4 * (jvp ? 2 : 1);
+constexpr int gm_fwd_groups(int GW, int NL) { return gm_fo(GW, NL) + 2 * GW; }
+constexpr int gm_all_groups(int GW, int NL, bool jvp) { return gm_groups(GW, NL) + (jvp ? gm_fwd_groups(GW, NL) : 0); }
+constexpr size_t gm_lds_bytes(int GW, int NL, bool jvp) {
+  return (size_t)gm_all_groups(GW, NL, jvp) * 3 * 64 * 16 + (size_t)NL * 32 * GW * 4 * (jvp ? 2 : 1);
 }
 
 __device__ __forceinline__ constexpr int urow(int r, int kb) { return (r & 3) + 8 * (r >> 2) + 4 * kb; }
@@ -181,16 +181,16 @@ __device__ __forceinline__ f32x16 bias_tile(f32x16 acc, const Frag (&dt)[2][3], 
 
 constexpr int GM_CRITIC = 100;  // mean((V - target)^2); the policy modes are PASS_INIT / PASS_PPO / PASS_EVAL (kernels.hpp)
 
-template <int MODE, int NL>
+template <int MODE, int NL, int GW>
 __global__ void __launch_bounds__(GWAVES * 64)
     k_gen_mfma(TrajDev tr, GmArgs g, float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB,
                float inv_B, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   extern __shared__ uint4 gm_lds[];
   uint4(*img)[64] = reinterpret_cast<uint4(*)[64]>(gm_lds);
   constexpr bool JVP = MODE == PASS_JVP;
-  constexpr int TG = gm_groups(NL);  // first fragment group of the tangent parameters (JVP)
-  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_all_groups(NL, JVP) * 3 * 64);  // [NL][64]: layers 1 .. NL
-  float *tbias = bias + NL * 64;                                                               // (JVP) of the tangent
+  constexpr int TG = gm_groups(GW, NL);  // first fragment group of the tangent parameters (JVP)
+  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_all_groups(GW, NL, JVP) * 3 * 64);  // [NL][32 GW]: layers 1 .. NL
+  float *tbias = bias + NL * 32 * GW;                                                               // (JVP) of the tangent
   constexpr bool BWD = MODE != PASS_EVAL;
   if (skip != nullptr && *skip != 0) return;
 #ifdef GM_FIXED_RELU
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
           const int j = dir == 0 ? own : across, k = dir == 0 ? across : own;
           v[e] = (j < N && k < K) ? W[j * K + k] : 0.0f;
         }
-        put_group(g0 + (dir == 0 ? gm_fh(l) : gm_bh(NL, l)) + r2, ln, v);
+        put_group(g0 + (dir == 0 ? gm_fh(GW, l) : gm_bh(GW, NL, l)) + r2, ln, v);
       }
     }
     {  // output layer: forward [ks], backward [it]
@@ -264,13 +264,13 @@ __global__ void __launch_bounds__(GWAVES * 64)
           }
           v[e] = (j < g.out_dim && k < K) ? W[j * K + k] : 0.0f;
         }
-        put_group(g0 + (q < 2 * GW ? gm_fo(NL) + q : gm_bo(NL) + (q - 2 * GW)), ln, v);
+        put_group(g0 + (q < 2 * GW ? gm_fo(GW, NL) + q : gm_bo(GW, NL) + (q - 2 * GW)), ln, v);
       }
     }
 #pragma unroll
     for (int l = 1; l <= NL; ++l) {
       const int N = Nof(l), K = Kof(l);
-      for (int u = threadIdx.x; u < 64; u += GWAVES * 64) bias_out[(l - 1) * 64 + u] = u < N ? src[g.off[l] + N * K + u] : 0.0f;
+      for (int u = threadIdx.x; u < 32 * GW; u += GWAVES * 64) bias_out[(l - 1) * 32 * GW + u] = u < N ? src[g.off[l] + N * K + u] : 0.0f;
     }
   };
   build(g.params, 0, true, bias);
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
     auto bias_rows = [&](const float *table, int l, int ot) {  // accumulator initialised with the bias of its row's unit
       f32x16 c;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = table[(l - 1) * 64 + ot * 32 + urow(r, kb)];
+      for (int r = 0; r < 16; ++r) c[r] = table[(l - 1) * 32 * GW + ot * 32 + urow(r, kb)];
       return c;
     };
 #pragma unroll
@@ -442,15 +442,15 @@ __global__ void __launch_bounds__(GWAVES * 64)
       for (int ot = 0; ot < GW; ++ot) {
         f32x16 c = bias_rows(bias, l, ot);
 #pragma unroll
-        for (int ks = 0; ks < 2 * GW; ++ks) c = prod6_lds(c, img, gm_fh(l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
+        for (int ks = 0; ks < 2 * GW; ++ks) c = prod6_lds(c, img, gm_fh(GW, l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
         gm_act_tile(g.act, c);
         a[l][ot] = c;
         if (JVP) {
           f32x16 tc = bias_rows(tbias, l, ot);
 #pragma unroll
           for (int ks = 0; ks < 2 * GW; ++ks) {
-            tc = prod6_lds(tc, img, gm_fh(l) + ot * 2 * GW + ks, lane, tb[JVP ? ks >> 1 : 0][ks & 1]);
-            tc = prod6_lds(tc, img, TG + gm_fh(l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
+            tc = prod6_lds(tc, img, gm_fh(GW, l) + ot * 2 * GW + ks, lane, tb[JVP ? ks >> 1 : 0][ks & 1]);
+            tc = prod6_lds(tc, img, TG + gm_fh(GW, l) + ot * 2 * GW + ks, lane, ab[ks >> 1][ks & 1]);
           }
           gm_slope_tile(g.act, tc, c);
           ta[ot] = tc;  // (the pieces of the previous layer's tangent are in tb already)
@@ -465,15 +465,15 @@ __global__ void __launch_bounds__(GWAVES * 64)
 #pragma unroll
         for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1][it], q, ab[it][q]);
 #pragma unroll
-      for (int ks = 0; ks < 2 * GW; ++ks) zt = prod6_lds(zt, img, gm_fo(NL) + ks, lane, ab[ks >> 1][ks & 1]);
+      for (int ks = 0; ks < 2 * GW; ++ks) zt = prod6_lds(zt, img, gm_fo(GW, NL) + ks, lane, ab[ks >> 1][ks & 1]);
       if (JVP) {
         tzt = bias_rows(tbias, NL, 0);
 #pragma unroll
         for (int ks = 0; ks < 2 * GW; ++ks) {
           Frag tb[3];
           pieces_trunc(ta[ks >> 1], ks & 1, tb);
-          tzt = prod6_lds(tzt, img, gm_fo(NL) + ks, lane, tb);
-          tzt = prod6_lds(tzt, img, TG + gm_fo(NL) + ks, lane, ab[ks >> 1][ks & 1]);
+          tzt = prod6_lds(tzt, img, gm_fo(GW, NL) + ks, lane, tb);
+          tzt = prod6_lds(tzt, img, TG + gm_fo(GW, NL) + ks, lane, ab[ks >> 1][ks & 1]);
         }
       }
     }
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
         for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1][it], q, ab[q]);
         transpose_pieces<2>(ab, idb, aT[it]);
         dWo[it] = wgrad_tile(dWo[it], dT[0], aT[it]);
-        f32x16 c = prod6_lds(zero16, img, gm_bo(NL) + it, lane, dob[0]);
+        f32x16 c = prod6_lds(zero16, img, gm_bo(GW, NL) + it, lane, dob[0]);
         gm_slope_tile(g.act, c, a[NL - 1][it]);
         dl[it] = c;
       }
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(GWAVES * 64)
           f32x16 c = zero16;
 #pragma unroll
           for (int ks = 0; ks < 2 * GW; ++ks)
-            c = prod6_lds(c, img, gm_bh(NL, l) + it * 2 * GW + ks, lane, db[ks >> 1][ks & 1]);
+            c = prod6_lds(c, img, gm_bh(GW, NL, l) + it * 2 * GW + ks, lane, db[ks >> 1][ks & 1]);
           gm_slope_tile(g.act, c, a[l - 1][it]);
           dn[it] = c;
         }
@@ -662,29 +662,40 @@ __global__ void __launch_bounds__(GWAVES * 64)
   }
 }
 
-template <int MODE, int NL>
+template <int MODE, int NL, int GW>
 void gm_launch(rl_traj *t, const GmArgs &g, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
                float clip_hi) {
-  const size_t lds = gm_lds_bytes(NL, MODE == PASS_JVP);
+  const size_t lds = gm_lds_bytes(GW, NL, MODE == PASS_JVP);
   {
     static std::mutex mu;
     static std::set<int> raised;
     std::lock_guard<std::mutex> lock(mu);
     if (raised.insert(t->eng->device).second)
-      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_mfma<MODE, NL>),
+      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_mfma<MODE, NL, GW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL((k_gen_mfma<MODE, NL>), dim3(nwg), dim3(GWAVES * 64), lds, t->eng->stream, t->d, g, t->lp0, t->slabA,
-                     t->slabB, inv_B, d_skip, clip_lo, clip_hi);
+  hipLaunchKernelGGL((k_gen_mfma<MODE, NL, GW>), dim3(nwg), dim3(GWAVES * 64), lds, t->eng->stream, t->d, g, t->lp0,
+                     t->slabA, t->slabB, inv_B, d_skip, clip_lo, clip_hi);
   RL_HIP_CHECK(hipGetLastError());
 }
 
+// gw = 4: one hidden layer of up to 128 units; gw = 2: up to three of up to 64
 template <int MODE>
-void gm_launch_nl(rl_traj *t, const GmArgs &g, int NL, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
-                  float clip_hi) {
-  if (NL == 1) gm_launch<MODE, 1>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
-  else if (NL == 2) gm_launch<MODE, 2>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
-  else gm_launch<MODE, 3>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+void gm_launch_nl(rl_traj *t, const GmArgs &g, int NL, int gw, uint32_t nwg, float inv_B, const int32_t *d_skip,
+                  float clip_lo, float clip_hi) {
+  if (gw == 4) gm_launch<MODE, 1, 4>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (NL == 1) gm_launch<MODE, 1, 2>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (NL == 2) gm_launch<MODE, 2, 2>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else gm_launch<MODE, 3, 2>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+}
+
+// tiles per hidden layer of the instantiation that takes the module, 0 if none does
+int gm_width_tiles(const rl_mlp *m) {
+  uint32_t wmax = 0;
+  for (uint32_t l = 0; l < m->n_hidden; ++l) wmax = m->widths[l] > wmax ? m->widths[l] : wmax;
+  if (wmax <= 64) return 2;
+  if (wmax <= 128 && m->n_hidden == 1) return 4;
+  return 0;
 }
 
 }  // namespace
@@ -693,8 +704,7 @@ void gm_launch_nl(rl_traj *t, const GmArgs &g, int NL, uint32_t nwg, float inv_B
 bool gen_mfma_fits(const rl_traj *t, const rl_mlp *m) {
   if (!m->general || m->n_hidden < 1 || m->n_hidden > (uint32_t)GM_MAX_HIDDEN) return false;
   if (m->in_dim > (uint32_t)GM_MAX_IN || m->out_dim > 2 || m->in_dim != t->d.D) return false;
-  for (uint32_t l = 0; l < m->n_hidden; ++l)
-    if (m->widths[l] > 32u * GW) return false;
+  if (gm_width_tiles(m) == 0) return false;
   if ((uint64_t)(t->d.T + 1) * t->d.n * m->in_dim >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
   return true;
 }
@@ -706,7 +716,7 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
   if (!gen_mfma_fits(t, m)) return false;
   if (mode != RL_GEN_CRITIC && mode != PASS_INIT && mode != PASS_PPO && mode != PASS_EVAL && mode != PASS_JVP) return false;
   // the tangent's forward fragments next to the parameters': 114 KB of LDS for two hidden layers, too much for three
-  if (mode == PASS_JVP && (d_tangent == nullptr || gm_lds_bytes((int)m->n_hidden, true) > 160 * 1024)) return false;
+  if (mode == PASS_JVP && (d_tangent == nullptr || gm_lds_bytes(gm_width_tiles(m), (int)m->n_hidden, true) > 160 * 1024)) return false;
   if (mode != RL_GEN_CRITIC && m->out_dim != 2) return false;
   if (mode == RL_GEN_CRITIC && m->out_dim != 1) return false;
   GmArgs g{};
@@ -726,11 +736,11 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
   gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
   traj_ensure_slabs(t, t->last_rows, m->P, t->last_rows);
   const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
-  const int NL = (int)m->n_hidden;
-  if (mode == RL_GEN_CRITIC) gm_launch_nl<GM_CRITIC>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
-  else if (mode == PASS_INIT) gm_launch_nl<PASS_INIT>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
-  else if (mode == PASS_PPO) gm_launch_nl<PASS_PPO>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
-  else if (mode == PASS_JVP) gm_launch_nl<PASS_JVP>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
-  else gm_launch_nl<PASS_EVAL>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  const int NL = (int)m->n_hidden, gw = gm_width_tiles(m);
+  if (mode == RL_GEN_CRITIC) gm_launch_nl<GM_CRITIC>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (mode == PASS_INIT) gm_launch_nl<PASS_INIT>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (mode == PASS_PPO) gm_launch_nl<PASS_PPO>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (mode == PASS_JVP) gm_launch_nl<PASS_JVP>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else gm_launch_nl<PASS_EVAL>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   return true;
 }

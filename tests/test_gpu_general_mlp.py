@@ -290,10 +290,12 @@ def test_gradients_and_fisher_vector_products(engine, hidden, act, out_act):
 
 @pytest.mark.parametrize("hidden,act,out_act,n,T", [
     ([64, 64], "Relu", "Identity", 3, 5), ([64, 64], "Tanh", "Identity", 700, 9), ([33], "Relu", "Identity", 65, 7),
-    ([32, 16, 8], "Sigmoid", "Tanh", 130, 20), ([17, 64], "Relu", "Sigmoid", 96, 12), ([64, 1, 64], "Tanh", "Identity", 50, 3)])
+    ([32, 16, 8], "Sigmoid", "Tanh", 130, 20), ([17, 64], "Relu", "Sigmoid", 96, 12), ([64, 1, 64], "Tanh", "Identity", 50, 3),
+    ([100], "Tanh", "Identity", 70, 9), ([128], "Sigmoid", "Tanh", 33, 4)])
 def test_fused_matrix_passes_agree_with_the_layer_kernels(engine, hidden, act, out_act, n, T):
     """Shapes the fused matrix-pipe launch takes (kernels_gen_mfma.hip: 1-3 hidden layers of at most 64 units) against
-    the per-layer f32 kernels (kernel variant 1) on the same trajectory: two implementations that share no code beyond
+    the per-layer f32 kernels (kernel variant 1; one hidden layer of up to 128 units with other activations than the
+    fused module's included) on the same trajectory: two implementations that share no code beyond
     the activation definitions.  Sample counts below one tile, ragged last tiles, fewer tiles than waves; every pass:
     gradient, loss / KL, Fisher-vector product, PPO steps, critic gradient and critic steps."""
     pol, cri = make(engine, 5, hidden, 2, 41, act, out_act), make(engine, 5, hidden, 1, 42, act, out_act)
