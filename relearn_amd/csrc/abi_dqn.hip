@@ -70,16 +70,18 @@ static void dqn_own_arrays(rl_dqn *q) {
   q->mb->d.obs = q->own_obs;
   q->mb->d.adv = q->own_target;
   q->mb->d.action = q->own_action;
+  q->mb->d.flag = q->own_flag;
+  q->td_in_kernel = false;
 }
 
 // every device allocation of a DQN handle (also the clean-up of a failed rl_dqn_create)
 static void dqn_release_device(rl_dqn *q) {
   replay_free(q->rp);
   void *ptrs[] = {q->d_agent_pos, q->d_ep_lane, q->d_ep_start, q->d_ep_len, q->d_ep_off, q->d_counts, q->d_flags,
-                  q->all_obs,     q->all_target, q->all_action};
+                  q->all_obs,     q->all_target, q->all_action, q->all_flag};
   for (void *p : ptrs) dfree(p);
   q->all_obs = q->all_target = nullptr;
-  q->all_action = nullptr;
+  q->all_action = q->all_flag = nullptr;
   if (q->draw_stream) {
     (void)hipStreamSynchronize(q->draw_stream);
     (void)hipStreamDestroy(q->draw_stream);
@@ -160,6 +162,7 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     q->own_obs = q->mb->d.obs;
     q->own_target = q->mb->d.adv;
     q->own_action = q->mb->d.action;
+    q->own_flag = q->mb->d.flag;
     sync(e);
     } catch (...) {  // (unique_ptr frees the host struct only)
       dqn_release_device(q.get());
@@ -334,7 +337,8 @@ static void dqn_gradient(rl_dqn *q, rl_adam *step_opt = nullptr, int loss_slot =
   rl_traj *mb = q->mb;
   uint32_t P = (uint32_t)q->qnet->P;
   uint32_t rowsA, rowsB;
-  if (q->eng->kernel_variant == 0 && launch_dqn_step_bf16(mb, q->qnet, q->last_total_steps)) {
+  if (q->eng->kernel_variant == 0 &&
+      launch_dqn_step_bf16(mb, q->qnet, q->last_total_steps, q->td_in_kernel, q->cfg.discount_factor)) {
     rowsA = rowsB = mb->nbV2;
   } else {
     launch_policy_pass(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr);
@@ -363,12 +367,18 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
     // one launch each, and an optimisation step is a gradient launch and a reduction + Adam launch.  (One-step TD targets
     // use the current network: those minibatches are still built one step at a time.)
     const uint64_t D = q->rp.D, cap = q->max_steps_mb;
-    const bool all_at_once = K > 1 && q->cfg.target == RL_DQN_TARGET_REWARD_TO_GO && K * cap * (8 * D + 5) <= (8ull << 30);
+    // One-step TD targets use the current network: on the matrix-pipe kernel they are formed inside the gradient launch
+    // (a second forward over the successor observations, which the gather leaves in time slot 1 of the workspace); the
+    // other kernels still build those minibatches one step at a time.
+    const bool td = q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD;
+    const bool td_fused = td && e->kernel_variant == 0 && D == 5 && q->qnet->hidden == 128 && !q->qnet->general;
+    const bool all_at_once = K > 1 && (!td || td_fused) && K * cap * (8 * D + 6) <= (8ull << 30);
     if (all_at_once && !q->all_obs) {
       q->all_obs = dalloc<float>(K * D * 2 * cap);
       q->all_target = dalloc<float>(K * cap);
       q->all_action = dalloc<uint8_t>(K * cap);
     }
+    if (all_at_once && td && !q->all_flag) q->all_flag = dalloc<uint8_t>(K * cap);
     // The draws do not depend on the network either, but they are one sequential chain through the agent's Prng (12 us
     // per minibatch on one CU).  One rank: the chain runs on a second stream in chunks of 2, 4, 8, ... minibatches
     // while the main stream trains on the chunks already drawn — the draw is faster than the training, so only the first
@@ -428,7 +438,7 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
           launch_dqn_build_all(e, q->rp, size, widest, q->max_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o,
                                q->d_ep_off + o, q->d_counts + first, q->all_obs + first * D * 2 * cap,
                                (size_t)(D * 2 * cap), q->all_action + first * cap, q->all_target + first * cap,
-                               (size_t)cap, q->cfg.discount_factor);
+                               (size_t)cap, q->cfg.discount_factor, td ? q->all_flag + first * cap : (uint8_t *)nullptr);
         }
         for (uint64_t k = first; k < first + size; ++k) {
           if (all_at_once) {
@@ -442,6 +452,8 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
             mb->d.obs = q->all_obs + k * D * 2 * cap;
             mb->d.action = q->all_action + k * cap;
             mb->d.adv = q->all_target + k * cap;
+            if (td) mb->d.flag = q->all_flag + k * cap;
+            q->td_in_kernel = td;
           } else {
             dqn_build_minibatch(q, (uint32_t)k, counts[k], totals[k]);
           }
@@ -454,7 +466,10 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
       q->last_n_eps = q->last_n_steps = 0;  // no minibatch to read after a failed update
       throw;
     }
-    // (after an all-at-once update `mb` keeps looking at the last minibatch: rl_dqn_minibatch_read / _gradient work)
+    // (after an all-at-once update `mb` keeps looking at the last minibatch: rl_dqn_minibatch_read / _gradient work;
+    // with in-kernel TD targets the workspace holds rewards, not targets: the last minibatch is built once more by the
+    // one-at-a-time builder, with the targets of the parameters the update ends on)
+    if (all_at_once && td && K) dqn_build_minibatch(q, (uint32_t)(K - 1), counts[K - 1], totals[K - 1]);
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
     if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));

@@ -281,7 +281,9 @@ struct rl_dqn {
   rl_traj *mb = nullptr;             // minibatch workspace: T = 1, n = current minibatch size
   // reward-to-go updates: the compact samples of ALL minibatches of an update, built in one launch (first update)
   float *all_obs = nullptr, *all_target = nullptr;  // [K][D][2 * max_steps_mb], [K][max_steps_mb]
-  uint8_t *all_action = nullptr;                    // [K][max_steps_mb]
+  uint8_t *all_action = nullptr, *all_flag = nullptr;  // [K][max_steps_mb]; successor codes (one-step TD only)
+  bool td_in_kernel = false;  // the workspace holds rewards / successor codes / successor observations: the gradient
+                              // kernel forms the one-step TD targets itself
   // ... drawn on a second stream in growing chunks while the main stream already trains on the earlier ones
   hipStream_t draw_stream = nullptr;
   std::vector<hipEvent_t> draw_events;
@@ -289,7 +291,7 @@ struct rl_dqn {
   DqnCountsDev *h_counts = nullptr;  // pinned, [K]
   // ... `mb` then points into them (the last minibatch stays readable); its own arrays, for the one-at-a-time builder:
   float *own_obs = nullptr, *own_target = nullptr;
-  uint8_t *own_action = nullptr;
+  uint8_t *own_action = nullptr, *own_flag = nullptr;
   uint64_t global_steps = 0;         // as of the last update (dqn.rs:276)
   uint64_t steps_per_lane = 0;       // collected so far
   uint32_t last_n_eps = 0, last_n_steps = 0, last_batch_index = 0;

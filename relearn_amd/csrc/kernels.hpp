@@ -61,9 +61,9 @@ void launch_dqn_sample(rl_engine *eng, hipStream_t stream, const ReplayDev &rp, 
 void launch_dqn_build_all(rl_engine *eng, const ReplayDev &rp, uint32_t n_batches, uint32_t widest_eps, uint32_t max_eps,
                           const uint32_t *d_lane, const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                           const DqnCountsDev *d_counts, float *d_obs, size_t obs_stride, uint8_t *d_action,
-                          float *d_target, size_t step_stride, float gamma);
+                          float *d_target, size_t step_stride, float gamma, uint8_t *d_flag);
 void launch_replay_planes(rl_engine *eng, const ReplayDev &rp, int field, void *d_out);
-bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total);
+bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total, bool td_in_kernel, float gamma);
 void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,
                                 const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                                 float *d_obs, size_t out_plane, uint8_t *d_action, float *d_target, float gamma,

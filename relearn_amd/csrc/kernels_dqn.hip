@@ -223,7 +223,12 @@ __global__ void __launch_bounds__(BUILD_ALL_WAVES * 64)
     k_dqn_build_all(ReplayDev rp, const uint32_t *__restrict__ ep_lane, const uint32_t *__restrict__ ep_start,
                     const uint32_t *__restrict__ ep_len, const uint32_t *__restrict__ ep_offset, uint32_t max_eps,
                     const DqnCountsDev *__restrict__ counts, float *__restrict__ out_obs, size_t obs_stride,
-                    uint8_t *__restrict__ out_action, float *__restrict__ out_target, size_t step_stride, float gamma) {
+                    uint8_t *__restrict__ out_action, float *__restrict__ out_target, size_t step_stride, float gamma,
+                    uint8_t *__restrict__ out_flag) {
+  // out_flag != NULL: one-step TD — the targets are left to the gradient kernel (they use the current network): the
+  // reward goes where the target would, the successor code into out_flag, the successor observation (the next step's,
+  // or the stored one after an Interrupt / at the episode's last step) into time slot 1 of the observation planes
+  const bool td = out_flag != nullptr;
   const uint32_t b = blockIdx.y, lane = threadIdx.x & 63;
   const uint32_t e = blockIdx.x * BUILD_ALL_WAVES + (threadIdx.x >> 6);
   const uint32_t n_eps = counts[b].n_eps, n_steps = counts[b].n_steps;
@@ -259,7 +264,23 @@ __global__ void __launch_bounds__(BUILD_ALL_WAVES * 64)
 #pragma unroll
       for (int d = 0; d < D; ++d) obs_b[d * out_plane + off + i] = rec.x[d];
       act_b[off + i] = (uint8_t)(rec.af & 0xffu);
-      tgt_b[off + i] = out;
+      tgt_b[off + i] = td ? rew : out;
+      if (td) {
+        const uint32_t fl = rec.af >> 8;
+        out_flag[(size_t)b * step_stride + off + i] = (uint8_t)fl;
+        float nx[D];
+        if (fl == RL_SUCC_INTERRUPT || i + 1 == len) {
+          const ReplayNext *__restrict__ nrec = rp.next + (size_t)ln * rp.C + (start + i) % rp.C;
+#pragma unroll
+          for (int d = 0; d < D; ++d) nx[d] = nrec->x[d];
+        } else {
+          const ReplayRec r1 = rec_load(ring + (start + i + 1) % rp.C);
+#pragma unroll
+          for (int d = 0; d < D; ++d) nx[d] = r1.x[d];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) obs_b[d * out_plane + n_steps + off + i] = nx[d];
+      }
     }
     hi = lo;
   }
@@ -565,16 +586,16 @@ void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_
 void launch_dqn_build_all(rl_engine *eng, const ReplayDev &rp, uint32_t n_batches, uint32_t widest_eps, uint32_t max_eps,
                           const uint32_t *d_lane, const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                           const DqnCountsDev *d_counts, float *d_obs, size_t obs_stride, uint8_t *d_action,
-                          float *d_target, size_t step_stride, float gamma) {
+                          float *d_target, size_t step_stride, float gamma, uint8_t *d_flag) {
   ProfScope ps(eng, RL_K_VALUES);
   if (n_batches == 0 || widest_eps == 0) return;
   const dim3 grid(cdiv_d(widest_eps, BUILD_ALL_WAVES), n_batches), block(BUILD_ALL_WAVES * 64);
   if (rp.D == 5)
     hipLaunchKernelGGL(k_dqn_build_all<5>, grid, block, 0, eng->stream, rp, d_lane, d_start, d_len, d_off, max_eps,
-                       d_counts, d_obs, obs_stride, d_action, d_target, step_stride, gamma);
+                       d_counts, d_obs, obs_stride, d_action, d_target, step_stride, gamma, d_flag);
   else
     hipLaunchKernelGGL(k_dqn_build_all<4>, grid, block, 0, eng->stream, rp, d_lane, d_start, d_len, d_off, max_eps,
-                       d_counts, d_obs, obs_stride, d_action, d_target, step_stride, gamma);
+                       d_counts, d_obs, obs_stride, d_action, d_target, step_stride, gamma, d_flag);
   RL_HIP_CHECK(hipGetLastError());
 }
 
@@ -593,9 +614,13 @@ void launch_dqn_build_all(rl_engine *eng, const ReplayDev &rp, uint32_t n_batche
 constexpr int DQN_WAVES = 4;
 constexpr int DQN_FLUSH = 16;  // f32 -> f64 flush period in tiles
 
+// TD: the workspace holds rewards instead of targets (`adv`), successor codes (`flag`) and the successor observation in
+// time slot 1 of the T = 1 layout; the one-step TD target r + gamma max_a Q(s') (0 beyond a Terminate; critics/mod.rs:
+// 139-150, 203-229) comes from a second forward with the same parameters (torch's no_grad target of dqn.rs:299-311).
+template <bool TD>
 __global__ void __launch_bounds__(DQN_WAVES * 64)
     k_dqn_step_bf16(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
-                    double *__restrict__ slabB, float two_over_B, uint32_t P) {
+                    double *__restrict__ slabB, float two_over_B, uint32_t P, float gamma) {
   using bt::f32x16;
   using bt::Frag;
   constexpr int D = 5, H = 128, NT = bt::NT, A = 2;
@@ -654,7 +679,8 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   int since_flush = 0;
   struct TileOp {
     float xa, xb, xc, tgt;
-    int act;
+    float na, nb, nc;  // (TD) the successor observation
+    int act, succ;
     bool valid;
   };
   const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
@@ -671,6 +697,18 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
     o.xc = o.valid ? xc : 0.0f;
     o.tgt = o.valid ? tg : 0.0f;
     o.act = o.valid ? act : 0;
+    o.na = o.nb = o.nc = 0.0f;
+    o.succ = RL_SUCC_TERMINATE;
+    if (TD) {
+      const uint32_t s1 = B32 + sc;  // time slot 1
+      const float na = tr.obs[(uint32_t)(2 * hf) * plane32 + s1], nb = tr.obs[(uint32_t)(2 * hf + 1) * plane32 + s1];
+      const float nc = tr.obs[4u * plane32 + s1];
+      const int succ = (int)tr.flag[sc];
+      o.na = o.valid ? na : 0.0f;
+      o.nb = o.valid ? nb : 0.0f;
+      o.nc = o.valid ? nc : 0.0f;
+      o.succ = o.valid ? succ : RL_SUCC_TERMINATE;
+    }
     return o;
   };
   auto flush_all = [&]() {
@@ -685,47 +723,60 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   TileOp op = load_tile(wave_id);
   for (size_t g = wave_id; g < n_tiles; g += n_waves) {
     const TileOp next = load_tile(g + n_waves);
-    Frag fa[3];
-    bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
     Frag ga[NT][2];
-    float yp[A][16];
+    // both action values of one observation per sample lane; `masks`: keep relu' of this forward for the backward
+    auto forward = [&](float xa, float xb, float xc, bool masks, float (&qv)[A]) {
+      Frag fa[3];
+      bt::input_frags(xa, xb, xc, op.valid, hf, fa);
+      float yp[A][16];
 #pragma unroll
-    for (int a = 0; a < A; ++a)
+      for (int a = 0; a < A; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) yp[a][r] = 0.0f;
-    f32x16 c = bt::layer1(fa, fw[0]);
+        for (int r = 0; r < 16; ++r) yp[a][r] = 0.0f;
+      f32x16 c = bt::layer1(fa, fw[0]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 cn = c;
-      if (t + 1 < NT) cn = bt::layer1(fa, fw[t + 1]);
+      for (int t = 0; t < NT; ++t) {
+        f32x16 cn = c;
+        if (t + 1 < NT) cn = bt::layer1(fa, fw[t + 1]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float ab = __builtin_fabsf(c[r]);
-        yp[0][r] = __builtin_fmaf(ab, w2v[0][t], yp[0][r]);
-        yp[1][r] = __builtin_fmaf(ab, w2v[1][t], yp[1][r]);
+        for (int r = 0; r < 16; ++r) {
+          const float ab = __builtin_fabsf(c[r]);
+          yp[0][r] = __builtin_fmaf(ab, w2v[0][t], yp[0][r]);
+          yp[1][r] = __builtin_fmaf(ab, w2v[1][t], yp[1][r]);
+        }
+        if (masks) bt::mask_tile(c, ga[t]);
+        c = cn;
       }
-      bt::mask_tile(c, ga[t]);
-      c = cn;
+      // both outputs: transpose the 16 partial sums per lane through LDS (row = sample, column = source lane)
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ysh[wave][a][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[a][r];
+      bt::wave_lds_fence();
+#pragma unroll
+      for (int a = 0; a < A; ++a) {
+        float part = bt::row_sum16(&Ysh[wave][a][n][hf * 16]);
+        float lin = lv[a][0] * xa;
+        lin = __builtin_fmaf(lv[a][1], xb, lin);
+        lin = __builtin_fmaf(lv[a][2], hf == 0 ? xc : 1.0f, lin);
+        part = part + lin;
+        float p0, p1;
+        bt::both_halves(part, p0, p1);
+        qv[a] = 0.5f * (p0 + p1) + (a == 0 ? b20 : b21);
+      }
+      bt::wave_lds_fence();  // Ysh is rewritten by the next forward
+    };
+    float tgt = op.tgt;
+    if (TD) {
+      float qn[A];
+      forward(op.na, op.nb, op.nc, false, qn);
+      const float vnext = op.succ == RL_SUCC_TERMINATE ? 0.0f : (qn[1] > qn[0] ? qn[1] : qn[0]);  // amax(-1)
+      const float dn = gamma * vnext;
+      tgt = op.tgt + dn;  // (op.tgt holds the reward)
     }
-    // both outputs: transpose the 16 partial sums per lane through LDS (row = sample, column = source lane)
-#pragma unroll
-    for (int a = 0; a < A; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Ysh[wave][a][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[a][r];
-    bt::wave_lds_fence();
     float qv[A];
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      float part = bt::row_sum16(&Ysh[wave][a][n][hf * 16]);
-      float lin = lv[a][0] * op.xa;
-      lin = __builtin_fmaf(lv[a][1], op.xb, lin);
-      lin = __builtin_fmaf(lv[a][2], hf == 0 ? op.xc : 1.0f, lin);
-      part = part + lin;
-      float p0, p1;
-      bt::both_halves(part, p0, p1);
-      qv[a] = 0.5f * (p0 + p1) + (a == 0 ? b20 : b21);
-    }
-    const float d = (op.act == 0 ? qv[0] : qv[1]) - op.tgt;
+    forward(op.xa, op.xb, op.xc, true, qv);
+    const float d = (op.act == 0 ? qv[0] : qv[1]) - tgt;
     const float gq = op.valid ? d * two_over_B : 0.0f;
     const float g0 = op.act == 0 ? gq : 0.0f, g1 = op.act == 0 ? 0.0f : gq;
     if (hf == 0 && op.valid) {
@@ -738,7 +789,6 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
     bt::backward(ga, ub, dm[0]);
     bt::piece_frags_mfma(g1, op.xa, op.xb, op.xc, hf, selb, ub);
     bt::backward(ga, ub, dm[1]);
-    bt::wave_lds_fence();  // Ysh is rewritten by the next tile
     if (++since_flush == DQN_FLUSH) {
       since_flush = 0;
       flush_all();
@@ -793,7 +843,7 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
 }
 
 // returns false when the kernel is not built for this shape (the caller falls back to the f32 passes)
-bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total) {
+bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total, bool td_in_kernel, float gamma) {
   if (mb->d.D != 5 || qnet->hidden != 128 || qnet->out_dim != 2 || qnet->general) return false;
   if ((uint64_t)(mb->d.T + 1) * mb->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
   ProfScope ps(mb->eng, RL_K_POLICY_FUSED);
@@ -801,8 +851,12 @@ bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total) {
   uint64_t nb = (n_tiles + DQN_WAVES - 1) / DQN_WAVES;
   if (nb > cus) nb = cus;
   mb->nbV2 = (uint32_t)nb;  // slab rows of this launch (the slabs are sized for any grid up to 8 x CUs)
-  hipLaunchKernelGGL(k_dqn_step_bf16, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, mb->d,
-                     qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P);
+  if (td_in_kernel)
+    hipLaunchKernelGGL(k_dqn_step_bf16<true>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, mb->d,
+                       qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
+  else
+    hipLaunchKernelGGL(k_dqn_step_bf16<false>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, mb->d,
+                       qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
   RL_HIP_CHECK(hipGetLastError());
   return true;
 }

@@ -25,6 +25,8 @@ opt = ra.Adam(q)
 cfg = ra.dqn_config_default()
 cfg.buffer_capacity = 50_000_000 // N
 cfg.update_first, cfg.update_rest = 5_000_000, 100_000
+if os.environ.get("DQN_TD") == "1":  # one-step TD targets instead of the default reward-to-go
+    cfg.target = ra.DQN_TARGET_ONE_STEP_TD
 for i in range(8):
     cfg.agent_key[i] = 1000 + i
 dqn = ra.Dqn(env, q, opt, cfg)
@@ -33,7 +35,7 @@ eng.sync()
 eng.timer_begin()
 dqn.collect(first_T, want_stats=False)
 ms_first = eng.timer_end()
-out = {"lanes": N, "buffer_capacity_per_lane": int(cfg.buffer_capacity), "first_collect_steps": first_T * N,
+out = {"target": "one-step-td" if cfg.target == ra.DQN_TARGET_ONE_STEP_TD else "reward-to-go", "lanes": N, "buffer_capacity_per_lane": int(cfg.buffer_capacity), "first_collect_steps": first_T * N,
        "first_collect_ms": ms_first, "first_collect_steps_per_s": first_T * N / ms_first * 1e3}
 st = dqn.update()  # warm-up
 # device time of an update without the per-kernel profiling events
