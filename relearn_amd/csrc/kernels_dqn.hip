@@ -25,13 +25,6 @@ __device__ __forceinline__ void rec_store(ReplayRec *__restrict__ p, const Repla
   reinterpret_cast<uint4 *>(p)[1] = make_uint4(__float_as_uint(r.x[4]), __float_as_uint(r.reward), r.af, 0u);
 }
 
-struct DevEpEnds {
-  uint32_t *base;  // [E][N]
-  uint32_t N, lane;
-  __device__ uint32_t get(uint32_t i) const { return base[(size_t)i * N + lane]; }
-  __device__ void set(uint32_t i, uint32_t v) { base[(size_t)i * N + lane] = v; }
-};
-
 // Sequential per-lane actor generator: ChaCha8(seed_actor), stream = global lane id, word position `pos` kept in
 // HBM between launches (it is the `rng_actor: Prng` of Steps, src/simulation/steps.rs:15-28).  The current
 // 16-word block is parked in a lane-private LDS column.
@@ -64,7 +57,11 @@ struct LaneActorRng {
 // T env-actor steps per lane with the DQN actor:
 //   if rng.gen_bool(eps) { action_space.sample(rng) = gen_range(0..2) } else { argmax_a Q(obs)[a] }
 // every step is appended to the lane's replay ring.
-template <int D, int BLOCK>
+// G threads per lane (G consecutive lanes of a wave) share the greedy branch's Q-network forward, as in the fused TRPO
+// rollout (kernels_rollout.hip: a launch lasts T x the latency of one step, and most of a greedy step is the 128-unit
+// forward); everything else — draws, physics, ring bookkeeping — is repeated by every thread of the group, thread 0
+// stores.  The result does not depend on G (mlp_forward_group_lds).
+template <int D, int BLOCK, int G>
 __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, EnvStateDev st, ReplayDev rp,
                                                                 const float *__restrict__ qnet, int H, uint32_t T,
                                                                 uint64_t p_int, int always_explore,
@@ -74,14 +71,27 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
   const uint32_t n = rp.N;
   mlp_pack_lds<D>(pk, qnet, H, threadIdx.x, BLOCK);
   __syncthreads();
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
+  const uint32_t i0 = (blockIdx.x * BLOCK + threadIdx.x) / G;
+  const int g = threadIdx.x % G;
+  // lanes past the end follow lane n - 1 without storing: the group shuffles need every thread of a group
+  const bool live = i0 < n;
+  const uint32_t i = live ? i0 : n - 1;
+  const bool writer = live && g == 0;
   const uint64_t lane = c.lane_offset + i;
   LaneState s;
   lane_load(st, i, s);
   LaneRing ring{rp.head[i], rp.count[i], rp.ep_head[i], rp.ep_count[i], rp.total[i]};
-  DevEpEnds eps{rp.ep_end, n, i};
+  struct GroupEpEnds {  // every thread of the group reads the lane's episode table, thread 0 writes it
+    uint32_t *base;
+    uint32_t N, lane;
+    bool writer;
+    __device__ uint32_t get(uint32_t k) const { return base[(size_t)k * N + lane]; }
+    __device__ void set(uint32_t k, uint32_t v) {
+      if (writer) base[(size_t)k * N + lane] = v;
+    }
+  } eps{rp.ep_end, n, i, writer};
   LaneActorRng<BLOCK> rng{&words[threadIdx.x], c.key_actor, lane, rp.actor_pos[i], ~0ull};
+  bool full = false;
   for (uint32_t t = 0; t < T; ++t) {
     float f[D];
     cp_features<D>(c, s, f);
@@ -100,7 +110,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
       }
     } else {
       float z[2];
-      mlp_forward_lane_lds<D>(pk, H, f, z);
+      mlp_forward_group_lds<D, G>(pk, H, g, f, z);
       a = z[1] > z[0] ? 1 : 0;  // argmax: first maximal index
     }
     int succ = cp_step(c, s, a);
@@ -110,24 +120,30 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
     const int succ_rec = horizon_cut ? RL_SUCC_INTERRUPT : succ;
     const uint32_t slot_abs = ring_write_step(ring, rp.C, rp.E, eps, succ_rec != RL_SUCC_CONTINUE);
     if (slot_abs == 0xffffffffu) {
-      *rp.error = 1;  // WriteExperienceError::Full: a single episode longer than the lane's capacity
+      full = true;  // WriteExperienceError::Full: a single episode longer than the lane's capacity
       break;
     }
     const size_t o = (size_t)i * rp.C + slot_abs % rp.C;
-    ReplayRec rec;
+    if (writer) {
+      ReplayRec rec;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) rec.x[d] = d < D ? f[d < D ? d : 0] : 0.0f;
-    rec.reward = 1.0f;  // CartPole::step reward (cartpole.rs:140)
-    rec.af = (uint32_t)a | (uint32_t)succ_rec << 8;
-    rec_store(rp.rec + o, rec);
+      for (int d = 0; d < 5; ++d) rec.x[d] = d < D ? f[d < D ? d : 0] : 0.0f;
+      rec.reward = 1.0f;  // CartPole::step reward (cartpole.rs:140)
+      rec.af = (uint32_t)a | (uint32_t)succ_rec << 8;
+      rec_store(rp.rec + o, rec);
+    }
     if (succ_rec == RL_SUCC_INTERRUPT) {
       cp_features<D>(c, s, f);
+      if (writer) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) rp.next[o].x[d] = f[d];
+        for (int d = 0; d < D; ++d) rp.next[o].x[d] = f[d];
+      }
     }
-    flags_out[(size_t)t * n + i] = (uint8_t)succ_rec;
+    if (writer) flags_out[(size_t)t * n + i] = (uint8_t)succ_rec;
     if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, lane);
   }
+  if (!writer) return;
+  if (full) *rp.error = 1;
   rp.head[i] = ring.head;
   rp.count[i] = ring.count;
   rp.ep_head[i] = ring.ep_head;
@@ -554,17 +570,37 @@ void launch_dqn_sample(rl_engine *eng, hipStream_t stream, const ReplayDev &rp, 
 
 static inline uint32_t cdiv_d(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
+template <int G>
+static void launch_rollout_dqn_g(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
+                                 int always_explore, uint8_t *d_flags) {
+  constexpr int BLOCK = 64;
+  const uint32_t n = (uint32_t)env->cfg.n_lanes;
+  const dim3 grid(cdiv_d((size_t)n * G, BLOCK)), blk(BLOCK);
+  if (env->D == 5)
+    hipLaunchKernelGGL((k_rollout_cartpole_dqn<5, BLOCK, G>), grid, blk, 0, env->eng->stream, env->dev, env->st, rp,
+                       qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags);
+  else
+    hipLaunchKernelGGL((k_rollout_cartpole_dqn<4, BLOCK, G>), grid, blk, 0, env->eng->stream, env->dev, env->st, rp,
+                       qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags);
+}
+
 void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
                         int always_explore, uint8_t *d_flags) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
-  constexpr int BLOCK = 64;
-  uint32_t n = (uint32_t)env->cfg.n_lanes;
-  if (env->D == 5)
-    hipLaunchKernelGGL((k_rollout_cartpole_dqn<5, BLOCK>), dim3(cdiv_d(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream,
-                       env->dev, env->st, rp, qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags);
-  else
-    hipLaunchKernelGGL((k_rollout_cartpole_dqn<4, BLOCK>), dim3(cdiv_d(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream,
-                       env->dev, env->st, rp, qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags);
+  // threads per lane: as many as keep the launch within one wave per SIMD (launch_rollout, kernels_rollout.hip); a
+  // collection that always explores never runs the forward and keeps one thread per lane
+  const uint64_t simds = 4ull * (uint64_t)env->eng->prop.multiProcessorCount, n = env->cfg.n_lanes;
+  int G = 1;
+  while (!always_explore && G < 16 && n * (uint64_t)(2 * G) <= simds * 64) G *= 2;
+  if (env->eng->kernel_variant == 1) G = 1;
+  switch (G) {
+    case 16: launch_rollout_dqn_g<16>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
+    case 8: launch_rollout_dqn_g<8>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
+    case 4: launch_rollout_dqn_g<4>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
+    case 2: launch_rollout_dqn_g<2>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
+    default: launch_rollout_dqn_g<1>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
+  }
+  RL_HIP_CHECK(hipGetLastError());
 }
 
 void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,
