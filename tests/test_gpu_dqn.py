@@ -115,6 +115,23 @@ def test_buffer_full_is_an_error(engine):
     assert osim.collect(30, 0.0)[1]
 
 
+@pytest.mark.parametrize("td", [False, True], ids=["reward-to-go", "one-step-td"])
+def test_update_on_an_empty_store_fails_before_any_step(engine, td):
+    """sampling from lanes without a complete episode (Uniform::new(0, 0) panics in the reference) is reported by the
+    first chunk of the pipelined draws: no optimisation step has run, the parameters are untouched, and the agent works
+    normally afterwards"""
+    dqn, osim = make(engine, n=64, capacity=64, minibatch=300, opt_steps=5, td=td)
+    before = dqn.qnet.get_params()
+    with pytest.raises(ra.RelearnError) as e:
+        dqn.update()
+    assert e.value.code == ra.ERR_INVALID_ARGUMENT
+    assert np.array_equal(dqn.qnet.get_params(), before)
+    dqn.collect(40)
+    st = dqn.update()
+    assert st.opt_steps == 5 and np.isfinite(st.loss_last)
+    assert not np.array_equal(dqn.qnet.get_params(), before)
+
+
 def test_linear_schedule_and_collection_bound(engine):
     dqn, osim = make(engine, n=128, capacity=64, eps=("linear", 1.0, 0.1, 20000), minibatch=300, opt_steps=1)
     L = O.lib()
