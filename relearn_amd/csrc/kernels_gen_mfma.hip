@@ -179,6 +179,83 @@ __device__ __forceinline__ f32x16 bias_tile(f32x16 acc, const Frag (&dt)[2][3], 
   return acc;
 }
 
+// ---- the weight image: every fragment in the acc_row order of the tile it meets.  `src`: the parameters (forward and
+// backward fragments from group g0 = 0) or the tangent (forward fragments only, from group TG); every thread of the
+// workgroup (`nthreads`) calls it, the caller synchronises.
+template <int NL, int GW>
+__device__ __forceinline__ void gm_build_image(const GmArgs &g, const float *__restrict__ src, uint4 (*img)[64], int g0,
+                                               bool with_backward, float *bias_out, int nthreads) {
+  auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
+  auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
+  auto put_group = [&](int grp, int ln, const float (&v)[8]) {
+    uint32_t p[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bt::split3(v[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      img[grp * 3 + c][ln] = make_uint4(bt::pk(p[c][0], p[c][1]), bt::pk(p[c][2], p[c][3]), bt::pk(p[c][4], p[c][5]),
+                                        bt::pk(p[c][6], p[c][7]));
+  };
+  // forward, layer 0 [ot]: inputs 4 hh + e (e < 4), the bias as input `in_dim`
+  for (int idx = threadIdx.x; idx < GW * 64; idx += nthreads) {
+    const int ot = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+    const int unit = ot * 32 + mm, N = Nof(0);
+    const float *W = src + g.off[0];
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = bt::acc_row(0, hh, e);
+      v[e] = unit < N ? (k < g.in_dim ? W[unit * g.in_dim + k] : (k == g.in_dim ? W[N * g.in_dim + unit] : 0.0f)) : 0.0f;
+    }
+    put_group(g0 + ot, ln, v);
+  }
+  // forward [ot][ks] and backward [it][ks] through hidden layer l
+#pragma unroll
+  for (int l = 1; l < NL; ++l) {
+    const int K = Kof(l), N = Nof(l);
+    const float *W = src + g.off[l];
+    for (int idx = threadIdx.x; idx < (with_backward ? 2 : 1) * 2 * GW * GW * 64; idx += nthreads) {
+      const int dir = idx / (2 * GW * GW * 64), r2 = (idx >> 6) % (2 * GW * GW), ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+      const int tile = r2 / (2 * GW), ks = r2 % (2 * GW);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int across = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e), own = tile * 32 + mm;
+        // forward: row = own output unit, column = input `across`; backward (W^T): row = own input, column = output
+        const int j = dir == 0 ? own : across, k = dir == 0 ? across : own;
+        v[e] = (j < N && k < K) ? W[j * K + k] : 0.0f;
+      }
+      put_group(g0 + (dir == 0 ? gm_fh(GW, l) : gm_bh(GW, NL, l)) + r2, ln, v);
+    }
+  }
+  {  // output layer: forward [ks], backward [it]
+    const int K = Kof(NL);
+    const float *W = src + g.off[NL];
+    for (int idx = threadIdx.x; idx < (with_backward ? 3 : 2) * GW * 64; idx += nthreads) {
+      const int q = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int j, k;
+        if (q < 2 * GW) {
+          j = mm;
+          k = 32 * (q >> 1) + bt::acc_row(q & 1, hh, e);
+        } else {
+          j = bt::acc_row(0, hh, e);
+          k = (q - 2 * GW) * 32 + mm;
+        }
+        v[e] = (j < g.out_dim && k < K) ? W[j * K + k] : 0.0f;
+      }
+      put_group(g0 + (q < 2 * GW ? gm_fo(GW, NL) + q : gm_bo(GW, NL) + (q - 2 * GW)), ln, v);
+    }
+  }
+#pragma unroll
+  for (int l = 1; l <= NL; ++l) {
+    const int N = Nof(l), K = Kof(l);
+    for (int u = threadIdx.x; u < 32 * GW; u += nthreads) bias_out[(l - 1) * 32 * GW + u] = u < N ? src[g.off[l] + N * K + u] : 0.0f;
+  }
+}
+
 constexpr int GM_CRITIC = 100;  // mean((V - target)^2); the policy modes are PASS_INIT / PASS_PPO / PASS_EVAL (kernels.hpp)
 
 template <int MODE, int NL, int GW>
@@ -202,79 +279,8 @@ __global__ void __launch_bounds__(GWAVES * 64)
   auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
   auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
 
-  // ---- the weight image: every fragment in the acc_row order of the tile it meets
-  auto put_group = [&](int grp, int ln, const float (&v)[8]) {
-    uint32_t p[3][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bt::split3(v[e], p[0][e], p[1][e], p[2][e]);
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      img[grp * 3 + c][ln] = make_uint4(bt::pk(p[c][0], p[c][1]), bt::pk(p[c][2], p[c][3]), bt::pk(p[c][4], p[c][5]),
-                                        bt::pk(p[c][6], p[c][7]));
-  };
-  // `src`: the parameters (forward and backward fragments from group 0) or the tangent (forward fragments from group TG)
-  auto build = [&](const float *__restrict__ src, int g0, bool with_backward, float *bias_out) {
-    // forward, layer 0 [ot]: inputs 4 hh + e (e < 4), the bias as input `in_dim`
-    for (int idx = threadIdx.x; idx < GW * 64; idx += GWAVES * 64) {
-      const int ot = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
-      const int unit = ot * 32 + mm, N = Nof(0);
-      const float *W = src + g.off[0];
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = bt::acc_row(0, hh, e);
-        v[e] = unit < N ? (k < g.in_dim ? W[unit * g.in_dim + k] : (k == g.in_dim ? W[N * g.in_dim + unit] : 0.0f)) : 0.0f;
-      }
-      put_group(g0 + ot, ln, v);
-    }
-    // forward [ot][ks] and backward [it][ks] through hidden layer l
-#pragma unroll
-    for (int l = 1; l < NL; ++l) {
-      const int K = Kof(l), N = Nof(l);
-      const float *W = src + g.off[l];
-      for (int idx = threadIdx.x; idx < (with_backward ? 2 : 1) * 2 * GW * GW * 64; idx += GWAVES * 64) {
-        const int dir = idx / (2 * GW * GW * 64), r2 = (idx >> 6) % (2 * GW * GW), ln = idx & 63, mm = ln & 31, hh = ln >> 5;
-        const int tile = r2 / (2 * GW), ks = r2 % (2 * GW);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int across = 32 * (ks >> 1) + bt::acc_row(ks & 1, hh, e), own = tile * 32 + mm;
-          // forward: row = own output unit, column = input `across`; backward (W^T): row = own input, column = output
-          const int j = dir == 0 ? own : across, k = dir == 0 ? across : own;
-          v[e] = (j < N && k < K) ? W[j * K + k] : 0.0f;
-        }
-        put_group(g0 + (dir == 0 ? gm_fh(GW, l) : gm_bh(GW, NL, l)) + r2, ln, v);
-      }
-    }
-    {  // output layer: forward [ks], backward [it]
-      const int K = Kof(NL);
-      const float *W = src + g.off[NL];
-      for (int idx = threadIdx.x; idx < (with_backward ? 3 : 2) * GW * 64; idx += GWAVES * 64) {
-        const int q = idx >> 6, ln = idx & 63, mm = ln & 31, hh = ln >> 5;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          int j, k;
-          if (q < 2 * GW) {
-            j = mm;
-            k = 32 * (q >> 1) + bt::acc_row(q & 1, hh, e);
-          } else {
-            j = bt::acc_row(0, hh, e);
-            k = (q - 2 * GW) * 32 + mm;
-          }
-          v[e] = (j < g.out_dim && k < K) ? W[j * K + k] : 0.0f;
-        }
-        put_group(g0 + (q < 2 * GW ? gm_fo(GW, NL) + q : gm_bo(GW, NL) + (q - 2 * GW)), ln, v);
-      }
-    }
-#pragma unroll
-    for (int l = 1; l <= NL; ++l) {
-      const int N = Nof(l), K = Kof(l);
-      for (int u = threadIdx.x; u < 32 * GW; u += GWAVES * 64) bias_out[(l - 1) * 32 * GW + u] = u < N ? src[g.off[l] + N * K + u] : 0.0f;
-    }
-  };
-  build(g.params, 0, true, bias);
-  if (JVP) build(g.tangent, TG, false, tbias);
+  gm_build_image<NL, GW>(g, g.params, img, 0, true, bias, GWAVES * 64);
+  if (JVP) gm_build_image<NL, GW>(g, g.tangent, img, TG, false, tbias, GWAVES * 64);
   __syncthreads();
 
   Frag idb[2];
