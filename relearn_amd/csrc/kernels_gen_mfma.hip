@@ -258,6 +258,97 @@ __device__ __forceinline__ void gm_build_image(const GmArgs &g, const float *__r
 
 constexpr int GM_CRITIC = 100;  // mean((V - target)^2); the policy modes are PASS_INIT / PASS_PPO / PASS_EVAL (kernels.hpp)
 
+// one lane's view of a tile: its sample's inputs 4 kb .. 4 kb + 3 (bias input included) and per-sample scalars
+struct TileIn {
+  float x[4], tgt, adv, l0, l1;
+  int act;
+  bool valid;
+};
+
+// The per-sample loss terms from the module's two (pre-activation) outputs z0, z1 (JVP: and their tangents):
+// d0 / d1 = d loss / d (pre-activation of output 0 / 1) on `owner` lanes, the pass's scalar sums on lanes that `counts`
+// (the arithmetic of k_policy_bf16's per-sample section, kernels_mfma.hip; critic: mean((V - target)^2), inv_B = 2 / B).
+template <int MODE>
+__device__ __forceinline__ void gm_sample_terms(const GmArgs &g, float z0, float z1, float tz0, float tz1, const TileIn &op,
+                                                bool owner, bool counts, float inv_B, float clip_lo, float clip_hi,
+                                                float *__restrict__ lp0, uint32_t sidx, uint32_t B32, float (&sum32)[3],
+                                                float &d0, float &d1) {
+  constexpr bool JVP = MODE == PASS_JVP;
+  if (MODE == GM_CRITIC) {
+    const float v = gm_act(g.out_act, z0);
+    const float d = v - op.tgt;
+    if (owner) {
+      if (counts) sum32[0] = __builtin_fmaf(d, d, sum32[0]);
+      d0 = d * inv_B * gm_slope(g.out_act, v);  // inv_B = 2 / B here
+    }
+  } else if (JVP) {
+    // Fisher metric of the categorical head on the tangent outputs: dz_a = p_a (ty_a - sum_b p_b ty_b) / B; two
+    // actions: dz_0 = -dz_1 = p_0 p_1 (ty_0 - ty_1) / B
+    const float y0 = gm_act(g.out_act, z0), y1 = gm_act(g.out_act, z1);
+    const float s0 = gm_slope(g.out_act, y0), s1 = gm_slope(g.out_act, y1);
+    const SoftPair sp = soft_pair(y0 - y1);
+    const float gz = (sp.p[0] * sp.p[1]) * (tz0 * s0 - tz1 * s1) * inv_B;
+    if (owner) {
+      d0 = gz * s0;
+      d1 = -gz * s1;
+    }
+  } else {
+    const float y0 = gm_act(g.out_act, z0), y1 = gm_act(g.out_act, z1);
+    const SoftPair sp = soft_pair(y0 - y1);
+    const float adv = op.adv;
+    const int act = op.act;
+    const float lpa = act == 0 ? sp.lp[0] : sp.lp[1];
+    float g0 = 0.0f, g1 = 0.0f;  // d loss / d output
+    if (MODE == PASS_INIT) {
+      if (owner && counts) {
+        lp0[sidx] = sp.lp[0];
+        lp0[B32 + sidx] = sp.lp[1];
+      }
+      const float cc = -adv * inv_B;  // ratio = exp(lpa - lpa) = 1
+      g0 = cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]);
+      g1 = cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]);
+      const float cl0 = sp.lp[0] < -3.402823466e+38f ? -3.402823466e+38f : sp.lp[0];
+      const float cl1 = sp.lp[1] < -3.402823466e+38f ? -3.402823466e+38f : sp.lp[1];
+      float ent = cl0 * sp.p[0];
+      ent += cl1 * sp.p[1];
+      if (owner && counts) {
+        sum32[0] = sum32[0] + adv;  // ratio * adv
+        sum32[1] = sum32[1] - ent;
+        sum32[2] = __builtin_fmaf(lpa, adv, sum32[2]);
+      }
+    } else if (MODE == PASS_PPO) {
+      // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
+      const float l0a = act == 0 ? op.l0 : op.l1;
+      const float ratio = fast_expf(lpa - l0a);
+      const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
+      const float u1 = ratio * adv, u2 = clipped * adv;
+      const bool inside = ratio >= clip_lo && ratio <= clip_hi;
+      const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
+      const float cc = -(gr * ratio) * inv_B;
+      g0 = cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]);
+      g1 = cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]);
+      if (owner && counts) sum32[0] = sum32[0] + (u1 < u2 ? u1 : u2);
+    } else {  // PASS_EVAL: surrogate and KL(pi_0 || pi) of candidate parameters
+      const float l0a = act == 0 ? op.l0 : op.l1;
+      const float ratio = fast_expf(lpa - l0a);
+      float rel0 = op.l0 - sp.lp[0], rel1 = op.l1 - sp.lp[1];
+      if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
+      if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
+      const SoftPair old = soft_pair(op.l0 - op.l1);
+      float kl = rel0 * old.p[0];
+      kl += rel1 * old.p[1];
+      if (owner && counts) {
+        sum32[0] = __builtin_fmaf(ratio, adv, sum32[0]);
+        sum32[1] = sum32[1] + kl;
+      }
+    }
+    if (owner) {
+      d0 = g0 * gm_slope(g.out_act, y0);
+      d1 = g1 * gm_slope(g.out_act, y1);
+    }
+  }
+}
+
 template <int MODE, int NL, int GW>
 __global__ void __launch_bounds__(GWAVES * 64)
     k_gen_mfma(TrajDev tr, GmArgs g, float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB,
@@ -362,11 +453,6 @@ __global__ void __launch_bounds__(GWAVES * 64)
     first_flush = false;
   };
 
-  struct TileIn {
-    float x[4], tgt, adv, l0, l1;
-    int act;
-    bool valid;
-  };
   auto load_tile = [&](size_t t) {  // (branch-free: padding lanes read sample B - 1 and are zeroed)
     TileIn o;
     const uint32_t sidx = (uint32_t)t * 32u + (uint32_t)m;
@@ -484,82 +570,9 @@ __global__ void __launch_bounds__(GWAVES * 64)
       }
     }
     // ---- per-sample terms on the lanes of half 0 (rows 0 and 1 of the output tile are the module's outputs)
-    const bool owner = kb == 0 && op.valid;
     float d0 = 0.0f, d1 = 0.0f;  // d loss / d (pre-activation of output 0 / 1)
-    if (MODE == GM_CRITIC) {
-      const float v = gm_act(g.out_act, zt[0]);
-      const float d = v - op.tgt;
-      if (owner) {
-        sum32[0] = __builtin_fmaf(d, d, sum32[0]);
-        d0 = d * inv_B * gm_slope(g.out_act, v);  // inv_B = 2 / B here
-      }
-    } else if (JVP) {
-      // Fisher metric of the categorical head on the tangent outputs: dz_a = p_a (ty_a - sum_b p_b ty_b) / B; two
-      // actions: dz_0 = -dz_1 = p_0 p_1 (ty_0 - ty_1) / B
-      const float y0 = gm_act(g.out_act, zt[0]), y1 = gm_act(g.out_act, zt[1]);
-      const float s0 = gm_slope(g.out_act, y0), s1 = gm_slope(g.out_act, y1);
-      const SoftPair sp = soft_pair(y0 - y1);
-      const float gz = (sp.p[0] * sp.p[1]) * (tzt[0] * s0 - tzt[1] * s1) * inv_B;
-      if (owner) {
-        d0 = gz * s0;
-        d1 = -gz * s1;
-      }
-    } else {
-      const float y0 = gm_act(g.out_act, zt[0]), y1 = gm_act(g.out_act, zt[1]);
-      const SoftPair sp = soft_pair(y0 - y1);
-      const float adv = op.adv;
-      const int act = op.act;
-      const float lpa = act == 0 ? sp.lp[0] : sp.lp[1];
-      float g0 = 0.0f, g1 = 0.0f;  // d loss / d output
-      if (MODE == PASS_INIT) {
-        if (owner) {
-          const uint32_t sidx = (uint32_t)t * 32u + (uint32_t)m;
-          lp0[sidx] = sp.lp[0];
-          lp0[B32 + sidx] = sp.lp[1];
-        }
-        const float cc = -adv * inv_B;  // ratio = exp(lpa - lpa) = 1
-        g0 = cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]);
-        g1 = cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]);
-        const float cl0 = sp.lp[0] < -3.402823466e+38f ? -3.402823466e+38f : sp.lp[0];
-        const float cl1 = sp.lp[1] < -3.402823466e+38f ? -3.402823466e+38f : sp.lp[1];
-        float ent = cl0 * sp.p[0];
-        ent += cl1 * sp.p[1];
-        if (owner) {
-          sum32[0] = sum32[0] + adv;  // ratio * adv
-          sum32[1] = sum32[1] - ent;
-          sum32[2] = __builtin_fmaf(lpa, adv, sum32[2]);
-        }
-      } else if (MODE == PASS_PPO) {
-        // clipped surrogate (policies/ppo.rs:124-137); see k_policy_pass for the tie rules of minimum()/clamp()
-        const float l0a = act == 0 ? op.l0 : op.l1;
-        const float ratio = fast_expf(lpa - l0a);
-        const float clipped = ratio < clip_lo ? clip_lo : (ratio > clip_hi ? clip_hi : ratio);
-        const float u1 = ratio * adv, u2 = clipped * adv;
-        const bool inside = ratio >= clip_lo && ratio <= clip_hi;
-        const float gr = u1 < u2 ? adv : (u1 > u2 ? (inside ? adv : 0.0f) : (inside ? adv : 0.5f * adv));
-        const float cc = -(gr * ratio) * inv_B;
-        g0 = cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]);
-        g1 = cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]);
-        if (owner) sum32[0] = sum32[0] + (u1 < u2 ? u1 : u2);
-      } else {  // PASS_EVAL: surrogate and KL(pi_0 || pi) of candidate parameters
-        const float l0a = act == 0 ? op.l0 : op.l1;
-        const float ratio = fast_expf(lpa - l0a);
-        float rel0 = op.l0 - sp.lp[0], rel1 = op.l1 - sp.lp[1];
-        if (rel0 < -3.402823466e+38f) rel0 = -3.402823466e+38f;
-        if (rel1 < -3.402823466e+38f) rel1 = -3.402823466e+38f;
-        const SoftPair old = soft_pair(op.l0 - op.l1);
-        float kl = rel0 * old.p[0];
-        kl += rel1 * old.p[1];
-        if (owner) {
-          sum32[0] = __builtin_fmaf(ratio, adv, sum32[0]);
-          sum32[1] = sum32[1] + kl;
-        }
-      }
-      if (owner) {
-        d0 = g0 * gm_slope(g.out_act, y0);
-        d1 = g1 * gm_slope(g.out_act, y1);
-      }
-    }
+    gm_sample_terms<MODE>(g, zt[0], zt[1], tzt[0], tzt[1], op, kb == 0 && op.valid, true, inv_B, clip_lo, clip_hi, lp0,
+                          (uint32_t)t * 32u + (uint32_t)m, B32, sum32, d0, d1);
     if (BWD) {
       // ---- output layer: delta pieces (units 0 and 1 = elements 0 and 1 of half 0's k-step 0)
       Frag dob[1][3];
