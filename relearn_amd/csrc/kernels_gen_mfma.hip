@@ -681,6 +681,356 @@ __global__ void __launch_bounds__(GWAVES * 64)
   }
 }
 
+// ================================================================================================
+// The same passes with a tile shared by TWO waves (hidden layers of at most 64 units = two 32-unit tiles): wave h of a
+// pair owns unit tile h of every hidden layer — its activations, its deltas, the weight-gradient rows of its units — and
+// the two meet through LDS where a product needs the other half: the operand pieces of a_{l-1} (forward), of D_l
+// (backward chain) and of A_{l-1}^T (weight gradients), 6 KB each way, plus the two partial sums of the output layer.
+// A wave then carries 80 accumulator registers instead of 144 and ~230 in all: TWO waves per SIMD, each hiding the
+// other's dependency chains (the one-wave kernel above waits 42 % of its cycles).  Every pair of a workgroup walks the
+// same number of tiles (a pair without a tile runs on zeros): the exchanges are workgroup barriers.
+// One exchange region per wave: write, barrier, the partner reads; the next barrier in program order (there is always
+// one before the region's next write) guards the reuse.
+// ================================================================================================
+constexpr int GP_PAIRS = 4;
+
+template <int MODE, int NL, int PAIRS>
+__global__ void __launch_bounds__(PAIRS * 128)
+    k_gen_pair(TrajDev tr, GmArgs g, float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB,
+               float inv_B, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
+  constexpr int GW = 2;
+  constexpr bool JVP = MODE == PASS_JVP, BWD = MODE != PASS_EVAL;
+  static_assert(!JVP, "the pair kernel is built for the gradient and evaluation passes");
+  extern __shared__ uint4 gm_lds[];
+  uint4(*img)[64] = reinterpret_cast<uint4(*)[64]>(gm_lds);
+  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_groups(GW, NL) * 3 * 64);  // [NL][64]: layers 1 .. NL
+  uint4(*xch)[64] = reinterpret_cast<uint4(*)[64]>(bias + NL * 64);                      // [PAIRS][2][6][64]
+  float *zbuf = reinterpret_cast<float *>(xch + PAIRS * 2 * 6);                           // [PAIRS][2][2][32]
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, kb = lane >> 5, pair = wave >> 1, h = wave & 1;
+  auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
+  auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
+  gm_build_image<NL, GW>(g, g.params, img, 0, true, bias, PAIRS * 128);
+  __syncthreads();
+
+  Frag idb[2];
+  bt::ident_frags(lane, idb);
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // this wave's rows of the weight gradients: layer 0 (unit tile h x inputs + bias), hidden layer l (unit tile h x input
+  // tile it), the output layer's columns of input tile h, the bias columns of its tiles (wave 0: and the output layer's)
+  // (hidden layers: dWown = against this wave's own input tile h, dWoth = against the partner's tile 1 - h; two named
+  // arrays: an index that depends on h would put the accumulators in memory)
+  f32x16 dW0 = zero16, dWown[NL > 1 ? NL - 1 : 1], dWoth[NL > 1 ? NL - 1 : 1], dWo = zero16, dbt = zero16;
+#pragma unroll
+  for (int l = 0; l < (NL > 1 ? NL - 1 : 1); ++l) dWown[l] = dWoth[l] = zero16;
+  double sum64[3] = {0.0, 0.0, 0.0};
+  float sum32[3] = {0.0f, 0.0f, 0.0f};
+
+  const size_t B = (size_t)tr.T * tr.n;
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)((size_t)(tr.T + 1) * tr.n);
+  const size_t n_tiles = (B + 31) / 32;
+  const size_t pair_id = (size_t)blockIdx.x * PAIRS + pair, n_pairs = (size_t)gridDim.x * PAIRS;
+  const size_t iters = (n_tiles + n_pairs - 1) / n_pairs;
+  double *__restrict__ row = slabA + pair_id * g.P;  // the pair's row: the two waves fill disjoint entries
+  bool first_flush = true;
+  auto put = [&](uint32_t at, float v) {
+    if (first_flush) row[at] = (double)v;
+    else row[at] = row[at] + (double)v;
+  };
+  auto flush_w = [&](f32x16 &t, int l, int ot, int it) {
+    const int K = Kof(l), N = Nof(l), k = it * 32 + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = ot * 32 + urow(r, kb);
+      if (j < N) {
+        if (k < K) put(g.off[l] + (uint32_t)(j * K + k), t[r]);
+        else if (l == 0 && k == K) put(g.off[0] + (uint32_t)(N * K + j), t[r]);
+      }
+      t[r] = 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto flush_all = [&]() {
+    flush_w(dW0, 0, h, 0);
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+      flush_w(dWown[l - 1], l, h, h);
+      flush_w(dWoth[l - 1], l, h, 1 - h);
+    }
+    flush_w(dWo, NL, 0, h);
+#pragma unroll
+    for (int l = 1; l <= NL; ++l) {  // bias column (l - 1) GW + ot: this wave's tile of a hidden layer; wave 0: the outputs
+      const int N = Nof(l), K = Kof(l), ot = m - (l - 1) * GW;
+      if (l < NL ? ot == h : (ot == 0 && h == 0)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = ot * 32 + urow(r, kb);
+          if (j < N) put(g.off[l] + (uint32_t)(N * K + j), dbt[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dbt[r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      sum64[q] += (double)sum32[q];
+      sum32[q] = 0.0f;
+    }
+    first_flush = false;
+  };
+  auto load_tile = [&](size_t t) {  // (branch-free: padding lanes read sample B - 1 and are zeroed)
+    TileIn o;
+    const uint32_t sidx = (uint32_t)t * 32u + (uint32_t)m;
+    o.valid = t < n_tiles && sidx < B32;
+    const uint32_t sc = o.valid ? sidx : B32 - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * kb + e;
+      float v = 0.0f;
+      if (k < g.in_dim) v = tr.obs[(uint32_t)k * plane32 + sc];
+      else if (k == g.in_dim) v = 1.0f;
+      o.x[e] = o.valid ? v : 0.0f;
+    }
+    o.tgt = o.adv = o.l0 = o.l1 = 0.0f;
+    o.act = 0;
+    if (MODE == GM_CRITIC) {
+      const float tg = tr.tgt[sc];
+      o.tgt = o.valid ? tg : 0.0f;
+    } else {
+      const float adv = tr.adv[sc];
+      const int act = (int)tr.action[sc];
+      o.adv = o.valid ? adv : 0.0f;
+      o.act = o.valid ? act : 0;
+      if (MODE != PASS_INIT) {
+        const float l0 = lp0[sc], l1 = lp0[B32 + sc];
+        o.l0 = o.valid ? l0 : 0.0f;
+        o.l1 = o.valid ? l1 : 0.0f;
+      }
+    }
+    return o;
+  };
+  auto bias_rows = [&](int l) {  // accumulator of this wave's tile initialised with the biases of its rows' units
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = bias[(l - 1) * 64 + h * 32 + urow(r, kb)];
+    return c;
+  };
+  // the exchange: this wave's two k-steps x three pieces to the partner, the partner's to this wave
+  uint4(*mine)[64] = xch + (pair * 2 + h) * 6, (*theirs)[64] = xch + (pair * 2 + (1 - h)) * 6;
+  auto xput = [&](const Frag(&P)[2][3]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) mine[q * 3 + c][lane] = P[q][c].x;
+  };
+  auto xget = [&](Frag(&P)[2][3]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) P[q][c].x = theirs[q * 3 + c][lane];
+  };
+
+  int since_flush = 0;
+  TileIn op = load_tile(pair_id);
+  for (size_t it_ = 0; it_ < iters; ++it_) {
+    const size_t t = pair_id + it_ * n_pairs;
+    const TileIn next = load_tile(t + n_pairs);
+    // ---- forward: this wave's unit tile of every layer
+    Frag xb0[1][3];
+    {
+      uint32_t p[3][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bt::split3t(op.x[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xb0[0][c].u[0] = bt::pkh(p[c][0], p[c][1]);
+        xb0[0][c].u[1] = bt::pkh(p[c][2], p[c][3]);
+        xb0[0][c].u[2] = xb0[0][c].u[3] = 0u;
+      }
+    }
+    f32x16 a[NL];
+    a[0] = prod6_lds(zero16, img, h, lane, xb0[0]);
+    gm_act_tile(g.act, a[0]);
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+      // (own products first, then the partner's: one set of operand pieces alive at a time)
+      Frag pc[2][3];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) pieces_trunc(a[l - 1], q, pc[q]);
+      if (l > 1) __syncthreads();  // (the partner has read the previous layer's pieces)
+      xput(pc);
+      f32x16 c = bias_rows(l);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_fh(GW, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+      __syncthreads();
+      xget(pc);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_fh(GW, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+      gm_act_tile(g.act, c);
+      a[l] = c;
+    }
+    // output layer: each wave sums over its own tile's units, the two partial sums meet in LDS (the bias with half 0's)
+    f32x16 zp = zero16;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      Frag ab[3];
+      pieces_trunc(a[NL - 1], q, ab);
+      zp = prod6_lds(zp, img, gm_fo(GW, NL) + h * 2 + q, lane, ab);
+    }
+    float *zmine = zbuf + ((pair * 2 + h) * 2) * 32, *ztheirs = zbuf + ((pair * 2 + (1 - h)) * 2) * 32;
+    if (kb == 0) {
+      zmine[m] = zp[0];
+      zmine[32 + m] = zp[1];
+    }
+    __syncthreads();
+    float z0, z1;
+    {
+      const float o0 = ztheirs[m], o1 = ztheirs[32 + m];
+      const float p00 = h == 0 ? zp[0] : o0, p01 = h == 0 ? o0 : zp[0];  // (half 0's part first in both waves)
+      const float p10 = h == 0 ? zp[1] : o1, p11 = h == 0 ? o1 : zp[1];
+      z0 = (p00 + p01) + bias[(NL - 1) * 64 + 0];
+      z1 = (p10 + p11) + bias[(NL - 1) * 64 + 1];
+    }
+    // ---- per-sample terms: both waves compute them (identically), wave 0 counts them
+    float d0 = 0.0f, d1 = 0.0f;
+    gm_sample_terms<MODE>(g, z0, z1, 0.0f, 0.0f, op, kb == 0 && op.valid, h == 0, inv_B, clip_lo, clip_hi, lp0,
+                          (uint32_t)t * 32u + (uint32_t)m, B32, sum32, d0, d1);
+    if (BWD) {
+      Frag dob[1][3];
+      {
+        uint32_t p0[3], p1[3];
+        bt::split3(d0, p0[0], p0[1], p0[2]);
+        bt::split3(d1, p1[0], p1[1], p1[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dob[0][c].u[0] = kb == 0 ? bt::pk(p0[c], p1[c]) : 0u;
+          dob[0][c].u[1] = dob[0][c].u[2] = dob[0][c].u[3] = 0u;
+        }
+      }
+      Frag dT[2][3], aT[2][3];  // transposed pieces: the deltas in hand, the activations below them
+      transpose_pieces<1>(dob, idb, dT);
+      if (h == 0) dbt = bias_tile(dbt, dT, (NL - 1) * GW, m);
+      f32x16 dl;  // this wave's tile of the deltas of the hidden layer in hand
+      {
+        Frag ab[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1], q, ab[q]);
+        transpose_pieces<2>(ab, idb, aT);
+        dWo = wgrad_tile(dWo, dT, aT);
+        dl = prod6_lds(zero16, img, gm_bo(GW, NL) + h, lane, dob[0]);
+        gm_slope_tile(g.act, dl, a[NL - 1]);
+      }
+#pragma unroll
+      for (int l = NL - 1; l >= 1; --l) {
+        // deltas of layer l - 1, this wave's tile: own k-steps, then the partner's
+        f32x16 c = zero16;
+        {
+          Frag pc[2][3];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) pieces_round(dl, q, pc[q]);
+          if (l < NL - 1) __syncthreads();  // (the partner has read the transposed activations of the layer above)
+          xput(pc);  // (first use after the z exchange's barrier)
+          transpose_pieces<2>(pc, idb, dT);
+          dbt = bias_tile(dbt, dT, (l - 1) * GW + h, m);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_bh(GW, NL, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+          __syncthreads();
+          xget(pc);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_bh(GW, NL, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+        }
+        gm_slope_tile(g.act, c, a[l - 1]);
+        // weight gradients of layer l: this wave's output units against its own input tile, then the partner's
+        {
+          Frag ab[2][3];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) pieces_trunc(a[l - 1], q, ab[q]);
+          transpose_pieces<2>(ab, idb, aT);
+        }
+        __syncthreads();  // (the partner has read the delta pieces)
+        xput(aT);
+        dWown[l - 1] = wgrad_tile(dWown[l - 1], dT, aT);
+        __syncthreads();
+        xget(aT);
+        dWoth[l - 1] = wgrad_tile(dWoth[l - 1], dT, aT);
+        dl = c;
+      }
+      // ---- layer 0
+      {
+        Frag db[2][3], xT[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_round(dl, q, db[q]);
+        transpose_pieces<2>(db, idb, dT);
+        transpose_pieces<1>(xb0, idb, xT);
+        dW0 = wgrad_tile(dW0, dT, xT);
+      }
+    }
+    __syncthreads();  // the exchange regions are free for the next tile
+    if (++since_flush == GM_FLUSH || it_ + 1 == iters) {
+      since_flush = 0;
+      if (BWD) {
+        flush_all();
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          sum64[q] += (double)sum32[q];
+          sum32[q] = 0.0f;
+        }
+      }
+    }
+    op = next;
+  }
+  if (h != 0) return;  // the scalar sums live on wave 0 of the pair
+  auto xlane = [](double v, int mask) {
+    uint64_t bits = rl_f64_bits(v);
+    uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
+    uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), mask, 64);
+    return rl_f64_from_bits(((uint64_t)hi << 32) | lo);
+  };
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double s = kb == 0 ? sum64[q] : 0.0;
+#pragma unroll
+    for (int sft = 16; sft > 0; sft >>= 1) s = s + xlane(s, sft);
+    sum64[q] = s;
+  }
+  if (lane == 0) {
+    double *sb = slabB + pair_id * 4;
+    sb[0] = sum64[0];
+    sb[1] = sum64[1];
+    sb[2] = sum64[2];
+    sb[3] = 0.0;
+  }
+}
+
+constexpr size_t gp_lds_bytes(int NL, int pairs) {
+  return (size_t)gm_groups(2, NL) * 3 * 64 * 16 + (size_t)NL * 64 * 4 + (size_t)pairs * 2 * 6 * 64 * 16 + (size_t)pairs * 2 * 2 * 32 * 4;
+}
+
+template <int MODE, int NL>
+void gp_launch(rl_traj *t, const GmArgs &g, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo, float clip_hi) {
+  const size_t lds = gp_lds_bytes(NL, GP_PAIRS);
+  {
+    static std::mutex mu;
+    static std::set<int> raised;
+    std::lock_guard<std::mutex> lock(mu);
+    if (raised.insert(t->eng->device).second)
+      RL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gen_pair<MODE, NL, GP_PAIRS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL((k_gen_pair<MODE, NL, GP_PAIRS>), dim3(nwg), dim3(GP_PAIRS * 128), lds, t->eng->stream, t->d, g, t->lp0,
+                     t->slabA, t->slabB, inv_B, d_skip, clip_lo, clip_hi);
+  RL_HIP_CHECK(hipGetLastError());
+}
+template <int MODE>
+void gp_launch_nl(rl_traj *t, const GmArgs &g, int NL, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
+                  float clip_hi) {
+  if (NL == 1) gp_launch<MODE, 1>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else if (NL == 2) gp_launch<MODE, 2>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+  else gp_launch<MODE, 3>(t, g, nwg, inv_B, d_skip, clip_lo, clip_hi);
+}
+
 template <int MODE, int NL, int GW>
 void gm_launch(rl_traj *t, const GmArgs &g, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo,
                float clip_hi) {
@@ -749,13 +1099,26 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
   for (uint32_t l = 0; l <= m->n_hidden; ++l) g.off[l] = (uint32_t)m->layer_offset(l);
   g.P = (uint32_t)m->P;
   const uint64_t n_tiles = (t->B + 31) / 32, cus = (uint64_t)t->eng->prop.multiProcessorCount;
+  const int NL = (int)m->n_hidden, gw = gm_width_tiles(m);
+  const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
+  gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
+  static const bool one_wave = getenv("RELEARN_GEN_ONE_WAVE") != nullptr;  // measurement override: the one-wave kernel
+  if (gw == 2 && mode != PASS_JVP && gp_lds_bytes(NL, GP_PAIRS) <= 160 * 1024 && !one_wave) {
+    // a tile per pair of waves, two waves per SIMD
+    uint64_t nwg = (n_tiles + GP_PAIRS - 1) / GP_PAIRS;
+    if (nwg > cus) nwg = cus;
+    t->last_rows = (uint32_t)(nwg * GP_PAIRS);  // one slab row per pair
+    traj_ensure_slabs(t, t->last_rows, m->P, t->last_rows);
+    if (mode == RL_GEN_CRITIC) gp_launch_nl<GM_CRITIC>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+    else if (mode == PASS_INIT) gp_launch_nl<PASS_INIT>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+    else if (mode == PASS_PPO) gp_launch_nl<PASS_PPO>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+    else gp_launch_nl<PASS_EVAL>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+    return true;
+  }
   uint64_t nwg = (n_tiles + GWAVES - 1) / GWAVES;
   if (nwg > cus) nwg = cus;
   t->last_rows = (uint32_t)(nwg * GWAVES < n_tiles ? nwg * GWAVES : n_tiles);  // one slab row per wave that has tiles
-  gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
   traj_ensure_slabs(t, t->last_rows, m->P, t->last_rows);
-  const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
-  const int NL = (int)m->n_hidden, gw = gm_width_tiles(m);
   if (mode == RL_GEN_CRITIC) gm_launch_nl<GM_CRITIC>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   else if (mode == PASS_INIT) gm_launch_nl<PASS_INIT>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
   else if (mode == PASS_PPO) gm_launch_nl<PASS_PPO>(t, g, NL, gw, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
