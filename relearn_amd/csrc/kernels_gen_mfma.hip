@@ -1103,7 +1103,7 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
   const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
   gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
   static const bool one_wave = getenv("RELEARN_GEN_ONE_WAVE") != nullptr;  // measurement override: the one-wave kernel
-  if (gw == 2 && mode != PASS_JVP && gp_lds_bytes(NL, GP_PAIRS) <= 160 * 1024 && !one_wave) {
+  if (gw == 2 && mode != PASS_JVP && mode != PASS_EVAL && gp_lds_bytes(NL, GP_PAIRS) <= 160 * 1024 && !one_wave) {
     // a tile per pair of waves, two waves per SIMD
     uint64_t nwg = (n_tiles + GP_PAIRS - 1) / GP_PAIRS;
     if (nwg > cus) nwg = cus;

@@ -26,13 +26,14 @@ for name, h in (("fused_128", 128), ("general", hidden)):
         t = {}
         eng.timer_begin(); ra.rollout(env, pol, traj); t["rollout_ms"] = eng.timer_end()
         eng.timer_begin(); ra.gae(traj, cri, 0.99, 0.95); t["gae_ms"] = eng.timer_end()
-        eng.timer_begin(); ra.trpo_update(pol, traj); t["trpo_ms"] = eng.timer_end()
+        eng.timer_begin(); st = ra.trpo_update(pol, traj); t["trpo_ms"] = eng.timer_end()
+        t["trpo_cg_iterations"], t["trpo_backtracks"] = int(st.cg_iterations), int(st.num_backtracks)
         eng.timer_begin(); ra.critic_update(cri, opt, traj, steps); t["critic_ms"] = eng.timer_end()
         return t
 
     period()
     t = period()
-    t["period_ms"] = sum(t.values())
+    t["period_ms"] = sum(v for k, v in t.items() if k.endswith("_ms"))
     t["hidden_sizes"] = h if isinstance(h, list) else [h]
     t["env_steps_per_s"] = n * T / t["period_ms"] * 1e3
     out[name] = t
