@@ -179,12 +179,23 @@ __device__ __forceinline__ f32x16 bias_tile(f32x16 acc, const Frag (&dt)[2][3], 
   return acc;
 }
 
+// The pair kernel's image: the same groups without the output layer's forward fragments — of their 32 rows only the
+// module's (at most two) outputs are non-zero, so they live apart, one 16-byte entry per (group, piece, output, lane half)
+// instead of 64: 1.5 KB instead of 12 KB (24 KB with the tangent's), which is what lets four pairs of waves and the
+// tangent image share a CU's LDS.
+constexpr int cp_bh(int GW, int NL, int l) { return GW + (NL - 1) * 2 * GW * GW + (l - 1) * 2 * GW * GW; }
+constexpr int cp_bo(int GW, int NL) { return cp_bh(GW, NL, NL); }
+constexpr int cp_groups(int GW, int NL) { return cp_bo(GW, NL) + GW; }
+constexpr int cp_tan_groups(int GW, int NL) { return GW + (NL - 1) * 2 * GW * GW; }
+
 // ---- the weight image: every fragment in the acc_row order of the tile it meets.  `src`: the parameters (forward and
 // backward fragments from group g0 = 0) or the tangent (forward fragments only, from group TG); every thread of the
 // workgroup (`nthreads`) calls it, the caller synchronises.
+// `outc` != NULL: the compact layout above (output-layer forward fragments into outc[(ks * 3 + piece) * 4 + 2 j + half]).
 template <int NL, int GW>
 __device__ __forceinline__ void gm_build_image(const GmArgs &g, const float *__restrict__ src, uint4 (*img)[64], int g0,
-                                               bool with_backward, float *bias_out, int nthreads) {
+                                               bool with_backward, float *bias_out, int nthreads, uint4 *outc = nullptr) {
+  const bool compact = outc != nullptr;
   auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
   auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
   auto put_group = [&](int grp, int ln, const float (&v)[8]) {
@@ -225,7 +236,7 @@ __device__ __forceinline__ void gm_build_image(const GmArgs &g, const float *__r
         const int j = dir == 0 ? own : across, k = dir == 0 ? across : own;
         v[e] = (j < N && k < K) ? W[j * K + k] : 0.0f;
       }
-      put_group(g0 + (dir == 0 ? gm_fh(GW, l) : gm_bh(GW, NL, l)) + r2, ln, v);
+      put_group(g0 + (dir == 0 ? gm_fh(GW, l) : (compact ? cp_bh(GW, NL, l) : gm_bh(GW, NL, l))) + r2, ln, v);
     }
   }
   {  // output layer: forward [ks], backward [it]
@@ -246,7 +257,19 @@ __device__ __forceinline__ void gm_build_image(const GmArgs &g, const float *__r
         }
         v[e] = (j < g.out_dim && k < K) ? W[j * K + k] : 0.0f;
       }
-      put_group(g0 + (q < 2 * GW ? gm_fo(GW, NL) + q : gm_bo(GW, NL) + (q - 2 * GW)), ln, v);
+      if (compact && q < 2 * GW) {
+        if (mm < 2) {
+          uint32_t p[3][8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bt::split3(v[e], p[0][e], p[1][e], p[2][e]);
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            outc[(q * 3 + c) * 4 + 2 * mm + hh] = make_uint4(bt::pk(p[c][0], p[c][1]), bt::pk(p[c][2], p[c][3]),
+                                                             bt::pk(p[c][4], p[c][5]), bt::pk(p[c][6], p[c][7]));
+        }
+      } else {
+        put_group(g0 + (q < 2 * GW ? gm_fo(GW, NL) + q : (compact ? cp_bo(GW, NL) : gm_bo(GW, NL)) + (q - 2 * GW)), ln, v);
+      }
     }
   }
 #pragma unroll
@@ -700,18 +723,24 @@ __global__ void __launch_bounds__(PAIRS * 128)
                float inv_B, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   constexpr int GW = 2;
   constexpr bool JVP = MODE == PASS_JVP, BWD = MODE != PASS_EVAL;
-  static_assert(!JVP, "the pair kernel is built for the gradient and evaluation passes");
+  constexpr int TG = cp_groups(GW, NL);                                  // first fragment group of the tangent (JVP)
+  constexpr int NG = TG + (JVP ? cp_tan_groups(GW, NL) : 0);             // groups of the image
+  constexpr int ZV = JVP ? 4 : 2;                                         // partial outputs a wave hands over per sample
   extern __shared__ uint4 gm_lds[];
   uint4(*img)[64] = reinterpret_cast<uint4(*)[64]>(gm_lds);
-  float *bias = reinterpret_cast<float *>(gm_lds + (size_t)gm_groups(GW, NL) * 3 * 64);  // [NL][64]: layers 1 .. NL
-  uint4(*xch)[64] = reinterpret_cast<uint4(*)[64]>(bias + NL * 64);                      // [PAIRS][2][6][64]
-  float *zbuf = reinterpret_cast<float *>(xch + PAIRS * 2 * 6);                           // [PAIRS][2][2][32]
+  uint4 *outc = gm_lds + (size_t)NG * 3 * 64;                             // compact output-layer forward fragments ...
+  uint4 *toutc = outc + 2 * GW * 3 * 4;                                   // ... and the tangent's
+  float *bias = reinterpret_cast<float *>(toutc + (JVP ? 2 * GW * 3 * 4 : 0));  // [NL][64]: layers 1 .. NL
+  float *tbias = bias + NL * 64;                                                 // (JVP) of the tangent
+  uint4(*xch)[64] = reinterpret_cast<uint4(*)[64]>(bias + NL * 64 * (JVP ? 2 : 1));  // [PAIRS][2][6][64]
+  float *zbuf = reinterpret_cast<float *>(xch + PAIRS * 2 * 6);                         // [PAIRS][2][ZV][32]
   if (skip != nullptr && *skip != 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 31, kb = lane >> 5, pair = wave >> 1, h = wave & 1;
   auto Kof = [&](int l) { return l == 0 ? g.in_dim : g.width[l - 1]; };
   auto Nof = [&](int l) { return l == NL ? g.out_dim : g.width[l]; };
-  gm_build_image<NL, GW>(g, g.params, img, 0, true, bias, PAIRS * 128);
+  gm_build_image<NL, GW>(g, g.params, img, 0, true, bias, PAIRS * 128, outc);
+  if (JVP) gm_build_image<NL, GW>(g, g.tangent, img, TG, false, tbias, PAIRS * 128, toutc);
   __syncthreads();
 
   Frag idb[2];
@@ -797,7 +826,7 @@ __global__ void __launch_bounds__(PAIRS * 128)
     if (MODE == GM_CRITIC) {
       const float tg = tr.tgt[sc];
       o.tgt = o.valid ? tg : 0.0f;
-    } else {
+    } else if (!JVP) {
       const float adv = tr.adv[sc];
       const int act = (int)tr.action[sc];
       o.adv = o.valid ? adv : 0.0f;
@@ -810,11 +839,18 @@ __global__ void __launch_bounds__(PAIRS * 128)
     }
     return o;
   };
-  auto bias_rows = [&](int l) {  // accumulator of this wave's tile initialised with the biases of its rows' units
+  auto bias_rows = [&](const float *table, int l) {  // accumulator of this wave's tile initialised with its units' biases
     f32x16 c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c[r] = bias[(l - 1) * 64 + h * 32 + urow(r, kb)];
+    for (int r = 0; r < 16; ++r) c[r] = table[(l - 1) * 64 + h * 32 + urow(r, kb)];
     return c;
+  };
+  // acc += (output-layer weights of k-step ks of this wave's tile) x pieces, from the compact fragments
+  auto out_prod = [&](f32x16 acc, const uint4 *oc, int ks, const Frag(&x)[3]) {
+    Frag w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w[c].x = m < 2 ? oc[(ks * 3 + c) * 4 + 2 * m + kb] : make_uint4(0u, 0u, 0u, 0u);
+    return prod6(acc, w, x);
   };
   // the exchange: this wave's two k-steps x three pieces to the partner, the partner's to this wave
   uint4(*mine)[64] = xch + (pair * 2 + h) * 6, (*theirs)[64] = xch + (pair * 2 + (1 - h)) * 6;
@@ -849,9 +885,14 @@ __global__ void __launch_bounds__(PAIRS * 128)
         xb0[0][c].u[2] = xb0[0][c].u[3] = 0u;
       }
     }
-    f32x16 a[NL];
+    // (JVP: the tangent rides along, ta_l = act'(.) (W_l ta_{l-1} + V_l a_{l-1} + vb_l), as in the one-wave kernel)
+    f32x16 a[NL], ta = zero16;
     a[0] = prod6_lds(zero16, img, h, lane, xb0[0]);
     gm_act_tile(g.act, a[0]);
+    if (JVP) {
+      ta = prod6_lds(zero16, img, TG + h, lane, xb0[0]);
+      gm_slope_tile(g.act, ta, a[0]);
+    }
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
       // (own products first, then the partner's: one set of operand pieces alive at a time)
@@ -860,41 +901,77 @@ __global__ void __launch_bounds__(PAIRS * 128)
       for (int q = 0; q < 2; ++q) pieces_trunc(a[l - 1], q, pc[q]);
       if (l > 1) __syncthreads();  // (the partner has read the previous layer's pieces)
       xput(pc);
-      f32x16 c = bias_rows(l);
+      f32x16 c = bias_rows(bias, l), tc = zero16;
+      if (JVP) tc = bias_rows(tbias, l);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_fh(GW, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+      for (int q = 0; q < 2; ++q) {
+        c = prod6_lds(c, img, gm_fh(GW, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+        if (JVP) tc = prod6_lds(tc, img, TG + gm_fh(GW, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+      }
       __syncthreads();
       xget(pc);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_fh(GW, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+      for (int q = 0; q < 2; ++q) {
+        c = prod6_lds(c, img, gm_fh(GW, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+        if (JVP) tc = prod6_lds(tc, img, TG + gm_fh(GW, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+      }
+      if (JVP) {  // the tangent of the layer below, the same way
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pieces_trunc(ta, q, pc[q]);
+        __syncthreads();  // (the partner has read the activation pieces)
+        xput(pc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tc = prod6_lds(tc, img, gm_fh(GW, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+        __syncthreads();
+        xget(pc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tc = prod6_lds(tc, img, gm_fh(GW, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+      }
       gm_act_tile(g.act, c);
       a[l] = c;
+      if (JVP) {
+        gm_slope_tile(g.act, tc, c);
+        ta = tc;
+      }
     }
     // output layer: each wave sums over its own tile's units, the two partial sums meet in LDS (the bias with half 0's)
-    f32x16 zp = zero16;
+    f32x16 zp = zero16, tzp = zero16;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       Frag ab[3];
       pieces_trunc(a[NL - 1], q, ab);
-      zp = prod6_lds(zp, img, gm_fo(GW, NL) + h * 2 + q, lane, ab);
+      zp = out_prod(zp, outc, h * 2 + q, ab);
+      if (JVP) {
+        tzp = out_prod(tzp, toutc, h * 2 + q, ab);
+        Frag tb[3];
+        pieces_trunc(ta, q, tb);
+        tzp = out_prod(tzp, outc, h * 2 + q, tb);
+      }
     }
-    float *zmine = zbuf + ((pair * 2 + h) * 2) * 32, *ztheirs = zbuf + ((pair * 2 + (1 - h)) * 2) * 32;
+    float *zmine = zbuf + ((pair * 2 + h) * ZV) * 32, *ztheirs = zbuf + ((pair * 2 + (1 - h)) * ZV) * 32;
     if (kb == 0) {
       zmine[m] = zp[0];
       zmine[32 + m] = zp[1];
+      if (JVP) {
+        zmine[64 + m] = tzp[0];
+        zmine[96 + m] = tzp[1];
+      }
     }
     __syncthreads();
-    float z0, z1;
+    float z0, z1, tz0 = 0.0f, tz1 = 0.0f;
     {
-      const float o0 = ztheirs[m], o1 = ztheirs[32 + m];
-      const float p00 = h == 0 ? zp[0] : o0, p01 = h == 0 ? o0 : zp[0];  // (half 0's part first in both waves)
-      const float p10 = h == 0 ? zp[1] : o1, p11 = h == 0 ? o1 : zp[1];
-      z0 = (p00 + p01) + bias[(NL - 1) * 64 + 0];
-      z1 = (p10 + p11) + bias[(NL - 1) * 64 + 1];
+      // (half 0's part first in both waves: the two compute identical sums)
+      auto meet = [&](float minev, float theirv, float b) { return ((h == 0 ? minev : theirv) + (h == 0 ? theirv : minev)) + b; };
+      z0 = meet(zp[0], ztheirs[m], bias[(NL - 1) * 64 + 0]);
+      z1 = meet(zp[1], ztheirs[32 + m], bias[(NL - 1) * 64 + 1]);
+      if (JVP) {
+        tz0 = meet(tzp[0], ztheirs[64 + m], tbias[(NL - 1) * 64 + 0]);
+        tz1 = meet(tzp[1], ztheirs[96 + m], tbias[(NL - 1) * 64 + 1]);
+      }
     }
     // ---- per-sample terms: both waves compute them (identically), wave 0 counts them
     float d0 = 0.0f, d1 = 0.0f;
-    gm_sample_terms<MODE>(g, z0, z1, 0.0f, 0.0f, op, kb == 0 && op.valid, h == 0, inv_B, clip_lo, clip_hi, lp0,
+    gm_sample_terms<MODE>(g, z0, z1, tz0, tz1, op, kb == 0 && op.valid, h == 0, inv_B, clip_lo, clip_hi, lp0,
                           (uint32_t)t * 32u + (uint32_t)m, B32, sum32, d0, d1);
     if (BWD) {
       Frag dob[1][3];
@@ -918,7 +995,7 @@ __global__ void __launch_bounds__(PAIRS * 128)
         for (int q = 0; q < 2; ++q) pieces_trunc(a[NL - 1], q, ab[q]);
         transpose_pieces<2>(ab, idb, aT);
         dWo = wgrad_tile(dWo, dT, aT);
-        dl = prod6_lds(zero16, img, gm_bo(GW, NL) + h, lane, dob[0]);
+        dl = prod6_lds(zero16, img, cp_bo(GW, NL) + h, lane, dob[0]);
         gm_slope_tile(g.act, dl, a[NL - 1]);
       }
 #pragma unroll
@@ -934,11 +1011,11 @@ __global__ void __launch_bounds__(PAIRS * 128)
           transpose_pieces<2>(pc, idb, dT);
           dbt = bias_tile(dbt, dT, (l - 1) * GW + h, m);
 #pragma unroll
-          for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_bh(GW, NL, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
+          for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, cp_bh(GW, NL, l) + h * 2 * GW + h * 2 + q, lane, pc[q]);
           __syncthreads();
           xget(pc);
 #pragma unroll
-          for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, gm_bh(GW, NL, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
+          for (int q = 0; q < 2; ++q) c = prod6_lds(c, img, cp_bh(GW, NL, l) + h * 2 * GW + (1 - h) * 2 + q, lane, pc[q]);
         }
         gm_slope_tile(g.act, c, a[l - 1]);
         // weight gradients of layer l: this wave's output units against its own input tile, then the partner's
@@ -1004,13 +1081,14 @@ __global__ void __launch_bounds__(PAIRS * 128)
   }
 }
 
-constexpr size_t gp_lds_bytes(int NL, int pairs) {
-  return (size_t)gm_groups(2, NL) * 3 * 64 * 16 + (size_t)NL * 64 * 4 + (size_t)pairs * 2 * 6 * 64 * 16 + (size_t)pairs * 2 * 2 * 32 * 4;
+constexpr size_t gp_lds_bytes(int NL, int pairs, bool jvp) {
+  return (size_t)(cp_groups(2, NL) + (jvp ? cp_tan_groups(2, NL) : 0)) * 3 * 64 * 16 + (size_t)(jvp ? 2 : 1) * 4 * 3 * 4 * 16 +
+         (size_t)NL * 64 * 4 * (jvp ? 2 : 1) + (size_t)pairs * 2 * 6 * 64 * 16 + (size_t)pairs * 2 * (jvp ? 4 : 2) * 32 * 4;
 }
 
 template <int MODE, int NL>
 void gp_launch(rl_traj *t, const GmArgs &g, uint32_t nwg, float inv_B, const int32_t *d_skip, float clip_lo, float clip_hi) {
-  const size_t lds = gp_lds_bytes(NL, GP_PAIRS);
+  const size_t lds = gp_lds_bytes(NL, GP_PAIRS, MODE == PASS_JVP);
   {
     static std::mutex mu;
     static std::set<int> raised;
@@ -1085,7 +1163,9 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
   if (!gen_mfma_fits(t, m)) return false;
   if (mode != RL_GEN_CRITIC && mode != PASS_INIT && mode != PASS_PPO && mode != PASS_EVAL && mode != PASS_JVP) return false;
   // the tangent's forward fragments next to the parameters': 114 KB of LDS for two hidden layers, too much for three
-  if (mode == PASS_JVP && (d_tangent == nullptr || gm_lds_bytes(gm_width_tiles(m), (int)m->n_hidden, true) > 160 * 1024)) return false;
+  if (mode == PASS_JVP && (d_tangent == nullptr || (gm_lds_bytes(gm_width_tiles(m), (int)m->n_hidden, true) > 160 * 1024 &&
+                                                    !(gm_width_tiles(m) == 2 && gp_lds_bytes((int)m->n_hidden, GP_PAIRS, true) <= 160 * 1024))))
+    return false;
   if (mode != RL_GEN_CRITIC && m->out_dim != 2) return false;
   if (mode == RL_GEN_CRITIC && m->out_dim != 1) return false;
   GmArgs g{};
@@ -1103,7 +1183,7 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
   const float inv_B = (mode == RL_GEN_CRITIC ? 2.0f : 1.0f) / (float)B_total;
   gen_ensure(t, m, 0, false, true);  // the P-sized vectors of the update workspace follow the module
   static const bool one_wave = getenv("RELEARN_GEN_ONE_WAVE") != nullptr;  // measurement override: the one-wave kernel
-  if (gw == 2 && mode != PASS_JVP && mode != PASS_EVAL && gp_lds_bytes(NL, GP_PAIRS) <= 160 * 1024 && !one_wave) {
+  if (gw == 2 && mode != PASS_EVAL && gp_lds_bytes(NL, GP_PAIRS, mode == PASS_JVP) <= 160 * 1024 && !one_wave) {
     // a tile per pair of waves, two waves per SIMD
     uint64_t nwg = (n_tiles + GP_PAIRS - 1) / GP_PAIRS;
     if (nwg > cus) nwg = cus;
@@ -1112,7 +1192,7 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
     if (mode == RL_GEN_CRITIC) gp_launch_nl<GM_CRITIC>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
     else if (mode == PASS_INIT) gp_launch_nl<PASS_INIT>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
     else if (mode == PASS_PPO) gp_launch_nl<PASS_PPO>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
-    else gp_launch_nl<PASS_EVAL>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
+    else gp_launch_nl<PASS_JVP>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
     return true;
   }
   uint64_t nwg = (n_tiles + GWAVES - 1) / GWAVES;
