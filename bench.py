@@ -59,6 +59,9 @@ def parse_args():
                     help="do not wrap launches in HIP events inside the timed region")
     ap.add_argument("--profile-steps", type=int, default=1,
                     help="number of timed periods (the last ones) whose launches are wrapped in HIP events")
+    ap.add_argument("--serial-update", action="store_true",
+                    help="run the TRPO chain and the critic chain of every period one after the other on one stream "
+                         "(default: side by side on two streams, rl_actor_critic_update)")
     ap.add_argument("--cpu-sample-steps", type=int, default=262144,
                     help="total env-steps of the bounded CPU-baseline sample (split over the host cores)")
     return ap.parse_args()
@@ -214,14 +217,18 @@ def main():
     traj = ra.Trajectory(eng, n_local, T, 5)
     trpo_cfg = ra.trpo_config_default()
     gamma = min(0.99, 0.99)  # min(max_discount_factor, env discount) (critics/opt.rs:73)
+    critic_cfg = ra.values_opt_config_default()  # ValuesOptConfig::default: reward-to-go targets
+    critic_cfg.opt_steps_per_update, critic_cfg.discount_factor = args.critic_steps, gamma
+    eng.set_serial_update(args.serial_update)
 
     last = {}
 
     def period():
         ra.rollout(env, policy, traj)
         ra.gae(traj, critic, gamma, 0.95)
-        last["trpo"] = ra.trpo_update(policy, traj, trpo_cfg)
-        last["critic"] = ra.critic_update(critic, opt, traj, args.critic_steps)
+        # policy.update and critic.update of ActorCriticAgent::batch_update_slice (actor_critic.rs:196-208): independent
+        # given the trajectory and its advantages, so the engine runs the two launch chains side by side on two streams
+        last["trpo"], last["critic"] = ra.actor_critic_update(policy, critic, opt, traj, trpo_cfg, critic_cfg)
 
     def barrier():
         # eng.sync() = hipStreamSynchronize(engine stream) + hipDeviceSynchronize(); torch.cuda.synchronize() is the
@@ -245,12 +252,16 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         if prof_steps and k == args.steps - prof_steps:
+            # the profiled period(s) run the two chains one after the other: a launch timed by events on its stream while
+            # another stream's kernels share the CUs would not be that kernel's duration (`roofline`, `phases`)
             eng.profile_enable(True)
+            eng.set_serial_update(True)
         period()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read(reset=True) if not args.no_kernel_profile else None
     eng.profile_enable(False)
+    eng.set_serial_update(args.serial_update)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -265,8 +276,8 @@ def main():
     # One launch = forward + MSE loss + backward of the 5-128-1 critic over every sample of the rank.
     # The kernel's contractions run on the bf16 matrix pipe as EXACT three-piece splits (relearn_amd/csrc/bf16_tile.hpp:
     # every product exact, f32 accumulation — f32-equivalent arithmetic), so the roof it sits under is the dense bf16 MFMA
-    # peak and `achieved` counts the flop that pipe EXECUTES: 48 contraction slots x 128 units forward + 32 piece columns
-    # x 128 units backward, 2 flop each = 20,480 per sample.  The algorithmic f32 rate (3 x critic forward =
+    # peak and `achieved` counts the flop that pipe EXECUTES: 22 v_mfma_f32_32x32x16_bf16 per 32-sample tile (12 forward, 2
+    # routing the pieces of dy * x, 8 backward) x 32,768 flop = 22,528 per sample.  The algorithmic f32 rate (3 x critic forward =
     # 4,608 flop per sample) is reported beside it as `f32_equivalent_TFLOPs`, never as a fraction of a roof.
     roofline = None
     roofline_policy = None
@@ -325,7 +336,7 @@ def main():
             }
         else:
             roofline = {
-                "kernel": "k_critic_fwd + k_mlp_backward (v1, vector unit)", "bound": "mfma", "achieved": algorithmic,
+                "kernel": "k_critic_fwd + k_mlp_backward (v1, vector unit)", "bound": "valu", "achieved": algorithmic,
                 "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": algorithmic / F32_PEAK_TFLOPS, "traffic": None,
                 "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1), "samples_per_launch": B_local,
                 "algorithmic_flop_per_sample": flop_c,
@@ -448,6 +459,9 @@ def main():
                                 args.max_episode_steps, args.envs, T, H, H, args.critic_steps),
                 "n_envs_total": args.envs, "n_envs_per_gpu": n_local, "horizon": T, "hidden": H,
                 "critic_steps": args.critic_steps,
+                "update_chains": ("policy and critic chains one after the other" if args.serial_update else
+                                  "policy and critic chains side by side on two streams (the %d profiled period(s) of "
+                                  "the timed region run them in turn)" % prof_steps),
                 "parallelism": "env-sharded x%d + %s" % (world, {"none": "no collective (one rank)", "rccl": "RCCL all-reduce",
                                                                "ipc": "single-launch all-reduce over peer-mapped mailboxes",
                                                                "gloo": "host-staged all-reduce over gloo (fallback)"}[comm_kind]),

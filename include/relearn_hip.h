@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 4
+#define RL_ABI_VERSION 5
 
 /* ---------------------------------------------------------------------------------------------
  * Status codes.  The non-generic ones mirror the reference's error enums:
@@ -389,6 +389,27 @@ typedef struct {
 int32_t rl_values_opt_config_default(rl_values_opt_config *cfg);
 int32_t rl_values_opt_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, const rl_values_opt_config *cfg,
                              rl_critic_stats *stats, float *losses_out /* may be NULL */);
+
+/* ---------------------------------------------------------------------------------------------
+ * The two updates of ActorCriticAgent::batch_update_slice (src/torch/agents/actor_critic.rs:176-211) after the
+ * advantages — `policy.update(&features, advantages, ..)` (Trpo::update) and `critic.update(&features, ..)`
+ * (ValuesOpt::update) — as ONE call.  They share no data beyond the trajectory: the advantages come from the critic as
+ * it stood BEFORE either update (rl_gae), the critic's targets are the returns (or one-step TD values of the critic as
+ * it stands when the call begins), so the reference's sequential order is not a dependence.  The engine therefore
+ * enqueues the critic chain (targets + opt_steps_per_update x {gradient, reduce + Adam}) on a second HIP stream, with its
+ * own slab rows / reduced vector / collective channel, and runs the TRPO chain on the main stream beside it: each
+ * chain's single-workgroup bookkeeping launches (and, with several ranks, its latency-bound all-reduces) hide under
+ * the other chain's compute.  Arithmetic and order INSIDE each chain are those of rl_trpo_update and
+ * rl_values_opt_update: results are bit-identical to calling the two one after the other (tests/test_gpu_parity.py).
+ * The chains run one after the other instead when the modules are not the fused 5-128-{2,1} MLPs, when kernel variant 1
+ * or rl_engine_set_serial_update(engine, 1) / RELEARN_SERIAL_UPDATE=1 is selected, or when an RCCL job could not build
+ * its second communicator.  Later calls on the engine are ordered after both chains.  Errors: as the two calls. */
+int32_t rl_actor_critic_update(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_opt, rl_traj *traj,
+                               const rl_trpo_config *policy_cfg, const rl_values_opt_config *critic_cfg,
+                               rl_trpo_stats *policy_stats, rl_critic_stats *critic_stats /* may be NULL */,
+                               float *critic_losses_out /* may be NULL */);
+/* 1: rl_actor_critic_update runs its two chains one after the other on the main stream (A/B runs, per-kernel timing) */
+int32_t rl_engine_set_serial_update(rl_engine *engine, int32_t serial);
 
 /* ---------------------------------------------------------------------------------------------
  * First-order policy updates and the critic-free advantage (the rest of the ActorCriticConfig matrix,

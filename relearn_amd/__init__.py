@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient", "rl_values_opt_config_default", "rl_values_opt_update",
+    "rl_actor_critic_update", "rl_engine_set_serial_update",
     "rl_ppo_config_default", "rl_ppo_update", "rl_reinforce_update", "rl_reward_to_go",
     "rl_actor_to_cbor", "rl_module_from_cbor", "rl_tensor_def_to_cbor", "rl_tensor_def_from_cbor",
     "rl_indexed_type_space_to_cbor",
@@ -198,6 +199,10 @@ class Engine(_Handle):
 
     def set_kernel_variant(self, variant):
         _check(lib().rl_engine_set_kernel_variant(self.h, C.c_int32(variant)), self.h)
+
+    def set_serial_update(self, serial):
+        """rl_actor_critic_update: True = the two chains one after the other on the main stream"""
+        _check(lib().rl_engine_set_serial_update(self.h, C.c_int32(1 if serial else 0)), self.h)
 
     def timer_begin(self):
         _check(lib().rl_timer_begin(self.h), self.h)
@@ -711,6 +716,20 @@ def values_opt_update(critic, opt, traj, cfg=None, want_losses=False):
     _check(lib().rl_values_opt_update(critic.h, opt.h, traj.h, C.byref(cfg), C.byref(st),
                                       losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
     return (st, losses[:K]) if want_losses else st
+
+
+def actor_critic_update(policy, critic, critic_opt, traj, trpo_cfg=None, critic_cfg=None, want_losses=False):
+    """policy.update + critic.update of ActorCriticAgent::batch_update_slice (actor_critic.rs:196-208) as one call:
+    the TRPO chain and the critic chain side by side on two streams (rl_actor_critic_update)"""
+    trpo_cfg = trpo_cfg if trpo_cfg is not None else trpo_config_default()
+    critic_cfg = critic_cfg if critic_cfg is not None else values_opt_config_default()
+    pst, cst = TrpoStats(), CriticStats()
+    K = critic_cfg.opt_steps_per_update
+    losses = np.zeros(max(K, 1), dtype=np.float32)
+    _check(lib().rl_actor_critic_update(policy.h, critic.h, critic_opt.h, traj.h, C.byref(trpo_cfg), C.byref(critic_cfg),
+                                        C.byref(pst), C.byref(cst),
+                                        losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
+    return (pst, cst, losses[:K]) if want_losses else (pst, cst)
 
 
 def critic_gradient(critic, traj):

@@ -193,7 +193,10 @@ void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
   }
   ProfScope ps(e, RL_K_ALLREDUCE);
   // ncclFloat32 = 7, ncclSum = 0
-  rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 7, 0, e->comm, e->stream), "ncclAllReduce");
+  // (the auxiliary chain has a communicator of its own: collectives of two chains in flight on two streams must not
+  // share one — rl_actor_critic_update runs the chains one after the other when there is no second communicator)
+  void *comm = e->chan == 1 && e->comm_aux ? e->comm_aux : e->comm;
+  rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 7, 0, comm, e->stream), "ncclAllReduce");
 }
 
 extern "C" {
@@ -224,7 +227,11 @@ int32_t rl_engine_create(int32_t device_ordinal, rl_engine **out) {
     if (std::strncmp(e->prop.gcnArchName, "gfx950", 6) != 0)
       throw RlError(RL_ERR_NO_DEVICE,
                     std::string("device is ") + e->prop.gcnArchName + ", this library is built for gfx950 only");
-    RL_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    RL_HIP_CHECK(hipStreamCreateWithFlags(&e->main_stream, hipStreamNonBlocking));
+    RL_HIP_CHECK(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+    e->stream = e->main_stream;
+    RL_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    RL_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     RL_HIP_CHECK(hipEventCreate(&e->ev_begin));
     RL_HIP_CHECK(hipEventCreate(&e->ev_end));
     e->pinned_bytes = 1 << 16;
@@ -252,7 +259,9 @@ void engine_release_child(rl_engine *e) {
 
 static void engine_teardown(rl_engine *e) {
   (void)hipSetDevice(e->device);
-  (void)hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->main_stream);
+  (void)hipStreamSynchronize(e->aux_stream);
+  if (e->comm_aux && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm_aux);
   if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
   ipc_teardown(e);
   prof_drain(e);
@@ -260,7 +269,10 @@ static void engine_teardown(rl_engine *e) {
   if (e->pinned) (void)hipHostFree(e->pinned);
   (void)hipEventDestroy(e->ev_begin);
   (void)hipEventDestroy(e->ev_end);
-  (void)hipStreamDestroy(e->stream);
+  (void)hipEventDestroy(e->ev_fork);
+  (void)hipEventDestroy(e->ev_join);
+  (void)hipStreamDestroy(e->aux_stream);
+  (void)hipStreamDestroy(e->main_stream);
   delete e;
 }
 
@@ -308,6 +320,13 @@ int32_t rl_engine_set_kernel_variant(rl_engine *e, int32_t variant) {
     RL_REQUIRE(e, "engine is NULL");
     RL_REQUIRE(variant == 0 || variant == 1, "kernel variant must be 0 (best) or 1 (v1 reference kernels)");
     e->kernel_variant = variant;
+  });
+}
+
+int32_t rl_engine_set_serial_update(rl_engine *e, int32_t serial) {
+  return guarded(e, [&] {
+    RL_REQUIRE(e, "engine is NULL");
+    e->serial_update = serial != 0;
   });
 }
 
@@ -413,6 +432,34 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
     e->comm = comm;
     e->rank = rank;
     e->n_ranks = n_ranks;
+    // A second communicator over the same ranks for the auxiliary update chain (rl_actor_critic_update runs the policy
+    // and the critic chain on two streams, each with its collectives).  Its unique id is made on rank 0 and handed out
+    // through the first communicator — an all-reduce in which only rank 0 contributes (bytes as small integers: exact in
+    // f32) — so the caller's bootstrap stays one id.  Failure is not fatal: without it the two chains run in turn.
+    // RELEARN_NO_AUX_COMM=1 skips it.
+    if (!std::getenv("RELEARN_NO_AUX_COMM")) {
+      float *d_id = nullptr;
+      try {
+        UniqueId id2;
+        std::memset(id2.bytes, 0, sizeof(id2.bytes));
+        if (rank == 0) rccl_check(g_rccl.GetUniqueId(id2.bytes), "ncclGetUniqueId");
+        float h_id[128];
+        for (int i = 0; i < 128; ++i) h_id[i] = rank == 0 ? (float)(unsigned char)id2.bytes[i] : 0.0f;
+        d_id = dalloc<float>(128);
+        h2d(e, d_id, h_id, sizeof(h_id));
+        rccl_check(g_rccl.AllReduce(d_id, d_id, 128, 7, 0, e->comm, e->stream), "ncclAllReduce (second unique id)");
+        d2h(e, h_id, d_id, sizeof(h_id));
+        for (int i = 0; i < 128; ++i) id2.bytes[i] = (char)(unsigned char)h_id[i];
+        void *comm2 = nullptr;
+        rccl_check(init(&comm2, n_ranks, id2, rank), "ncclCommInitRank (auxiliary chain)");
+        e->comm_aux = comm2;
+      } catch (const RlError &err) {
+        e->comm_aux = nullptr;
+        std::fprintf(stderr, "relearn_hip: no second communicator (%s): update chains will run one after the other\n",
+                     err.what());
+      }
+      dfree(d_id);
+    }
   });
 }
 
@@ -478,6 +525,11 @@ int32_t rl_comm_destroy(rl_engine *e) {
     RL_REQUIRE(e, "engine is NULL");
     e->host_allreduce = nullptr;
     e->host_allreduce_ctx = nullptr;
+    if (e->comm_aux) {
+      RL_HIP_CHECK(hipStreamSynchronize(e->aux_stream));
+      rccl_check(g_rccl.CommDestroy(e->comm_aux), "ncclCommDestroy");
+      e->comm_aux = nullptr;
+    }
     if (e->comm) {
       sync(e);
       rccl_check(g_rccl.CommDestroy(e->comm), "ncclCommDestroy");
@@ -1248,10 +1300,11 @@ static void seq_free(rl_traj *t);
 int32_t rl_traj_destroy(rl_traj *t) {
   if (!t) return RL_OK;
   (void)hipSetDevice(t->eng->device);
-  (void)hipStreamSynchronize(t->eng->stream);
+  (void)hipStreamSynchronize(t->eng->main_stream);
+  (void)hipStreamSynchronize(t->eng->aux_stream);
   void *ptrs[] = {t->d.obs, t->d.action, t->d.reward, t->d.flag, t->d.term_obs, t->d.values, t->d.adv, t->d.rtg,
                   t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
-                  t->losses, t->trpo, t->td};
+                  t->losses, t->trpo, t->td, t->aux_slabA, t->aux_slabB, t->aux_vec};
   for (void *p : ptrs) dfree(p);
   seq_free(t);
   gen_free(t);

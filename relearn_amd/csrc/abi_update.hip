@@ -107,58 +107,67 @@ static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, cons
   rl_allreduce_sum_f32(traj->eng, traj->vec, P);
 }
 
+// Trpo::update (trpo.rs:97-164) on the engine's current stream; synchronises that stream only
+static void trpo_update_impl(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats) {
+  rl_engine *e = traj->eng;
+  uint32_t P = (uint32_t)policy->P;
+  uint64_t Bt = b_total(traj);
+  float reg = (float)cfg->hpv_reg_coeff;
+  // loss gradient at theta0 and CG prologue
+  run_policy_gradient(policy, traj);
+  launch_trpo_begin(traj, policy, Bt);
+  // x = A^-1 g by `iterations` CG steps (early exit handled on the device)
+  for (uint64_t it = 0; it < cfg->iterations; ++it) {
+    run_policy_fvp(policy, traj, traj->cg_p, &traj->trpo->cg_done);
+    launch_cg_step(traj, P, reg, 1e-10f);
+  }
+  launch_cg_finish(traj, P);
+  // step size from x^T A x
+  run_policy_fvp(policy, traj, traj->cg_x, nullptr);
+  launch_step_size(traj, policy, reg, cfg->max_policy_step_kl);
+  // backtracking line search
+  double ratio = 1.0;
+  for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
+    if (i > 0) ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
+    launch_ls_set_params(traj, policy, ratio);
+    run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
+    launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
+    // once a candidate is accepted the remaining iterations are no-ops on the device (every launch tests the flag);
+    // reading the flag back every second candidate spares their launches — and, with several ranks, their
+    // all-reduces.  Replicas are identical, so every rank leaves the loop at the same iteration.
+    if ((i & 1) == 1 && i + 1 < cfg->max_backtracks) {
+      int32_t accepted = 0;
+      d2h(e, &accepted, &traj->trpo->ls_accepted, sizeof(accepted));
+      if (accepted != 0) break;
+    }
+  }
+  launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
+  TrpoStateDev h;
+  d2h(e, &h, traj->trpo, sizeof(h));
+  ipc_check(e);
+  stats->entropy = (double)h.entropy;
+  stats->step_size = h.step_size;
+  stats->loss_initial = (double)h.loss0;
+  stats->loss_final = (double)h.ls_loss;
+  stats->constraint_val_final = (double)h.ls_kl;
+  stats->step_scale = h.ls_accepted ? h.ls_ratio : 0.0;
+  stats->num_backtracks = h.ls_accepted ? (int64_t)h.ls_index : -1;
+  stats->status = h.status;
+  stats->cg_iterations = h.cg_iters;
+}
+
+static void trpo_raise_nan(const rl_trpo_stats *stats) {
+  if (stats->status == RL_OPT_NAN_LOSS || stats->status == RL_OPT_NAN_CONSTRAINT)
+    throw RlError(RL_ERR_OPT_NAN, stats->status == RL_OPT_NAN_LOSS ? "NaN loss in policy optimization"
+                                                                   : "NaN constraint in policy optimization");
+}
+
 int32_t rl_trpo_update(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats) {
   return guarded(traj ? traj->eng : nullptr, [&] {
     check_policy(policy, traj);
     RL_REQUIRE(cfg && stats, "NULL argument");
-    rl_engine *e = traj->eng;
-    uint32_t P = (uint32_t)policy->P;
-    uint64_t Bt = b_total(traj);
-    float reg = (float)cfg->hpv_reg_coeff;
-    // loss gradient at theta0 and CG prologue
-    run_policy_gradient(policy, traj);
-    launch_trpo_begin(traj, policy, Bt);
-    // x = A^-1 g by `iterations` CG steps (early exit handled on the device)
-    for (uint64_t it = 0; it < cfg->iterations; ++it) {
-      run_policy_fvp(policy, traj, traj->cg_p, &traj->trpo->cg_done);
-      launch_cg_step(traj, P, reg, 1e-10f);
-    }
-    launch_cg_finish(traj, P);
-    // step size from x^T A x
-    run_policy_fvp(policy, traj, traj->cg_x, nullptr);
-    launch_step_size(traj, policy, reg, cfg->max_policy_step_kl);
-    // backtracking line search
-    double ratio = 1.0;
-    for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
-      if (i > 0) ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
-      launch_ls_set_params(traj, policy, ratio);
-      run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
-      launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
-      // once a candidate is accepted the remaining iterations are no-ops on the device (every launch tests the flag);
-      // reading the flag back every second candidate spares their launches — and, with several ranks, their
-      // all-reduces.  Replicas are identical, so every rank leaves the loop at the same iteration.
-      if ((i & 1) == 1 && i + 1 < cfg->max_backtracks) {
-        int32_t accepted = 0;
-        d2h(e, &accepted, &traj->trpo->ls_accepted, sizeof(accepted));
-        if (accepted != 0) break;
-      }
-    }
-    launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
-    TrpoStateDev h;
-    d2h(e, &h, traj->trpo, sizeof(h));
-    ipc_check(e);
-    stats->entropy = (double)h.entropy;
-    stats->step_size = h.step_size;
-    stats->loss_initial = (double)h.loss0;
-    stats->loss_final = (double)h.ls_loss;
-    stats->constraint_val_final = (double)h.ls_kl;
-    stats->step_scale = h.ls_accepted ? h.ls_ratio : 0.0;
-    stats->num_backtracks = h.ls_accepted ? (int64_t)h.ls_index : -1;
-    stats->status = h.status;
-    stats->cg_iterations = h.cg_iters;
-    if (h.status == RL_OPT_NAN_LOSS || h.status == RL_OPT_NAN_CONSTRAINT)
-      throw RlError(RL_ERR_OPT_NAN, h.status == RL_OPT_NAN_LOSS ? "NaN loss in policy optimization"
-                                                                : "NaN constraint in policy optimization");
+    trpo_update_impl(policy, traj, cfg, stats);
+    trpo_raise_nan(stats);
   });
 }
 
@@ -303,9 +312,9 @@ static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
   rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
 }
 
-// n_backward_steps (src/torch/agents/mod.rs:35-72) of full-batch MSE against traj->d.tgt with Adam
-static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
-                             float *losses_out) {
+// n_backward_steps (src/torch/agents/mod.rs:35-72) of full-batch MSE against traj->d.tgt with Adam: the launches, on the
+// engine's current stream, without any host synchronisation (feed-forward modules on a device-side collective)
+static void critic_enqueue_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps) {
   RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
   uint64_t Bt = b_total(traj);
   // no separate all-reduce between the reduction and the (elementwise) optimiser step: one rank, or the peer-mailbox
@@ -324,6 +333,10 @@ static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64
       launch_adam_step(traj, opt, (int)k, Bt);
     }
   }
+}
+
+// the losses of the steps just enqueued (synchronises the engine's current stream)
+static void critic_collect(rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats, float *losses_out) {
   if (stats || losses_out) {
     std::vector<float> h(opt_steps ? opt_steps : 1);
     if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
@@ -335,6 +348,12 @@ static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64
       stats->loss_last = opt_steps ? (double)h[opt_steps - 1] : 0.0;
     }
   }
+}
+
+static void critic_opt_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
+                             float *losses_out) {
+  critic_enqueue_steps(critic, opt, traj, opt_steps);
+  critic_collect(traj, opt_steps, stats, losses_out);
 }
 
 int32_t rl_critic_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats,
@@ -356,35 +375,144 @@ int32_t rl_values_opt_config_default(rl_values_opt_config *c) {
   });
 }
 
+static void check_values_opt(const rl_mlp *critic, const rl_adam *opt, const rl_traj *traj,
+                             const rl_values_opt_config *cfg) {
+  check_critic(critic, traj);
+  RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
+  RL_REQUIRE(cfg, "cfg is NULL");
+  RL_REQUIRE(cfg->target == RL_VALUE_TARGET_REWARD_TO_GO || cfg->target == RL_VALUE_TARGET_ONE_STEP_TD,
+             "unknown value target");
+  RL_REQUIRE(cfg->discount_factor >= 0.0f && cfg->discount_factor <= 1.0f, "discount factor must be in [0, 1]");
+}
+
+// targets: once, from the critic as it stands now (tch::no_grad, opt.rs:101-104) -> traj->td, selected as traj->d.tgt
+static void values_opt_targets(rl_mlp *critic, rl_traj *traj, const rl_values_opt_config *cfg) {
+  if (traj->td == nullptr) {
+    RL_HIP_CHECK(hipSetDevice(traj->eng->device));
+    traj->td = dalloc<float>((size_t)traj->d.T * traj->d.n);
+  }
+  traj->d.tgt = traj->td;
+  if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO) {
+    launch_value_targets(traj, nullptr, cfg->discount_factor);
+  } else if (rl_module_is_recurrent(critic->kind)) {
+    seq_ensure(traj, critic, false);
+    launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
+    launch_seq_value_targets(traj, cfg->discount_factor);
+  } else if (critic->general) {
+    launch_gen_values(traj, critic);
+    launch_seq_value_targets(traj, cfg->discount_factor);
+  } else {
+    launch_values(traj, critic);
+    launch_value_targets(traj, critic, cfg->discount_factor);
+  }
+}
+
 int32_t rl_values_opt_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, const rl_values_opt_config *cfg,
                              rl_critic_stats *stats, float *losses_out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
-    check_critic(critic, traj);
-    RL_REQUIRE(opt && opt->mod == critic, "optimizer does not belong to this module");
-    RL_REQUIRE(cfg, "cfg is NULL");
-    RL_REQUIRE(cfg->target == RL_VALUE_TARGET_REWARD_TO_GO || cfg->target == RL_VALUE_TARGET_ONE_STEP_TD,
-               "unknown value target");
-    RL_REQUIRE(cfg->discount_factor >= 0.0f && cfg->discount_factor <= 1.0f, "discount factor must be in [0, 1]");
-    if (traj->td == nullptr) {
-      RL_HIP_CHECK(hipSetDevice(traj->eng->device));
-      traj->td = dalloc<float>((size_t)traj->d.T * traj->d.n);
-    }
-    // targets: once, from the critic as it stands now (tch::no_grad, opt.rs:101-104)
-    traj->d.tgt = traj->td;
-    if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO) {
-      launch_value_targets(traj, nullptr, cfg->discount_factor);
-    } else if (rl_module_is_recurrent(critic->kind)) {
-      seq_ensure(traj, critic, false);
-      launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
-      launch_seq_value_targets(traj, cfg->discount_factor);
-    } else if (critic->general) {
-      launch_gen_values(traj, critic);
-      launch_seq_value_targets(traj, cfg->discount_factor);
-    } else {
-      launch_values(traj, critic);
-      launch_value_targets(traj, critic, cfg->discount_factor);
-    }
+    check_values_opt(critic, opt, traj, cfg);
+    values_opt_targets(critic, traj, cfg);
     critic_opt_steps(critic, opt, traj, cfg->opt_steps_per_update, stats, losses_out);
+  });
+}
+
+// ---------------------------------------------------------------- policy and critic update side by side
+// The critic chain of rl_actor_critic_update runs on the engine's auxiliary stream with a workspace of its own (slab
+// rows, reduced vector) and the auxiliary collective channel: inside this scope every launcher — they all read
+// traj->eng->stream and the trajectory's workspace pointers at enqueue time — serves that chain.
+struct AuxChain {
+  rl_engine *e;
+  rl_traj *t;
+  AuxChain(rl_traj *traj) : e(traj->eng), t(traj) {
+    if (t->aux_vec == nullptr) {
+      RL_HIP_CHECK(hipSetDevice(e->device));
+      t->aux_vec = dalloc<float>(t->Pmax + 4);
+      t->aux_slabA = dalloc<double>(t->cap_slabA);
+      t->aux_slabB = dalloc<double>(t->cap_slabB);
+      t->aux_cap_slabA = t->cap_slabA;
+      t->aux_cap_slabB = t->cap_slabB;
+    }
+    swap();
+    e->stream = e->aux_stream;
+    e->chan = 1;
+  }
+  ~AuxChain() {
+    e->stream = e->main_stream;
+    e->chan = 0;
+    swap();
+  }
+  void swap() {
+    std::swap(t->vec, t->aux_vec);
+    std::swap(t->slabA, t->aux_slabA);
+    std::swap(t->slabB, t->aux_slabB);
+    std::swap(t->cap_slabA, t->aux_cap_slabA);
+    std::swap(t->cap_slabB, t->aux_cap_slabB);
+    std::swap(t->last_rows, t->aux_last_rows);
+  }
+};
+
+// may the two chains be in flight together?  Both must run on kernels that keep everything but the slab rows and the
+// reduced vector out of the trajectory's shared workspace (the fused single-launch passes), and a multi-rank job needs
+// a collective that can serve two streams at once: the mailbox channels, the second RCCL communicator, or one of the
+// host-blocking test transports (which serialise the chains on the host, correctly).
+static bool chains_can_overlap(const rl_mlp *policy, const rl_mlp *critic, const rl_traj *traj,
+                               const rl_values_opt_config *ccfg) {
+  const rl_engine *e = traj->eng;
+  if (std::getenv("RELEARN_SERIAL_UPDATE")) return false;
+  if (e->serial_update || e->kernel_variant == 1) return false;
+  (void)ccfg;
+  // (general hidden_sizes keep P-sized vectors and activation planes in workspaces both chains would share)
+  auto fused_passes = [&](const rl_mlp *m) {
+    return m->kind == RL_MODULE_MLP && !m->general && traj->d.D == 5 && m->hidden == 128;
+  };
+  if (!fused_passes(policy) || !fused_passes(critic)) return false;
+  if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // (the fused kernels' own limit)
+  if (e->comm != nullptr && e->comm_aux == nullptr) return false;
+  return true;
+}
+
+int32_t rl_actor_critic_update(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_opt, rl_traj *traj,
+                               const rl_trpo_config *pcfg, const rl_values_opt_config *ccfg, rl_trpo_stats *pstats,
+                               rl_critic_stats *cstats, float *critic_losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    check_policy(policy, traj);
+    RL_REQUIRE(pcfg && pstats, "NULL argument");
+    check_values_opt(critic, critic_opt, traj, ccfg);
+    RL_REQUIRE(policy != critic, "policy and critic must be different modules");
+    rl_engine *e = traj->eng;
+    const uint64_t K = ccfg->opt_steps_per_update;
+    if (!chains_can_overlap(policy, critic, traj, ccfg)) {
+      // policy.update, then critic.update (actor_critic.rs:196-208); the critic's targets do not depend on the policy
+      trpo_update_impl(policy, traj, pcfg, pstats);
+      values_opt_targets(critic, traj, ccfg);
+      critic_opt_steps(critic, critic_opt, traj, K, cstats, critic_losses_out);
+      trpo_raise_nan(pstats);
+      return;
+    }
+    // fork: the auxiliary stream sees everything enqueued so far (rollout, values, advantages)
+    RL_HIP_CHECK(hipEventRecord(e->ev_fork, e->main_stream));
+    RL_HIP_CHECK(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+    try {
+      {  // the whole critic chain is enqueued first: no host round trip in it
+        AuxChain aux(traj);
+        values_opt_targets(critic, traj, ccfg);
+        critic_enqueue_steps(critic, critic_opt, traj, K);
+      }
+      trpo_update_impl(policy, traj, pcfg, pstats);  // (its read-backs wait for the main stream only)
+    } catch (...) {
+      (void)hipStreamSynchronize(e->aux_stream);  // nothing of this update may still be running when the error returns
+      (void)hipStreamSynchronize(e->main_stream);
+      throw;
+    }
+    // join: later work on the main stream (the next rollout, values) follows the critic's last step
+    RL_HIP_CHECK(hipEventRecord(e->ev_join, e->aux_stream));
+    RL_HIP_CHECK(hipStreamWaitEvent(e->main_stream, e->ev_join, 0));
+    {
+      AuxChain aux(traj);  // (the losses were written by the auxiliary chain: read them on its stream)
+      critic_collect(traj, K, cstats, critic_losses_out);
+    }
+    if (!cstats && !critic_losses_out) RL_HIP_CHECK(hipStreamSynchronize(e->aux_stream));
+    trpo_raise_nan(pstats);
   });
 }
 

@@ -64,7 +64,7 @@ void ipc_teardown(rl_engine *e) {
   if (e->ipc_err) (void)hipFree(e->ipc_err);
   e->ipc_box = nullptr;
   e->ipc_err = nullptr;
-  e->ipc_seq = 0;
+  e->ipc_seq[0] = e->ipc_seq[1] = 0;
 }
 
 extern "C" {

@@ -16,7 +16,10 @@ constexpr uint64_t IPC_TIMEOUT_MS_DEFAULT = 30000;  // wall-clock bound of one w
 __host__ __device__ inline size_t ipc_word_off(uint32_t sender, uint32_t slot) {
   return ((size_t)sender * 2 + slot) * IPC_CAP;
 }
-inline size_t ipc_box_bytes(uint32_t n_ranks) { return (size_t)n_ranks * 2 * IPC_CAP * sizeof(uint64_t); }
+// a mailbox holds two channels (rl_engine::chan: the main and the auxiliary update chain may both have a collective in
+// flight), each with its own rows and its own sequence numbers
+inline size_t ipc_chan_words(uint32_t n_ranks) { return (size_t)n_ranks * 2 * IPC_CAP; }
+inline size_t ipc_box_bytes(uint32_t n_ranks) { return 2 * ipc_chan_words(n_ranks) * sizeof(uint64_t); }
 
 struct IpcPeers {
   float *box[RL_IPC_MAX_RANKS];  // box[r] = rank r's mailbox as seen from this process (box[rank] = the own one)
@@ -25,13 +28,14 @@ struct IpcPeers {
   uint64_t timeout_ticks;        // bound of one wait in ticks of the constant 100 MHz counter (s_memrealtime)
 };
 
-inline IpcPeers ipc_peers_next(rl_engine *e) {  // the descriptor of the engine's NEXT collective
+inline IpcPeers ipc_peers_next(rl_engine *e) {  // the descriptor of the NEXT collective of the engine's current channel
   IpcPeers p;
-  for (int r = 0; r < RL_IPC_MAX_RANKS; ++r) p.box[r] = r < e->n_ranks ? e->ipc_peer[r] : nullptr;
-  e->ipc_seq += 1;
+  const size_t chan_floats = 2 * ipc_chan_words((uint32_t)e->n_ranks) * (size_t)e->chan;  // (64-bit words)
+  for (int r = 0; r < RL_IPC_MAX_RANKS; ++r) p.box[r] = r < e->n_ranks ? e->ipc_peer[r] + chan_floats : nullptr;
+  e->ipc_seq[e->chan] += 1;
   p.rank = (uint32_t)e->rank;
   p.n_ranks = (uint32_t)e->n_ranks;
-  p.seq = e->ipc_seq;
+  p.seq = e->ipc_seq[e->chan];
   p.err = e->ipc_err;
   p.timeout_ticks = e->ipc_timeout_ticks;
   return p;

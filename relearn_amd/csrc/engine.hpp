@@ -109,6 +109,7 @@ struct TrpoStateDev {
   double ls_ratio;
   float ls_loss, ls_kl;  // last evaluated
   int32_t status;
+  int32_t prev_saved;  // k_step_size has saved the parameters: a rollback has something to restore
 };
 
 // ---- host-side handle structs ----------------------------------------------------------------------
@@ -119,7 +120,13 @@ constexpr int RL_IPC_MAX_RANKS = 16;
 
 struct rl_engine {
   int device = -1;
+  // `stream` is the stream every launcher enqueues on: the engine's main stream, or — inside an AuxChain scope
+  // (abi_update.hip: the critic chain of rl_actor_critic_update) — the auxiliary one.  `chan` names the collective
+  // channel that goes with it (0 main, 1 auxiliary): two chains in flight must not share a communicator / mailbox.
   hipStream_t stream = nullptr;
+  hipStream_t main_stream = nullptr, aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int chan = 0;
   hipDeviceProp_t prop{};
   std::string last_error;
   // timing
@@ -131,6 +138,8 @@ struct rl_engine {
   std::vector<hipEvent_t> prof_event_pool;
   // comm
   void *comm = nullptr;  // ncclComm_t
+  void *comm_aux = nullptr;  // a second communicator over the same ranks for the auxiliary chain (NULL: none — two chains
+                             // then run one after the other)
   struct LoopbackGroup *loopback = nullptr;  // in-process test collective (RELEARN_LOOPBACK_COMM=1)
   rl_host_allreduce_fn host_allreduce = nullptr;  // host-staged collective (rl_comm_init_host)
   void *host_allreduce_ctx = nullptr;
@@ -140,7 +149,7 @@ struct rl_engine {
   float *ipc_box = nullptr;
   float *ipc_peer[RL_IPC_MAX_RANKS] = {nullptr};
   int32_t *ipc_err = nullptr;
-  uint32_t ipc_seq = 0;
+  uint32_t ipc_seq[2] = {0, 0};  // per channel: each has its own half of every mailbox
   uint64_t ipc_timeout_ticks = 0;  // bound of one mailbox wait, 100 MHz ticks (RELEARN_IPC_TIMEOUT_MS)
   int ipc_box_ranks = 0, ipc_rank_of_box = -1;
   bool ipc_active = false;
@@ -158,6 +167,9 @@ struct rl_engine {
   bool zombie = false;
   // 0: best available kernels (MFMA v2 where the shape allows); 1: v1 reference kernels only
   int kernel_variant = 0;
+  // rl_actor_critic_update: run the policy chain and the critic chain one after the other on the main stream (what the
+  // separate entry points do) instead of side by side on two streams — for A/B measurements and per-kernel profiling
+  bool serial_update = false;
 };
 
 struct rl_env {
@@ -259,6 +271,11 @@ struct rl_traj {
   uint32_t nbA = 0, nbB = 0, nbV2 = 0, nbC = 0, Pmax = 0, max_losses = 0;
   uint32_t last_rows = 0;   // slab rows the last fused pass (launch_policy_v2 / launch_critic_step_v2) wrote
   uint64_t cap_slabA = 0, cap_slabB = 0;  // doubles allocated (traj_ensure_slabs grows them)
+  // the auxiliary chain's own copies (rl_actor_critic_update; swapped in by AuxChain, allocated on first use)
+  double *aux_slabA = nullptr, *aux_slabB = nullptr;
+  float *aux_vec = nullptr;
+  uint64_t aux_cap_slabA = 0, aux_cap_slabB = 0;
+  uint32_t aux_last_rows = 0;
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
   GenDev gen;

@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(SB) k_trpo_begin(const float *__restrict__ vec
     st->ls_index = -1;
     st->ls_ratio = 0.0;
     st->status = RL_OPT_OK;
+    st->prev_saved = 0;
   }
 }
 
@@ -390,6 +391,7 @@ __global__ void __launch_bounds__(SB) k_step_size(const float *__restrict__ vec,
     st->step_size = step_size;
     st->ls_loss = st->loss0;
     st->ls_kl = __builtin_inff();
+    st->prev_saved = 1;
     ss_shared = (float)step_size;
   }
   __syncthreads();
@@ -400,11 +402,19 @@ __global__ void __launch_bounds__(SB) k_step_size(const float *__restrict__ vec,
   }
 }
 
+// A failed collective (the sticky error word of the peer-mailbox transport, comm_ipc.hpp; NULL without that transport)
+// has left a vector of LOCAL sums behind: nothing computed from it may reach the parameters or the optimiser state.  The
+// kernels that write them test the word — a candidate is not set, the line search rolls back to the saved parameters,
+// an Adam step is skipped — and the host raises RL_ERR_COMM at its next synchronising call.
+__device__ __forceinline__ bool comm_failed(const int32_t *comm_err) {
+  return comm_err != nullptr && __hip_atomic_load(comm_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
 // param.copy_(prev_param - ratio * step) (conjugate_gradient.rs:204-213)
 __global__ void __launch_bounds__(SB) k_ls_set_params(float *__restrict__ params, const float *__restrict__ prev,
                                                       const float *__restrict__ descent, uint32_t P, float ratio,
-                                                      const TrpoStateDev *st) {
-  if (st->ls_accepted) return;
+                                                      const TrpoStateDev *st, const int32_t *comm_err) {
+  if (st->ls_accepted || comm_failed(comm_err)) return;
   for (uint32_t i = threadIdx.x; i < P; i += SB) params[i] = prev[i] - ratio * descent[i];
 }
 
@@ -426,8 +436,13 @@ __global__ void k_ls_check(const float *__restrict__ vec, uint32_t P, double inv
 // final classification + rollback (conjugate_gradient.rs:228-253)
 __global__ void __launch_bounds__(SB) k_ls_finalize(float *__restrict__ params, const float *__restrict__ prev,
                                                     uint32_t P, double max_kl, int accept_violation,
-                                                    TrpoStateDev *st) {
+                                                    TrpoStateDev *st, const int32_t *comm_err) {
   __shared__ int status_shared;
+  if (comm_failed(comm_err)) {  // (uniform) the update is void: back to the parameters it started from, if it got that far
+    if (st->prev_saved)
+      for (uint32_t i = threadIdx.x; i < P; i += SB) params[i] = prev[i];
+    return;
+  }
   if (threadIdx.x == 0) {
     double loss = (double)st->ls_loss, cval = (double)st->ls_kl, initial = (double)st->loss0;
     int status;
@@ -452,7 +467,8 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
                                                   uint32_t P, uint64_t step, float neg_step_size, float sqrt_bc2,
                                                   double beta1, double beta2, double eps, double weight_decay,
                                                   const float *__restrict__ loss_sum, double inv_B,
-                                                  float *__restrict__ loss_out) {
+                                                  float *__restrict__ loss_out, const int32_t *comm_err) {
+  if (comm_failed(comm_err)) return;  // `grad` holds local sums: no step, no step count
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *step_ptr = step;
     if (loss_out) *loss_out = (float)((double)(*loss_sum) * inv_B);
@@ -535,6 +551,9 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
 }
 
 // ---------------------------------------------------------------- launchers
+// the word a failed mailbox exchange sets (NULL when that transport is not in use)
+static const int32_t *comm_err_word(const rl_engine *e) { return e->ipc_active ? e->ipc_err : (const int32_t *)nullptr; }
+
 void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                         const int32_t *d_skip, float clip_lo, float clip_hi) {
   ProfScope ps(traj->eng, RL_K_POLICY_PASS);
@@ -628,7 +647,7 @@ void launch_step_size(rl_traj *traj, rl_mlp *policy, float reg, double max_kl) {
 void launch_ls_set_params(rl_traj *traj, rl_mlp *policy, double ratio) {
   ProfScope ps(traj->eng, RL_K_SMALL);
   hipLaunchKernelGGL(k_ls_set_params, dim3(1), dim3(SB), 0, traj->eng->stream, policy->d_params, traj->prev_params,
-                     traj->descent, (uint32_t)policy->P, (float)ratio, traj->trpo);
+                     traj->descent, (uint32_t)policy->P, (float)ratio, traj->trpo, comm_err_word(traj->eng));
 }
 
 void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, double ratio, double max_kl) {
@@ -640,7 +659,7 @@ void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, dou
 void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept_violation) {
   ProfScope ps(traj->eng, RL_K_SMALL);
   hipLaunchKernelGGL(k_ls_finalize, dim3(1), dim3(SB), 0, traj->eng->stream, policy->d_params, traj->prev_params,
-                     (uint32_t)policy->P, max_kl, accept_violation, traj->trpo);
+                     (uint32_t)policy->P, max_kl, accept_violation, traj->trpo, comm_err_word(traj->eng));
 }
 
 // bias corrections of the optimiser's NEXT step (advances the host's step count)
@@ -683,7 +702,7 @@ void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_tot
   hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, traj->eng->stream, opt->mod->d_params, traj->vec, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, traj->vec + P, 1.0 / (double)B_total,
-                     loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr);
+                     loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr, comm_err_word(traj->eng));
 }
 
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
@@ -693,5 +712,6 @@ void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
   adam_next_step(opt, &neg_step_size, &sqrt_bc2);
   hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
-                     opt->cfg.eps, opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr);
+                     opt->cfg.eps, opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr,
+                     (const int32_t *)nullptr);
 }

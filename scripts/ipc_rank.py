@@ -15,7 +15,8 @@ import relearn_amd as ra  # noqa: E402
 rank, world, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 n_total = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 T = int(sys.argv[5]) if len(sys.argv) > 5 else 48
-desert = len(sys.argv) > 6 and sys.argv[6] == "desert"
+desert = len(sys.argv) > 6 and sys.argv[6] in ("desert", "desert_trpo")
+desert_trpo = desert and sys.argv[6] == "desert_trpo"
 
 
 def wait_for(paths, what, limit=120.0):
@@ -52,16 +53,20 @@ if world > 1:
         traj = ra.Trajectory(eng, 64, 16, 5)
         ra.rollout(env, pol, traj)
         ra.gae(traj, cri, 0.99, 0.95)
-        before = cri.get_params()
+        before, before_pol = cri.get_params(), pol.get_params()
         t0 = time.time()
         try:
-            ra.critic_update(cri, opt, traj, 3)
+            if desert_trpo:  # stand-alone all-reduce launches: gradient, Fisher-vector products, line search
+                ra.trpo_update(pol, traj)
+            else:            # the exchange inside the reduce + Adam launch
+                ra.critic_update(cri, opt, traj, 3)
             eng.sync()
             sys.exit("rank %d: the update with a missing peer did not fail" % rank)
         except ra.RelearnError as err:
             assert err.code == ra.ERR_COMM, err
         first = time.time() - t0
         assert np.array_equal(cri.get_params(), before), "a failed exchange must not step the parameters"
+        assert np.array_equal(pol.get_params(), before_pol), "a failed exchange must not move the policy"
         t0 = time.time()
         try:
             eng.comm_selftest()
@@ -88,8 +93,13 @@ for period in range(2):
     if period == 0:
         out["action"] = traj.read(ra.TRAJ_ACTION)
         out["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
-    st = ra.trpo_update(pol, traj)
-    cs, losses = ra.critic_update(cri, opt, traj, 6, want_losses=True)
+    if period == 0:
+        st = ra.trpo_update(pol, traj)
+        cs, losses = ra.critic_update(cri, opt, traj, 6, want_losses=True)
+    else:  # the two chains side by side, each on its own half of the mailboxes
+        ccfg = ra.values_opt_config_default()
+        ccfg.opt_steps_per_update = 6
+        st, cs, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
     out["policy%d" % period] = pol.get_params()
     out["critic%d" % period] = cri.get_params()
     out["losses%d" % period] = losses

@@ -36,8 +36,15 @@ def run_rank(rank, world, uid, n_total, T, out, barrier):
         for period in range(2):
             ra.rollout(env, pol, traj)
             ra.gae(traj, cri, 0.99, 0.95)
-            st = ra.trpo_update(pol, traj)
-            cs, losses = ra.critic_update(cri, opt, traj, 10, want_losses=True)
+            # period 0: the two updates in turn; period 1: side by side on two streams, each chain with its own
+            # collective channel (rl_actor_critic_update) — identical replicas either way
+            if period == 0:
+                st = ra.trpo_update(pol, traj)
+                cs, losses = ra.critic_update(cri, opt, traj, 10, want_losses=True)
+            else:
+                ccfg = ra.values_opt_config_default()
+                ccfg.opt_steps_per_update = 10
+                st, cs, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
             res[period] = dict(action=traj.read(ra.TRAJ_ACTION), adv=traj.read(ra.TRAJ_ADVANTAGES),
                                policy=pol.get_params(), critic=cri.get_params(), trpo=st.as_dict(), losses=losses)
         # DQN on the same lanes: the minibatch size is summed over ranks, gradients all-reduced
@@ -293,12 +300,27 @@ def test_four_processes_over_the_peer_mailbox_collective(tmp_path):
     _check_sharded_against_single(_ipc_results(tmp_path, 4), single)
 
 
-def test_a_missing_peer_fails_the_mailbox_collective_without_touching_the_replica(tmp_path):
+def test_four_loopback_ranks_keep_identical_replicas():
+    """four ranks in the in-process group: after the sequential and after the two-stream update every rank holds the
+    same policy and critic, bit for bit"""
+    quad = launch(4, 512, 32)
+    for period in range(2):
+        for r in range(1, 4):
+            assert np.array_equal(quad[0][period]["policy"], quad[r][period]["policy"])
+            assert np.array_equal(quad[0][period]["critic"], quad[r][period]["critic"])
+        assert np.all(np.isfinite(quad[0][period]["losses"])) and quad[0][period]["trpo"]["status"] == ra.OPT_OK
+
+
+@pytest.mark.parametrize("what", ["desert", "desert_trpo"])
+def test_a_missing_peer_fails_the_mailbox_collective_without_touching_the_replica(tmp_path, what):
     """A rank that never joins a collective: the others' waits end at the wall-clock bound (here 1.5 s), the exchange
     returns before anything is stored — the critic's parameters are bit-identical to what they were —, the engine's
     error word is sticky (the next collective fails in milliseconds, not after another bound), and both surface as
     RL_ERR_COMM (comm_ipc.hpp)."""
-    _, outs = _run_ipc_ranks(tmp_path, 3, extra=("512", "48", "desert"), env_extra={"RELEARN_IPC_TIMEOUT_MS": "1500"},
+    # `desert_trpo`: the same through rl_trpo_update, whose all-reduces are launches of their own — the kernels that write
+    # parameters (line-search candidates, the final rollback) test the error word, so the policy is bit-identical to what
+    # it was although the vector held local sums (ADVICE round 3: comm_ipc.hip)
+    _, outs = _run_ipc_ranks(tmp_path, 3, extra=("512", "48", what), env_extra={"RELEARN_IPC_TIMEOUT_MS": "1500"},
                              limit=120)
     assert "deserted" in outs[2]
     for o in outs[:2]:

@@ -413,6 +413,51 @@ def test_critic_gradient_and_update_match_oracle(engine, variant):
     assert st.steps == steps
 
 
+@pytest.mark.parametrize("n,T,target", [(512, 64, ra.VALUE_TARGET_REWARD_TO_GO), (8192, 32, ra.VALUE_TARGET_REWARD_TO_GO),
+                                        (1024, 48, ra.VALUE_TARGET_ONE_STEP_TD)])
+def test_actor_critic_update_equals_the_two_updates_in_turn(engine, n, T, target):
+    """rl_actor_critic_update runs the TRPO chain and the critic chain side by side on two streams; each chain's
+    arithmetic and order are those of rl_trpo_update / rl_values_opt_update, so every number it produces — parameters,
+    optimiser moments (through a further step), statistics, the per-step losses — is BIT-identical to calling the two
+    one after the other (policy.update then critic.update, actor_critic.rs:196-208), over two periods, and identical
+    again with the chains forced onto one stream."""
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update, ccfg.target = 12, target
+
+    def run(mode):
+        env = ra.CartPoleEnv(engine, n, max_steps=60, seed_env=21, seed_actor=22)
+        pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+        pol.init(2)
+        cri.init(3)
+        opt = ra.Adam(cri)
+        traj = ra.Trajectory(engine, n, T, 5)
+        out = []
+        engine.set_serial_update(mode == "serial")
+        try:
+            for period in range(2):
+                ra.rollout(env, pol, traj)
+                ra.gae(traj, cri, 0.99, 0.95)
+                if mode == "separate":
+                    pst = ra.trpo_update(pol, traj)
+                    cst, losses = ra.values_opt_update(cri, opt, traj, ccfg, want_losses=True)
+                else:
+                    pst, cst, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
+                out.append((pol.get_params(), cri.get_params(), pst.as_dict(), (cst.loss_first, cst.loss_last, cst.steps),
+                            losses.copy(), traj.read(ra.TRAJ_TARGETS) if target == ra.VALUE_TARGET_ONE_STEP_TD else None))
+        finally:
+            engine.set_serial_update(False)
+        return out
+
+    ref = run("separate")
+    for mode in ("overlap", "serial"):
+        got = run(mode)
+        for (p0, c0, s0, k0, l0, t0), (p1, c1, s1, k1, l1, t1) in zip(ref, got):
+            assert np.array_equal(p0, p1) and np.array_equal(c0, c1), mode
+            assert s0 == s1 and k0 == k1 and np.array_equal(l0, l1), mode
+            assert t0 is None or np.array_equal(t0, t1)
+    assert ref[0][2]["status"] == ra.OPT_OK and ref[0][4][-1] < ref[0][4][0]
+
+
 def test_adam_step_matches_oracle(engine):
     m = ra.Mlp(engine, 5, H, 1)
     m.init(9)
@@ -473,10 +518,17 @@ def test_rccl_call_path_single_rank():
             opt = ra.Adam(critic)
             cst = ra.critic_update(critic, opt, traj, 5)
             results.append((policy.get_params(), critic.get_params(), st.step_size, cst.loss_last))
+            eng.profile_enable(True)
+            ra.critic_update(critic, opt, traj, 2)
+            assert eng.profile_read(reset=True)["allreduce"][1] == (2 if force else 0)  # the collective really ran
+            # the two chains side by side, each on its own communicator (rl_comm_init builds the second one through the
+            # first): 3 critic all-reduces on the auxiliary stream next to the TRPO chain's on the main stream
+            ccfg = ra.values_opt_config_default()
+            ccfg.opt_steps_per_update = 3
+            pst, cst2 = ra.actor_critic_update(policy, critic, opt, traj, None, ccfg)
             if force:
-                prof_on = eng.profile_enable(True)
-                ra.critic_update(critic, opt, traj, 2)
-                assert eng.profile_read()["allreduce"][1] == 2  # the collective really ran
+                assert eng.profile_read()["allreduce"][1] >= 3 + 1 + 11 + 1
+            results[-1] = results[-1] + (policy.get_params(), critic.get_params(), pst.step_size, cst2.loss_last)
             for o in (opt, traj, critic, policy):
                 o.close()
             eng.close()
@@ -484,3 +536,5 @@ def test_rccl_call_path_single_rank():
             os.environ.pop("RELEARN_FORCE_RCCL", None)
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
     assert results[0][2] == results[1][2] and results[0][3] == results[1][3]
+    assert np.array_equal(results[0][4], results[1][4]) and np.array_equal(results[0][5], results[1][5])
+    assert results[0][6] == results[1][6] and results[0][7] == results[1][7]
