@@ -90,6 +90,19 @@ def cpu_baseline(args):
     wall = time.time() - t0
     O.lib().oracle_adam_free(opt)
     steps = int(st.steps)
+    # HOT LOOP A alone, long enough to be a measurement: a short calibration run, then >= ~2.5 s of stepping on every
+    # thread (thread start-up outside the clock; buffers cleared every 8,192 steps)
+    pp2 = O.mlp_init(ps, 2)
+    got = C.c_uint64()
+    cal = O.lib().oracle_cartpole_rollout_only(1, cores, 20000, 8192, args.max_episode_steps, H, O.f32p(pp2), C.byref(got))
+    per_thread_ro = int(min(max(2.5 * 20000 / max(cal, 1e-6), 50000), 20_000_000))
+    for attempt in range(3):  # (the calibration run is cold: repeat with the measured rate until the leg lasts >= 2 s)
+        ro_s = O.lib().oracle_cartpole_rollout_only(2 + attempt, cores, per_thread_ro, 8192, args.max_episode_steps, H,
+                                                    O.f32p(pp2), C.byref(got))
+        if ro_s >= 2.0:
+            break
+        per_thread_ro = int(min(per_thread_ro * 2.6 / max(ro_s, 1e-3), 40_000_000))
+    ro_steps = int(got.value)
     return {
         "value": steps / (st.rollout_seconds + st.update_seconds),
         "unit": "env-steps/s",
@@ -100,8 +113,10 @@ def cpu_baseline(args):
                   "GAE + TRPO + %d Adam steps; rollout %.2f s, update %.2f s" % (
                       cores, per_thread, steps, int(st.episodes), args.critic_steps,
                       st.rollout_seconds, st.update_seconds),
-        "rollout_only_steps_per_s": steps / max(st.rollout_seconds, 1e-9),
-        "wall_s": wall,
+        "rollout_only_steps_per_s": ro_steps / max(ro_s, 1e-9),
+        "rollout_only_sample": "%d threads x %d scalar Steps::step steps in %.2f s (worker threads started before the "
+                               "clock)" % (cores, per_thread_ro, ro_s),
+        "wall_s": time.time() - t0,
     }
 
 

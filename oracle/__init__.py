@@ -312,6 +312,8 @@ def _declare(L):
                                          P(C.c_float), P(C.c_float)]
     L.oracle_critic_update_f32.argtypes = [MlpShape, P(C.c_float), P(AdamState), P(AdamCfg), P(C.c_float),
                                            P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float)]
+    L.oracle_grad_f64_mt.argtypes = [C.c_int, MlpShape, P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float),
+                                     P(C.c_float), C.c_uint64, P(C.c_double), P(C.c_double)]
 
     L.oracle_tabular_q_new.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double]
     L.oracle_tabular_q_new.restype = C.c_void_p
@@ -437,6 +439,9 @@ def _declare(L):
     L.oracle_exploration_rate.restype = C.c_double
     L.oracle_collection_update_size.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
     L.oracle_collection_update_size.restype = Bound
+    L.oracle_cartpole_rollout_only.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                               P(C.c_float), P(C.c_uint64)]
+    L.oracle_cartpole_rollout_only.restype = C.c_double
     L.oracle_cartpole_trpo_period.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
                                               C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_float), P(AdamState),
                                               C.c_uint64, P(PeriodStats)]
@@ -620,6 +625,24 @@ def flat_samples(traj):
     x = np.ascontiguousarray(obs[:, :T, :].reshape(D, T * n).T, dtype=np.float32)
     a = np.ascontiguousarray(traj["action"].reshape(T * n).astype(np.int64))
     return x, a
+
+
+def grad_f64_mt(kind, shape, params, x, actions=None, aux=None, v=None):
+    """f64 ground truth over all samples, OpenMP over chunks (oracle_grad_f64_mt): kind "policy" (surrogate gradient,
+    aux = advantages), "fvp" (Fisher-vector product with tangent v, no regulariser), "critic" (MSE gradient, aux =
+    targets); x [B][D] f32, actions [B] u8.  Returns (gradient f64 [P], loss f64)."""
+    k = {"policy": 0, "fvp": 1, "critic": 2}[kind]
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    g = np.zeros(len(params), dtype=np.float64)
+    loss = C.c_double(0.0)
+    keep = [np.ascontiguousarray(t, dtype=d) if t is not None else None
+            for t, d in ((actions, np.uint8), (aux, np.float32), (v, np.float32))]
+    ptr = lambda a, ct: _p(a, ct) if a is not None else None  # noqa: E731
+    lib().oracle_grad_f64_mt(k, shape, _p(params, C.c_float), _p(x, C.c_float), ptr(keep[0], C.c_uint8),
+                             ptr(keep[1], C.c_float), ptr(keep[2], C.c_float), n, _p(g, C.c_double), C.byref(loss))
+    return g, loss.value
 
 
 def u32p(a):

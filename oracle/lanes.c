@@ -326,6 +326,74 @@ static double now_s(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* HOT LOOP A alone, long enough to time: every worker thread runs `steps_per_thread` scalar Steps::step calls
+ * (steps.rs:113-167; PolicyActor::act as a batch-1 MLP forward) into its own VecBuffer, which is cleared every
+ * `clear_every` steps (a period's worth: memory stays bounded).  Returns the wall time of the stepping (threads started
+ * before the clock) and the total number of steps taken. */
+double oracle_cartpole_rollout_only(uint64_t seed, uint32_t n_threads, uint64_t steps_per_thread, uint64_t clear_every,
+                                    uint64_t max_steps, uint32_t hidden, const float *policy_params,
+                                    uint64_t *steps_out) {
+  oracle_cartpole env;
+  oracle_cartpole_default(&env);
+  oracle_mlp_shape ps = {5, hidden, 2};
+  oracle_prng *t_env = (oracle_prng *)malloc(n_threads * sizeof(oracle_prng));
+  oracle_prng *t_agent = (oracle_prng *)malloc(n_threads * sizeof(oracle_prng));
+  uint64_t *counts = (uint64_t *)calloc(n_threads, sizeof(uint64_t));
+  oracle_prng root, rng_env;
+  oracle_prng_seed_from_u64(&root, seed);
+  oracle_prng_from_rng(&rng_env, &root);
+  for (uint32_t i = 0; i < n_threads; ++i) {
+    oracle_prng_from_rng(&t_env[i], &rng_env);
+    oracle_prng_from_rng(&t_agent[i], &root);
+  }
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+  { (void)omp_get_thread_num(); }
+#endif
+  double t0 = now_s();
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+#endif
+  for (uint32_t i = 0; i < n_threads; ++i) {
+    oracle_vecbuffer *buf = oracle_vecbuffer_new(5);
+    int have_state = 0;
+    oracle_cartpole_state s;
+    uint64_t remaining = 0;
+    float f[5], nf[5];
+    for (uint64_t n = 0; n < steps_per_thread; ++n) {
+      if (!have_state) {
+        oracle_cartpole_initial_state(&env, &t_env[i], &s);
+        remaining = max_steps;
+        have_state = 1;
+      }
+      oracle_cartpole_features(&s, ORACLE_LIMIT_VISIBLE, remaining, max_steps, f);
+      float u = oracle_prng_gen_f32(&t_agent[i]);
+      int a = policy_act(ps, policy_params, f, u);
+      double r;
+      int succ = oracle_cartpole_step(&env, &s, a, &r);
+      succ = oracle_step_limit_apply(succ, &remaining);
+      const float *np = NULL;
+      if (succ == ORACLE_INTERRUPT) {
+        oracle_cartpole_features(&s, ORACLE_LIMIT_VISIBLE, remaining, max_steps, nf);
+        np = nf;
+      }
+      if (succ != ORACLE_CONTINUE) have_state = 0;
+      oracle_vecbuffer_write_step(buf, f, a, r, succ, np);
+      counts[i] += 1;
+      if (clear_every && (n + 1) % clear_every == 0) oracle_vecbuffer_clear(buf);
+    }
+    oracle_vecbuffer_free(buf);
+  }
+  double secs = now_s() - t0;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n_threads; ++i) total += counts[i];
+  if (steps_out) *steps_out = total;
+  free(counts);
+  free(t_env);
+  free(t_agent);
+  return secs;
+}
+
 void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
                                  uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
                                  float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
@@ -347,6 +415,12 @@ void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t 
     oracle_prng_from_rng(&t_agent[i], &root);
     buffers[i] = oracle_vecbuffer_new(5);
   }
+#ifdef _OPENMP
+  /* the worker threads exist before the clock starts (train_parallel's threads are spawned per period, train.rs:124;
+   * what is timed here is their stepping, not the OpenMP runtime's pool start-up) */
+#pragma omp parallel num_threads(n_threads)
+  { (void)omp_get_thread_num(); }
+#endif
   double t0 = now_s();
   uint64_t n_take_max = steps_per_thread + slack_steps;
 #ifdef _OPENMP

@@ -259,6 +259,82 @@ void oracle_critic_grad_f32(oracle_mlp_shape s, const float *params, const float
   free(g);
 }
 
+/* ---- f64 ground truth over MANY samples (full-size parity: 65,536 lanes x 128 steps = 8.4 M samples), OpenMP over
+ * chunks of samples.  Inputs in the device's f32 storage (converted per chunk); every chunk runs the single-threaded
+ * f64 functions above on its samples, and the chunk results — means over the chunk — are combined with their sample
+ * weights in f64.  Chunk order does not matter at f64 resolution for the 1e-6 comparisons these serve. */
+#define ORACLE_MT_CHUNK 4096
+static void critic_grad_f64_chunk(oracle_mlp_shape s, const double *params, const double *obs, const double *targets,
+                                  uint64_t n, double *grad_out, double *loss_out) {
+  mlp_view_f64 m = view_f64(s, params);
+  uint64_t P = oracle_mlp_num_params(s);
+  double *pre = (double *)malloc(sizeof(double) * (2 * m.H + 2));
+  double *h = pre + m.H, *z = h + m.H, *dz = z + 1;
+  double loss = 0.0;
+  for (uint64_t i = 0; i < P; ++i) grad_out[i] = 0.0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const double *x = obs + i * m.D;
+    mlp_fwd_f64(&m, x, pre, h, z);
+    double d = z[0] - targets[i];
+    loss += d * d;
+    dz[0] = d * (2.0 / (double)n);
+    mlp_bwd_acc_f64(&m, x, pre, h, dz, grad_out);
+  }
+  *loss_out = loss / (double)n;
+  free(pre);
+}
+
+/* kind 0: policy surrogate gradient (aux = advantages; loss_out = -mean(A) at ratio 1), 1: Fisher-vector product with
+ * tangent v (no reg term; loss_out untouched), 2: critic MSE gradient (aux = targets; loss_out = mean squared error) */
+void oracle_grad_f64_mt(int kind, oracle_mlp_shape s, const float *params, const float *obs, const uint8_t *actions,
+                        const float *aux, const float *v, uint64_t n, double *grad_out, double *loss_out) {
+  const uint64_t P = oracle_mlp_num_params(s), D = s.in_dim;
+  const uint64_t n_chunks = (n + ORACLE_MT_CHUNK - 1) / ORACLE_MT_CHUNK;
+  double *pd = (double *)malloc(sizeof(double) * 2 * P);
+  double *vd = pd + P;
+  for (uint64_t i = 0; i < P; ++i) {
+    pd[i] = (double)params[i];
+    vd[i] = v ? (double)v[i] : 0.0;
+  }
+  for (uint64_t i = 0; i < P; ++i) grad_out[i] = 0.0;
+  double loss_total = 0.0;
+#pragma omp parallel
+  {
+    double *g = (double *)calloc(2 * P, sizeof(double));
+    double *gc = g + P;
+    double *x = (double *)malloc(sizeof(double) * ORACLE_MT_CHUNK * (D + 1));
+    double *a = x + ORACLE_MT_CHUNK * D;
+    int64_t *act = (int64_t *)malloc(sizeof(int64_t) * ORACLE_MT_CHUNK);
+    double loss = 0.0;
+#pragma omp for schedule(dynamic, 1)
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+      const uint64_t lo = c * ORACLE_MT_CHUNK, m = (lo + ORACLE_MT_CHUNK <= n ? ORACLE_MT_CHUNK : n - lo);
+      for (uint64_t i = 0; i < m * D; ++i) x[i] = (double)obs[lo * D + i];
+      for (uint64_t i = 0; i < m; ++i) {
+        a[i] = aux ? (double)aux[lo + i] : 0.0;
+        act[i] = actions ? (int64_t)actions[lo + i] : 0;
+      }
+      double l = 0.0;
+      if (kind == 0) oracle_policy_grad_f64(s, pd, x, act, a, m, gc, &l);
+      else if (kind == 1) oracle_policy_fvp_f64(s, pd, x, m, vd, 0.0, gc);
+      else critic_grad_f64_chunk(s, pd, x, a, m, gc, &l);
+      const double w = (double)m / (double)n;  /* chunk mean -> its share of the full mean */
+      for (uint64_t i = 0; i < P; ++i) g[i] += w * gc[i];
+      loss += w * l;
+    }
+#pragma omp critical
+    {
+      for (uint64_t i = 0; i < P; ++i) grad_out[i] += g[i];
+      loss_total += loss;
+    }
+    free(act);
+    free(x);
+    free(g);
+  }
+  if (loss_out) *loss_out = loss_total;
+  free(pd);
+}
+
 /* ValuesOpt::update via n_backward_steps (critics/opt.rs:100-126; torch/agents/mod.rs:35-72;
  * COptimizer::backward_step coptimizer.rs:14-26) */
 void oracle_critic_update_f32(oracle_mlp_shape s, float *params, oracle_adam_state *st, const oracle_adam_cfg *cfg,

@@ -263,6 +263,10 @@ oracle_adam_state *oracle_adam_new(uint64_t n);
 void oracle_adam_free(oracle_adam_state *st);
 void oracle_adam_step_f32(oracle_adam_state *st, const oracle_adam_cfg *cfg, float *params, const float *grad);
 
+/* f64 ground truth over millions of samples (OpenMP over chunks): kind 0 policy gradient, 1 Fisher-vector product
+ * (no regulariser), 2 critic MSE gradient; inputs in the device's f32 storage, obs [n][D], results in f64 */
+void oracle_grad_f64_mt(int kind, oracle_mlp_shape s, const float *params, const float *obs, const uint8_t *actions,
+                        const float *aux, const float *v, uint64_t n, double *grad_out, double *loss_out);
 void oracle_critic_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const float *targets,
                             uint64_t n, float *grad_out, float *loss_out);
 /* n_steps x {mse; backward; adam}; losses_out[n_steps] = loss BEFORE each step (opt.rs:100-126) */
@@ -473,6 +477,9 @@ typedef struct {
 /* One train_parallel period of CartPole+VisibleStepLimit MLP-TRPO: `n_threads` OS threads each run the
  * scalar Steps::step loop for `steps_per_thread` steps (TakeAlignedSteps with slack), then the calling
  * thread does GAE -> TRPO -> critic update on the packed batch. */
+double oracle_cartpole_rollout_only(uint64_t seed, uint32_t n_threads, uint64_t steps_per_thread, uint64_t clear_every,
+                                    uint64_t max_steps, uint32_t hidden, const float *policy_params,
+                                    uint64_t *steps_out);
 void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
                                  uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
                                  float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,

@@ -71,6 +71,103 @@ def test_full_size_sharding_invariance_and_gradient_linearity(engine, full):
     assert abs(0.5 * (halves[0][2] + halves[1][2]) - ent) < 1e-6
 
 
+def test_full_size_update_kernels_against_the_f64_oracle(engine, full):
+    """The update kernels at the size the bench runs them — 65,536 x 128 = 8.39 M samples: 256 persistent workgroups,
+    1,024 tiles per wave, 16 f32 -> f64 flushes per wave — against the oracle's f64 ground truth over ALL samples
+    (oracle_grad_f64_mt: the f64 functions of oracle/nn_impl.inc, OpenMP over chunks): surrogate gradient, one
+    Fisher-vector product, critic gradient; the tolerance of tests/test_gpu_parity.py (1e-6 of the vector's largest
+    entry).  Reference: trpo.rs:124-131, conjugate_gradient.rs:312-338, critics/opt.rs:109-115."""
+    x, a = O.flat_samples(full["data"])
+    adv, rtg = full["adv"].reshape(-1), full["rtg"].reshape(-1)
+    pp, cp = full["pol"].get_params(), full["cri"].get_params()
+    assert len(a) == N * T
+    g_d, loss_d, ent_d = ra.policy_gradient(full["pol"], full["traj"])
+    g64, l64 = O.grad_f64_mt("policy", PS, pp, x, a.astype(np.uint8), adv)
+    assert rel_err(g_d, g64) < 1e-6
+    assert abs(loss_d - l64) <= 1e-6 * max(1.0, abs(l64))
+    v = np.random.default_rng(7).standard_normal(len(pp)).astype(np.float32)
+    h_d = ra.policy_fvp(full["pol"], full["traj"], v, 0.0)
+    h64, _ = O.grad_f64_mt("fvp", PS, pp, x, v=v)
+    assert rel_err(h_d, h64) < 1e-6
+    gc_d, lc_d = ra.critic_gradient(full["cri"], full["traj"])
+    gc64, lc64 = O.grad_f64_mt("critic", CS, cp, x, aux=rtg)
+    assert rel_err(gc_d, gc64) < 1e-6
+    assert abs(lc_d - lc64) <= 1e-6 * lc64
+
+
+def test_critic_adam_steps_at_one_ranks_share_against_the_f32_oracle(engine):
+    """five full-batch Adam steps of the critic on 8,192 x 128 samples (one rank's share of the headline at 8 GPUs)
+    against oracle_critic_update_f32 — per-step losses and the parameters, tolerances of
+    tests/test_gpu_parity.py::test_critic_gradient_and_update_match_oracle.  Reference: critics/opt.rs:100-126,
+    torch/agents/mod.rs:35-72, optimizers/coptimizer.rs:158-167."""
+    import ctypes as C
+    n, steps = 8192, 5
+    env = ra.CartPoleEnv(engine, n, max_steps=500, seed_env=0, seed_actor=1)
+    pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+    pol.init(2)
+    cri.init(3)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    x, _ = O.flat_samples(traj.read_all())
+    rtg = np.ascontiguousarray(traj.read(ra.TRAJ_RETURNS).reshape(-1))
+    cp = cri.get_params()
+    st, losses_d = ra.critic_update(cri, ra.Adam(cri), traj, steps, want_losses=True)
+    ad = O.lib().oracle_adam_new(len(cp))
+    ac = O.AdamCfg()
+    O.lib().oracle_adam_cfg_default(C.byref(ac))
+    losses_o = np.zeros(steps, dtype=np.float32)
+    c_o = cp.copy()
+    O.lib().oracle_critic_update_f32(CS, O.f32p(c_o), ad, C.byref(ac), O.f32p(x), O.f32p(rtg), len(rtg), steps,
+                                     O.f32p(losses_o))
+    O.lib().oracle_adam_free(ad)
+    assert np.allclose(losses_d, losses_o, rtol=1e-4)
+    assert np.abs(cri.get_params() - c_o).max() < 2e-5 + 1e-3 * steps * 1e-3
+    assert losses_d[-1] < losses_d[0] and st.steps == steps
+
+
+def test_general_mlp_pair_kernel_at_size_against_f64(engine):
+    """`[64, 64]` modules (k_gen_pair, kernels_gen_mfma.hip) at 16,384 x 128 = 2.1 M samples against an f64 NumPy
+    restatement evaluated in chunks: surrogate gradient, Fisher-vector product, critic gradient; tolerances of
+    tests/test_gpu_general_mlp.py::test_gradients_and_fisher_vector_products.  Reference: ff/mlp.rs:139-151."""
+    from test_gpu_general_mlp import backward64, forward64, jvp64, unflatten
+    n, hidden = 16384, [64, 64]
+    pol, cri = ra.Mlp(engine, 5, hidden, 2), ra.Mlp(engine, 5, hidden, 1)
+    pol.init(21)
+    cri.init(22)
+    env = ra.CartPoleEnv(engine, n, max_steps=500, seed_env=3, seed_actor=4)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    tr = traj.read_all()
+    B = n * T
+    x = np.ascontiguousarray(tr["obs"][:, :T, :].reshape(5, B).T)
+    a = tr["action"].reshape(-1).astype(np.int64)
+    adv = traj.read(ra.TRAJ_ADVANTAGES).reshape(-1).astype(np.float64)
+    rtg = traj.read(ra.TRAJ_RETURNS).reshape(-1).astype(np.float64)
+    pnet, cnet = unflatten(pol.get_params(), 5, hidden, 2), unflatten(cri.get_params(), 5, hidden, 1)
+    vec = np.random.default_rng(5).normal(size=pol.P).astype(np.float32)
+    tnet = unflatten(vec, 5, hidden, 2)
+    want, fwant, cwant = np.zeros(pol.P), np.zeros(pol.P), np.zeros(cri.P)
+    for lo in range(0, B, 1 << 17):
+        sl = slice(lo, min(B, lo + (1 << 17)))
+        z, acts = forward64(pnet, x[sl])
+        zmax = z.max(axis=1, keepdims=True)
+        lp = z - zmax - np.log(np.exp(z - zmax).sum(axis=1, keepdims=True))
+        p = np.exp(lp)
+        want += backward64(pnet, x[sl], acts, -(adv[sl, None]) * (np.eye(2)[a[sl]] - p) / B)
+        _, tz = jvp64(pnet, tnet, x[sl])
+        fwant += backward64(pnet, x[sl], acts, p * (tz - (p * tz).sum(axis=1, keepdims=True)) / B)
+        v, cacts = forward64(cnet, x[sl])
+        cwant += backward64(cnet, x[sl], cacts, 2.0 * (v - rtg[sl, None]) / B)
+    got = ra.policy_gradient(pol, traj)[0]
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max() + 1e-9
+    fgot = ra.policy_fvp(pol, traj, vec, 0.0)
+    assert np.abs(fgot - fwant).max() <= 5e-5 * np.abs(fwant).max() + 1e-9
+    cgot = ra.critic_gradient(cri, traj)[0]
+    assert np.abs(cgot - cwant).max() <= 2e-5 * np.abs(cwant).max() + 1e-9
+
+
 def test_full_size_return_scan_properties(engine, full):
     """gamma = 1 with unit rewards: the return is the number of steps to the end of the lane's episode segment;
     returns restart after every episode end; scaling gamma * lambda to 0 makes advantages one-step residuals"""
