@@ -314,6 +314,7 @@ def _declare(L):
                                            P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float)]
     L.oracle_grad_f64_mt.argtypes = [C.c_int, MlpShape, P(C.c_float), P(C.c_float), P(C.c_uint8), P(C.c_float),
                                      P(C.c_float), C.c_uint64, P(C.c_double), P(C.c_double)]
+    L.oracle_grad_f32_mt.argtypes = L.oracle_grad_f64_mt.argtypes
 
     L.oracle_tabular_q_new.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double]
     L.oracle_tabular_q_new.restype = C.c_void_p
@@ -627,10 +628,11 @@ def flat_samples(traj):
     return x, a
 
 
-def grad_f64_mt(kind, shape, params, x, actions=None, aux=None, v=None):
+def grad_f64_mt(kind, shape, params, x, actions=None, aux=None, v=None, f32_samples=False):
     """f64 ground truth over all samples, OpenMP over chunks (oracle_grad_f64_mt): kind "policy" (surrogate gradient,
     aux = advantages), "fvp" (Fisher-vector product with tangent v, no regulariser), "critic" (MSE gradient, aux =
-    targets); x [B][D] f32, actions [B] u8.  Returns (gradient f64 [P], loss f64)."""
+    targets); x [B][D] f32, actions [B] u8.  Returns (gradient f64 [P], loss f64).  f32_samples: the per-sample
+    arithmetic of the f32 oracle functions instead (chunk sums still in f64) — a correct f32 evaluation as yardstick."""
     k = {"policy": 0, "fvp": 1, "critic": 2}[kind]
     params = np.ascontiguousarray(params, dtype=np.float32)
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -640,7 +642,8 @@ def grad_f64_mt(kind, shape, params, x, actions=None, aux=None, v=None):
     keep = [np.ascontiguousarray(t, dtype=d) if t is not None else None
             for t, d in ((actions, np.uint8), (aux, np.float32), (v, np.float32))]
     ptr = lambda a, ct: _p(a, ct) if a is not None else None  # noqa: E731
-    lib().oracle_grad_f64_mt(k, shape, _p(params, C.c_float), _p(x, C.c_float), ptr(keep[0], C.c_uint8),
+    fn = lib().oracle_grad_f32_mt if f32_samples else lib().oracle_grad_f64_mt
+    fn(k, shape, _p(params, C.c_float), _p(x, C.c_float), ptr(keep[0], C.c_uint8),
                              ptr(keep[1], C.c_float), ptr(keep[2], C.c_float), n, _p(g, C.c_double), C.byref(loss))
     return g, loss.value
 

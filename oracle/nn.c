@@ -286,8 +286,23 @@ static void critic_grad_f64_chunk(oracle_mlp_shape s, const double *params, cons
 
 /* kind 0: policy surrogate gradient (aux = advantages; loss_out = -mean(A) at ratio 1), 1: Fisher-vector product with
  * tangent v (no reg term; loss_out untouched), 2: critic MSE gradient (aux = targets; loss_out = mean squared error) */
+static void grad_mt(int kind, int f32_samples, oracle_mlp_shape s, const float *params, const float *obs,
+                    const uint8_t *actions, const float *aux, const float *v, uint64_t n, double *grad_out,
+                    double *loss_out);
 void oracle_grad_f64_mt(int kind, oracle_mlp_shape s, const float *params, const float *obs, const uint8_t *actions,
                         const float *aux, const float *v, uint64_t n, double *grad_out, double *loss_out) {
+  grad_mt(kind, 0, s, params, obs, actions, aux, v, n, grad_out, loss_out);
+}
+/* the same with the per-sample arithmetic of the f32 oracle functions (engine transcendentals, f32 fma chains; sums over a
+ * chunk in f64, rounded to f32 per chunk, chunks combined in f64): what a correct f32 evaluation of the pass gives at
+ * this sample count — the yardstick for the device's distance from the f64 truth */
+void oracle_grad_f32_mt(int kind, oracle_mlp_shape s, const float *params, const float *obs, const uint8_t *actions,
+                        const float *aux, const float *v, uint64_t n, double *grad_out, double *loss_out) {
+  grad_mt(kind, 1, s, params, obs, actions, aux, v, n, grad_out, loss_out);
+}
+static void grad_mt(int kind, int f32_samples, oracle_mlp_shape s, const float *params, const float *obs,
+                    const uint8_t *actions, const float *aux, const float *v, uint64_t n, double *grad_out,
+                    double *loss_out) {
   const uint64_t P = oracle_mlp_num_params(s), D = s.in_dim;
   const uint64_t n_chunks = (n + ORACLE_MT_CHUNK - 1) / ORACLE_MT_CHUNK;
   double *pd = (double *)malloc(sizeof(double) * 2 * P);
@@ -315,7 +330,18 @@ void oracle_grad_f64_mt(int kind, oracle_mlp_shape s, const float *params, const
         act[i] = actions ? (int64_t)actions[lo + i] : 0;
       }
       double l = 0.0;
-      if (kind == 0) oracle_policy_grad_f64(s, pd, x, act, a, m, gc, &l);
+      if (f32_samples) {
+        float *gf = (float *)malloc(sizeof(float) * P);
+        float lf = 0.0f;
+        static const float zero_adv = 0.0f;
+        (void)zero_adv;
+        if (kind == 0) oracle_policy_grad_f32(s, params, obs + lo * D, act, aux + lo, m, gf, &lf);
+        else if (kind == 1) oracle_policy_fvp_f32(s, params, obs + lo * D, m, v, 0.0f, gf);
+        else oracle_critic_grad_f32(s, params, obs + lo * D, aux + lo, m, gf, &lf);
+        for (uint64_t i = 0; i < P; ++i) gc[i] = (double)gf[i];
+        l = (double)lf;
+        free(gf);
+      } else if (kind == 0) oracle_policy_grad_f64(s, pd, x, act, a, m, gc, &l);
       else if (kind == 1) oracle_policy_fvp_f64(s, pd, x, m, vd, 0.0, gc);
       else critic_grad_f64_chunk(s, pd, x, a, m, gc, &l);
       const double w = (double)m / (double)n;  /* chunk mean -> its share of the full mean */

@@ -267,6 +267,8 @@ void oracle_adam_step_f32(oracle_adam_state *st, const oracle_adam_cfg *cfg, flo
  * (no regulariser), 2 critic MSE gradient; inputs in the device's f32 storage, obs [n][D], results in f64 */
 void oracle_grad_f64_mt(int kind, oracle_mlp_shape s, const float *params, const float *obs, const uint8_t *actions,
                         const float *aux, const float *v, uint64_t n, double *grad_out, double *loss_out);
+void oracle_grad_f32_mt(int kind, oracle_mlp_shape s, const float *params, const float *obs, const uint8_t *actions,
+                        const float *aux, const float *v, uint64_t n, double *grad_out, double *loss_out);
 void oracle_critic_grad_f32(oracle_mlp_shape s, const float *params, const float *obs, const float *targets,
                             uint64_t n, float *grad_out, float *loss_out);
 /* n_steps x {mse; backward; adam}; losses_out[n_steps] = loss BEFORE each step (opt.rs:100-126) */

@@ -107,6 +107,30 @@ __device__ __forceinline__ float row_sum16(const float *row) {
   for (int c = 4; c < 16; ++c) a[c & 3] = a[c & 3] + row[c];
   return (a[0] + a[1]) + (a[2] + a[3]);
 }
+// the same from a 16-byte aligned row (rows of YROW floats: four ds_read_b128 instead of eight ds_read2_b32, and the
+// 144-byte row stride keeps the four lane groups of a b128 read on distinct banks: scripts/lds_conflicts.py)
+constexpr int YROW = 36;
+__device__ __forceinline__ float row_sum16v(const float *row) {
+  const float4 *v = reinterpret_cast<const float4 *>(row);
+  const float4 q0 = v[0], q1 = v[1], q2 = v[2], q3 = v[3];
+  const float a0 = ((q0.x + q1.x) + q2.x) + q3.x, a1 = ((q0.y + q1.y) + q2.y) + q3.y;
+  const float a2 = ((q0.z + q1.z) + q2.z) + q3.z, a3 = ((q0.w + q1.w) + q2.w) + q3.w;
+  return (a0 + a1) + (a2 + a3);
+}
+
+// ---- tile operands through buffer loads: a raw buffer resource over a device array (loads past `bytes` return 0), a
+// per-lane byte offset that never changes and the tile's byte offset in an SGPR — no vector address arithmetic per tile
+// (64-bit global addresses cost ~15 vector instructions per tile in these kernels' loops)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(rsrc_t r, uint32_t lane_off, uint32_t tile_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)tile_off, 0));
+}
+__device__ __forceinline__ uint32_t buf_u8(rsrc_t r, uint32_t lane_off, uint32_t tile_off) {
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, (int)lane_off, (int)tile_off, 0);
+}
 
 union Frag {
   bf16x8 v;

@@ -92,10 +92,12 @@ __device__ __forceinline__ void cp_reset(const CartPoleDev &c, LaneState &s, uin
   uint32_t w[16];
   uint32_t k = s.reset_count;
   rl_chacha_block(c.key_env, (uint64_t)(k >> 1), global_lane, 4, w);
-  bool hi = (k & 1u) != 0;
+  // the upper or the lower half of the block by a bit select per word (v_bfi_b32): an index that depends on the lane
+  // would put the block into scratch memory
+  const uint32_t hi = 0u - (k & 1u);
   uint32_t v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = hi ? w[8 + i] : w[i];
+  for (int i = 0; i < 8; ++i) v[i] = (w[8 + i] & hi) | (w[i] & ~hi);
   s.x = rl_uniform_f64_from_u64(((uint64_t)v[1] << 32) | v[0], c.init_low, c.init_scale);
   s.xdot = rl_uniform_f64_from_u64(((uint64_t)v[3] << 32) | v[2], c.init_low, c.init_scale);
   s.th = rl_uniform_f64_from_u64(((uint64_t)v[5] << 32) | v[4], c.init_low, c.init_scale);

@@ -17,6 +17,8 @@
 // loses here: 0.259 against 0.219 ms per step; this kernel has one |pre| chain to replace, not a second layer-1 product
 // with its LDS-resident operands, and 16 more matrix instructions per tile push it against the matrix pipe.)
 // Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2 x backward of the 5-128-1 MLP).
+#include <type_traits>
+
 #include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
@@ -34,10 +36,11 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
                        double *__restrict__ slabB, float two_over_B, uint32_t P) {
   constexpr int D = 5, H = 128, NT = bt::NT;
   constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] (slot 6 unused); then db2, loss
-  __shared__ float Ysh[CRITIC_WAVES][32][33];
+  __shared__ __attribute__((aligned(16))) float Ysh[CRITIC_WAVES][32][bt::YROW];
   __shared__ double Acc[CRITIC_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: tile indices stay scalar
   const int n = lane & 31, hf = lane >> 5;
   const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H;
   const float b2 = W2[H];
@@ -80,39 +83,42 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 
   Frag selb[2];  // piece-column selection (B operand of the routing product)
   bt::sel_frags(lane, selb);
-  const size_t n_tiles = (B + 31) / 32;
-  const size_t wave_id = (size_t)blockIdx.x * CRITIC_WAVES + wave, n_waves = (size_t)gridDim.x * CRITIC_WAVES;
+  // Tiles: the full ones in the loop, a ragged last one (B not a multiple of 32) after it on the wave whose turn it
+  // is, through the same code with a per-lane `valid` — the loop itself carries no validity selects.  Tile indices are
+  // wave-uniform (SGPRs); the operands come through buffer loads with a constant per-lane byte offset and the tile's
+  // offset as the scalar operand: no vector address arithmetic per tile.
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
+  const uint32_t n_full = B32 / 32u, tail = B32 & 31u;
+  const uint32_t wave_id = blockIdx.x * CRITIC_WAVES + (uint32_t)wave, n_waves = gridDim.x * CRITIC_WAVES;
+  const bt::rsrc_t obs_r = bt::make_rsrc(tr.obs, (uint32_t)D * plane32 * 4u), tgt_r = bt::make_rsrc(tr.tgt, B32 * 4u);
+  const uint32_t off_a = ((uint32_t)(2 * hf) * plane32 + (uint32_t)n) * 4u, off_b = off_a + plane32 * 4u;
+  const uint32_t off_c = (4u * plane32 + (uint32_t)n) * 4u, off_t = (uint32_t)n * 4u;
   int since_flush = 0;
   // per lane: features 2 hf, 2 hf + 1 and 4 of sample n, and its target
   struct TileOp {
     float xa, xb, xc, tgt;
-    bool valid;
   };
-  // branch-free (padding lanes read sample B - 1 and are zeroed): the loads of tile i + 1 stay in flight across tile i
-  // (32-bit element offsets from the uniform base pointers: a launch covers < 2^30 samples, checked by the launcher)
-  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
-  auto load_tile = [&](size_t g) {
+  auto load_tile = [&](uint32_t g) {  // g: wave-uniform tile index (< 2^25: the launcher bounds the element count)
     TileOp o;
-    const uint32_t sidx = (uint32_t)g * 32u + (uint32_t)n;
-    o.valid = g < n_tiles && sidx < B32;
-    const uint32_t sc = o.valid ? sidx : B32 - 1;
-    const float xa = tr.obs[(uint32_t)(2 * hf) * plane32 + sc], xb = tr.obs[(uint32_t)(2 * hf + 1) * plane32 + sc];
-    const float xc = tr.obs[4u * plane32 + sc], tg = tr.tgt[sc];
-    o.xa = o.valid ? xa : 0.0f;
-    o.xb = o.valid ? xb : 0.0f;
-    o.xc = o.valid ? xc : 0.0f;
-    o.tgt = o.valid ? tg : 0.0f;
+    const uint32_t soff = g * 128u;
+    o.xa = bt::buf_f32(obs_r, off_a, soff);
+    o.xb = bt::buf_f32(obs_r, off_b, soff);
+    o.xc = bt::buf_f32(obs_r, off_c, soff);
+    o.tgt = bt::buf_f32(tgt_r, off_t, soff);
     return o;
   };
 
-  TileOp op = load_tile(wave_id);
-  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
-    // global loads run one tile ahead.  (Two tiles ahead — by register moves or by rotating three named buffers through
-    // a loop unrolled three times — is SLOWER, 0.237 against 0.220 ms per step, although a timing build without the
-    // loads runs in 0.197: what the loads cost is issue slots and address arithmetic, not exposed latency.)
-    const TileOp next = load_tile(g + n_waves);
+  auto tile = [&](auto ragged, TileOp op) {
+    constexpr bool RAGGED = decltype(ragged)::value;
+    const bool valid = RAGGED ? (uint32_t)n < tail : true;
+    if (RAGGED) {  // (the observation planes extend past sample B - 1: what a padding lane read is not zero)
+      op.xa = valid ? op.xa : 0.0f;
+      op.xb = valid ? op.xb : 0.0f;
+      op.xc = valid ? op.xc : 0.0f;
+      op.tgt = valid ? op.tgt : 0.0f;
+    }
     Frag fa[3];
-    bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
+    bt::input_frags(op.xa, op.xb, op.xc, valid, hf, fa);
     // ---- forward, one hidden tile at a time, software-pipelined: the matrix pipe works on hidden tile t + 1 while the
     // VALU does the partial y and the relu' mask of hidden tile t; the mask is packed as the backward's A operand
     Frag ga[NT][2];
@@ -133,7 +139,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
     bt::wave_lds_fence();
-    float part = bt::row_sum16(&Ysh[wave][n][hf * 16]);
+    float part = bt::row_sum16v(&Ysh[wave][n][hf * 16]);
     {  // the linear half of relu: this half's inputs of sample n
       float lin = lv[0] * op.xa;
       lin = __builtin_fmaf(lv[1], op.xb, lin);
@@ -144,8 +150,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     bt::both_halves(part, p0, p1);
     const float y = 0.5f * (p0 + p1) + b2;
     const float d = y - op.tgt;
-    const float dy = op.valid ? d * two_over_B : 0.0f;
-    if (hf == 0 && op.valid) {
+    const float dy = valid ? d * two_over_B : 0.0f;
+    if (hf == 0 && valid) {
       loss32 = __builtin_fmaf(d, d, loss32);
       db2_32 = db2_32 + dy;
     }
@@ -162,8 +168,22 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
       db2_64 += (double)db2_32;
       loss32 = db2_32 = 0.0f;
     }
-    op = next;
+  };
+
+  if (wave_id < n_full) {
+    TileOp op = load_tile(wave_id);
+    for (uint32_t g = wave_id; g < n_full; g += n_waves) {
+      // global loads run one tile ahead (past the wave's last tile: that tile again).  (Two tiles ahead — by register
+      // moves or by rotating three named buffers through a loop unrolled three times — is SLOWER, 0.237 against 0.220 ms
+      // per step, although a timing build without the loads runs in 0.197: what the loads cost is issue slots, not
+      // exposed latency.)
+      const uint32_t gn = g + n_waves;
+      const TileOp next = load_tile(gn < n_full ? gn : g);
+      tile(std::false_type{}, op);
+      op = next;
+    }
   }
+  if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full));
   bt::flush(dm, acc64, 7, n, hf);
   loss64 += (double)loss32;
   db2_64 += (double)db2_32;

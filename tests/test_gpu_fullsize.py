@@ -74,16 +74,22 @@ def test_full_size_sharding_invariance_and_gradient_linearity(engine, full):
 def test_full_size_update_kernels_against_the_f64_oracle(engine, full):
     """The update kernels at the size the bench runs them — 65,536 x 128 = 8.39 M samples: 256 persistent workgroups,
     1,024 tiles per wave, 16 f32 -> f64 flushes per wave — against the oracle's f64 ground truth over ALL samples
-    (oracle_grad_f64_mt: the f64 functions of oracle/nn_impl.inc, OpenMP over chunks): surrogate gradient, one
-    Fisher-vector product, critic gradient; the tolerance of tests/test_gpu_parity.py (1e-6 of the vector's largest
-    entry).  Reference: trpo.rs:124-131, conjugate_gradient.rs:312-338, critics/opt.rs:109-115."""
+    (oracle_grad_f64_mt: the f64 functions of oracle/nn_impl.inc, OpenMP over chunks): one Fisher-vector product and
+    the critic gradient within 1e-6 of the vector's largest entry (measured: 5e-8, 4e-8); the surrogate gradient by the
+    criterion of tests/test_gpu_parity.py::test_policy_gradient_matches_oracle — no farther from the f64 truth than
+    4 x what the f32 ORACLE is, evaluated over the same 8.39 M samples (oracle_grad_f32_mt).  That gradient is a sum
+    of terms of either sign, -A (1[a] - p) / B with mean(A) = 8, that cancel to ~ B^-1/2 of their size; per-sample f32
+    arithmetic leaves 1.4e-6 of max|g| in it (the f32 oracle), the device 2.8e-6.
+    Reference: trpo.rs:124-131, conjugate_gradient.rs:312-338, critics/opt.rs:109-115."""
     x, a = O.flat_samples(full["data"])
     adv, rtg = full["adv"].reshape(-1), full["rtg"].reshape(-1)
     pp, cp = full["pol"].get_params(), full["cri"].get_params()
     assert len(a) == N * T
     g_d, loss_d, ent_d = ra.policy_gradient(full["pol"], full["traj"])
     g64, l64 = O.grad_f64_mt("policy", PS, pp, x, a.astype(np.uint8), adv)
-    assert rel_err(g_d, g64) < 1e-6
+    g32, _ = O.grad_f64_mt("policy", PS, pp, x, a.astype(np.uint8), adv, f32_samples=True)
+    assert rel_err(g_d, g64) < max(4 * rel_err(g32, g64), 1e-6) and rel_err(g_d, g64) < 1e-5
+    assert rel_err(g_d, g32) < 5e-6
     assert abs(loss_d - l64) <= 1e-6 * max(1.0, abs(l64))
     v = np.random.default_rng(7).standard_normal(len(pp)).astype(np.float32)
     h_d = ra.policy_fvp(full["pol"], full["traj"], v, 0.0)
