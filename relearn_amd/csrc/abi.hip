@@ -718,10 +718,15 @@ int32_t rl_debug_stream_words(rl_engine *engine, uint64_t seed, uint64_t stream,
     AgentKey key;
     rl_seed_from_u64(seed, key.w);
     uint32_t *d = dalloc<uint32_t>(n_words);
-    hipLaunchKernelGGL(k_debug_stream_words, dim3((n_words + 255) / 256), dim3(256), 0, engine->stream, key, stream,
-                       first_word, n_words, d);
-    RL_HIP_CHECK(hipGetLastError());
-    d2h(engine, words_out, d, (size_t)n_words * sizeof(uint32_t));
+    try {
+      hipLaunchKernelGGL(k_debug_stream_words, dim3((n_words + 255) / 256), dim3(256), 0, engine->stream, key, stream,
+                         first_word, n_words, d);
+      RL_HIP_CHECK(hipGetLastError());
+      d2h(engine, words_out, d, (size_t)n_words * sizeof(uint32_t));
+    } catch (...) {
+      dfree(d);
+      throw;
+    }
     dfree(d);
   });
 }

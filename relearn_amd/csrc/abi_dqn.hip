@@ -92,6 +92,7 @@ static void dqn_release_device(rl_dqn *q) {
   if (q->main_event) (void)hipEventDestroy(q->main_event);
   q->main_event = nullptr;
   if (q->h_counts) (void)hipHostFree(q->h_counts);
+  dfree(q->snap);
   q->h_counts = nullptr;
   q->d_agent_pos = nullptr;
   q->d_ep_lane = q->d_ep_start = q->d_ep_len = q->d_ep_off = nullptr;
@@ -418,6 +419,17 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
       chunk_end.push_back((uint32_t)K);
     }
     rl_traj *mb = q->mb;
+    // With pipelined draws a sampler error can surface in a LATER chunk, after the earlier chunks' optimisation steps
+    // have run: the update is all or nothing, so the network and the optimiser state are saved first and put back then
+    // (four device copies of <= 4 KB; the one-launch draw validates every minibatch before the first step).
+    const uint64_t Pq = q->qnet->P, host_step0 = q->opt->host_step;
+    if (pipelined) {
+      if (!q->snap) q->snap = dalloc<float>(3 * Pq + 2);
+      RL_HIP_CHECK(hipMemcpyAsync(q->snap, q->qnet->d_params, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+      RL_HIP_CHECK(hipMemcpyAsync(q->snap + Pq, q->opt->d_m, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+      RL_HIP_CHECK(hipMemcpyAsync(q->snap + 2 * Pq, q->opt->d_v, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+      RL_HIP_CHECK(hipMemcpyAsync(q->snap + 3 * Pq, q->opt->d_step, sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream));
+    }
     try {
       for (size_t c = 0; c < chunk_end.size(); ++c) {
         const uint32_t first = c ? chunk_end[c - 1] : 0, size = chunk_end[c] - first;
@@ -426,6 +438,9 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
           const char *what = "";
           const int32_t code = dqn_check_counts(q, q->h_counts + first, size, &what);
           if (code != RL_OK) throw RlError(code, what);
+          // (test facility: RELEARN_DQN_FAIL_CHUNK=c fails chunk c as a sampler error would, tests/test_gpu_dqn.py)
+          if (const char *inj = std::getenv("RELEARN_DQN_FAIL_CHUNK"))
+            if ((size_t)std::atoi(inj) == c) throw RlError(RL_ERR_INVALID_ARGUMENT, "injected sampler failure");
           for (uint32_t k = first; k < first + size; ++k) {
             counts[k] = q->h_counts[k];
             totals[k] = counts[k].n_steps;
@@ -461,7 +476,15 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
         }
       }
     } catch (...) {
-      if (pipelined) (void)hipStreamSynchronize(q->draw_stream);  // the later chunks' draws still advance the agent's Prng
+      if (pipelined) {
+        (void)hipStreamSynchronize(q->draw_stream);  // the later chunks' draws still advance the agent's Prng
+        (void)hipMemcpyAsync(q->qnet->d_params, q->snap, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
+        (void)hipMemcpyAsync(q->opt->d_m, q->snap + Pq, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
+        (void)hipMemcpyAsync(q->opt->d_v, q->snap + 2 * Pq, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
+        (void)hipMemcpyAsync(q->opt->d_step, q->snap + 3 * Pq, sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        q->opt->host_step = host_step0;
+      }
       dqn_own_arrays(q);
       q->last_n_eps = q->last_n_steps = 0;  // no minibatch to read after a failed update
       throw;

@@ -13,10 +13,16 @@
 // This replaces the `Vec<buffer>` hand-off of the reference's threads (src/simulation/train.rs:180) for the multi-GPU
 // configuration; RCCL (abi.hip) stays the default transport — its small-message latency is what this path avoids.
 // Every wait is bounded in wall-clock time (30 s by default, RELEARN_IPC_TIMEOUT_MS; rank skew — a first-launch code
-// object load, a host stall, a profiler — is far below that): a peer that never arrives sets the engine's STICKY error
-// word, the wave returns before it stores anything (no stale sum reaches the vector, the parameters or the optimiser
-// state), every later collective fails fast without publishing, and the host raises RL_ERR_COMM at its next
-// synchronising call.
+// object load, a host stall, a profiler — is far below that).  A peer that never arrives sets the engine's STICKY error
+// word; the exchange is FAIL-STOP: the wave that timed out returns before it stores anything, every later collective
+// fails fast without publishing, every kernel that writes parameters or optimiser state from a reduced vector tests the
+// word first (k_reduce_adam's fused exchange; k_adam_step, k_ls_set_params and k_ls_finalize behind the stand-alone
+// k_ipc_allreduce, which leaves LOCAL sums in the vector when it fails — kernels_update.hip: a TRPO update ends on the
+// parameters it started from), and the host raises RL_ERR_COMM at its next synchronising call.  The decision is taken
+// per 64-element chunk: when a peer never publishes, nothing is stepped anywhere (tests/test_gpu_multirank.py, both
+// update kinds); a peer that arrives within microseconds of the bound can pass some chunks of a fused reduce + Adam
+// launch and fail others, and sees all of this rank's words itself — after RL_ERR_COMM the replicas are not defined
+// and the job must stop (or restore a checkpoint): the word stays set so that nothing continues by accident.
 // EXPERIMENTAL: the protocol has run between processes sharing one GPU (IPC handles of one device map like peer windows)
 // and never across xGMI; rl_comm_init_ipc checks what it can for mailboxes on other devices (peer access, native
 // atomics), the self-test hammers both slots and every chunk with random payloads, but 8-byte store atomicity and

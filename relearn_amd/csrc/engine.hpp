@@ -306,6 +306,7 @@ struct rl_dqn {
   std::vector<hipEvent_t> draw_events;
   hipEvent_t main_event = nullptr;
   DqnCountsDev *h_counts = nullptr;  // pinned, [K]
+  float *snap = nullptr;             // parameters + Adam moments + step count as of the start of a pipelined update
   // ... `mb` then points into them (the last minibatch stays readable); its own arrays, for the one-at-a-time builder:
   float *own_obs = nullptr, *own_target = nullptr;
   uint8_t *own_action = nullptr, *own_flag = nullptr;

@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     const float y = 0.5f * (p0 + p1) + b2;
     const float d = y - op.tgt;
     const float dy = valid ? d * two_over_B : 0.0f;
-    if (hf == 0 && valid) {
+    if (valid) {  // (both halves hold sample n and count it; the reduction after the loop reads half 0 only)
       loss32 = __builtin_fmaf(d, d, loss32);
       db2_32 = db2_32 + dy;
     }
@@ -171,16 +171,18 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   };
 
   if (wave_id < n_full) {
-    TileOp op = load_tile(wave_id);
-    for (uint32_t g = wave_id; g < n_full; g += n_waves) {
-      // global loads run one tile ahead (past the wave's last tile: that tile again).  (Two tiles ahead — by register
-      // moves or by rotating three named buffers through a loop unrolled three times — is SLOWER, 0.237 against 0.220 ms
-      // per step, although a timing build without the loads runs in 0.197: what the loads cost is issue slots, not
-      // exposed latency.)
-      const uint32_t gn = g + n_waves;
-      const TileOp next = load_tile(gn < n_full ? gn : g);
-      tile(std::false_type{}, op);
-      op = next;
+    // global loads run one tile ahead (past the wave's last tile: that tile again), into two named buffers that take
+    // turns — no register moves.  (Two tiles ahead — by register moves or by rotating three named buffers through a
+    // loop unrolled three times — is SLOWER, 0.237 against 0.220 ms per step, although a timing build without the loads
+    // runs in 0.197: what the loads cost is issue slots, not exposed latency.)
+    TileOp op_a = load_tile(wave_id), op_b = op_a;
+    for (uint32_t g = wave_id; g < n_full; g += 2 * n_waves) {
+      const uint32_t g1 = g + n_waves, g2 = g1 + n_waves;
+      op_b = load_tile(g1 < n_full ? g1 : g);
+      tile(std::false_type{}, op_a);
+      if (g1 >= n_full) break;
+      op_a = load_tile(g2 < n_full ? g2 : g1);
+      tile(std::false_type{}, op_b);
     }
   }
   if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full));

@@ -1195,6 +1195,9 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
     else gp_launch_nl<PASS_JVP>(t, g, NL, (uint32_t)nwg, inv_B, d_skip, clip_lo, clip_hi);
     return true;
   }
+  // (only reachable for a pass the pair kernel was admitted for when RELEARN_GEN_ONE_WAVE forces this kernel: the caller
+  // then takes the per-layer path)
+  if (gm_lds_bytes(gw, NL, mode == PASS_JVP) > 160 * 1024) return false;
   uint64_t nwg = (n_tiles + GWAVES - 1) / GWAVES;
   if (nwg > cus) nwg = cus;
   t->last_rows = (uint32_t)(nwg * GWAVES < n_tiles ? nwg * GWAVES : n_tiles);  // one slab row per wave that has tiles

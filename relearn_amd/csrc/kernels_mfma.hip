@@ -3,6 +3,8 @@
 // kernels_critic.hip, the DQN gradient (two outputs, two backward channels) is k_dqn_step_bf16 in kernels_dqn.hip.
 // (Rounds 1-2 ran these passes on the f32 MFMA with the backward on the VALU; that kernel is gone — its last user was
 // the DQN gradient.)
+#include <type_traits>
+
 #include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
@@ -44,13 +46,14 @@ __global__ void __launch_bounds__(WAVES * 64)
   constexpr bool JVP = MODE == PASS_JVP;
   constexpr int IW = 7;              // f64 image slots per hidden unit (six columns)
   constexpr int PIMG_M = H * IW + 5; // then db2[0], db2[1], sum0, sum1, sum2
-  __shared__ float Ysh[JVP ? 1 : WAVES][32][33];
+  __shared__ __attribute__((aligned(16))) float Ysh[JVP ? 1 : WAVES][32][bt::YROW];
   __shared__ double Acc[WAVES][BWD ? PIMG_M : 4];
   __shared__ uint4 Fz[JVP ? bt::L2_KS : 1][64];  // JVP: A operands of the masked sum over the hidden units (pieces of Z)
   __shared__ uint4 Fw[FW_LDS ? NT * 3 : 1][64];  // FW_LDS: the weight fragments live in LDS, shared by the waves
   if (skip != nullptr && *skip != 0) return;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: tile indices stay scalar
   const int n = lane & 31, hf = lane >> 5;
   const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H,
                            *__restrict__ b2 = W2 + A * H;
@@ -134,7 +137,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ysh[JVP ? 0 : wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
     bt::wave_lds_fence();
-    float part = bt::row_sum16(&Ysh[JVP ? 0 : wave][n][hf * 16]);
+    float part = bt::row_sum16v(&Ysh[JVP ? 0 : wave][n][hf * 16]);
     part = part + lin;
     float p0, p1;
     bt::both_halves(part, p0, p1);
@@ -142,48 +145,59 @@ __global__ void __launch_bounds__(WAVES * 64)
     return p0 + p1;
   };
 
-  const size_t n_tiles = (B + 31) / 32;
-  const size_t wave_id = (size_t)blockIdx.x * WAVES + wave, n_waves = (size_t)gridDim.x * WAVES;
+  // Tiles: the full ones in the loop, a ragged last one (B not a multiple of 32) after it on the wave whose turn it is,
+  // through the same code with a per-lane `valid` — the loop carries no validity selects.  Tile indices are wave-uniform
+  // (SGPRs); the operands come through buffer loads with a constant per-lane byte offset and the tile's offset as the
+  // scalar operand: no vector address arithmetic per tile (kernels_critic.hip has the same loop).
+  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
+  const uint32_t n_full = B32 / 32u, tail = B32 & 31u;
+  const uint32_t wave_id = blockIdx.x * WAVES + (uint32_t)wave, n_waves = gridDim.x * WAVES;
+  const bt::rsrc_t obs_r = bt::make_rsrc(tr.obs, (uint32_t)D * plane32 * 4u), lp0_r = bt::make_rsrc(lp0, 2u * B32 * 4u);
+  const bt::rsrc_t adv_r = bt::make_rsrc(tr.adv, B32 * 4u), act_r = bt::make_rsrc(tr.action, B32);
+  const uint32_t off_a = ((uint32_t)(2 * hf) * plane32 + (uint32_t)n) * 4u, off_b = off_a + plane32 * 4u;
+  const uint32_t off_c = (4u * plane32 + (uint32_t)n) * 4u, off_s = (uint32_t)n * 4u, off_s1 = off_s + B32 * 4u;
   int since_flush = 0;
   // per lane: features 2 hf, 2 hf + 1 and 4 of sample n, and the per-sample scalars the pass needs (log pi_0 of both
   // actions; advantage and action) — all requested one tile ahead
   struct TileOp {
     float xa, xb, xc, l0, l1, adv;
     int act;
-    bool valid;
   };
-  // branch-free (padding lanes read sample B - 1 and are zeroed): the loads of tile i + 1 stay in flight across tile i
-  // (32-bit element offsets from the uniform base pointers: a launch covers < 2^30 samples, checked by the launcher)
-  const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
-  auto load_tile = [&](size_t g) {
+  auto load_tile = [&](uint32_t g) {  // g: wave-uniform tile index
     TileOp o;
-    const uint32_t sidx = (uint32_t)g * 32u + (uint32_t)n;
-    o.valid = g < n_tiles && sidx < B32;
-    const uint32_t sc = o.valid ? sidx : B32 - 1;
-    const float xa = tr.obs[(uint32_t)(2 * hf) * plane32 + sc], xb = tr.obs[(uint32_t)(2 * hf + 1) * plane32 + sc];
-    const float xc = tr.obs[4u * plane32 + sc];
+    const uint32_t soff = g * 128u;
+    o.xa = bt::buf_f32(obs_r, off_a, soff);
+    o.xb = bt::buf_f32(obs_r, off_b, soff);
+    o.xc = bt::buf_f32(obs_r, off_c, soff);
     o.l0 = o.l1 = o.adv = 0.0f;
     o.act = 0;
     if (MODE != PASS_INIT) {  // log pi_0 (written by PASS_INIT, read by the others)
-      const float l0 = lp0[sc], l1 = lp0[B32 + sc];
-      o.l0 = o.valid ? l0 : 0.0f;
-      o.l1 = o.valid ? l1 : 0.0f;
+      o.l0 = bt::buf_f32(lp0_r, off_s, soff);
+      o.l1 = bt::buf_f32(lp0_r, off_s1, soff);
     }
     if (!JVP) {
-      const float adv = tr.adv[sc];
-      const int act = (int)tr.action[sc];
-      o.adv = o.valid ? adv : 0.0f;
-      o.act = o.valid ? act : 0;
+      o.adv = bt::buf_f32(adv_r, off_s, soff);
+      o.act = (int)bt::buf_u8(act_r, (uint32_t)n, g * 32u);
     }
-    o.xa = o.valid ? xa : 0.0f;
-    o.xb = o.valid ? xb : 0.0f;
-    o.xc = o.valid ? xc : 0.0f;
     return o;
   };
-  TileOp op = load_tile(wave_id);
-  for (size_t g = wave_id; g < n_tiles; g += n_waves) {
-    const TileOp next = load_tile(g + n_waves);
-    const size_t sidx = g * 32 + n;
+  auto tile = [&](auto ragged, TileOp op_in, uint32_t g) {
+    constexpr bool RAGGED = decltype(ragged)::value;
+    struct {
+      float xa, xb, xc, l0, l1, adv;
+      int act;
+      bool valid;
+    } op;
+    op.valid = RAGGED ? (uint32_t)n < tail : true;
+    // (the arrays extend past sample B - 1 or the loads return 0 there: a padding lane's operands are zeroed)
+    op.xa = op.valid ? op_in.xa : 0.0f;
+    op.xb = op.valid ? op_in.xb : 0.0f;
+    op.xc = op.valid ? op_in.xc : 0.0f;
+    op.l0 = op.valid ? op_in.l0 : 0.0f;
+    op.l1 = op.valid ? op_in.l1 : 0.0f;
+    op.adv = op.valid ? op_in.adv : 0.0f;
+    op.act = op.valid ? op_in.act : 0;
+    const size_t sidx = (size_t)g * 32 + n;
     Frag fa[3];
     bt::input_frags(op.xa, op.xb, op.xc, op.valid, hf, fa);
     Frag ga[NT][2];
@@ -248,7 +262,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         const float cc = -(gr * ratio) * inv_B;
         dz0 = op.valid ? cc * ((act == 0 ? 1.0f : 0.0f) - sp.p[0]) : 0.0f;
         dz1 = op.valid ? cc * ((act == 1 ? 1.0f : 0.0f) - sp.p[1]) : 0.0f;
-        if (op.valid && hf == 0) s0f = s0f + (u1 < u2 ? u1 : u2);
+        if (op.valid) s0f = s0f + (u1 < u2 ? u1 : u2);  // (both halves count sample n; the final reduction reads half 0)
       } else if (MODE == PASS_INIT) {
         if (op.valid && hf == 0) {
           lp0[sidx] = lp[0];
@@ -264,7 +278,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         const float cl1 = lp[1] < -3.402823466e+38f ? -3.402823466e+38f : lp[1];
         float ent = cl0 * pa0;
         ent += cl1 * pa1;
-        if (op.valid && hf == 0) {
+        if (op.valid) {
           s0f = __builtin_fmaf(ratio, adv, s0f);
           s1f = s1f - ent;
           s2f = __builtin_fmaf(lpa, adv, s2f);
@@ -280,17 +294,15 @@ __global__ void __launch_bounds__(WAVES * 64)
         const SoftPair old = soft_pair(l00 - l01);  // pi_0 from its stored log-probabilities
         float kl = rel0 * old.p[0];
         kl += rel1 * old.p[1];
-        if (op.valid && hf == 0) {
+        if (op.valid) {
           s0f = __builtin_fmaf(ratio, adv, s0f);
           s1f = s1f + kl;
         }
       }
     }
     if (BWD) {
-      if (hf == 0) {
-        d0f = d0f + dz0;
-        d1f = d1f + dz1;
-      }
+      d0f = d0f + dz0;  // (dz is 0 on padding lanes)
+      d1f = d1f + dz1;
       // one channel: u[sample][k] = g * x~_k with g = (dz_0 - dz_1) / 2, masked sum over the samples on the matrix pipe
       Frag ub[2];
       bt::piece_frags_mfma(0.5f * (dz0 - dz1), op.xa, op.xb, op.xc, hf, selb, ub);
@@ -304,8 +316,30 @@ __global__ void __launch_bounds__(WAVES * 64)
       since_flush = 0;
       fold();
     }
-    op = next;
+  };
+  if (wave_id < n_full) {
+    // loads run one tile ahead (past the wave's last tile: that tile again), into two named buffers that take turns
+    // (the Fisher-vector pass has no registers for a second buffer: one buffer and a move per operand there)
+    TileOp op_a = load_tile(wave_id), op_b = op_a;
+    if (JVP) {
+      for (uint32_t g = wave_id; g < n_full; g += n_waves) {
+        const uint32_t g1 = g + n_waves;
+        op_b = load_tile(g1 < n_full ? g1 : g);
+        tile(std::false_type{}, op_a, g);
+        op_a = op_b;
+      }
+    } else {
+      for (uint32_t g = wave_id; g < n_full; g += 2 * n_waves) {
+        const uint32_t g1 = g + n_waves, g2 = g1 + n_waves;
+        op_b = load_tile(g1 < n_full ? g1 : g);
+        tile(std::false_type{}, op_a, g);
+        if (g1 >= n_full) break;
+        op_a = load_tile(g2 < n_full ? g2 : g1);
+        tile(std::false_type{}, op_b, g1);
+      }
+    }
   }
+  if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full), n_full);
   if (BWD) bt::flush(dm, acc64, IW, n, hf);
   fold();
   auto xlane = [](double v, int mask) {

@@ -132,6 +132,39 @@ def test_update_on_an_empty_store_fails_before_any_step(engine, td):
     assert not np.array_equal(dqn.qnet.get_params(), before)
 
 
+def test_a_sampler_failure_in_a_later_chunk_leaves_the_agent_as_it_was(engine):
+    """With pipelined draws the chunks of an update are validated one by one while earlier chunks already train.  A
+    failure in a later chunk (injected: RELEARN_DQN_FAIL_CHUNK) must still leave network, Adam moments and step count as
+    they were before the call — the update is all or nothing — so that the next update does exactly what
+    it does for an agent that never saw the failure."""
+    import os
+    ref, _ = make(engine, n=256, capacity=64, minibatch=400, opt_steps=12)
+    dqn, _ = make(engine, n=256, capacity=64, minibatch=400, opt_steps=12)
+    ref.collect(40)
+    dqn.collect(40)
+    before = dqn.qnet.get_params()
+    os.environ["RELEARN_DQN_FAIL_CHUNK"] = "2"  # chunks of 2, 4, 8 minibatches: six steps have run by then
+    try:
+        with pytest.raises(ra.RelearnError) as e:
+            dqn.update()
+        assert e.value.code == ra.ERR_INVALID_ARGUMENT
+    finally:
+        os.environ.pop("RELEARN_DQN_FAIL_CHUNK", None)
+    assert np.array_equal(dqn.qnet.get_params(), before)
+    # the failed call consumed its draws from the agent's Prng (as the reference's sampler would have before panicking);
+    # give the reference agent the same position by letting it fail the same way, then both update identically
+    os.environ["RELEARN_DQN_FAIL_CHUNK"] = "0"
+    try:
+        with pytest.raises(ra.RelearnError):
+            ref.update()
+    finally:
+        os.environ.pop("RELEARN_DQN_FAIL_CHUNK", None)
+    assert dqn.agent_rng_pos() == ref.agent_rng_pos()
+    a, la = dqn.update(want_losses=True)
+    b, lb = ref.update(want_losses=True)
+    assert np.array_equal(la, lb) and np.array_equal(dqn.qnet.get_params(), ref.qnet.get_params())
+
+
 def test_linear_schedule_and_collection_bound(engine):
     dqn, osim = make(engine, n=128, capacity=64, eps=("linear", 1.0, 0.1, 20000), minibatch=300, opt_steps=1)
     L = O.lib()
