@@ -79,13 +79,11 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
   const uint32_t n = tr.n, T = tr.T;
   mlp_pack_lds<D>(pk, policy, H, threadIdx.x, BLOCK);
   __syncthreads();
-  // Workgroups are dealt to the eight XCDs round-robin, and each XCD has its own L2: with the launch order as the lane
-  // order, the four 32-byte pieces of a 128-byte line of the byte-wide `action` / `flag` planes (a wave of G = 2 owns 32
-  // lanes) would be written through four different L2s, each evicting a partial line.  So the workgroups of one XCD
-  // take a contiguous range of lanes.
-  uint32_t blk_id = blockIdx.x;
-  if ((gridDim.x & 7u) == 0) blk_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const uint32_t i = (blk_id * BLOCK + threadIdx.x) / G;
+  // (Launch order = lane order.  Giving each XCD a contiguous range of lanes, so that the 32-byte pieces a wave of G = 2
+  // writes into the byte-wide `action` / `flag` planes meet in one L2, was measured in round 4: WRITE_SIZE is 222 MB per
+  // launch either way — the 302 MB of the round-3 counter pass was the FIRST launch over untouched memory — and the
+  // remapped launch is 2 % slower.)
+  const uint32_t i = (blockIdx.x * BLOCK + threadIdx.x) / G;
   const int g = threadIdx.x % G;
   // lanes past the end follow lane n - 1 without storing: the group shuffles below need every lane of a group
   const bool live = i < n;
