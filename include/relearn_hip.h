@@ -269,7 +269,14 @@ int32_t rl_mlp_forward(rl_mlp *mlp, const float *rows, uint64_t n_rows, float *o
  * Linear(gru_hidden, mlp_hidden) -> ReLU -> Linear(mlp_hidden, out_dim).  The handle type is shared with the MLP:
  * every entry point that takes a module dispatches on its kind.  Flat parameter order = trainable_variables():
  * W_ih [3H, in] (gate rows r, z, n), W_hh [3H, H], b_ih [3H], b_hh [3H], then the MLP's kernel/bias pairs.
- * Built for gru_hidden = mlp_hidden = 128, in_dim = 5, out_dim in {1, 2}; lanes in multiples of 32.
+ * The kernels are built for gru_hidden = mlp_hidden = 128, in_dim = 5; narrower chains — in_dim 1..5, gru_hidden
+ * 1..128, mlp_hidden 1..128 (RnnBaseConfig::hidden_size / ChainConfig::hidden_dim, MlpConfig::hidden_sizes = [h]; e.g.
+ * the GRU(3 -> 4) of the reference's benches/rnn.rs) — run on the same kernels embedded with zero padding: padded
+ * units stay exactly 0 and every real dot product only gains terms fma(0, 0, acc), so outputs, gradients and
+ * Fisher-vector products are those of the narrow chain (forward bit-identical to the oracle's, tests/test_gpu_gru.py).
+ * out_dim in {1, 2}; lanes in multiples of 32; trajectories of obs_dim = in_dim (rollouts need an env with five
+ * observation features; narrower inputs come from rl_traj_write).  RnnBaseConfig::num_layers > 1 is not built
+ * (rl_rnn_mlp_create -> RL_ERR_UNSUPPORTED).
  * rl_mlp_init: Glorot-uniform W_ih, orthogonal W_hh, zero biases (RnnBaseConfig::default), Linear::new for the MLP. */
 int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden,
                           uint32_t out_dim, rl_mlp **out);
@@ -281,6 +288,12 @@ int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidde
  * serialisation). */
 int32_t rl_lstm_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t lstm_hidden, uint32_t mlp_hidden,
                            uint32_t out_dim, rl_mlp **out);
+/* Both chains with RnnBaseConfig's fields spelled out (seq/rnn/mod.rs:20-45: hidden_size, num_layers; the initializers
+ * are RnnBaseConfig::default's): cell = RL_CELL_GRU | RL_CELL_LSTM.  num_layers must be 1 (the reference's default);
+ * 0 -> RL_ERR_BUILD_AGENT, > 1 -> RL_ERR_UNSUPPORTED. */
+enum { RL_CELL_GRU = 0, RL_CELL_LSTM = 1 };
+int32_t rl_rnn_mlp_create(rl_engine *engine, int32_t cell, uint32_t in_dim, uint32_t hidden_size, uint32_t num_layers,
+                          uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out);
 
 /* ---------------------------------------------------------------------------------------------
  * Trajectory store (replaces VecBuffer + LazyHistoryFeatures: src/agents/buffers/vec.rs:15-143,
@@ -297,6 +310,7 @@ typedef enum {
   RL_TRAJ_TARGETS = 8    /* f32 [T][n] value targets of the last rl_values_opt_update (StepValueTarget::targets) */
 } rl_traj_field;
 
+/* obs_dim in 1..5 (feed-forward modules take 4 or 5; narrower trajectories serve recurrent chains of that in_dim) */
 int32_t rl_traj_create(rl_engine *engine, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, rl_traj **out);
 int32_t rl_traj_destroy(rl_traj *traj);
 int32_t rl_traj_field_bytes(const rl_traj *traj, int32_t field, uint64_t *bytes);

@@ -876,38 +876,83 @@ int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidd
   });
 }
 
-static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t rnn_hidden, uint32_t mlp_hidden,
-                              uint32_t out_dim, rl_mlp **out) {
+// ChainConfig<GruConfig | LstmConfig, MlpConfig>::build_module (modules/chain.rs:19-56, seq/rnn/mod.rs:20-45,223-281):
+// RnnBaseConfig { hidden_size, num_layers, .. } -> ReLU -> Mlp with one hidden layer.  The kernels are built for
+// 5 -> 128 -> 128 -> {1, 2}; narrower shapes (in_dim <= 5, widths <= 128) run on them embedded with zero padding
+// (rl_mlp::exec).  num_layers > 1 is not built.
+static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t rnn_hidden, uint32_t num_layers,
+                              uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out) {
   RL_REQUIRE(e && out, "NULL argument");
   *out = nullptr;
-  if (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128 || !(out_dim == 1 || out_dim == 2))
+  if (num_layers == 0) throw RlError(RL_ERR_BUILD_AGENT, "RnnBaseConfig::num_layers must be at least 1");
+  if (num_layers != 1)
+    throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built for RnnBaseConfig::num_layers = 1 (the reference's "
+                                      "default); stacked layers are not");
+  if (in_dim < 1 || in_dim > 5 || rnn_hidden < 1 || rnn_hidden > 128 || mlp_hidden < 1 || mlp_hidden > 128 ||
+      !(out_dim == 1 || out_dim == 2))
     throw RlError(RL_ERR_BUILD_AGENT,
-                  "supported recurrent chain shape: in_dim 5, recurrent hidden 128, mlp_hidden 128, out_dim in {1,2}");
+                  "supported recurrent chain shapes: in_dim 1..5, recurrent hidden 1..128, mlp_hidden 1..128, out_dim in {1,2}");
   RL_HIP_CHECK(hipSetDevice(e->device));
-  std::unique_ptr<rl_mlp> m(new rl_mlp());
-  m->eng = e;
-  m->kind = kind;
-  m->in_dim = in_dim;
-  m->gru_hidden = rnn_hidden;
-  m->hidden = mlp_hidden;
-  m->out_dim = out_dim;
-  const uint64_t H = rnn_hidden, D = in_dim, H2 = mlp_hidden, A = out_dim, G = rl_module_gates(kind);
-  m->P = G * H * D + G * H * H + 2 * G * H + H2 * H + H2 + A * H2 + A;
-  m->d_params = dalloc<float>(m->P);
-  RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+  auto make = [&](uint32_t D, uint32_t H, uint32_t H2) {
+    std::unique_ptr<rl_mlp> m(new rl_mlp());
+    m->eng = e;
+    m->kind = kind;
+    m->in_dim = D;
+    m->gru_hidden = H;
+    m->hidden = H2;
+    m->out_dim = out_dim;
+    const uint64_t A = out_dim, G = rl_module_gates(kind);
+    m->P = G * H * D + G * H * H + 2 * G * H + (uint64_t)H2 * H + H2 + A * H2 + A;
+    m->d_params = dalloc<float>(m->P);
+    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+    return m;
+  };
+  std::unique_ptr<rl_mlp> m = make(in_dim, rnn_hidden, mlp_hidden);
+  if (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128) {
+    std::unique_ptr<rl_mlp> x;
+    try {
+      x = make(5, 128, 128);  // every padding entry stays 0 for the life of the module
+      m->x_tmp = dalloc<float>(x->P);
+      m->x_tan = dalloc<float>(x->P);
+      RL_HIP_CHECK(hipMemsetAsync(m->x_tan, 0, x->P * sizeof(float), e->stream));
+    } catch (...) {
+      if (x) dfree(x->d_params);
+      dfree(m->x_tmp);
+      dfree(m->x_tan);
+      dfree(m->d_params);
+      throw;
+    }
+    m->exec = x.release();
+  }
   sync(e);
   e->live_handles += 1;
   *out = m.release();
 }
 
+// the module the recurrent kernels run (see rl_mlp::exec), its parameter image refreshed from the module's flat vector
+rl_mlp *seq_exec(const rl_mlp *m) {
+  if (m->exec == nullptr) return const_cast<rl_mlp *>(m);
+  launch_seq_pad(m, m->exec->d_params, m->d_params);
+  return m->exec;
+}
+
 int32_t rl_gru_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden, uint32_t out_dim,
                           rl_mlp **out) {
-  return guarded(e, [&] { seq_module_create(e, RL_MODULE_GRU_MLP, in_dim, gru_hidden, mlp_hidden, out_dim, out); });
+  return guarded(e, [&] { seq_module_create(e, RL_MODULE_GRU_MLP, in_dim, gru_hidden, 1, mlp_hidden, out_dim, out); });
 }
 
 int32_t rl_lstm_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t lstm_hidden, uint32_t mlp_hidden, uint32_t out_dim,
                            rl_mlp **out) {
-  return guarded(e, [&] { seq_module_create(e, RL_MODULE_LSTM_MLP, in_dim, lstm_hidden, mlp_hidden, out_dim, out); });
+  return guarded(e, [&] { seq_module_create(e, RL_MODULE_LSTM_MLP, in_dim, lstm_hidden, 1, mlp_hidden, out_dim, out); });
+}
+
+int32_t rl_rnn_mlp_create(rl_engine *e, int32_t cell, uint32_t in_dim, uint32_t hidden_size, uint32_t num_layers,
+                          uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out) {
+  return guarded(e, [&] {
+    if (cell != RL_CELL_GRU && cell != RL_CELL_LSTM) throw RlError(RL_ERR_BUILD_AGENT, "unknown recurrent cell");
+    seq_module_create(e, cell == RL_CELL_GRU ? RL_MODULE_GRU_MLP : RL_MODULE_LSTM_MLP, in_dim, hidden_size, num_layers,
+                      mlp_hidden, out_dim, out);
+  });
 }
 
 // RnnWeights::new with RnnBaseConfig::default (seq/rnn/mod.rs:36-45,223-257) + the MLP's Linear::new layers.
@@ -981,6 +1026,12 @@ int32_t rl_mlp_destroy(rl_mlp *m) {
   (void)hipSetDevice(m->eng->device);
   (void)hipStreamSynchronize(m->eng->stream);
   dfree(m->d_params);
+  if (m->exec) {
+    dfree(m->exec->d_params);
+    delete m->exec;
+  }
+  dfree(m->x_tmp);
+  dfree(m->x_tan);
   rl_engine *eng = m->eng;
   delete m;
   engine_release_child(eng);
@@ -1238,7 +1289,7 @@ void traj_plan(rl_traj *t, uint64_t B) {
 rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, bool resizable) {
   RL_REQUIRE(n_lanes > 0 && n_lanes < (1ull << 31), "bad n_lanes");
   RL_REQUIRE(horizon > 0 && horizon < (1ull << 20), "bad horizon");
-  RL_REQUIRE(obs_dim == 4 || obs_dim == 5, "obs_dim must be 4 or 5");
+  RL_REQUIRE(obs_dim >= 1 && obs_dim <= 5, "obs_dim must be in 1..5");
   RL_REQUIRE(n_lanes * horizon < (1ull << 32), "T * n must fit 32 bits");
   RL_HIP_CHECK(hipSetDevice(e->device));
   std::unique_ptr<rl_traj> t(new rl_traj());
@@ -1246,8 +1297,11 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   t->d.n = (uint32_t)n_lanes;
   t->d.T = (uint32_t)horizon;
   t->d.D = obs_dim;
-  uint64_t n = n_lanes, T = horizon, D = obs_dim;
+  // (five observation planes whatever the logical width: the recurrent kernels are built for five features and read
+  // the planes past the module's in_dim as zeros)
+  uint64_t n = n_lanes, T = horizon, D = 5;
   t->d.obs = dalloc<float>(D * (T + 1) * n);
+  RL_HIP_CHECK(hipMemsetAsync(t->d.obs, 0, D * (T + 1) * n * 4, e->stream));
   t->d.action = dalloc<uint8_t>(T * n);
   t->d.reward = dalloc<float>(T * n);
   t->d.flag = dalloc<uint8_t>(T * n);
@@ -1406,8 +1460,12 @@ int32_t rl_seq_forward(rl_mlp *mod, rl_traj *traj, float *out, float *succ_out) 
   return guarded(traj ? traj->eng : nullptr, [&] {
     RL_REQUIRE(mod && traj && out, "NULL argument");
     RL_REQUIRE(mod->eng == traj->eng, "handles belong to different engines");
-    seq_ensure(traj, mod, false);
-    launch_gru_seq_forward(traj, mod, traj->seq.out, succ_out ? traj->seq.succ : nullptr, nullptr);
+    RL_REQUIRE(rl_module_is_recurrent(mod->kind), "not a recurrent module");
+    {
+      SeqScope sc(traj, mod);
+      seq_ensure(traj, sc.x, false);
+      launch_gru_seq_forward(traj, sc.x, traj->seq.out, succ_out ? traj->seq.succ : nullptr, nullptr);
+    }
     uint64_t bytes = (uint64_t)mod->out_dim * traj->d.T * traj->d.n * sizeof(float);
     d2h(traj->eng, out, traj->seq.out, bytes);
     if (succ_out) d2h(traj->eng, succ_out, traj->seq.succ, bytes);
@@ -1426,8 +1484,10 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
       return;
     }
     if (rl_module_is_recurrent(policy->kind)) {
-      seq_ensure(traj, policy, false);
-      launch_rollout_gru(env, policy, traj);
+      SeqScope sc(traj, policy);  // (in_dim == env->D == 5 here: the rollout kernels compute five features)
+      RL_REQUIRE(env->D == 5, "recurrent rollouts need an env with five observation features");
+      seq_ensure(traj, sc.x, false);
+      launch_rollout_gru(env, sc.x, traj);
     } else if (env->kind != RL_ENV_CARTPOLE) {
       launch_rollout_chain_mlp(env, policy, traj);
     } else {
@@ -1442,8 +1502,9 @@ int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
     RL_REQUIRE(traj && critic, "NULL argument");
     RL_REQUIRE(critic->in_dim == traj->d.D && critic->out_dim == 1, "critic shape does not match the trajectory");
     if (rl_module_is_recurrent(critic->kind)) {
-      seq_ensure(traj, critic, false);
-      launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
+      SeqScope sc(traj, critic);
+      seq_ensure(traj, sc.x, false);
+      launch_gru_seq_forward(traj, sc.x, traj->seq.out, traj->seq.succ, nullptr);
       launch_seq_gae(traj, gamma, lambda);
       return;
     }

@@ -73,4 +73,22 @@ void engine_release_child(rl_engine *e);
 void traj_plan(rl_traj *t, uint64_t B);
 rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, bool resizable);
 void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training);
+rl_mlp *seq_exec(const rl_mlp *m);
 }
+
+// Running the recurrent kernels for module `m` on trajectory `t`: `x` is the module they run (m itself, or its zero-padded
+// twin with the parameter image refreshed: rl_mlp::exec), and the trajectory is presented with the five observation
+// planes it physically has (planes past its logical width are zeros).
+struct SeqScope {
+  rl_traj *t;
+  uint32_t logical_D;
+  rl_mlp *x;
+  SeqScope(rl_traj *traj, const rl_mlp *m) : t(traj), logical_D(traj->d.D), x(nullptr) {
+    RL_REQUIRE(m->in_dim == traj->d.D, "module input width does not match the trajectory");
+    x = seq_exec(m);
+    t->d.D = 5;
+  }
+  ~SeqScope() { t->d.D = logical_D; }
+  SeqScope(const SeqScope &) = delete;
+  SeqScope &operator=(const SeqScope &) = delete;
+};

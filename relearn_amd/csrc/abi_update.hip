@@ -6,12 +6,24 @@ extern "C" {
 // ---------------------------------------------------------------- recurrent gradient passes
 // policy: teacher-forced forward (activation record) -> d loss / d logits -> [backward through time -> weight
 // gradients -> reduce] -> traj->vec[0..P) and the per-sample sums in vec[P..P+4)
+// (widths other than the kernels' run on the module's zero-padded twin: SeqScope; the gradient comes back in the twin's
+// layout and is gathered into the module's flat order before anything else touches the vector)
+static void seq_gradient_to_flat_order(const rl_mlp *mod, rl_traj *traj) {
+  if (mod->exec == nullptr) return;
+  launch_seq_unpad(mod, traj->vec, mod->x_tmp);
+  RL_HIP_CHECK(hipMemcpyAsync(traj->vec, mod->x_tmp, mod->P * sizeof(float), hipMemcpyDeviceToDevice, traj->eng->stream));
+}
+
 static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backward, float lo, float hi) {
-  seq_ensure(traj, policy, true);
+  SeqScope sc(traj, policy);
+  seq_ensure(traj, sc.x, true);
   uint32_t P = (uint32_t)policy->P;
-  launch_gru_seq_forward(traj, policy, traj->seq.out, nullptr, backward ? traj->seq.act : nullptr);
+  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, backward ? traj->seq.act : nullptr);
   launch_seq_policy_dlogits(traj, mode, b_total(traj), lo, hi);
-  if (backward) launch_gru_backward(traj, policy);
+  if (backward) {
+    launch_gru_backward(traj, sc.x);
+    seq_gradient_to_flat_order(policy, traj);
+  }
   launch_reduce(traj, P, false, true, 0, traj->nbB);
   if (backward) rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
   else rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
@@ -19,9 +31,10 @@ static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backwa
 
 // (loss, KL) of the current parameters against log pi_0: forward without a record -> sums in vec[P..P+4)
 static void seq_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip) {
-  seq_ensure(traj, policy, true);
+  SeqScope sc(traj, policy);
+  seq_ensure(traj, sc.x, true);
   uint32_t P = (uint32_t)policy->P;
-  launch_gru_seq_forward(traj, policy, traj->seq.out, nullptr, nullptr, d_skip);
+  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, nullptr, d_skip);
   launch_seq_policy_dlogits(traj, PASS_EVAL, b_total(traj), 0.0f, 0.0f, d_skip);
   launch_reduce(traj, P, false, true, 0, traj->nbB);
   rl_allreduce_sum_f32(traj->eng, traj->vec + P, 4);
@@ -30,18 +43,27 @@ static void seq_policy_eval(rl_mlp *policy, rl_traj *traj, const int32_t *d_skip
 // Fisher-vector product with the tangent d_v at the parameters whose activation record is in place (the last
 // seq_policy_pass with backward = true): vec[0..P) <- J^T (diag(p) - p p^T) J v / B
 static void seq_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, const int32_t *d_skip) {
-  seq_ensure(traj, policy, true);
-  launch_gru_tangent(traj, policy, d_v, b_total(traj), d_skip);
-  launch_gru_backward(traj, policy, d_skip);
+  SeqScope sc(traj, policy);
+  seq_ensure(traj, sc.x, true);
+  const float *tangent = d_v;
+  if (policy->exec != nullptr) {  // the tangent in the twin's layout (its padding entries stay zero)
+    launch_seq_pad(policy, policy->x_tan, d_v);
+    tangent = policy->x_tan;
+  }
+  launch_gru_tangent(traj, sc.x, tangent, b_total(traj), d_skip);
+  launch_gru_backward(traj, sc.x, d_skip);
+  seq_gradient_to_flat_order(policy, traj);
   rl_allreduce_sum_f32(traj->eng, traj->vec, (uint32_t)policy->P);
 }
 
 static void seq_critic_pass(rl_mlp *critic, rl_traj *traj) {
-  seq_ensure(traj, critic, true);
+  SeqScope sc(traj, critic);
+  seq_ensure(traj, sc.x, true);
   uint32_t P = (uint32_t)critic->P;
-  launch_gru_seq_forward(traj, critic, traj->seq.out, nullptr, traj->seq.act);
+  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, traj->seq.act);
   launch_seq_critic_dvalues(traj, b_total(traj));
-  launch_gru_backward(traj, critic);
+  launch_gru_backward(traj, sc.x);
+  seq_gradient_to_flat_order(critic, traj);
   launch_reduce(traj, P, false, true, 0, traj->nbB);
   rl_allreduce_sum_f32(traj->eng, traj->vec, P + 4);
 }
@@ -395,8 +417,9 @@ static void values_opt_targets(rl_mlp *critic, rl_traj *traj, const rl_values_op
   if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO) {
     launch_value_targets(traj, nullptr, cfg->discount_factor);
   } else if (rl_module_is_recurrent(critic->kind)) {
-    seq_ensure(traj, critic, false);
-    launch_gru_seq_forward(traj, critic, traj->seq.out, traj->seq.succ, nullptr);
+    SeqScope sc(traj, critic);
+    seq_ensure(traj, sc.x, false);
+    launch_gru_seq_forward(traj, sc.x, traj->seq.out, traj->seq.succ, nullptr);
     launch_seq_value_targets(traj, cfg->discount_factor);
   } else if (critic->general) {
     launch_gen_values(traj, critic);

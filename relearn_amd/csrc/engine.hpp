@@ -208,6 +208,15 @@ struct rl_mlp {
   bool general = false;
   // MlpConfig::activation / output_activation (rl_activation); the fused kernels are built for Relu / Identity
   int act = 1, out_act = 0;
+  // Recurrent chains of other widths than the kernels' 5 -> 128 -> 128 (RnnBaseConfig::hidden_size, ChainConfig::
+  // hidden_dim, MlpConfig::hidden_sizes = [h]; in_dim <= 5, widths <= 128): `exec` is the module the kernels run — the
+  // same network embedded in the built shape, every padding weight and bias zero, so padded units stay exactly 0 (GRU:
+  // h' = h / 2 from h = 0; LSTM: c' = c / 2, h' = tanh(0) / 2) and every real dot product only gains terms fma(0, 0, acc).
+  // Its parameter image is refreshed from this module's flat vector before a pass (seq_exec, abi.hip); gradients and
+  // tangents are gathered / scattered between the two layouts (launch_seq_pad / _unpad).  NULL: the module is the built
+  // shape itself.
+  rl_mlp *exec = nullptr;
+  float *x_tmp = nullptr, *x_tan = nullptr;  // [exec->P]: gather scratch, padded tangent (zero outside the real entries)
   // layer l (0 .. n_hidden; the last one is the output layer): fan-in, fan-out, offset of its kernel in the flat
   // parameter vector ([W, b] per layer, the reference's order)
   uint32_t n_layers() const { return n_hidden + 1; }

@@ -94,6 +94,10 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
                      const int32_t *d_skip, float clip_lo, float clip_hi);
 void launch_gen_values(rl_traj *t, const rl_mlp *critic);  // -> seq.out / seq.succ (plane 0)
 void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t);
+// a recurrent chain of other widths embedded in the kernels' shape (rl_mlp::exec): copy the flat vector `real_src`
+// (layout of `real`) into the padded layout `exec_dst` / gather the padded vector `exec_src` into the flat layout
+void launch_seq_pad(const rl_mlp *real, float *exec_dst, const float *real_src);
+void launch_seq_unpad(const rl_mlp *real, const float *exec_src, float *real_dst);
 // kernels_seq_train.hip: the GRU chain's training passes with the recurrence on the bf16 matrix pipe
 void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
 void launch_gru_train_head_backward(rl_traj *traj, const rl_mlp *mod, float *d_slab, const int32_t *d_skip);

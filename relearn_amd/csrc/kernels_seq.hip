@@ -792,7 +792,10 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
         const bool ended = ends[m] != 0;
         const float hv = peeking ? hown[r] : hout[r];
         hown[r] = ended ? 0.0f : hv;
-        if (ended && r < 8) sh.hT[buf][j][m] = 0.0f;
+        // (after a peek the LDS image of the post-step state is written again from the owners' registers: the LSTM cell
+        // parks the head's activations in the buffer it has just read — the peek's input, i.e. exactly that state; found
+        // in round 4 with histories whose lanes are interrupted at different steps)
+        if ((ended || peeking) && r < 8) sh.hT[buf][j][m] = hown[r];
       }
       cur = buf;
       // every thread has `peeking` in a register: the flag in LDS may be cleared while others still evaluate the branch
@@ -911,6 +914,54 @@ void launch_seq_gae(rl_traj *traj, float gamma, float lambda) {
   uint32_t n = traj->d.n;
   hipLaunchKernelGGL(k_seq_gae, dim3(cdiv_s(n, 64)), dim3(64), 0, traj->eng->stream, traj->d, traj->seq.out,
                      traj->seq.succ, gamma, lambda);
+}
+
+// ---------------------------------------------------------------- other widths embedded in the built shape
+// index in the padded (5 -> GH -> MH) layout of element i of a chain's flat vector with logical widths D, H (recurrent),
+// H2 (MLP hidden), A outputs and NG gates — RnnWeights order: w_ih [NG H, D], w_hh [NG H, H], b_ih, b_hh, then the MLP
+__device__ __forceinline__ uint32_t seq_pad_index(uint32_t i, uint32_t D, uint32_t H, uint32_t H2, uint32_t A, uint32_t NG) {
+  const uint32_t nWih = NG * H * D, nWhh = NG * H * H, nb = NG * H, nW1 = H2 * H, nW2 = A * H2;
+  const uint32_t xWhh = NG * GH * 5, xbih = xWhh + NG * GH * GH, xbhh = xbih + NG * GH, xW1 = xbhh + NG * GH;
+  const uint32_t xb1 = xW1 + MH * GH, xW2 = xb1 + MH, xb2 = xW2 + A * MH;
+  if (i < nWih) {
+    const uint32_t row = i / D, d = i % D;
+    return ((row / H) * GH + row % H) * 5 + d;
+  }
+  i -= nWih;
+  if (i < nWhh) {
+    const uint32_t row = i / H, k = i % H;
+    return xWhh + ((row / H) * GH + row % H) * GH + k;
+  }
+  i -= nWhh;
+  if (i < nb) return xbih + (i / H) * GH + i % H;
+  i -= nb;
+  if (i < nb) return xbhh + (i / H) * GH + i % H;
+  i -= nb;
+  if (i < nW1) return xW1 + (i / H) * GH + i % H;
+  i -= nW1;
+  if (i < H2) return xb1 + i;
+  i -= H2;
+  if (i < nW2) return xW2 + (i / H2) * MH + i % H2;
+  return xb2 + (i - nW2);
+}
+template <bool GATHER>
+__global__ void k_seq_pad(const float *__restrict__ src, float *__restrict__ dst, uint32_t P, uint32_t D, uint32_t H,
+                          uint32_t H2, uint32_t A, uint32_t NG) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t x = seq_pad_index(i, D, H, H2, A, NG);
+  if (GATHER) dst[i] = src[x];
+  else dst[x] = src[i];
+}
+void launch_seq_pad(const rl_mlp *real, float *exec_dst, const float *real_src) {
+  const uint32_t P = (uint32_t)real->P;
+  hipLaunchKernelGGL(k_seq_pad<false>, dim3((P + 255) / 256), dim3(256), 0, real->eng->stream, real_src, exec_dst, P,
+                     real->in_dim, real->gru_hidden, real->hidden, real->out_dim, (uint32_t)rl_module_gates(real->kind));
+}
+void launch_seq_unpad(const rl_mlp *real, const float *exec_src, float *real_dst) {
+  const uint32_t P = (uint32_t)real->P;
+  hipLaunchKernelGGL(k_seq_pad<true>, dim3((P + 255) / 256), dim3(256), 0, real->eng->stream, exec_src, real_dst, P,
+                     real->in_dim, real->gru_hidden, real->hidden, real->out_dim, (uint32_t)rl_module_gates(real->kind));
 }
 
 void launch_chain_reset(rl_env *env) {

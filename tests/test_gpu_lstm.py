@@ -25,8 +25,8 @@ def test_lstm_init_bit_exact(engine):
         assert m.P == L.oracle_gru_num_params(shape) == 4 * 128 * 5 + 4 * 128 * 128 + 8 * 128 + 128 * 128 + 128 + \
             shape.out_dim * 128 + shape.out_dim
         assert np.array_equal(m.get_params(), O.gru_init(shape, seed))
-    with pytest.raises(ra.RelearnError) as e:
-        ra.LstmMlp(engine, 5, 2, lstm_hidden=64)
+    with pytest.raises(ra.RelearnError) as e:  # (narrower chains are built since round 4: tests/test_gpu_gru.py)
+        ra.LstmMlp(engine, 5, 2, lstm_hidden=129)
     assert e.value.code == ra.ERR_BUILD_AGENT
 
 
@@ -255,3 +255,21 @@ def test_the_lstm_policy_learns_the_memory_game(engine):
         ra.reward_to_go(traj, 1.0)
         ra.ppo_update(pol, opt, traj, cfg)
     assert 0.4 < acc[0] < 0.6 and acc[-1] >= 0.9, acc
+
+
+def test_successor_evaluations_leave_the_state_of_the_other_lanes_alone(engine):
+    """A history whose lanes are interrupted at DIFFERENT steps (what CartPole lanes under a step limit produce once
+    episodes have ended at different times): the successor evaluation of an interrupted lane runs as an extra iteration
+    of its whole tile, and every other lane must enter the next step with the state it had.  (Round 4: the LSTM cell
+    parked the head's activations in the state buffer that iteration had just read; the env-made histories of the other
+    tests interrupt all lanes of a tile at once, where the state is reset anyway.)  Outputs and successor outputs bit
+    for bit against the oracle, for both cells."""
+    from test_gpu_gru import synthetic_history
+    for cls, shape in ((ra.LstmMlp, O.LstmShape(5, 128, 128, 1)), (ra.GruMlp, O.GruShape(5, 128, 128, 2))):
+        m = cls(engine, 5, shape.out_dim)
+        m.init(17)
+        traj, want = synthetic_history(engine, 96, 20, 5, 8)
+        out_d, succ_d = m.seq_forward(traj)
+        out_o, succ_o = O.gru_seq_forward(shape, m.get_params(), want)
+        assert np.array_equal(out_d, out_o) and np.array_equal(succ_d, succ_o)
+        assert 0 < (want["flag"] == O.INTERRUPT).mean() < 0.5
