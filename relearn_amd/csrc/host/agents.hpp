@@ -424,6 +424,10 @@ class Trpo final : public Policy {  // policies/trpo.rs:63-164
     rl_trpo_stats st{};
     check(rl_trpo_update(module_->handle(), history.handle(), &cfg_, &st), eng_.handle());  // OptimizerNanError: the
                                                                                            // reference panics (trpo.rs:154-162)
+    log_stats(st, logger);
+  }
+  const rl_trpo_config &config() const { return cfg_; }
+  void log_stats(const rl_trpo_stats &st, StatsLogger &logger) {
     logger.log_scalar("entropy", st.entropy);                  // trpo.rs:119
     logger.log_scalar("step_size", st.step_size);              // conjugate_gradient.rs:164
     logger.log_scalar("loss_initial", st.loss_initial);        // :200
@@ -542,6 +546,14 @@ class ValuesOpt final : public Critic {  // critics/opt.rs:41-126
     check(rl_values_opt_update(module_->handle(), optimizer_->handle(), history.handle(), &vc, &cs, nullptr), eng_.handle());
     logger.log_scalar("loss", cs.loss_last);  // n_backward_steps, ToLog::All (torch/agents/mod.rs:68-70)
   }
+  rl_values_opt_config config() const {
+    rl_values_opt_config vc{};
+    vc.opt_steps_per_update = steps_;
+    vc.target = target_ == StepValueTarget::OneStepTd ? RL_VALUE_TARGET_ONE_STEP_TD : RL_VALUE_TARGET_REWARD_TO_GO;
+    vc.discount_factor = gamma_;
+    return vc;
+  }
+  Optimizer &optimizer() { return *optimizer_; }
   Module *module() override { return module_.get(); }
   double discount_factor() const override { return gamma_; }
 
@@ -658,8 +670,28 @@ class ActorCriticAgent {
       eng_.sync();
     });
     ScopedLogger pl(logger, "policy");
-    log_elapsed(pl, "update_time", [&] { policy_->update(history, pl); eng_.sync(); });
     ScopedLogger cl(logger, "critic");
+    Trpo *trpo = dynamic_cast<Trpo *>(policy_.get());
+    ValuesOpt *vopt = dynamic_cast<ValuesOpt *>(critic_.get());
+    if (trpo != nullptr && vopt != nullptr) {
+      // policy.update and critic.update share nothing but the history and its advantages: one call, the two launch chains
+      // side by side on two streams (rl_actor_critic_update; the same numbers as the two updates in turn).  Both scopes
+      // log the joint wall time as their update_time.
+      rl_trpo_stats ps{};
+      rl_critic_stats cs{};
+      const rl_values_opt_config vc = vopt->config();
+      const auto t0 = std::chrono::steady_clock::now();
+      check(rl_actor_critic_update(trpo->module().handle(), vopt->module()->handle(), vopt->optimizer().handle(),
+                                   history.handle(), &trpo->config(), &vc, &ps, &cs, nullptr),
+            eng_.handle());
+      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      trpo->log_stats(ps, pl);
+      pl.log_duration("update_time", secs);
+      cl.log_scalar("loss", cs.loss_last);
+      cl.log_duration("update_time", secs);
+      return;
+    }
+    log_elapsed(pl, "update_time", [&] { policy_->update(history, pl); eng_.sync(); });
     log_elapsed(cl, "update_time", [&] { critic_->update(history, cl); });
   }
 

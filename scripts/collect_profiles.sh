@@ -4,7 +4,7 @@
 #   and the PMC passes (SQ counters, FETCH_SIZE, WRITE_SIZE) over one period of the hot path.
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 OUT="gpurun_out/prof_$TAG"
 rm -rf "$OUT" && mkdir -p "$OUT"
@@ -17,12 +17,13 @@ for n in 65536 8192 4096; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$n" -- python3 bench.py --envs $n --steps 3 --warmup 1 --no-cpu-baseline \
     > "$OUT/bench_under_rocprof_$n.json" 2> "$OUT/stats_$n.log" || echo "rocprof stats $n failed"
 done
-bash scripts/pmc_passes.sh "${TAG}_65536" scripts/path_once.py 65536 1 80 > "$OUT/pmc_65536.log" 2>&1 || echo "pmc failed"
+bash scripts/pmc_passes.sh "${TAG}_65536" scripts/path_once.py 65536 2 80 > "$OUT/pmc_65536.log" 2>&1 || echo "pmc failed"
 cp "gpurun_out/pmc/${TAG}_65536/summary.json" "$OUT/pmc_65536_summary.json" 2>/dev/null
 # the other configurations: DQN (config 3) with its kernel trace, GRU (config 5), the general MLP period and its passes
 python3 scripts/dqn_config3.py > "$OUT/dqn_config3.json" 2> "$OUT/dqn_config3.err" || echo "dqn failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dqn" -- python3 scripts/dqn_config3.py 4096 1221 3 \
   > "$OUT/dqn_under_rocprof.json" 2> "$OUT/stats_dqn.log" || echo "rocprof dqn failed"
+python3 scripts/lstm_config5.py > "$OUT/lstm_config5.json" 2> "$OUT/lstm_config5.err" || echo "lstm failed"
 python3 scripts/gru_config5.py > "$OUT/gru_config5.json" 2> "$OUT/gru_config5.err" || echo "gru failed"
 python3 scripts/general_mlp_period.py > "$OUT/general_mlp_period.json" 2> "$OUT/general_mlp_period.err" || echo "general failed"
 python3 scripts/gen_passes.py > "$OUT/general_mlp_passes.txt" 2>&1 || echo "gen passes failed"
