@@ -234,7 +234,8 @@ typedef enum {
  * 128 units with the reference's defaults (Relu, Identity) is rl_mlp_create — the fused kernels every BASELINE
  * configuration runs on, which are built for exactly that; any other shape or activation runs per-layer kernels
  * (relearn_amd/csrc/kernels_general.hip: the general path, not the fast one) behind the same entry points — rollouts,
- * GAE, TRPO / PPO / REINFORCE and critic updates, row-wise forward, actor serialisation; DQN takes fused modules only. */
+ * GAE, TRPO / PPO / REINFORCE and critic updates, DQN (collection one launch sequence per step), row-wise forward,
+ * actor serialisation. */
 int32_t rl_mlp_create_layers(rl_engine *engine, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
                              uint32_t out_dim, int32_t activation, int32_t output_activation, rl_mlp **out);
 int32_t rl_mlp_destroy(rl_mlp *mlp);
@@ -479,7 +480,9 @@ typedef struct {
 /* DqnConfig::default (dqn.rs:57-72) with buffer_capacity left at 0 (the caller divides its step budget over the
  * lanes) and discount 0.99 (CartPole, src/envs/cartpole.rs:203-213) */
 int32_t rl_dqn_config_default(rl_dqn_config *cfg);
-/* `qnet` maps obs_dim -> n_actions; `opt` must have been created for `qnet` */
+/* `qnet` maps obs_dim -> n_actions; `opt` must have been created for `qnet`.  DqnConfig<MB> is generic over the module
+ * (dqn.rs:26-39): any feed-forward module builds — the fused 5-128-2 shape on the fused kernels, other MlpConfigs on the
+ * per-layer kernels; recurrent modules -> RL_ERR_BUILD_AGENT. */
 int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_config *cfg, rl_dqn **out);
 int32_t rl_dqn_destroy(rl_dqn *dqn);
 /* ExplorationRateSchedule::exploration_rate(global_steps, mode) (schedules.rs:35-45); training = 0 -> 0.0 */

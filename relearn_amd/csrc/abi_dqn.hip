@@ -93,6 +93,8 @@ static void dqn_release_device(rl_dqn *q) {
   q->main_event = nullptr;
   if (q->h_counts) (void)hipHostFree(q->h_counts);
   dfree(q->snap);
+  dfree(q->d_q);
+  dfree(q->d_q_next);
   q->h_counts = nullptr;
   q->d_agent_pos = nullptr;
   q->d_ep_lane = q->d_ep_start = q->d_ep_len = q->d_ep_off = nullptr;
@@ -124,8 +126,10 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     RL_REQUIRE(opt->mod == qnet, "optimizer does not belong to the action-value module");
     RL_REQUIRE(qnet->in_dim == env->D && qnet->out_dim == env->A, "action-value module does not match the env");
     RL_REQUIRE(env->A == 2, "DQN kernels are built for 2-action envs");
-    if (qnet->general || rl_module_is_recurrent(qnet->kind))
-      throw RlError(RL_ERR_BUILD_AGENT, "DQN is built for action-value modules with one hidden layer of at most 128 units");
+    // DqnConfig<MB> is generic over the module (dqn.rs:26-39): feed-forward modules of any MlpConfig build (the fused
+    // 5-128-2 shape on the fused kernels, others on the per-layer kernels); recurrent action-value modules do not
+    if (rl_module_is_recurrent(qnet->kind))
+      throw RlError(RL_ERR_BUILD_AGENT, "DQN is built for feed-forward action-value modules");
     RL_REQUIRE(cfg->target == RL_DQN_TARGET_REWARD_TO_GO || cfg->target == RL_DQN_TARGET_ONE_STEP_TD, "bad target");
     RL_REQUIRE(cfg->minibatch_steps > 0 && cfg->minibatch_steps < (1ull << 30), "bad minibatch_steps");
     RL_REQUIRE(cfg->buffer_capacity > 0 && cfg->buffer_capacity < (1ull << 31), "bad buffer_capacity");
@@ -226,7 +230,12 @@ int32_t rl_dqn_collect(rl_dqn *q, uint64_t horizon, rl_dqn_collect_stats *stats)
     RL_REQUIRE(eps >= 0.0 && eps <= 1.0, "exploration rate outside [0, 1]");
     int always = eps == 1.0 ? 1 : 0;
     uint64_t p_int = always ? ~0ull : (uint64_t)(eps * 18446744073709551616.0);
-    launch_rollout_dqn(q->env, q->qnet, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
+    if (q->qnet->general) {
+      if (!q->d_q) q->d_q = dalloc<float>(2 * (size_t)q->rp.N);
+      launch_rollout_dqn_general(q->env, q->qnet, q->mb, q->d_q, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
+    } else {
+      launch_rollout_dqn(q->env, q->qnet, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
+    }
     q->env->t_global += horizon;
     q->steps_per_lane += horizon;
     q->last_horizon = horizon;
@@ -319,9 +328,26 @@ static void dqn_build_minibatch(rl_dqn *q, uint32_t k, const DqnCountsDev &c, ui
   mb->d.T = 1;
   traj_plan(mb, c.n_steps);
   const size_t o = (size_t)k * q->max_eps;
+  const bool td = q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD;
+  if (td && q->qnet->general) {
+    // the builder's in-kernel forward is the fused module's; any other module: gather with rewards, successor codes and
+    // successor observations (time slot 1), the module's layer kernels over the successor observations, then the targets
+    launch_dqn_build_all(q->eng, q->rp, 1, c.n_eps, q->max_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o,
+                         q->d_ep_off + o, q->d_counts + k, mb->d.obs, 0, mb->d.action, mb->d.adv, 0,
+                         q->cfg.discount_factor, mb->d.flag);
+    if (q->cap_q_next < 2ull * c.n_steps) {
+      dfree(q->d_q_next);
+      q->d_q_next = nullptr;
+      q->d_q_next = dalloc<float>(2ull * q->max_steps_mb);
+      q->cap_q_next = 2ull * q->max_steps_mb;
+    }
+    launch_gen_forward(mb, q->qnet, mb->d.obs + c.n_steps, (size_t)2 * c.n_steps, c.n_steps, q->d_q_next);
+    launch_dqn_td_targets(q->eng, mb->d.adv, mb->d.flag, q->d_q_next, c.n_steps, q->cfg.discount_factor);
+    return;
+  }
   launch_dqn_build_minibatch(q->eng, q->rp, c.n_eps, q->d_ep_lane + o, q->d_ep_start + o, q->d_ep_len + o,
                              q->d_ep_off + o, mb->d.obs, (size_t)2 * c.n_steps, mb->d.action, mb->d.adv,
-                             q->cfg.discount_factor, q->cfg.target == RL_DQN_TARGET_ONE_STEP_TD ? 1 : 0, q->qnet);
+                             q->cfg.discount_factor, td ? 1 : 0, q->qnet);
 }
 
 static void dqn_sample_minibatch(rl_dqn *q, int sequential) {

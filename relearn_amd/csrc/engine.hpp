@@ -315,6 +315,9 @@ struct rl_dqn {
   std::vector<hipEvent_t> draw_events;
   hipEvent_t main_event = nullptr;
   DqnCountsDev *h_counts = nullptr;  // pinned, [K]
+  float *d_q = nullptr, *d_q_next = nullptr;  // module outputs of a collection step [2][N] / at a minibatch's successor
+                                              // observations (action-value modules on the per-layer kernels)
+  uint64_t cap_q_next = 0;
   float *snap = nullptr;             // parameters + Adam moments + step count as of the start of a pipelined update
   // ... `mb` then points into them (the last minibatch stays readable); its own arrays, for the one-at-a-time builder:
   float *own_obs = nullptr, *own_target = nullptr;

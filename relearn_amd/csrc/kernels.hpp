@@ -53,6 +53,12 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
 // kernels_dqn.hip
 void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
                         int always_explore, uint8_t *d_flags);
+// an action-value module of any shape (rl_mlp::general): one launch sequence per step; `ws` lends the layer kernels their
+// workspace, d_q [2][n] receives the module's outputs of every step
+void launch_rollout_dqn_general(rl_env *env, const rl_mlp *qnet, rl_traj *ws, float *d_q, const ReplayDev &rp, uint32_t T,
+                                uint64_t p_int, int always_explore, uint8_t *d_flags);
+void launch_dqn_td_targets(rl_engine *eng, float *d_target, const uint8_t *d_flag, const float *d_q_next, uint32_t n,
+                           float gamma);
 struct AgentKey { uint32_t w[8]; };
 void launch_dqn_sample(rl_engine *eng, hipStream_t stream, const ReplayDev &rp, const AgentKey &key, uint64_t *d_agent_pos,
                        uint32_t minibatch_steps, uint32_t max_eps, uint32_t *d_lane, uint32_t *d_start,

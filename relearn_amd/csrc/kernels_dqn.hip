@@ -153,6 +153,96 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
   lane_store(st, i, s);
 }
 
+// ---------------------------------------------------------------- collection with an action-value module of any shape
+// DqnConfig<MB> is generic over the module (src/torch/agents/dqn.rs:26-39).  A module the fused collection kernel is not
+// built for (rl_mlp::general: several hidden layers, other activations, a wider layer) collects one launch sequence per
+// step — observe, the module's layer kernels over all lanes (kernels_general.hip), then this kernel: DqnActor::act
+// (dqn.rs:360-379) from the lane's actor stream with the greedy branch reading the module's outputs, the env step, the
+// ring write — with the fused kernel's stream discipline, ring bookkeeping and horizon rule (above), one thread per lane.
+template <int D, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_dqn_lane_step(CartPoleDev c, EnvStateDev st, ReplayDev rp,
+                                                         const float *__restrict__ q_values /* [2][n] */, uint64_t p_int,
+                                                         int always_explore, int last_step,
+                                                         uint8_t *__restrict__ flags_row) {
+  __shared__ uint32_t words[16 * BLOCK];
+  const uint32_t n = rp.N;
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t lane = c.lane_offset + i;
+  LaneState s;
+  lane_load(st, i, s);
+  LaneRing ring{rp.head[i], rp.count[i], rp.ep_head[i], rp.ep_count[i], rp.total[i]};
+  struct EpEnds {
+    uint32_t *base;
+    uint32_t N, lane;
+    __device__ uint32_t get(uint32_t k) const { return base[(size_t)k * N + lane]; }
+    __device__ void set(uint32_t k, uint32_t v) { base[(size_t)k * N + lane] = v; }
+  } eps{rp.ep_end, n, i};
+  LaneActorRng<BLOCK> rng{&words[threadIdx.x], c.key_actor, lane, rp.actor_pos[i], ~0ull};
+  float f[D];
+  cp_features<D>(c, s, f);
+  int a;
+  bool explore = always_explore != 0;
+  if (!explore) explore = rng.next_u64() < p_int;  // Bernoulli::sample: v < (p * 2^64) as u64
+  if (explore) {
+    for (;;) {  // UniformInt::sample_single(0, 2)
+      const uint64_t v = rng.next_u64();
+      const uint64_t lo = v << 1, hi = v >> 63;
+      if (lo <= 0x7fffffffffffffffull) {
+        a = (int)hi;
+        break;
+      }
+    }
+  } else {
+    a = q_values[n + i] > q_values[i] ? 1 : 0;  // argmax: first maximal index
+  }
+  int succ = cp_step(c, s, a);
+  const bool horizon_cut = succ == RL_SUCC_CONTINUE && last_step != 0;
+  const int succ_rec = horizon_cut ? RL_SUCC_INTERRUPT : succ;
+  const uint32_t slot_abs = ring_write_step(ring, rp.C, rp.E, eps, succ_rec != RL_SUCC_CONTINUE);
+  if (slot_abs == 0xffffffffu) {  // WriteExperienceError::Full (the lane stops here; the host raises the error)
+    *rp.error = 1;
+    return;
+  }
+  const size_t o = (size_t)i * rp.C + slot_abs % rp.C;
+  ReplayRec rec;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) rec.x[d] = d < D ? f[d < D ? d : 0] : 0.0f;
+  rec.reward = 1.0f;
+  rec.af = (uint32_t)a | (uint32_t)succ_rec << 8;
+  rec_store(rp.rec + o, rec);
+  if (succ_rec == RL_SUCC_INTERRUPT) {
+    cp_features<D>(c, s, f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) rp.next[o].x[d] = f[d];
+  }
+  flags_row[i] = (uint8_t)succ_rec;
+  if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, lane);
+  rp.head[i] = ring.head;
+  rp.count[i] = ring.count;
+  rp.ep_head[i] = ring.ep_head;
+  rp.ep_count[i] = ring.ep_count;
+  rp.total[i] = ring.total;
+  rp.actor_pos[i] = rng.pos;
+  lane_store(st, i, s);
+}
+
+// one-step TD targets from the module's outputs at the successor observations (the gather left rewards where the
+// targets go and the successor codes in `flag`): r + gamma * max_a Q(s'), 0 beyond a Terminate — the arithmetic of
+// k_dqn_build_minibatch (amax, `scalar * tensor`, then `tensor + tensor`)
+__global__ void k_dqn_td_targets(float *__restrict__ tgt, const uint8_t *__restrict__ flag,
+                                 const float *__restrict__ q_next /* [2][n] */, uint32_t n, float gamma) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float vnext = 0.0f;
+  if (flag[i] != RL_SUCC_TERMINATE) {
+    const float z0 = q_next[i], z1 = q_next[n + i];
+    vnext = z1 > z0 ? z1 : z0;
+  }
+  const float dn = gamma * vnext;
+  tgt[i] = tgt[i] + dn;
+}
+
 // Minibatch builder: one workgroup per sampled episode.  Gathers the episode's steps from the ring into the compact
 // sample arrays (obs plane stride `out_plane`) and computes the value targets:
 //   RewardToGo: G_t = r_t + gamma * G_{t+1} (f32 multiply, then add — packed.rs:312-342 arithmetic)
@@ -601,6 +691,34 @@ void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, ui
     default: launch_rollout_dqn_g<1>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
   }
   RL_HIP_CHECK(hipGetLastError());
+}
+
+void launch_rollout_dqn_general(rl_env *env, const rl_mlp *qnet, rl_traj *ws, float *d_q, const ReplayDev &rp, uint32_t T,
+                                uint64_t p_int, int always_explore, uint8_t *d_flags) {
+  ProfScope ps(env->eng, RL_K_ROLLOUT);
+  constexpr int BLOCK = 64;
+  const uint32_t n = (uint32_t)env->cfg.n_lanes;
+  for (uint32_t t = 0; t < T; ++t) {
+    if (!always_explore) {  // (a collection that always explores never reads the module)
+      launch_env_observe(env, env->d_obs);                          // [D][n]
+      launch_gen_forward(ws, qnet, env->d_obs, (size_t)n, n, d_q);  // [2][n]
+    }
+    if (env->D == 5)
+      hipLaunchKernelGGL((k_dqn_lane_step<5, BLOCK>), dim3(cdiv_d(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream, env->dev,
+                         env->st, rp, d_q, p_int, always_explore, t + 1 == T ? 1 : 0, d_flags + (size_t)t * n);
+    else
+      hipLaunchKernelGGL((k_dqn_lane_step<4, BLOCK>), dim3(cdiv_d(n, BLOCK)), dim3(BLOCK), 0, env->eng->stream, env->dev,
+                         env->st, rp, d_q, p_int, always_explore, t + 1 == T ? 1 : 0, d_flags + (size_t)t * n);
+  }
+  RL_HIP_CHECK(hipGetLastError());
+}
+
+void launch_dqn_td_targets(rl_engine *eng, float *d_target, const uint8_t *d_flag, const float *d_q_next, uint32_t n,
+                           float gamma) {
+  ProfScope ps(eng, RL_K_VALUES);
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_dqn_td_targets, dim3(cdiv_d(n, 256)), dim3(256), 0, eng->stream, d_target, d_flag, d_q_next, n,
+                     gamma);
 }
 
 void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,

@@ -281,3 +281,118 @@ def test_cartpole_dqn_learns_something(engine):
         last = st.loss_last
         assert np.isfinite(st.loss_first) and np.isfinite(st.loss_last)
     assert last < first
+
+
+# ------------------------------------------------------------------ action-value modules of any MlpConfig
+# DqnConfig<MB> is generic over the module (src/torch/agents/dqn.rs:26-39): several hidden layers, other activations or
+# a wider layer run the per-layer kernels (collection: one launch sequence per step).  Checked against DqnActor::act
+# restated here on the raw actor stream (oracle Prng), the oracle's lanes for the env side, and the f64 NumPy network of
+# tests/test_gpu_general_mlp.py.
+def make_general(engine, hidden, act="Relu", n=64, capacity=64, minibatch=700, td=False, opt_steps=3, max_steps=23,
+                 eps=0.3):
+    env = ra.CartPoleEnv(engine, n, max_steps=max_steps, limit=ra.LIMIT_VISIBLE, seed_env=21, seed_actor=34)
+    sim = O.LaneSim(n, max_steps=max_steps, limit=ra.LIMIT_VISIBLE, seed_env=21, seed_actor=34)
+    q = ra.Mlp(engine, 5, hidden, 2, act, "Identity")
+    q.init(77)
+    cfg = ra.dqn_config_default()
+    cfg.target = ra.DQN_TARGET_ONE_STEP_TD if td else ra.DQN_TARGET_REWARD_TO_GO
+    cfg.exploration_kind, cfg.exploration_start = ra.SCHEDULE_CONSTANT, eps
+    cfg.minibatch_steps, cfg.opt_steps_per_update, cfg.buffer_capacity, cfg.discount_factor = minibatch, opt_steps, capacity, 0.99
+    for i, k in enumerate(KEY):
+        cfg.agent_key[i] = k
+    return ra.Dqn(env, q, ra.Adam(q), cfg), sim, q
+
+
+@pytest.mark.parametrize("hidden,act", [([64, 64], "Relu"), ([200], "Relu"), ([32, 16, 8], "Tanh")])
+def test_general_action_value_module_collection(engine, hidden, act):
+    """every step of a collection: the env side replays bit for bit through the oracle's lanes, the explore / greedy
+    decision and the random action are the lane's sequential actor-stream draws (Bernoulli, then gen_range(0..2)), the
+    greedy action is the argmax of the module's outputs (compared where the two values are not within 1e-5), and the
+    stream position the lane ends on is the oracle generator's"""
+    import ctypes as C
+    from test_gpu_general_mlp import forward64, unflatten
+    n, T, eps = 64, 40, 0.3
+    dqn, sim, q = make_general(engine, hidden, act, n=n, eps=eps)
+    obs0 = sim.observe()
+    dqn.collect(T)
+    obs, act_rec, flag = dqn.replay_read(ra.REPLAY_OBS), dqn.replay_read(ra.REPLAY_ACTION), dqn.replay_read(ra.REPLAY_FLAG)
+    nobs = dqn.replay_read(ra.REPLAY_NEXT_OBS)
+    assert np.array_equal(dqn.replay_read(ra.REPLAY_TOTAL), np.full(n, T, dtype=np.uint32))
+    net = unflatten(q.get_params(), 5, hidden, 2)
+    L = O.lib()
+    rngs = []
+    for i in range(n):
+        r = O.Prng()
+        L.oracle_prng_seed_from_u64(C.byref(r), 34)
+        L.oracle_prng_set_stream(C.byref(r), i)
+        L.oracle_prng_set_word_pos(C.byref(r), 0)
+        rngs.append(r)
+    cur, greedy_checked, explored = obs0, 0, 0
+    for t in range(T):
+        assert np.array_equal(obs[:, t, :], cur), t  # slot t = step t (no eviction: T <= capacity)
+        z, _ = forward64(net, cur.T, act, "Identity")
+        for i in range(n):
+            if L.oracle_prng_gen_bool(C.byref(rngs[i]), eps):
+                assert act_rec[t, i] == L.oracle_prng_gen_range_u64(C.byref(rngs[i]), 0, 2), (t, i)
+                explored += 1
+            elif abs(z[i, 1] - z[i, 0]) > 1e-5:
+                assert act_rec[t, i] == (1 if z[i, 1] > z[i, 0] else 0), (t, i)
+                greedy_checked += 1
+        reward, fl, nxt, term = sim.step(act_rec[t])
+        want_flag = fl.copy()
+        if t == T - 1:
+            want_flag[fl == O.CONTINUE] = O.INTERRUPT  # the horizon rule: the open episode closes as Interrupt(successor)
+        assert np.array_equal(flag[t], want_flag), t
+        m = fl == O.INTERRUPT
+        assert np.array_equal(nobs[:, t, m], term[:, m])
+        cur = nxt
+    assert explored > 0.2 * n * T and greedy_checked > 0.5 * n * T
+    pos = np.array([L.oracle_prng_word_pos(C.byref(r)) for r in rngs], dtype=np.uint64)
+    assert np.array_equal(dqn.replay_read(ra.REPLAY_ACTOR_POS), pos)
+
+
+@pytest.mark.parametrize("td", [False, True], ids=["reward-to-go", "one-step-td"])
+def test_general_action_value_module_update(engine, td):
+    """a minibatch's targets and the MSE gradient on the taken action's value for a [64, 64] module against the f64
+    NumPy network (one-step TD: r + gamma max_a Q(s'), 0 beyond a Terminate, successor = the next stored step or the
+    stored Interrupt successor), then an update whose loss falls"""
+    from test_gpu_general_mlp import backward64, forward64, unflatten
+    hidden = [64, 64]
+    dqn, sim, q = make_general(engine, hidden, td=td, n=128, capacity=96, minibatch=3000, opt_steps=8)
+    dqn.collect(70)
+    ne, ns = dqn.minibatch_sample()
+    obs, a, tgt = dqn.minibatch_read(ra.MB_OBS), dqn.minibatch_read(ra.MB_ACTION), dqn.minibatch_read(ra.MB_TARGET)
+    lanes, starts, lens = (dqn.minibatch_read(f) for f in (ra.MB_EP_LANE, ra.MB_EP_START, ra.MB_EP_LEN))
+    net = unflatten(q.get_params(), 5, hidden, 2)
+    robs, rflag, rnext = dqn.replay_read(ra.REPLAY_OBS), dqn.replay_read(ra.REPLAY_FLAG), dqn.replay_read(ra.REPLAY_NEXT_OBS)
+    rrew = dqn.replay_read(ra.REPLAY_REWARD)
+    want_t, k = np.zeros(ns), 0
+    for ln, st, le in zip(lanes, starts, lens):
+        slots = (int(st) + np.arange(int(le))) % dqn.C
+        r = rrew[slots, ln].astype(np.float64)
+        if td:
+            succ = np.where((rflag[slots, ln] == O.INTERRUPT)[None] | (np.arange(le) == le - 1)[None],
+                            rnext[:, slots, ln], robs[:, np.roll(slots, -1), ln])
+            zn, _ = forward64(net, succ.T)
+            vn = np.where(rflag[slots, ln] == O.TERMINATE, 0.0, zn.max(axis=1))
+            want_t[k:k + le] = r + 0.99 * vn
+        else:
+            g = 0.0
+            for j in range(int(le) - 1, -1, -1):
+                g = r[j] + (0.99 * g if j < le - 1 else 0.0)
+                want_t[k + j] = g
+        k += int(le)
+    assert k == ns and np.allclose(tgt, want_t, rtol=2e-5, atol=2e-5)
+    z, acts = forward64(net, obs.T)
+    qa = z[np.arange(ns), a]
+    dz = np.zeros_like(z)
+    dz[np.arange(ns), a] = 2.0 * (qa - tgt.astype(np.float64)) / ns
+    want_g = backward64(net, obs.T, acts, dz)
+    g_d, loss_d = dqn.minibatch_gradient()
+    assert np.abs(g_d - want_g).max() <= 2e-5 * np.abs(want_g).max() + 1e-9
+    assert abs(loss_d - ((qa - tgt) ** 2).mean()) <= 1e-5 * ((qa - tgt) ** 2).mean()
+    p0 = q.get_params()
+    st, losses = dqn.update(want_losses=True)
+    assert st.opt_steps == 8 and np.all(np.isfinite(losses)) and not np.array_equal(q.get_params(), p0)
+    if not td:  # (bootstrapped targets move with the network: eight steps on eight different minibatches need not lower it)
+        assert losses[-1] < losses[0]

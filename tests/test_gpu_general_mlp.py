@@ -157,17 +157,18 @@ def test_invalid_activations_are_refused(engine):
     # the reference's defaults on one hidden layer of <= 128 units are the fused module, anything else the general one
     q = ra.Mlp(engine, 5, [64], 2, "Tanh", "Identity")
     env = ra.CartPoleEnv(engine, 64)
-    with pytest.raises(ra.RelearnError):  # DQN: fused modules only
-        ra.Dqn(env, q, ra.Adam(q), ra.dqn_config_default())
+    cfg = ra.dqn_config_default()
+    cfg.buffer_capacity, cfg.minibatch_steps = 64, 100
+    ra.Dqn(env, q, ra.Adam(q), cfg).close()  # (DQN takes any feed-forward module: tests/test_gpu_dqn.py)
 
 
 def test_unsupported_shapes_are_refused(engine):
     for hidden in ([300], [8] * 5, [0]):
         with pytest.raises(ra.RelearnError):
             ra.Mlp(engine, 5, hidden, 2)
-    q = ra.Mlp(engine, 5, [64, 64], 2)
+    q = ra.GruMlp(engine, 5, 2)
     env = ra.CartPoleEnv(engine, 64)
-    with pytest.raises(ra.RelearnError):  # DQN: single-hidden-layer modules only
+    with pytest.raises(ra.RelearnError):  # DQN: feed-forward action-value modules only
         ra.Dqn(env, q, ra.Adam(q), ra.dqn_config_default())
 
 
