@@ -17,8 +17,24 @@ for n in 65536 8192 4096; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$n" -- python3 bench.py --envs $n --steps 3 --warmup 1 --no-cpu-baseline \
     > "$OUT/bench_under_rocprof_$n.json" 2> "$OUT/stats_$n.log" || echo "rocprof stats $n failed"
 done
+# the same command with the two update chains in turn: per-kernel averages that agree with the HIP-event figures of the
+# bench line (its profiled period runs the chains in turn; side by side, a launch's span includes the other chain's work)
+for n in 65536 8192; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial_$n" -- python3 bench.py --envs $n --steps 3 --warmup 1 --no-cpu-baseline --serial-update \
+    > "$OUT/bench_under_rocprof_serial_$n.json" 2> "$OUT/stats_serial_$n.log" || echo "rocprof serial stats $n failed"
+done
 bash scripts/pmc_passes.sh "${TAG}_65536" scripts/path_once.py 65536 2 80 > "$OUT/pmc_65536.log" 2>&1 || echo "pmc failed"
 cp "gpurun_out/pmc/${TAG}_65536/summary.json" "$OUT/pmc_65536_summary.json" 2>/dev/null
+# which launches of the two update chains ran side by side (the non-profiled periods of the traced bench run)
+python3 scripts/overlap_summary.py "$OUT/stats_65536" "$OUT/overlap_trace_65536.csv" "$OUT/overlap_65536.json" > /dev/null 2>&1 || echo "overlap 65536 failed"
+python3 scripts/overlap_summary.py "$OUT/stats_8192" "$OUT/overlap_trace_8192.csv" "$OUT/overlap_8192.json" > /dev/null 2>&1 || echo "overlap 8192 failed"
+# counters of the other configurations' dominant kernels: the pair kernel of a [64, 64] critic, the DQN update, the GRU passes
+bash scripts/pmc_passes.sh "${TAG}_gen_pair" scripts/gen_critic_only.py 16384 10 64 64 > "$OUT/pmc_gen_pair.log" 2>&1 || echo "pmc gen failed"
+cp "gpurun_out/pmc/${TAG}_gen_pair/summary.json" "$OUT/pmc_gen_pair_summary.json" 2>/dev/null
+bash scripts/pmc_passes.sh "${TAG}_dqn" scripts/dqn_config3.py 4096 1221 3 > "$OUT/pmc_dqn.log" 2>&1 || echo "pmc dqn failed"
+cp "gpurun_out/pmc/${TAG}_dqn/summary.json" "$OUT/pmc_dqn_summary.json" 2>/dev/null
+bash scripts/pmc_passes.sh "${TAG}_gru" scripts/gru_config5.py 16384 100 8 1 > "$OUT/pmc_gru.log" 2>&1 || echo "pmc gru failed"
+cp "gpurun_out/pmc/${TAG}_gru/summary.json" "$OUT/pmc_gru_config5_summary.json" 2>/dev/null
 # the other configurations: DQN (config 3) with its kernel trace, GRU (config 5), the general MLP period and its passes
 python3 scripts/dqn_config3.py > "$OUT/dqn_config3.json" 2> "$OUT/dqn_config3.err" || echo "dqn failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dqn" -- python3 scripts/dqn_config3.py 4096 1221 3 \
