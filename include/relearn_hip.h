@@ -238,6 +238,13 @@ typedef enum {
  * actor serialisation. */
 int32_t rl_mlp_create_layers(rl_engine *engine, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
                              uint32_t out_dim, int32_t activation, int32_t output_activation, rl_mlp **out);
+/* The same with MlpConfig::linear_config's choice of bias vectors (LinearConfig { kernel_init, bias_init: Option<..> },
+ * ff/linear.rs:13-33,54-68): bias = 0 builds every layer WITHOUT a bias vector (bias_init = None) — the flat parameter
+ * vector then holds the kernels only (trainable_variables of such a Linear: the kernel, linear.rs:104-117), actor
+ * documents carry `bias: null`, rl_mlp_init draws the kernels only and rl_mlp_init_with takes bias_init = NULL.  Such
+ * modules run the per-layer kernels (also the 1 x <= 128 Relu shape the fused kernels would otherwise take). */
+int32_t rl_mlp_create_config(rl_engine *engine, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
+                             uint32_t out_dim, int32_t activation, int32_t output_activation, int32_t bias, rl_mlp **out);
 int32_t rl_mlp_destroy(rl_mlp *mlp);
 int32_t rl_mlp_num_params(const rl_mlp *mlp, uint64_t *n);
 /* Linear::new Glorot-uniform init (ff/linear.rs:54-68) from the engine-defined stream ChaCha8(seed) */

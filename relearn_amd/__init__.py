@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "rl_cartpole_params_default", "rl_env_create", "rl_env_destroy", "rl_env_dims", "rl_env_reset",
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
-    "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_mlp_init_with", "rl_params_get", "rl_params_set",
+    "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_create_config", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_mlp_init_with", "rl_params_get", "rl_params_set",
     "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_rnn_mlp_create", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
@@ -512,19 +512,21 @@ class Initializer(C.Structure):
 class Mlp(_Handle):
     """`MlpConfig{hidden_sizes:[H], activation: Relu}.build_module(in, out)`; flat params in reference order."""
 
-    def __init__(self, engine, in_dim, hidden, out_dim, activation="Relu", output_activation="Identity"):
+    def __init__(self, engine, in_dim, hidden, out_dim, activation="Relu", output_activation="Identity", bias=True):
         """`hidden`: the width of the single hidden layer, or MlpConfig's `hidden_sizes` as a list (any number of layers:
         shapes other than one layer of <= 128 units, and activations other than Relu / Identity, run the general
         per-layer kernels); activations by the reference's variant names (ff/activation.rs:11-20)"""
         self.eng = engine
         self.h = C.c_void_p()
-        self.activation, self.output_activation = activation, output_activation
-        if isinstance(hidden, (list, tuple)) or (activation, output_activation) != ("Relu", "Identity"):
+        self.activation, self.output_activation, self.bias = activation, output_activation, bias
+        if isinstance(hidden, (list, tuple)) or (activation, output_activation) != ("Relu", "Identity") or not bias:
             hidden = list(hidden) if isinstance(hidden, (list, tuple)) else [hidden]
             sizes = (C.c_uint32 * max(len(hidden), 1))(*hidden)
-            _check(lib().rl_mlp_create_layers(engine.h, C.c_uint32(in_dim), sizes, C.c_uint32(len(hidden)),
+            # bias = False: LinearConfig::bias_init = None, layers without a bias vector (rl_mlp_create_config)
+            _check(lib().rl_mlp_create_config(engine.h, C.c_uint32(in_dim), sizes, C.c_uint32(len(hidden)),
                                               C.c_uint32(out_dim), C.c_int32(ACTIVATIONS.index(activation)),
-                                              C.c_int32(ACTIVATIONS.index(output_activation)), C.byref(self.h)),
+                                              C.c_int32(ACTIVATIONS.index(output_activation)),
+                                              C.c_int32(1 if bias else 0), C.byref(self.h)),
                    engine.h)
         else:
             _check(lib().rl_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(hidden), C.c_uint32(out_dim),
@@ -549,6 +551,10 @@ class Mlp(_Handle):
             return
         default = ("Uniform", "FanAvg", 0.0)
         k = Initializer.of(kernel_init or default)
+        if not getattr(self, "bias", True):  # LinearConfig::bias_init = None
+            assert bias_init is None, "a module without bias vectors takes no bias initializer"
+            _check(lib().rl_mlp_init_with(self.h, C.c_uint64(seed), C.byref(k), None), self.eng.h)
+            return
         b = Initializer.of(bias_init or default)
         _check(lib().rl_mlp_init_with(self.h, C.c_uint64(seed), C.byref(k), C.byref(b)), self.eng.h)
 

@@ -838,10 +838,11 @@ int32_t rl_mlp_create(rl_engine *e, uint32_t in_dim, uint32_t hidden, uint32_t o
   });
 }
 
-int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
-                             uint32_t out_dim, int32_t activation, int32_t output_activation, rl_mlp **out) {
-  // one hidden layer of at most 128 units, Relu inside and Identity on the output: the fused kernels
-  if (e && out && hidden_sizes && n_hidden == 1 && hidden_sizes[0] <= 128 && activation == RL_ACT_RELU &&
+static int32_t mlp_create_config(rl_engine *e, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
+                                 uint32_t out_dim, int32_t activation, int32_t output_activation, bool has_bias,
+                                 rl_mlp **out) {
+  // one hidden layer of at most 128 units, Relu inside and Identity on the output, with biases: the fused kernels
+  if (has_bias && e && out && hidden_sizes && n_hidden == 1 && hidden_sizes[0] <= 128 && activation == RL_ACT_RELU &&
       output_activation == RL_ACT_IDENTITY)
     return rl_mlp_create(e, in_dim, hidden_sizes[0], out_dim, out);
   return guarded(e, [&] {
@@ -867,13 +868,26 @@ int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidd
     m->general = true;
     m->act = activation;
     m->out_act = output_activation;
+    m->has_bias = has_bias;
     m->P = m->layer_offset(m->n_layers());
-    m->d_params = dalloc<float>(m->P);
-    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+    // (bias-less layers read their dot products' starting value from zeros behind the parameters: rl_mlp::bias_offset)
+    const size_t alloc = m->P + (has_bias ? 0 : RL_MLP_MAX_WIDTH);
+    m->d_params = dalloc<float>(alloc);
+    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, alloc * sizeof(float), e->stream));
     sync(e);
     e->live_handles += 1;
     *out = m.release();
   });
+}
+
+int32_t rl_mlp_create_layers(rl_engine *e, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
+                             uint32_t out_dim, int32_t activation, int32_t output_activation, rl_mlp **out) {
+  return mlp_create_config(e, in_dim, hidden_sizes, n_hidden, out_dim, activation, output_activation, true, out);
+}
+
+int32_t rl_mlp_create_config(rl_engine *e, uint32_t in_dim, const uint32_t *hidden_sizes, uint32_t n_hidden,
+                             uint32_t out_dim, int32_t activation, int32_t output_activation, int32_t bias, rl_mlp **out) {
+  return mlp_create_config(e, in_dim, hidden_sizes, n_hidden, out_dim, activation, output_activation, bias != 0, out);
 }
 
 // ChainConfig<GruConfig | LstmConfig, MlpConfig>::build_module (modules/chain.rs:19-56, seq/rnn/mod.rs:20-45,223-281):
@@ -1139,8 +1153,10 @@ static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit,
     const uint64_t in = m->fan_in(l), out = m->fan_out(l);
     fill(kinit, h.data() + k, out, in, (double)(in + 1));  // kernel [out][in]
     k += (size_t)in * out;
-    fill(binit, h.data() + k, out, 1, (double)(in + 1));   // bias [out]
-    k += out;
+    if (m->has_bias) {  // (LinearConfig::bias_init = None: no tensor, no draws — linear.rs:54-68)
+      fill(binit, h.data() + k, out, 1, (double)(in + 1));  // bias [out]
+      k += out;
+    }
   }
   h2d(m->eng, m->d_params, h.data(), m->P * sizeof(float));
 }
@@ -1165,19 +1181,22 @@ int32_t rl_mlp_init_with(rl_mlp *m, uint64_t seed, const rl_initializer *kernel_
     if (rl_module_is_recurrent(m->kind))
       throw RlError(RL_ERR_UNSUPPORTED, "rl_mlp_init_with: feed-forward modules only (the recurrent chains use "
                                         "RnnBaseConfig::default's initializers)");
-    if (bias_init == nullptr)
-      throw RlError(RL_ERR_UNSUPPORTED, "LinearConfig::bias_init = None (layers without a bias vector) is not built: the "
-                                        "kernels fold the bias in as an input");
+    // LinearConfig::bias_init = None <=> the module was built without bias vectors (rl_mlp_create_config, bias = 0)
+    if ((bias_init == nullptr) != !m->has_bias)
+      throw RlError(RL_ERR_INVALID_ARGUMENT, m->has_bias ? "this module has bias vectors: bias_init must be given (build it "
+                                                           "with rl_mlp_create_config(..., bias = 0) for bias_init = None)"
+                                                         : "this module has no bias vectors: bias_init must be NULL");
     for (const rl_initializer *i : {kernel_init, bias_init}) {
+      if (i == nullptr) continue;
       RL_REQUIRE(i->kind >= RL_INIT_ZEROS && i->kind <= RL_INIT_ORTHOGONAL, "unknown initializer kind");
       if (i->kind == RL_INIT_UNIFORM || i->kind == RL_INIT_NORMAL) {
         RL_REQUIRE(i->scale >= RL_SCALE_CONSTANT && i->scale <= RL_SCALE_FAN_AVG, "unknown variance scale");
         RL_REQUIRE(i->scale != RL_SCALE_CONSTANT || i->value >= 0.0, "a variance must not be negative");
       }
     }
-    if (bias_init->kind == RL_INIT_ORTHOGONAL)  // init_orthogonal asserts shape.len() >= 2 (initializers.rs:331-334)
+    if (bias_init && bias_init->kind == RL_INIT_ORTHOGONAL)  // init_orthogonal asserts shape.len() >= 2 (initializers.rs:331-334)
       throw RlError(RL_ERR_INVALID_ARGUMENT, "tensor for orthogonal init must be at least 2D: not a bias initializer");
-    mlp_init_host(m, seed, *kernel_init, *bias_init);
+    mlp_init_host(m, seed, *kernel_init, bias_init ? *bias_init : *kernel_init);
   });
 }
 

@@ -95,7 +95,7 @@ static TensorDefView cbor_parse_tensor_def(const cbor::Value &t) {
 // unit variants of `Activation` as serde writes them: the variant's name (ff/activation.rs:11-20)
 static const char *const kActivationNames[4] = {"Identity", "Relu", "Sigmoid", "Tanh"};
 static void cbor_mlp_layers(cbor::Writer &w, const float *p, const std::vector<int64_t> &widths, int act = RL_ACT_RELU,
-                            int out_act = RL_ACT_IDENTITY) {
+                            int out_act = RL_ACT_IDENTITY, bool has_bias = true) {
   w.map(3);
   w.key("layers");
   w.array(widths.size() - 1);
@@ -105,9 +105,13 @@ static void cbor_mlp_layers(cbor::Writer &w, const float *p, const std::vector<i
     w.key("kernel");
     cbor_tensor(w, p, {out, in});
     p += in * out;
-    w.key("bias");
-    cbor_tensor(w, p, {out});
-    p += out;
+    w.key("bias");  // Option<TensorDef> (ff/linear.rs:45-50): None -> null
+    if (has_bias) {
+      cbor_tensor(w, p, {out});
+      p += out;
+    } else {
+      w.null();
+    }
   }
   w.key("activation");
   w.text(kActivationNames[act]);
@@ -126,7 +130,7 @@ static std::vector<int64_t> mlp_widths(const rl_mlp *m) {
 
 static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<float> &p) {
   if (m->kind == RL_MODULE_MLP) {
-    cbor_mlp_layers(w, p.data(), mlp_widths(m), m->act, m->out_act);
+    cbor_mlp_layers(w, p.data(), mlp_widths(m), m->act, m->out_act, m->has_bias);
     return;
   }
   // Gru and Lstm are both RnnBase<impl> (seq/rnn/gru.rs:17, lstm.rs:12): the same document, gate rows 3H or 4H
@@ -236,7 +240,7 @@ static void cbor_read_tensor(const cbor::Value &t, std::initializer_list<int64_t
 }
 
 static float *cbor_read_mlp_layers(const cbor::Value &m, const std::vector<int64_t> &widths, float *dst,
-                                   int act = RL_ACT_RELU, int out_act = RL_ACT_IDENTITY) {
+                                   int act = RL_ACT_RELU, int out_act = RL_ACT_IDENTITY, bool has_bias = true) {
   RL_REQUIRE(m.at("activation").s == kActivationNames[act] && m.at("output_activation").s == kActivationNames[out_act],
              "CBOR module: the document's activations are not the module's");
   const cbor::Value &layers = m.at("layers");
@@ -247,9 +251,12 @@ static float *cbor_read_mlp_layers(const cbor::Value &m, const std::vector<int64
     const cbor::Value &lin = *layers.items[l];
     cbor_read_tensor(lin.at("kernel"), {out, in}, dst);
     dst += in * out;
-    RL_REQUIRE(lin.at("bias").kind == cbor::Value::MAP, "CBOR module: layers without bias are not built");
-    cbor_read_tensor(lin.at("bias"), {out}, dst);
-    dst += out;
+    RL_REQUIRE((lin.at("bias").kind == cbor::Value::MAP) == has_bias,
+               "CBOR module: the document's layers and the module disagree about bias vectors");
+    if (has_bias) {
+      cbor_read_tensor(lin.at("bias"), {out}, dst);
+      dst += out;
+    }
   }
   return dst;
 }
@@ -265,7 +272,7 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
     std::vector<float> p(module->P);
     float *end;
     if (module->kind == RL_MODULE_MLP) {
-      end = cbor_read_mlp_layers(mod, mlp_widths(module), p.data(), module->act, module->out_act);
+      end = cbor_read_mlp_layers(mod, mlp_widths(module), p.data(), module->act, module->out_act, module->has_bias);
     } else {
       const int64_t H = module->gru_hidden, D = module->in_dim, GHR = (int64_t)rl_module_gates(module->kind) * H;
       RL_REQUIRE(mod.at("activation").s == "Relu", "CBOR module: Chain activation must be Relu");

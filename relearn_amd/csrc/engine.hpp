@@ -224,9 +224,15 @@ struct rl_mlp {
   uint32_t fan_out(uint32_t l) const { return l == n_hidden ? out_dim : widths[l]; }
   uint64_t layer_offset(uint32_t l) const {
     uint64_t o = 0;
-    for (uint32_t i = 0; i < l; ++i) o += (uint64_t)fan_in(i) * fan_out(i) + fan_out(i);
+    for (uint32_t i = 0; i < l; ++i) o += (uint64_t)fan_in(i) * fan_out(i) + (has_bias ? fan_out(i) : 0);
     return o;
   }
+  // LinearConfig::bias_init = None (ff/linear.rs:13-33): layers without a bias vector — the flat vector holds the
+  // kernels only.  Every layer kernel starts its dot products from `bias`; such a module's layers read it from
+  // RL_MLP_MAX_WIDTH zeros kept BEHIND the P parameters in the same allocation (never written), and its gradient passes
+  // skip the bias columns.  Always on the per-layer path (`general`).
+  bool has_bias = true;
+  uint64_t bias_offset(uint32_t l) const { return has_bias ? layer_offset(l) + (uint64_t)fan_in(l) * fan_out(l) : P; }
   uint32_t hidden_units() const {
     uint32_t s = 0;
     for (uint32_t i = 0; i < n_hidden; ++i) s += widths[i];

@@ -1149,7 +1149,7 @@ int gm_width_tiles(const rl_mlp *m) {
 
 // true when the module's passes run as fused matrix-pipe launches (kernel documentation above for the shapes)
 bool gen_mfma_fits(const rl_traj *t, const rl_mlp *m) {
-  if (!m->general || m->n_hidden < 1 || m->n_hidden > (uint32_t)GM_MAX_HIDDEN) return false;
+  if (!m->general || !m->has_bias || m->n_hidden < 1 || m->n_hidden > (uint32_t)GM_MAX_HIDDEN) return false;
   if (m->in_dim > (uint32_t)GM_MAX_IN || m->out_dim > 2 || m->in_dim != t->d.D) return false;
   if (gm_width_tiles(m) == 0) return false;
   if ((uint64_t)(t->d.T + 1) * t->d.n * m->in_dim >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel

@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) k_gen_wgrad(const float *__restrict__ dY,
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (tk0 + tk + j < K) row[offW + (size_t)n * K + tk0 + tk + j] = accw[i][j];
-    if (tk0 == 0 && tk == 0) row[offB + n] = accb[i];
+    if (offB != 0xFFFFFFFFu && tk0 == 0 && tk == 0) row[offB + n] = accb[i];  // (no column: a layer without a bias)
   }
 }
 
@@ -431,6 +431,7 @@ struct ChainNet {
   int n_layers, act, out_act;
   int K[RL_MLP_MAX_HIDDEN + 1], N[RL_MLP_MAX_HIDDEN + 1];
   uint32_t off[RL_MLP_MAX_HIDDEN + 1];
+  uint32_t boff[RL_MLP_MAX_HIDDEN + 1];  // the layer's bias vector (a bias-less module: zeros behind its parameters)
   int wmax;  // widest input of any layer (rows of an LDS tile)
 };
 
@@ -441,7 +442,7 @@ __device__ __forceinline__ float *chain_forward_tile(const ChainNet &net, float 
   for (int l = 0; l < net.n_layers; ++l) {
     const int K = net.K[l], N = net.N[l];
     const float *__restrict__ W = net.params + net.off[l];
-    const float *__restrict__ b = W + (size_t)N * K;
+    const float *__restrict__ b = net.params + net.boff[l];
     const int act = l + 1 == net.n_layers ? net.out_act : net.act;
     for (int n0 = 4 * g; n0 < N; n0 += 4 * waves) {
       float acc[4];
@@ -594,6 +595,7 @@ bool chain_net(const rl_mlp *m, ChainNet *net) {
     net->K[l] = (int)m->fan_in(l);
     net->N[l] = (int)m->fan_out(l);
     net->off[l] = (uint32_t)m->layer_offset(l);
+    net->boff[l] = (uint32_t)m->bias_offset(l);
     if (net->N[l] > wmax) wmax = net->N[l];
   }
   net->wmax = wmax;
@@ -731,9 +733,10 @@ static void gen_forward_impl(rl_traj *t, const rl_mlp *m, const float *x, size_t
     a.K = (int)m->fan_in(l);
     a.N = (int)m->fan_out(l);
     a.W = m->d_params + off;
-    a.b = a.W + (size_t)a.N * a.K;
+    a.b = m->d_params + m->bias_offset(l);
     a.V = tangent ? tangent + off : nullptr;
-    a.vb = tangent ? a.V + (size_t)a.N * a.K : nullptr;
+    // (a bias-less module's tangent has no bias entries either: the zeros behind the module's parameters)
+    a.vb = tangent ? (m->has_bias ? a.V + (size_t)a.N * a.K : m->d_params + m->P) : nullptr;
     a.Y = last ? out : g.act + unit0 * rows;
     a.tY = last ? tout : g.tact + unit0 * rows;
     a.ys = rows;
@@ -828,7 +831,8 @@ void launch_gen_backward(rl_traj *t, const rl_mlp *m, const int32_t *d_skip) {
     }
     const uint32_t tiles = (uint32_t)(((N + 63) / 64) * ((K + 63) / 64));
     hipLaunchKernelGGL(k_gen_wgrad, dim3(tiles, t->nbA), dim3(256), 0, e->stream, dY, (size_t)B, N, X, xs, K, (size_t)B,
-                       t->bwd_chunk, t->slabA, P, (uint32_t)off, (uint32_t)(off + (uint64_t)N * K), d_skip);
+                       t->bwd_chunk, t->slabA, P, (uint32_t)off,
+                       m->has_bias ? (uint32_t)(off + (uint64_t)N * K) : 0xFFFFFFFFu, d_skip);
     if (l > 0) {
       float *dX = g.delta + (size_t)(l & 1) * wmax * B;
       hipLaunchKernelGGL(k_gen_delta, dim3(cdiv_g(B, GT)), dim3(256), (size_t)N * GT * sizeof(float), e->stream, dY,

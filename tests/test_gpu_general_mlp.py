@@ -477,7 +477,8 @@ def test_initializers_match_the_oracle_and_their_definitions(engine, kinit, bini
 def test_initializer_argument_checks(engine):
     m = ra.Mlp(engine, 5, 128, 2)
     k = ra.Initializer.of(("Uniform", "FanAvg", 0.0))
-    assert ra.lib().rl_mlp_init_with(m.h, C.c_uint64(1), C.byref(k), None) == ra.ERR_UNSUPPORTED  # bias_init: None
+    # bias_init: None belongs to modules built without bias vectors (rl_mlp_create_config: test_layers_without_bias_vectors)
+    assert ra.lib().rl_mlp_init_with(m.h, C.c_uint64(1), C.byref(k), None) == ra.ERR_INVALID_ARGUMENT
     with pytest.raises(ra.RelearnError):  # init_orthogonal needs two dimensions (initializers.rs:331-334)
         m.init(1, ("Uniform", "FanAvg", 0.0), ("Orthogonal", "FanIn", 0.0))
     bad = ra.Initializer(7, 0, 0.0)
@@ -489,3 +490,105 @@ def test_initializer_argument_checks(engine):
     a.init(5)
     b.init(5, ("Uniform", "FanAvg", 0.0), ("Uniform", "FanAvg", 0.0))
     assert np.array_equal(a.get_params(), b.get_params())
+
+
+# ------------------------------------------------------------------ LinearConfig::bias_init = None (ff/linear.rs:13-33)
+def with_zero_biases(p, in_dim, hidden, out_dim):
+    """the bias-less flat vector with a zero bias vector inserted after every kernel: what a module WITH biases holds when
+    they are all zero — `acc = 0; acc = fma(x_k, w_k, acc)` is the bias-less chain"""
+    out, k = [], 0
+    for fi, fo in layers(in_dim, hidden, out_dim):
+        out += [p[k:k + fi * fo], np.zeros(fo, dtype=np.float32)]
+        k += fi * fo
+    assert k == p.size
+    return np.concatenate(out)
+
+
+def drop_bias_entries(g, in_dim, hidden, out_dim):
+    out, k = [], 0
+    for fi, fo in layers(in_dim, hidden, out_dim):
+        out.append(g[k:k + fi * fo])
+        k += fi * fo + fo
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("hidden,act,out_act", [([64, 64], "Relu", "Identity"), ([100], "Tanh", "Identity"),
+                                                ([32, 16, 8], "Sigmoid", "Tanh"), ([], "Relu", "Identity")])
+def test_layers_without_bias_vectors(engine, hidden, act, out_act):
+    """MlpConfig with LinearConfig { bias_init: None }: the flat vector holds the kernels only (Linear::
+    trainable_variables, linear.rs:104-117); forward bit-identical to the oracle's network with all-zero biases;
+    gradients, Fisher-vector products and the critic gradient against the f64 NumPy network, the bias entries dropped;
+    the actor document carries `bias: null` and loads back; updates move the kernels."""
+    from cbor_ref import decode
+    pol = ra.Mlp(engine, 5, hidden, 2, act, out_act, bias=False)
+    cri = ra.Mlp(engine, 5, hidden, 1, act, out_act, bias=False)
+    pol.init(21)
+    cri.init(22, kernel_init=("Normal", "FanIn", 0.0))
+    assert pol.P == sum(fi * fo for fi, fo in layers(5, hidden, 2)) and cri.P == sum(fi * fo for fi, fo in layers(5, hidden, 1))
+    p, c = pol.get_params(), cri.get_params()
+    k = 0
+    for fi, fo in layers(5, hidden, 2):  # Linear::new: Uniform(+-sqrt(6 / (fan_in + 1 + fan_out))), kernels only
+        lim = np.float32(np.sqrt(3.0 * (2.0 / ((fi + 1) + fo))))
+        assert np.abs(p[k:k + fi * fo]).max() <= lim
+        k += fi * fo
+    with pytest.raises(ra.RelearnError):  # a bias initializer for a module that has no bias vectors
+        ra._check(ra.lib().rl_mlp_init_with(pol.h, C.c_uint64(1), C.byref(ra.Initializer.of(("Zeros", "Constant", 0.0))),
+                                            C.byref(ra.Initializer.of(("Zeros", "Constant", 0.0)))), engine.h)
+    x = (2.0 * np.random.default_rng(4).normal(size=(257, 5))).astype(np.float32)
+    want = O.mlp_layers_forward(5, hidden, 2, with_zero_biases(p, 5, hidden, 2), x, act, out_act)
+    assert np.array_equal(pol.forward(x), want)
+    env, traj = collect(engine, pol)
+    ra.gae(traj, cri, 0.99, 0.95)
+    tr = traj.read_all()
+    n, T = tr["action"].shape[1], tr["action"].shape[0]
+    B = n * T
+    xs = tr["obs"][:, :T, :].reshape(5, B).T
+    adv, rtg = traj.read(ra.TRAJ_ADVANTAGES).reshape(-1), traj.read(ra.TRAJ_RETURNS).reshape(-1)
+    pnet = unflatten(with_zero_biases(p, 5, hidden, 2), 5, hidden, 2)
+    cnet = unflatten(with_zero_biases(c, 5, hidden, 1), 5, hidden, 1)
+    z, acts = forward64(pnet, xs, act, out_act)
+    zmax = z.max(axis=1, keepdims=True)
+    lp = z - zmax - np.log(np.exp(z - zmax).sum(axis=1, keepdims=True))
+    pr = np.exp(lp)
+    a = tr["action"].reshape(-1).astype(np.int64)
+    want_g = drop_bias_entries(backward64(pnet, xs, acts, -(adv[:, None].astype(np.float64)) * (np.eye(2)[a] - pr) / B), 5, hidden, 2)
+    got_g = ra.policy_gradient(pol, traj)[0]
+    assert got_g.shape == want_g.shape and np.abs(got_g - want_g).max() <= 2e-5 * np.abs(want_g).max() + 1e-9
+    vec = np.random.default_rng(5).normal(size=pol.P).astype(np.float32)
+    tnet = unflatten(with_zero_biases(vec, 5, hidden, 2), 5, hidden, 2)
+    _, tz = jvp64(pnet, tnet, xs, act, out_act)
+    want_f = drop_bias_entries(backward64(pnet, xs, acts, pr * (tz - (pr * tz).sum(axis=1, keepdims=True)) / B), 5, hidden, 2)
+    got_f = ra.policy_fvp(pol, traj, vec, 0.0)
+    assert np.abs(got_f - want_f).max() <= 5e-5 * np.abs(want_f).max() + 1e-9
+    v, cacts = forward64(cnet, xs, act, out_act)
+    want_c = drop_bias_entries(backward64(cnet, xs, cacts, 2.0 * (v - rtg[:, None].astype(np.float64)) / B), 5, hidden, 1)
+    got_c = ra.critic_gradient(cri, traj)[0]
+    assert np.abs(got_c - want_c).max() <= 2e-5 * np.abs(want_c).max() + 1e-9
+    # the document: Linear { kernel, bias: None }
+    doc = ra.actor_to_cbor(env, pol)
+
+    def find(vv):
+        if isinstance(vv, dict):
+            if "activation" in vv and "layers" in vv:
+                return vv
+            vv = list(vv.values())
+        if isinstance(vv, (list, tuple)):
+            for item in vv:
+                hit = find(item)
+                if hit is not None:
+                    return hit
+        return None
+    mod = find(decode(bytes(doc)))
+    assert mod is not None and all(layer["bias"] is None for layer in mod["layers"])
+    twin = ra.Mlp(engine, 5, hidden, 2, act, out_act, bias=False)
+    ra.module_from_cbor(twin, doc)
+    assert np.array_equal(twin.get_params(), p)
+    biased = ra.Mlp(engine, 5, hidden if hidden else [7], 2, act, out_act)
+    if hidden:
+        with pytest.raises(ra.RelearnError):  # a document without bias vectors is not a module's that has them
+            ra.module_from_cbor(biased, doc)
+    # updates work on the kernels-only vector
+    st = ra.trpo_update(pol, traj)
+    cs, losses = ra.critic_update(cri, ra.Adam(cri), traj, 3, want_losses=True)
+    assert st.status in (ra.OPT_OK, ra.OPT_LOSS_NOT_IMPROVING, ra.OPT_CONSTRAINT_VIOLATED)
+    assert losses[-1] < losses[0] and not np.array_equal(cri.get_params(), c)
