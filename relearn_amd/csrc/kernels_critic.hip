@@ -29,7 +29,7 @@ using bt::Frag;
 constexpr int CRITIC_WAVES = 8;  // waves per workgroup, one workgroup per CU (two waves per SIMD: the
                                                // tile state — 64 accumulators of each pass, 48 weight-piece registers —
                                                // does not fit three)
-constexpr int C_FLUSH = 64;                    // f32 -> f64 flush period in tiles (2048 samples per accumulator: the accumulated error stays below a 128-sample f32 fma chain's, scripts/probe/mfma_bf16_mask.hip)
+constexpr int C_FLUSH = 64;                     // f32 -> f64 flush period in tiles (2048 samples per accumulator: the accumulated error stays below a 128-sample f32 fma chain's, scripts/probe/mfma_bf16_mask.hip)
 
 __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,

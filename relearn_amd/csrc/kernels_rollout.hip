@@ -32,7 +32,9 @@ __global__ void k_env_observe(CartPoleDev c, EnvStateDev st, uint32_t n, float *
 // Environment::step for every lane (reference src/envs/cartpole.rs:128-154 through the step-limit wrapper),
 // with auto-reset.  Algorithmic traffic per env-step: read state 32 B + sign 1 B + remaining 4 B
 // + action 1 B; write state 37 B + reward 4 B + flag 1 B + next-obs 4*D B  => 100 B at D = 5.
-template <int D>
+// (FILLED: the same code under a second name for launches of >= 2^20 lanes, so that a kernel trace keeps the workload's
+// latency-bound launches and the chip-filling ones of bench.py's `roofline_env_step.filled` apart)
+template <int D, bool FILLED>
 __global__ void __launch_bounds__(256) k_env_step(CartPoleDev c, EnvStateDev st, uint32_t n,
                                                   const uint8_t *__restrict__ actions, float *__restrict__ reward,
                                                   uint8_t *__restrict__ flag, float *__restrict__ obs_next,
@@ -350,12 +352,18 @@ void launch_env_step(rl_env *env) {
   if (env->kind != RL_ENV_CARTPOLE) return launch_chain_step(env);
   ProfScope ps(env->eng, RL_K_ENV_STEP);
   uint32_t n = (uint32_t)env->cfg.n_lanes;
-  if (env->D == 5)
-    hipLaunchKernelGGL(k_env_step<5>, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n,
-                       env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs);
-  else
-    hipLaunchKernelGGL(k_env_step<4>, dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n,
-                       env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs);
+#define ENV_STEP(DD, FF)                                                                                              \
+  hipLaunchKernelGGL((k_env_step<DD, FF>), dim3(cdiv(n, 256)), dim3(256), 0, env->eng->stream, env->dev, env->st, n, \
+                     env->d_actions, env->d_reward, env->d_flag, env->d_obs, env->d_term_obs)
+  const bool filled = n >= (1u << 20);
+  if (env->D == 5) {
+    if (filled) ENV_STEP(5, true);
+    else ENV_STEP(5, false);
+  } else {
+    if (filled) ENV_STEP(4, true);
+    else ENV_STEP(4, false);
+  }
+#undef ENV_STEP
 }
 
 template <int D, int G>
