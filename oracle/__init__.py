@@ -347,6 +347,13 @@ def _declare(L):
     L.oracle_gru_num_params.argtypes = [GruShape]
     L.oracle_gru_num_params.restype = C.c_uint64
     L.oracle_gru_init.argtypes = [GruShape, C.c_uint64, P(C.c_float)]
+    L.oracle_stack_num_params.argtypes = [GruShape, C.c_uint32]
+    L.oracle_stack_num_params.restype = C.c_uint64
+    L.oracle_stack_init.argtypes = [GruShape, C.c_uint32, C.c_uint64, P(C.c_float)]
+    L.oracle_stack_seq_forward_f32.argtypes = [GruShape, C.c_uint32, P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float),
+                                               P(C.c_uint8), P(C.c_float), P(C.c_float), P(C.c_float)]
+    L.oracle_stack_seq_forward_f64.argtypes = [GruShape, C.c_uint32, P(C.c_double), C.c_uint64, C.c_uint64,
+                                               P(C.c_double), P(C.c_uint8), P(C.c_double), P(C.c_double), P(C.c_double)]
     L.oracle_gru_step_f32.argtypes = [GruShape, P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float)]
     L.oracle_gru_step_f64.argtypes = [GruShape, P(C.c_double), P(C.c_double), P(C.c_double), P(C.c_double)]
     L.oracle_gru_seq_forward_f32.argtypes = [GruShape, P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float),
@@ -782,6 +789,29 @@ def gru_seq_forward(shape, params, traj, f64=False, want_succ=True):
     succ = np.zeros((shape.out_dim, T, n), dtype=dt) if want_succ else None
     fn = lib().oracle_gru_seq_forward_f64 if f64 else lib().oracle_gru_seq_forward_f32
     fn(shape, ptr(np.ascontiguousarray(params, dtype=dt)), n, T, ptr(np.ascontiguousarray(obs, dtype=dt)),
+       u8p(traj["flag"]), ptr(np.ascontiguousarray(traj["term_obs"], dtype=dt)), ptr(out),
+       ptr(succ) if want_succ else None)
+    return out, succ
+
+
+def stack_init(shape, num_layers, seed):
+    """RnnBaseConfig { num_layers } chain (oracle/stack_impl.inc): the flat vector of oracle_stack_init"""
+    p = np.zeros(int(lib().oracle_stack_num_params(shape, num_layers)), dtype=np.float32)
+    lib().oracle_stack_init(shape, num_layers, seed, f32p(p))
+    return p
+
+
+def stack_seq_forward(shape, num_layers, params, traj, f64=False, want_succ=True):
+    """gru_seq_forward for a chain of `num_layers` stacked recurrent layers"""
+    obs = traj["obs"]
+    D, T1, n = obs.shape
+    T = T1 - 1
+    dt = np.float64 if f64 else np.float32
+    ptr = f64p if f64 else f32p
+    out = np.zeros((shape.out_dim, T, n), dtype=dt)
+    succ = np.zeros((shape.out_dim, T, n), dtype=dt) if want_succ else None
+    fn = lib().oracle_stack_seq_forward_f64 if f64 else lib().oracle_stack_seq_forward_f32
+    fn(shape, num_layers, ptr(np.ascontiguousarray(params, dtype=dt)), n, T, ptr(np.ascontiguousarray(obs, dtype=dt)),
        u8p(traj["flag"]), ptr(np.ascontiguousarray(traj["term_obs"], dtype=dt)), ptr(out),
        ptr(succ) if want_succ else None)
     return out, succ

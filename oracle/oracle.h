@@ -400,6 +400,15 @@ typedef struct { uint32_t in_dim, hidden, mlp_hidden, out_dim, cell; } oracle_gr
 /* flat parameter order = trainable_variables(): W_ih [3H,in], W_hh [3H,H], b_ih, b_hh, W1 [H2,H], b1, W2 [A,H2], b2 */
 uint64_t oracle_gru_num_params(oracle_gru_shape s);
 void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params);
+/* RnnBaseConfig::num_layers > 1 (seq/rnn/mod.rs:223-257): per layer [W_ih, W_hh, b_ih, b_hh] (layer 0 reads in_dim features,
+ * layer l > 0 the hidden output of layer l - 1), then the head as above; stack_impl.inc */
+uint64_t oracle_stack_num_params(oracle_gru_shape s, uint32_t num_layers);
+void oracle_stack_init(oracle_gru_shape s, uint32_t num_layers, uint64_t seed, float *params);
+void oracle_stack_seq_forward_f32(oracle_gru_shape s, uint32_t num_layers, const float *params, uint64_t n, uint64_t T,
+                                  const float *obs, const uint8_t *flag, const float *term_obs, float *out, float *succ_out);
+void oracle_stack_seq_forward_f64(oracle_gru_shape s, uint32_t num_layers, const double *params, uint64_t n, uint64_t T,
+                                  const double *obs, const uint8_t *flag, const double *term_obs, double *out,
+                                  double *succ_out);
 void oracle_gru_step_f32(oracle_gru_shape s, const float *params, const float *x, float *h, float *out);
 void oracle_gru_step_f64(oracle_gru_shape s, const double *params, const double *x, double *h, double *out);
 void oracle_gru_seq_forward_f32(oracle_gru_shape s, const float *params, uint64_t n, uint64_t T, const float *obs,

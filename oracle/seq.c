@@ -28,6 +28,7 @@ uint64_t oracle_gru_num_params(oracle_gru_shape s) {
 #define RSIG(x) rl_sigmoidf(x)
 #define RTANH(x) rl_tanhf(x)
 #include "seq_impl.inc"
+#include "stack_impl.inc"
 #undef REAL
 #undef SUF
 #undef RFMA
@@ -40,6 +41,7 @@ uint64_t oracle_gru_num_params(oracle_gru_shape s) {
 #define RSIG(x) (1.0 / (1.0 + exp(-(x))))
 #define RTANH(x) tanh(x)
 #include "seq_impl.inc"
+#include "stack_impl.inc"
 #undef REAL
 #undef SUF
 #undef RFMA
@@ -54,22 +56,18 @@ uint64_t oracle_gru_num_params(oracle_gru_shape s) {
  * stream 0, one gen::<f32>() per uniform element; normals by Box-Muller on consecutive pairs of draws
  * (z0 = rho cos, z1 = rho sin, rho = sqrt(-2 ln(1 - u1)), angle 2 pi u2) in f64; QR by modified Gram-Schmidt
  * applied twice in f64 (R has a positive diagonal, so the sign fold is the identity). */
-void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params) {
-  const uint64_t H = s.hidden, D = s.in_dim, H2 = s.mlp_hidden, A = s.out_dim;
-  const uint64_t R = (s.cell == ORACLE_CELL_LSTM ? 4 : 3) * H; /* rows of the gate matrices */
-  oracle_prng r;
-  oracle_prng_seed_from_u64(&r, seed);
-  float *p = params;
-  float lim = (float)sqrt(3.0 * (2.0 / ((double)D + (double)R)));
-  for (uint64_t i = 0; i < R * D; ++i) {
-    float u = oracle_prng_gen_f32(&r);
+/* one recurrent layer's [W_ih (R x K), W_hh (R x H), b_ih, b_hh] drawn from r; returns the position behind it */
+static float *init_rnn_layer(oracle_prng *r, float *p, uint64_t R, uint64_t K, uint64_t H) {
+  float lim = (float)sqrt(3.0 * (2.0 / ((double)K + (double)R)));
+  for (uint64_t i = 0; i < R * K; ++i) {
+    float u = oracle_prng_gen_f32(r);
     *p++ = (2.0f * u - 1.0f) * lim;
   }
   double *a = (double *)malloc(sizeof(double) * R * H); /* column-major: a[c * R + row] */
   double *rowmajor = (double *)malloc(sizeof(double) * R * H);
   const double two_pi = 6.283185307179586;
   for (uint64_t i = 0; i < R * H; i += 2) {
-    double u1 = (double)oracle_prng_gen_f32(&r), u2 = (double)oracle_prng_gen_f32(&r);
+    double u1 = (double)oracle_prng_gen_f32(r), u2 = (double)oracle_prng_gen_f32(r);
     double rho = sqrt(-2.0 * log(1.0 - u1)), sn, cs;
     rl_sincos(two_pi * u2, &sn, &cs);
     rowmajor[i] = rho * cs;
@@ -96,6 +94,17 @@ void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params) {
   free(rowmajor);
   free(a);
   for (uint64_t i = 0; i < 2 * R; ++i) *p++ = 0.0f;
+  return p;
+}
+
+/* RnnWeights::new's layer loop (seq/rnn/mod.rs:223-257): layer 0 reads in_dim features, the others the hidden size */
+void oracle_stack_init(oracle_gru_shape s, uint32_t num_layers, uint64_t seed, float *params) {
+  const uint64_t H = s.hidden, D = s.in_dim, H2 = s.mlp_hidden, A = s.out_dim;
+  const uint64_t R = (s.cell == ORACLE_CELL_LSTM ? 4 : 3) * H; /* rows of the gate matrices */
+  oracle_prng r;
+  oracle_prng_seed_from_u64(&r, seed);
+  float *p = params;
+  for (uint32_t l = 0; l < num_layers; ++l) p = init_rnn_layer(&r, p, R, l == 0 ? D : H, H);
   uint64_t dims[2][2] = {{H, H2}, {H2, A}};
   for (int l = 0; l < 2; ++l) {
     uint64_t in = dims[l][0], out = dims[l][1];
@@ -105,6 +114,13 @@ void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params) {
       *p++ = (2.0f * u - 1.0f) * lm;
     }
   }
+}
+
+void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params) { oracle_stack_init(s, 1, seed, params); }
+
+uint64_t oracle_stack_num_params(oracle_gru_shape s, uint32_t num_layers) {
+  uint64_t H = s.hidden, G = s.cell == ORACLE_CELL_LSTM ? 4 : 3;
+  return oracle_gru_num_params(s) + (uint64_t)(num_layers - 1) * (G * H * 2 * H + 2 * G * H);
 }
 
 /* ------------------------------------------------------------------ vectorised Chain lanes */
