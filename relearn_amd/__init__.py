@@ -455,16 +455,21 @@ class MemoryEnv(ChainEnv):
 class GruMlp(_Handle):
     """`GruMlpConfig::default().build_module(in, out)`: GRU(128) -> ReLU -> MLP([128]); flat reference order."""
 
-    def __init__(self, engine, in_dim, out_dim, gru_hidden=128, mlp_hidden=128):
+    CELL = 0  # RL_CELL_GRU
+
+    def __init__(self, engine, in_dim, out_dim, gru_hidden=128, mlp_hidden=128, num_layers=1):
+        """num_layers: RnnBaseConfig::num_layers (stacked layers, 1..4)"""
         self.eng = engine
         self.h = C.c_void_p()
-        _check(lib().rl_gru_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(gru_hidden), C.c_uint32(mlp_hidden),
-                                       C.c_uint32(out_dim), C.byref(self.h)), engine.h)
+        _check(lib().rl_rnn_mlp_create(engine.h, C.c_int32(self.CELL), C.c_uint32(in_dim), C.c_uint32(gru_hidden),
+                                       C.c_uint32(num_layers), C.c_uint32(mlp_hidden), C.c_uint32(out_dim),
+                                       C.byref(self.h)), engine.h)
         _register(self)
         n = C.c_uint64()
         _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)
         self.P = n.value
         self.in_dim, self.hidden, self.out_dim, self.gru_hidden = in_dim, mlp_hidden, out_dim, gru_hidden
+        self.num_layers = num_layers
 
     close = None  # set below
     init = None
@@ -482,16 +487,10 @@ class GruMlp(_Handle):
 class LstmMlp(GruMlp):
     """`ChainConfig<LstmConfig, MlpConfig>::default().build_module(in, out)`: LSTM(128) -> ReLU -> MLP([128])."""
 
-    def __init__(self, engine, in_dim, out_dim, lstm_hidden=128, mlp_hidden=128):
-        self.eng = engine
-        self.h = C.c_void_p()
-        _check(lib().rl_lstm_mlp_create(engine.h, C.c_uint32(in_dim), C.c_uint32(lstm_hidden), C.c_uint32(mlp_hidden),
-                                        C.c_uint32(out_dim), C.byref(self.h)), engine.h)
-        _register(self)
-        n = C.c_uint64()
-        _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)
-        self.P = n.value
-        self.in_dim, self.hidden, self.out_dim, self.gru_hidden = in_dim, mlp_hidden, out_dim, lstm_hidden
+    CELL = 1  # RL_CELL_LSTM
+
+    def __init__(self, engine, in_dim, out_dim, lstm_hidden=128, mlp_hidden=128, num_layers=1):
+        GruMlp.__init__(self, engine, in_dim, out_dim, lstm_hidden, mlp_hidden, num_layers)
 
 
 ACTIVATIONS = ["Identity", "Relu", "Sigmoid", "Tanh"]  # rl_activation, in the reference enum's order

@@ -893,21 +893,21 @@ int32_t rl_mlp_create_config(rl_engine *e, uint32_t in_dim, const uint32_t *hidd
 // ChainConfig<GruConfig | LstmConfig, MlpConfig>::build_module (modules/chain.rs:19-56, seq/rnn/mod.rs:20-45,223-281):
 // RnnBaseConfig { hidden_size, num_layers, .. } -> ReLU -> Mlp with one hidden layer.  The kernels are built for
 // 5 -> 128 -> 128 -> {1, 2}; narrower shapes (in_dim <= 5, widths <= 128) run on them embedded with zero padding
-// (rl_mlp::exec).  num_layers > 1 is not built.
+// (rl_mlp::exec).  num_layers in 2..4 (stacked layers): the lane-per-thread kernels of kernels_seq_stack.hip at the
+// module's own widths.
 static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t rnn_hidden, uint32_t num_layers,
                               uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out) {
   RL_REQUIRE(e && out, "NULL argument");
   *out = nullptr;
   if (num_layers == 0) throw RlError(RL_ERR_BUILD_AGENT, "RnnBaseConfig::num_layers must be at least 1");
-  if (num_layers != 1)
-    throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built for RnnBaseConfig::num_layers = 1 (the reference's "
-                                      "default); stacked layers are not");
+  if (num_layers > RL_RNN_MAX_LAYERS)
+    throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built for RnnBaseConfig::num_layers <= 4");
   if (in_dim < 1 || in_dim > 5 || rnn_hidden < 1 || rnn_hidden > 128 || mlp_hidden < 1 || mlp_hidden > 128 ||
       !(out_dim == 1 || out_dim == 2))
     throw RlError(RL_ERR_BUILD_AGENT,
                   "supported recurrent chain shapes: in_dim 1..5, recurrent hidden 1..128, mlp_hidden 1..128, out_dim in {1,2}");
   RL_HIP_CHECK(hipSetDevice(e->device));
-  auto make = [&](uint32_t D, uint32_t H, uint32_t H2) {
+  auto make = [&](uint32_t D, uint32_t H, uint32_t H2, uint32_t layers) {
     std::unique_ptr<rl_mlp> m(new rl_mlp());
     m->eng = e;
     m->kind = kind;
@@ -915,17 +915,18 @@ static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t 
     m->gru_hidden = H;
     m->hidden = H2;
     m->out_dim = out_dim;
-    const uint64_t A = out_dim, G = rl_module_gates(kind);
-    m->P = G * H * D + G * H * H + 2 * G * H + (uint64_t)H2 * H + H2 + A * H2 + A;
+    const uint64_t A = out_dim;
+    m->rnn_layers = layers;
+    m->P = m->rnn_layer_offset(m->rnn_layers) + (uint64_t)H2 * H + H2 + A * H2 + A;
     m->d_params = dalloc<float>(m->P);
     RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
     return m;
   };
-  std::unique_ptr<rl_mlp> m = make(in_dim, rnn_hidden, mlp_hidden);
-  if (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128) {
+  std::unique_ptr<rl_mlp> m = make(in_dim, rnn_hidden, mlp_hidden, num_layers);
+  if (num_layers == 1 && (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128)) {
     std::unique_ptr<rl_mlp> x;
     try {
-      x = make(5, 128, 128);  // every padding entry stays 0 for the life of the module
+      x = make(5, 128, 128, 1);  // every padding entry stays 0 for the life of the module
       m->x_tmp = dalloc<float>(x->P);
       m->x_tan = dalloc<float>(x->P);
       RL_HIP_CHECK(hipMemsetAsync(m->x_tan, 0, x->P * sizeof(float), e->stream));
@@ -987,14 +988,16 @@ static void gru_mlp_init_host(const rl_mlp *m, uint64_t seed, std::vector<float>
     return u;
   };
   size_t k = 0;
-  float lim = (float)std::sqrt(3.0 * (2.0 / ((double)D + (double)R)));
-  for (uint64_t i = 0; i < R * D; ++i) {
+  std::vector<double> rowmajor(R * H), a(R * H);
+  for (uint32_t layer = 0; layer < m->rnn_layers; ++layer) {  // RnnWeights::new's layer loop (seq/rnn/mod.rs:223-257)
+  const uint64_t K = layer == 0 ? D : H;
+  float lim = (float)std::sqrt(3.0 * (2.0 / ((double)K + (double)R)));
+  for (uint64_t i = 0; i < R * K; ++i) {
     float u = next_f32();
     float t = 2.0f * u;
     t = t - 1.0f;
     h[k++] = t * lim;
   }
-  std::vector<double> rowmajor(R * H), a(R * H);
   const double two_pi = 6.283185307179586;
   for (uint64_t i = 0; i < R * H; i += 2) {
     double u1 = (double)next_f32(), u2 = (double)next_f32();
@@ -1022,6 +1025,7 @@ static void gru_mlp_init_host(const rl_mlp *m, uint64_t seed, std::vector<float>
   for (uint64_t row = 0; row < R; ++row)
     for (uint64_t c = 0; c < H; ++c) h[k++] = (float)a[c * R + row];
   k += 2 * R;  // biases stay zero
+  }
   uint64_t dims[2][2] = {{H, H2}, {H2, A}};
   for (int l = 0; l < 2; ++l) {
     uint64_t in = dims[l][0], out = dims[l][1];
@@ -1423,8 +1427,25 @@ int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t byte
 }
 
 // ---------------------------------------------------------------- recurrent workspace
+// the P-sized vectors of the update workspace grow with the module
+void traj_ensure_pvec(rl_traj *t, uint64_t P) {
+  if (t->Pmax >= P) return;
+  for (float **p : {&t->vec, &t->cg_x, &t->cg_r, &t->cg_p, &t->prev_params, &t->descent}) {
+    dfree(*p);
+    *p = nullptr;
+  }
+  t->Pmax = (uint32_t)P;
+  t->vec = dalloc<float>(t->Pmax + 4);
+  t->cg_x = dalloc<float>(t->Pmax);
+  t->cg_r = dalloc<float>(t->Pmax);
+  t->cg_p = dalloc<float>(t->Pmax);
+  t->prev_params = dalloc<float>(t->Pmax);
+  t->descent = dalloc<float>(t->Pmax);
+}
+
 void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
   RL_REQUIRE(rl_module_is_recurrent(mod->kind), "not a recurrent module");
+  if (mod->rnn_layers > 1) return stack_ensure(t, mod, training);  // lane-per-thread kernels: no tile or width condition
   RL_REQUIRE(t->d.n % 32 == 0, "the recurrent kernels work on tiles of 32 lanes: n_lanes must be a multiple of 32");
   RL_REQUIRE(t->d.D == 5 && mod->in_dim == 5, "recurrent path: built for 5 observation features");
   SeqDev &q = t->seq;
@@ -1452,26 +1473,14 @@ void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
     // + the rows of the head kernel (head columns) and of the backward recurrence (one per tile, input-side columns)
     q.wg_slab = dalloc<float>((size_t)(q.chunks + (q.tiles > RL_SEQ_HEAD_ROWS ? q.tiles : RL_SEQ_HEAD_ROWS)) * mod->P);
     q.P = mod->P;
-    // the P-sized vectors of the update workspace grow with the module
-    if (t->Pmax < mod->P) {
-      for (float **p : {&t->vec, &t->cg_x, &t->cg_r, &t->cg_p, &t->prev_params, &t->descent}) {
-        dfree(*p);
-        *p = nullptr;
-      }
-      t->Pmax = (uint32_t)mod->P;
-      t->vec = dalloc<float>(t->Pmax + 4);
-      t->cg_x = dalloc<float>(t->Pmax);
-      t->cg_r = dalloc<float>(t->Pmax);
-      t->cg_p = dalloc<float>(t->Pmax);
-      t->prev_params = dalloc<float>(t->Pmax);
-      t->descent = dalloc<float>(t->Pmax);
-    }
+    traj_ensure_pvec(t, mod->P);
   }
 }
 
 static void seq_free(rl_traj *t) {
   SeqDev &q = t->seq;
   for (float *p : {q.act, q.dpre, q.out, q.succ, q.wg_slab}) dfree(p);
+  stack_free(t);
   q = SeqDev{};
 }
 
@@ -1500,6 +1509,11 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
     if (policy->general) {  // any hidden_sizes: one launch sequence per step, either env family (advances t_global)
       launch_gen_rollout(env, policy, traj);
+      return;
+    }
+    if (rl_module_is_recurrent(policy->kind) && policy->rnn_layers > 1) {  // stacked layers: a launch sequence per step
+      seq_ensure(traj, policy, false);
+      launch_stack_rollout(env, policy, traj);  // (advances t_global)
       return;
     }
     if (rl_module_is_recurrent(policy->kind)) {

@@ -141,16 +141,19 @@ static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<floa
   w.key("weights");
   w.map(2);  // RnnWeights { flat_weights, has_biases } (seq/rnn/mod.rs:186-191)
   w.key("flat_weights");
-  w.array(4);
+  w.array(4 * m->rnn_layers);  // per layer [w_ih, w_hh, b_ih, b_hh] (seq/rnn/mod.rs:223-257)
   const float *q = p.data();
-  cbor_tensor(w, q, {GHR, D});
-  q += GHR * D;
-  cbor_tensor(w, q, {GHR, H});
-  q += GHR * H;
-  cbor_tensor(w, q, {GHR});
-  q += GHR;
-  cbor_tensor(w, q, {GHR});
-  q += GHR;
+  for (uint32_t l = 0; l < m->rnn_layers; ++l) {
+    const int64_t K = l == 0 ? D : H;
+    cbor_tensor(w, q, {GHR, K});
+    q += GHR * K;
+    cbor_tensor(w, q, {GHR, H});
+    q += GHR * H;
+    cbor_tensor(w, q, {GHR});
+    q += GHR;
+    cbor_tensor(w, q, {GHR});
+    q += GHR;
+  }
   w.key("has_biases");
   w.boolean(true);
   w.key("hidden_size");
@@ -282,16 +285,20 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
       const cbor::Value &wts = rnn.at("weights");
       RL_REQUIRE(wts.at("has_biases").kind == cbor::Value::BOOL && wts.at("has_biases").b, "CBOR module: GRU biases required");
       const cbor::Value &fw = wts.at("flat_weights");
-      RL_REQUIRE(fw.kind == cbor::Value::ARRAY && fw.items.size() == 4, "CBOR module: expected a one-layer GRU");
+      RL_REQUIRE(fw.kind == cbor::Value::ARRAY && fw.items.size() == (size_t)4 * module->rnn_layers,
+                 "CBOR module: the recurrent layer count does not match the module");
       float *q = p.data();
-      cbor_read_tensor(*fw.items[0], {GHR, D}, q);
-      q += GHR * D;
-      cbor_read_tensor(*fw.items[1], {GHR, H}, q);
-      q += GHR * H;
-      cbor_read_tensor(*fw.items[2], {GHR}, q);
-      q += GHR;
-      cbor_read_tensor(*fw.items[3], {GHR}, q);
-      q += GHR;
+      for (uint32_t l = 0; l < module->rnn_layers; ++l) {
+        const int64_t K = l == 0 ? D : H;
+        cbor_read_tensor(*fw.items[4 * l + 0], {GHR, K}, q);
+        q += GHR * K;
+        cbor_read_tensor(*fw.items[4 * l + 1], {GHR, H}, q);
+        q += GHR * H;
+        cbor_read_tensor(*fw.items[4 * l + 2], {GHR}, q);
+        q += GHR;
+        cbor_read_tensor(*fw.items[4 * l + 3], {GHR}, q);
+        q += GHR;
+      }
       end = cbor_read_mlp(mod.at("second"), H, module->hidden, module->out_dim, q);
     }
     RL_REQUIRE((uint64_t)(end - p.data()) == module->P, "CBOR module: parameter count mismatch");

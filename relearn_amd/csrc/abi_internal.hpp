@@ -73,6 +73,7 @@ void engine_release_child(rl_engine *e);
 void traj_plan(rl_traj *t, uint64_t B);
 rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, bool resizable);
 void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training);
+void traj_ensure_pvec(rl_traj *t, uint64_t P);
 rl_mlp *seq_exec(const rl_mlp *m);
 }
 
@@ -86,7 +87,7 @@ struct SeqScope {
   SeqScope(rl_traj *traj, const rl_mlp *m) : t(traj), logical_D(traj->d.D), x(nullptr) {
     RL_REQUIRE(m->in_dim == traj->d.D, "module input width does not match the trajectory");
     x = seq_exec(m);
-    t->d.D = 5;
+    if (m->rnn_layers == 1) t->d.D = 5;  // (stacked layers run at the module's own input width)
   }
   ~SeqScope() { t->d.D = logical_D; }
   SeqScope(const SeqScope &) = delete;

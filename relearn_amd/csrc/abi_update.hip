@@ -14,11 +14,16 @@ static void seq_gradient_to_flat_order(const rl_mlp *mod, rl_traj *traj) {
   RL_HIP_CHECK(hipMemcpyAsync(traj->vec, mod->x_tmp, mod->P * sizeof(float), hipMemcpyDeviceToDevice, traj->eng->stream));
 }
 
+// where a training forward of `mod` keeps its activation record (non-NULL asks the forward for one)
+static float *seq_record(rl_traj *traj, const rl_mlp *mod) {
+  return mod->rnn_layers > 1 ? traj->seq.stack.rec : traj->seq.act;
+}
+
 static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backward, float lo, float hi) {
   SeqScope sc(traj, policy);
   seq_ensure(traj, sc.x, true);
   uint32_t P = (uint32_t)policy->P;
-  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, backward ? traj->seq.act : nullptr);
+  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, backward ? seq_record(traj, sc.x) : nullptr);
   launch_seq_policy_dlogits(traj, mode, b_total(traj), lo, hi);
   if (backward) {
     launch_gru_backward(traj, sc.x);
@@ -60,7 +65,7 @@ static void seq_critic_pass(rl_mlp *critic, rl_traj *traj) {
   SeqScope sc(traj, critic);
   seq_ensure(traj, sc.x, true);
   uint32_t P = (uint32_t)critic->P;
-  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, traj->seq.act);
+  launch_gru_seq_forward(traj, sc.x, traj->seq.out, nullptr, seq_record(traj, sc.x));
   launch_seq_critic_dvalues(traj, b_total(traj));
   launch_gru_backward(traj, sc.x);
   seq_gradient_to_flat_order(critic, traj);

@@ -192,6 +192,7 @@ inline uint64_t rl_module_gates(int kind) { return kind == RL_MODULE_LSTM_MLP ? 
 
 constexpr uint32_t RL_MLP_MAX_HIDDEN = 4;   // hidden layers of a general MlpConfig
 constexpr uint32_t RL_MLP_MAX_WIDTH = 256;  // widest hidden layer
+constexpr uint32_t RL_RNN_MAX_LAYERS = 4;   // RnnBaseConfig::num_layers of a recurrent chain
 
 struct rl_mlp {
   rl_engine *eng;
@@ -200,6 +201,15 @@ struct rl_mlp {
   float *d_params = nullptr;
   int kind = RL_MODULE_MLP;
   uint32_t gru_hidden = 0;
+  // RnnBaseConfig::num_layers (seq/rnn/mod.rs:20-45,223-257).  > 1: stacked layers — flat order [W_ih, W_hh, b_ih, b_hh]
+  // per layer (layer l > 0 reads the hidden output of layer l - 1), then the head; such a module runs the lane-per-thread
+  // kernels of kernels_seq_stack.hip at its own widths (no twin).
+  uint32_t rnn_layers = 1;
+  uint64_t rnn_layer_offset(uint32_t l) const {  // W_ih of layer l; l == rnn_layers: the head's W1
+    const uint64_t GH = (kind == RL_MODULE_LSTM_MLP ? 4 : 3) * (uint64_t)gru_hidden;
+    if (l == 0) return 0;
+    return GH * (in_dim + gru_hidden) + 2 * GH + (uint64_t)(l - 1) * (GH * 2 * gru_hidden + 2 * GH);
+  }
   // MlpConfig::hidden_sizes (ff/mlp.rs:13-34).  `general`: a shape the fused single-hidden-layer kernels do not cover
   // (no hidden layer, several, or one wider than 128) — it runs the per-layer kernels of kernels_general.hip; then
   // `hidden` is 0, which keeps every fused launcher away.
@@ -249,6 +259,21 @@ struct SeqDev {
   float *wg_slab = nullptr; // [chunks][P] partial weight gradients (f32)
   uint32_t tiles = 0, chunks = 0, blocks_per_chunk = 0;
   uint64_t P = 0;
+  // stacked layers (kernels_seq_stack.hip; grow-only arrays, capacities in floats)
+  struct Stack {
+    float *st = nullptr;    // [10][L][H][n] per-lane states: two (h, c) sets in turn, the successor evaluation's, two tangent sets
+    float *u = nullptr;     // [H2][n] the head's hidden units of the step at hand
+    float *z = nullptr;     // [2][n] logits of a rollout step
+    float *din = nullptr;   // [H][n] backward: gradient into the layer below, same step
+    float *dst = nullptr;   // [2][L][H][n] backward: gradients carried to the step before (h, c)
+    float *rec = nullptr;   // [L][8][H][B] activation record of the last training forward
+    float *a1 = nullptr;    // [H][B] relu(top layer's output)
+    float *ur = nullptr;    // [H2][B] the head's hidden units
+    float *dg = nullptr;    // [L][4H][B] d loss / d pre-activations
+    float *du = nullptr;    // [H2][B]
+    uint64_t cap_st = 0, cap_u = 0, cap_din = 0, cap_dst = 0, cap_rec = 0, cap_a1 = 0, cap_ur = 0, cap_dg = 0, cap_du = 0;
+    uint32_t wg_rows = 0, wg_chunk = 0;  // weight-gradient partials: slab rows, samples per row
+  } stack;
 };
 
 // workspace of the general-MLP path (kernels_general.hip), attached to a trajectory on first use

@@ -265,12 +265,23 @@ struct MlpConfig {  // MlpConfig { hidden_sizes, activation, output_activation }
   }
 };
 
+// RnnBaseConfig's shape field (seq/rnn/mod.rs:20-45; the initializers are the default's: Glorot-uniform input weights,
+// orthogonal hidden weights, zero biases)
+struct RnnBaseConfig {
+  uint32_t num_layers = 1;  // stacked layers: 1..4
+};
+using GruConfig = RnnBaseConfig;
+using LstmConfig = RnnBaseConfig;
+
 struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mod.rs:14, chain.rs:19-32)
+  GruConfig first_config;
   uint32_t hidden_dim = 128;
   MlpConfig second_config;
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_gru_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.single_hidden_size(), out_dim, &h), eng.handle());
+    check(rl_rnn_mlp_create(eng.handle(), RL_CELL_GRU, in_dim, hidden_dim, first_config.num_layers,
+                            second_config.single_hidden_size(), out_dim, &h),
+          eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     check(rl_mlp_init(h, seed), eng.handle());
     return m;
@@ -285,11 +296,14 @@ using LstmMlpConfig = GruMlpConfig;
 // ChainConfig<LstmConfig, MlpConfig>::default (chain.rs:19-32 with Lstm = RnnBase<LstmImpl>, seq/rnn/lstm.rs:12-51): what a
 // user of the reference writes out to get an actual LSTM chain.
 struct ChainLstmMlpConfig {
+  LstmConfig first_config;
   uint32_t hidden_dim = 128;
   MlpConfig second_config;
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_lstm_mlp_create(eng.handle(), in_dim, hidden_dim, second_config.single_hidden_size(), out_dim, &h), eng.handle());
+    check(rl_rnn_mlp_create(eng.handle(), RL_CELL_LSTM, in_dim, hidden_dim, first_config.num_layers,
+                            second_config.single_hidden_size(), out_dim, &h),
+          eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     check(rl_mlp_init(h, seed), eng.handle());
     return m;

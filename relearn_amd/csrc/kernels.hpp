@@ -1,5 +1,6 @@
 // kernels.hpp — host launchers implemented in the .hip translation units.
 #pragma once
+#include <functional>
 // arrays of [128 units][32 lanes] floats per (step, tile) block in the recurrent training workspace (kernels_seq.hip)
 #define RL_SEQ_ACT_ARRAYS 9
 #define RL_SEQ_DPRE_ARRAYS 6
@@ -100,6 +101,19 @@ bool launch_gen_mfma(rl_traj *t, const rl_mlp *m, int mode, const float *d_tange
                      const int32_t *d_skip, float clip_lo, float clip_hi);
 void launch_gen_values(rl_traj *t, const rl_mlp *critic);  // -> seq.out / seq.succ (plane 0)
 void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t);
+void launch_rollout_stepwise(rl_env *env, rl_traj *t, const float *z, const std::function<void(uint32_t)> &forward);
+void launch_gen_wgrad_planes(rl_traj *t, const float *dY, size_t dys, int N, const float *X, size_t xs, int K, size_t S,
+                             uint32_t chunk, uint32_t rows, uint32_t P, uint32_t offW, uint32_t offB,
+                             const int32_t *d_skip);
+// kernels_seq_stack.hip: recurrent chains with RnnBaseConfig::num_layers > 1 (one thread per lane, the unit loop of a
+// layer dealt to a workgroup's waves; no lane-tile or width restriction)
+void stack_ensure(rl_traj *t, const rl_mlp *mod, bool training);
+void stack_free(rl_traj *t);
+void launch_stack_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj);
+void launch_stack_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, bool record,
+                          const int32_t *d_skip);
+void launch_stack_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip);  // dz, record -> vec[0..P)
+void launch_stack_tangent(rl_traj *traj, const rl_mlp *mod, const float *d_tangent, const int32_t *d_skip);  // -> seq.out
 // a recurrent chain of other widths embedded in the kernels' shape (rl_mlp::exec): copy the flat vector `real_src`
 // (layout of `real`) into the padded layout `exec_dst` / gather the padded vector `exec_src` into the flat layout
 void launch_seq_pad(const rl_mlp *real, float *exec_dst, const float *real_src);

@@ -896,18 +896,28 @@ void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t) {
     env->t_global += T;
     return;
   }
+  launch_rollout_stepwise(env, t, g.z, [&](uint32_t) {
+    gen_forward_impl(t, policy, env->d_obs, (size_t)n, n, g.z, nullptr, nullptr, nullptr);
+  });
+}
+
+// T steps of every lane as launch sequences: `forward(step)` leaves the policy's logits for env->d_obs ([D][n]) in z
+// ([2][n]); the rest of a step is PolicyActor::act, the env's step kernel and the step's record.  Advances t_global.
+void launch_rollout_stepwise(rl_env *env, rl_traj *t, const float *z, const std::function<void(uint32_t)> &forward) {
+  rl_engine *e = env->eng;
+  const uint32_t n = t->d.n, T = t->d.T;
   const dim3 grid(cdiv_g(n, 256)), blk(256);
   launch_env_observe(env, env->d_obs);
-  if (env->kind == RL_ENV_CARTPOLE && policy->out_dim == 2 && e->kernel_variant != 1) {
-    // CartPole lanes: a step is the policy's layer launches and one launch for everything else
+  if (env->kind == RL_ENV_CARTPOLE && env->A == 2 && e->kernel_variant != 1) {
+    // CartPole lanes: a step is the policy's launches and one launch for everything else
     hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, 0u);
     for (uint32_t step = 0; step < T; ++step) {
-      gen_forward_impl(t, policy, env->d_obs, (size_t)n, n, g.z, nullptr, nullptr, nullptr);
+      forward(step);
       if (env->D == 5)
-        hipLaunchKernelGGL(k_gen_step_cartpole<5>, grid, blk, 0, e->stream, env->dev, env->st, t->d, g.z, env->t_global,
+        hipLaunchKernelGGL(k_gen_step_cartpole<5>, grid, blk, 0, e->stream, env->dev, env->st, t->d, z, env->t_global,
                            step, env->d_obs);
       else
-        hipLaunchKernelGGL(k_gen_step_cartpole<4>, grid, blk, 0, e->stream, env->dev, env->st, t->d, g.z, env->t_global,
+        hipLaunchKernelGGL(k_gen_step_cartpole<4>, grid, blk, 0, e->stream, env->dev, env->st, t->d, z, env->t_global,
                            step, env->d_obs);
       env->t_global += 1;
     }
@@ -916,12 +926,23 @@ void launch_gen_rollout(rl_env *env, const rl_mlp *policy, rl_traj *t) {
   }
   for (uint32_t step = 0; step < T; ++step) {
     hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, step);
-    gen_forward_impl(t, policy, env->d_obs, (size_t)n, n, g.z, nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL(k_gen_sample_actions, grid, blk, 0, e->stream, env->dev, g.z, n, env->t_global, env->d_actions);
+    forward(step);
+    hipLaunchKernelGGL(k_gen_sample_actions, grid, blk, 0, e->stream, env->dev, z, n, env->t_global, env->d_actions);
     launch_env_step(env);  // leaves reward, flag, the next observation and the interrupted successor in the env's buffers
     env->t_global += 1;
     hipLaunchKernelGGL(k_gen_record_step, grid, blk, 0, e->stream, t->d, env->d_actions, env->d_reward, env->d_flag,
                        env->d_term_obs, step);
   }
   hipLaunchKernelGGL(k_gen_record_obs, grid, blk, 0, e->stream, t->d, env->d_obs, T);
+  RL_HIP_CHECK(hipGetLastError());
+}
+
+// dW = dY X^T (+ db) over S samples in `rows` slab rows of `chunk` samples: the weight-gradient kernel on caller-given
+// planes (the stacked recurrent layers' gate deltas and inputs, kernels_seq_stack.hip)
+void launch_gen_wgrad_planes(rl_traj *t, const float *dY, size_t dys, int N, const float *X, size_t xs, int K, size_t S,
+                             uint32_t chunk, uint32_t rows, uint32_t P, uint32_t offW, uint32_t offB,
+                             const int32_t *d_skip) {
+  const uint32_t tiles = (uint32_t)(((N + 63) / 64) * ((K + 63) / 64));
+  hipLaunchKernelGGL(k_gen_wgrad, dim3(tiles, rows), dim3(256), 0, t->eng->stream, dY, dys, N, X, xs, K, S, chunk,
+                     t->slabA, P, offW, offB, d_skip);
 }

@@ -553,8 +553,8 @@ def test_narrow_chain_rolls_out_and_learns_on_chain_lanes(engine):
 
 def test_recurrent_shapes_that_are_not_built_are_refused(engine):
     h = C.c_void_p()
-    assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(0), C.c_uint32(5), C.c_uint32(32), C.c_uint32(2),
-                                      C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_UNSUPPORTED  # num_layers = 2
+    assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(0), C.c_uint32(5), C.c_uint32(32), C.c_uint32(5),
+                                      C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_UNSUPPORTED  # num_layers = 5
     assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(0), C.c_uint32(5), C.c_uint32(32), C.c_uint32(0),
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_BUILD_AGENT
     for bad in ((6, 32, 32, 2), (5, 129, 32, 2), (5, 32, 200, 2), (5, 32, 32, 3), (0, 4, 4, 1)):
