@@ -283,8 +283,8 @@ int32_t rl_mlp_forward(rl_mlp *mlp, const float *rows, uint64_t n_rows, float *o
  * units stay exactly 0 and every real dot product only gains terms fma(0, 0, acc), so outputs, gradients and
  * Fisher-vector products are those of the narrow chain (forward bit-identical to the oracle's, tests/test_gpu_gru.py).
  * out_dim in {1, 2}; lanes in multiples of 32; trajectories of obs_dim = in_dim (rollouts need an env with five
- * observation features; narrower inputs come from rl_traj_write).  RnnBaseConfig::num_layers > 1 is not built
- * (rl_rnn_mlp_create -> RL_ERR_UNSUPPORTED).
+ * observation features; narrower inputs come from rl_traj_write).  in_dim 6..8 and stacked layers
+ * (RnnBaseConfig::num_layers 2..4, rl_rnn_mlp_create) run the lane-per-thread kernels instead: see there.
  * rl_mlp_init: Glorot-uniform W_ih, orthogonal W_hh, zero biases (RnnBaseConfig::default), Linear::new for the MLP. */
 int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden,
                           uint32_t out_dim, rl_mlp **out);
@@ -297,8 +297,18 @@ int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidde
 int32_t rl_lstm_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t lstm_hidden, uint32_t mlp_hidden,
                            uint32_t out_dim, rl_mlp **out);
 /* Both chains with RnnBaseConfig's fields spelled out (seq/rnn/mod.rs:20-45: hidden_size, num_layers; the initializers
- * are RnnBaseConfig::default's): cell = RL_CELL_GRU | RL_CELL_LSTM.  num_layers must be 1 (the reference's default);
- * 0 -> RL_ERR_BUILD_AGENT, > 1 -> RL_ERR_UNSUPPORTED. */
+ * are RnnBaseConfig::default's): cell = RL_CELL_GRU | RL_CELL_LSTM; in_dim 1..8, hidden_size and mlp_hidden 1..128.
+ * num_layers 1..4 (0 -> RL_ERR_BUILD_AGENT, > 4 -> RL_ERR_UNSUPPORTED).  Stacked layers (num_layers > 1): flat order
+ * per layer [W_ih, W_hh, b_ih, b_hh] (RnnWeights::new, seq/rnn/mod.rs:223-257) — layer 0 reads the in_dim features,
+ * layer l > 0 the hidden output of layer l - 1 of the same step (Tensor::gru / ::lstm with num_layers, gru.rs:41-66),
+ * no dropout — then the MLP's kernel/bias pairs; rl_mlp_init draws layer after layer from one stream; the actor
+ * document holds 4 tensors per layer.  Stacked chains, and chains of in_dim 6..8, run general lane-per-thread kernels
+ * at the module's own widths (kernels_seq_stack.hip: any lane count, one launch sequence per rollout step; the path for
+ * shapes the fused 5 -> 128 -> 128 tile kernels do not cover, not a fast one).  Every entry point of the single-layer
+ * chains applies: rl_rollout (two-action policies on either lane family), rl_seq_forward, rl_gae, rl_trpo_update,
+ * rl_ppo_update, rl_policy_gradient / _fvp / _loss_kl, rl_values_opt_update, rl_critic_update, serialisation.  Forward
+ * bit-identical to the C restatement; gradients and Fisher-vector products to f32 tolerance against the f64
+ * restatement, both pinned by PyTorch vectors (tests/test_gpu_stacked.py, tests/test_oracle_stacked.py). */
 enum { RL_CELL_GRU = 0, RL_CELL_LSTM = 1 };
 int32_t rl_rnn_mlp_create(rl_engine *engine, int32_t cell, uint32_t in_dim, uint32_t hidden_size, uint32_t num_layers,
                           uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out);
@@ -318,7 +328,8 @@ typedef enum {
   RL_TRAJ_TARGETS = 8    /* f32 [T][n] value targets of the last rl_values_opt_update (StepValueTarget::targets) */
 } rl_traj_field;
 
-/* obs_dim in 1..5 (feed-forward modules take 4 or 5; narrower trajectories serve recurrent chains of that in_dim) */
+/* obs_dim in 1..8 (feed-forward modules take 4 or 5; the others serve recurrent chains of that in_dim, written through
+ * rl_traj_write: the envs of this library have 4 or 5 features) */
 int32_t rl_traj_create(rl_engine *engine, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, rl_traj **out);
 int32_t rl_traj_destroy(rl_traj *traj);
 int32_t rl_traj_field_bytes(const rl_traj *traj, int32_t field, uint64_t *bytes);

@@ -902,10 +902,10 @@ static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t 
   if (num_layers == 0) throw RlError(RL_ERR_BUILD_AGENT, "RnnBaseConfig::num_layers must be at least 1");
   if (num_layers > RL_RNN_MAX_LAYERS)
     throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built for RnnBaseConfig::num_layers <= 4");
-  if (in_dim < 1 || in_dim > 5 || rnn_hidden < 1 || rnn_hidden > 128 || mlp_hidden < 1 || mlp_hidden > 128 ||
-      !(out_dim == 1 || out_dim == 2))
+  if (in_dim < 1 || in_dim > RL_TRAJ_MAX_OBS_DIM || rnn_hidden < 1 || rnn_hidden > 128 || mlp_hidden < 1 ||
+      mlp_hidden > 128 || !(out_dim == 1 || out_dim == 2))
     throw RlError(RL_ERR_BUILD_AGENT,
-                  "supported recurrent chain shapes: in_dim 1..5, recurrent hidden 1..128, mlp_hidden 1..128, out_dim in {1,2}");
+                  "supported recurrent chain shapes: in_dim 1..8, recurrent hidden 1..128, mlp_hidden 1..128, out_dim in {1,2}");
   RL_HIP_CHECK(hipSetDevice(e->device));
   auto make = [&](uint32_t D, uint32_t H, uint32_t H2, uint32_t layers) {
     std::unique_ptr<rl_mlp> m(new rl_mlp());
@@ -923,7 +923,7 @@ static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t 
     return m;
   };
   std::unique_ptr<rl_mlp> m = make(in_dim, rnn_hidden, mlp_hidden, num_layers);
-  if (num_layers == 1 && (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128)) {
+  if (!m->lane_kernels() && (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128)) {
     std::unique_ptr<rl_mlp> x;
     try {
       x = make(5, 128, 128, 1);  // every padding entry stays 0 for the life of the module
@@ -1312,7 +1312,7 @@ void traj_plan(rl_traj *t, uint64_t B) {
 rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t obs_dim, bool resizable) {
   RL_REQUIRE(n_lanes > 0 && n_lanes < (1ull << 31), "bad n_lanes");
   RL_REQUIRE(horizon > 0 && horizon < (1ull << 20), "bad horizon");
-  RL_REQUIRE(obs_dim >= 1 && obs_dim <= 5, "obs_dim must be in 1..5");
+  RL_REQUIRE(obs_dim >= 1 && obs_dim <= RL_TRAJ_MAX_OBS_DIM, "obs_dim must be in 1..8");
   RL_REQUIRE(n_lanes * horizon < (1ull << 32), "T * n must fit 32 bits");
   RL_HIP_CHECK(hipSetDevice(e->device));
   std::unique_ptr<rl_traj> t(new rl_traj());
@@ -1320,9 +1320,9 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   t->d.n = (uint32_t)n_lanes;
   t->d.T = (uint32_t)horizon;
   t->d.D = obs_dim;
-  // (five observation planes whatever the logical width: the recurrent kernels are built for five features and read
-  // the planes past the module's in_dim as zeros)
-  uint64_t n = n_lanes, T = horizon, D = 5;
+  // (at least five observation planes whatever the logical width: the fused recurrent kernels are built for five features
+  // and read the planes past the module's in_dim as zeros)
+  uint64_t n = n_lanes, T = horizon, D = obs_dim > 5 ? obs_dim : 5;
   t->d.obs = dalloc<float>(D * (T + 1) * n);
   RL_HIP_CHECK(hipMemsetAsync(t->d.obs, 0, D * (T + 1) * n * 4, e->stream));
   t->d.action = dalloc<uint8_t>(T * n);
@@ -1445,7 +1445,7 @@ void traj_ensure_pvec(rl_traj *t, uint64_t P) {
 
 void seq_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
   RL_REQUIRE(rl_module_is_recurrent(mod->kind), "not a recurrent module");
-  if (mod->rnn_layers > 1) return stack_ensure(t, mod, training);  // lane-per-thread kernels: no tile or width condition
+  if (mod->lane_kernels()) return stack_ensure(t, mod, training);  // lane-per-thread kernels: no tile or width condition
   RL_REQUIRE(t->d.n % 32 == 0, "the recurrent kernels work on tiles of 32 lanes: n_lanes must be a multiple of 32");
   RL_REQUIRE(t->d.D == 5 && mod->in_dim == 5, "recurrent path: built for 5 observation features");
   SeqDev &q = t->seq;
@@ -1511,7 +1511,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
       launch_gen_rollout(env, policy, traj);
       return;
     }
-    if (rl_module_is_recurrent(policy->kind) && policy->rnn_layers > 1) {  // stacked layers: a launch sequence per step
+    if (rl_module_is_recurrent(policy->kind) && policy->lane_kernels()) {  // a launch sequence per step
       seq_ensure(traj, policy, false);
       launch_stack_rollout(env, policy, traj);  // (advances t_global)
       return;

@@ -87,7 +87,7 @@ struct SeqScope {
   SeqScope(rl_traj *traj, const rl_mlp *m) : t(traj), logical_D(traj->d.D), x(nullptr) {
     RL_REQUIRE(m->in_dim == traj->d.D, "module input width does not match the trajectory");
     x = seq_exec(m);
-    if (m->rnn_layers == 1) t->d.D = 5;  // (stacked layers run at the module's own input width)
+    if (!m->lane_kernels()) t->d.D = 5;  // (the lane-per-thread kernels run at the module's own input width)
   }
   ~SeqScope() { t->d.D = logical_D; }
   SeqScope(const SeqScope &) = delete;

@@ -16,7 +16,7 @@ static void seq_gradient_to_flat_order(const rl_mlp *mod, rl_traj *traj) {
 
 // where a training forward of `mod` keeps its activation record (non-NULL asks the forward for one)
 static float *seq_record(rl_traj *traj, const rl_mlp *mod) {
-  return mod->rnn_layers > 1 ? traj->seq.stack.rec : traj->seq.act;
+  return mod->lane_kernels() ? traj->seq.stack.rec : traj->seq.act;
 }
 
 static void seq_policy_pass(rl_mlp *policy, rl_traj *traj, int mode, bool backward, float lo, float hi) {

@@ -192,6 +192,7 @@ inline uint64_t rl_module_gates(int kind) { return kind == RL_MODULE_LSTM_MLP ? 
 
 constexpr uint32_t RL_MLP_MAX_HIDDEN = 4;   // hidden layers of a general MlpConfig
 constexpr uint32_t RL_MLP_MAX_WIDTH = 256;  // widest hidden layer
+constexpr uint32_t RL_TRAJ_MAX_OBS_DIM = 8;  // observation features of a trajectory (the envs here have 4 or 5)
 constexpr uint32_t RL_RNN_MAX_LAYERS = 4;   // RnnBaseConfig::num_layers of a recurrent chain
 
 struct rl_mlp {
@@ -205,6 +206,9 @@ struct rl_mlp {
   // per layer (layer l > 0 reads the hidden output of layer l - 1), then the head; such a module runs the lane-per-thread
   // kernels of kernels_seq_stack.hip at its own widths (no twin).
   uint32_t rnn_layers = 1;
+  // the lane-per-thread kernels run this recurrent module (stacked layers, or more input features than the fused tile
+  // kernels' five)
+  bool lane_kernels() const { return rnn_layers > 1 || in_dim > 5; }
   uint64_t rnn_layer_offset(uint32_t l) const {  // W_ih of layer l; l == rnn_layers: the head's W1
     const uint64_t GH = (kind == RL_MODULE_LSTM_MLP ? 4 : 3) * (uint64_t)gru_hidden;
     if (l == 0) return 0;

@@ -993,7 +993,7 @@ void launch_chain_step(rl_env *env) {
 }
 
 void launch_rollout_gru(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
-  RL_REQUIRE(policy->rnn_layers == 1, "stacked recurrent layers roll out through launch_stack_rollout");
+  RL_REQUIRE(!policy->lane_kernels(), "this module rolls out through launch_stack_rollout");
   ProfScope ps(env->eng, RL_K_ROLLOUT);
   RL_REQUIRE(env->D == 5, "recurrent rollout: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;
@@ -1021,7 +1021,7 @@ void launch_rollout_chain_mlp(rl_env *env, const rl_mlp *policy, rl_traj *traj) 
 
 void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_succ, float *d_act,
                             const int32_t *d_skip) {
-  if (mod->rnn_layers > 1) return launch_stack_forward(traj, mod, d_out, d_succ, d_act != nullptr, d_skip);
+  if (mod->lane_kernels()) return launch_stack_forward(traj, mod, d_out, d_succ, d_act != nullptr, d_skip);
   ProfScope ps(traj->eng, RL_K_POLICY_FUSED);
   RL_REQUIRE(traj->d.D == 5, "recurrent forward: built for 5 observation features");
   uint32_t tiles = traj->d.n / TL;

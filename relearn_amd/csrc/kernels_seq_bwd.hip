@@ -674,7 +674,7 @@ void launch_seq_critic_dvalues(rl_traj *traj, uint64_t B_total) {
 
 // backward through time + weight-gradient GEMMs + reduction: traj->vec[0..P) <- sum over this rank's samples
 void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip) {
-  if (mod->rnn_layers > 1) return launch_stack_backward(traj, mod, d_skip);
+  if (mod->lane_kernels()) return launch_stack_backward(traj, mod, d_skip);
   rl_engine *e = traj->eng;
   const SeqDev &q = traj->seq;
   uint32_t P = (uint32_t)mod->P, blocks = traj->d.T * q.tiles;

@@ -377,7 +377,7 @@ void launch_gru_tangent(rl_traj *traj, const rl_mlp *mod, const float *d_tangent
   const SeqDev &q = traj->seq;
   RL_REQUIRE(mod->out_dim == 2, "Fisher-vector products are for 2-action policies");
   uint32_t blocks = traj->d.T * q.tiles;
-  if (mod->rnn_layers > 1) launch_stack_tangent(traj, mod, d_tangent, d_skip);  // -> seq.out
+  if (mod->lane_kernels()) launch_stack_tangent(traj, mod, d_tangent, d_skip);  // -> seq.out
   else {
     ProfScope ps(e, RL_K_POLICY_FUSED);
     if (mod->kind == RL_MODULE_LSTM_MLP) {

@@ -6,7 +6,7 @@
 //
 // The single-layer chains have fused tile kernels (kernels_seq*.hip, built for 5 -> 128 -> 128); this is the general
 // path for the stacked ones, at the module's own widths: ONE THREAD PER LANE, 64 lanes per workgroup, and the unit loop
-// of a layer dealt in quads to the workgroup's four waves (a quad's gate rows share every loaded input value: 12-16 fma
+// of a layer dealt in quads to the workgroup's eight waves (a quad's gate rows share every loaded input value: 12-16 fma
 // per load; weights come through wave-uniform loads).  States and the step's scratch live in [unit][lane] arrays in
 // device memory (L2-resident: a workgroup's slice is 64 lanes wide), records of a training forward in [unit][sample]
 // planes — the layout the per-layer weight-gradient kernel of kernels_general.hip reads, which forms every dW = dY X^T
@@ -22,8 +22,9 @@
 namespace {
 
 constexpr int SL = 64;  // lanes per workgroup
-constexpr int SW = 4;   // waves per workgroup
-constexpr int UQ = 4;   // units per pass
+constexpr int SW = 8;   // waves per workgroup
+constexpr int UQ = 4;   // units per pass (forward-style products: the quad's gate rows share every loaded input)
+constexpr int KB = 8;   // outputs per pass of the transposed products of the backward scan
 constexpr int LSTM = RL_MODULE_LSTM_MLP, GRU = RL_MODULE_GRU_MLP;
 
 // record planes of a layer: [RPN][H][B]
@@ -68,6 +69,67 @@ __device__ __forceinline__ LaneCtx lane_ctx(uint32_t n) {
   return c;
 }
 
+// acc[r] = fma(x_k, W[row[r]][k], acc[r]) for k ascending: R rows of a [.][K] matrix against one input vector.  Four k
+// per trip: a row's four weights are contiguous (one wide wave-uniform load each), the four inputs are in flight
+// together; every sum stays the k-ascending fma chain of the arithmetic contract.
+template <int R, class XF>
+__device__ __forceinline__ void dot_rows(float (&acc)[R], const float *__restrict__ W, const int (&row)[R], int K,
+                                         XF x_at) {
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    float x[4], w[R][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = x_at(k + q);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[r][q] = W[(size_t)row[r] * K + k + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(x[q], w[r][q], acc[r]);
+  }
+  for (; k < K; ++k) {
+    const float x = x_at(k);
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(x, W[(size_t)row[r] * K + k], acc[r]);
+  }
+}
+
+// acc[u] += sum over r < R of d_r W[r][k0 + u]: N outputs k0 .. k0 + N - 1 of the transposed product W^T d (W rows `ld`
+// floats apart).  FULL: all N outputs exist (contiguous weights, wide loads); else indices past kmax are clamped.
+template <int N, bool FULL, class DF>
+__device__ __forceinline__ void tdot_n(float (&acc)[N], const float *__restrict__ W, int ld, int k0, int kmax, int R,
+                                       DF d_at) {
+  int kk[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) kk[u] = FULL ? k0 + u : (k0 + u < kmax ? k0 + u : kmax);
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {
+    float d[4], w[4][N];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = d_at(r + q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < N; ++u) w[q][u] = W[(size_t)(r + q) * ld + kk[u]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < N; ++u) acc[u] = __builtin_fmaf(d[q], w[q][u], acc[u]);
+  }
+  for (; r < R; ++r) {
+    const float d = d_at(r);
+#pragma unroll
+    for (int u = 0; u < N; ++u) acc[u] = __builtin_fmaf(d, W[(size_t)r * ld + kk[u]], acc[u]);
+  }
+}
+template <int N, class DF>
+__device__ __forceinline__ void tdot(float (&acc)[N], const float *__restrict__ W, int ld, int k0, int K, int R, DF d_at) {
+  if (k0 + N <= K) tdot_n<N, true>(acc, W, ld, k0, K - 1, R, d_at);
+  else tdot_n<N, false>(acc, W, ld, k0, K - 1, R, d_at);
+}
+
 // layer l of one step: in[k * in_stride + lane] (K inputs), states (h, c) -> (hn, cn); `fresh`: the lane's state is zero
 template <int CELL, bool REC>
 __device__ __forceinline__ void stack_cell(const StackNet &net, const StackWs &ws, int l, const float *__restrict__ in,
@@ -80,31 +142,27 @@ __device__ __forceinline__ void stack_cell(const StackNet &net, const StackWs &w
   const float *__restrict__ Wih = net.p + net.off[l], *__restrict__ Whh = Wih + (size_t)G * H * K;
   const float *__restrict__ bih = Whh + (size_t)G * H * H, *__restrict__ bhh = bih + G * H;
   for (int j0 = UQ * lc.wave; j0 < H; j0 += UQ * SW) {
-    float gi[G][UQ], gh[G][UQ];
-    int row[G][UQ];
+    float gif[G * UQ], ghf[G * UQ];  // [gate][unit of the quad]
+    int row[G * UQ];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         const int j = j0 + u < H ? j0 + u : H - 1;
-        row[g][u] = g * H + j;
-        gi[g][u] = bih[row[g][u]];
-        gh[g][u] = bhh[row[g][u]];
+        row[g * UQ + u] = g * H + j;
+        gif[g * UQ + u] = bih[g * H + j];
+        ghf[g * UQ + u] = bhh[g * H + j];
       }
-    for (int k = 0; k < K; ++k) {
-      const float x = in[(size_t)k * in_stride + lc.ii];
+    dot_rows(gif, Wih, row, K, [&](int k) { return in[(size_t)k * in_stride + lc.ii]; });
+    dot_rows(ghf, Whh, row, H, [&](int k) { return fresh ? 0.0f : h[(size_t)k * n + lc.ii]; });
+    float gi[G][UQ], gh[G][UQ];
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int u = 0; u < UQ; ++u) gi[g][u] = __builtin_fmaf(x, Wih[(size_t)row[g][u] * K + k], gi[g][u]);
-    }
-    for (int k = 0; k < H; ++k) {
-      const float hv = fresh ? 0.0f : h[(size_t)k * n + lc.ii];
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int u = 0; u < UQ; ++u) gh[g][u] = __builtin_fmaf(hv, Whh[(size_t)row[g][u] * H + k], gh[g][u]);
-    }
+      for (int u = 0; u < UQ; ++u) {
+        gi[g][u] = gif[g * UQ + u];
+        gh[g][u] = ghf[g * UQ + u];
+      }
 #pragma unroll
     for (int u = 0; u < UQ; ++u) {
       const int j = j0 + u;
@@ -173,12 +231,10 @@ __device__ __forceinline__ void stack_head(const StackNet &net, const StackWs &w
       jj[u] = j0 + u < H2 ? j0 + u : H2 - 1;
       acc[u] = b1[jj[u]];
     }
-    for (int k = 0; k < H; ++k) {
+    dot_rows(acc, W1, jj, H, [&](int k) {
       const float tv = top[(size_t)k * n + lc.ii];
-      const float a1 = tv > 0.0f ? tv : 0.0f;
-#pragma unroll
-      for (int u = 0; u < UQ; ++u) acc[u] = __builtin_fmaf(a1, W1[(size_t)jj[u] * H + k], acc[u]);
-    }
+      return tv > 0.0f ? tv : 0.0f;
+    });
 #pragma unroll
     for (int u = 0; u < UQ; ++u)
       if (j0 + u < H2 && lc.live) {
@@ -193,15 +249,10 @@ __device__ __forceinline__ void stack_head(const StackNet &net, const StackWs &w
       ws.a1[(size_t)k * ws.B + b] = tv > 0.0f ? tv : 0.0f;
     }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    out[q] = 0.0f;
-    if (q < A) {
-      float acc = b2[q];
-      for (int j = 0; j < H2; ++j) acc = __builtin_fmaf(ws.u[(size_t)j * n + lc.ii], W2[(size_t)q * H2 + j], acc);
-      out[q] = acc;
-    }
-  }
+  const int qq[2] = {0, A > 1 ? 1 : 0};
+  out[0] = b2[qq[0]];
+  out[1] = b2[qq[1]];
+  dot_rows(out, W2, qq, H2, [&](int j) { return ws.u[(size_t)j * n + lc.ii]; });
 }
 
 // all layers + head of one step: states of set `cur` (zero where `fresh`) -> set `nxt`
@@ -287,31 +338,22 @@ __global__ void __launch_bounds__(SL *SW) k_stack_backward(StackNet net, StackWs
   for (size_t t = T; t-- > 0;) {
     const size_t b = t * n + lc.ii;
     const bool ended = t == T - 1 || tr.flag[b] != RL_SUCC_CONTINUE;  // nothing flows in from step t + 1
-    for (int j0 = UQ * lc.wave; j0 < H2; j0 += UQ * SW)
+    for (int j0 = KB * lc.wave; j0 < H2; j0 += KB * SW) {
+      float acc[KB] = {};
+      tdot(acc, W2, H2, j0, H2, A, [&](int q) { return dz[(size_t)q * B + b]; });
 #pragma unroll
-      for (int u = 0; u < UQ; ++u) {
-        const int j = j0 + u;
-        if (j >= H2) break;
-        float acc = 0.0f;
-        for (int q = 0; q < A; ++q) acc = __builtin_fmaf(dz[(size_t)q * B + b], W2[(size_t)q * H2 + j], acc);
-        if (!(ws.ur[(size_t)j * B + b] > 0.0f)) acc = 0.0f;
-        if (lc.live) ws.du[(size_t)j * B + b] = acc;
-      }
+      for (int u = 0; u < KB; ++u)
+        if (j0 + u < H2 && lc.live)
+          ws.du[(size_t)(j0 + u) * B + b] = ws.ur[(size_t)(j0 + u) * B + b] > 0.0f ? acc[u] : 0.0f;
+    }
     __syncthreads();
     {
       const float *__restrict__ top = rec_plane(ws, net, L - 1, RP_HOUT);
-      for (int k0 = UQ * lc.wave; k0 < H; k0 += UQ * SW) {
-        float acc[UQ] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int kk[UQ];
+      for (int k0 = KB * lc.wave; k0 < H; k0 += KB * SW) {
+        float acc[KB] = {};
+        tdot(acc, W1, H, k0, H, H2, [&](int j) { return ws.du[(size_t)j * B + b]; });
 #pragma unroll
-        for (int u = 0; u < UQ; ++u) kk[u] = k0 + u < H ? k0 + u : H - 1;
-        for (int j = 0; j < H2; ++j) {
-          const float d = ws.du[(size_t)j * B + b];
-#pragma unroll
-          for (int u = 0; u < UQ; ++u) acc[u] = __builtin_fmaf(d, W1[(size_t)j * H + kk[u]], acc[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < UQ; ++u)
+        for (int u = 0; u < KB; ++u)
           if (k0 + u < H && lc.live)
             ws.din[(size_t)(k0 + u) * n + lc.ii] = top[(size_t)(k0 + u) * B + b] > 0.0f ? acc[u] : 0.0f;
       }
@@ -363,25 +405,16 @@ __global__ void __launch_bounds__(SL *SW) k_stack_backward(StackNet net, StackWs
         }
       __syncthreads();
       // (B)
-      for (int k0 = UQ * lc.wave; k0 < H; k0 += UQ * SW) {
-        float acc[UQ] = {0.0f, 0.0f, 0.0f, 0.0f}, acc2[UQ] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int kk[UQ];
-#pragma unroll
-        for (int u = 0; u < UQ; ++u) kk[u] = k0 + u < H ? k0 + u : H - 1;
-        for (int row = 0; row < G * H; ++row) {
-          // hidden-side delta of gate row `row`: the GRU's n rows take their fourth plane
+      for (int k0 = KB * lc.wave; k0 < H; k0 += KB * SW) {
+        float acc[KB] = {}, acc2[KB] = {};
+        // hidden-side delta of gate row `row`: the GRU's n rows take their fourth plane
+        tdot(acc, Whh, H, k0, H, G * H, [&](int row) {
           const int hrow = (CELL == GRU && row >= 2 * H) ? row + H : row;
-          const float dh_ = dg[(size_t)hrow * B + b];
+          return dg[(size_t)hrow * B + b];
+        });
+        if (l > 0) tdot(acc2, Wih, K, k0, H, G * H, [&](int row) { return dg[(size_t)row * B + b]; });
 #pragma unroll
-          for (int u = 0; u < UQ; ++u) acc[u] = __builtin_fmaf(dh_, Whh[(size_t)row * H + kk[u]], acc[u]);
-          if (l > 0) {
-            const float di = dg[(size_t)row * B + b];
-#pragma unroll
-            for (int u = 0; u < UQ; ++u) acc2[u] = __builtin_fmaf(di, Wih[(size_t)row * K + kk[u]], acc2[u]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UQ; ++u)
+        for (int u = 0; u < KB; ++u)
           if (k0 + u < H && lc.live) {
             const size_t kn = (size_t)(k0 + u) * n + lc.ii;
             dhc[kn] = dhc[kn] + acc[u];
@@ -424,39 +457,29 @@ __global__ void __launch_bounds__(SL *SW) k_stack_tangent(StackNet net, StackNet
       const float *__restrict__ hd = slot(ws, net, cur, 0, l), *__restrict__ cd = slot(ws, net, cur, 1, l);
       float *__restrict__ hdn = slot(ws, net, nxt, 0, l), *__restrict__ cdn = slot(ws, net, nxt, 1, l);
       for (int j0 = UQ * lc.wave; j0 < H; j0 += UQ * SW) {
-        float gid[G][UQ], ghd[G][UQ];
-        int row[G][UQ];
+        float gidf[G * UQ], ghdf[G * UQ];
+        int row[G * UQ];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
           for (int u = 0; u < UQ; ++u) {
             const int j = j0 + u < H ? j0 + u : H - 1;
-            row[g][u] = g * H + j;
-            gid[g][u] = vbih[row[g][u]];
-            ghd[g][u] = vbhh[row[g][u]];
+            row[g * UQ + u] = g * H + j;
+            gidf[g * UQ + u] = vbih[g * H + j];
+            ghdf[g * UQ + u] = vbhh[g * H + j];
           }
-        for (int k = 0; k < K; ++k) {
-          const float x = in[(size_t)k * in_stride];
-          const float xd = l == 0 ? 0.0f : ind[(size_t)k * n + lc.ii];
+        dot_rows(gidf, Vih, row, K, [&](int k) { return in[(size_t)k * in_stride]; });
+        if (l > 0) dot_rows(gidf, Wih, row, K, [&](int k) { return ind[(size_t)k * n + lc.ii]; });
+        dot_rows(ghdf, Vhh, row, H, [&](int k) { return hprev[(size_t)k * B + b]; });
+        dot_rows(ghdf, Whh, row, H, [&](int k) { return fresh ? 0.0f : hd[(size_t)k * n + lc.ii]; });
+        float gid[G][UQ], ghd[G][UQ];
 #pragma unroll
-          for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int u = 0; u < UQ; ++u) {
-              gid[g][u] = __builtin_fmaf(x, Vih[(size_t)row[g][u] * K + k], gid[g][u]);
-              if (l > 0) gid[g][u] = __builtin_fmaf(xd, Wih[(size_t)row[g][u] * K + k], gid[g][u]);
-            }
-        }
-        for (int k = 0; k < H; ++k) {
-          const float hp = hprev[(size_t)k * B + b];
-          const float hdk = fresh ? 0.0f : hd[(size_t)k * n + lc.ii];
-#pragma unroll
-          for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int u = 0; u < UQ; ++u) {
-              ghd[g][u] = __builtin_fmaf(hp, Vhh[(size_t)row[g][u] * H + k], ghd[g][u]);
-              ghd[g][u] = __builtin_fmaf(hdk, Whh[(size_t)row[g][u] * H + k], ghd[g][u]);
-            }
-        }
+          for (int u = 0; u < UQ; ++u) {
+            gid[g][u] = gidf[g * UQ + u];
+            ghd[g][u] = ghdf[g * UQ + u];
+          }
 #pragma unroll
         for (int u = 0; u < UQ; ++u) {
           const int j = j0 + u;
@@ -502,15 +525,9 @@ __global__ void __launch_bounds__(SL *SW) k_stack_tangent(StackNet net, StackNet
           jj[u] = j0 + u < H2 ? j0 + u : H2 - 1;
           acc[u] = vb1[jj[u]];
         }
-        for (int k = 0; k < H; ++k) {
-          const float a1 = ws.a1[(size_t)k * B + b];
-          const float a1d = top[(size_t)k * B + b] > 0.0f ? topd[(size_t)k * n + lc.ii] : 0.0f;
-#pragma unroll
-          for (int u = 0; u < UQ; ++u) {
-            acc[u] = __builtin_fmaf(a1, V1[(size_t)jj[u] * H + k], acc[u]);
-            acc[u] = __builtin_fmaf(a1d, W1[(size_t)jj[u] * H + k], acc[u]);
-          }
-        }
+        dot_rows(acc, V1, jj, H, [&](int k) { return ws.a1[(size_t)k * B + b]; });
+        dot_rows(acc, W1, jj, H,
+                 [&](int k) { return top[(size_t)k * B + b] > 0.0f ? topd[(size_t)k * n + lc.ii] : 0.0f; });
 #pragma unroll
         for (int u = 0; u < UQ; ++u)
           if (j0 + u < H2 && lc.live)
@@ -518,15 +535,14 @@ __global__ void __launch_bounds__(SL *SW) k_stack_tangent(StackNet net, StackNet
       }
     }
     __syncthreads();
-    if (lc.wave == 0)
-      for (int q = 0; q < A; ++q) {
-        float acc = vb2[q];
-        for (int j = 0; j < H2; ++j) {
-          acc = __builtin_fmaf(ws.ur[(size_t)j * B + b], V2[(size_t)q * H2 + j], acc);
-          acc = __builtin_fmaf(ws.u[(size_t)j * n + lc.ii], W2[(size_t)q * H2 + j], acc);
-        }
-        if (lc.live) out_dot[(size_t)q * B + b] = acc;
-      }
+    if (lc.wave == 0) {
+      const int qq[2] = {0, A > 1 ? 1 : 0};
+      float od[2] = {vb2[qq[0]], vb2[qq[1]]};
+      dot_rows(od, V2, qq, H2, [&](int j) { return ws.ur[(size_t)j * B + b]; });
+      dot_rows(od, W2, qq, H2, [&](int j) { return ws.u[(size_t)j * n + lc.ii]; });
+      if (lc.live)
+        for (int q = 0; q < A; ++q) out_dot[(size_t)q * B + b] = od[q];
+    }
     fresh = tr.flag[b] != RL_SUCC_CONTINUE;
     cur = nxt;
   }
@@ -575,7 +591,7 @@ inline uint32_t cdiv_k(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) /
 }  // namespace
 
 void stack_ensure(rl_traj *t, const rl_mlp *mod, bool training) {
-  RL_REQUIRE(rl_module_is_recurrent(mod->kind) && mod->rnn_layers > 1, "not a stacked recurrent module");
+  RL_REQUIRE(rl_module_is_recurrent(mod->kind) && mod->lane_kernels(), "not a module of the lane-per-thread kernels");
   RL_REQUIRE(mod->in_dim == t->d.D, "module input width does not match the trajectory");
   SeqDev &q = t->seq;
   SeqDev::Stack &k = q.stack;

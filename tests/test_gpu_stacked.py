@@ -19,7 +19,9 @@ L = O.lib()
 
 # (cell, in_dim, hidden, num_layers, mlp_hidden, out_dim): widths that are / are not multiples of the unit quads
 SHAPES = [("gru", 5, 32, 2, 16, 2), ("lstm", 3, 18, 3, 10, 1), ("gru", 2, 7, 4, 5, 1), ("lstm", 5, 64, 2, 33, 2),
-          ("gru", 5, 128, 2, 128, 2)]
+          ("gru", 5, 128, 2, 128, 2),
+          # more input features than the fused tile kernels' five: the same lane-per-thread kernels, one layer or several
+          ("gru", 7, 12, 1, 8, 2), ("lstm", 8, 16, 2, 8, 1)]
 GRAD_RTOL = 5e-6
 
 
@@ -245,5 +247,5 @@ def test_layer_counts_that_are_not_built_are_refused(engine):
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_UNSUPPORTED
     assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(0), C.c_uint32(5), C.c_uint32(32), C.c_uint32(0),
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_BUILD_AGENT
-    assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(1), C.c_uint32(6), C.c_uint32(32), C.c_uint32(2),
+    assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(1), C.c_uint32(9), C.c_uint32(32), C.c_uint32(2),
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_BUILD_AGENT
