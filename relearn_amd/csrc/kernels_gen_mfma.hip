@@ -429,10 +429,15 @@ __global__ void __launch_bounds__(GWAVES * 64)
     else row[at] = row[at] + (double)v;
   };
   auto flush_w = [&](f32x16 &t, int l, int ot, int it) {
-    const int K = Kof(l), N = Nof(l), k = it * 32 + m;
+    // (the lane's column through a register the optimiser cannot see through: with a visible one, the ~100 slab addresses
+    // and bounds of a flush are loop-invariant, get computed ahead of the tile loop and live in scratch until the flush —
+    // ~1 KB per lane written and read back by every launch: 270 MB at 16,384 x 128 samples)
+    int mo = m, kbo = kb;
+    asm volatile("" : "+v"(mo), "+v"(kbo));
+    const int K = Kof(l), N = Nof(l), k = it * 32 + mo;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = ot * 32 + urow(r, kb);
+      const int j = ot * 32 + urow(r, kbo);
       if (j < N) {
         if (k < K) put(g.off[l] + (uint32_t)(j * K + k), t[r]);
         else if (l == 0 && k == K) put(g.off[0] + (uint32_t)(N * K + j), t[r]);
@@ -457,11 +462,13 @@ __global__ void __launch_bounds__(GWAVES * 64)
     // biases of layers 1 .. NL: column c = (l - 1) GW + ot of the bias tile
 #pragma unroll
     for (int l = 1; l <= NL; ++l) {
-      const int N = Nof(l), K = Kof(l), ot = m - (l - 1) * GW;
+      int mo = m, kbo = kb;
+      asm volatile("" : "+v"(mo), "+v"(kbo));
+      const int N = Nof(l), K = Kof(l), ot = mo - (l - 1) * GW;
       if (ot >= 0 && ot < (l < NL ? GW : 1)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int j = ot * 32 + urow(r, kb);
+          const int j = ot * 32 + urow(r, kbo);
           if (j < N) put(g.off[l] + (uint32_t)(N * K + j), dbt[r]);
         }
       }
@@ -711,7 +718,10 @@ __global__ void __launch_bounds__(GWAVES * 64)
 // (backward chain) and of A_{l-1}^T (weight gradients), 6 KB each way, plus the two partial sums of the output layer.
 // A wave then carries 80 accumulator registers instead of 144 and ~230 in all: TWO waves per SIMD, each hiding the
 // other's dependency chains (the one-wave kernel above waits 42 % of its cycles).  Every pair of a workgroup walks the
-// same number of tiles (a pair without a tile runs on zeros): the exchanges are workgroup barriers.
+// same number of tiles (a pair without a tile runs on zeros): the exchanges are workgroup barriers.  (Hand-overs between
+// the two waves of a pair only — arrival counters in LDS, the partner polling — were measured and are SLOWER: 13.5
+// against 12.5 ms for 20 critic steps of [64, 64] at 16,384 x 128; a polling wave takes issue slots from the SIMD's other
+// wave.)
 // One exchange region per wave: write, barrier, the partner reads; the next barrier in program order (there is always
 // one before the region's next write) guards the reuse.
 // ================================================================================================
@@ -768,10 +778,15 @@ __global__ void __launch_bounds__(PAIRS * 128)
     else row[at] = row[at] + (double)v;
   };
   auto flush_w = [&](f32x16 &t, int l, int ot, int it) {
-    const int K = Kof(l), N = Nof(l), k = it * 32 + m;
+    // (the lane's column through a register the optimiser cannot see through: with a visible one, the ~100 slab addresses
+    // and bounds of a flush are loop-invariant, get computed ahead of the tile loop and live in scratch until the flush —
+    // ~1 KB per lane written and read back by every launch: 270 MB at 16,384 x 128 samples)
+    int mo = m, kbo = kb;
+    asm volatile("" : "+v"(mo), "+v"(kbo));
+    const int K = Kof(l), N = Nof(l), k = it * 32 + mo;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = ot * 32 + urow(r, kb);
+      const int j = ot * 32 + urow(r, kbo);
       if (j < N) {
         if (k < K) put(g.off[l] + (uint32_t)(j * K + k), t[r]);
         else if (l == 0 && k == K) put(g.off[0] + (uint32_t)(N * K + j), t[r]);
@@ -790,11 +805,13 @@ __global__ void __launch_bounds__(PAIRS * 128)
     flush_w(dWo, NL, 0, h);
 #pragma unroll
     for (int l = 1; l <= NL; ++l) {  // bias column (l - 1) GW + ot: this wave's tile of a hidden layer; wave 0: the outputs
-      const int N = Nof(l), K = Kof(l), ot = m - (l - 1) * GW;
+      int mo = m, kbo = kb;
+      asm volatile("" : "+v"(mo), "+v"(kbo));
+      const int N = Nof(l), K = Kof(l), ot = mo - (l - 1) * GW;
       if (l < NL ? ot == h : (ot == 0 && h == 0)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int j = ot * 32 + urow(r, kb);
+          const int j = ot * 32 + urow(r, kbo);
           if (j < N) put(g.off[l] + (uint32_t)(N * K + j), dbt[r]);
         }
       }

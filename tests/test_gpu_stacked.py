@@ -227,6 +227,41 @@ def test_trpo_step_against_the_f64_pieces(engine):
     assert abs(st.constraint_val_final - kl_o) <= 1e-3 * kl_o + 3e-8 and 1e-5 < kl_o <= 0.0101
 
 
+@pytest.mark.parametrize("kind", ["stacked", "single-layer", "general"])
+def test_actor_critic_update_with_modules_off_the_fused_path(engine, kind):
+    """rl_actor_critic_update (the batch_update verb) with modules the two-stream pairing is not built for — stacked and
+    single-layer recurrent chains, an MLP on the per-layer kernels — runs the two updates in turn on one stream:
+    bit-identical to rl_trpo_update followed by rl_values_opt_update"""
+    n, T = 64, 20
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update = 5
+
+    def run(joint):
+        env = ra.CartPoleEnv(engine, n, max_steps=9, seed_env=5, seed_actor=6)
+        if kind == "stacked":
+            pol, cri = ra.GruMlp(engine, 5, 2, 16, 12, num_layers=2), ra.LstmMlp(engine, 5, 1, 12, 8, num_layers=2)
+        elif kind == "single-layer":
+            pol, cri = ra.GruMlp(engine, 5, 2, 32, 16), ra.GruMlp(engine, 5, 1, 32, 16)
+        else:
+            pol, cri = ra.Mlp(engine, 5, [24, 24], 2), ra.Mlp(engine, 5, [130], 1)
+        pol.init(2)
+        cri.init(3)
+        opt = ra.Adam(cri)
+        traj = ra.Trajectory(engine, n, T, 5)
+        ra.rollout(env, pol, traj)
+        ra.gae(traj, cri, 0.99, 0.95)
+        if joint:
+            pst, cst, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
+        else:
+            pst = ra.trpo_update(pol, traj)
+            cst, losses = ra.values_opt_update(cri, opt, traj, ccfg, want_losses=True)
+        return pol.get_params(), cri.get_params(), pst.as_dict(), losses.copy()
+
+    a, b = run(False), run(True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+    assert a[2]["status"] == ra.OPT_OK and a[3][-1] < a[3][0]
+
+
 def test_actor_document_round_trip(engine):
     """RnnWeights { flat_weights } holds 4 tensors per layer (seq/rnn/mod.rs:186-191,223-257): written and read back"""
     pol, _, _ = modules(engine, "lstm", 5, 12, 3, 6, 2, 19)
