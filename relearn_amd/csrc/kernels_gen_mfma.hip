@@ -721,7 +721,8 @@ __global__ void __launch_bounds__(GWAVES * 64)
 // same number of tiles (a pair without a tile runs on zeros): the exchanges are workgroup barriers.  (Hand-overs between
 // the two waves of a pair only — arrival counters in LDS, the partner polling — were measured and are SLOWER: 13.5
 // against 12.5 ms for 20 critic steps of [64, 64] at 16,384 x 128; a polling wave takes issue slots from the SIMD's other
-// wave.)
+// wave.  Nor does running half of the pairs half a tile behind the others behind the SAME barriers help — every barrier
+// interval then lasts as long as the longer of two different program segments: 16.3 ms.)
 // One exchange region per wave: write, barrier, the partner reads; the next barrier in program order (there is always
 // one before the region's next write) guards the reuse.
 // ================================================================================================
