@@ -43,5 +43,8 @@ python3 scripts/lstm_config5.py > "$OUT/lstm_config5.json" 2> "$OUT/lstm_config5
 python3 scripts/gru_config5.py > "$OUT/gru_config5.json" 2> "$OUT/gru_config5.err" || echo "gru failed"
 python3 scripts/general_mlp_period.py > "$OUT/general_mlp_period.json" 2> "$OUT/general_mlp_period.err" || echo "general failed"
 python3 scripts/gen_passes.py > "$OUT/general_mlp_passes.txt" 2>&1 || echo "gen passes failed"
+# stacked recurrent layers on the lane-per-thread kernels (2-layer GRU / LSTM of width 128, 4,096 lanes x 100 steps)
+python3 scripts/stacked_period.py 4096 100 128 2 gru > "$OUT/stacked_gru_l2.json" 2> "$OUT/stacked_gru_l2.err" || echo "stacked gru failed"
+python3 scripts/stacked_period.py 4096 100 128 2 lstm > "$OUT/stacked_lstm_l2.json" 2> "$OUT/stacked_lstm_l2.err" || echo "stacked lstm failed"
 find "$OUT" -name "*kernel_stats.csv" | head
 echo "collect_profiles done"
