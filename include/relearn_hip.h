@@ -257,8 +257,9 @@ int32_t rl_mlp_init(rl_mlp *mlp, uint64_t seed);
  * shape.  Feed-forward modules only; every layer uses the same pair, as MlpConfig::linear_config does.  The draws come
  * from the engine's stream ChaCha8(seed), stream 0, in flat parameter order: one f32 per uniform element, Box-Muller
  * on consecutive pairs for normal ones (libtorch's generator is never seeded by the reference).
- * `bias_init` NULL (LinearConfig::bias_init = None: layers without a bias vector) -> RL_ERR_UNSUPPORTED: every kernel
- * of this library folds the bias in as a sixth input.  rl_mlp_init(m, seed) = both Uniform(FanAvg), the default. */
+ * `bias_init` NULL <=> the module was built without bias vectors (rl_mlp_create_config(..., bias = 0):
+ * LinearConfig::bias_init = None); a mismatch -> RL_ERR_INVALID_ARGUMENT.  rl_mlp_init(m, seed) = both Uniform(FanAvg),
+ * the default. */
 typedef enum { RL_INIT_ZEROS = 0, RL_INIT_CONSTANT = 1, RL_INIT_UNIFORM = 2, RL_INIT_NORMAL = 3, RL_INIT_ORTHOGONAL = 4 } rl_init_kind;
 typedef enum { RL_SCALE_CONSTANT = 0, RL_SCALE_FAN_IN = 1, RL_SCALE_FAN_OUT = 2, RL_SCALE_FAN_AVG = 3 } rl_variance_scale;
 typedef struct {
@@ -267,6 +268,16 @@ typedef struct {
   double value;   /* Constant(value); VarianceScale::Constant(value) */
 } rl_initializer;
 int32_t rl_mlp_init_with(rl_mlp *mlp, uint64_t seed, const rl_initializer *kernel_init, const rl_initializer *bias_init);
+/* The same for a recurrent chain: RnnBaseConfig { input_weights_init, hidden_weights_init, bias_init }
+ * (seq/rnn/mod.rs:20-45; RnnWeights::new, :223-257: per layer W_ih from input_weights_init, W_hh from
+ * hidden_weights_init, b_ih and b_hh from bias_init — 1-D tensors: fan_in 1, fan_out = gate rows) and the chain's
+ * MlpConfig::linear_config { kernel_init, bias_init } (fan_in = in + 1), layer after layer from the same stream.
+ * rl_mlp_init(m, seed) on a recurrent chain = (Uniform(FanAvg), Orthogonal, Zeros; Uniform(FanAvg) x 2), the defaults.
+ * bias_init NULL (RnnBaseConfig::bias_init = None: weights without bias vectors) -> RL_ERR_UNSUPPORTED; Orthogonal on a
+ * bias -> RL_ERR_INVALID_ARGUMENT (init_orthogonal asserts two dimensions, initializers.rs:331-334). */
+int32_t rl_rnn_mlp_init_with(rl_mlp *module, uint64_t seed, const rl_initializer *input_weights_init,
+                             const rl_initializer *hidden_weights_init, const rl_initializer *bias_init,
+                             const rl_initializer *mlp_kernel_init, const rl_initializer *mlp_bias_init);
 int32_t rl_params_get(rl_mlp *mlp, float *host, uint64_t n);
 int32_t rl_params_set(rl_mlp *mlp, const float *host, uint64_t n);
 /* Forward::forward on host rows [n_rows][in_dim] -> [n_rows][out_dim] (test/utility path) */

@@ -350,6 +350,7 @@ def _declare(L):
     L.oracle_stack_num_params.argtypes = [GruShape, C.c_uint32]
     L.oracle_stack_num_params.restype = C.c_uint64
     L.oracle_stack_init.argtypes = [GruShape, C.c_uint32, C.c_uint64, P(C.c_float)]
+    L.oracle_stack_init_with.argtypes = [GruShape, C.c_uint32, C.c_uint64, C.c_void_p, P(C.c_float)]
     L.oracle_stack_seq_forward_f32.argtypes = [GruShape, C.c_uint32, P(C.c_float), C.c_uint64, C.c_uint64, P(C.c_float),
                                                P(C.c_uint8), P(C.c_float), P(C.c_float), P(C.c_float)]
     L.oracle_stack_seq_forward_f64.argtypes = [GruShape, C.c_uint32, P(C.c_double), C.c_uint64, C.c_uint64,
@@ -798,6 +799,25 @@ def stack_init(shape, num_layers, seed):
     """RnnBaseConfig { num_layers } chain (oracle/stack_impl.inc): the flat vector of oracle_stack_init"""
     p = np.zeros(int(lib().oracle_stack_num_params(shape, num_layers)), dtype=np.float32)
     lib().oracle_stack_init(shape, num_layers, seed, f32p(p))
+    return p
+
+
+class InitSpec(C.Structure):
+    """oracle_init_spec"""
+    _fields_ = [("kind", C.c_int32), ("scale", C.c_int32), ("value", C.c_double)]
+
+
+_INIT_KINDS = ["Zeros", "Constant", "Uniform", "Normal", "Orthogonal"]
+_INIT_SCALES = ["Constant", "FanIn", "FanOut", "FanAvg"]
+RNN_DEFAULT_INITS = (("Uniform", "FanAvg", 0.0), ("Orthogonal", "FanAvg", 0.0), ("Zeros", "FanAvg", 0.0),
+                     ("Uniform", "FanAvg", 0.0), ("Uniform", "FanAvg", 0.0))
+
+
+def stack_init_with(shape, num_layers, seed, inits=RNN_DEFAULT_INITS):
+    """RnnBaseConfig's (input, hidden, bias) initializers and the chain MLP's (kernel, bias) as (kind, scale, value)"""
+    p = np.zeros(int(lib().oracle_stack_num_params(shape, num_layers)), dtype=np.float32)
+    arr = (InitSpec * 5)(*[InitSpec(_INIT_KINDS.index(k), _INIT_SCALES.index(sc), float(v)) for k, sc, v in inits])
+    lib().oracle_stack_init_with(shape, num_layers, seed, arr, f32p(p))
     return p
 
 

@@ -551,3 +551,35 @@ void oracle_mlp_layers_init(uint32_t in_dim, const uint32_t *hidden_sizes, uint3
     K = N;
   }
 }
+
+/* RnnWeights::new with RnnBaseConfig { input_weights_init, hidden_weights_init, bias_init } (seq/rnn/mod.rs:20-45,223-257:
+ * per layer W_ih [G H, layer input], W_hh [G H, H], b_ih, b_hh [G H] — 1-D tensors: fan_in 1, fan_out G H,
+ * calculate_fan_in_and_fan_out, initializers.rs:90-103) and Linear::new with LinearConfig's pair (fan_in = in + 1) for
+ * the chain's MLP; the engine's draw stream, layer after layer.  inits: input, hidden, bias, mlp kernel, mlp bias. */
+void oracle_stack_init_with(oracle_gru_shape s, uint32_t num_layers, uint64_t seed, const oracle_init_spec *inits,
+                            float *params) {
+  const uint64_t H = s.hidden, D = s.in_dim, H2 = s.mlp_hidden, A = s.out_dim;
+  const uint64_t R = (s.cell == ORACLE_CELL_LSTM ? 4 : 3) * H;
+  oracle_prng r;
+  oracle_prng_seed_from_u64(&r, seed);
+  float *p = params;
+  for (uint32_t l = 0; l < num_layers; ++l) {
+    const uint64_t K = l == 0 ? D : H;
+    layers_fill(&r, inits[0].kind, inits[0].scale, inits[0].value, p, R, K, (double)K);
+    p += R * K;
+    layers_fill(&r, inits[1].kind, inits[1].scale, inits[1].value, p, R, H, (double)H);
+    p += R * H;
+    for (int b = 0; b < 2; ++b) {
+      layers_fill(&r, inits[2].kind, inits[2].scale, inits[2].value, p, R, 1, 1.0);
+      p += R;
+    }
+  }
+  const uint64_t dims[2][2] = {{H, H2}, {H2, A}};
+  for (int l = 0; l < 2; ++l) {
+    const uint64_t fin = dims[l][0], fout = dims[l][1];
+    layers_fill(&r, inits[3].kind, inits[3].scale, inits[3].value, p, fout, fin, (double)fin + 1.0);
+    p += fin * fout;
+    layers_fill(&r, inits[4].kind, inits[4].scale, inits[4].value, p, fout, 1, (double)fin + 1.0);
+    p += fout;
+  }
+}

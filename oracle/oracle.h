@@ -404,6 +404,10 @@ void oracle_gru_init(oracle_gru_shape s, uint64_t seed, float *params);
  * layer l > 0 the hidden output of layer l - 1), then the head as above; stack_impl.inc */
 uint64_t oracle_stack_num_params(oracle_gru_shape s, uint32_t num_layers);
 void oracle_stack_init(oracle_gru_shape s, uint32_t num_layers, uint64_t seed, float *params);
+/* ... with RnnBaseConfig's three initializers and the chain MLP's two (kind / scale codes of oracle_mlp_layers_init): nn.c */
+typedef struct { int32_t kind, scale; double value; } oracle_init_spec;
+void oracle_stack_init_with(oracle_gru_shape s, uint32_t num_layers, uint64_t seed, const oracle_init_spec *inits,
+                            float *params);
 void oracle_stack_seq_forward_f32(oracle_gru_shape s, uint32_t num_layers, const float *params, uint64_t n, uint64_t T,
                                   const float *obs, const uint8_t *flag, const float *term_obs, float *out, float *succ_out);
 void oracle_stack_seq_forward_f64(oracle_gru_shape s, uint32_t num_layers, const double *params, uint64_t n, uint64_t T,

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
     "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_create_config", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_mlp_init_with", "rl_params_get", "rl_params_set",
-    "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_rnn_mlp_create", "rl_seq_forward",
+    "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_rnn_mlp_create", "rl_rnn_mlp_init_with", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
@@ -475,6 +475,13 @@ class GruMlp(_Handle):
     init = None
     get_params = None
     set_params = None
+
+    def init_with(self, seed, input_weights=("Uniform", "FanAvg", 0.0), hidden_weights=("Orthogonal", "FanAvg", 0.0),
+                  bias=("Zeros", "FanAvg", 0.0), mlp_kernel=("Uniform", "FanAvg", 0.0), mlp_bias=("Uniform", "FanAvg", 0.0)):
+        """RnnBaseConfig's initializers and the chain MLP's LinearConfig as (kind, scale, value) triples"""
+        spec = [Initializer.of(x) if x is not None else None for x in (input_weights, hidden_weights, bias, mlp_kernel, mlp_bias)]
+        _check(lib().rl_rnn_mlp_init_with(self.h, C.c_uint64(seed), *[C.byref(x) if x is not None else None for x in spec]),
+               self.eng.h)
 
     def seq_forward(self, traj, want_succ=True):
         out = np.zeros((self.out_dim, traj.T, traj.n), dtype=np.float32)

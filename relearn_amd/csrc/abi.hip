@@ -970,119 +970,23 @@ int32_t rl_rnn_mlp_create(rl_engine *e, int32_t cell, uint32_t in_dim, uint32_t 
   });
 }
 
-// RnnWeights::new with RnnBaseConfig::default (seq/rnn/mod.rs:36-45,223-257) + the MLP's Linear::new layers.
-// Engine-defined stream: ChaCha8(seed), stream 0, one Standard f32 per uniform element; normals for the orthogonal
-// matrix by Box-Muller on consecutive draw pairs, QR by modified Gram-Schmidt applied twice in f64 (positive
-// diagonal of R, so the sign fold of init_orthogonal, initializers.rs:345-348, is the identity).
-static void gru_mlp_init_host(const rl_mlp *m, uint64_t seed, std::vector<float> &h) {
-  const uint64_t H = m->gru_hidden, D = m->in_dim, H2 = m->hidden, A = m->out_dim, R = rl_module_gates(m->kind) * H;
-  h.assign(m->P, 0.0f);
+// The engine's initialisation stream and TensorBuilder::build on it (initializers.rs:8-64,67-83,152-176,328-364):
+// ChaCha8(seed), stream 0; one Standard f32 per uniform element, value = (2u - 1) * lim in f32; normal elements by
+// Box-Muller on consecutive draw pairs (an odd count leaves the pair's second value unused); orthogonal: QR of the normal
+// matrix by modified Gram-Schmidt applied twice in f64 — positive diagonal of R, so the sign fold of init_orthogonal is the
+// identity.  Zeros / Constant draw nothing.  (libtorch's RNG is unseeded in the reference: the stream is engine-defined.)
+struct InitStream {
   uint32_t key[8];
-  rl_seed_from_u64(seed, key);
   uint32_t words[16];
   uint64_t widx = 0;
-  auto next_f32 = [&]() {
+  explicit InitStream(uint64_t seed) { rl_seed_from_u64(seed, key); }
+  float next_f32() {
     if ((widx & 15) == 0) rl_chacha_block(key, widx >> 4, 0, 4, words);
     float u = rl_u32_to_unit_f32(words[widx & 15]);
     widx += 1;
     return u;
-  };
-  size_t k = 0;
-  std::vector<double> rowmajor(R * H), a(R * H);
-  for (uint32_t layer = 0; layer < m->rnn_layers; ++layer) {  // RnnWeights::new's layer loop (seq/rnn/mod.rs:223-257)
-  const uint64_t K = layer == 0 ? D : H;
-  float lim = (float)std::sqrt(3.0 * (2.0 / ((double)K + (double)R)));
-  for (uint64_t i = 0; i < R * K; ++i) {
-    float u = next_f32();
-    float t = 2.0f * u;
-    t = t - 1.0f;
-    h[k++] = t * lim;
   }
-  const double two_pi = 6.283185307179586;
-  for (uint64_t i = 0; i < R * H; i += 2) {
-    double u1 = (double)next_f32(), u2 = (double)next_f32();
-    double rho = std::sqrt(-2.0 * std::log(1.0 - u1)), sn, cs;
-    rl_sincos(two_pi * u2, &sn, &cs);
-    rowmajor[i] = rho * cs;
-    if (i + 1 < R * H) rowmajor[i + 1] = rho * sn;
-  }
-  for (uint64_t row = 0; row < R; ++row)
-    for (uint64_t c = 0; c < H; ++c) a[c * R + row] = rowmajor[row * H + c];
-  for (uint64_t c = 0; c < H; ++c) {
-    double *v = a.data() + c * R;
-    for (int pass = 0; pass < 2; ++pass)
-      for (uint64_t q = 0; q < c; ++q) {
-        const double *w = a.data() + q * R;
-        double dot = 0.0;
-        for (uint64_t row = 0; row < R; ++row) dot += w[row] * v[row];
-        for (uint64_t row = 0; row < R; ++row) v[row] -= dot * w[row];
-      }
-    double nrm = 0.0;
-    for (uint64_t row = 0; row < R; ++row) nrm += v[row] * v[row];
-    nrm = std::sqrt(nrm);
-    for (uint64_t row = 0; row < R; ++row) v[row] /= nrm;
-  }
-  for (uint64_t row = 0; row < R; ++row)
-    for (uint64_t c = 0; c < H; ++c) h[k++] = (float)a[c * R + row];
-  k += 2 * R;  // biases stay zero
-  }
-  uint64_t dims[2][2] = {{H, H2}, {H2, A}};
-  for (int l = 0; l < 2; ++l) {
-    uint64_t in = dims[l][0], out = dims[l][1];
-    float lm = (float)std::sqrt(3.0 * (2.0 / ((double)(in + 1) + (double)out)));
-    for (uint64_t i = 0; i < in * out + out; ++i) {
-      float u = next_f32();
-      float t = 2.0f * u;
-      t = t - 1.0f;
-      h[k++] = t * lm;
-    }
-  }
-}
-
-int32_t rl_mlp_destroy(rl_mlp *m) {
-  if (!m) return RL_OK;
-  (void)hipSetDevice(m->eng->device);
-  (void)hipStreamSynchronize(m->eng->stream);
-  dfree(m->d_params);
-  if (m->exec) {
-    dfree(m->exec->d_params);
-    delete m->exec;
-  }
-  dfree(m->x_tmp);
-  dfree(m->x_tan);
-  rl_engine *eng = m->eng;
-  delete m;
-  engine_release_child(eng);
-  return RL_OK;
-}
-
-int32_t rl_mlp_num_params(const rl_mlp *m, uint64_t *n) {
-  return guarded(m ? m->eng : nullptr, [&] {
-    RL_REQUIRE(m && n, "NULL argument");
-    *n = m->P;
-  });
-}
-
-// Linear::new for every layer of a feed-forward module (reference src/torch/modules/ff/linear.rs:54-68) with the
-// given initializers (initializers.rs:152-176: TensorBuilder::build; :67-83 VarianceScale::variance; :328-364
-// init_orthogonal).  Stream (engine-defined, libtorch's RNG is unseeded in the reference): ChaCha8(seed), stream 0, in
-// flat parameter order (kernel then bias per layer): one Standard f32 per uniform element, value = (2u - 1) * lim in
-// f32; normal elements by Box-Muller on consecutive draw pairs (an odd count leaves the pair's second value unused);
-// orthogonal kernels: QR of the normal matrix by modified Gram-Schmidt applied twice in f64 — positive diagonal of R,
-// so the sign fold of init_orthogonal is the identity.  Zeros / Constant draw nothing.
-static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit, const rl_initializer &binit) {
-  std::vector<float> h(m->P);
-  uint32_t key[8];
-  rl_seed_from_u64(seed, key);
-  uint32_t words[16];
-  uint64_t widx = 0;
-  auto next_f32 = [&]() {
-    if ((widx & 15) == 0) rl_chacha_block(key, widx >> 4, 0, 4, words);
-    float u = rl_u32_to_unit_f32(words[widx & 15]);
-    widx += 1;
-    return u;
-  };
-  auto normals = [&](size_t count, std::vector<double> &z) {
+  void normals(size_t count, std::vector<double> &z) {
     z.assign(count, 0.0);
     const double two_pi = 6.283185307179586;
     for (size_t i = 0; i < count; i += 2) {
@@ -1092,18 +996,18 @@ static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit,
       z[i] = rho * cs;
       if (i + 1 < count) z[i + 1] = rho * sn;
     }
-  };
-  auto variance = [](const rl_initializer &it, double fan_in, double fan_out) {
+  }
+  static double variance(const rl_initializer &it, double fan_in, double fan_out) {
     switch (it.scale) {
       case RL_SCALE_CONSTANT: return it.value;
       case RL_SCALE_FAN_IN: return 1.0 / fan_in;
       case RL_SCALE_FAN_OUT: return 1.0 / fan_out;
       default: return 2.0 / (fan_in + fan_out);
     }
-  };
-  // one tensor of `rows` x `cols` elements (a bias: rows = out, cols = 1; fan_out = shape[0] either way,
+  }
+  // one tensor of `rows` x `cols` elements (a 1-D tensor: rows = its length, cols = 1; fan_out = shape[0] either way,
   // calculate_fan_in_and_fan_out, initializers.rs:90-103)
-  auto fill = [&](const rl_initializer &it, float *dst, uint64_t rows, uint64_t cols, double fan_in) {
+  void fill(const rl_initializer &it, float *dst, uint64_t rows, uint64_t cols, double fan_in) {
     const size_t count = (size_t)rows * cols;
     const double fan_out = (double)rows;
     if (it.kind == RL_INIT_ZEROS) {
@@ -1151,6 +1055,77 @@ static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit,
       for (uint64_t r = 0; r < rows; ++r)
         for (uint64_t c = 0; c < cols; ++c) dst[(size_t)r * cols + c] = (float)(wide ? a[(size_t)r * R + c] : a[(size_t)c * R + r]);
     }
+  }
+};
+
+// RnnWeights::new (seq/rnn/mod.rs:223-257: per layer W_ih [G H, layer input] from input_weights_init, W_hh [G H, H] from
+// hidden_weights_init, b_ih and b_hh [G H] from bias_init — 1-D tensors: fan_in 1, fan_out G H) + the MLP's Linear::new
+// layers (ff/linear.rs:54-68: kernel and bias with fan_in = in + 1), drawn in flat order from one stream.
+struct RnnInits {
+  rl_initializer input, hidden, bias, mlp_kernel, mlp_bias;
+};
+static RnnInits rnn_default_inits() {  // RnnBaseConfig::default (seq/rnn/mod.rs:36-45), LinearConfig::default
+  const rl_initializer glorot{RL_INIT_UNIFORM, RL_SCALE_FAN_AVG, 0.0}, ortho{RL_INIT_ORTHOGONAL, RL_SCALE_FAN_AVG, 0.0},
+      zeros{RL_INIT_ZEROS, RL_SCALE_FAN_AVG, 0.0};
+  return RnnInits{glorot, ortho, zeros, glorot, glorot};
+}
+static void rnn_mlp_init_host(const rl_mlp *m, uint64_t seed, const RnnInits &in, std::vector<float> &h) {
+  const uint64_t H = m->gru_hidden, D = m->in_dim, H2 = m->hidden, A = m->out_dim, R = rl_module_gates(m->kind) * H;
+  h.assign(m->P, 0.0f);
+  InitStream st(seed);
+  size_t k = 0;
+  for (uint32_t layer = 0; layer < m->rnn_layers; ++layer) {
+    const uint64_t K = layer == 0 ? D : H;
+    st.fill(in.input, h.data() + k, R, K, (double)K);
+    k += R * K;
+    st.fill(in.hidden, h.data() + k, R, H, (double)H);
+    k += R * H;
+    st.fill(in.bias, h.data() + k, R, 1, 1.0);
+    k += R;
+    st.fill(in.bias, h.data() + k, R, 1, 1.0);
+    k += R;
+  }
+  const uint64_t dims[2][2] = {{H, H2}, {H2, A}};
+  for (int l = 0; l < 2; ++l) {
+    const uint64_t fin = dims[l][0], fout = dims[l][1];
+    st.fill(in.mlp_kernel, h.data() + k, fout, fin, (double)(fin + 1));
+    k += fin * fout;
+    st.fill(in.mlp_bias, h.data() + k, fout, 1, (double)(fin + 1));
+    k += fout;
+  }
+}
+
+int32_t rl_mlp_destroy(rl_mlp *m) {
+  if (!m) return RL_OK;
+  (void)hipSetDevice(m->eng->device);
+  (void)hipStreamSynchronize(m->eng->stream);
+  dfree(m->d_params);
+  if (m->exec) {
+    dfree(m->exec->d_params);
+    delete m->exec;
+  }
+  dfree(m->x_tmp);
+  dfree(m->x_tan);
+  rl_engine *eng = m->eng;
+  delete m;
+  engine_release_child(eng);
+  return RL_OK;
+}
+
+int32_t rl_mlp_num_params(const rl_mlp *m, uint64_t *n) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m && n, "NULL argument");
+    *n = m->P;
+  });
+}
+
+// Linear::new for every layer of a feed-forward module (reference src/torch/modules/ff/linear.rs:54-68) with the given
+// initializers, drawn from the engine's stream (InitStream above) in flat parameter order (kernel then bias per layer)
+static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit, const rl_initializer &binit) {
+  std::vector<float> h(m->P);
+  InitStream st(seed);
+  auto fill = [&](const rl_initializer &it, float *dst, uint64_t rows, uint64_t cols, double fan_in) {
+    st.fill(it, dst, rows, cols, fan_in);
   };
   size_t k = 0;
   for (uint32_t l = 0; l < m->n_layers(); ++l) {
@@ -1170,7 +1145,7 @@ int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
     RL_REQUIRE(m, "mlp is NULL");
     if (rl_module_is_recurrent(m->kind)) {
       std::vector<float> hp;
-      gru_mlp_init_host(m, seed, hp);
+      rnn_mlp_init_host(m, seed, rnn_default_inits(), hp);
       h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
       return;
     }
@@ -1201,6 +1176,32 @@ int32_t rl_mlp_init_with(rl_mlp *m, uint64_t seed, const rl_initializer *kernel_
     if (bias_init && bias_init->kind == RL_INIT_ORTHOGONAL)  // init_orthogonal asserts shape.len() >= 2 (initializers.rs:331-334)
       throw RlError(RL_ERR_INVALID_ARGUMENT, "tensor for orthogonal init must be at least 2D: not a bias initializer");
     mlp_init_host(m, seed, *kernel_init, bias_init ? *bias_init : *kernel_init);
+  });
+}
+
+int32_t rl_rnn_mlp_init_with(rl_mlp *m, uint64_t seed, const rl_initializer *input_weights_init,
+                             const rl_initializer *hidden_weights_init, const rl_initializer *bias_init,
+                             const rl_initializer *mlp_kernel_init, const rl_initializer *mlp_bias_init) {
+  return guarded(m ? m->eng : nullptr, [&] {
+    RL_REQUIRE(m, "module is NULL");
+    if (!rl_module_is_recurrent(m->kind))
+      throw RlError(RL_ERR_INVALID_ARGUMENT, "rl_rnn_mlp_init_with: recurrent chains only (rl_mlp_init_with for MLPs)");
+    if (bias_init == nullptr || mlp_bias_init == nullptr)  // RnnBaseConfig::bias_init = None: has_biases = false
+      throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built with bias vectors: bias_init = None is not");
+    RL_REQUIRE(input_weights_init && hidden_weights_init && mlp_kernel_init, "NULL initializer");
+    for (const rl_initializer *i : {input_weights_init, hidden_weights_init, bias_init, mlp_kernel_init, mlp_bias_init}) {
+      RL_REQUIRE(i->kind >= RL_INIT_ZEROS && i->kind <= RL_INIT_ORTHOGONAL, "unknown initializer kind");
+      if (i->kind == RL_INIT_UNIFORM || i->kind == RL_INIT_NORMAL) {
+        RL_REQUIRE(i->scale >= RL_SCALE_CONSTANT && i->scale <= RL_SCALE_FAN_AVG, "unknown variance scale");
+        RL_REQUIRE(i->scale != RL_SCALE_CONSTANT || i->value >= 0.0, "a variance must not be negative");
+      }
+    }
+    if (bias_init->kind == RL_INIT_ORTHOGONAL || mlp_bias_init->kind == RL_INIT_ORTHOGONAL)  // initializers.rs:331-334
+      throw RlError(RL_ERR_INVALID_ARGUMENT, "tensor for orthogonal init must be at least 2D: not a bias initializer");
+    std::vector<float> hp;
+    rnn_mlp_init_host(m, seed, RnnInits{*input_weights_init, *hidden_weights_init, *bias_init, *mlp_kernel_init, *mlp_bias_init},
+                      hp);
+    h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
   });
 }
 

@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <optional>
 #include <vector>
 
 #include "../../../include/relearn_hip.h"
@@ -245,10 +246,26 @@ class Module {
 
 enum class Activation { Identity = RL_ACT_IDENTITY, Relu = RL_ACT_RELU, Sigmoid = RL_ACT_SIGMOID, Tanh = RL_ACT_TANH };
 
-struct MlpConfig {  // MlpConfig { hidden_sizes, activation, output_activation } (ff/mlp.rs:13-34)
+// Initializer / VarianceScale (src/torch/initializers.rs:8-64): the C ABI's rl_initializer with the reference's names
+struct Initializer {
+  rl_initializer raw;
+  static Initializer Zeros() { return {{RL_INIT_ZEROS, RL_SCALE_FAN_AVG, 0.0}}; }
+  static Initializer Constant(double v) { return {{RL_INIT_CONSTANT, RL_SCALE_FAN_AVG, v}}; }
+  static Initializer Uniform(int32_t scale = RL_SCALE_FAN_AVG, double variance = 0.0) { return {{RL_INIT_UNIFORM, scale, variance}}; }
+  static Initializer Normal(int32_t scale = RL_SCALE_FAN_AVG, double variance = 0.0) { return {{RL_INIT_NORMAL, scale, variance}}; }
+  static Initializer Orthogonal() { return {{RL_INIT_ORTHOGONAL, RL_SCALE_FAN_AVG, 0.0}}; }
+};
+
+struct LinearConfig {  // LinearConfig { kernel_init, bias_init } (ff/linear.rs:13-33); default: Uniform(FanAvg) both
+  Initializer kernel_init = Initializer::Uniform();
+  std::optional<Initializer> bias_init = Initializer::Uniform();  // nullopt: layers without a bias vector
+};
+
+struct MlpConfig {  // MlpConfig { hidden_sizes, activation, output_activation, linear_config } (ff/mlp.rs:13-34)
   std::vector<uint32_t> hidden_sizes{128};  // MlpConfig::default; any list of up to four widths <= 256 builds
   Activation activation = Activation::Relu;             // between the hidden layers (ff/activation.rs:11-27)
   Activation output_activation = Activation::Identity;  // on the output
+  LinearConfig linear_config;
   // width of the single hidden layer (the recurrent chains take exactly one)
   uint32_t single_hidden_size() const {
     if (hidden_sizes.size() != 1) throw BuildAgentError(RL_ERR_BUILD_AGENT, "the chain's MLP takes one hidden layer");
@@ -256,19 +273,23 @@ struct MlpConfig {  // MlpConfig { hidden_sizes, activation, output_activation }
   }
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_mlp_create_layers(eng.handle(), in_dim, hidden_sizes.data(), (uint32_t)hidden_sizes.size(), out_dim,
-                               (int32_t)activation, (int32_t)output_activation, &h),
+    check(rl_mlp_create_config(eng.handle(), in_dim, hidden_sizes.data(), (uint32_t)hidden_sizes.size(), out_dim,
+                               (int32_t)activation, (int32_t)output_activation, linear_config.bias_init ? 1 : 0, &h),
           eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
-    check(rl_mlp_init(h, seed), eng.handle());
+    check(rl_mlp_init_with(h, seed, &linear_config.kernel_init.raw,
+                           linear_config.bias_init ? &linear_config.bias_init->raw : nullptr),
+          eng.handle());
     return m;
   }
 };
 
-// RnnBaseConfig's shape field (seq/rnn/mod.rs:20-45; the initializers are the default's: Glorot-uniform input weights,
-// orthogonal hidden weights, zero biases)
+// RnnBaseConfig (seq/rnn/mod.rs:20-45): the layer count and the three initializers
 struct RnnBaseConfig {
   uint32_t num_layers = 1;  // stacked layers: 1..4
+  Initializer input_weights_init = Initializer::Uniform();     // RnnBaseConfig::default: Uniform(FanAvg)
+  Initializer hidden_weights_init = Initializer::Orthogonal();
+  std::optional<Initializer> bias_init = Initializer::Zeros();  // nullopt (no bias vectors) does not build
 };
 using GruConfig = RnnBaseConfig;
 using LstmConfig = RnnBaseConfig;
@@ -283,7 +304,11 @@ struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mo
                             second_config.single_hidden_size(), out_dim, &h),
           eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
-    check(rl_mlp_init(h, seed), eng.handle());
+    const LinearConfig &lc = second_config.linear_config;
+    check(rl_rnn_mlp_init_with(h, seed, &first_config.input_weights_init.raw, &first_config.hidden_weights_init.raw,
+                               first_config.bias_init ? &first_config.bias_init->raw : nullptr, &lc.kernel_init.raw,
+                               lc.bias_init ? &lc.bias_init->raw : nullptr),
+          eng.handle());
     return m;
   }
 };
@@ -305,7 +330,11 @@ struct ChainLstmMlpConfig {
                             second_config.single_hidden_size(), out_dim, &h),
           eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
-    check(rl_mlp_init(h, seed), eng.handle());
+    const LinearConfig &lc = second_config.linear_config;
+    check(rl_rnn_mlp_init_with(h, seed, &first_config.input_weights_init.raw, &first_config.hidden_weights_init.raw,
+                               first_config.bias_init ? &first_config.bias_init->raw : nullptr, &lc.kernel_init.raw,
+                               lc.bias_init ? &lc.bias_init->raw : nullptr),
+          eng.handle());
     return m;
   }
 };

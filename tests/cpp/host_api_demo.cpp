@@ -63,6 +63,27 @@ int main() {
       train_batched(*agent, env, history, 1, log);
       dump("ppo_gru", log, checksum(agent->policy_module().parameters()), checksum(agent->critic_module()->parameters()), false);
     }
+    {  // a stacked recurrent chain with RnnBaseConfig's fields spelled out: two GRU layers of 24 units, Normal(FanIn) input
+       // weights, an MLP head of 16 units with constant biases — through the same agent configuration
+      ChainLanes env(eng, 64, 100, StepLimit::Latent, 3, 4);
+      ActorCriticConfig<PpoConfig<GruMlpConfig>, ValuesOptConfig<GruMlpConfig>> cfg;
+      for (GruMlpConfig *c : {&cfg.policy_config.policy_fn_config, &cfg.critic_config.state_value_fn_config}) {
+        c->first_config.num_layers = 2;
+        c->first_config.input_weights_init = Initializer::Normal(RL_SCALE_FAN_IN);
+        c->hidden_dim = 24;
+        c->second_config.hidden_sizes = {16};
+        c->second_config.linear_config.bias_init = Initializer::Constant(0.125);
+      }
+      cfg.policy_config.opt_steps_per_update = 2;
+      cfg.critic_config.opt_steps_per_update = 2;
+      auto agent = cfg.build_agent(env, 15);
+      const uint64_t G = 3 * 24, want = G * 5 + G * 24 + 2 * G + G * 24 + G * 24 + 2 * G + 16 * 24 + 16 + 2 * 16 + 2;
+      if (agent->policy_module().num_parameters() != want) return 4;
+      DeviceHistory history = agent->buffer(20);
+      RecordingLogger log;
+      train_batched(*agent, env, history, 1, log);
+      dump("ppo_gru_stacked", log, checksum(agent->policy_module().parameters()), checksum(agent->critic_module()->parameters()), false);
+    }
     {  // PPO with the critic-free reward-to-go advantage on MemoryGame lanes; `LstmMlpConfig` as the reference defines it
       MemoryGameLanes env(eng, 64, 2, 3, 0, StepLimit::None, 5, 6);
       ActorCriticConfig<PpoConfig<LstmMlpConfig>, RewardToGoConfig> cfg;

@@ -284,3 +284,28 @@ def test_layer_counts_that_are_not_built_are_refused(engine):
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_BUILD_AGENT
     assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(1), C.c_uint32(9), C.c_uint32(32), C.c_uint32(2),
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_BUILD_AGENT
+
+
+def test_init_with_initializers(engine):
+    """rl_rnn_mlp_init_with: RnnBaseConfig { input_weights_init, hidden_weights_init, bias_init } and the chain MLP's
+    LinearConfig, against the oracle's stream bit for bit; bias_init = None and Orthogonal biases are refused"""
+    inits = (("Normal", "FanIn", 0.0), ("Uniform", "Constant", 0.25), ("Normal", "FanOut", 0.0), ("Orthogonal", "FanAvg", 0.0),
+             ("Constant", "FanAvg", 0.5))
+    for cell, NL in (("lstm", 2), ("gru", 1), ("gru", 3)):
+        cls = ra.GruMlp if cell == "gru" else ra.LstmMlp
+        m = cls(engine, 5, 2, 16, 8, num_layers=NL)
+        shape = O.GruShape(5, 16, 8, 2, O.CELL_GRU if cell == "gru" else O.CELL_LSTM)
+        m.init_with(7, *inits)
+        assert np.array_equal(m.get_params(), O.stack_init_with(shape, NL, 7, inits))
+        m.init_with(9)  # the defaults
+        assert np.array_equal(m.get_params(), O.stack_init(shape, NL, 9))
+        with pytest.raises(ra.RelearnError) as e:
+            m.init_with(7, bias=None)
+        assert e.value.code == ra.ERR_UNSUPPORTED
+        with pytest.raises(ra.RelearnError) as e:
+            m.init_with(7, bias=("Orthogonal", "FanAvg", 0.0))
+        assert e.value.code == ra.ERR_INVALID_ARGUMENT
+    with pytest.raises(ra.RelearnError):
+        ra.lib().rl_rnn_mlp_init_with  # (exported)
+        mlp = ra.Mlp(engine, 5, 32, 2)
+        ra._check(ra.lib().rl_rnn_mlp_init_with(mlp.h, C.c_uint64(1), None, None, None, None, None), engine.h)

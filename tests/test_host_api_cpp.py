@@ -87,6 +87,21 @@ def test_cpp_host_api_matches_the_ctypes_path(engine):
     g = out["ppo_gru"]
     assert g["policy_checksum"] == checksum(gp.get_params()) and g["critic_checksum"] == checksum(gc.get_params())
     assert g["scalars"]["policy/entropy"] == ps.entropy and g["scalars"]["critic/loss"] == gcs.loss_last
+    # ---- the same with a stacked chain and RnnBaseConfig's / LinearConfig's initializers spelled out
+    senv = ra.ChainEnv(engine, 64, max_steps=100, seed_env=3, seed_actor=4)
+    sp, sc = ra.GruMlp(engine, 5, 2, 24, 16, num_layers=2), ra.GruMlp(engine, 5, 1, 24, 16, num_layers=2)
+    kw = dict(input_weights=("Normal", "FanIn", 0.0), mlp_bias=("Constant", "FanAvg", 0.125))
+    sp.init_with(15, **kw)
+    sc.init_with(16, **kw)
+    spopt, scopt = ra.Adam(sp), ra.Adam(sc)
+    straj = ra.Trajectory(engine, 64, 20, 5)
+    ra.rollout(senv, sp, straj)
+    ra.gae(straj, sc, 0.95, 0.95)
+    sps = ra.ppo_update(sp, spopt, straj, cfg)
+    scs = ra.critic_update(sc, scopt, straj, 2)
+    g = out["ppo_gru_stacked"]
+    assert g["policy_checksum"] == checksum(sp.get_params()) and g["critic_checksum"] == checksum(sc.get_params())
+    assert g["scalars"]["policy/entropy"] == sps.entropy and g["scalars"]["critic/loss"] == scs.loss_last
     # ---- PPO + reward-to-go on MemoryGame lanes (discount factor 1.0: memory.rs:74-76)
     menv = ra.MemoryEnv(engine, 64, seed_env=5, seed_actor=6)
     mp = ra.GruMlp(engine, 5, 2)

@@ -100,3 +100,23 @@ def test_init_layers():
         assert np.allclose(w["Whh"].T @ w["Whh"], np.eye(16), atol=1e-6)
         assert not w["bih"].any() and not w["bhh"].any()
     assert head["W1"].any() and head["W2"].any()
+
+
+def test_init_with_initializers():
+    """RnnBaseConfig's initializers spelled out: the defaults reproduce oracle_stack_init bit for bit; other choices have
+    the statistics their variance scale prescribes (1-D biases: fan_in 1, fan_out = gate rows) and draw from one stream"""
+    shape = O.GruShape(5, 16, 8, 2, O.CELL_LSTM)
+    for L in (1, 3):
+        assert np.array_equal(O.stack_init_with(shape, L, 33), O.stack_init(shape, L, 33))
+    inits = (("Normal", "FanIn", 0.0), ("Uniform", "Constant", 0.25), ("Normal", "FanOut", 0.0), ("Orthogonal", "FanAvg", 0.0),
+             ("Constant", "FanAvg", 0.5))
+    p = O.stack_init_with(shape, 2, 7, inits)
+    spec = S.Spec(S.LSTM, 5, 16, 2, 8, 2)
+    layers, head = spec.unpack(p)
+    assert abs(layers[1]["Wih"].std() - np.sqrt(1.0 / 16)) < 0.03           # Normal, variance 1 / fan_in (16)
+    assert np.abs(layers[0]["Whh"]).max() <= np.sqrt(3 * 0.25) + 1e-6        # Uniform, variance 0.25
+    assert abs(layers[0]["Whh"].var() - 0.25) < 0.03
+    assert abs(layers[0]["bih"].std() - np.sqrt(1.0 / 64)) < 0.04            # Normal, variance 1 / fan_out (64 gate rows)
+    assert not np.array_equal(layers[0]["bih"], layers[0]["bhh"])
+    assert np.allclose(head["W1"] @ head["W1"].T, np.eye(8), atol=1e-6)      # wide [8, 16]: orthonormal rows
+    assert np.all(head["b1"] == 0.5) and np.all(head["b2"] == 0.5)
