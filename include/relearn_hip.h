@@ -294,7 +294,7 @@ int32_t rl_mlp_forward(rl_mlp *mlp, const float *rows, uint64_t n_rows, float *o
  * units stay exactly 0 and every real dot product only gains terms fma(0, 0, acc), so outputs, gradients and
  * Fisher-vector products are those of the narrow chain (forward bit-identical to the oracle's, tests/test_gpu_gru.py).
  * out_dim in {1, 2}; lanes in multiples of 32; trajectories of obs_dim = in_dim (rollouts need an env with five
- * observation features; narrower inputs come from rl_traj_write).  in_dim 6..8 and stacked layers
+ * observation features; narrower inputs come from rl_traj_write).  in_dim 6..8, widths 129..256 and stacked layers
  * (RnnBaseConfig::num_layers 2..4, rl_rnn_mlp_create) run the lane-per-thread kernels instead: see there.
  * rl_mlp_init: Glorot-uniform W_ih, orthogonal W_hh, zero biases (RnnBaseConfig::default), Linear::new for the MLP. */
 int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidden, uint32_t mlp_hidden,
@@ -308,12 +308,12 @@ int32_t rl_gru_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t gru_hidde
 int32_t rl_lstm_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t lstm_hidden, uint32_t mlp_hidden,
                            uint32_t out_dim, rl_mlp **out);
 /* Both chains with RnnBaseConfig's fields spelled out (seq/rnn/mod.rs:20-45: hidden_size, num_layers; the initializers
- * are RnnBaseConfig::default's): cell = RL_CELL_GRU | RL_CELL_LSTM; in_dim 1..8, hidden_size and mlp_hidden 1..128.
+ * are RnnBaseConfig::default's): cell = RL_CELL_GRU | RL_CELL_LSTM; in_dim 1..8, hidden_size and mlp_hidden 1..256.
  * num_layers 1..4 (0 -> RL_ERR_BUILD_AGENT, > 4 -> RL_ERR_UNSUPPORTED).  Stacked layers (num_layers > 1): flat order
  * per layer [W_ih, W_hh, b_ih, b_hh] (RnnWeights::new, seq/rnn/mod.rs:223-257) — layer 0 reads the in_dim features,
  * layer l > 0 the hidden output of layer l - 1 of the same step (Tensor::gru / ::lstm with num_layers, gru.rs:41-66),
  * no dropout — then the MLP's kernel/bias pairs; rl_mlp_init draws layer after layer from one stream; the actor
- * document holds 4 tensors per layer.  Stacked chains, and chains of in_dim 6..8, run general lane-per-thread kernels
+ * document holds 4 tensors per layer.  Stacked chains, chains of in_dim 6..8 and widths above 128 run general lane-per-thread kernels
  * at the module's own widths (kernels_seq_stack.hip: any lane count, one launch sequence per rollout step; the path for
  * shapes the fused 5 -> 128 -> 128 tile kernels do not cover, not a fast one).  Every entry point of the single-layer
  * chains applies: rl_rollout (two-action policies on either lane family), rl_seq_forward, rl_gae, rl_trpo_update,

@@ -902,10 +902,10 @@ static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t 
   if (num_layers == 0) throw RlError(RL_ERR_BUILD_AGENT, "RnnBaseConfig::num_layers must be at least 1");
   if (num_layers > RL_RNN_MAX_LAYERS)
     throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built for RnnBaseConfig::num_layers <= 4");
-  if (in_dim < 1 || in_dim > RL_TRAJ_MAX_OBS_DIM || rnn_hidden < 1 || rnn_hidden > 128 || mlp_hidden < 1 ||
-      mlp_hidden > 128 || !(out_dim == 1 || out_dim == 2))
+  if (in_dim < 1 || in_dim > RL_TRAJ_MAX_OBS_DIM || rnn_hidden < 1 || rnn_hidden > RL_MLP_MAX_WIDTH || mlp_hidden < 1 ||
+      mlp_hidden > RL_MLP_MAX_WIDTH || !(out_dim == 1 || out_dim == 2))
     throw RlError(RL_ERR_BUILD_AGENT,
-                  "supported recurrent chain shapes: in_dim 1..8, recurrent hidden 1..128, mlp_hidden 1..128, out_dim in {1,2}");
+                  "supported recurrent chain shapes: in_dim 1..8, recurrent hidden 1..256, mlp_hidden 1..256, out_dim in {1,2}");
   RL_HIP_CHECK(hipSetDevice(e->device));
   auto make = [&](uint32_t D, uint32_t H, uint32_t H2, uint32_t layers) {
     std::unique_ptr<rl_mlp> m(new rl_mlp());

@@ -206,9 +206,9 @@ struct rl_mlp {
   // per layer (layer l > 0 reads the hidden output of layer l - 1), then the head; such a module runs the lane-per-thread
   // kernels of kernels_seq_stack.hip at its own widths (no twin).
   uint32_t rnn_layers = 1;
-  // the lane-per-thread kernels run this recurrent module (stacked layers, or more input features than the fused tile
-  // kernels' five)
-  bool lane_kernels() const { return rnn_layers > 1 || in_dim > 5; }
+  // the lane-per-thread kernels run this recurrent module (stacked layers, more input features than the fused tile
+  // kernels' five, or widths above their 128)
+  bool lane_kernels() const { return rnn_layers > 1 || in_dim > 5 || gru_hidden > 128 || hidden > 128; }
   uint64_t rnn_layer_offset(uint32_t l) const {  // W_ih of layer l; l == rnn_layers: the head's W1
     const uint64_t GH = (kind == RL_MODULE_LSTM_MLP ? 4 : 3) * (uint64_t)gru_hidden;
     if (l == 0) return 0;

@@ -557,7 +557,7 @@ def test_recurrent_shapes_that_are_not_built_are_refused(engine):
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_UNSUPPORTED  # num_layers = 5
     assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(0), C.c_uint32(5), C.c_uint32(32), C.c_uint32(0),
                                       C.c_uint32(32), C.c_uint32(2), C.byref(h)) == ra.ERR_BUILD_AGENT
-    for bad in ((9, 32, 32, 2), (5, 129, 32, 2), (5, 32, 200, 2), (5, 32, 32, 3), (0, 4, 4, 1)):
+    for bad in ((9, 32, 32, 2), (5, 257, 32, 2), (5, 32, 300, 2), (5, 32, 32, 3), (0, 4, 4, 1)):
         assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(1), C.c_uint32(bad[0]), C.c_uint32(bad[1]), C.c_uint32(1),
                                           C.c_uint32(bad[2]), C.c_uint32(bad[3]), C.byref(h)) == ra.ERR_BUILD_AGENT
     assert ra.lib().rl_rnn_mlp_create(engine.h, C.c_int32(1), C.c_uint32(4), C.c_uint32(7), C.c_uint32(1), C.c_uint32(9),

@@ -25,8 +25,8 @@ def test_lstm_init_bit_exact(engine):
         assert m.P == L.oracle_gru_num_params(shape) == 4 * 128 * 5 + 4 * 128 * 128 + 8 * 128 + 128 * 128 + 128 + \
             shape.out_dim * 128 + shape.out_dim
         assert np.array_equal(m.get_params(), O.gru_init(shape, seed))
-    with pytest.raises(ra.RelearnError) as e:  # (narrower chains are built since round 4: tests/test_gpu_gru.py)
-        ra.LstmMlp(engine, 5, 2, lstm_hidden=129)
+    with pytest.raises(ra.RelearnError) as e:  # (other widths are built since round 4: tests/test_gpu_gru.py, test_gpu_stacked.py)
+        ra.LstmMlp(engine, 5, 2, lstm_hidden=257)
     assert e.value.code == ra.ERR_BUILD_AGENT
 
 

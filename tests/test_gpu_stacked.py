@@ -21,7 +21,9 @@ L = O.lib()
 SHAPES = [("gru", 5, 32, 2, 16, 2), ("lstm", 3, 18, 3, 10, 1), ("gru", 2, 7, 4, 5, 1), ("lstm", 5, 64, 2, 33, 2),
           ("gru", 5, 128, 2, 128, 2),
           # more input features than the fused tile kernels' five: the same lane-per-thread kernels, one layer or several
-          ("gru", 7, 12, 1, 8, 2), ("lstm", 8, 16, 2, 8, 1)]
+          ("gru", 7, 12, 1, 8, 2), ("lstm", 8, 16, 2, 8, 1),
+          # wider than the fused kernels' 128
+          ("gru", 5, 160, 1, 130, 2), ("lstm", 4, 132, 2, 40, 1)]
 GRAD_RTOL = 5e-6
 
 
