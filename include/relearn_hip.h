@@ -229,7 +229,8 @@ typedef enum {
 } rl_activation;
 /* MlpConfig { hidden_sizes, activation, output_activation, .. } (src/torch/modules/ff/mlp.rs:13-34,139-151): in_dim ->
  * hidden_sizes[0] -> ... -> out_dim with `activation` after every hidden layer and `output_activation` on the output;
- * parameters flat as [W, b] per layer in layer order.  `n_hidden` in [0, 4], every width in [1, 256], in_dim in {4, 5},
+ * parameters flat as [W, b] per layer in layer order.  `n_hidden` in [0, 4], every width in [1, 256], in_dim in [1, 8]
+ * (the envs of this library have 4 or 5 features: other widths work on host-made histories, rl_traj_write),
  * out_dim in {1, 2}, activations from rl_activation; anything else -> RL_ERR_BUILD_AGENT.  One hidden layer of at most
  * 128 units with the reference's defaults (Relu, Identity) is rl_mlp_create — the fused kernels every BASELINE
  * configuration runs on, which are built for exactly that; any other shape or activation runs per-layer kernels

@@ -843,15 +843,16 @@ static int32_t mlp_create_config(rl_engine *e, uint32_t in_dim, const uint32_t *
                                  rl_mlp **out) {
   // one hidden layer of at most 128 units, Relu inside and Identity on the output, with biases: the fused kernels
   if (has_bias && e && out && hidden_sizes && n_hidden == 1 && hidden_sizes[0] <= 128 && activation == RL_ACT_RELU &&
-      output_activation == RL_ACT_IDENTITY)
+      output_activation == RL_ACT_IDENTITY && (in_dim == 4 || in_dim == 5))
     return rl_mlp_create(e, in_dim, hidden_sizes[0], out_dim, out);
   return guarded(e, [&] {
     RL_REQUIRE(e && out && (hidden_sizes || n_hidden == 0), "NULL argument");
     *out = nullptr;
-    bool ok = (in_dim == 4 || in_dim == 5) && (out_dim == 1 || out_dim == 2) && n_hidden <= RL_MLP_MAX_HIDDEN;
+    // (the envs of this library have 4 or 5 features; other widths serve host-made histories: rl_traj_write)
+    bool ok = in_dim >= 1 && in_dim <= RL_TRAJ_MAX_OBS_DIM && (out_dim == 1 || out_dim == 2) && n_hidden <= RL_MLP_MAX_HIDDEN;
     for (uint32_t l = 0; ok && l < n_hidden; ++l) ok = hidden_sizes[l] >= 1 && hidden_sizes[l] <= RL_MLP_MAX_WIDTH;
     if (!ok)
-      throw RlError(RL_ERR_BUILD_AGENT, "supported MLP shapes: in_dim in {4,5}, at most 4 hidden layers of 1..256 units, "
+      throw RlError(RL_ERR_BUILD_AGENT, "supported MLP shapes: in_dim 1..8, at most 4 hidden layers of 1..256 units, "
                                         "out_dim in {1,2}");
     if (activation < RL_ACT_IDENTITY || activation > RL_ACT_TANH || output_activation < RL_ACT_IDENTITY ||
         output_activation > RL_ACT_TANH)

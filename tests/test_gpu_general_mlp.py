@@ -166,10 +166,53 @@ def test_unsupported_shapes_are_refused(engine):
     for hidden in ([300], [8] * 5, [0]):
         with pytest.raises(ra.RelearnError):
             ra.Mlp(engine, 5, hidden, 2)
+    for in_dim in (0, 9):
+        with pytest.raises(ra.RelearnError):
+            ra.Mlp(engine, in_dim, [32, 32], 2)
     q = ra.GruMlp(engine, 5, 2)
     env = ra.CartPoleEnv(engine, 64)
     with pytest.raises(ra.RelearnError):  # DQN: feed-forward action-value modules only
         ra.Dqn(env, q, ra.Adam(q), ra.dqn_config_default())
+
+
+@pytest.mark.parametrize("in_dim,hidden,n,T", [(3, [16, 16], 70, 9), (7, [32], 64, 6), (8, [130], 33, 5), (1, [], 96, 4),
+                                               (6, [64, 64], 128, 8)])
+def test_other_input_widths_on_host_made_histories(engine, in_dim, hidden, n, T):
+    """MlpConfig modules of in_dim 1..8 (the envs here have 4 or 5 features: the observations come from rl_traj_write):
+    values / GAE, the surrogate and critic gradients and a Fisher-vector product against the f64 NumPy network — the
+    matrix-pipe launch takes up to seven inputs, the per-layer kernels any"""
+    rng = np.random.default_rng(in_dim * 31 + len(hidden))
+    pol, cri = make(engine, in_dim, hidden, 2, 21), make(engine, in_dim, hidden, 1, 22)
+    want = {"obs": rng.normal(size=(in_dim, T + 1, n)).astype(np.float32),
+            "flag": rng.choice(np.array([0, 0, 0, 1, 2], dtype=np.uint8), size=(T, n)),
+            "term_obs": rng.normal(size=(in_dim, T, n)).astype(np.float32),
+            "action": rng.integers(0, 2, size=(T, n)).astype(np.uint8),
+            "reward": rng.normal(size=(T, n)).astype(np.float32)}
+    traj = ra.Trajectory(engine, n, T, in_dim)
+    traj.write_all(want)
+    B = n * T
+    x = want["obs"][:, :T, :].reshape(in_dim, B).T
+    cnet, pnet = unflatten(cri.get_params(), in_dim, hidden, 1), unflatten(pol.get_params(), in_dim, hidden, 2)
+    ra.gae(traj, cri, 0.99, 0.95)
+    v = forward64(cnet, x)[0][:, 0]
+    assert np.allclose(traj.read(ra.TRAJ_VALUES)[:T].reshape(-1), v, rtol=2e-5, atol=2e-6)
+    adv, rtg = traj.read(ra.TRAJ_ADVANTAGES).reshape(-1), traj.read(ra.TRAJ_RETURNS).reshape(-1)
+    z, acts = forward64(pnet, x)
+    lp = z - np.log(np.exp(z - z.max(axis=1, keepdims=True)).sum(axis=1, keepdims=True)) - z.max(axis=1, keepdims=True)
+    p = np.exp(lp)
+    onehot = np.eye(2)[want["action"].reshape(-1).astype(np.int64)]
+    gwant = backward64(pnet, x, acts, -(adv[:, None].astype(np.float64)) * (onehot - p) / B)
+    got = ra.policy_gradient(pol, traj)[0]
+    assert got.shape == gwant.shape and np.abs(got - gwant).max() <= 2e-5 * np.abs(gwant).max() + 1e-9
+    _, cacts = forward64(cnet, x)
+    cwant = backward64(cnet, x, cacts, (2.0 * (v - rtg.astype(np.float64)) / B)[:, None])
+    assert np.abs(ra.critic_gradient(cri, traj)[0] - cwant).max() <= 2e-5 * np.abs(cwant).max() + 1e-9
+    vec = rng.normal(size=pol.P).astype(np.float32)
+    _, tz = jvp64(pnet, unflatten(vec, in_dim, hidden, 2), x)
+    fwant = backward64(pnet, x, acts, p * (tz - (p * tz).sum(axis=1, keepdims=True)) / B) + 1e-5 * vec.astype(np.float64)
+    assert np.abs(ra.policy_fvp(pol, traj, vec, 1e-5) - fwant).max() <= 5e-5 * np.abs(fwant).max() + 1e-9
+    st, losses = ra.critic_update(cri, ra.Adam(cri), traj, 3, want_losses=True)
+    assert losses[-1] < losses[0]
 
 
 def collect(engine, pol, n=96, T=12, seed=3):
