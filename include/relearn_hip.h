@@ -274,8 +274,10 @@ int32_t rl_mlp_init_with(rl_mlp *mlp, uint64_t seed, const rl_initializer *kerne
  * hidden_weights_init, b_ih and b_hh from bias_init — 1-D tensors: fan_in 1, fan_out = gate rows) and the chain's
  * MlpConfig::linear_config { kernel_init, bias_init } (fan_in = in + 1), layer after layer from the same stream.
  * rl_mlp_init(m, seed) on a recurrent chain = (Uniform(FanAvg), Orthogonal, Zeros; Uniform(FanAvg) x 2), the defaults.
- * bias_init NULL (RnnBaseConfig::bias_init = None: weights without bias vectors) -> RL_ERR_UNSUPPORTED; Orthogonal on a
- * bias -> RL_ERR_INVALID_ARGUMENT (init_orthogonal asserts two dimensions, initializers.rs:331-334). */
+ * bias_init NULL <=> the module was built without recurrent bias vectors (rl_rnn_mlp_create_config, bias = 0:
+ * RnnBaseConfig::bias_init = None); a mismatch -> RL_ERR_INVALID_ARGUMENT; mlp_bias_init NULL -> RL_ERR_UNSUPPORTED (the
+ * chain's MLP is built with bias vectors); Orthogonal on a bias -> RL_ERR_INVALID_ARGUMENT (init_orthogonal asserts two
+ * dimensions, initializers.rs:331-334). */
 int32_t rl_rnn_mlp_init_with(rl_mlp *module, uint64_t seed, const rl_initializer *input_weights_init,
                              const rl_initializer *hidden_weights_init, const rl_initializer *bias_init,
                              const rl_initializer *mlp_kernel_init, const rl_initializer *mlp_bias_init);
@@ -324,6 +326,15 @@ int32_t rl_lstm_mlp_create(rl_engine *engine, uint32_t in_dim, uint32_t lstm_hid
 enum { RL_CELL_GRU = 0, RL_CELL_LSTM = 1 };
 int32_t rl_rnn_mlp_create(rl_engine *engine, int32_t cell, uint32_t in_dim, uint32_t hidden_size, uint32_t num_layers,
                           uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out);
+/* The same with RnnBaseConfig::bias_init's choice of bias vectors (Option<Initializer>, seq/rnn/mod.rs:20-45,246-251):
+ * bias = 0 builds the recurrent layers WITHOUT b_ih / b_hh (RnnWeights::has_biases = false) — flat order per layer
+ * [W_ih, W_hh], then the MLP's kernel/bias pairs (the chain's MLP keeps its own LinearConfig); actor documents carry
+ * `has_biases: false` and two tensors per layer; rl_mlp_init draws the weights only; rl_rnn_mlp_init_with takes
+ * bias_init = NULL.  Such a module runs the lane-per-thread kernels (the gate rows start from zeros kept behind the
+ * parameters); outputs are bit-identical to those of the same module with zero bias vectors, gradients are that module's
+ * without the bias entries. */
+int32_t rl_rnn_mlp_create_config(rl_engine *engine, int32_t cell, uint32_t in_dim, uint32_t hidden_size,
+                                 uint32_t num_layers, int32_t bias, uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out);
 
 /* ---------------------------------------------------------------------------------------------
  * Trajectory store (replaces VecBuffer + LazyHistoryFeatures: src/agents/buffers/vec.rs:15-143,

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "rl_env_observe", "rl_env_step", "rl_env_upload_actions", "rl_env_step_resident", "rl_env_get_state",
     "rl_env_set_state",
     "rl_mlp_create", "rl_mlp_create_layers", "rl_mlp_create_config", "rl_mlp_destroy", "rl_mlp_num_params", "rl_mlp_init", "rl_mlp_init_with", "rl_params_get", "rl_params_set",
-    "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_rnn_mlp_create", "rl_rnn_mlp_init_with", "rl_seq_forward",
+    "rl_mlp_forward", "rl_gru_mlp_create", "rl_lstm_mlp_create", "rl_rnn_mlp_create", "rl_rnn_mlp_create_config", "rl_rnn_mlp_init_with", "rl_seq_forward",
     "rl_traj_create", "rl_traj_destroy", "rl_traj_field_bytes", "rl_traj_read", "rl_traj_write",
     "rl_rollout", "rl_gae",
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
@@ -457,13 +457,14 @@ class GruMlp(_Handle):
 
     CELL = 0  # RL_CELL_GRU
 
-    def __init__(self, engine, in_dim, out_dim, gru_hidden=128, mlp_hidden=128, num_layers=1):
-        """num_layers: RnnBaseConfig::num_layers (stacked layers, 1..4)"""
+    def __init__(self, engine, in_dim, out_dim, gru_hidden=128, mlp_hidden=128, num_layers=1, rnn_bias=True):
+        """num_layers: RnnBaseConfig::num_layers (stacked layers, 1..4); rnn_bias False: RnnBaseConfig::bias_init = None
+        (recurrent layers without bias vectors)"""
         self.eng = engine
         self.h = C.c_void_p()
-        _check(lib().rl_rnn_mlp_create(engine.h, C.c_int32(self.CELL), C.c_uint32(in_dim), C.c_uint32(gru_hidden),
-                                       C.c_uint32(num_layers), C.c_uint32(mlp_hidden), C.c_uint32(out_dim),
-                                       C.byref(self.h)), engine.h)
+        _check(lib().rl_rnn_mlp_create_config(engine.h, C.c_int32(self.CELL), C.c_uint32(in_dim), C.c_uint32(gru_hidden),
+                                              C.c_uint32(num_layers), C.c_int32(1 if rnn_bias else 0),
+                                              C.c_uint32(mlp_hidden), C.c_uint32(out_dim), C.byref(self.h)), engine.h)
         _register(self)
         n = C.c_uint64()
         _check(lib().rl_mlp_num_params(self.h, C.byref(n)), engine.h)
@@ -496,8 +497,8 @@ class LstmMlp(GruMlp):
 
     CELL = 1  # RL_CELL_LSTM
 
-    def __init__(self, engine, in_dim, out_dim, lstm_hidden=128, mlp_hidden=128, num_layers=1):
-        GruMlp.__init__(self, engine, in_dim, out_dim, lstm_hidden, mlp_hidden, num_layers)
+    def __init__(self, engine, in_dim, out_dim, lstm_hidden=128, mlp_hidden=128, num_layers=1, rnn_bias=True):
+        GruMlp.__init__(self, engine, in_dim, out_dim, lstm_hidden, mlp_hidden, num_layers, rnn_bias)
 
 
 ACTIVATIONS = ["Identity", "Relu", "Sigmoid", "Tanh"]  # rl_activation, in the reference enum's order

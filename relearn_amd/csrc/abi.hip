@@ -897,7 +897,7 @@ int32_t rl_mlp_create_config(rl_engine *e, uint32_t in_dim, const uint32_t *hidd
 // (rl_mlp::exec).  num_layers in 2..4 (stacked layers): the lane-per-thread kernels of kernels_seq_stack.hip at the
 // module's own widths.
 static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t rnn_hidden, uint32_t num_layers,
-                              uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out) {
+                              uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out, bool rnn_bias = true) {
   RL_REQUIRE(e && out, "NULL argument");
   *out = nullptr;
   if (num_layers == 0) throw RlError(RL_ERR_BUILD_AGENT, "RnnBaseConfig::num_layers must be at least 1");
@@ -908,7 +908,7 @@ static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t 
     throw RlError(RL_ERR_BUILD_AGENT,
                   "supported recurrent chain shapes: in_dim 1..8, recurrent hidden 1..256, mlp_hidden 1..256, out_dim in {1,2}");
   RL_HIP_CHECK(hipSetDevice(e->device));
-  auto make = [&](uint32_t D, uint32_t H, uint32_t H2, uint32_t layers) {
+  auto make = [&](uint32_t D, uint32_t H, uint32_t H2, uint32_t layers, bool bias) {
     std::unique_ptr<rl_mlp> m(new rl_mlp());
     m->eng = e;
     m->kind = kind;
@@ -918,16 +918,19 @@ static void seq_module_create(rl_engine *e, int kind, uint32_t in_dim, uint32_t 
     m->out_dim = out_dim;
     const uint64_t A = out_dim;
     m->rnn_layers = layers;
+    m->has_bias = bias;  // of the recurrent weights (RnnBaseConfig::bias_init); the chain's MLP always has its own
     m->P = m->rnn_layer_offset(m->rnn_layers) + (uint64_t)H2 * H + H2 + A * H2 + A;
-    m->d_params = dalloc<float>(m->P);
-    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, m->P * sizeof(float), e->stream));
+    // (bias-less recurrent weights: the gate rows start from zeros kept behind the parameters)
+    const size_t alloc = m->P + (m->has_bias ? 0 : 4 * RL_MLP_MAX_WIDTH);
+    m->d_params = dalloc<float>(alloc);
+    RL_HIP_CHECK(hipMemsetAsync(m->d_params, 0, alloc * sizeof(float), e->stream));
     return m;
   };
-  std::unique_ptr<rl_mlp> m = make(in_dim, rnn_hidden, mlp_hidden, num_layers);
+  std::unique_ptr<rl_mlp> m = make(in_dim, rnn_hidden, mlp_hidden, num_layers, rnn_bias);
   if (!m->lane_kernels() && (in_dim != 5 || rnn_hidden != 128 || mlp_hidden != 128)) {
     std::unique_ptr<rl_mlp> x;
     try {
-      x = make(5, 128, 128, 1);  // every padding entry stays 0 for the life of the module
+      x = make(5, 128, 128, 1, true);  // every padding entry stays 0 for the life of the module
       m->x_tmp = dalloc<float>(x->P);
       m->x_tan = dalloc<float>(x->P);
       RL_HIP_CHECK(hipMemsetAsync(m->x_tan, 0, x->P * sizeof(float), e->stream));
@@ -968,6 +971,15 @@ int32_t rl_rnn_mlp_create(rl_engine *e, int32_t cell, uint32_t in_dim, uint32_t 
     if (cell != RL_CELL_GRU && cell != RL_CELL_LSTM) throw RlError(RL_ERR_BUILD_AGENT, "unknown recurrent cell");
     seq_module_create(e, cell == RL_CELL_GRU ? RL_MODULE_GRU_MLP : RL_MODULE_LSTM_MLP, in_dim, hidden_size, num_layers,
                       mlp_hidden, out_dim, out);
+  });
+}
+
+int32_t rl_rnn_mlp_create_config(rl_engine *e, int32_t cell, uint32_t in_dim, uint32_t hidden_size, uint32_t num_layers,
+                                 int32_t bias, uint32_t mlp_hidden, uint32_t out_dim, rl_mlp **out) {
+  return guarded(e, [&] {
+    if (cell != RL_CELL_GRU && cell != RL_CELL_LSTM) throw RlError(RL_ERR_BUILD_AGENT, "unknown recurrent cell");
+    seq_module_create(e, cell == RL_CELL_GRU ? RL_MODULE_GRU_MLP : RL_MODULE_LSTM_MLP, in_dim, hidden_size, num_layers,
+                      mlp_hidden, out_dim, out, bias != 0);
   });
 }
 
@@ -1081,10 +1093,12 @@ static void rnn_mlp_init_host(const rl_mlp *m, uint64_t seed, const RnnInits &in
     k += R * K;
     st.fill(in.hidden, h.data() + k, R, H, (double)H);
     k += R * H;
-    st.fill(in.bias, h.data() + k, R, 1, 1.0);
-    k += R;
-    st.fill(in.bias, h.data() + k, R, 1, 1.0);
-    k += R;
+    if (m->has_bias) {  // (RnnBaseConfig::bias_init = None: no tensors, no draws — seq/rnn/mod.rs:246-251)
+      st.fill(in.bias, h.data() + k, R, 1, 1.0);
+      k += R;
+      st.fill(in.bias, h.data() + k, R, 1, 1.0);
+      k += R;
+    }
   }
   const uint64_t dims[2][2] = {{H, H2}, {H2, A}};
   for (int l = 0; l < 2; ++l) {
@@ -1187,20 +1201,27 @@ int32_t rl_rnn_mlp_init_with(rl_mlp *m, uint64_t seed, const rl_initializer *inp
     RL_REQUIRE(m, "module is NULL");
     if (!rl_module_is_recurrent(m->kind))
       throw RlError(RL_ERR_INVALID_ARGUMENT, "rl_rnn_mlp_init_with: recurrent chains only (rl_mlp_init_with for MLPs)");
-    if (bias_init == nullptr || mlp_bias_init == nullptr)  // RnnBaseConfig::bias_init = None: has_biases = false
-      throw RlError(RL_ERR_UNSUPPORTED, "recurrent chains are built with bias vectors: bias_init = None is not");
+    // RnnBaseConfig::bias_init = None <=> the module was built without recurrent bias vectors (rl_rnn_mlp_create_config)
+    if ((bias_init == nullptr) != !m->has_bias)
+      throw RlError(RL_ERR_INVALID_ARGUMENT, m->has_bias ? "this module has recurrent bias vectors: bias_init must be given "
+                                                           "(rl_rnn_mlp_create_config(..., bias = 0, ...) builds it without)"
+                                                         : "this module has no recurrent bias vectors: bias_init must be NULL");
+    if (mlp_bias_init == nullptr)
+      throw RlError(RL_ERR_UNSUPPORTED, "the chain's MLP is built with bias vectors: its bias_init = None is not");
     RL_REQUIRE(input_weights_init && hidden_weights_init && mlp_kernel_init, "NULL initializer");
     for (const rl_initializer *i : {input_weights_init, hidden_weights_init, bias_init, mlp_kernel_init, mlp_bias_init}) {
+      if (i == nullptr) continue;
       RL_REQUIRE(i->kind >= RL_INIT_ZEROS && i->kind <= RL_INIT_ORTHOGONAL, "unknown initializer kind");
       if (i->kind == RL_INIT_UNIFORM || i->kind == RL_INIT_NORMAL) {
         RL_REQUIRE(i->scale >= RL_SCALE_CONSTANT && i->scale <= RL_SCALE_FAN_AVG, "unknown variance scale");
         RL_REQUIRE(i->scale != RL_SCALE_CONSTANT || i->value >= 0.0, "a variance must not be negative");
       }
     }
-    if (bias_init->kind == RL_INIT_ORTHOGONAL || mlp_bias_init->kind == RL_INIT_ORTHOGONAL)  // initializers.rs:331-334
+    if ((bias_init && bias_init->kind == RL_INIT_ORTHOGONAL) || mlp_bias_init->kind == RL_INIT_ORTHOGONAL)  // initializers.rs:331-334
       throw RlError(RL_ERR_INVALID_ARGUMENT, "tensor for orthogonal init must be at least 2D: not a bias initializer");
     std::vector<float> hp;
-    rnn_mlp_init_host(m, seed, RnnInits{*input_weights_init, *hidden_weights_init, *bias_init, *mlp_kernel_init, *mlp_bias_init},
+    rnn_mlp_init_host(m, seed, RnnInits{*input_weights_init, *hidden_weights_init, bias_init ? *bias_init : *mlp_bias_init,
+                                        *mlp_kernel_init, *mlp_bias_init},
                       hp);
     h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
   });

@@ -141,7 +141,7 @@ static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<floa
   w.key("weights");
   w.map(2);  // RnnWeights { flat_weights, has_biases } (seq/rnn/mod.rs:186-191)
   w.key("flat_weights");
-  w.array(4 * m->rnn_layers);  // per layer [w_ih, w_hh, b_ih, b_hh] (seq/rnn/mod.rs:223-257)
+  w.array((m->has_bias ? 4 : 2) * m->rnn_layers);  // per layer [w_ih, w_hh (, b_ih, b_hh)] (seq/rnn/mod.rs:223-257)
   const float *q = p.data();
   for (uint32_t l = 0; l < m->rnn_layers; ++l) {
     const int64_t K = l == 0 ? D : H;
@@ -149,13 +149,15 @@ static void cbor_module(cbor::Writer &w, const rl_mlp *m, const std::vector<floa
     q += GHR * K;
     cbor_tensor(w, q, {GHR, H});
     q += GHR * H;
-    cbor_tensor(w, q, {GHR});
-    q += GHR;
-    cbor_tensor(w, q, {GHR});
-    q += GHR;
+    if (m->has_bias) {
+      cbor_tensor(w, q, {GHR});
+      q += GHR;
+      cbor_tensor(w, q, {GHR});
+      q += GHR;
+    }
   }
   w.key("has_biases");
-  w.boolean(true);
+  w.boolean(m->has_bias);
   w.key("hidden_size");
   w.uint((uint64_t)H);
   w.key("dropout");
@@ -283,21 +285,25 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
       RL_REQUIRE(rnn.at("hidden_size").as_int() == H, "CBOR module: GRU hidden size mismatch");
       RL_REQUIRE(rnn.at("dropout").as_float() == 0.0, "CBOR module: dropout is not built");
       const cbor::Value &wts = rnn.at("weights");
-      RL_REQUIRE(wts.at("has_biases").kind == cbor::Value::BOOL && wts.at("has_biases").b, "CBOR module: GRU biases required");
+      RL_REQUIRE(wts.at("has_biases").kind == cbor::Value::BOOL && wts.at("has_biases").b == module->has_bias,
+                 "CBOR module: has_biases does not match the module");
       const cbor::Value &fw = wts.at("flat_weights");
-      RL_REQUIRE(fw.kind == cbor::Value::ARRAY && fw.items.size() == (size_t)4 * module->rnn_layers,
+      const size_t per = module->has_bias ? 4 : 2;
+      RL_REQUIRE(fw.kind == cbor::Value::ARRAY && fw.items.size() == per * module->rnn_layers,
                  "CBOR module: the recurrent layer count does not match the module");
       float *q = p.data();
       for (uint32_t l = 0; l < module->rnn_layers; ++l) {
         const int64_t K = l == 0 ? D : H;
-        cbor_read_tensor(*fw.items[4 * l + 0], {GHR, K}, q);
+        cbor_read_tensor(*fw.items[per * l + 0], {GHR, K}, q);
         q += GHR * K;
-        cbor_read_tensor(*fw.items[4 * l + 1], {GHR, H}, q);
+        cbor_read_tensor(*fw.items[per * l + 1], {GHR, H}, q);
         q += GHR * H;
-        cbor_read_tensor(*fw.items[4 * l + 2], {GHR}, q);
-        q += GHR;
-        cbor_read_tensor(*fw.items[4 * l + 3], {GHR}, q);
-        q += GHR;
+        if (module->has_bias) {
+          cbor_read_tensor(*fw.items[per * l + 2], {GHR}, q);
+          q += GHR;
+          cbor_read_tensor(*fw.items[per * l + 3], {GHR}, q);
+          q += GHR;
+        }
       }
       end = cbor_read_mlp(mod.at("second"), H, module->hidden, module->out_dim, q);
     }

@@ -208,11 +208,13 @@ struct rl_mlp {
   uint32_t rnn_layers = 1;
   // the lane-per-thread kernels run this recurrent module (stacked layers, more input features than the fused tile
   // kernels' five, or widths above their 128)
-  bool lane_kernels() const { return rnn_layers > 1 || in_dim > 5 || gru_hidden > 128 || hidden > 128; }
+  // (or recurrent weights without bias vectors, RnnBaseConfig::bias_init = None: `has_bias` false — the gate rows then
+  // start from 4 x 256 zeros kept behind the P parameters, like the bias-less MLP layers; the chain's MLP keeps its own)
+  bool lane_kernels() const { return rnn_layers > 1 || in_dim > 5 || gru_hidden > 128 || hidden > 128 || !has_bias; }
   uint64_t rnn_layer_offset(uint32_t l) const {  // W_ih of layer l; l == rnn_layers: the head's W1
-    const uint64_t GH = (kind == RL_MODULE_LSTM_MLP ? 4 : 3) * (uint64_t)gru_hidden;
+    const uint64_t GH = (kind == RL_MODULE_LSTM_MLP ? 4 : 3) * (uint64_t)gru_hidden, nb = has_bias ? 2 * GH : 0;
     if (l == 0) return 0;
-    return GH * (in_dim + gru_hidden) + 2 * GH + (uint64_t)(l - 1) * (GH * 2 * gru_hidden + 2 * GH);
+    return GH * (in_dim + gru_hidden) + nb + (uint64_t)(l - 1) * (GH * 2 * gru_hidden + nb);
   }
   // MlpConfig::hidden_sizes (ff/mlp.rs:13-34).  `general`: a shape the fused single-hidden-layer kernels do not cover
   // (no hidden layer, several, or one wider than 128) — it runs the per-layer kernels of kernels_general.hip; then

@@ -289,7 +289,7 @@ struct RnnBaseConfig {
   uint32_t num_layers = 1;  // stacked layers: 1..4
   Initializer input_weights_init = Initializer::Uniform();     // RnnBaseConfig::default: Uniform(FanAvg)
   Initializer hidden_weights_init = Initializer::Orthogonal();
-  std::optional<Initializer> bias_init = Initializer::Zeros();  // nullopt (no bias vectors) does not build
+  std::optional<Initializer> bias_init = Initializer::Zeros();  // nullopt: recurrent layers without bias vectors
 };
 using GruConfig = RnnBaseConfig;
 using LstmConfig = RnnBaseConfig;
@@ -300,8 +300,8 @@ struct GruMlpConfig {  // ChainConfig<GruConfig, MlpConfig>::default (modules/mo
   MlpConfig second_config;
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_rnn_mlp_create(eng.handle(), RL_CELL_GRU, in_dim, hidden_dim, first_config.num_layers,
-                            second_config.single_hidden_size(), out_dim, &h),
+    check(rl_rnn_mlp_create_config(eng.handle(), RL_CELL_GRU, in_dim, hidden_dim, first_config.num_layers,
+                                   first_config.bias_init ? 1 : 0, second_config.single_hidden_size(), out_dim, &h),
           eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     const LinearConfig &lc = second_config.linear_config;
@@ -326,8 +326,8 @@ struct ChainLstmMlpConfig {
   MlpConfig second_config;
   std::unique_ptr<Module> build_module(Engine &eng, uint32_t in_dim, uint32_t out_dim, uint64_t seed) const {
     rl_mlp *h = nullptr;
-    check(rl_rnn_mlp_create(eng.handle(), RL_CELL_LSTM, in_dim, hidden_dim, first_config.num_layers,
-                            second_config.single_hidden_size(), out_dim, &h),
+    check(rl_rnn_mlp_create_config(eng.handle(), RL_CELL_LSTM, in_dim, hidden_dim, first_config.num_layers,
+                                   first_config.bias_init ? 1 : 0, second_config.single_hidden_size(), out_dim, &h),
           eng.handle());
     std::unique_ptr<Module> m(new Module(eng, h));
     const LinearConfig &lc = second_config.linear_config;

@@ -34,9 +34,19 @@ enum { SET_A = 0, SET_B = 1, SET_PEEK = 2, SET_TA = 3, SET_TB = 4, N_SETS = 5 };
 
 struct StackNet {
   const float *p;  // flat parameters (or a tangent in the same layout)
+  const float *z;  // >= 4 H zeros: what a layer WITHOUT bias vectors starts its gate rows from (NULL: the layers have them)
   int D, H, H2, A, L;
   uint32_t off[RL_RNN_MAX_LAYERS + 1];  // W_ih of layer l; [L]: the head's W1
 };
+// b_ih / b_hh of a layer whose W_hh starts at Whh
+template <int G>
+__device__ __forceinline__ const float *stack_bih(const StackNet &net, const float *Whh) {
+  return net.z != nullptr ? net.z : Whh + (size_t)G * net.H * net.H;
+}
+template <int G>
+__device__ __forceinline__ const float *stack_bhh(const StackNet &net, const float *Whh) {
+  return net.z != nullptr ? net.z : Whh + (size_t)G * net.H * net.H + G * net.H;
+}
 
 struct StackWs {
   float *st, *u, *din, *dst, *rec, *a1, *ur, *dg, *du;
@@ -140,7 +150,7 @@ __device__ __forceinline__ void stack_cell(const StackNet &net, const StackWs &w
   const int H = net.H, K = l == 0 ? net.D : net.H;
   const size_t n = ws.n;
   const float *__restrict__ Wih = net.p + net.off[l], *__restrict__ Whh = Wih + (size_t)G * H * K;
-  const float *__restrict__ bih = Whh + (size_t)G * H * H, *__restrict__ bhh = bih + G * H;
+  const float *__restrict__ bih = stack_bih<G>(net, Whh), *__restrict__ bhh = stack_bhh<G>(net, Whh);
   for (int j0 = UQ * lc.wave; j0 < H; j0 += UQ * SW) {
     float gif[G * UQ], ghf[G * UQ];  // [gate][unit of the quad]
     int row[G * UQ];
@@ -449,7 +459,7 @@ __global__ void __launch_bounds__(SL *SW) k_stack_tangent(StackNet net, StackNet
       const int K = l == 0 ? net.D : H;
       const float *__restrict__ Wih = net.p + net.off[l], *__restrict__ Whh = Wih + (size_t)G * H * K;
       const float *__restrict__ Vih = tv.p + net.off[l], *__restrict__ Vhh = Vih + (size_t)G * H * K;
-      const float *__restrict__ vbih = Vhh + (size_t)G * H * H, *__restrict__ vbhh = vbih + G * H;
+      const float *__restrict__ vbih = stack_bih<G>(tv, Vhh), *__restrict__ vbhh = stack_bhh<G>(tv, Vhh);
       const float *__restrict__ in = l == 0 ? tr.obs + t * n + lc.ii : rec_plane(ws, net, l - 1, RP_HOUT) + b;
       const size_t in_stride = l == 0 ? plane : B;
       const float *__restrict__ ind = l == 0 ? nullptr : slot(ws, net, nxt, 0, l - 1);
@@ -551,6 +561,7 @@ __global__ void __launch_bounds__(SL *SW) k_stack_tangent(StackNet net, StackNet
 StackNet stack_net(const rl_mlp *m, const float *p) {
   StackNet s;
   s.p = p;
+  s.z = m->has_bias ? nullptr : m->d_params + m->P;  // (the module's zeros also serve a tangent's absent bias entries)
   s.D = (int)m->in_dim;
   s.H = (int)m->gru_hidden;
   s.H2 = (int)m->hidden;
@@ -696,8 +707,10 @@ void launch_stack_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_sk
     const size_t plane = (size_t)(T + 1) * n;
     for (int l = 0; l < L; ++l) {
       const int K = l == 0 ? net.D : H;
-      const uint64_t oWih = net.off[l], oWhh = oWih + (uint64_t)G * H * K, obih = oWhh + (uint64_t)G * H * H,
-                     obhh = obih + (uint64_t)G * H;
+      const uint64_t oWih = net.off[l], oWhh = oWih + (uint64_t)G * H * K;
+      // (layers without bias vectors: no bias columns in the flat vector)
+      const uint64_t obih = mod->has_bias ? oWhh + (uint64_t)G * H * H : 0xFFFFFFFFull;
+      const uint64_t obhh = mod->has_bias ? obih + (uint64_t)G * H : 0xFFFFFFFFull;
       const float *dg = k.dg + (size_t)l * 4 * H * B;
       const float *X = l == 0 ? traj->d.obs : k.rec + ((size_t)(l - 1) * RPN + RP_HOUT) * H * B;
       const float *hp = k.rec + ((size_t)l * RPN + RP_HPREV) * H * B;
@@ -706,7 +719,8 @@ void launch_stack_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_sk
         wgrad(dg, 4 * H, hp, (size_t)B, H, oWhh, obhh);
       } else {  // hidden side: rows [r; z] as on the input side, the n rows from the fourth plane
         wgrad(dg, 2 * H, hp, (size_t)B, H, oWhh, obhh);
-        wgrad(dg + (size_t)3 * H * B, H, hp, (size_t)B, H, oWhh + (uint64_t)2 * H * H, obhh + (uint64_t)2 * H);
+        wgrad(dg + (size_t)3 * H * B, H, hp, (size_t)B, H, oWhh + (uint64_t)2 * H * H,
+              mod->has_bias ? obhh + (uint64_t)2 * H : 0xFFFFFFFFull);
       }
     }
     const uint64_t oW1 = net.off[L], ob1 = oW1 + (uint64_t)H2 * H, oW2 = ob1 + H2, ob2 = oW2 + (uint64_t)A * H2;

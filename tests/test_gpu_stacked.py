@@ -301,8 +301,11 @@ def test_init_with_initializers(engine):
         assert np.array_equal(m.get_params(), O.stack_init_with(shape, NL, 7, inits))
         m.init_with(9)  # the defaults
         assert np.array_equal(m.get_params(), O.stack_init(shape, NL, 9))
-        with pytest.raises(ra.RelearnError) as e:
+        with pytest.raises(ra.RelearnError) as e:  # (bias_init = None belongs to modules built without bias vectors)
             m.init_with(7, bias=None)
+        assert e.value.code == ra.ERR_INVALID_ARGUMENT
+        with pytest.raises(ra.RelearnError) as e:
+            m.init_with(7, mlp_bias=None)
         assert e.value.code == ra.ERR_UNSUPPORTED
         with pytest.raises(ra.RelearnError) as e:
             m.init_with(7, bias=("Orthogonal", "FanAvg", 0.0))
@@ -311,3 +314,71 @@ def test_init_with_initializers(engine):
         ra.lib().rl_rnn_mlp_init_with  # (exported)
         mlp = ra.Mlp(engine, 5, 32, 2)
         ra._check(ra.lib().rl_rnn_mlp_init_with(mlp.h, C.c_uint64(1), None, None, None, None, None), engine.h)
+
+
+def _bias_index(spec):
+    """indices of the recurrent bias entries in the flat vector of the module WITH bias vectors"""
+    idx = []
+    for name, l, shp, o in spec.slices()[0]:
+        if name in ("bih", "bhh"):
+            idx += list(range(o, o + int(np.prod(shp))))
+    return np.array(idx)
+
+
+@pytest.mark.parametrize("cell,D,H,NL,H2,A", [("gru", 5, 128, 1, 128, 2), ("lstm", 5, 24, 2, 12, 2), ("gru", 3, 10, 3, 6, 1)])
+def test_recurrent_layers_without_bias_vectors(engine, cell, D, H, NL, H2, A):
+    """RnnBaseConfig::bias_init = None (seq/rnn/mod.rs:20-45,246-251): the flat vector holds [W_ih, W_hh] per layer; the
+    default initialisation draws the same stream (Zeros draw nothing); outputs are bit-identical to the module with zero
+    bias vectors, gradients and Fisher-vector products are that module's without the bias entries (f64 restatement);
+    actor documents carry has_biases: false"""
+    cls = ra.GruMlp if cell == "gru" else ra.LstmMlp
+    m = cls(engine, D, A, H, H2, num_layers=NL, rnn_bias=False)
+    full, shape, spec = modules(engine, cell, D, H, NL, H2, A, 51)
+    keep = np.setdiff1d(np.arange(full.P), _bias_index(spec))
+    assert m.P == len(keep)
+    m.init(51)
+    assert np.array_equal(m.get_params(), full.get_params()[keep])
+    traj, want = synthetic_history(engine, 70, 8, D, 9)
+    out_b, succ_b = m.seq_forward(traj)
+    out_f, succ_f = O.stack_seq_forward(shape, NL, full.get_params(), want)
+    assert np.array_equal(out_b, out_f) and np.array_equal(succ_b, succ_f)
+    p = full.get_params()
+    B = want["action"].size
+    if A == 2:
+        g_d = ra.policy_gradient(m, traj)[0]
+        logits, _, _ = S.forward(spec, p, want, want_succ=False)
+        z = logits - logits.max(0)
+        pr = np.exp(z - np.log(np.exp(z).sum(0)))
+        a = want["action"].astype(np.int64)
+        ind = np.stack([a == 0, a == 1]).astype(np.float64)
+        g64 = S.backward(spec, p, want, -(want["adv"].astype(np.float64) / B) * (ind - pr))[keep]
+        assert rel_err(g_d, g64) < GRAD_RTOL
+        v = np.random.default_rng(3).normal(size=m.P).astype(np.float32)
+        vfull = np.zeros(full.P)
+        vfull[keep] = v
+        h64 = S.policy_fvp(spec, p, vfull, want, 1e-5)[keep]
+        assert rel_err(ra.policy_fvp(m, traj, v, 1e-5), h64) < 2e-5
+        if D == 5:  # rolls out on an env and learns
+            env = ra.ChainEnv(engine, 64, max_steps=9, seed_env=3, seed_actor=4)
+            t2 = ra.Trajectory(engine, 64, 16, 5)
+            ra.rollout(env, m, t2)
+            ra.reward_to_go(t2, 0.95)
+            cfg = ra.ppo_config_default()
+            cfg.opt_steps_per_update = 3
+            st, losses = ra.ppo_update(m, ra.Adam(m), t2, cfg, want_losses=True)
+            assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    else:
+        g_d, loss_d = ra.critic_gradient(m, traj)
+        vv, _, _ = S.forward(spec, p, want, want_succ=False)
+        d = vv - want["rtg"].astype(np.float64)[None]
+        assert rel_err(g_d, S.backward(spec, p, want, 2.0 * d / B)[keep]) < GRAD_RTOL
+    env = ra.CartPoleEnv(engine, 64, max_steps=9, seed_env=3, seed_actor=4)
+    if D == 5 and A == 2:
+        doc = ra.actor_to_cbor(env, m)
+        other = cls(engine, D, A, H, H2, num_layers=NL, rnn_bias=False)
+        ra.module_from_cbor(other, doc)
+        assert np.array_equal(other.get_params(), m.get_params())
+        with pytest.raises(ra.RelearnError):
+            ra.module_from_cbor(full, doc)
+    m.init_with(5, bias=None)
+    assert m.get_params().shape == (m.P,)
