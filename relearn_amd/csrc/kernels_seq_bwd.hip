@@ -679,7 +679,8 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   const SeqDev &q = traj->seq;
   uint32_t P = (uint32_t)mod->P, blocks = traj->d.T * q.tiles;
   const bool lstm = mod->kind == RL_MODULE_LSTM_MLP;
-  const bool gru_head = !lstm && e->kernel_variant != 1;  // kernels_seq_train.hip
+  const bool gru_head = e->kernel_variant != 1;  // kernels_seq_train.hip: the head's backward (with its weight gradients)
+                                                // and the recurrent weight gradients on the bf16 pipe, either cell
   {
     ProfScope ps(e, RL_K_BACKWARD);
     const bool split_head = lstm || e->kernel_variant != 1;  // the head's backward as its own block-parallel kernel
@@ -714,20 +715,20 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
   hipLaunchKernelGGL((k_gru_wgrad<5, AA, NGT, G0, GN, W1>), dim3(q.chunks), dim3(256), 0, e->stream, traj->d, traj->dz, \
                      q.act, q.dpre, q.wg_slab, P, q.tiles, blocks, q.blocks_per_chunk, d_skip)
     if (mod->out_dim == 2) {
-      if (lstm) {
+      if (gru_head) {
+        launch_gru_train_wgrad(traj, mod, d_skip);
+      } else if (lstm) {
         WG(2, 4, 0, 2, true);
         WG(2, 4, 2, 2, false);
-      } else if (gru_head) {
-        launch_gru_train_wgrad(traj, mod, d_skip);
       } else {
         WG(2, 3, 0, 3, true);
       }
     } else {
-      if (lstm) {
+      if (gru_head) {
+        launch_gru_train_wgrad(traj, mod, d_skip);
+      } else if (lstm) {
         WG(1, 4, 0, 2, true);
         WG(1, 4, 2, 2, false);
-      } else if (gru_head) {
-        launch_gru_train_wgrad(traj, mod, d_skip);
       } else {
         WG(1, 3, 0, 3, true);
       }
@@ -744,7 +745,12 @@ void launch_gru_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip
       segs.rows[segs.n] = rows;
       segs.n += 1;
     };
-    if (gru_head) {
+    if (gru_head && lstm) {
+      // every recurrent column from the weight-gradient kernel's rows, the head from the head kernel's
+      const uint32_t oW1 = 4 * GH * 5 + 4 * GH * GH + 8 * GH;
+      seg(0, oW1, q.wg_slab, q.chunks);
+      seg(oW1, P, q.wg_slab + (size_t)q.chunks * P, RL_SEQ_HEAD_ROWS);
+    } else if (gru_head) {
       // kernels_seq_train.hip: W_hh, the r / z rows of W_ih and b_ih, and b_hh from the weight-gradient kernel's rows;
       // the n rows of W_ih and b_ih from the backward recurrence's rows (one per tile); the head from the head kernel's
       const uint32_t oWhh = 3 * GH * 5, obih = oWhh + 3 * GH * GH, obhh = obih + 3 * GH, oW1 = obhh + 3 * GH;

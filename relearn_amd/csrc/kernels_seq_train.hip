@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // blk = blockIdx.x, + gridDim.x, ... and writes one row of f32 partials (head columns only) for the f64 reduction.
 template <int A>
 __global__ void __launch_bounds__(W16 * 64, 2)
-    k_gru_head_backward(TrajDev tr, const float *__restrict__ params, int D, const float *__restrict__ dz,
+    k_gru_head_backward(TrajDev tr, const float *__restrict__ params, int D, int NG, const float *__restrict__ dz,
                         const float *__restrict__ act, float *__restrict__ dpre, float *__restrict__ slab, uint32_t P,
                         uint32_t tiles, uint32_t blocks, const int32_t *__restrict__ skip) {
   __shared__ __attribute__((aligned(16))) unsigned short uJ[3][TL * GH];  // img_at
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const int n16 = lane & 15, g4 = lane >> 4, j = 16 * wave + n16;
   const uint32_t N = tr.n, T = tr.T;
   const size_t B = (size_t)T * N;
-  const GruParams g = gru_params(params, D, A);
+  const GruParams g = seq_params(params, D, A, NG);  // (NG gate blocks in front of the head: 3 = GRU, 4 = LSTM)
   Frag w1f[MH / 32][3];  // B operand of d relu(h'): W1[32 kb + 8 g4 + 0..7][j] (rows: units of u; column: this lane's k)
 #pragma unroll
   for (int kb = 0; kb < MH / 32; ++kb) {
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     }
   }
   // ---- this workgroup's row of partials (head columns)
-  const size_t oW1 = (size_t)3 * GH * D + (size_t)3 * GH * GH + 6 * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH,
+  const size_t oW1 = (size_t)NG * GH * D + (size_t)NG * GH * GH + 2 * NG * GH, ob1 = oW1 + (size_t)MH * GH, oW2 = ob1 + MH,
                ob2 = oW2 + (size_t)A * MH;
   float *__restrict__ out = slab + (size_t)blockIdx.x * P;
 #pragma unroll
@@ -774,12 +774,16 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 // (lane = row, upper half-wave = upper chunk) and the staging writes (four lanes per row) are conflict-free
 // (scripts/lds_conflicts.py; the padded 48-byte rows before cost the writes twice their cycles)
 __device__ __forceinline__ int wimg_at(int row, int hw) { return row * 16 + (hw ^ (((row >> 3) & 1) << 3)); }
-template <int D>
+// NG gate blocks: 3 = GRU (hidden-side deltas: d pre_r, d pre_z, d pre_n r = dpre arrays 0, 1, 3; the input side of r and z
+// equals the hidden side), 4 = LSTM (d pre_i, f, g, o = arrays 0 .. 3; input side = hidden side for all four: this kernel
+// then forms every recurrent column, eight 32x32 tiles per wave)
+template <int D, int NG>
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_wgrad_bf16(TrajDev tr, const float *__restrict__ act, const float *__restrict__ dpre,
                      float *__restrict__ slab, uint32_t P, uint32_t tiles, uint32_t blocks, uint32_t blocks_per_chunk,
                      const int32_t *__restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) unsigned short AP[2][3][3 * GH * 16];  // d gh pieces, by half parity (wimg_at)
+  constexpr int NIN = NG == 3 ? 2 : NG;  // gates whose input-side sums are formed here
+  __shared__ __attribute__((aligned(16))) unsigned short AP[2][3][NG * GH * 16];  // d gh pieces, by half parity (wimg_at)
   __shared__ __attribute__((aligned(16))) unsigned short BP[2][3][GH * 16];      // h_prev pieces
   __shared__ float xS[2][TL][17];  // observations, by block parity: thread q holds column q / TL of sample q % TL (the
                                    // columns >= D are padding: every thread writes, no branch; 17: samples 4 rows apart
@@ -788,17 +792,17 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const int q = threadIdx.x, lane = q & 63, wave = q >> 6;
   const int n = lane & 31, hf = lane >> 5;
   const int nt = wave & 3, mset = wave >> 2;
-  bt::f32x16 acc[6];
+  bt::f32x16 acc[2 * NG];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) acc[i] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 2 * NG; ++i) acc[i] = (bt::f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // staging of a half: thread q takes the 16-byte piece (row q >> 2, samples 4 (q & 3) .. + 3 of the half) of each of
   // the three gate arrays and of h_prev
   const int srow = q >> 2, scol = 4 * (q & 3);
-  float dwih[2][D], dbh[3];
+  float dwih[NIN][D], dbh[NG];
 #pragma unroll
-  for (int g3 = 0; g3 < 3; ++g3) dbh[g3] = 0.0f;
+  for (int g3 = 0; g3 < NG; ++g3) dbh[g3] = 0.0f;
 #pragma unroll
-  for (int g2 = 0; g2 < 2; ++g2)
+  for (int g2 = 0; g2 < NIN; ++g2)
 #pragma unroll
     for (int d = 0; d < D; ++d) dwih[g2][d] = 0.0f;
   const uint32_t N = tr.n, T = tr.T;
@@ -808,7 +812,7 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const uint32_t n_half = b1 > b0 ? 2 * (b1 - b0) : 0;  // (a chunk past the end writes a row of zeros)
   // register stages of the global loads: half h lands in slot h & 1, two halves before its pieces are produced
   struct Slot {
-    f32x4 g[3], hB;
+    f32x4 g[NG], hB;
     float xn;
   };
   Slot slot[2];
@@ -820,9 +824,9 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     const float *__restrict__ ab = act + (size_t)blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + (size_t)blk * DPRE_ARR * GH * TL;
     const uint32_t o = rec_at(srow, 16 * (int)(h & 1) + scol);
-    sl.g[0] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(0 * GH * TL) + o);
-    sl.g[1] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(1 * GH * TL) + o);
-    sl.g[2] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(3 * GH * TL) + o);  // hidden side of the n gate
+#pragma unroll
+    for (int g3 = 0; g3 < NG; ++g3)  // (GRU: array 3 is the hidden side of the n gate)
+      sl.g[g3] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)((NG == 3 && g3 == 2 ? 3 : g3) * GH * TL) + o);
     sl.hB = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
     if ((h & 1) == 0 && (steady || blk + 1 < b1)) {  // feature q / TL of sample q % TL of the NEXT block (its sums run
       const uint32_t t = (blk + 1) / tiles, lane0 = ((blk + 1) % tiles) * TL;  // while its pieces are produced)
@@ -846,16 +850,16 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   auto stage = [&](uint32_t h, const Slot &sl) {
     const int buf = (int)(h & 1);
 #pragma unroll
-    for (int g3 = 0; g3 < 3; ++g3) park(AP[buf], g3 * GH + srow, sl.g[g3]);
+    for (int g3 = 0; g3 < NG; ++g3) park(AP[buf], g3 * GH + srow, sl.g[g3]);
     park(BP[buf], srow, sl.hB);
     if ((h & 1) == 0) xS[((h >> 1) + 1) & 1][q % TL][q / TL] = sl.xn;  // x of the next block
     const int xb = (int)((h >> 1) & 1);
 #pragma unroll
-    for (int g3 = 0; g3 < 3; ++g3)
+    for (int g3 = 0; g3 < NG; ++g3)
 #pragma unroll
       for (int i = 0; i < 4; ++i) dbh[g3] += sl.g[g3][i];
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2)
+    for (int g2 = 0; g2 < NIN; ++g2)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -867,13 +871,13 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 #pragma unroll
     for (int c = 0; c < 3; ++c) fb[c].x = *reinterpret_cast<const uint4 *>(&BP[buf][c][wimg_at(32 * nt + n, 8 * hf)]);
 #pragma unroll
-    for (int i = 0; i < 6; i += 2) {
+    for (int i = 0; i < 2 * NG; i += 2) {
       Frag fa[2][3];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[buf][c][wimg_at(192 * mset + 32 * (i + u) + n, 8 * hf)]);
+          fa[u][c].x = *reinterpret_cast<const uint4 *>(&AP[buf][c][wimg_at(64 * NG * mset + 32 * (i + u) + n, 8 * hf)]);
 #pragma unroll
       for (int pa = 2; pa >= 0; --pa)
 #pragma unroll
@@ -929,27 +933,27 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   }
   // ---- this workgroup's row of partials (recurrent columns)
   float *__restrict__ out = slab + (size_t)blockIdx.x * P;
-  const size_t oWhh = (size_t)3 * GH * D;
+  const size_t oWhh = (size_t)NG * GH * D;
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 2 * NG; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      out[oWhh + (size_t)(192 * mset + 32 * i + acc_row(r, hf)) * GH + 32 * nt + n] = acc[i][r];
+      out[oWhh + (size_t)(64 * NG * mset + 32 * i + acc_row(r, hf)) * GH + 32 * nt + n] = acc[i][r];
   // the four threads q & 3 of a row hold its partial sums over different samples
-  const size_t obih = oWhh + (size_t)3 * GH * GH, obhh = obih + 3 * GH;
+  const size_t obih = oWhh + (size_t)NG * GH * GH, obhh = obih + NG * GH;
   auto over4 = [](float v) {
     v = v + __shfl_xor(v, 1, 64);
     return v + __shfl_xor(v, 2, 64);
   };
 #pragma unroll
-  for (int g3 = 0; g3 < 3; ++g3) {
+  for (int g3 = 0; g3 < NG; ++g3) {
     const int row = g3 * GH + srow;
     const float vb = over4(dbh[g3]);
     if ((q & 3) == 0) {
       out[obhh + row] = vb;
-      if (g3 < 2) out[obih + row] = vb;  // (the n gate's input side comes from the backward recurrence)
+      if (g3 < NIN) out[obih + row] = vb;  // (the GRU's n gate: its input side comes from the backward recurrence)
     }
-    if (g3 < 2) {
+    if (g3 < NIN) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const float v = over4(dwih[g3][d]);
@@ -986,20 +990,25 @@ void launch_gru_train_head_backward(rl_traj *traj, const rl_mlp *mod, float *d_s
   if (grid < RL_SEQ_HEAD_ROWS)  // rows no workgroup writes
     RL_HIP_CHECK(hipMemsetAsync(d_slab + (size_t)grid * mod->P, 0, (size_t)(RL_SEQ_HEAD_ROWS - grid) * mod->P * sizeof(float),
                                 traj->eng->stream));
+  const int NG = (int)rl_module_gates(mod->kind);
   if (mod->out_dim == 2)
     hipLaunchKernelGGL(k_gru_head_backward<2>, dim3(grid), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params,
-                       5, traj->dz, q.act, q.dpre, d_slab, (uint32_t)mod->P, q.tiles, blocks, d_skip);
+                       5, NG, traj->dz, q.act, q.dpre, d_slab, (uint32_t)mod->P, q.tiles, blocks, d_skip);
   else
     hipLaunchKernelGGL(k_gru_head_backward<1>, dim3(grid), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params,
-                       5, traj->dz, q.act, q.dpre, d_slab, (uint32_t)mod->P, q.tiles, blocks, d_skip);
+                       5, NG, traj->dz, q.act, q.dpre, d_slab, (uint32_t)mod->P, q.tiles, blocks, d_skip);
 }
 
 // weight gradients of the recurrent parameters: rows [0, chunks) of seq.wg_slab, columns [0, W1)
 void launch_gru_train_wgrad(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip) {
   const SeqDev &q = traj->seq;
   const uint32_t blocks = traj->d.T * q.tiles;
-  hipLaunchKernelGGL(k_gru_wgrad_bf16<5>, dim3(q.chunks), dim3(W16 * 64), 0, traj->eng->stream, traj->d, q.act, q.dpre,
-                     q.wg_slab, (uint32_t)mod->P, q.tiles, blocks, q.blocks_per_chunk, d_skip);
+  if (mod->kind == RL_MODULE_LSTM_MLP)
+    hipLaunchKernelGGL((k_gru_wgrad_bf16<5, 4>), dim3(q.chunks), dim3(W16 * 64), 0, traj->eng->stream, traj->d, q.act,
+                       q.dpre, q.wg_slab, (uint32_t)mod->P, q.tiles, blocks, q.blocks_per_chunk, d_skip);
+  else
+    hipLaunchKernelGGL((k_gru_wgrad_bf16<5, 3>), dim3(q.chunks), dim3(W16 * 64), 0, traj->eng->stream, traj->d, q.act,
+                       q.dpre, q.wg_slab, (uint32_t)mod->P, q.tiles, blocks, q.blocks_per_chunk, d_skip);
 }
 
 // backward recurrence of the GRU chain (after the head's backward has left d relu(h') in seq.dpre)
