@@ -970,16 +970,24 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip) {
   RL_REQUIRE(traj->d.D == 5, "recurrent forward: built for 5 observation features");
   rl_engine *e = traj->eng;
-  const uint32_t tiles = traj->d.n / TL, blocks = traj->d.T * tiles;
+  const uint32_t tiles = traj->d.n / TL;
   const int A = (int)mod->out_dim;
   hipLaunchKernelGGL(k_gru_recur_fwd<5>, dim3(tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, A, d_act,
                      d_skip);
+  launch_seq_train_head_forward(traj, mod, d_out, d_act, d_skip);
+}
+
+// the head of either chain over all (step, tile) blocks: u (recorded) and the outputs from the recorded relu(h')
+void launch_seq_train_head_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip) {
+  rl_engine *e = traj->eng;
+  const uint32_t tiles = traj->d.n / TL, blocks = traj->d.T * tiles;
   const uint32_t grid = blocks < 2048 ? blocks : 2048;
-  if (A == 2)
-    hipLaunchKernelGGL(k_seq_head_forward<2>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, 3,
+  const int NG = (int)rl_module_gates(mod->kind);
+  if (mod->out_dim == 2)
+    hipLaunchKernelGGL(k_seq_head_forward<2>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, NG,
                        d_act, d_out, tiles, blocks, d_skip);
   else
-    hipLaunchKernelGGL(k_seq_head_forward<1>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, 3,
+    hipLaunchKernelGGL(k_seq_head_forward<1>, dim3(grid), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, 5, NG,
                        d_act, d_out, tiles, blocks, d_skip);
 }
 
