@@ -293,7 +293,8 @@ int32_t rl_engine_info(const rl_engine *e, char *name_out, size_t name_cap, char
                        int32_t *compute_units) {
   return guarded(const_cast<rl_engine *>(e), [&] {
     RL_REQUIRE(e, "engine is NULL");
-    if (name_out && name_cap) std::snprintf(name_out, name_cap, "%s", e->prop.name);
+    // (some driver stacks report an empty marketing name: the architecture then stands in for it)
+    if (name_out && name_cap) std::snprintf(name_out, name_cap, "%s", e->prop.name[0] ? e->prop.name : e->prop.gcnArchName);
     if (arch_out && arch_cap) std::snprintf(arch_out, arch_cap, "%s", e->prop.gcnArchName);
     if (compute_units) *compute_units = e->prop.multiProcessorCount;
   });

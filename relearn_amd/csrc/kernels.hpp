@@ -120,6 +120,7 @@ void launch_seq_pad(const rl_mlp *real, float *exec_dst, const float *real_src);
 void launch_seq_unpad(const rl_mlp *real, const float *exec_src, float *real_dst);
 // kernels_seq_train.hip: the GRU chain's training passes with the recurrence on the bf16 matrix pipe
 void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
+void launch_lstm_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
 void launch_seq_train_head_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip);
 void launch_gru_train_head_backward(rl_traj *traj, const rl_mlp *mod, float *d_slab, const int32_t *d_skip);
 void launch_gru_train_recur_backward(rl_traj *traj, const rl_mlp *mod, const int32_t *d_skip);

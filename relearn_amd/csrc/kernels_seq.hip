@@ -416,9 +416,7 @@ __device__ __forceinline__ void lstm_load_weights16(LstmFwdWeights16<D> &w, cons
   w.b1 = g.b1[j];
 }
 
-// HEAD = false: the recurrence only (the training forward: its head runs as a block-parallel kernel on the bf16 pipe,
-// k_seq_head_forward, from the recorded relu(h'))
-template <int D, int A, bool FINAL_BARRIER = true, bool HEAD = true>
+template <int D, int A, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeights16<D> &w, int cur,
                                             const float (&sown)[16], float (&snew)[16], float b2_mine,
                                             float *__restrict__ store, int wave, int lane) {
@@ -489,7 +487,6 @@ __device__ __forceinline__ void lstm_cell16(LstmFwdShared &sh, const LstmFwdWeig
       *reinterpret_cast<f32x4 *>(row + (size_t)LACT_TC * GH * TL) = tv;
     }
   }
-  if (!HEAD) return;  // (the caller's barrier ends the step)
   __syncthreads();
   // every wave has read h(t) by now: its buffer holds the MLP's hidden activations [m][j] until the next step's gates
   // write h(t+2) there (after the workgroup barrier that ends this step)
@@ -551,11 +548,10 @@ struct GruCell16 {
   static __device__ __forceinline__ void load(Weights<D> &w, const GruParams &g, Shared &, int wave, int lane) {
     seq_load_weights16<D>(w, g, wave, lane);
   }
-  template <int D, int A, bool FINAL_BARRIER = true, bool HEAD = true>
+  template <int D, int A, bool FINAL_BARRIER = true>
   static __device__ __forceinline__ void cell(Shared &sh, const Weights<D> &w, int cur, const float (&sown)[NS],
                                               float (&snew)[NS], float b2_mine, float *__restrict__ store, int wave,
                                               int lane) {
-    static_assert(HEAD, "the GRU's training forward has its own recurrence kernel (kernels_seq_train.hip)");
     seq_cell16<D, A, FINAL_BARRIER>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
   }
 };
@@ -569,11 +565,11 @@ struct LstmCell16 {
   static __device__ __forceinline__ void load(Weights<D> &w, const GruParams &g, Shared &sh, int wave, int lane) {
     lstm_load_weights16<D>(w, g, sh, wave, lane);
   }
-  template <int D, int A, bool FINAL_BARRIER = true, bool HEAD = true>
+  template <int D, int A, bool FINAL_BARRIER = true>
   static __device__ __forceinline__ void cell(Shared &sh, const Weights<D> &w, int cur, const float (&sown)[NS],
                                               float (&snew)[NS], float b2_mine, float *__restrict__ store, int wave,
                                               int lane) {
-    lstm_cell16<D, A, FINAL_BARRIER, HEAD>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
+    lstm_cell16<D, A, FINAL_BARRIER>(sh, w, cur, sown, snew, b2_mine, store, wave, lane);
   }
 };
 
@@ -713,7 +709,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_chain_mlp(CartPoleDev c, EnvS
 // SeqPacked::seq_packed of Chain<Gru, Mlp> (chain.rs:151-161; gru.rs:76-98) on the lane layout.  Writes the module
 // outputs out[a][t][lane]; optionally the outputs at the successor observations of cut episodes (extended
 // observation sequences, features.rs:132-178) and the activation record for the backward pass.
-template <int D, int A, class Cell, bool HEAD = true>
+template <int D, int A, class Cell>
 __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, const float *__restrict__ params,
                                                             float *__restrict__ out, float *__restrict__ succ_out,
                                                             float *__restrict__ act,
@@ -758,8 +754,8 @@ __global__ void __launch_bounds__(W16 * 64, 2) k_gru_seq_forward(TrajDev tr, con
   while (t < T) {
     float hout[NS];
     float *store = (act != nullptr && !peeking) ? act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL : nullptr;
-    Cell::template cell<D, A, false, HEAD>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
-    if (HEAD && io_lane) {  // (!HEAD: the training forward — no outputs here, no successor evaluations)
+    Cell::template cell<D, A, false>(sh, w, cur, hown, hout, b2_mine, store, wave, lane);
+    if (io_lane) {
       if (!peeking) {
 #pragma unroll
         for (int a = 0; a < A; ++a) out[((size_t)a * T + t) * N + i] = sh.outS[a][lane];
@@ -1039,15 +1035,9 @@ void launch_gru_seq_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, floa
     launch_gru_train_forward(traj, mod, d_out, d_act, d_skip);
     return;
   }
-  // training forward of the LSTM chain: the f32 cell without its head, then the head on the bf16 pipe from the record
+  // ... and of the LSTM chain: its recurrence on the bf16 pipe (four waves per tile), then the same head kernel
   if (lstm && d_act != nullptr && d_succ == nullptr && traj->eng->kernel_variant != 1) {
-    if (mod->out_dim == 2)
-      hipLaunchKernelGGL((k_gru_seq_forward<5, 2, LstmCell16, false>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream,
-                         traj->d, mod->d_params, d_out, d_succ, d_act, d_skip);
-    else
-      hipLaunchKernelGGL((k_gru_seq_forward<5, 1, LstmCell16, false>), dim3(tiles), dim3(W16 * 64), 0, traj->eng->stream,
-                         traj->d, mod->d_params, d_out, d_succ, d_act, d_skip);
-    launch_seq_train_head_forward(traj, mod, d_out, d_act, d_skip);
+    launch_lstm_train_forward(traj, mod, d_out, d_act, d_skip);
     return;
   }
   if (mod->out_dim == 2) {

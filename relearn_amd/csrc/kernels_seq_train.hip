@@ -45,6 +45,9 @@ using bt::Frag;
 // 1.8e-8).  PIECE_ORDER 5 multiplies all nine.
 constexpr int PIECE_ORDER = 3;
 constexpr int PIECE_PAIRS = PIECE_ORDER == 3 ? 6 : PIECE_ORDER == 4 ? 8 : 9;
+#ifndef LSTM_VALU_PER_MFMA
+#define LSTM_VALU_PER_MFMA 6
+#endif
 constexpr int VALU_PER_MFMA = 4;  // vector instructions the forward's schedule places after each matrix instruction  // vector instructions the schedule of the forward places between two matrix instructions
 // Piece images [sample][unit] in LDS: rows of GH halfwords (256 bytes — the width of the LDS), the 16-byte chunk c of
 // row m stored at chunk (c + img_rot(m)) & 15.  A ds_read_b128 is served in four groups of sixteen lanes that are NOT
@@ -321,6 +324,229 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     }
     if (io_lane && t + 1 < T) publish((int)((t + 1) & 1));
     __syncthreads();  // rows 16-31 of h(t+1) and the inputs of step t + 1 are complete; rows 0-15 have been read
+  }
+}
+
+// ---------------------------------------------------------------- forward recurrence of the LSTM chain
+// The same two-phase step as k_gru_recur_fwd with four gates.  Their W_hh piece fragments are 4 x 98 KB per tile: the
+// GRU's partition (eight waves of 256 registers, two gates in registers, one in LDS) cannot hold them — two gates in LDS
+// are 196 KB — so a tile is FOUR waves, one per SIMD, with the 512-register budget: wave w owns the units [32 w, 32 w +
+// 32) as two groups of 16 (u = 0, 1).  Of the twelve (gate, piece) fragment sets, eight stay in registers (256: what the
+// accumulation-register half holds — the vector ALU addresses the other 256 only) and four wait in LDS (128 KB: the o
+// gate and the g gate's third piece); the input projection's weights of a lane's two units are registers as well.  State per lane: c of its 2 x 8 (unit, sample) pairs and h (the record's h_prev); h as pieces in the
+// LDS image every wave's products read.  Gate functions: the fast forms of the GRU's training forward; records: i, f, g,
+// o, h_prev, relu(h'), c_prev, tanh(c') — the arrays lstm_cell16 (kernels_seq.hip) writes, read by k_lstm_bptt and the
+// head / weight-gradient kernels.
+template <int D>
+__global__ void __launch_bounds__(256, 1)
+    k_lstm_recur_fwd(TrajDev tr, const float *__restrict__ params, int A, float *__restrict__ act,
+                     const int32_t *__restrict__ skip) {
+  constexpr int LW = 4;  // waves per tile
+  __shared__ __attribute__((aligned(16))) unsigned short hP[3][TL * GH];  // h as pieces, [sample][unit] (img_at)
+  __shared__ float xS[2][TL][9];
+  __shared__ int endS[2][TL];
+  // W_hh fragments that do not fit the registers: the o gate's three pieces and the third piece of the g gate (128 KB)
+  __shared__ uint4 wlS[GH / 32][4][LW][2][64];
+  if (skip != nullptr && *skip != 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, g4 = lane >> 4;
+  const uint32_t N = tr.n, T = tr.T;
+  const uint32_t tile = blockIdx.x, tiles = gridDim.x, lane0 = tile * TL;
+  const GruParams g = seq_params(params, D, A, 4);
+  // in registers (256 of the accumulation-register half): the gates i, f with all pieces, the g gate's first two
+  Frag wf[2][2][GH / 32][3];  // [gate i, f][unit group][k-block][piece]: W_hh[gate * GH + j][32 kb + 8 g4 + 0..7]
+  Frag wg[2][GH / 32][2];     // [unit group][k-block][piece 0, 1] of the g gate
+  float bhh[4][2], wih[4][2][D], bih[4][2];  // (the input projection's weights of this lane's two units: registers too)
+#pragma unroll
+  for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = gte * GH + 32 * wave + 16 * u + n16;
+#pragma unroll
+      for (int kb = 0; kb < GH / 32; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = g.Whh[(size_t)row * GH + 32 * kb + 8 * g4 + i];
+        Frag f[3];
+        frags_of8(v, f);
+        if (gte < 2) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) wf[gte][u][kb][q] = f[q];
+        } else if (gte == 2) {
+          wg[u][kb][0] = f[0];
+          wg[u][kb][1] = f[1];
+          wlS[kb][3][wave][u][lane] = f[2].x;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) wlS[kb][q][wave][u][lane] = f[q].x;
+        }
+      }
+      bhh[gte][u] = g.bhh[row];
+      bih[gte][u] = g.bih[row];
+#pragma unroll
+      for (int d = 0; d < D; ++d) wih[gte][u][d] = g.Wih[(size_t)row * D + d];
+    }
+  for (int q = threadIdx.x; q < (int)(sizeof(hP) / 4); q += LW * 64) reinterpret_cast<uint32_t *>(&hP[0][0])[q] = 0u;
+  // (h itself is not kept: a step records the h it leaves behind as the NEXT step's h_prev — 16 registers less)
+  float cown[2][8];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cown[u][r] = 0.0f;
+  {  // h_prev of step 0
+    float *__restrict__ store0 = act + (size_t)tile * SEQ_ARR * GH * TL;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        *reinterpret_cast<f32x4 *>(store0 + (uint32_t)(ACT_HPREV * GH * TL) + rec_at(32 * wave + 16 * u + n16, 16 * mt + 4 * g4)) =
+            (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  const bool io_lane = wave == 0 && lane < TL;
+  const uint32_t i_lane = lane0 + (uint32_t)(lane & (TL - 1));
+  const size_t plane = (size_t)(T + 1) * N;
+  float xin[D];
+  int fin = 0;
+  auto fetch = [&](uint32_t tt) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) xin[d] = tr.obs[d * plane + (size_t)tt * N + i_lane];
+    fin = tr.flag[(size_t)tt * N + i_lane];
+  };
+  auto publish = [&](int buf) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) xS[buf][lane][d] = xin[d];
+    endS[buf][lane] = fin != RL_SUCC_CONTINUE;
+  };
+  if (io_lane) {
+    fetch(0);
+    publish(0);
+  }
+  __syncthreads();
+  f32x4 acc[4][2][2];  // [gate][unit group][M-tile]
+  auto start = [&](int mt) {
+#pragma unroll
+    for (int gte = 0; gte < 4; ++gte)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[gte][u][mt] = (f32x4){bhh[gte][u], bhh[gte][u], bhh[gte][u], bhh[gte][u]};
+  };
+  // (the register-resident fragments are asked into the accumulation-register half at every use: matrix instructions read
+  // their B operand from either half, the vector ALU only from the other — left to itself the allocator keeps the 256
+  // fragment registers in the vector half and spills the arithmetic around them)
+  auto pin = [](Frag &f) { asm volatile("" : "+a"(f.v)); };
+  auto products = [&](int mt) {
+#pragma unroll
+    for (int kb = 0; kb < GH / 32; ++kb) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          pin(wf[0][u][kb][q]);
+          pin(wf[1][u][kb][q]);
+        }
+        pin(wg[u][kb][0]);
+        pin(wg[u][kb][1]);
+      }
+      Frag fa[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        fa[p].x = *reinterpret_cast<const uint4 *>(&hP[p][img_at(16 * mt + n16, 32 * kb + 8 * g4)]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        Frag wo[3], wgg[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wo[q].x = wlS[kb][q][wave][u][lane];
+        wgg[0] = wg[u][kb][0];
+        wgg[1] = wg[u][kb][1];
+        wgg[2].x = wlS[kb][3][wave][u][lane];
+#pragma unroll
+        for (int gte = 0; gte < 2; ++gte) acc[gte][u][mt] = mfma_pieces(fa, wf[gte][u][kb], acc[gte][u][mt]);
+        acc[2][u][mt] = mfma_pieces(fa, wgg, acc[2][u][mt]);
+        acc[3][u][mt] = mfma_pieces(fa, wo, acc[3][u][mt]);
+      }
+    }
+  };
+  auto gates = [&](int mt, uint32_t t) {
+    const int cur = (int)(t & 1);
+    float *__restrict__ store = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
+    float *__restrict__ store_next = act + ((size_t)(t + 1 < T ? t + 1 : t) * tiles + tile) * SEQ_ARR * GH * TL;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 32 * wave + 16 * u + n16;
+      const uint32_t row = rec_at(j, 16 * mt + 4 * g4);
+      f32x4 iv, fv, gv, ov, pv, av, cv, tv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = acc16_row(mt, i, g4), r = 4 * mt + i;
+        float pre[4];
+#pragma unroll
+        for (int gte = 0; gte < 4; ++gte) {
+          float v = bih[gte][u];
+#pragma unroll
+          for (int d = 0; d < D; ++d) v = __builtin_fmaf(xS[cur][m][d], wih[gte][u][d], v);
+          pre[gte] = acc[gte][u][mt][i] + v;
+        }
+        const float ig = sigmoid_sel(pre[0]), fg = sigmoid_sel(pre[1]), gg = tanh_sel(pre[2]), og = sigmoid_sel(pre[3]);
+        const float cprev = cown[u][r];
+        const float cn = __builtin_fmaf(fg, cprev, ig * gg);
+        const float tc = tanh_sel(cn);
+        const float hv = og * tc;
+        iv[i] = ig;
+        fv[i] = fg;
+        gv[i] = gg;
+        ov[i] = og;
+        av[i] = hv > 0.0f ? hv : 0.0f;
+        cv[i] = cprev;
+        tv[i] = tc;
+        // the state the next step starts from: zero after an episode end
+        const bool ended = endS[cur][m] != 0;
+        const float hn = ended ? 0.0f : hv;
+        pv[i] = hn;
+        cown[u][r] = ended ? 0.0f : cn;
+        uint32_t p0, p1, p2;
+        bt::split3(hn, p0, p1, p2);
+        hP[0][img_at(m, j)] = (unsigned short)p0;
+        hP[1][img_at(m, j)] = (unsigned short)p1;
+        hP[2][img_at(m, j)] = (unsigned short)p2;
+      }
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(LACT_I * GH * TL) + row) = iv;
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(LACT_F * GH * TL) + row) = fv;
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(LACT_G * GH * TL) + row) = gv;
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(LACT_O * GH * TL) + row) = ov;
+      if (t + 1 < T) *reinterpret_cast<f32x4 *>(store_next + (uint32_t)(ACT_HPREV * GH * TL) + row) = pv;
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(LACT_CPREV * GH * TL) + row) = cv;
+      *reinterpret_cast<f32x4 *>(store + (uint32_t)(LACT_TC * GH * TL) + row) = tv;
+    }
+  };
+  auto interleave = [&](auto phase) {
+    constexpr int PHASE = decltype(phase)::value;
+#pragma unroll
+    for (int k = 0; k < (GH / 32) * 8 * PIECE_PAIRS; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, PHASE);              // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, LSTM_VALU_PER_MFMA, PHASE);  // VALU
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  start(0);
+  products(0);  // (h = 0: the biases)
+  for (uint32_t t = 0; t < T; ++t) {
+    if (io_lane && t + 1 < T) fetch(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    start(1);
+    gates(0, t);
+    products(1);
+    interleave(std::integral_constant<int, 0>{});
+    __syncthreads();  // rows 0-15 of h(t+1) are complete; every wave has read rows 16-31 of h(t)
+    int taken;
+    asm volatile("s_mov_b32 %0, 1" : "=s"(taken));
+    if (taken != 0) {
+      start(0);
+      products(0);
+      gates(1, t);
+      interleave(std::integral_constant<int, 1>{});
+    }
+    if (io_lane && t + 1 < T) publish((int)((t + 1) & 1));
+    __syncthreads();
   }
 }
 
@@ -974,6 +1200,15 @@ void launch_gru_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, fl
   const int A = (int)mod->out_dim;
   hipLaunchKernelGGL(k_gru_recur_fwd<5>, dim3(tiles), dim3(W16 * 64), 0, e->stream, traj->d, mod->d_params, A, d_act,
                      d_skip);
+  launch_seq_train_head_forward(traj, mod, d_out, d_act, d_skip);
+}
+
+// teacher-forced training forward of the LSTM chain: the recurrence on the bf16 pipe, then the head
+void launch_lstm_train_forward(rl_traj *traj, const rl_mlp *mod, float *d_out, float *d_act, const int32_t *d_skip) {
+  RL_REQUIRE(traj->d.D == 5, "recurrent forward: built for 5 observation features");
+  const uint32_t tiles = traj->d.n / TL;
+  hipLaunchKernelGGL(k_lstm_recur_fwd<5>, dim3(tiles), dim3(256), 0, traj->eng->stream, traj->d, mod->d_params,
+                     (int)mod->out_dim, d_act, d_skip);
   launch_seq_train_head_forward(traj, mod, d_out, d_act, d_skip);
 }
 

@@ -200,6 +200,26 @@ def test_ppo_and_critic_updates(engine):
     assert np.mean(np.abs(cri.get_params() - p) < 3e-5) > 0.97 and closs_d[-1] < closs_d[0]
 
 
+def test_bf16_pipe_training_passes_agree_with_the_f32_kernels(engine):
+    """the two builds of the LSTM chain's training passes — forward recurrence, head and weight gradients on the bf16 matrix
+    pipe with exact three-piece products (kernels_seq_train.hip: k_lstm_recur_fwd on four waves per tile, the GRU chain's
+    head and weight-gradient kernels with four gate blocks; the default) and round 1's f32 kernels (engine kernel variant
+    1) — give the same gradients and Fisher-vector products up to the order of their f32 sums and the 2-ulp gate
+    functions of the training forward"""
+    pol, cri, traj, want, _, _ = setup_update(engine, n=96, T=24, max_steps=7)
+    v = np.random.default_rng(9).normal(size=pol.P).astype(np.float32)
+    got = {}
+    for variant in (0, 1):
+        engine.set_kernel_variant(variant)
+        try:
+            got[variant] = (ra.policy_gradient(pol, traj)[0], ra.critic_gradient(cri, traj)[0],
+                            ra.policy_fvp(pol, traj, v, 0.0))
+        finally:
+            engine.set_kernel_variant(0)
+    for a, b in zip(got[0], got[1]):
+        assert np.abs(a).max() > 0 and rel_err(a, b.astype(np.float64)) < 5e-6
+
+
 def test_fisher_vector_product_through_time(engine):
     pol, cri, traj, want, _, _ = setup_update(engine)
     p = pol.get_params()
