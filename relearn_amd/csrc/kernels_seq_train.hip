@@ -432,10 +432,12 @@ __global__ void __launch_bounds__(256, 1)
   // (the register-resident fragments are asked into the accumulation-register half at every use: matrix instructions read
   // their B operand from either half, the vector ALU only from the other — left to itself the allocator keeps the 256
   // fragment registers in the vector half and spills the arithmetic around them)
+  // (once per phase, ahead of its arithmetic: an asm statement inside the products would keep the scheduler from mixing
+  // them with the gate arithmetic)
   auto pin = [](Frag &f) { asm volatile("" : "+a"(f.v)); };
-  auto products = [&](int mt) {
+  auto pin_all = [&]() {
 #pragma unroll
-    for (int kb = 0; kb < GH / 32; ++kb) {
+    for (int kb = 0; kb < GH / 32; ++kb)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -446,6 +448,10 @@ __global__ void __launch_bounds__(256, 1)
         pin(wg[u][kb][0]);
         pin(wg[u][kb][1]);
       }
+  };
+  auto products = [&](int mt) {
+#pragma unroll
+    for (int kb = 0; kb < GH / 32; ++kb) {
       Frag fa[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
@@ -527,19 +533,26 @@ __global__ void __launch_bounds__(256, 1)
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  pin_all();
   start(0);
   products(0);  // (h = 0: the biases)
   for (uint32_t t = 0; t < T; ++t) {
     if (io_lane && t + 1 < T) fetch(t + 1);
+    pin_all();
     __builtin_amdgcn_sched_barrier(0);
+    // (the products first in program order, as in the second phase: their LDS reads then precede the gates' LDS writes —
+    // other rows of the same image, which the compiler cannot tell apart — and the matrix instructions are free to sink
+    // between the gate arithmetic; with the gates first they all waited behind the last write)
     start(1);
-    gates(0, t);
     products(1);
+    gates(0, t);
     interleave(std::integral_constant<int, 0>{});
     __syncthreads();  // rows 0-15 of h(t+1) are complete; every wave has read rows 16-31 of h(t)
     int taken;
     asm volatile("s_mov_b32 %0, 1" : "=s"(taken));
     if (taken != 0) {
+      pin_all();
+      __builtin_amdgcn_sched_barrier(0);
       start(0);
       products(0);
       gates(1, t);
