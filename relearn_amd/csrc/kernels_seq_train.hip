@@ -693,11 +693,10 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       for (int q = 0; q < 3; ++q) wTS[kb - (KB - KBL)][q][wave][lane] = f[q].x;
     }
   }
-  struct StepIn {
-    f32x4 r[2], z[2], n[2], ghn[2], hp[2], da1[2];
-    uint32_t end[2];  // four flag bytes
-    float x;          // threads < TL * D: feature (tid / TL) of sample (tid % TL) of the step BEFORE (published a step
-                      // ahead, so that the sums need no barrier of their own)
+  // The record of one M-tile (16 samples: this lane's four) of a step
+  struct HalfIn {
+    f32x4 r, z, n, ghn, hp, da1;
+    uint32_t end;  // four flag bytes
   };
   // input side of the n gate (dW_ih[n], db_ih[n]) for this lane's unit: sums of d pre_n over its eight samples of every
   // step — d pre_n exists only here (the hidden side stores d pre_n r), so it never goes to HBM; the other gates' input
@@ -708,100 +707,126 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   const size_t plane = (size_t)(T + 1) * N;
   const uint32_t lo = rec_at(j, 4 * g4);  // + 16 mt: first of the lane's four contiguous samples (32-bit
                                                     // offsets from a uniform block base: no 64-bit address registers)
-  auto load = [&](StepIn &in, uint32_t t) {
+  auto load = [&](HalfIn &in, uint32_t t, int mt) {
     const size_t blk = (size_t)t * tiles + tile;
     const float *__restrict__ ab = act + blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + blk * DPRE_ARR * GH * TL;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const uint32_t o = lo + REC_HALF * mt;
-      in.r[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_R * GH * TL) + o);
-      in.z[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_Z * GH * TL) + o);
-      in.n[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_N * GH * TL) + o);
-      in.ghn[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_GHN * GH * TL) + o);
-      in.hp[mt] = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
-      in.da1[mt] = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + o);
-      in.end[mt] = *reinterpret_cast<const uint32_t *>(tr.flag + ((size_t)t * N + lane0) + (uint32_t)(16 * mt + 4 * g4));
-    }
-    if (threadIdx.x < TL * D && t > 0)
-      in.x = tr.obs[(size_t)(threadIdx.x / TL) * plane + (size_t)(t - 1) * N + lane0 + (threadIdx.x % TL)];
+    const uint32_t o = lo + REC_HALF * mt;
+    in.r = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_R * GH * TL) + o);
+    in.z = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_Z * GH * TL) + o);
+    in.n = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_N * GH * TL) + o);
+    in.ghn = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_GHN * GH * TL) + o);
+    in.hp = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
+    in.da1 = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + o);
+    in.end = *reinterpret_cast<const uint32_t *>(tr.flag + ((size_t)t * N + lane0) + (uint32_t)(16 * mt + 4 * g4));
   };
-  StepIn in;
-  if (threadIdx.x < TL * D)
-    xS[(T - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] =
-        tr.obs[(size_t)(threadIdx.x / TL) * plane + (size_t)(T - 1) * N + lane0 + (threadIdx.x % TL)];
-  load(in, T - 1);
-  __syncthreads();
-  f32x4 dhc[2];
+  const bool x_thread = threadIdx.x < TL * D;
+  auto load_x = [&](uint32_t t) {  // feature (tid / TL) of sample (tid % TL) of step t
+    return tr.obs[(size_t)(threadIdx.x / TL) * plane + (size_t)t * N + lane0 + (threadIdx.x % TL)];
+  };
+  f32x4 dhc[2], acc[2];  // dhc: d h flowing in from step t + 1; acc: d h_prev of the M-tile — the direct term dh z, then
+                          // the K = 384 product
   dhc[0] = dhc[1] = (f32x4){0, 0, 0, 0};
-  for (uint32_t t = T; t-- > 0;) {
+  // gate gradients of one M-tile of step t: pieces into the image rows of that M-tile, the three arrays the weight-gradient
+  // kernel reads, the direct term of d h_prev, the n gate's input-side sums
+  auto gates = [&](const HalfIn &in, uint32_t t, int mt) {
     float *__restrict__ db = dpre + ((size_t)t * tiles + tile) * DPRE_ARR * GH * TL;
-    f32x4 acc[2];  // d h_prev: starts as the direct term dh z, then the K = 384 product is added (two interleaved
-                   // chains keep the matrix pipe at full rate)
-    if (threadIdx.x < TL * D && t > 0) xS[(t - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] = in.x;
+    f32x4 grv, gzv, gnrv;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      f32x4 grv, gzv, gnrv;
+    for (int i = 0; i < 4; ++i) {
+      const int m = 16 * mt + 4 * g4 + i;
+      const float rr = in.r[i], zz = in.z[i], nn = in.n[i];
+      const bool ended = ((in.end >> (8 * i)) & 0xffu) != RL_SUCC_CONTINUE;
+      const float dh = (ended ? 0.0f : dhc[mt][i]) + in.da1[i];
+      const float dzg = dh * (in.hp[i] - nn);
+      const float dn = dh * (1.0f - zz);
+      const float dpn = dn * (1.0f - nn * nn);
+      const float dr = dpn * in.ghn[i];
+      grv[i] = dr * rr * (1.0f - rr);
+      gzv[i] = dzg * zz * (1.0f - zz);
+      gnrv[i] = dpn * rr;
+      acc[mt][i] = dh * zz;
+      dbin += dpn;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = 16 * mt + 4 * g4 + i;
-        const float rr = in.r[mt][i], zz = in.z[mt][i], nn = in.n[mt][i];
-        const bool ended = ((in.end[mt] >> (8 * i)) & 0xffu) != RL_SUCC_CONTINUE;
-        const float dh = (ended ? 0.0f : dhc[mt][i]) + in.da1[mt][i];
-        const float dzg = dh * (in.hp[mt][i] - nn);
-        const float dn = dh * (1.0f - zz);
-        const float dpn = dn * (1.0f - nn * nn);
-        const float dr = dpn * in.ghn[mt][i];
-        grv[i] = dr * rr * (1.0f - rr);
-        gzv[i] = dzg * zz * (1.0f - zz);
-        gnrv[i] = dpn * rr;
-        acc[mt][i] = dh * zz;
-        dbin += dpn;
+      for (int d = 0; d < D; ++d) dwin[d] = __builtin_fmaf(dpn, xS[t & 1][m][d], dwin[d]);
+      const float gv[3] = {grv[i], gzv[i], gnrv[i]};
 #pragma unroll
-        for (int d = 0; d < D; ++d) dwin[d] = __builtin_fmaf(dpn, xS[t & 1][m][d], dwin[d]);
-        const float gv[3] = {grv[i], gzv[i], gnrv[i]};
-#pragma unroll
-        for (int gte = 0; gte < 3; ++gte) {
-          uint32_t p0, p1, p2;
-          bt::split3(gv[gte], p0, p1, p2);
-          gP[0][m][gte * GH + j] = (unsigned short)p0;
-          gP[1][m][gte * GH + j] = (unsigned short)p1;
-          gP[2][m][gte * GH + j] = (unsigned short)p2;
-        }
+      for (int gte = 0; gte < 3; ++gte) {
+        uint32_t p0, p1, p2;
+        bt::split3(gv[gte], p0, p1, p2);
+        gP[0][m][gte * GH + j] = (unsigned short)p0;
+        gP[1][m][gte * GH + j] = (unsigned short)p1;
+        gP[2][m][gte * GH + j] = (unsigned short)p2;
       }
-      const uint32_t o = lo + REC_HALF * mt;
-      *reinterpret_cast<f32x4 *>(db + (uint32_t)(0 * GH * TL) + o) = grv;
-      *reinterpret_cast<f32x4 *>(db + (uint32_t)(1 * GH * TL) + o) = gzv;
-      *reinterpret_cast<f32x4 *>(db + (uint32_t)(3 * GH * TL) + o) = gnrv;  // (array 2, d pre_n, stays on chip)
     }
-    if (t > 0) load(in, t - 1);  // lands under the products below
-    __syncthreads();  // the image of step t is complete
-    // operand reads one (k-block, M-tile) ahead of the products, and no further (the scheduler would otherwise
-    // hoist more reads than the register budget holds)
-    auto frags = [&](int it, Frag (&a)[3]) {
-      const int kb = it >> 1, mt = it & 1;
+    const uint32_t o = lo + REC_HALF * mt;
+    *reinterpret_cast<f32x4 *>(db + (uint32_t)(0 * GH * TL) + o) = grv;
+    *reinterpret_cast<f32x4 *>(db + (uint32_t)(1 * GH * TL) + o) = gzv;
+    *reinterpret_cast<f32x4 *>(db + (uint32_t)(3 * GH * TL) + o) = gnrv;  // (array 2, d pre_n, stays on chip)
+  };
+  // acc[mt] += W_hh^T (gate gradients of M-tile mt): twelve k-blocks, the last three with their weights from LDS
+  auto products = [&](int mt) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[p].x = *reinterpret_cast<const uint4 *>(&gP[p][16 * mt + n16][32 * kb + 8 * g4]);
-    };
-    Frag fa[2][3];
-    frags(0, fa[0]);
+    for (int kb = 0; kb < KB; ++kb) {
+      Frag fa[3];
 #pragma unroll
-    for (int it = 0; it < 2 * KB; ++it) {
-      if (it + 1 < 2 * KB) frags(it + 1, fa[(it + 1) & 1]);
-      if ((it >> 1) < KB - KBL) {
-        acc[it & 1] = mfma_pieces(fa[it & 1], wT[(it >> 1) < KB - KBL ? (it >> 1) : 0], acc[it & 1]);
+      for (int p = 0; p < 3; ++p) fa[p].x = *reinterpret_cast<const uint4 *>(&gP[p][16 * mt + n16][32 * kb + 8 * g4]);
+      if (kb < KB - KBL) {
+        acc[mt] = mfma_pieces(fa, wT[kb < KB - KBL ? kb : 0], acc[mt]);
       } else {
         Frag wl[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) wl[q].x = wTS[(it >> 1) - (KB - KBL)][q][wave][lane];
-        acc[it & 1] = mfma_pieces(fa[it & 1], wl, acc[it & 1]);
+        for (int q = 0; q < 3; ++q) wl[q].x = wTS[kb - (KB - KBL)][q][wave][lane];
+        acc[mt] = mfma_pieces(fa, wl, acc[mt]);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
-    dhc[0] = acc[0];
-    dhc[1] = acc[1];
-    __syncthreads();  // every wave has read the image: step t - 1 may overwrite it
+    dhc[mt] = acc[mt];
+  };
+  // The two M-tiles of a step are half a step apart: the product of an M-tile needs the gate gradients of ITS 16 samples
+  // of all units and nothing of the other M-tile's, so
+  //   phase 1 of step t: products of M-tile 0 (step t)  | gate gradients of M-tile 1 (step t)
+  //   phase 2 of step t: products of M-tile 1 (step t)  | gate gradients of M-tile 0 (step t - 1)
+  // with a barrier after each — the matrix pipe and the vector ALU work side by side in both (one phase for the gradients
+  // of both M-tiles and one for both products, as before, added the two up: 7.2 µs per step).  In program order the
+  // products come first: their image reads then precede the gates' image writes (other rows, which the compiler cannot
+  // tell apart) and the matrix instructions may sink between the gate arithmetic.
+  HalfIn inA, inB;  // M-tile 0 of the step whose gates come next, M-tile 1 likewise
+  float xin = 0.0f;
+  if (x_thread) xS[(T - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] = load_x(T - 1);
+  load(inA, T - 1, 0);
+  load(inB, T - 1, 1);
+  if (x_thread && T > 1) xin = load_x(T - 2);
+  __syncthreads();
+  gates(inA, T - 1, 0);
+  if (T > 1) load(inA, T - 2, 0);
+  __syncthreads();
+  for (uint32_t t = T; t-- > 0;) {
+    if (x_thread && t > 0) xS[(t - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] = xin;  // the features of step t - 1
+    if (x_thread && t > 1) xin = load_x(t - 2);
+    // (the two waves of a SIMD — w and w + 4 — take the two jobs of a phase in opposite order, so that at any time one
+    // feeds the matrix pipe and the other the vector ALU: inside a wave the scheduler keeps the two jobs apart)
+    if (wave < W16 / 2) {
+      products(0);
+      __builtin_amdgcn_sched_barrier(0);
+      gates(inB, t, 1);
+    } else {
+      gates(inB, t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      products(0);
+    }
+    if (t > 0) load(inB, t - 1, 1);
+    __syncthreads();  // rows 16-31 of the image of step t are complete; rows 0-15 have been read
+    if (wave < W16 / 2) {
+      products(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) gates(inA, t - 1, 0);
+    } else {
+      if (t > 0) gates(inA, t - 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      products(1);
+    }
+    if (t > 1) load(inA, t - 2, 0);
+    __syncthreads();  // rows 0-15 of the image of step t - 1 are complete; rows 16-31 have been read
   }
   // ---- this tile's row of partials: the n gate's rows of W_ih and b_ih (the four lane groups of a wave hold
   // different samples of the same unit)
