@@ -45,9 +45,7 @@ using bt::Frag;
 // 1.8e-8).  PIECE_ORDER 5 multiplies all nine.
 constexpr int PIECE_ORDER = 3;
 constexpr int PIECE_PAIRS = PIECE_ORDER == 3 ? 6 : PIECE_ORDER == 4 ? 8 : 9;
-#ifndef LSTM_VALU_PER_MFMA
-#define LSTM_VALU_PER_MFMA 6
-#endif
+constexpr int LSTM_VALU_PER_MFMA = 6;  // ... of the LSTM's (0, 4, 6, 8 measured: no difference; its schedule is decided by the order of its phases' jobs)
 constexpr int VALU_PER_MFMA = 4;  // vector instructions the forward's schedule places after each matrix instruction  // vector instructions the schedule of the forward places between two matrix instructions
 // Piece images [sample][unit] in LDS: rows of GH halfwords (256 bytes — the width of the LDS), the 16-byte chunk c of
 // row m stored at chunk (c + img_rot(m)) & 15.  A ds_read_b128 is served in four groups of sixteen lanes that are NOT
