@@ -35,6 +35,8 @@ bash scripts/pmc_passes.sh "${TAG}_dqn" scripts/dqn_config3.py 4096 1221 3 > "$O
 cp "gpurun_out/pmc/${TAG}_dqn/summary.json" "$OUT/pmc_dqn_summary.json" 2>/dev/null
 bash scripts/pmc_passes.sh "${TAG}_gru" scripts/gru_config5.py 16384 100 8 1 > "$OUT/pmc_gru.log" 2>&1 || echo "pmc gru failed"
 cp "gpurun_out/pmc/${TAG}_gru/summary.json" "$OUT/pmc_gru_config5_summary.json" 2>/dev/null
+bash scripts/pmc_passes.sh "${TAG}_lstm" scripts/lstm_config5.py 16384 100 8 1 > "$OUT/pmc_lstm.log" 2>&1 || echo "pmc lstm failed"
+cp "gpurun_out/pmc/${TAG}_lstm/summary.json" "$OUT/pmc_lstm_config5_summary.json" 2>/dev/null
 # the other configurations: DQN (config 3) with its kernel trace, GRU (config 5), the general MLP period and its passes
 python3 scripts/dqn_config3.py > "$OUT/dqn_config3.json" 2> "$OUT/dqn_config3.err" || echo "dqn failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_dqn" -- python3 scripts/dqn_config3.py 4096 1221 3 \
