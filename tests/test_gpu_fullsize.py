@@ -255,12 +255,14 @@ def test_config3_replay_invariants_and_samplers(engine):
     assert np.isfinite(st.loss_last) and st.global_steps == total * n
 
 
-def test_config5_rollout_slices_and_update(engine):
-    """configs[4]: 16,384 Chain lanes under LatentStepLimit(100), GRU policy, T = 100"""
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_config5_rollout_slices_and_update(engine, cell):
+    """configs[4]: 16,384 Chain lanes under LatentStepLimit(100), GRU policy (and the same chain with the LSTM cell), T = 100"""
     n, Tc = 16384, 100
-    gs = O.GruShape(5, 128, 128, 2)
+    gs = O.GruShape(5, 128, 128, 2) if cell == "gru" else O.LstmShape(5, 128, 128, 2)
     env = ra.ChainEnv(engine, n, max_steps=100, seed_env=3, seed_actor=4)
-    pol, cri = ra.GruMlp(engine, 5, 2), ra.GruMlp(engine, 5, 1)
+    Mod = ra.GruMlp if cell == "gru" else ra.LstmMlp
+    pol, cri = Mod(engine, 5, 2), Mod(engine, 5, 1)
     pol.init(11)
     cri.init(12)
     traj = ra.Trajectory(engine, n, Tc, 5)
