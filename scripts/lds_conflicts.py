@@ -77,6 +77,19 @@ def patterns():
                 cycles("read_b128", lambda l: wimg(l & 31, 8 * (l >> 5))), 4))
     out.append(("weight-gradient [row][16] staging write", "write_b64",
                 cycles("write_b64", lambda l: wimg(l >> 2, 4 * (l & 3))), 4))
+    # k_lstm_bptt (kernels_seq_bwd.hip): gate deltas [sample][unit] in f32, rows of 228 floats, unit j at column
+    # 64 (j / 32) + j % 32; operand read: lane (n16 = sample row, g4 = unit quarter), 16 bytes = four consecutive units
+    def bg(m, j):
+        return 4 * (m * 228 + 64 * (j // 32) + j % 32)
+
+    for mt in range(2):
+        for k4 in (0, 3, 7):
+            out.append((f"LSTM backward [sample][unit] f32 operand read, M-tile {mt}, unit chunk {k4}", "read_b128",
+                        cycles("read_b128", lambda l: bg(16 * mt + (l & 15), 32 * (l >> 4) + 4 * k4)), 4))
+        for i in range(4):
+            for w in (0, 5):
+                out.append((f"LSTM backward [sample][unit] f32 delta write, M-tile {mt}, sample slot {i}, wave {w}",
+                            "write_b32", cycles("write_b32", lambda l: bg(16 * mt + 4 * (l >> 4) + i, 16 * w + (l & 15))), 2))
     return out
 
 

@@ -1,4 +1,5 @@
-"""The LDS piece-image layouts of kernels_seq_train.hip are conflict-free under the gfx950 banking rules
+"""The LDS piece-image layouts of kernels_seq_train.hip (and the f32 delta image of k_lstm_bptt, kernels_seq_bwd.hip) are
+conflict-free under the gfx950 banking rules
 (MI355X_MICROARCH.md, LDS: ds_read_b128 is served in four NON-contiguous groups of sixteen lanes).  The address
 functions are restated in scripts/lds_conflicts.py; the device side is checked by SQ_LDS_BANK_CONFLICT = 0 in
 profiles/r02_pmc_gru_config5_summary.json."""
@@ -22,3 +23,10 @@ def test_padded_rows_conflict_under_the_real_groups():
 def test_every_pattern_is_conflict_free():
     for name, kind, got, free in L.patterns():
         assert got == free, (name, kind, got, free)
+
+
+def test_the_lstm_backward_image_before_and_after():
+    # rows of 132 floats with the units in order (the first 16-byte-read layout tried): reads at twice their cycles
+    assert L.cycles("read_b128", lambda l: 4 * ((l & 15) * 132 + 32 * (l >> 4))) == 8
+    # 228-float rows with the unit quarters 64 columns apart: free (also asserted through patterns())
+    assert L.cycles("read_b128", lambda l: 4 * ((l & 15) * 228 + 64 * (l >> 4))) == 4
