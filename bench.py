@@ -62,6 +62,11 @@ def parse_args():
     ap.add_argument("--serial-update", action="store_true",
                     help="run the TRPO chain and the critic chain of every period one after the other on one stream "
                          "(default: side by side on two streams, rl_actor_critic_update)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="start period k+1's rollout under period k's critic chain (rl_actor_critic_update_begin / "
+                         "_finish over a pair of trajectories).  Off by default: it buys nothing on this part — a critic "
+                         "step is one 8-wave x 252-register workgroup per CU and cannot be placed on a CU that holds a "
+                         "rollout wave, so the two take turns (DESIGN 7b, profiles/r05_pipeline_timeline_8192.csv)")
     ap.add_argument("--cpu-sample-steps", type=int, default=262144,
                     help="total env-steps of the bounded CPU-baseline sample (split over the host cores)")
     return ap.parse_args()
@@ -229,7 +234,9 @@ def main():
     policy.init(2)   # every rank initialises identical replicas from the same stream
     critic.init(3)
     opt = ra.Adam(critic)
-    traj = ra.Trajectory(eng, n_local, T, 5)
+    # a pair of trajectories: period k + 1's rollout fills one while period k's critic chain still reads the other
+    pipelined = args.pipeline and not args.serial_update
+    trajs = [ra.Trajectory(eng, n_local, T, 5) for _ in range(2 if pipelined else 1)]
     trpo_cfg = ra.trpo_config_default()
     gamma = min(0.99, 0.99)  # min(max_discount_factor, env discount) (critics/opt.rs:73)
     critic_cfg = ra.values_opt_config_default()  # ValuesOptConfig::default: reward-to-go targets
@@ -238,12 +245,31 @@ def main():
 
     last = {}
 
-    def period():
-        ra.rollout(env, policy, traj)
-        ra.gae(traj, critic, gamma, 0.95)
-        # policy.update and critic.update of ActorCriticAgent::batch_update_slice (actor_critic.rs:196-208): independent
-        # given the trajectory and its advantages, so the engine runs the two launch chains side by side on two streams
-        last["trpo"], last["critic"] = ra.actor_critic_update(policy, critic, opt, traj, trpo_cfg, critic_cfg)
+    def periods(count, before_period=None):
+        """`count` whole periods: exactly `count` rollouts, advantage passes, TRPO updates and critic updates, nothing in
+        flight before or after.  Period k + 1's rollout needs only the policy TRPO k produced (the actors of the next
+        collection snapshot the policy: agents/mod.rs:48-59), so it is enqueued as soon as that chain has finished —
+        under critic chain k, which still reads the other trajectory of the pair; rl_gae of k + 1 then waits for chain k
+        on the device.  The first rollout of a call has nothing to hide under."""
+        pending = None
+        for k in range(count):
+            if before_period is not None:
+                before_period(k)
+            traj = trajs[k % len(trajs)]
+            ra.rollout(env, policy, traj)
+            ra.gae(traj, critic, gamma, 0.95)
+            if pending is not None:
+                last["critic"] = ra.actor_critic_update_finish(pending)
+            # policy.update and critic.update of ActorCriticAgent::batch_update_slice (actor_critic.rs:196-208):
+            # independent given the trajectory and its advantages, so the engine runs the two launch chains side by
+            # side on two streams and hands control back when the policy chain is done
+            last["trpo"] = ra.actor_critic_update_begin(policy, critic, opt, traj, trpo_cfg, critic_cfg)
+            pending = traj
+            if not pipelined:
+                last["critic"] = ra.actor_critic_update_finish(pending)
+                pending = None
+        if pending is not None:
+            last["critic"] = ra.actor_critic_update_finish(pending)
 
     def barrier():
         # eng.sync() = hipStreamSynchronize(engine stream) + hipDeviceSynchronize(); torch.cuda.synchronize() is the
@@ -255,8 +281,7 @@ def main():
             torch.cuda.synchronize(device)
         eng.sync()
 
-    for _ in range(args.warmup):
-        period()
+    periods(args.warmup)
     barrier()
     # Per-kernel HIP events (two per launch) cost ~2 ms of host time per period when they wrap all ~220 launches, so
     # they are switched on for the LAST `--profile-steps` periods of the timed region only; `roofline` / `phases`
@@ -265,13 +290,14 @@ def main():
     eng.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    def switch_to_profiling(k):
         if prof_steps and k == args.steps - prof_steps:
             # the profiled period(s) run the two chains one after the other: a launch timed by events on its stream while
             # another stream's kernels share the CUs would not be that kernel's duration (`roofline`, `phases`)
             eng.profile_enable(True)
             eng.set_serial_update(True)
-        period()
+
+    periods(args.steps, switch_to_profiling)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read(reset=True) if not args.no_kernel_profile else None
@@ -477,6 +503,9 @@ def main():
                 "update_chains": ("policy and critic chains one after the other" if args.serial_update else
                                   "policy and critic chains side by side on two streams (the %d profiled period(s) of "
                                   "the timed region run them in turn)" % prof_steps),
+                "pipeline": ("period k+1's rollout enqueued after TRPO k, under critic chain k (two trajectories; %d of "
+                             "the %d timed rollouts have a chain to hide under)" % (
+                                 max(args.steps - prof_steps - 1, 0), args.steps) if pipelined else "none"),
                 "parallelism": "env-sharded x%d + %s" % (world, {"none": "no collective (one rank)", "rccl": "RCCL all-reduce",
                                                                "ipc": "single-launch all-reduce over peer-mapped mailboxes",
                                                                "gloo": "host-staged all-reduce over gloo (fallback)"}[comm_kind]),

@@ -464,6 +464,28 @@ int32_t rl_actor_critic_update(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_o
                                const rl_trpo_config *policy_cfg, const rl_values_opt_config *critic_cfg,
                                rl_trpo_stats *policy_stats, rl_critic_stats *critic_stats /* may be NULL */,
                                float *critic_losses_out /* may be NULL */);
+/* The same update in two halves, so that the NEXT collection period can start under the critic chain.  The next
+ * period's actors depend on the updated policy only (`agent.actor(mode)` snapshots the policy, src/agents/mod.rs:48-59;
+ * train_parallel hands those actors to its workers, src/simulation/train.rs:98-151); the critic is next read when the
+ * following batch's advantages are formed (actor_critic.rs:190-194).
+ *   _begin   enqueues the critic chain on the auxiliary stream, runs the TRPO chain to its end on the main stream and
+ *            returns `policy_stats` — the critic chain may still be in flight.
+ *   between  rl_rollout(env, policy, OTHER trajectory) runs beside the critic chain.  Every other entry point of the
+ *            engine (and a rollout into the SAME trajectory, or with the critic as its policy) is ordered behind the
+ *            chain by a device-side wait: nothing can observe a half-updated critic, the calls just do not overlap.
+ *   _finish  waits for the chain and returns its statistics.  Exactly one update may be pending per engine
+ *            (RL_ERR_INVALID_ARGUMENT otherwise; _finish without _begin likewise).
+ * rl_actor_critic_update is _begin followed by _finish.  Every number is the one the sequential calls produce: the
+ * halves reorder launches across streams, never arithmetic (tests/test_gpu_parity.py).  When the chains cannot run
+ * side by side (see above) _begin runs both to the end and _finish only hands the statistics over.
+ * A NaN policy step (RL_ERR_OPT_NAN) is raised by _begin and ends the update (nothing stays pending); in the
+ * side-by-side form the critic chain has then already advanced the critic and its optimiser state — the reference,
+ * panicking inside policy.update, never reaches critic.update; in the sequential form neither does this library. */
+int32_t rl_actor_critic_update_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_opt, rl_traj *traj,
+                                     const rl_trpo_config *policy_cfg, const rl_values_opt_config *critic_cfg,
+                                     rl_trpo_stats *policy_stats);
+int32_t rl_actor_critic_update_finish(rl_traj *traj, rl_critic_stats *critic_stats /* may be NULL */,
+                                      float *critic_losses_out /* may be NULL */);
 /* 1: rl_actor_critic_update runs its two chains one after the other on the main stream (A/B runs, per-kernel timing) */
 int32_t rl_engine_set_serial_update(rl_engine *engine, int32_t serial);
 

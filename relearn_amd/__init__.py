@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "rl_trpo_config_default", "rl_trpo_update", "rl_policy_gradient", "rl_policy_fvp", "rl_policy_loss_kl",
     "rl_adam_config_default", "rl_adam_create", "rl_adam_destroy", "rl_adam_step_host",
     "rl_critic_update", "rl_critic_gradient", "rl_values_opt_config_default", "rl_values_opt_update",
-    "rl_actor_critic_update", "rl_engine_set_serial_update",
+    "rl_actor_critic_update", "rl_actor_critic_update_begin", "rl_actor_critic_update_finish", "rl_engine_set_serial_update",
     "rl_ppo_config_default", "rl_ppo_update", "rl_reinforce_update", "rl_reward_to_go",
     "rl_actor_to_cbor", "rl_module_from_cbor", "rl_tensor_def_to_cbor", "rl_tensor_def_from_cbor",
     "rl_indexed_type_space_to_cbor",
@@ -743,6 +743,27 @@ def actor_critic_update(policy, critic, critic_opt, traj, trpo_cfg=None, critic_
                                         C.byref(pst), C.byref(cst),
                                         losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
     return (pst, cst, losses[:K]) if want_losses else (pst, cst)
+
+
+def actor_critic_update_begin(policy, critic, critic_opt, traj, trpo_cfg=None, critic_cfg=None):
+    """first half of actor_critic_update: returns the TRPO statistics with the critic chain possibly still in flight on
+    the auxiliary stream (a rollout into ANOTHER trajectory may run beside it); actor_critic_update_finish ends it"""
+    trpo_cfg = trpo_cfg if trpo_cfg is not None else trpo_config_default()
+    critic_cfg = critic_cfg if critic_cfg is not None else values_opt_config_default()
+    pst = TrpoStats()
+    _check(lib().rl_actor_critic_update_begin(policy.h, critic.h, critic_opt.h, traj.h, C.byref(trpo_cfg),
+                                              C.byref(critic_cfg), C.byref(pst)), traj.eng.h)
+    traj._pending_steps = int(critic_cfg.opt_steps_per_update)
+    return pst
+
+
+def actor_critic_update_finish(traj, want_losses=False):
+    cst = CriticStats()
+    K = getattr(traj, "_pending_steps", 0)
+    losses = np.zeros(max(K, 1), dtype=np.float32)
+    _check(lib().rl_actor_critic_update_finish(traj.h, C.byref(cst),
+                                               losses.ctypes.data_as(C.c_void_p) if want_losses else None), traj.eng.h)
+    return (cst, losses[:K]) if want_losses else cst
 
 
 def critic_gradient(critic, traj):

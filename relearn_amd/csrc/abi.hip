@@ -667,6 +667,7 @@ int32_t rl_env_destroy(rl_env *env) {
   if (!env) return RL_OK;
   (void)hipSetDevice(env->eng->device);
   (void)hipStreamSynchronize(env->eng->stream);
+  (void)hipStreamSynchronize(env->eng->aux_stream);
   env_release_device(env);
   rl_engine *eng = env->eng;
   delete env;
@@ -1115,6 +1116,7 @@ int32_t rl_mlp_destroy(rl_mlp *m) {
   if (!m) return RL_OK;
   (void)hipSetDevice(m->eng->device);
   (void)hipStreamSynchronize(m->eng->stream);
+  (void)hipStreamSynchronize(m->eng->aux_stream);  // (a critic chain left in flight by rl_actor_critic_update_begin)
   dfree(m->d_params);
   if (m->exec) {
     dfree(m->exec->d_params);
@@ -1408,6 +1410,7 @@ int32_t rl_traj_destroy(rl_traj *t) {
   (void)hipSetDevice(t->eng->device);
   (void)hipStreamSynchronize(t->eng->main_stream);
   (void)hipStreamSynchronize(t->eng->aux_stream);
+  if (t->eng->pending.traj == t) t->eng->pending.active = false;  // (its pending update dies with it)
   void *ptrs[] = {t->d.obs, t->d.action, t->d.reward, t->d.flag, t->d.term_obs, t->d.values, t->d.adv, t->d.rtg,
                   t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
                   t->losses, t->trpo, t->td, t->aux_slabA, t->aux_slabB, t->aux_vec};
@@ -1529,6 +1532,10 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   return guarded(env ? env->eng : nullptr, [&] {
     RL_REQUIRE(env && policy && traj, "NULL argument");
     RL_REQUIRE(env->eng == traj->eng && env->eng == policy->eng, "handles belong to different engines");
+    // A critic chain left in flight by rl_actor_critic_update_begin reads its own trajectory and the critic: a rollout
+    // into ANOTHER trajectory touches neither (it reads the policy the TRPO chain has already finished with) and goes
+    // ahead beside it on the main stream; anything else waits for the chain like every other call.
+    if (traj == env->eng->pending.traj || policy == env->eng->pending.critic) engine_settle(env->eng);
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
     if (policy->general) {  // any hidden_sizes: one launch sequence per step, either env family (advances t_global)
@@ -1551,7 +1558,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
       launch_rollout(env, policy, traj);
     }
     env->t_global += traj->d.T;
-  });
+  }, false);
 }
 
 int32_t rl_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {

@@ -182,6 +182,7 @@ int32_t rl_dqn_destroy(rl_dqn *q) {
   if (!q) return RL_OK;
   (void)hipSetDevice(q->eng->device);
   (void)hipStreamSynchronize(q->eng->stream);
+  (void)hipStreamSynchronize(q->eng->aux_stream);
   dqn_release_device(q);
   rl_engine *eng = q->eng;
   delete q;

@@ -17,9 +17,20 @@
 // ---------------------------------------------------------------- error plumbing
 extern thread_local std::string g_last_error_no_engine;  // abi.hip
 
+// rl_actor_critic_update_begin may have left a critic chain in flight on the auxiliary stream.  Whatever an entry point
+// enqueues on the main stream is ordered behind that chain (a device-side wait, no host synchronisation) — except the
+// calls that say they handle it themselves (`settle` false: a rollout into another trajectory, _finish).
+static inline void engine_settle(rl_engine *e) {
+  if (e->pending.active && !e->pending.joined) {
+    RL_HIP_CHECK(hipStreamWaitEvent(e->main_stream, e->ev_join, 0));
+    e->pending.joined = true;
+  }
+}
+
 template <typename F>
-static inline int32_t guarded(rl_engine *eng, F &&f) {
+static inline int32_t guarded(rl_engine *eng, F &&f, bool settle = true) {
   try {
+    if (eng != nullptr && settle) engine_settle(eng);
     f();
     if (eng != nullptr) {
       // a kernel that could not be launched (bad configuration, out of resources) leaves only a sticky error behind

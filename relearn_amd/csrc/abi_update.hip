@@ -1,4 +1,6 @@
 // abi_update.hip — extern "C" entry points of include/relearn_hip.h, part: policy / critic updates (TRPO, PPO, REINFORCE, value fitting) (host side only; kernels live in kernels_*.hip).
+#include <chrono>
+
 #include "abi_internal.hpp"
 
 extern "C" {
@@ -134,9 +136,22 @@ static void run_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *d_v, cons
   rl_allreduce_sum_f32(traj->eng, traj->vec, P);
 }
 
-// Trpo::update (trpo.rs:97-164) on the engine's current stream; synchronises that stream only
-static void trpo_update_impl(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats) {
-  rl_engine *e = traj->eng;
+// Trpo::update (trpo.rs:97-164) on the engine's current stream, in two halves.  The head enqueues everything up to and
+// including the first two line-search candidates — about fifty launches without a host round trip; the tail reads the
+// acceptance flag back every second candidate and collects the statistics.  (rl_actor_critic_update enqueues the other
+// chain's launches between the two: the host is then never the reason one chain's kernels start late.)
+static inline void trpo_candidate(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, uint64_t i, double ratio) {
+  launch_ls_set_params(traj, policy, ratio);
+  run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
+  launch_ls_check(traj, (uint32_t)policy->P, b_total(traj), (int)i, ratio, cfg->max_policy_step_kl);
+}
+
+struct TrpoProgress {
+  uint64_t next = 0;   // line-search candidates [0, next) are enqueued
+  double ratio = 1.0;  // backtrack_ratio.powi(next - 1)
+};
+
+static TrpoProgress trpo_update_head(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg) {
   uint32_t P = (uint32_t)policy->P;
   uint64_t Bt = b_total(traj);
   float reg = (float)cfg->hpv_reg_coeff;
@@ -152,21 +167,30 @@ static void trpo_update_impl(rl_mlp *policy, rl_traj *traj, const rl_trpo_config
   // step size from x^T A x
   run_policy_fvp(policy, traj, traj->cg_x, nullptr);
   launch_step_size(traj, policy, reg, cfg->max_policy_step_kl);
-  // backtracking line search
-  double ratio = 1.0;
-  for (uint64_t i = 0; i < cfg->max_backtracks; ++i) {
-    if (i > 0) ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
-    launch_ls_set_params(traj, policy, ratio);
-    run_policy_eval(policy, traj, &traj->trpo->ls_accepted);
-    launch_ls_check(traj, P, Bt, (int)i, ratio, cfg->max_policy_step_kl);
+  // backtracking line search: the first two candidates
+  TrpoProgress pr;
+  for (; pr.next < cfg->max_backtracks && pr.next < 2; ++pr.next) {
+    if (pr.next > 0) pr.ratio *= cfg->backtrack_ratio;  // backtrack_ratio.powi(i)
+    trpo_candidate(policy, traj, cfg, pr.next, pr.ratio);
+  }
+  return pr;
+}
+
+static void trpo_update_tail(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, TrpoProgress pr,
+                             rl_trpo_stats *stats) {
+  rl_engine *e = traj->eng;
+  double ratio = pr.ratio;
+  for (uint64_t i = pr.next; i < cfg->max_backtracks; ++i) {
     // once a candidate is accepted the remaining iterations are no-ops on the device (every launch tests the flag);
     // reading the flag back every second candidate spares their launches — and, with several ranks, their
     // all-reduces.  Replicas are identical, so every rank leaves the loop at the same iteration.
-    if ((i & 1) == 1 && i + 1 < cfg->max_backtracks) {
+    if ((i & 1) == 0) {
       int32_t accepted = 0;
       d2h(e, &accepted, &traj->trpo->ls_accepted, sizeof(accepted));
       if (accepted != 0) break;
     }
+    ratio *= cfg->backtrack_ratio;
+    trpo_candidate(policy, traj, cfg, i, ratio);
   }
   launch_ls_finalize(traj, policy, cfg->max_policy_step_kl, cfg->accept_violation);
   TrpoStateDev h;
@@ -181,6 +205,10 @@ static void trpo_update_impl(rl_mlp *policy, rl_traj *traj, const rl_trpo_config
   stats->num_backtracks = h.ls_accepted ? (int64_t)h.ls_index : -1;
   stats->status = h.status;
   stats->cg_iterations = h.cg_iters;
+}
+
+static void trpo_update_impl(rl_mlp *policy, rl_traj *traj, const rl_trpo_config *cfg, rl_trpo_stats *stats) {
+  trpo_update_tail(policy, traj, cfg, trpo_update_head(policy, traj, cfg), stats);
 }
 
 static void trpo_raise_nan(const rl_trpo_stats *stats) {
@@ -287,6 +315,7 @@ int32_t rl_adam_destroy(rl_adam *o) {
   if (!o) return RL_OK;
   (void)hipSetDevice(o->eng->device);
   (void)hipStreamSynchronize(o->eng->stream);
+  (void)hipStreamSynchronize(o->eng->aux_stream);  // (a critic chain left in flight by rl_actor_critic_update_begin)
   dfree(o->d_m);
   dfree(o->d_v);
   dfree(o->d_step);
@@ -341,7 +370,7 @@ static void run_critic_gradient(rl_mlp *critic, rl_traj *traj) {
 
 // n_backward_steps (src/torch/agents/mod.rs:35-72) of full-batch MSE against traj->d.tgt with Adam: the launches, on the
 // engine's current stream, without any host synchronisation (feed-forward modules on a device-side collective)
-static void critic_enqueue_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps) {
+static void critic_enqueue_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, uint64_t opt_steps, uint64_t first = 0) {
   RL_REQUIRE(opt_steps <= traj->max_losses, "too many optimisation steps per update");
   uint64_t Bt = b_total(traj);
   // no separate all-reduce between the reduction and the (elementwise) optimiser step: one rank, or the peer-mailbox
@@ -350,7 +379,7 @@ static void critic_enqueue_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, ui
   const bool mailbox = eng->ipc_active && !eng->comm && !eng->loopback && !eng->host_allreduce &&
                        ipc_allreduce_fits(eng, critic->P + 4);
   const bool fused = critic->kind == RL_MODULE_MLP && (!eng->has_collective() || mailbox);
-  for (uint64_t k = 0; k < opt_steps; ++k) {
+  for (uint64_t k = first; k < opt_steps; ++k) {
     if (fused) {  // no all-reduce between the reduction and the (elementwise) optimiser step: one launch
       uint32_t rowsA, rowsB;
       critic_slabs(critic, traj, &rowsA, &rowsB);
@@ -499,48 +528,123 @@ static bool chains_can_overlap(const rl_mlp *policy, const rl_mlp *critic, const
   return true;
 }
 
+// _begin: fork, the whole critic chain onto the auxiliary stream, the TRPO chain on the main stream, the join event
+// recorded — and back to the caller with the critic chain possibly still in flight (engine->pending).
+static void actor_critic_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_opt, rl_traj *traj,
+                               const rl_trpo_config *pcfg, const rl_values_opt_config *ccfg, rl_trpo_stats *pstats) {
+  check_policy(policy, traj);
+  RL_REQUIRE(pcfg && pstats, "NULL argument");
+  check_values_opt(critic, critic_opt, traj, ccfg);
+  RL_REQUIRE(policy != critic, "policy and critic must be different modules");
+  rl_engine *e = traj->eng;
+  RL_REQUIRE(!e->pending.active, "an update is pending on this engine: call rl_actor_critic_update_finish first");
+  const uint64_t K = ccfg->opt_steps_per_update;
+  RL_REQUIRE(K <= traj->max_losses, "too many optimisation steps per update");
+  rl_engine::PendingUpdate &pu = e->pending;
+  pu.traj = traj;
+  pu.critic = critic;
+  pu.steps = K;
+  pu.stats = rl_critic_stats{};
+  pu.losses.assign(K ? K : 1, 0.0f);
+  if (!chains_can_overlap(policy, critic, traj, ccfg)) {
+    // policy.update, then critic.update (actor_critic.rs:196-208).  A NaN policy step is fatal BEFORE the critic moves,
+    // as in the reference (Trpo::update panics inside policy.update)
+    trpo_update_impl(policy, traj, pcfg, pstats);
+    trpo_raise_nan(pstats);
+    values_opt_targets(critic, traj, ccfg);
+    critic_opt_steps(critic, critic_opt, traj, K, &pu.stats, pu.losses.data());
+    pu.active = pu.joined = pu.collected = true;
+    return;
+  }
+  // fork: the auxiliary stream sees everything enqueued so far (rollout, values, advantages)
+  RL_HIP_CHECK(hipEventRecord(e->ev_fork, e->main_stream));
+  RL_HIP_CHECK(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
+  try {
+    // Neither chain has a host round trip before the line search's first read-back, and enqueuing a launch costs the
+    // host a few microseconds: the critic chain's ~160 launches in one go would keep the TRPO chain's first kernel
+    // waiting for the HOST (measured: profiles/r04_overlap_trace_8192.csv, the policy chain starts when the critic
+    // chain is nearly done).  So: a few critic steps to give the device something to do, the TRPO chain's head, the
+    // rest of the critic chain, and only then the TRPO chain's read-backs.
+    const uint64_t K0 = K < 6 ? K : 6;
+    static const bool marks = std::getenv("RELEARN_HOST_MARKS") != nullptr;  // debugging aid: host time of each phase
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = marks ? now() : 0.0;
+    {
+      AuxChain aux(traj);
+      values_opt_targets(critic, traj, ccfg);
+      critic_enqueue_steps(critic, critic_opt, traj, K0);
+    }
+    const double t1 = marks ? now() : 0.0;
+    const TrpoProgress pr = trpo_update_head(policy, traj, pcfg);
+    const double t2 = marks ? now() : 0.0;
+    {
+      AuxChain aux(traj);
+      critic_enqueue_steps(critic, critic_opt, traj, K, K0);
+    }
+    RL_HIP_CHECK(hipEventRecord(e->ev_join, e->aux_stream));
+    const double t3 = marks ? now() : 0.0;
+    trpo_update_tail(policy, traj, pcfg, pr, pstats);  // (its read-backs wait for the main stream only)
+    if (marks)
+      std::fprintf(stderr, "relearn_hip host marks (us): critic head %.0f, trpo head %.0f, critic rest %.0f, trpo tail %.0f\n",
+                   t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  } catch (...) {
+    (void)hipStreamSynchronize(e->aux_stream);  // nothing of this update may still be running when the error returns
+    (void)hipStreamSynchronize(e->main_stream);
+    throw;
+  }
+  pu.active = true;
+  pu.joined = pu.collected = false;
+  if (pstats->status == RL_OPT_NAN_LOSS || pstats->status == RL_OPT_NAN_CONSTRAINT) {
+    // fatal (the reference panics); the critic chain was already in flight beside the policy chain and has advanced the
+    // critic and its optimiser state — the one ordering the side-by-side form cannot keep (include/relearn_hip.h)
+    (void)hipStreamSynchronize(e->aux_stream);
+    pu.active = false;
+    trpo_raise_nan(pstats);
+  }
+}
+
+// _finish: later work on the main stream follows the critic's last step; the chain's losses come back
+static void actor_critic_finish(rl_traj *traj, rl_critic_stats *cstats, float *critic_losses_out) {
+  rl_engine *e = traj->eng;
+  rl_engine::PendingUpdate &pu = e->pending;
+  RL_REQUIRE(pu.active, "no update is pending on this engine");
+  RL_REQUIRE(pu.traj == traj, "the pending update belongs to another trajectory");
+  if (!pu.collected) {
+    engine_settle(e);
+    try {
+      AuxChain aux(traj);  // (the losses were written by the auxiliary chain: read them on its stream)
+      critic_collect(traj, pu.steps, &pu.stats, pu.losses.data());
+    } catch (...) {
+      (void)hipStreamSynchronize(e->aux_stream);
+      pu.active = false;
+      throw;
+    }
+  }
+  pu.active = false;
+  if (cstats) *cstats = pu.stats;
+  if (critic_losses_out && pu.steps) std::memcpy(critic_losses_out, pu.losses.data(), pu.steps * sizeof(float));
+}
+
+int32_t rl_actor_critic_update_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_opt, rl_traj *traj,
+                                     const rl_trpo_config *pcfg, const rl_values_opt_config *ccfg,
+                                     rl_trpo_stats *pstats) {
+  return guarded(traj ? traj->eng : nullptr,
+                 [&] { actor_critic_begin(policy, critic, critic_opt, traj, pcfg, ccfg, pstats); });
+}
+
+int32_t rl_actor_critic_update_finish(rl_traj *traj, rl_critic_stats *cstats, float *critic_losses_out) {
+  return guarded(traj ? traj->eng : nullptr, [&] {
+    RL_REQUIRE(traj, "NULL argument");
+    actor_critic_finish(traj, cstats, critic_losses_out);
+  }, false);
+}
+
 int32_t rl_actor_critic_update(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_opt, rl_traj *traj,
                                const rl_trpo_config *pcfg, const rl_values_opt_config *ccfg, rl_trpo_stats *pstats,
                                rl_critic_stats *cstats, float *critic_losses_out) {
   return guarded(traj ? traj->eng : nullptr, [&] {
-    check_policy(policy, traj);
-    RL_REQUIRE(pcfg && pstats, "NULL argument");
-    check_values_opt(critic, critic_opt, traj, ccfg);
-    RL_REQUIRE(policy != critic, "policy and critic must be different modules");
-    rl_engine *e = traj->eng;
-    const uint64_t K = ccfg->opt_steps_per_update;
-    if (!chains_can_overlap(policy, critic, traj, ccfg)) {
-      // policy.update, then critic.update (actor_critic.rs:196-208); the critic's targets do not depend on the policy
-      trpo_update_impl(policy, traj, pcfg, pstats);
-      values_opt_targets(critic, traj, ccfg);
-      critic_opt_steps(critic, critic_opt, traj, K, cstats, critic_losses_out);
-      trpo_raise_nan(pstats);
-      return;
-    }
-    // fork: the auxiliary stream sees everything enqueued so far (rollout, values, advantages)
-    RL_HIP_CHECK(hipEventRecord(e->ev_fork, e->main_stream));
-    RL_HIP_CHECK(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
-    try {
-      {  // the whole critic chain is enqueued first: no host round trip in it
-        AuxChain aux(traj);
-        values_opt_targets(critic, traj, ccfg);
-        critic_enqueue_steps(critic, critic_opt, traj, K);
-      }
-      trpo_update_impl(policy, traj, pcfg, pstats);  // (its read-backs wait for the main stream only)
-    } catch (...) {
-      (void)hipStreamSynchronize(e->aux_stream);  // nothing of this update may still be running when the error returns
-      (void)hipStreamSynchronize(e->main_stream);
-      throw;
-    }
-    // join: later work on the main stream (the next rollout, values) follows the critic's last step
-    RL_HIP_CHECK(hipEventRecord(e->ev_join, e->aux_stream));
-    RL_HIP_CHECK(hipStreamWaitEvent(e->main_stream, e->ev_join, 0));
-    {
-      AuxChain aux(traj);  // (the losses were written by the auxiliary chain: read them on its stream)
-      critic_collect(traj, K, cstats, critic_losses_out);
-    }
-    if (!cstats && !critic_losses_out) RL_HIP_CHECK(hipStreamSynchronize(e->aux_stream));
-    trpo_raise_nan(pstats);
+    actor_critic_begin(policy, critic, critic_opt, traj, pcfg, ccfg, pstats);
+    actor_critic_finish(traj, cstats, critic_losses_out);
   });
 }
 

@@ -170,6 +170,18 @@ struct rl_engine {
   // rl_actor_critic_update: run the policy chain and the critic chain one after the other on the main stream (what the
   // separate entry points do) instead of side by side on two streams — for A/B measurements and per-kernel profiling
   bool serial_update = false;
+  // rl_actor_critic_update_begin .. _finish: the critic chain of the update on `traj` is (or may still be) in flight on the
+  // auxiliary stream.  `joined`: the main stream already waits for its end (any entry point but a rollout into another
+  // trajectory orders itself behind it: engine_settle).  `collected`: the chains ran in turn inside _begin and the
+  // critic's statistics are already in `stats` / `losses`.
+  struct PendingUpdate {
+    bool active = false, joined = false, collected = false;
+    struct rl_traj *traj = nullptr;
+    const struct rl_mlp *critic = nullptr;
+    uint64_t steps = 0;
+    rl_critic_stats stats{};
+    std::vector<float> losses;
+  } pending;
 };
 
 struct rl_env {

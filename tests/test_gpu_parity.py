@@ -458,6 +458,132 @@ def test_actor_critic_update_equals_the_two_updates_in_turn(engine, n, T, target
     assert ref[0][2]["status"] == ra.OPT_OK and ref[0][4][-1] < ref[0][4][0]
 
 
+def _drop_pending_update(engine):
+    """a failed test must not leave the session's engine with an update pending (the trajectory it belongs to is
+    destroyed with the test's locals, which ends it; a traceback may keep those alive, so end it by hand)"""
+    engine.sync()
+    for t in _LIVE_TRAJS:
+        if t.h:
+            ra.lib().rl_actor_critic_update_finish(t.h, None, None)  # (an error code when nothing is pending on it)
+    del _LIVE_TRAJS[:]
+
+
+_LIVE_TRAJS = []
+
+
+@pytest.mark.parametrize("n,T,target", [(512, 64, ra.VALUE_TARGET_REWARD_TO_GO), (8192, 32, ra.VALUE_TARGET_REWARD_TO_GO),
+                                        (1024, 48, ra.VALUE_TARGET_ONE_STEP_TD)])
+def test_pipelined_periods_equal_the_serial_sequence(engine, n, T, target):
+    """rl_actor_critic_update_begin / _finish: period k + 1's rollout (into the other trajectory of a pair) is enqueued
+    as soon as TRPO k has finished, under critic chain k; rl_gae of k + 1 orders itself behind that chain on the device.
+    The next collection reads only the updated policy (agents/mod.rs:48-59; actor_critic.rs:196-208 orders policy.update
+    before critic.update), so every number over three periods — trajectories, advantages, parameters, statistics,
+    per-step critic losses — is BIT-identical to rollout / rl_gae / rl_trpo_update / rl_values_opt_update in turn."""
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update, ccfg.target = 12, target
+    periods = 3
+
+    def snapshot(traj, pol, cri, pst, cst, losses):
+        return (traj.read_all(), traj.read(ra.TRAJ_ADVANTAGES), pol.get_params(), cri.get_params(), pst.as_dict(),
+                (cst.loss_first, cst.loss_last, cst.steps), losses.copy())
+
+    def run(mode):
+        env = ra.CartPoleEnv(engine, n, max_steps=60, seed_env=21, seed_actor=22)
+        pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+        pol.init(2)
+        cri.init(3)
+        opt = ra.Adam(cri)
+        trajs = [ra.Trajectory(engine, n, T, 5), ra.Trajectory(engine, n, T, 5)]
+        _LIVE_TRAJS.extend(trajs)
+        out = []
+        if mode == "serial":
+            for k in range(periods):
+                tr = trajs[k & 1]
+                ra.rollout(env, pol, tr)
+                ra.gae(tr, cri, 0.99, 0.95)
+                pst = ra.trpo_update(pol, tr)
+                cst, losses = ra.values_opt_update(cri, opt, tr, ccfg, want_losses=True)
+                out.append(snapshot(tr, pol, cri, pst, cst, losses))
+            return out
+        # pipelined: nothing is read back between _begin(k) and the rollout of k + 1 (a read-back would order itself
+        # behind the critic chain: still correct, but no longer the overlapped sequence this test is about)
+        stats = []
+        for k in range(periods):
+            tr = trajs[k & 1]
+            ra.rollout(env, pol, tr)                      # beside critic chain k - 1 (other trajectory)
+            ra.gae(tr, cri, 0.99, 0.95)                   # device-side wait for critic chain k - 1
+            if k > 0:
+                cst, losses = ra.actor_critic_update_finish(trajs[(k - 1) & 1], want_losses=True)
+                stats[-1] += (cst, losses, cri.get_params(), trajs[(k - 1) & 1].read_all(),
+                              trajs[(k - 1) & 1].read(ra.TRAJ_ADVANTAGES))
+            pst = ra.actor_critic_update_begin(pol, cri, opt, tr, None, ccfg)
+            # (reading the policy waits for the main stream only after a settle: do it through the next period's reads)
+            stats.append((pst,))
+        cst, losses = ra.actor_critic_update_finish(trajs[(periods - 1) & 1], want_losses=True)
+        stats[-1] += (cst, losses, cri.get_params(), trajs[(periods - 1) & 1].read_all(),
+                      trajs[(periods - 1) & 1].read(ra.TRAJ_ADVANTAGES))
+        return stats, pol.get_params()
+
+    ref = run("serial")
+    try:
+        got, pol_final = run("pipelined")
+    finally:
+        _drop_pending_update(engine)
+    for k in range(periods):
+        tr0, adv0, p0, c0, s0, k0, l0 = ref[k]
+        pst, cst, losses, c1, tr1, adv1 = got[k]
+        for f in ("action", "flag", "reward", "obs"):
+            assert np.array_equal(tr0[f], tr1[f]), (k, f)
+        assert np.array_equal(adv0, adv1), k
+        assert s0 == pst.as_dict(), k
+        assert k0 == (cst.loss_first, cst.loss_last, cst.steps) and np.array_equal(l0, losses), k
+        # the critic read after _finish(k) of the pipelined run has seen exactly chain k
+        assert np.array_equal(c0, c1), k
+    assert np.array_equal(ref[-1][2], pol_final)
+    assert ref[0][4]["status"] == ra.OPT_OK
+
+
+def test_pending_update_orders_every_other_call_behind_the_critic_chain(engine):
+    """between _begin and _finish: reads of the critic, a rollout into the SAME trajectory and a second _begin — the first
+    two are ordered behind the chain (they see the finished critic / do not corrupt the chain's inputs), the third is an
+    error; _finish without _begin is an error too"""
+    n, T = 2048, 32
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update = 20
+
+    def setup():
+        env = ra.CartPoleEnv(engine, n, max_steps=60, seed_env=5, seed_actor=6)
+        pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+        pol.init(2)
+        cri.init(3)
+        _LIVE_TRAJS.append(ra.Trajectory(engine, n, T, 5))
+        return env, pol, cri, ra.Adam(cri), _LIVE_TRAJS[-1]
+
+    env, pol, cri, opt, traj = setup()
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    _, cst_ref, losses_ref = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
+    cri_ref = cri.get_params()
+
+    env, pol, cri, opt, traj = setup()
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    with pytest.raises(ra.RelearnError):
+        ra.actor_critic_update_finish(traj)
+    ra.actor_critic_update_begin(pol, cri, opt, traj, None, ccfg)
+    try:
+        with pytest.raises(ra.RelearnError):
+            ra.actor_critic_update_begin(pol, cri, opt, traj, None, ccfg)
+        assert np.array_equal(cri.get_params(), cri_ref)  # ordered behind the chain
+        ra.rollout(env, pol, traj)                    # same trajectory: after the chain, so the chain read the old one
+        cst, losses = ra.actor_critic_update_finish(traj, want_losses=True)
+    finally:
+        _drop_pending_update(engine)
+    assert np.array_equal(losses, losses_ref) and cst.loss_last == cst_ref.loss_last
+    with pytest.raises(ra.RelearnError):
+        ra.actor_critic_update_finish(traj)
+
+
 def test_adam_step_matches_oracle(engine):
     m = ra.Mlp(engine, 5, H, 1)
     m.init(9)
