@@ -136,7 +136,28 @@ def main():
                 args.gpus, args.gpus))
         args.gpus = world
 
+    # (multi-process GPU work on this driver stack needs dmabuf IPC: RCCL's peer mappings and the mailbox handles fail
+    # with "hipIpcGetMemHandle: invalid argument" otherwise; must be in the environment before the HIP runtime starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import relearn_amd as ra
+
+    # A multi-rank job that stalls (a collective some rank never joins) must end, and say where: every rank runs a
+    # watchdog that prints the phase it is stuck in and leaves with a non-zero exit instead of holding the node until the
+    # launcher's own limit.  RELEARN_BENCH_TIMEOUT (seconds, default 420) bounds everything after the rendezvous.
+    phase = {"name": "start", "since": time.time()}
+
+    def enter(name):
+        phase["name"], phase["since"] = name, time.time()
+
+    watchdog_all = None
+    if world > 1:
+        import threading
+
+        def stalled():
+            print("bench.py: rank %d of %d: no end after %s s, stuck in phase `%s` for %.0f s — giving up (exit 4)" % (
+                rank, world, os.environ.get("RELEARN_BENCH_TIMEOUT", "420"), phase["name"],
+                time.time() - phase["since"]), file=sys.stderr, flush=True)
+            os._exit(4)
 
     dist = None
     if world > 1:
@@ -144,7 +165,11 @@ def main():
         # collective is RCCL called from the library on its own HIP stream
         import torch
         import torch.distributed as dist
+        enter("rendezvous (gloo control group)")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        watchdog_all = threading.Timer(float(os.environ.get("RELEARN_BENCH_TIMEOUT", "420")), stalled)
+        watchdog_all.daemon = True
+        watchdog_all.start()
 
     assert args.envs % world == 0, "envs must divide evenly over GPUs"
     n_local = args.envs // world
@@ -153,8 +178,10 @@ def main():
     # one process per GPU; RELEARN_BENCH_SINGLE_DEVICE=1 puts every rank on device 0 (a rehearsal of the multi-process
     # path on a one-GPU box, only meaningful with --comm gloo: RCCL refuses two ranks on one device)
     device = 0 if os.environ.get("RELEARN_BENCH_SINGLE_DEVICE") else local_rank
+    enter("engine on device %d" % device)
     eng = ra.Engine(device)
     comm_kind = "none"
+    enter("collective set-up (%s)" % args.comm)
     if world > 1:
         comm_kind = args.comm
         if comm_kind == "ipc":
@@ -227,6 +254,7 @@ def main():
         if comm_kind == "gloo":
             eng.comm_init_host(rank, world, lambda a: dist.all_reduce(torch.from_numpy(a)))
 
+    enter("allocation")
     env = ra.CartPoleEnv(eng, n_local, max_steps=args.max_episode_steps, limit=ra.LIMIT_VISIBLE,
                          lane_offset=rank * n_local, seed_env=0, seed_actor=1)
     policy = ra.Mlp(eng, 5, H, 2)
@@ -281,6 +309,7 @@ def main():
             torch.cuda.synchronize(device)
         eng.sync()
 
+    enter("warm-up periods (%s collective)" % comm_kind)
     periods(args.warmup)
     barrier()
     # Per-kernel HIP events (two per launch) cost ~2 ms of host time per period when they wrap all ~220 launches, so
@@ -289,6 +318,7 @@ def main():
     prof_steps = 0 if args.no_kernel_profile else max(1, min(args.profile_steps, args.steps))
     eng.profile_read(reset=True)
     barrier()
+    enter("timed periods (%s collective)" % comm_kind)
     t0 = time.perf_counter()
     def switch_to_profiling(k):
         if prof_steps and k == args.steps - prof_steps:
@@ -300,6 +330,7 @@ def main():
     periods(args.steps, switch_to_profiling)
     barrier()
     elapsed = time.perf_counter() - t0
+    enter("after the timed region")
     prof = eng.profile_read(reset=True) if not args.no_kernel_profile else None
     eng.profile_enable(False)
     eng.set_serial_update(args.serial_update)
@@ -526,6 +557,8 @@ def main():
             out["value"] = None
             out["invalid"] = "the ranks' parameter replicas differ after the timed region"
         print(json.dumps(out))
+    if watchdog_all is not None:
+        watchdog_all.cancel()
     if dist is not None:
         try:
             eng.comm_destroy()  # every rank releases its communicator before the control group goes away

@@ -199,6 +199,35 @@ void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count) {
   rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 7, 0, comm, e->stream), "ncclAllReduce");
 }
 
+// Settings every rank has to take the same way, decided through the collective that was just installed: an all-reduce
+// that also counts the ranks (a transport that does not reach everybody fails here, not in the first update).
+//   RELEARN_SERIAL_UPDATE in ANY rank's environment -> the update chains run in turn on EVERY rank (a rank running them
+//   side by side would put the critic's collectives on the auxiliary channel, its peers on the main one).
+// rl_engine_set_serial_update is an API call, not an environment: the host program makes it on every rank or on none.
+void comm_agree(rl_engine *e) {
+  const bool mine = std::getenv("RELEARN_SERIAL_UPDATE") != nullptr;
+  if (!e->has_collective()) {
+    e->agreed_serial_env = mine;
+    return;
+  }
+  float h[2] = {mine ? 1.0f : 0.0f, 1.0f};
+  float *d = dalloc<float>(2);
+  try {
+    h2d(e, d, h, sizeof(h));
+    rl_allreduce_sum_f32(e, d, 2);
+    d2h(e, h, d, sizeof(h));
+    ipc_check(e);
+  } catch (...) {
+    dfree(d);
+    throw;
+  }
+  dfree(d);
+  if (h[1] != (float)e->n_ranks)
+    throw RlError(RL_ERR_COMM, "the collective's first all-reduce counted " + std::to_string((int)h[1]) + " of " +
+                                   std::to_string(e->n_ranks) + " ranks");
+  e->agreed_serial_env = h[0] != 0.0f;
+}
+
 extern "C" {
 
 int32_t rl_abi_version(void) { return RL_ABI_VERSION; }
@@ -420,6 +449,7 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
       e->loopback = grp.get();
       e->rank = rank;
       e->n_ranks = n_ranks;
+      e->agreed_serial_env = std::getenv("RELEARN_SERIAL_UPDATE") != nullptr;  // (one process: one environment)
       return;
     }
     if (n_ranks == 1 && !std::getenv("RELEARN_FORCE_RCCL")) return;
@@ -436,30 +466,62 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
     // A second communicator over the same ranks for the auxiliary update chain (rl_actor_critic_update runs the policy
     // and the critic chain on two streams, each with its collectives).  Its unique id is made on rank 0 and handed out
     // through the first communicator — an all-reduce in which only rank 0 contributes (bytes as small integers: exact in
-    // f32) — so the caller's bootstrap stays one id.  Failure is not fatal: without it the two chains run in turn.
-    // RELEARN_NO_AUX_COMM=1 skips it.
-    if (!std::getenv("RELEARN_NO_AUX_COMM")) {
-      float *d_id = nullptr;
+    // f32) — so the caller's bootstrap stays one id.  Whether the job HAS the second communicator is decided
+    // collectively: rank 0 joins the hand-out even when it could not make an id (zeros plus a failure flag), a rank with
+    // RELEARN_NO_AUX_COMM=1 in its environment vetoes for all, and after the attempt the ranks all-reduce their outcome
+    // over the first communicator — one rank without it and every rank drops it (the two chains then run in turn
+    // everywhere: ranks that disagreed would issue the critic's collectives on different communicators and hang).
+    try {
+      const bool want_aux = std::getenv("RELEARN_NO_AUX_COMM") == nullptr;
+      UniqueId id2;
+      std::memset(id2.bytes, 0, sizeof(id2.bytes));
+      bool id_ok = false;
+      if (rank == 0 && want_aux) id_ok = g_rccl.GetUniqueId(id2.bytes) == 0;
+      float h_id[130];
+      for (int i = 0; i < 128; ++i) h_id[i] = rank == 0 && id_ok ? (float)(unsigned char)id2.bytes[i] : 0.0f;
+      h_id[128] = rank == 0 && !id_ok ? 1.0f : 0.0f;  // rank 0 has no id to offer
+      h_id[129] = want_aux ? 0.0f : 1.0f;             // this rank declines
+      float *d_id = dalloc<float>(130);
+      void *comm2 = nullptr;
       try {
-        UniqueId id2;
-        std::memset(id2.bytes, 0, sizeof(id2.bytes));
-        if (rank == 0) rccl_check(g_rccl.GetUniqueId(id2.bytes), "ncclGetUniqueId");
-        float h_id[128];
-        for (int i = 0; i < 128; ++i) h_id[i] = rank == 0 ? (float)(unsigned char)id2.bytes[i] : 0.0f;
-        d_id = dalloc<float>(128);
         h2d(e, d_id, h_id, sizeof(h_id));
-        rccl_check(g_rccl.AllReduce(d_id, d_id, 128, 7, 0, e->comm, e->stream), "ncclAllReduce (second unique id)");
+        rccl_check(g_rccl.AllReduce(d_id, d_id, 130, 7, 0, e->comm, e->stream), "ncclAllReduce (second unique id)");
         d2h(e, h_id, d_id, sizeof(h_id));
-        for (int i = 0; i < 128; ++i) id2.bytes[i] = (char)(unsigned char)h_id[i];
-        void *comm2 = nullptr;
-        rccl_check(init(&comm2, n_ranks, id2, rank), "ncclCommInitRank (auxiliary chain)");
-        e->comm_aux = comm2;
-      } catch (const RlError &err) {
-        e->comm_aux = nullptr;
-        std::fprintf(stderr, "relearn_hip: no second communicator (%s): update chains will run one after the other\n",
-                     err.what());
+        const bool attempt = h_id[128] == 0.0f && h_id[129] == 0.0f;
+        float outcome = 0.0f;
+        if (attempt) {
+          for (int i = 0; i < 128; ++i) id2.bytes[i] = (char)(unsigned char)h_id[i];
+          if (init(&comm2, n_ranks, id2, rank) == 0 && comm2 != nullptr) outcome = 1.0f;
+          else comm2 = nullptr;
+        }
+        h2d(e, d_id, &outcome, sizeof(outcome));
+        rccl_check(g_rccl.AllReduce(d_id, d_id, 1, 7, 0, e->comm, e->stream), "ncclAllReduce (second communicator: outcome)");
+        d2h(e, &outcome, d_id, sizeof(outcome));
+        if (outcome == (float)n_ranks) {
+          e->comm_aux = comm2;
+          comm2 = nullptr;
+        } else {
+          if (rank == 0)
+            std::fprintf(stderr, "relearn_hip: no second communicator (%s): update chains will run one after the other "
+                                 "on every rank\n",
+                         !attempt ? (h_id[129] != 0.0f ? "RELEARN_NO_AUX_COMM on some rank" : "rank 0 could not make an id")
+                                  : "ncclCommInitRank failed on some rank");
+        }
+      } catch (...) {
+        if (comm2) g_rccl.CommDestroy(comm2);
+        dfree(d_id);
+        throw;
       }
+      if (comm2) g_rccl.CommDestroy(comm2);  // created here, but not everywhere
       dfree(d_id);
+      comm_agree(e);
+    } catch (...) {  // the first communicator could not even carry the agreement: no collective at all
+      if (e->comm_aux) g_rccl.CommDestroy(e->comm_aux);
+      g_rccl.CommDestroy(e->comm);
+      e->comm = e->comm_aux = nullptr;
+      e->rank = 0;
+      e->n_ranks = 1;
+      throw;
     }
   });
 }
@@ -473,6 +535,15 @@ int32_t rl_comm_init_host(rl_engine *e, int32_t rank, int32_t n_ranks, rl_host_a
     e->n_ranks = n_ranks;
     e->host_allreduce = fn;
     e->host_allreduce_ctx = ctx;
+    try {
+      comm_agree(e);  // (every rank installs its callback at the same point of the job: the first all-reduce runs here)
+    } catch (...) {
+      e->host_allreduce = nullptr;
+      e->host_allreduce_ctx = nullptr;
+      e->rank = 0;
+      e->n_ranks = 1;
+      throw;
+    }
   });
 }
 

@@ -481,11 +481,23 @@ struct AuxChain {
   rl_engine *e;
   rl_traj *t;
   AuxChain(rl_traj *traj) : e(traj->eng), t(traj) {
-    if (t->aux_vec == nullptr) {
+    if (t->aux_vec == nullptr) {  // all three or none: a failed allocation must not leave a half-made workspace behind
       RL_HIP_CHECK(hipSetDevice(e->device));
-      t->aux_vec = dalloc<float>(t->Pmax + 4);
-      t->aux_slabA = dalloc<double>(t->cap_slabA);
-      t->aux_slabB = dalloc<double>(t->cap_slabB);
+      float *v = nullptr;
+      double *a = nullptr, *b = nullptr;
+      try {
+        v = dalloc<float>(t->Pmax + 4);
+        a = dalloc<double>(t->cap_slabA);
+        b = dalloc<double>(t->cap_slabB);
+      } catch (...) {
+        dfree(v);
+        dfree(a);
+        dfree(b);
+        throw;
+      }
+      t->aux_vec = v;
+      t->aux_slabA = a;
+      t->aux_slabB = b;
       t->aux_cap_slabA = t->cap_slabA;
       t->aux_cap_slabB = t->cap_slabB;
     }
@@ -515,7 +527,8 @@ struct AuxChain {
 static bool chains_can_overlap(const rl_mlp *policy, const rl_mlp *critic, const rl_traj *traj,
                                const rl_values_opt_config *ccfg) {
   const rl_engine *e = traj->eng;
-  if (std::getenv("RELEARN_SERIAL_UPDATE")) return false;
+  // (with several ranks the environment switch is the one the ranks agreed on when the collective was installed)
+  if (e->n_ranks > 1 ? e->agreed_serial_env : std::getenv("RELEARN_SERIAL_UPDATE") != nullptr) return false;
   if (e->serial_update || e->kernel_variant == 1) return false;
   (void)ccfg;
   // (general hidden_sizes keep P-sized vectors and activation planes in workspaces both chains would share)
@@ -523,6 +536,7 @@ static bool chains_can_overlap(const rl_mlp *policy, const rl_mlp *critic, const
     return m->kind == RL_MODULE_MLP && !m->general && traj->d.D == 5 && m->hidden == 128;
   };
   if (!fused_passes(policy) || !fused_passes(critic)) return false;
+  if (policy->P > traj->Pmax || critic->P > traj->Pmax) return false;  // (the auxiliary vector is sized Pmax + 4)
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // (the fused kernels' own limit)
   if (e->comm != nullptr && e->comm_aux == nullptr) return false;
   return true;

@@ -28,11 +28,25 @@
 // atomics), the self-test hammers both slots and every chunk with random payloads, but 8-byte store atomicity and
 // visibility through a real peer window are unverified on this pool.  RCCL is the default transport.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "abi_internal.hpp"
 #include "comm_ipc.hpp"
 
 namespace {
+
+// Mailboxes of THIS process by their handle bytes.  A host that drives several engines from one process (one thread per
+// GPU — how a Rust host would replace train_parallel's threads, src/simulation/train.rs:98-151) hands every engine the
+// same list of handles; an engine recognises the ones made in its own address space and takes their mailboxes by
+// address (hipIpcOpenMemHandle refuses a handle of the calling process), enabling peer access when the mailbox lives on
+// another device.
+struct LocalBox {
+  float *box;
+  int device;
+};
+std::mutex g_local_mu;
+std::map<std::string, LocalBox> g_local_boxes;
 
 // one workgroup (one wave) per 64-column chunk
 __global__ void __launch_bounds__(IPC_CHUNK) k_ipc_allreduce(float *__restrict__ vec, uint32_t count, IpcPeers peers) {
@@ -63,8 +77,15 @@ void ipc_check(rl_engine *e) {
 
 void ipc_teardown(rl_engine *e) {
   for (int r = 0; r < RL_IPC_MAX_RANKS; ++r) {
-    if (e->ipc_peer[r] != nullptr && r != e->ipc_rank_of_box) (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
+    if (e->ipc_peer[r] != nullptr && r != e->ipc_rank_of_box && !e->ipc_peer_local[r])
+      (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
     e->ipc_peer[r] = nullptr;
+    e->ipc_peer_local[r] = false;
+  }
+  if (e->ipc_box) {
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    for (auto it = g_local_boxes.begin(); it != g_local_boxes.end();)
+      it = it->second.box == e->ipc_box ? g_local_boxes.erase(it) : std::next(it);
   }
   if (e->ipc_box) (void)hipFree(e->ipc_box);
   if (e->ipc_err) (void)hipFree(e->ipc_err);
@@ -107,6 +128,8 @@ int32_t rl_comm_ipc_handle(rl_engine *e, int32_t n_ranks, uint8_t handle_out[64]
     hipIpcMemHandle_t h;
     RL_HIP_CHECK(hipIpcGetMemHandle(&h, e->ipc_box));
     std::memcpy(handle_out, &h, 64);
+    std::lock_guard<std::mutex> lk(g_local_mu);
+    g_local_boxes[std::string((const char *)handle_out, 64)] = LocalBox{e->ipc_box, e->device};
   });
 }
 
@@ -126,7 +149,27 @@ int32_t rl_comm_init_ipc(rl_engine *e, int32_t rank, int32_t n_ranks, const uint
         hipIpcMemHandle_t h;
         std::memcpy(&h, handles + (size_t)r * 64, 64);
         void *p = nullptr;
-        RL_HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        LocalBox local{nullptr, -1};
+        {
+          std::lock_guard<std::mutex> lk(g_local_mu);
+          auto it = g_local_boxes.find(std::string((const char *)handles + (size_t)r * 64, 64));
+          if (it != g_local_boxes.end()) local = it->second;
+        }
+        if (local.box != nullptr) {  // an engine of this process: no IPC mapping, its mailbox by address
+          if (local.device != e->device) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(local.device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+              (void)hipGetLastError();
+              throw RlError(RL_ERR_COMM, "peer-mailbox transport: device " + std::to_string(e->device) +
+                                             " cannot enable peer access to device " + std::to_string(local.device));
+            }
+            (void)hipGetLastError();
+          }
+          p = local.box;
+          e->ipc_peer_local[r] = true;
+        } else {
+          RL_HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        }
         e->ipc_peer[r] = (float *)p;
         // a mailbox on ANOTHER device is reached through a peer window: the protocol needs peer access and 64-bit
         // stores that land as one unit (native atomics over the link); refuse the transport otherwise
@@ -143,8 +186,9 @@ int32_t rl_comm_init_ipc(rl_engine *e, int32_t rank, int32_t n_ranks, const uint
       }
     } catch (...) {
       for (int r = 0; r < n_ranks; ++r) {
-        if (r != rank && e->ipc_peer[r]) (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
+        if (r != rank && e->ipc_peer[r] && !e->ipc_peer_local[r]) (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
         e->ipc_peer[r] = nullptr;
+        e->ipc_peer_local[r] = false;
       }
       throw;
     }
@@ -152,6 +196,19 @@ int32_t rl_comm_init_ipc(rl_engine *e, int32_t rank, int32_t n_ranks, const uint
     e->ipc_active = true;
     e->rank = rank;
     e->n_ranks = n_ranks;
+    try {
+      comm_agree(e);  // (also the first exchange with every peer: a mailbox that cannot be reached fails here)
+    } catch (...) {
+      e->ipc_active = false;
+      e->rank = 0;
+      e->n_ranks = 1;
+      for (int r = 0; r < n_ranks; ++r) {
+        if (r != rank && e->ipc_peer[r] && !e->ipc_peer_local[r]) (void)hipIpcCloseMemHandle(e->ipc_peer[r]);
+        e->ipc_peer[r] = nullptr;
+        e->ipc_peer_local[r] = false;
+      }
+      throw;
+    }
   });
 }
 

@@ -148,6 +148,7 @@ struct rl_engine {
   // handles, the sequence number of the last collective, a device word a timed-out wait sets
   float *ipc_box = nullptr;
   float *ipc_peer[RL_IPC_MAX_RANKS] = {nullptr};
+  bool ipc_peer_local[RL_IPC_MAX_RANKS] = {false};  // the peer is an engine of THIS process: its mailbox by address
   int32_t *ipc_err = nullptr;
   uint32_t ipc_seq[2] = {0, 0};  // per channel: each has its own half of every mailbox
   uint64_t ipc_timeout_ticks = 0;  // bound of one mailbox wait, 100 MHz ticks (RELEARN_IPC_TIMEOUT_MS)
@@ -158,6 +159,9 @@ struct rl_engine {
     return comm != nullptr || loopback != nullptr || host_allreduce != nullptr || ipc_active;
   }
   int rank = 0, n_ranks = 1;
+  // settings every rank must take the same way, agreed through the collective when it is installed (comm_agree, abi.hip):
+  // RELEARN_SERIAL_UPDATE set in ANY rank's environment
+  bool agreed_serial_env = false;
   // host pinned scratch for small readbacks
   void *pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -388,6 +392,7 @@ struct ProfScope {
 
 // abi.hip
 void rl_allreduce_sum_f32(rl_engine *e, float *d_buf, size_t count);
+void comm_agree(rl_engine *e);  // settings all ranks must share, agreed through the collective just installed
 // comm_ipc.hip
 bool ipc_allreduce_fits(const rl_engine *e, size_t count);
 void ipc_allreduce(rl_engine *e, float *d_buf, size_t count);

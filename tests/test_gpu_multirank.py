@@ -125,7 +125,7 @@ def test_two_ranks_equal_one_rank():
     assert np.all(np.isfinite(double[0]["dqn"]["losses"]))
 
 
-def run_bench(world, extra_env=None):
+def run_bench(world, extra_env=None, workload=("--envs", "2048", "--horizon", "32", "--critic-steps", "5"), limit=150):
     """bench.py exactly as the driver launches it (torch.distributed.run, one process per rank), on a small workload"""
     import json
     import subprocess
@@ -133,8 +133,7 @@ def run_bench(world, extra_env=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # ONE period: the rollouts of the two runs are then identical and only the order of the f32 sums differs (a second
     # period would start from policies that already differ by TRPO's amplified rounding, and drift apart from there)
-    args = ["--gpus", str(world), "--steps", "1", "--warmup", "0", "--envs", "2048", "--horizon", "32",
-            "--critic-steps", "5", "--no-cpu-baseline"]
+    args = ["--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + list(workload)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     import socket
     with socket.socket() as sock:  # a free rendezvous port
@@ -149,12 +148,12 @@ def run_bench(world, extra_env=None):
     proc = subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                             start_new_session=True)
     try:
-        stdout, stderr = proc.communicate(timeout=150)
+        stdout, stderr = proc.communicate(timeout=limit)
     except subprocess.TimeoutExpired:
         import signal
         os.killpg(proc.pid, signal.SIGKILL)
         proc.communicate()
-        raise AssertionError("bench.py --gpus %d did not finish within 150 s" % world)
+        raise AssertionError("bench.py --gpus %d did not finish within %d s" % (world, limit))
 
     class out:  # the fields the checks below read
         returncode = proc.returncode
@@ -328,3 +327,139 @@ def test_a_missing_peer_fails_the_mailbox_collective_without_touching_the_replic
         secs = float(o.split("saw the timeout after ")[1].split(" s")[0])
         fast = float(o.split("failed fast in ")[1].split(" s")[0])
         assert 1.0 < secs < 30.0 and fast < 1.0, o[-500:]
+
+
+# ---------------------------------------------------------------- config 4 at its exact split: 8 ranks x 8,192 lanes
+# (BASELINE.json configs[3]: 65,536 envs over 8 GPUs, T = 128, 80 critic steps; replaces the thread fan-out of
+# src/simulation/train.rs:98-158,180).  A one-GPU box can host the eight ranks as eight engines of one process (the
+# in-process loopback collective) or — the pool admits at most six GPU processes — as four processes of two ranks each
+# over the peer mailboxes.  The driver's 8-process launch of bench.py is rehearsed with four processes for the same
+# reason (16,384 lanes per rank, the full workload otherwise).
+CONFIG4 = dict(n_total=65536, T=128, critic_steps=80, periods=2)
+
+
+def _config4_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ipc_multi", os.path.join(root, "scripts", "ipc_multi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _config4_loopback(world):
+    mod = _config4_module()
+    os.environ["RELEARN_LOOPBACK_COMM"] = "1"
+    try:
+        uid = ra.comm_unique_id()
+        out = {}
+
+        def run(rank):
+            try:
+                eng = ra.Engine(0)
+                if world > 1:
+                    eng.comm_init(rank, world, uid)
+                out[rank] = mod.config4_rank(eng, rank, world, **CONFIG4)
+            except BaseException as exc:
+                out[rank] = exc
+                raise
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=280)
+        for r in range(world):
+            assert r in out and not isinstance(out[r], BaseException), out.get(r)
+        return [out[r] for r in range(world)]
+    finally:
+        os.environ.pop("RELEARN_LOOPBACK_COMM", None)
+
+
+@pytest.fixture(scope="module")
+def config4_single():
+    return _config4_loopback(1)[0]
+
+
+def _check_config4(ranks, single):
+    """rollouts bit-identical lane for lane; every rank's replica identical after both periods; TRPO statistics and
+    critic losses of the first period within the two-rank tolerances (same samples, other order of the f32 sums)"""
+    world = len(ranks)
+    assert world == 8 and ranks[0]["action"].shape == (128, 8192)
+    for f in ("action", "flag", "adv"):
+        assert np.array_equal(np.concatenate([r[f] for r in ranks], axis=1), single[f]), f
+    for period in range(CONFIG4["periods"]):
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0]["policy%d" % period], r["policy%d" % period]), period
+            assert np.array_equal(ranks[0]["critic%d" % period], r["critic%d" % period]), period
+            assert np.array_equal(ranks[0]["losses%d" % period], r["losses%d" % period]), period
+        assert ranks[0]["trpo%d" % period][4] == ra.OPT_OK
+    # 1 gradient + 11 Fisher-vector products + >= 2 line-search pairs + 80 critic steps, per period, on every rank
+    assert len({int(r["allreduce_launches"][0]) for r in ranks}) == 1
+    assert ranks[0]["allreduce_launches"][0] >= 2 * (1 + 11 + 2 + 80)
+    a, b = ranks[0]["trpo0"], single["trpo0"]
+    assert abs(a[0] - b[0]) < 1e-6 and abs(a[1] - b[1]) < 1e-6 and a[3] == b[3] and a[4] == b[4]
+    assert abs(a[2] - b[2]) < 1e-1 * b[2]  # CG-amplified rounding, see test_two_ranks_equal_one_rank
+    assert np.max(np.abs(ranks[0]["losses0"] - single["losses0"]) / single["losses0"]) < 1e-5
+    assert np.mean(np.abs(ranks[0]["critic0"] - single["critic0"]) < 2e-5) > 0.97
+
+
+def test_eight_loopback_ranks_at_the_config4_split(config4_single):
+    """(a) eight engines of one process x 8,192 lanes against one engine x 65,536 lanes, two periods of
+    rl_actor_critic_update at the full workload"""
+    _check_config4(_config4_loopback(8), config4_single)
+
+
+def test_eight_mailbox_ranks_at_the_config4_split(tmp_path, config4_single):
+    """(b) the same eight ranks over the peer-mailbox transport: four processes of two ranks each (the pool admits six
+    GPU processes), every rank running the library's 240-round self-test first.  Ranks of one process reach each other's
+    mailboxes by address, ranks of other processes through IPC handles."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "ipc_multi.py")
+    d = os.path.join(str(tmp_path), "config4")
+    os.makedirs(d)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [str(CONFIG4[k]) for k in ("n_total", "T", "critic_steps", "periods")]
+    procs = [subprocess.Popen([sys.executable, script, str(p), "4", "2", d] + args, cwd=root, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+             for p in range(4)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=280)
+        except subprocess.TimeoutExpired:
+            import signal
+            for q in procs:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+            raise AssertionError("ipc_multi.py (4 x 2 ranks) did not finish within 280 s")
+        outs.append(o.decode())
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+    ranks = [dict(np.load(os.path.join(d, "out%d_of_8.npz" % r))) for r in range(8)]
+    _check_config4(ranks, config4_single)
+
+
+def test_bench_as_four_processes_at_the_full_workload():
+    """(c) bench.py launched as the driver launches it, FOUR processes (the pool's limit is six on one card) on this box's
+    one GPU over the host-staged collective and over the mailboxes, at the metric's workload (65,536 envs, T = 128, 80
+    critic steps): the line says n_gpus 4, the replicas are identical, and `allreduce_per_rank` is filled for every
+    rank — what the first real multi-GPU run will be read by."""
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
+    for comm in ("gloo", "ipc"):
+        res = run_bench(4, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": comm},
+                        workload=("--steps", "2", "--warmup", "1"), limit=280)
+        assert res["n_gpus"] == 4 and res["config"]["n_envs_per_gpu"] == 16384 and res["config"]["n_envs_total"] == 65536
+        assert res["replicas_identical"] is True, res["_stderr"][-1500:]
+        assert ("gloo" if comm == "gloo" else "mailboxes") in res["config"]["parallelism"], res["_stderr"][-1500:]
+        per_rank = res["allreduce_per_rank"]
+        assert len(per_rank) == 4 and all(p is not None and p["rank"] == i for i, p in enumerate(per_rank))
+        # (over the mailboxes the critic chain's 80 exchanges run INSIDE its reduce + Adam launches)
+        assert all(p["launches_per_step"] >= 1 + 11 + 2 + (80 if comm == "gloo" else 0) for p in per_rank)
+        assert res["last_update"]["trpo_status"] == ra.OPT_OK
