@@ -90,8 +90,9 @@ def cpu_baseline(args):
     st = O.PeriodStats()
     t0 = time.time()
     per_thread = max(64, args.cpu_sample_steps // cores)
-    O.lib().oracle_cartpole_trpo_period(0, 0, cores, per_thread, 100, args.max_episode_steps, H,
-                                        O.f32p(pp), O.f32p(cp), opt, args.critic_steps, C.byref(st))
+    # (the update twice: on one thread, and with every full-batch pass split over the cores like libtorch's intra-op pool)
+    O.lib().oracle_cartpole_trpo_period_ex(0, 0, cores, per_thread, 100, args.max_episode_steps, H,
+                                           O.f32p(pp), O.f32p(cp), opt, args.critic_steps, cores, C.byref(st))
     wall = time.time() - t0
     O.lib().oracle_adam_free(opt)
     steps = int(st.steps)
@@ -109,15 +110,20 @@ def cpu_baseline(args):
         per_thread_ro = int(min(per_thread_ro * 2.6 / max(ro_s, 1e-3), 40_000_000))
     ro_steps = int(got.value)
     return {
-        "value": steps / (st.rollout_seconds + st.update_seconds),
+        # the reference's agent update runs on one Rust thread, but its batched matmuls run on libtorch's intra-op pool:
+        # the headline CPU figure is the one with the update's passes split over the cores (the faster, fairer one)
+        "value": steps / (st.rollout_seconds + st.update_intraop_seconds),
+        "value_single_threaded_update": steps / (st.rollout_seconds + st.update_seconds),
+        "update_seconds": {"one_thread": st.update_seconds, "passes_over_%d_threads" % cores: st.update_intraop_seconds},
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
         "build": "gcc -O3 -ffp-contract=off -mavx2 -mfma -fopenmp (oracle/Makefile)",
-        "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes), then single-threaded "
-                  "GAE + TRPO + %d Adam steps; rollout %.2f s, update %.2f s" % (
-                      cores, per_thread, steps, int(st.episodes), args.critic_steps,
-                      st.rollout_seconds, st.update_seconds),
+        "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes), then GAE + TRPO + %d Adam "
+                  "steps: on one thread %.2f s, with every full-batch pass split over %d threads %.2f s (the figure in "
+                  "`value`); rollout %.2f s" % (
+                      cores, per_thread, steps, int(st.episodes), args.critic_steps, st.update_seconds, cores,
+                      st.update_intraop_seconds, st.rollout_seconds),
         "rollout_only_steps_per_s": ro_steps / max(ro_s, 1e-9),
         "rollout_only_sample": "%d threads x %d scalar Steps::step steps in %.2f s (worker threads started before the "
                                "clock)" % (cores, per_thread_ro, ro_s),
@@ -348,9 +354,9 @@ def main():
     # One launch = forward + MSE loss + backward of the 5-128-1 critic over every sample of the rank.
     # The kernel's contractions run on the bf16 matrix pipe as EXACT three-piece splits (relearn_amd/csrc/bf16_tile.hpp:
     # every product exact, f32 accumulation — f32-equivalent arithmetic), so the roof it sits under is the dense bf16 MFMA
-    # peak and `achieved` counts the flop that pipe EXECUTES: 22 v_mfma_f32_32x32x16_bf16 per 32-sample tile (12 forward, 2
-    # routing the pieces of dy * x, 8 backward) x 32,768 flop = 22,528 per sample.  The algorithmic f32 rate (3 x critic forward =
-    # 4,608 flop per sample) is reported beside it as `f32_equivalent_TFLOPs`, never as a fraction of a roof.
+    # peak.  `achieved` / `frac` count the ALGORITHMIC flop (3 x critic forward = 4,608 per sample); what the
+    # pipe EXECUTES for it — 22 v_mfma_f32_32x32x16_bf16 per 32-sample tile (12 forward, 2 routing the pieces of dy * x, 8
+    # backward) x 32,768 flop = 22,528 per sample — is reported beside it as `pipe_occupancy`.
     roofline = None
     roofline_policy = None
     phases = None
@@ -360,6 +366,7 @@ def main():
         scripts/path_once.py, scripts/pmc_passes.sh), with the build it was taken from"""
         tpath = os.path.join(ROOT, "profiles", PMC_SUMMARY)
         out = {"traffic": None, "valu_busy_frac": None, "mfma_busy_frac": None, "valu_issue_frac": None,
+               "issue_port_frac": None,
                "source": {"file": "profiles/" + PMC_SUMMARY, "kind": "committed rocprofv3 PMC summary, not measured in this run",
                           "applies": False}}
         if not (os.path.exists(tpath) and args.envs // world == 65536 and T == 128):
@@ -376,6 +383,10 @@ def main():
                 if row.get("SQ_INSTS_VALU") and row.get("SQ_BUSY_CU_CYCLES"):
                     # vector instructions x 4 issue cycles against the SIMD cycles of the launch (4 SIMDs per busy CU cycle)
                     out["valu_issue_frac"] = 4.0 * row["SQ_INSTS_VALU"] / (4.0 * row["SQ_BUSY_CU_CYCLES"])
+                    # the SIMD's shared issue port: a vector instruction holds it ~4 cycles, a matrix instruction 8, an
+                    # LDS instruction ~18 (profiles/r03_slot_cost.txt), against 4 SIMDs x the busy CU cycles of the launch
+                    out["issue_port_frac"] = (4.0 * row["SQ_INSTS_VALU"] + 8.0 * row.get("SQ_INSTS_MFMA", 0.0) +
+                                              18.0 * row.get("SQ_INSTS_LDS", 0.0)) / (4.0 * row["SQ_BUSY_CU_CYCLES"])
         return out
 
     if prof is not None:
@@ -391,20 +402,28 @@ def main():
         ctr = counters("k_critic_step_mfma")
         if fused:
             roofline = {
-                "kernel": "k_critic_step_mfma", "bound": "mfma", "achieved": executed, "peak": BF16_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": executed / BF16_PEAK_TFLOPS, "traffic": ctr["traffic"],
-                "executed_bf16_flop_per_sample": bf16_flop,
-                "f32_equivalent_TFLOPs": algorithmic, "algorithmic_flop_per_sample": flop_c,
+                # achieved = ALGORITHMIC flop (3 x critic forward = 4,608 per sample) x samples / launch time,
+                # against the peak of the unit that runs it (the dense bf16 matrix pipe)
+                "kernel": "k_critic_step_mfma", "bound": "mfma", "achieved": algorithmic, "peak": BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": algorithmic / BF16_PEAK_TFLOPS, "traffic": ctr["traffic"],
+                "frac_algorithmic": algorithmic / BF16_PEAK_TFLOPS,
+                "algorithmic_flop_per_sample": flop_c,
+                "frac_of_f32_mfma_peak": algorithmic / F32_PEAK_TFLOPS,
+                # what the pipe EXECUTES for that (exact three-piece splits, K padding: 22,528 flop per sample)
+                "pipe_occupancy": executed / BF16_PEAK_TFLOPS, "executed_TFLOPs": executed,
+                "executed_bf16_flop_per_sample": bf16_flop, "useful_over_executed": flop_c / float(bf16_flop),
+                "issue_port_frac": ctr["issue_port_frac"],
                 "valu_issue_frac": ctr["valu_issue_frac"], "valu_busy_frac": ctr["valu_busy_frac"],
                 "mfma_busy_frac": ctr["mfma_busy_frac"], "source": ctr["source"],
                 "launches": int(cf_n), "avg_launch_us": 1e3 * cf_ms / max(cf_n, 1), "samples_per_launch": B_local,
-                "note": "achieved = flop the bf16 matrix pipe executes (22,528 per sample: exact three-piece splits of "
-                        "f32 operands, f32 accumulation) / launch time, peak = dense bf16 MFMA.  What keeps the pipe "
-                        "from its peak is not HBM (traffic = bytes per launch, 1.0x the algorithmic 24 B per sample) but "
-                        "the SIMD's shared issue port (a vector instruction ~4 cycles, a matrix instruction 8, an LDS "
-                        "instruction 14-25: profiles/r03_slot_cost.txt) and per-tile latency chains at two waves per "
-                        "SIMD (DESIGN 5.3); valu_issue_frac / *_busy_frac are counter-derived (see source).  Per-rank "
-                        "figures.",
+                "note": "frac = algorithmic f32 flop (SURVEY 8d) / launch time / dense bf16 MFMA peak.  The contractions run "
+                        "on the bf16 pipe as exact three-piece splits with f32 accumulation (f32-equivalent arithmetic: "
+                        "parity at 1e-6), which executes 4.9x the algorithmic flop: pipe_occupancy = executed / peak, "
+                        "frac = pipe_occupancy x useful_over_executed.  The same work is 1.4-1.5x the f32 MFMA roof "
+                        "(frac_of_f32_mfma_peak), which is why that roof is not the denominator.  What stops the pipe "
+                        "is not HBM (traffic = bytes per launch, 1.0x the algorithmic 24 B per sample) but the SIMD's "
+                        "shared issue port: issue_port_frac = (4 x vector + 8 x matrix + 18 x LDS instructions) / SIMD "
+                        "cycles, from the committed counters (see source).  Per-rank figures.",
             }
         else:
             roofline = {
@@ -428,9 +447,13 @@ def main():
             ach = flop_p * B_local * fv_n / (fv_ms * 1e-3) / 1e12
             exe = (38 * 32768 // 32) * B_local * fv_n / (fv_ms * 1e-3) / 1e12
             pc = counters("void k_policy_bf16<2")
-            roofline_policy = {"kernel": "k_policy_bf16<PASS_JVP>", "bound": "mfma", "achieved": exe,
-                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exe / BF16_PEAK_TFLOPS,
-                               "traffic": pc["traffic"], "f32_equivalent_TFLOPs": ach,
+            roofline_policy = {"kernel": "k_policy_bf16<PASS_JVP>", "bound": "mfma", "achieved": ach,
+                               "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                               "frac_algorithmic": ach / BF16_PEAK_TFLOPS,
+                               "frac_of_f32_mfma_peak": ach / F32_PEAK_TFLOPS,
+                               "pipe_occupancy": exe / BF16_PEAK_TFLOPS, "executed_TFLOPs": exe,
+                               "executed_bf16_flop_per_sample": 38 * 32768 // 32,
+                               "traffic": pc["traffic"], "issue_port_frac": pc["issue_port_frac"],
                                "valu_issue_frac": pc["valu_issue_frac"], "valu_busy_frac": pc["valu_busy_frac"],
                                "mfma_busy_frac": pc["mfma_busy_frac"], "source": pc["source"],
                                "launches": int(fv_n), "avg_launch_us": 1e3 * fv_ms / fv_n,

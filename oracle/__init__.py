@@ -126,7 +126,8 @@ class Lanes(C.Structure):
 class PeriodStats(C.Structure):
     _fields_ = [("rollout_seconds", C.c_double), ("update_seconds", C.c_double), ("steps", C.c_uint64),
                 ("episodes", C.c_uint64), ("mean_episode_length", C.c_double), ("trpo", TrpoStats),
-                ("critic_loss_first", C.c_float), ("critic_loss_last", C.c_float)]
+                ("critic_loss_first", C.c_float), ("critic_loss_last", C.c_float),
+                ("update_intraop_seconds", C.c_double), ("update_intraop_threads", C.c_uint32)]
 
 
 _lib = None
@@ -454,6 +455,9 @@ def _declare(L):
     L.oracle_cartpole_trpo_period.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
                                               C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_float), P(AdamState),
                                               C.c_uint64, P(PeriodStats)]
+    L.oracle_cartpole_trpo_period_ex.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
+                                                 C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_float), P(AdamState),
+                                                 C.c_uint64, C.c_uint32, P(PeriodStats)]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -358,16 +358,18 @@ double oracle_cartpole_rollout_only(uint64_t seed, uint32_t n_threads, uint64_t 
     oracle_vecbuffer *buf = oracle_vecbuffer_new(5);
     int have_state = 0;
     oracle_cartpole_state s;
-    uint64_t remaining = 0;
+    uint64_t remaining = 0, count = 0;  /* (counted locally: a shared array of counters would bounce its cache line
+                                           between the cores on every step) */
+    oracle_prng my_env = t_env[i], my_agent = t_agent[i];  /* generators on the thread's own stack, for the same reason */
     float f[5], nf[5];
     for (uint64_t n = 0; n < steps_per_thread; ++n) {
       if (!have_state) {
-        oracle_cartpole_initial_state(&env, &t_env[i], &s);
+        oracle_cartpole_initial_state(&env, &my_env, &s);
         remaining = max_steps;
         have_state = 1;
       }
       oracle_cartpole_features(&s, ORACLE_LIMIT_VISIBLE, remaining, max_steps, f);
-      float u = oracle_prng_gen_f32(&t_agent[i]);
+      float u = oracle_prng_gen_f32(&my_agent);
       int a = policy_act(ps, policy_params, f, u);
       double r;
       int succ = oracle_cartpole_step(&env, &s, a, &r);
@@ -379,9 +381,10 @@ double oracle_cartpole_rollout_only(uint64_t seed, uint32_t n_threads, uint64_t 
       }
       if (succ != ORACLE_CONTINUE) have_state = 0;
       oracle_vecbuffer_write_step(buf, f, a, r, succ, np);
-      counts[i] += 1;
+      count += 1;
       if (clear_every && (n + 1) % clear_every == 0) oracle_vecbuffer_clear(buf);
     }
+    counts[i] = count;
     oracle_vecbuffer_free(buf);
   }
   double secs = now_s() - t0;
@@ -394,10 +397,92 @@ double oracle_cartpole_rollout_only(uint64_t seed, uint32_t n_threads, uint64_t 
   return secs;
 }
 
+/* The update's full-batch passes with every pass split over the cores (chunks of samples under `omp for`, chunk results
+ * combined in f64 by sample weight): what libtorch's intra-op thread pool does to the reference's batched matmuls while
+ * the agent itself runs on one Rust thread (torch/agents/actor_critic.rs:176-211).  Same pass COUNT as the
+ * single-threaded update just made (n_evals line-search evaluations), same per-sample arithmetic; the parameters it
+ * steps are private copies.  Returns seconds. */
+#define INTRAOP_CHUNK 1024
+static double update_intraop_seconds(oracle_mlp_shape ps, oracle_mlp_shape cs, const float *policy_params,
+                                     const float *critic_params, const oracle_features *feat, const float *adv,
+                                     const float *rtg, uint64_t cg_iterations, uint64_t n_evals, uint64_t critic_steps,
+                                     uint32_t n_threads) {
+  const uint64_t n = feat->n_steps, Pp = oracle_mlp_num_params(ps), Pc = oracle_mlp_num_params(cs);
+  const uint64_t n_chunks = (n + INTRAOP_CHUNK - 1) / INTRAOP_CHUNK;
+  float *pp = (float *)malloc(sizeof(float) * Pp), *cp = (float *)malloc(sizeof(float) * Pc);
+  float *v = (float *)malloc(sizeof(float) * Pp);
+  double *acc = (double *)malloc(sizeof(double) * (Pp > Pc ? Pp : Pc));
+  float *g = (float *)malloc(sizeof(float) * (Pp > Pc ? Pp : Pc));
+  memcpy(pp, policy_params, sizeof(float) * Pp);
+  memcpy(cp, critic_params, sizeof(float) * Pc);
+  for (uint64_t i = 0; i < Pp; ++i) v[i] = 1e-3f * (float)((i * 2654435761u) % 1000u) / 1000.0f;
+  oracle_adam_state *opt = oracle_adam_new(Pc);
+  oracle_adam_cfg acfg;
+  oracle_adam_cfg_default(&acfg);
+  /* kind 0: policy gradient, 1: Fisher-vector product, 2: (loss, KL) evaluation, 3: critic gradient */
+  #define INTRAOP_PASS(kind, P)                                                                              \
+    do {                                                                                                     \
+      for (uint64_t i = 0; i < (P); ++i) acc[i] = 0.0;                                                       \
+      _Pragma("omp parallel num_threads(n_threads)")                                                         \
+      {                                                                                                      \
+        double *mine = (double *)calloc((P), sizeof(double));                                                \
+        float *gc = (float *)malloc(sizeof(float) * (P));                                                    \
+        _Pragma("omp for schedule(dynamic, 1)")                                                              \
+        for (uint64_t c = 0; c < n_chunks; ++c) {                                                            \
+          const uint64_t lo = c * INTRAOP_CHUNK, m = lo + INTRAOP_CHUNK <= n ? INTRAOP_CHUNK : n - lo;       \
+          float l0 = 0.0f, l1 = 0.0f;                                                                        \
+          if ((kind) == 0) oracle_policy_grad_f32(ps, pp, feat->obs + lo * 5, feat->actions + lo, adv + lo, m, gc, &l0); \
+          else if ((kind) == 1) oracle_policy_fvp_f32(ps, pp, feat->obs + lo * 5, m, v, 0.0f, gc);           \
+          else if ((kind) == 2) {                                                                            \
+            oracle_policy_loss_kl_f32(ps, pp, policy_params, feat->obs + lo * 5, feat->actions + lo, adv + lo, m, &l0, &l1); \
+            gc[0] = l0;                                                                                      \
+            gc[1] = l1;                                                                                      \
+          } else oracle_critic_grad_f32(cs, cp, feat->obs + lo * 5, rtg + lo, m, gc, &l0);                   \
+          const double w = (double)m / (double)n;                                                            \
+          const uint64_t cnt = (kind) == 2 ? 2 : (P);                                                        \
+          for (uint64_t i = 0; i < cnt; ++i) mine[i] += w * (double)gc[i];                                   \
+        }                                                                                                    \
+        _Pragma("omp critical")                                                                              \
+        for (uint64_t i = 0; i < (P); ++i) acc[i] += mine[i];                                                \
+        free(gc);                                                                                            \
+        free(mine);                                                                                          \
+      }                                                                                                      \
+      for (uint64_t i = 0; i < (P); ++i) g[i] = (float)acc[i];                                               \
+    } while (0)
+  const double t0 = now_s();
+  INTRAOP_PASS(0, Pp);
+  for (uint64_t it = 0; it < cg_iterations + 1; ++it) {
+    INTRAOP_PASS(1, Pp);
+    for (uint64_t i = 0; i < Pp; ++i) v[i] = 0.5f * v[i] + 0.5f * g[i]; /* (a vector update per iteration, like CG's) */
+  }
+  for (uint64_t e = 0; e < n_evals; ++e) INTRAOP_PASS(2, Pp);
+  for (uint64_t k = 0; k < critic_steps; ++k) {
+    INTRAOP_PASS(3, Pc);
+    oracle_adam_step_f32(opt, &acfg, cp, g);
+  }
+  const double secs = now_s() - t0;
+  #undef INTRAOP_PASS
+  oracle_adam_free(opt);
+  free(g);
+  free(acc);
+  free(v);
+  free(cp);
+  free(pp);
+  return secs;
+}
+
 void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
                                  uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
                                  float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
                                  oracle_period_stats *stats) {
+  oracle_cartpole_trpo_period_ex(seed, period_index, n_threads, steps_per_thread, slack_steps, max_steps, hidden,
+                                 policy_params, critic_params, critic_opt, critic_steps, 0, stats);
+}
+
+void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
+                                    uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
+                                    float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
+                                    uint32_t intraop_threads, oracle_period_stats *stats) {
   oracle_cartpole env;
   oracle_cartpole_default(&env);
   oracle_mlp_shape ps = {5, hidden, 2}, cs = {5, hidden, 1};
@@ -481,6 +566,12 @@ void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t 
     stats->critic_loss_last = losses[critic_steps - 1];
   }
   stats->update_seconds = now_s() - t1;
+  if (intraop_threads > 0 && feat->n_steps > 0) {
+    const uint64_t n_evals = stats->trpo.num_backtracks >= 0 ? (uint64_t)stats->trpo.num_backtracks + 1 : cfg.max_backtracks;
+    stats->update_intraop_seconds = update_intraop_seconds(ps, cs, policy_params, critic_params, feat, adv, rtg,
+                                                           cfg.iterations, n_evals, critic_steps, intraop_threads);
+    stats->update_intraop_threads = intraop_threads;
+  }
   free(losses);
   free(adv);
   free(rtg);

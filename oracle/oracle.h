@@ -487,6 +487,11 @@ typedef struct {
   double mean_episode_length;
   oracle_trpo_stats trpo;
   float critic_loss_first, critic_loss_last;
+  /* the same update's full-batch passes (1 policy gradient, iterations + 1 Fisher-vector products, the line search's
+   * evaluations, critic_steps x {critic gradient, Adam}) with every pass split over `n_threads` cores the way libtorch's
+   * intra-op pool splits the reference's matmuls; 0 when not requested (intraop_threads == 0) */
+  double update_intraop_seconds;
+  uint32_t update_intraop_threads;
 } oracle_period_stats;
 
 /* One train_parallel period of CartPole+VisibleStepLimit MLP-TRPO: `n_threads` OS threads each run the
@@ -499,6 +504,12 @@ void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t 
                                  uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
                                  float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
                                  oracle_period_stats *stats);
+/* ... and, when intraop_threads > 0, the update's passes once more with intra-op parallelism (timing only: parameters
+ * and optimiser state are left as the single-threaded update made them) */
+void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
+                                    uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
+                                    float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
+                                    uint32_t intraop_threads, oracle_period_stats *stats);
 
 #ifdef __cplusplus
 }
