@@ -136,8 +136,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB_PATH)
+        # ORACLE_LIB: another build of the same sources (the sanitizer build of tests/test_sanitizers_cpu.py)
+        path = os.environ.get("ORACLE_LIB")
+        if not path:
+            build()
+            path = _LIB_PATH
+        _lib = C.CDLL(path)
         _declare(_lib)
     return _lib
 
