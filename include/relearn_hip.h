@@ -91,6 +91,24 @@ int32_t rl_engine_info(const rl_engine *engine, char *name_out, size_t name_cap,
  * obs_dim 5); 1 = the v1 kernels only (what other shapes fall back to; kept selectable as an in-library cross-check:
  * same results within the tolerances stated in tests/test_gpu_parity.py). */
 int32_t rl_engine_set_kernel_variant(rl_engine *engine, int32_t variant);
+/* Numeric range of the fused kernels (variant 0 at hidden 128, obs_dim 5: rl_trpo_update, rl_ppo_update,
+ * rl_reinforce_update, rl_critic_update / rl_values_opt_update / rl_actor_critic_update, rl_policy_gradient / _fvp /
+ * _loss_kl, rl_critic_gradient, rl_dqn_update).  The reference's forward is plain f32 (Mlp::forward,
+ * src/torch/modules/ff/mlp.rs:139-151) and has no bound beyond f32's own.  The fused kernels compute every product of
+ * layer 1 exactly on the bf16 matrix pipe with the weights scaled by 2^96 and read relu' off the scaled accumulator, which
+ * is exact — bit-for-bit the mask of the f32 pre-activation's sign — when, for every hidden unit j,
+ *     sum_k |W1[j][k]| * max|obs| + |b1[j]|  <  2^31      (the scaled accumulator stays finite), and
+ *     max(max_k |W1[j][k]| * min{|obs| : obs != 0}, |b1[j]|)  >=  2^-46   unless the unit's weights and bias are all zero
+ *                                                         (a non-zero pre-activation cannot fall below 2^-96),
+ * and every observation is finite.  With Glorot-initialised 5-128 layers (|w| <= 0.22) that is |obs| < 1.9e9 whatever the
+ * small end when the biases are non-zero, and |obs| >= 7e-14 when they are zero.  Observation pieces below 2^-126 (bf16
+ * subnormals: |obs| < 2^-110) may be flushed by the matrix pipe; inside the range above their contribution is below the
+ * f32 rounding of the terms that carry the pre-activation.
+ * The library checks the condition on every fused launch, from the weights it has just loaded and the magnitude range of
+ * the trajectory's observation planes (measured once per rollout / rl_traj_write; the DQN minibatches use fixed bounds
+ * for CartPole-generated observations, 2^-64 <= |obs| <= 2^16).  Outside the range the call returns RL_ERR_UNSUPPORTED
+ * — never a silently wrong mask; its outputs (and, for an update, the parameters it was stepping) are then not valid.
+ * Kernel variant 1 is plain f32 and takes any magnitudes.  tests/test_gpu_numeric_range.py. */
 /* HIP-event timing of everything enqueued between begin and end on the engine stream (milliseconds) */
 int32_t rl_timer_begin(rl_engine *engine);
 int32_t rl_timer_end(rl_engine *engine, float *elapsed_ms);

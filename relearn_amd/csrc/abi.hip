@@ -1430,6 +1430,8 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   t->d.adv = dalloc<float>(T * n);
   t->d.rtg = dalloc<float>(T * n);
   t->d.tgt = t->d.rtg;  // the critic regresses on the returns unless rl_values_opt_update selects other targets
+  t->d.range = dalloc<uint32_t>(4);
+  RL_HIP_CHECK(hipMemsetAsync(t->d.range, 0, 4 * sizeof(uint32_t), e->stream));
   t->lp0 = dalloc<float>(2 * n * T);
   t->dz = dalloc<float>(2 * n * T);
   t->Pmax = 128 * 5 + 128 + 2 * 128 + 2;
@@ -1484,7 +1486,7 @@ int32_t rl_traj_destroy(rl_traj *t) {
   if (t->eng->pending.traj == t) t->eng->pending.active = false;  // (its pending update dies with it)
   void *ptrs[] = {t->d.obs, t->d.action, t->d.reward, t->d.flag, t->d.term_obs, t->d.values, t->d.adv, t->d.rtg,
                   t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
-                  t->losses, t->trpo, t->td, t->aux_slabA, t->aux_slabB, t->aux_vec};
+                  t->losses, t->trpo, t->td, t->aux_slabA, t->aux_slabB, t->aux_vec, t->d.range};
   for (void *p : ptrs) dfree(p);
   seq_free(t);
   gen_free(t);
@@ -1521,6 +1523,7 @@ int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t byte
     traj_field(t, field, &p, &need);
     RL_REQUIRE(bytes == need, "byte count mismatch for trajectory field");
     h2d(t->eng, p, host, bytes);
+    if (field == RL_TRAJ_OBS) t->range_valid = false;  // (the fused kernels' range guard reads the planes' magnitudes)
   });
 }
 
@@ -1607,6 +1610,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     // into ANOTHER trajectory touches neither (it reads the policy the TRPO chain has already finished with) and goes
     // ahead beside it on the main stream; anything else waits for the chain like every other call.
     if (traj == env->eng->pending.traj || policy == env->eng->pending.critic) engine_settle(env->eng);
+    traj->range_valid = false;  // new observations: the fused update kernels' range guard measures them again
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
     if (policy->general) {  // any hidden_sizes: one launch sequence per step, either env family (advances t_global)

@@ -164,6 +164,13 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     q->d_counts = dalloc<DqnCountsDev>(nb);
     RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, nb * sizeof(DqnCountsDev), e->stream));
     q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
+    {  // the fused step's range guard (bf16_tile.hpp): the minibatches hold observations this env produced — bounded by
+       // its termination thresholds and, for the velocities, by what a 500-step episode can reach; fixed bounds with room
+      const float lo = 0x1p-64f, hi = 0x1p16f;
+      const uint32_t words[4] = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi), 0u, 0u};
+      h2d(e, q->mb->d.range, words, sizeof(words));
+      q->mb->range_fixed = true;
+    }
     q->own_obs = q->mb->d.obs;
     q->own_target = q->mb->d.adv;
     q->own_action = q->mb->d.action;
@@ -522,6 +529,7 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
     if (all_at_once && td && K) dqn_build_minibatch(q, (uint32_t)(K - 1), counts[K - 1], totals[K - 1]);
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
+    range_check(q->mb);
     if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
     if (stats) {
       stats->opt_steps = K;

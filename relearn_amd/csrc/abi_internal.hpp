@@ -76,6 +76,20 @@ static inline void d2h(rl_engine *e, void *h, const void *d, size_t bytes) {
   sync(e);
 }
 
+// The fused kernels' range guard (bf16_tile.hpp range_guard) found weights / observations outside the range in which the
+// 2^96-scaled forward is exact: their results are not to be used.  Synchronises the engine's current stream.
+static inline void range_check(rl_traj *t) {
+  if (t->d.range == nullptr) return;
+  uint32_t err = 0;
+  d2h(t->eng, &err, t->d.range + 2, sizeof(err));
+  if (err == 0) return;
+  RL_HIP_CHECK(hipMemsetAsync(t->d.range + 2, 0, sizeof(uint32_t), t->eng->stream));
+  throw RlError(RL_ERR_UNSUPPORTED,
+                "numeric range of the fused update kernels exceeded (|pre-activation| bound 2^31 or a non-zero "
+                "pre-activation below 2^-46 possible, or a non-finite observation): the result of this call is not "
+                "valid; use rl_engine_set_kernel_variant(engine, 1) for these magnitudes (include/relearn_hip.h)");
+}
+
 // ---------------------------------------------------------------- shared between the units (C linkage like the entry
 // points they sit next to)
 extern "C" {

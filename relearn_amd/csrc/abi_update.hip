@@ -196,6 +196,7 @@ static void trpo_update_tail(rl_mlp *policy, rl_traj *traj, const rl_trpo_config
   TrpoStateDev h;
   d2h(e, &h, traj->trpo, sizeof(h));
   ipc_check(e);
+  range_check(traj);
   stats->entropy = (double)h.entropy;
   stats->step_size = h.step_size;
   stats->loss_initial = (double)h.loss0;
@@ -234,6 +235,7 @@ int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float
     run_policy_gradient(policy, traj);
     std::vector<float> h(P + 4);
     d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
+    range_check(traj);
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     double inv_B = 1.0 / (double)b_total(traj);
     if (loss_out) *loss_out = (float)(-((double)h[P] * inv_B));
@@ -251,6 +253,7 @@ int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, 
     run_policy_fvp(policy, traj, traj->cg_x, nullptr);
     std::vector<float> h(P);
     d2h(traj->eng, h.data(), traj->vec, P * sizeof(float));
+    range_check(traj);
     for (uint32_t i = 0; i < P; ++i) out[i] = h[i] + reg * v[i];
   });
 }
@@ -271,6 +274,7 @@ int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, f
     run_policy_eval(policy, traj, nullptr);
     float h[4];
     d2h(e, h, traj->vec + P, sizeof(h));
+    range_check(traj);
     double inv_B = 1.0 / (double)Bt;
     *loss_out = (float)(-((double)h[0] * inv_B));
     *kl_out = (float)((double)h[1] * inv_B);
@@ -397,6 +401,7 @@ static void critic_collect(rl_traj *traj, uint64_t opt_steps, rl_critic_stats *s
     std::vector<float> h(opt_steps ? opt_steps : 1);
     if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
     ipc_check(traj->eng);
+    range_check(traj);
     if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
     if (stats) {
       stats->steps = opt_steps;
@@ -570,6 +575,7 @@ static void actor_critic_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_o
     pu.active = pu.joined = pu.collected = true;
     return;
   }
+  traj_ensure_range(traj);  // (both chains' kernels read the observation range: measured once, before the fork)
   // fork: the auxiliary stream sees everything enqueued so far (rollout, values, advantages)
   RL_HIP_CHECK(hipEventRecord(e->ev_fork, e->main_stream));
   RL_HIP_CHECK(hipStreamWaitEvent(e->aux_stream, e->ev_fork, 0));
@@ -671,6 +677,7 @@ int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float
     run_critic_gradient(critic, traj);
     std::vector<float> h(P + 4);
     d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
+    range_check(traj);
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     if (loss_out) *loss_out = (float)((double)h[P] / (double)b_total(traj));
   });
@@ -723,6 +730,7 @@ int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_
     }
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), traj->losses, K * sizeof(float));
+    range_check(traj);
     for (auto &v : h) v = -v;  // loss = -mean(min(...))
     if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
     if (stats) {
@@ -746,6 +754,7 @@ int32_t rl_reinforce_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, rl_poli
     float h0[4];
     d2h(e, h0, traj->vec + P, sizeof(h0));
     launch_adam_step(traj, opt, -1, Bt);
+    range_check(traj);
     if (stats) {
       stats->entropy = (double)h0[1] / (double)Bt;
       stats->steps = 1;

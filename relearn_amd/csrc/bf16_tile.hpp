@@ -219,6 +219,33 @@ __device__ __forceinline__ void pack_mask_now(const float (&gm)[16], Frag (&ga)[
 // conversion's own clamp leaves unchanged — and every asm statement takes its result as an extra operand, so all of
 // them follow it in program order, behind the wait states the compiler inserted for it.
 constexpr float FWD_SCALE = 0x1p96f, FWD_UNSCALE = 0x1p-96f;
+
+// The numeric range in which the scaled forward is exact (include/relearn_hip.h, "Numeric range of the fused kernels"),
+// checked once per launch from the weights this lane has just loaded (hidden unit j: its weights for inputs 2 hf, 2 hf + 1,
+// input 4 and its bias) and the magnitude range of the trajectory's observations (range[0] = bits of the smallest
+// non-zero |x|, range[1] = bits of the largest |x|; a NaN / Inf observation shows up as range[1] >= 0x7F800000):
+//   overflow   2^96 pre must stay finite with room for the partial sums:  sum_k |W1[j][k]| max|x| + |b1[j]| < 2^31;
+//   relu'      a non-zero pre must reach 2^-96, or the clamped conversion returns a FRACTIONAL mask.  pre is a sum of
+//              exact products whose f32 accumulation can cancel down to 2^-48 of its largest term, so the largest term of
+//              a unit that is not identically zero must be able to reach 2^-46: max(max_k |W1[j][k]| min_nz|x|, |b1[j]|).
+// A violation sets the sticky word range[2]; the launch goes on (its numbers are then not to be used) and the host raises
+// RL_ERR_UNSUPPORTED at its next read-back (kernel variant 1 has no such bound).  ~60 instructions per wave and launch.
+__device__ __forceinline__ void range_guard(float wa, float wb, float w4, float bj, int hf, uint32_t *range) {
+  if (range == nullptr) return;
+  const float xmax = __builtin_bit_cast(float, range[1]);
+  const float xmin = range[1] == 0u ? 0.0f : __builtin_bit_cast(float, range[0]);  // (all observations zero: pre = bias)
+  const float aa = __builtin_fabsf(wa), ab = __builtin_fabsf(wb);
+  const float own = hf == 0 ? __builtin_fabsf(w4) : 0.0f, bias = __builtin_fabsf(bj);
+  float hi = (aa + ab + own) * xmax, lo = __builtin_fmaxf(__builtin_fmaxf(aa, ab), own) * xmin, nz = aa + ab + own;
+  float hi0, hi1, lo0, lo1, nz0, nz1;
+  both_halves(hi, hi0, hi1);
+  both_halves(lo, lo0, lo1);
+  both_halves(nz, nz0, nz1);
+  const float upper = hi0 + hi1 + bias, largest = __builtin_fmaxf(__builtin_fmaxf(lo0, lo1), bias);
+  const bool zero_unit = nz0 + nz1 + bias == 0.0f;
+  const bool bad = !(upper < 0x1p31f) || (!zero_unit && !(largest >= 0x1p-46f));
+  if (bad) __hip_atomic_store(range + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t mask_pair(float lo, float hi, float after) {
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(lo), "v"(hi), "v"(after));

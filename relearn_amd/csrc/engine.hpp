@@ -64,6 +64,9 @@ struct TrajDev {
   float *rtg;       // [T][n]
   float *tgt;       // [T][n] regression targets of the critic update: rtg, or the one-step TD targets (StepValueTarget)
   uint32_t n, T, D;
+  // [4] numeric range of the observation planes, for the fused kernels' guard (bf16_tile.hpp range_guard): bits of the
+  // smallest non-zero |obs|, bits of the largest |obs| (k_obs_range), the sticky range-error word, unused
+  uint32_t *range;
 };
 
 // the DQN replay store: every lane is one ReplayBuffer (src/agents/buffers/replay.rs:11-27), see replay.hpp for the
@@ -338,6 +341,9 @@ struct rl_traj {
   float *aux_vec = nullptr;
   uint64_t aux_cap_slabA = 0, aux_cap_slabB = 0;
   uint32_t aux_last_rows = 0;
+  // d.range[0..1] describe the current observation planes (false after anything rewrote them: traj_ensure_range, abi.hip);
+  // `range_fixed`: the words are constants of the producer (the DQN minibatch workspace: CartPole-generated observations)
+  bool range_valid = false, range_fixed = false;
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
   GenDev gen;

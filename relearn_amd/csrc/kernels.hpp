@@ -16,6 +16,14 @@ void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda);
 // critic regression targets into traj->d.tgt: one-step TD from traj->d.values (critic != NULL) or reward-to-go (NULL)
 void launch_value_targets(rl_traj *traj, const rl_mlp *critic, float gamma);
 void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t rows, float *d_out_soa);
+// magnitude range of the trajectory's observation planes -> traj->d.range[0..1] (the fused kernels' range guard)
+void launch_obs_range(rl_traj *traj);
+// ... once per content of the planes: whoever rewrites them (rollouts, rl_traj_write) clears `range_valid`
+inline void traj_ensure_range(rl_traj *traj) {
+  if (traj->range_valid || traj->range_fixed) return;
+  launch_obs_range(traj);
+  traj->range_valid = true;
+}
 
 // kernels_update.hip
 enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2, PASS_DQN = 3, PASS_PPO = 4 };

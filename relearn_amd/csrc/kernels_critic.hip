@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     lv[2] = __builtin_fmaf(w2, hf == 0 ? w4 : bj, lv[2]);
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain takes the scale
     // back out through w2 (both exact)
+    if (blockIdx.x == 0 && wave == 0) bt::range_guard(wa, wb, w4, bj, hf, tr.range);  // (one wave sees all 128 units)
     const float sc = bt::FWD_SCALE;
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
     w2v[t] = bt::FWD_UNSCALE * w2;
@@ -243,6 +244,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (critic->general) return launch_gen_mfma(traj, critic, RL_GEN_CRITIC, nullptr, B_total, nullptr, 0.0f, 0.0f);
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
+  traj_ensure_range(traj);
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
   // persistent grid: one fat workgroup per CU (fewer, fatter workgroups = fewer slab rows for the reduction that follows

@@ -799,6 +799,7 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   for (int t = 0; t < NT; ++t) {
     const int j = t * 32 + n;
     const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
+    if (blockIdx.x == 0 && wave == 0) bt::range_guard(wa, wb, w4, bj, hf, tr.range);  // (one wave sees all 128 units)
     const float sc = bt::FWD_SCALE;  // relu' by conversion (bf16_tile.hpp); the |pre| chains take the scale back out
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
 #pragma unroll

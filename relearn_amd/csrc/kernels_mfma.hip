@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain of the gradient /
     // evaluation passes takes the scale back out through w2d (both exact); the Fisher-vector pass only needs the masks
+    if (blockIdx.x == 0 && wave == 0) bt::range_guard(wa, wb, w4, bj, hf, tr.range);  // (one wave sees all 128 units)
     const float sc = bt::FWD_SCALE;
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
     if (FW_LDS && wave == t) {
@@ -418,6 +419,7 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   if (traj->d.D != 5 || policy->hidden != 128 || policy->out_dim != 2) return false;
   if (mode == PASS_DQN) return false;  // k_dqn_step_bf16 (kernels_dqn.hip)
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernels
+  traj_ensure_range(traj);
   ProfScope ps(traj->eng, mode == PASS_JVP ? RL_K_POLICY_FVP : RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
   traj->last_rows = traj->nbV2;

@@ -329,6 +329,44 @@ __global__ void __launch_bounds__(64) k_value_targets_rtg(TrajDev tr, float gamm
 // ---------------------------------------------------------------- host launchers
 static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------- magnitude range of the observation planes
+// range[0] = bits of the smallest non-zero |x|, range[1] = bits of the largest |x| over `count` floats (|x| as an unsigned
+// integer orders like the magnitude; NaN and Inf come out on top): what the fused update kernels' range guard reads
+// (bf16_tile.hpp).  One pass over the planes per period, HBM-bound (0.17 GB at the metric's size: ~40 us).
+__global__ void __launch_bounds__(256) k_obs_range(const float *__restrict__ x, size_t count, uint32_t *__restrict__ range) {
+  uint32_t lo = 0x7F7FFFFFu, hi = 0u;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, x[i]) & 0x7FFFFFFFu;
+    hi = a > hi ? a : hi;
+    lo = a != 0u && a < lo ? a : lo;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, m, 64), oh = (uint32_t)__shfl_xor((int)hi, m, 64);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(range + 0, lo);
+    atomicMax(range + 1, hi);
+  }
+}
+__global__ void k_obs_range_reset(uint32_t *range) {
+  range[0] = 0x7F7FFFFFu;
+  range[1] = 0u;
+}
+
+void launch_obs_range(rl_traj *traj) {
+  ProfScope ps(traj->eng, RL_K_SMALL);
+  const uint64_t D = traj->d.D > 5 ? traj->d.D : 5;
+  const size_t count = (size_t)D * (traj->d.T + 1) * traj->d.n;
+  size_t blocks = (count + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_obs_range_reset, dim3(1), dim3(1), 0, traj->eng->stream, traj->d.range);
+  hipLaunchKernelGGL(k_obs_range, dim3((unsigned)blocks), dim3(256), 0, traj->eng->stream, traj->d.obs, count,
+                     traj->d.range);
+}
+
 void launch_env_reset(rl_env *env) {
   if (env->kind != RL_ENV_CARTPOLE) return launch_chain_reset(env);
   ProfScope ps(env->eng, RL_K_SMALL);
