@@ -290,3 +290,67 @@ def test_config5_rollout_slices_and_update(engine, cell):
             engine.set_kernel_variant(0)
     for a, b in zip(grads[0], grads[1]):
         assert np.isfinite(a).all() and np.abs(a).max() > 0 and rel_err(a, b) < 1e-4, rel_err(a, b)
+
+
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_config5_gradients_against_the_f64_oracle_on_lane_slices(engine, cell):
+    """The recurrent gradient passes AT config-5 size (16,384 lanes x 100 steps: 512 tiles, 51,200 (step, tile) blocks,
+    every chunk and flush path of the five kernels) against the f64 BPTT oracle.  A gradient is a sum over lanes, and the
+    f64 oracle over 1.64 M sample-steps would take minutes, so the check uses linearity: the advantages (policy) /
+    regression residuals (critic) are made zero on every lane outside three 32-lane slices — first tile, a slice that
+    straddles two tiles in the middle, last tile — and the device's full-size gradient must then equal the oracle's
+    gradient of those 96 lanes, weighted by their share of the batch.  (The bf16-pipe build against the f32 kernels at
+    this size is the test above; this one pins both to the oracle.)  Reference: seq/rnn/gru.rs:20-98, lstm.rs,
+    modules/chain.rs:163-186, policies/trpo.rs:124-131, critics/opt.rs:109-115."""
+    n, Tc = 16384, 100
+    gs_p = O.GruShape(5, 128, 128, 2) if cell == "gru" else O.LstmShape(5, 128, 128, 2)
+    gs_c = O.GruShape(5, 128, 128, 1) if cell == "gru" else O.LstmShape(5, 128, 128, 1)
+    env = ra.ChainEnv(engine, n, max_steps=100, seed_env=3, seed_actor=4)
+    Mod = ra.GruMlp if cell == "gru" else ra.LstmMlp
+    pol, cri = Mod(engine, 5, 2), Mod(engine, 5, 1)
+    pol.init(11)
+    cri.init(12)
+    traj = ra.Trajectory(engine, n, Tc, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.95, 0.95)
+    got = traj.read_all()
+    adv, rtg = traj.read(ra.TRAJ_ADVANTAGES), traj.read(ra.TRAJ_RETURNS)
+    slices = (0, 9001, n - 32)
+    keep = np.zeros(n, dtype=bool)
+    for lo in slices:
+        keep[lo:lo + 32] = True
+    B = n * Tc
+
+    def lanes(lo):
+        return dict(obs=np.ascontiguousarray(got["obs"][..., lo:lo + 32]), action=np.ascontiguousarray(got["action"][:, lo:lo + 32]),
+                    flag=np.ascontiguousarray(got["flag"][:, lo:lo + 32]),
+                    term_obs=np.ascontiguousarray(got["term_obs"][..., lo:lo + 32]))
+
+    # ---- policy: zero advantages outside the slices (their d loss / d logits is then exactly 0)
+    traj.write(ra.TRAJ_ADVANTAGES, np.where(keep[None, :], adv, 0.0).astype(np.float32))
+    g_d, _, _ = ra.policy_gradient(pol, traj)
+    p = pol.get_params()
+    g64 = np.zeros(len(p))
+    for lo in slices:
+        want = lanes(lo)
+        logits, _ = O.gru_seq_forward(gs_p, p, want, f64=True, want_succ=False)
+        z = logits - logits.max(0)
+        pr = np.exp(z - np.log(np.exp(z).sum(0)))
+        a = want["action"].astype(np.int64)
+        ind = np.stack([a == 0, a == 1]).astype(np.float64)
+        dl = -(adv[:, lo:lo + 32].astype(np.float64) / B) * (ind - pr)
+        g64 += O.gru_seq_backward(gs_p, p, want, dl, f64=True)
+    assert np.abs(g64).max() > 0 and rel_err(g_d, g64) < 5e-6, rel_err(g_d, g64)
+    # ---- critic: outside the slices the targets are the critic's own values (residual 0 up to the last bit of two f32
+    # forwards), inside them the returns
+    values, _ = cri.seq_forward(traj, want_succ=False)
+    traj.write(ra.TRAJ_RETURNS, np.where(keep[None, :], rtg, values[0]).astype(np.float32))
+    gc_d, _ = ra.critic_gradient(cri, traj)
+    pc = cri.get_params()
+    gc64 = np.zeros(len(pc))
+    for lo in slices:
+        want = lanes(lo)
+        v, _ = O.gru_seq_forward(gs_c, pc, want, f64=True, want_succ=False)
+        d = v - rtg[:, lo:lo + 32].astype(np.float64)[None]
+        gc64 += O.gru_seq_backward(gs_c, pc, want, 2.0 * d / B, f64=True)
+    assert np.abs(gc64).max() > 0 and rel_err(gc_d, gc64) < 5e-6, rel_err(gc_d, gc64)
