@@ -118,6 +118,71 @@ __device__ __forceinline__ float row_sum16v(const float *row) {
   return (a0 + a1) + (a2 + a3);
 }
 
+// Sums over the 32 unit lanes of a half WITHOUT LDS (round 5).  An accumulator tile has the hidden unit on the lane and
+// the sample in the registers; the output layer needs, for each of the 16 rows, the sum over the half's 32 lanes.  Through
+// LDS that is a transpose: 8 ds_write2 + 4 ds_read_b128 per tile, and an LDS instruction holds the SIMD's issue port for
+// ~18 cycles (profiles/r03_slot_cost.txt).  Here the rows are folded across the lanes by a halving butterfly in registers:
+//   level 1  partner lane ^ 8 (row_ror:8): lanes with bit 3 clear keep rows 0..7, the others rows 8..15 — one
+//            v_add_f32_dpp per row and lane group, the groups separated by the instruction's bank mask (16 issues -> 8 rows)
+//   level 2  partner lane ^ 7 (row_half_mirror; it preserves bit 3): groups by bit 2, again a bank mask (8 issues -> 4)
+//   level 3  partner lane ^ 2 (quad_perm), groups by bit 1: inside a bank, so two sums and a select (6 -> 2 rows)
+//   level 4  partner lane ^ 1, groups by bit 0 (3 -> 1 row)
+//   level 5  the other 16-lane row of the half (v_permlane16_swap, 3)
+// after which lane L of a half holds the half-wide sum of ITS row L & 15 (36 vector instructions, no memory).  The sums
+// reach the sample-owning lanes through one ds_bpermute_b32 (row_sums_to_samples).  Every level adds each pair in the
+// same order on both partners, so the result does not depend on which lane ends up holding it.
+// The DPP instructions are inline asm (the bank-masked second write into the same destination cannot be expressed with
+// the builtins); a DPP read of a register needs two wait states after the vector instruction that wrote it, which the
+// compiler does not track into asm statements: every statement starts with s_nop 1.
+__device__ __forceinline__ float fold_rows16(const float (&v)[16], int lane) {
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(a[i])
+        : "v"(v[i]), "v"(v[i + 8]));
+  float b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(b[i])
+        : "v"(a[i]), "v"(a[i + 4]));
+  const bool bit1 = (lane & 2) != 0, bit0 = (lane & 1) != 0;
+  float c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float lo, hi;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(b[i]), "v"(b[i + 2]));
+    c[i] = bit1 ? hi : lo;
+  }
+  float lo, hi;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(c[0]), "v"(c[1]));
+  float d = bit0 ? hi : lo;
+  // the two 16-lane rows of the half: the instruction swaps the odd rows of its first operand with the even rows of its
+  // second (fed one value twice: the first then holds the even rows' values everywhere, the second the odd rows')
+  float e = d;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(d), "+v"(e));
+  return d + e;
+}
+// byte address (for ds_bpermute_b32) of the lane that holds, after fold_rows16, the sum of sample n's row: the half that
+// owns the sample (accumulator rows of half h are the samples with bit 2 == h) and its row index there
+__device__ __forceinline__ int row_sum_source(int n) { return 4 * (32 * ((n >> 2) & 1) + ((n & 3) | ((n >> 3) << 2))); }
+__device__ __forceinline__ float row_sums_to_samples(float folded, int src_addr) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_addr, __builtin_bit_cast(int, folded)));
+}
+
 // ---- tile operands through buffer loads: a raw buffer resource over a device array (loads past `bytes` return 0), a
 // per-lane byte offset that never changes and the tile's byte offset in an SGPR — no vector address arithmetic per tile
 // (64-bit global addresses cost ~15 vector instructions per tile in these kernels' loops)

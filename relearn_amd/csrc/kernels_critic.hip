@@ -36,7 +36,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
                        double *__restrict__ slabB, float two_over_B, uint32_t P) {
   constexpr int D = 5, H = 128, NT = bt::NT;
   constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] (slot 6 unused); then db2, loss
+#ifndef RL_CRITIC_Y_IN_REGISTERS
   __shared__ __attribute__((aligned(16))) float Ysh[CRITIC_WAVES][32][bt::YROW];
+#endif
   __shared__ double Acc[CRITIC_WAVES][IMG];  // f64 level of the two-level accumulation, one image per wave
 
   const int lane = threadIdx.x & 63;
@@ -95,6 +97,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   const uint32_t off_a = ((uint32_t)(2 * hf) * plane32 + (uint32_t)n) * 4u, off_b = off_a + plane32 * 4u;
   const uint32_t off_c = (4u * plane32 + (uint32_t)n) * 4u, off_t = (uint32_t)n * 4u;
   int since_flush = 0;
+#ifdef RL_CRITIC_Y_IN_REGISTERS
+  const int ysrc = bt::row_sum_source(n);  // where fold_rows16 leaves the output-layer sum of sample n
+#endif
   // per lane: features 2 hf, 2 hf + 1 and 4 of sample n, and its target
   struct TileOp {
     float xa, xb, xc, tgt;
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
       bt::mask_tile(c, ga[t]);  // relu'(pre): one conversion per two values
       c = cn;
     }
+#ifndef RL_CRITIC_Y_IN_REGISTERS
     // ---- y: transpose the 16 partial sums per lane through LDS (row = sample, column = source lane)
 #pragma unroll
     for (int r = 0; r < 16; ++r) Ysh[wave][(r & 3) + 8 * (r >> 2) + 4 * hf][n] = yp[r];
@@ -150,6 +156,19 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     float p0, p1;
     bt::both_halves(part, p0, p1);
     const float y = 0.5f * (p0 + p1) + b2;
+#else
+    // ---- y (A/B build, -DRL_CRITIC_Y_IN_REGISTERS): the 16 partial sums per lane folded over the half's 32 unit lanes in
+    // registers (bf16_tile.hpp fold_rows16), then one permute brings sample n's sum to both lanes that own sample n.
+    // Measured in round 5: 11 LDS instructions fewer, 18 vector instructions and 21 wait states more per tile — the same
+    // 0.20 ms per step (scripts/critic_only.py, both builds on one box): the LDS round trip was not what the tile waits for.
+    const float abs_sum = bt::row_sums_to_samples(bt::fold_rows16(yp, lane), ysrc);
+    float lin = lv[0] * op.xa;  // the linear half of relu: this half's inputs of sample n, then the other half's
+    lin = __builtin_fmaf(lv[1], op.xb, lin);
+    lin = __builtin_fmaf(lv[2], hf == 0 ? op.xc : 1.0f, lin);
+    float l0, l1;
+    bt::both_halves(lin, l0, l1);
+    const float y = 0.5f * (abs_sum + (l0 + l1)) + b2;
+#endif
     const float d = y - op.tgt;
     const float dy = valid ? d * two_over_B : 0.0f;
     if (valid) {  // (both halves hold sample n and count it; the reduction after the loop reads half 0 only)
@@ -161,7 +180,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     Frag ub[2];
     bt::piece_frags_mfma(dy, op.xa, op.xb, op.xc, hf, selb, ub);
     bt::backward(ga, ub, dm);
+#ifndef RL_CRITIC_Y_IN_REGISTERS
     bt::wave_lds_fence();  // Ysh is rewritten by the next tile
+#endif
     if (++since_flush == C_FLUSH) {
       since_flush = 0;
       bt::flush(dm, acc64, 7, n, hf);
