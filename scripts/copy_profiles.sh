@@ -1,13 +1,14 @@
 #!/bin/bash
 # Copies what scripts/collect_profiles.sh left under gpurun_out/prof_<tag>/ into profiles/<tag>_* (the tracked evidence).
 set -u
-TAG="${1:-r04}"
+TAG="${1:-r05}"
 SRC="gpurun_out/prof_$TAG"
 DST="profiles"
 for f in bench_65536 bench_32768 bench_16384 bench_8192 bench_4096 bench_under_rocprof_65536 bench_under_rocprof_8192 \
          bench_under_rocprof_4096 bench_under_rocprof_serial_65536 bench_under_rocprof_serial_8192 dqn_config3 gru_config5 \
          lstm_config5 general_mlp_period overlap_65536 overlap_8192 pmc_65536_summary pmc_gen_pair_summary pmc_dqn_summary \
-         pmc_gru_config5_summary pmc_lstm_config5_summary stacked_gru_l2 stacked_lstm_l2; do
+         pmc_gru_config5_summary pmc_lstm_config5_summary stacked_gru_l2 stacked_lstm_l2 bench_65536_with_counters \
+         rccl_one_rank_floor_8192; do
   [ -s "$SRC/$f.json" ] && cp "$SRC/$f.json" "$DST/${TAG}_$f.json"
 done
 cp "$SRC/general_mlp_passes.txt" "$DST/${TAG}_general_mlp_passes.txt" 2>/dev/null

@@ -6,6 +6,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import relearn_amd as ra  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
@@ -69,4 +70,28 @@ for name, (cls, flop) in passes.items():
             "ms": ms, "f32_equivalent_tflops": flop / ms / 1e9, "frac_of_f32_mfma_peak": flop / ms / 1e9 / 157.3,
             "executed_bf16_tflops": 6 * flop / ms / 1e9, "frac_of_bf16_mfma_peak": 6 * flop / ms / 1e9 / 2500.0}
 out["ms_per_gradient"] = sum(v["ms"] for v in out["gradient_passes"].values()) + (k.get("reduce", 0) + k.get("small", 0)) / n_grad
+# ---- roofline of a gradient evaluation, as bench.py reports it for config 4.  The five kernels of an
+# evaluation are HBM-bound on the activation record they hand each other: 24 plane transfers of N x T x 128 x 4 B
+#  against an algorithmic input of the observations, actions, advantages and flags of the batch.
+import roofline_util as ru  # noqa: E402
+plane = 4.0 * 128 * steps
+accounted = 24.0 * plane
+alg_bytes = (5 * 4 + 1 + 4 + 1) * steps
+kernels, src = ru.pmc_kernels("r05_pmc_gru_config5_summary.json")
+traffic, found = ru.traffic_of(kernels if src["applies"] else {}, {
+    "k_gru_recur_fwd": 1.0, "k_seq_head_forward<1>": 80.0 / n_grad, "k_seq_head_forward<2>": 10.0 / n_grad,
+    "k_gru_head_backward<1>": 80.0 / n_grad, "k_gru_head_backward<2>": 10.0 / n_grad, "k_gru_recur_bwd": 1.0,
+    "k_gru_wgrad_bf16": 1.0})
+ms = out["ms_per_gradient"]
+moved = traffic if traffic else accounted
+out["roofline"] = {
+    "kernel": "one gradient evaluation through time (k_gru_recur_fwd, k_seq_head_forward, k_gru_head_backward, "
+              "k_gru_recur_bwd, k_gru_wgrad_bf16)",
+    "bound": "hbm", "achieved": moved / (ms * 1e-3) / 1e9, "peak": ru.HBM_PEAK_GBS, "unit": "GB/s",
+    "frac": moved / (ms * 1e-3) / 1e9 / ru.HBM_PEAK_GBS, "traffic": traffic,
+    "bytes_used_for_achieved": "counters" if traffic else "plane accounting (24 planes)",
+    "accounted_bytes": accounted, "algorithmic_bytes": alg_bytes, "moved_over_algorithmic": moved / alg_bytes,
+    "ms_per_gradient": ms, "gradients_per_period": n_grad, "source": src, "kernels_in_traffic": found,
+    "note": "achieved = bytes the evaluation MOVES / its time (the bench contract's HBM form); the algorithmic input of the "
+            "batch is ~400x smaller: the traffic is the activation record of backpropagation through time (DESIGN 13a)"}
 print(json.dumps(out))
