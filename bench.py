@@ -83,16 +83,37 @@ def cpu_baseline(args):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # the cores this job may actually use at once: a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) can be far
+    # below the visible CPU count; passes with a barrier per pass (the intra-op leg) must not be oversubscribed
+    usable = cores
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                usable = max(1, min(cores, int(q / p_ + 0.5)))
+        except Exception:
+            pass
     H = args.hidden
     ps, cs = O.MlpShape(5, H, 2), O.MlpShape(5, H, 1)
     pp, cp = O.mlp_init(ps, 2), O.mlp_init(cs, 3)
+    # (no quota to read: a one-GPU job's share of the host is 16 cores on this pool; a pass has a barrier at its end, and
+    # a pool wider than the cores it really gets spends the update spinning — 20 s instead of 2 s with 256 threads)
+    if usable == cores:
+        usable = min(cores, 16)
+    if os.environ.get("RELEARN_BENCH_USABLE_CORES"):
+        usable = max(1, min(cores, int(os.environ["RELEARN_BENCH_USABLE_CORES"])))
     opt = O.lib().oracle_adam_new(len(cp))
     st = O.PeriodStats()
     t0 = time.time()
     per_thread = max(64, args.cpu_sample_steps // cores)
     # (the update twice: on one thread, and with every full-batch pass split over the cores like libtorch's intra-op pool)
     O.lib().oracle_cartpole_trpo_period_ex(0, 0, cores, per_thread, 100, args.max_episode_steps, H,
-                                           O.f32p(pp), O.f32p(cp), opt, args.critic_steps, cores, C.byref(st))
+                                           O.f32p(pp), O.f32p(cp), opt, args.critic_steps, usable, C.byref(st))
     wall = time.time() - t0
     O.lib().oracle_adam_free(opt)
     steps = int(st.steps)
@@ -112,17 +133,18 @@ def cpu_baseline(args):
     return {
         # the reference's agent update runs on one Rust thread, but its batched matmuls run on libtorch's intra-op pool:
         # the headline CPU figure is the one with the update's passes split over the cores (the faster, fairer one)
-        "value": steps / (st.rollout_seconds + st.update_intraop_seconds),
+        "value": steps / (st.rollout_seconds + min(st.update_intraop_seconds, st.update_seconds)),
         "value_single_threaded_update": steps / (st.rollout_seconds + st.update_seconds),
-        "update_seconds": {"one_thread": st.update_seconds, "passes_over_%d_threads" % cores: st.update_intraop_seconds},
+        "update_seconds": {"one_thread": st.update_seconds, "passes_over_%d_threads" % usable: st.update_intraop_seconds},
+        "usable_cores": usable,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
         "build": "gcc -O3 -ffp-contract=off -mavx2 -mfma -fopenmp (oracle/Makefile)",
         "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes), then GAE + TRPO + %d Adam "
-                  "steps: on one thread %.2f s, with every full-batch pass split over %d threads %.2f s (the figure in "
-                  "`value`); rollout %.2f s" % (
-                      cores, per_thread, steps, int(st.episodes), args.critic_steps, st.update_seconds, cores,
+                  "steps: on one thread %.2f s, with every full-batch pass split over %d threads %.2f s (`value` takes the "
+                  "faster of the two); rollout %.2f s" % (
+                      cores, per_thread, steps, int(st.episodes), args.critic_steps, st.update_seconds, usable,
                       st.update_intraop_seconds, st.rollout_seconds),
         "rollout_only_steps_per_s": ro_steps / max(ro_s, 1e-9),
         "rollout_only_sample": "%d threads x %d scalar Steps::step steps in %.2f s (worker threads started before the "
