@@ -104,9 +104,11 @@ int32_t rl_engine_set_kernel_variant(rl_engine *engine, int32_t variant);
  * small end when the biases are non-zero, and |obs| >= 7e-14 when they are zero.  Observation pieces below 2^-126 (bf16
  * subnormals: |obs| < 2^-110) may be flushed by the matrix pipe; inside the range above their contribution is below the
  * f32 rounding of the terms that carry the pre-activation.
- * The library checks the condition on every fused launch, from the weights it has just loaded and the magnitude range of
- * the trajectory's observation planes (measured once per rollout / rl_traj_write; the DQN minibatches use fixed bounds
- * for CartPole-generated observations, 2^-64 <= |obs| <= 2^16).  Outside the range the call returns RL_ERR_UNSUPPORTED
+ * The library checks the condition in the first fused launch of each module of every call (the later launches of the
+ * same call start from parameters that call produced itself, in steps bounded by the learning rate or the KL constraint),
+ * from the weights the launch has just loaded and the magnitude range of the trajectory's observation planes (measured
+ * once per rollout / rl_traj_write; the DQN minibatches use fixed bounds for CartPole-generated observations,
+ * 2^-64 <= |obs| <= 2^16).  Outside the range the call returns RL_ERR_UNSUPPORTED
  * — never a silently wrong mask; its outputs (and, for an update, the parameters it was stepping) are then not valid.
  * Kernel variant 1 is plain f32 and takes any magnitudes.  tests/test_gpu_numeric_range.py. */
 /* HIP-event timing of everything enqueued between begin and end on the engine stream (milliseconds) */

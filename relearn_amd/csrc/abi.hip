@@ -1430,8 +1430,17 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   t->d.adv = dalloc<float>(T * n);
   t->d.rtg = dalloc<float>(T * n);
   t->d.tgt = t->d.rtg;  // the critic regresses on the returns unless rl_values_opt_update selects other targets
-  t->d.range = dalloc<uint32_t>(4);
-  RL_HIP_CHECK(hipMemsetAsync(t->d.range, 0, 4 * sizeof(uint32_t), e->stream));
+  t->d.range = dalloc<uint32_t>(RL_RANGE_WORDS);
+  RL_HIP_CHECK(hipMemsetAsync(t->d.range, 0, RL_RANGE_WORDS * sizeof(uint32_t), e->stream));
+  {
+    void *hp = nullptr;
+    RL_HIP_CHECK(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+    *static_cast<volatile uint32_t *>(hp) = 0u;
+    void *dp = nullptr;
+    RL_HIP_CHECK(hipHostGetDevicePointer(&dp, hp, 0));
+    t->h_range_err = static_cast<uint32_t *>(hp);
+    t->d.range_err = static_cast<uint32_t *>(dp);
+  }
   t->lp0 = dalloc<float>(2 * n * T);
   t->dz = dalloc<float>(2 * n * T);
   t->Pmax = 128 * 5 + 128 + 2 * 128 + 2;
@@ -1488,6 +1497,7 @@ int32_t rl_traj_destroy(rl_traj *t) {
                   t->lp0, t->dz, t->slabA, t->slabB, t->vec, t->cg_x, t->cg_r, t->cg_p, t->prev_params, t->descent,
                   t->losses, t->trpo, t->td, t->aux_slabA, t->aux_slabB, t->aux_vec, t->d.range};
   for (void *p : ptrs) dfree(p);
+  if (t->h_range_err) (void)hipHostFree(t->h_range_err);
   seq_free(t);
   gen_free(t);
   rl_engine *eng = t->eng;
@@ -1523,7 +1533,7 @@ int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t byte
     traj_field(t, field, &p, &need);
     RL_REQUIRE(bytes == need, "byte count mismatch for trajectory field");
     h2d(t->eng, p, host, bytes);
-    if (field == RL_TRAJ_OBS) t->range_valid = false;  // (the fused kernels' range guard reads the planes' magnitudes)
+    if (field == RL_TRAJ_OBS) t->range_valid = t->range_reset = false;  // (the range guard reads the planes' magnitudes)
   });
 }
 
@@ -1610,7 +1620,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     // into ANOTHER trajectory touches neither (it reads the policy the TRPO chain has already finished with) and goes
     // ahead beside it on the main stream; anything else waits for the chain like every other call.
     if (traj == env->eng->pending.traj || policy == env->eng->pending.critic) engine_settle(env->eng);
-    traj->range_valid = false;  // new observations: the fused update kernels' range guard measures them again
+    traj->range_valid = traj->range_reset = false;  // new observations: the range guard has them measured again
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
     if (policy->general) {  // any hidden_sizes: one launch sequence per step, either env family (advances t_global)

@@ -167,8 +167,12 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     {  // the fused step's range guard (bf16_tile.hpp): the minibatches hold observations this env produced — bounded by
        // its termination thresholds and, for the velocities, by what a 500-step episode can reach; fixed bounds with room
       const float lo = 0x1p-64f, hi = 0x1p16f;
-      const uint32_t words[4] = {__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi), 0u, 0u};
-      h2d(e, q->mb->d.range, words, sizeof(words));
+      std::vector<uint32_t> words(RL_RANGE_WORDS, 0u);  // every slot of the minima / the maxima (bf16_tile.hpp)
+      for (int s = 0; s < 64; ++s) {
+        words[(size_t)s * 32] = __builtin_bit_cast(uint32_t, lo);
+        words[(size_t)(64 + s) * 32] = __builtin_bit_cast(uint32_t, hi);
+      }
+      h2d(e, q->mb->d.range, words.data(), words.size() * sizeof(uint32_t));
       q->mb->range_fixed = true;
     }
     q->own_obs = q->mb->d.obs;
@@ -640,6 +644,7 @@ int32_t rl_dqn_minibatch_gradient(rl_dqn *q, float *grad_out, float *loss_out) {
     dqn_gradient(q);
     std::vector<float> h(P + 4);
     d2h(q->eng, h.data(), q->mb->vec, (P + 4) * sizeof(float));
+    range_check(q->mb);
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     if (loss_out) *loss_out = (float)((double)h[P] / (double)q->last_total_steps);
   });

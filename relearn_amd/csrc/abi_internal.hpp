@@ -77,13 +77,14 @@ static inline void d2h(rl_engine *e, void *h, const void *d, size_t bytes) {
 }
 
 // The fused kernels' range guard (bf16_tile.hpp range_guard) found weights / observations outside the range in which the
-// 2^96-scaled forward is exact: their results are not to be used.  Synchronises the engine's current stream.
+// 2^96-scaled forward is exact: their results are not to be used.  Called after the entry point has synchronised the
+// stream its fused launches ran on (every caller has just read results back): the error word lives in host memory.
 static inline void range_check(rl_traj *t) {
-  if (t->d.range == nullptr) return;
-  uint32_t err = 0;
-  d2h(t->eng, &err, t->d.range + 2, sizeof(err));
-  if (err == 0) return;
-  RL_HIP_CHECK(hipMemsetAsync(t->d.range + 2, 0, sizeof(uint32_t), t->eng->stream));
+  t->guard_next_policy = t->guard_next_critic = true;  // the next entry point's first fused launches check again
+  if (t->h_range_err == nullptr) return;
+  volatile uint32_t *w = t->h_range_err;
+  if (*w == 0u) return;
+  *w = 0u;
   throw RlError(RL_ERR_UNSUPPORTED,
                 "numeric range of the fused update kernels exceeded (|pre-activation| bound 2^31 or a non-zero "
                 "pre-activation below 2^-46 possible, or a non-finite observation): the result of this call is not "

@@ -585,7 +585,11 @@ static void actor_critic_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_o
     // waiting for the HOST (measured: profiles/r04_overlap_trace_8192.csv, the policy chain starts when the critic
     // chain is nearly done).  So: a few critic steps to give the device something to do, the TRPO chain's head, the
     // rest of the critic chain, and only then the TRPO chain's read-backs.
-    const uint64_t K0 = K < 6 ? K : 6;
+    uint64_t K0 = K < 6 ? K : 6;
+    if (const char *k0 = std::getenv("RELEARN_CRITIC_HEAD_STEPS")) {  // (A/B: K = the whole critic chain first, round 4's order)
+      const long long v = std::atoll(k0);
+      K0 = v < 0 ? 0 : ((uint64_t)v > K ? K : (uint64_t)v);
+    }
     static const bool marks = std::getenv("RELEARN_HOST_MARKS") != nullptr;  // debugging aid: host time of each phase
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = marks ? now() : 0.0;

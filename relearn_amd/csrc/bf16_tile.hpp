@@ -286,19 +286,49 @@ __device__ __forceinline__ void pack_mask_now(const float (&gm)[16], Frag (&ga)[
 constexpr float FWD_SCALE = 0x1p96f, FWD_UNSCALE = 0x1p-96f;
 
 // The numeric range in which the scaled forward is exact (include/relearn_hip.h, "Numeric range of the fused kernels"),
-// checked once per launch from the weights this lane has just loaded (hidden unit j: its weights for inputs 2 hf, 2 hf + 1,
-// input 4 and its bias) and the magnitude range of the trajectory's observations (range[0] = bits of the smallest
-// non-zero |x|, range[1] = bits of the largest |x|; a NaN / Inf observation shows up as range[1] >= 0x7F800000):
+// checked once per call from the weights the first fused launch has just loaded (hidden unit j: its weights for inputs
+// 2 hf, 2 hf + 1, input 4 and its bias) and the magnitude range of the trajectory's observations (xmin = the smallest
+// non-zero |x|, xmax = the largest |x|, from the range words: range_bounds; a NaN / Inf observation shows up as a
+// non-finite xmax):
 //   overflow   2^96 pre must stay finite with room for the partial sums:  sum_k |W1[j][k]| max|x| + |b1[j]| < 2^31;
 //   relu'      a non-zero pre must reach 2^-96, or the clamped conversion returns a FRACTIONAL mask.  pre is a sum of
 //              exact products whose f32 accumulation can cancel down to 2^-48 of its largest term, so the largest term of
 //              a unit that is not identically zero must be able to reach 2^-46: max(max_k |W1[j][k]| min_nz|x|, |b1[j]|).
-// A violation sets the sticky word range[2]; the launch goes on (its numbers are then not to be used) and the host raises
-// RL_ERR_UNSUPPORTED at its next read-back (kernel variant 1 has no such bound).  ~60 instructions per wave and launch.
-__device__ __forceinline__ void range_guard(float wa, float wb, float w4, float bj, int hf, uint32_t *range) {
-  if (range == nullptr) return;
-  const float xmax = __builtin_bit_cast(float, range[1]);
-  const float xmin = range[1] == 0u ? 0.0f : __builtin_bit_cast(float, range[0]);  // (all observations zero: pre = bias)
+// A violation sets the word *err (host memory mapped into the device); the launch goes on (its numbers are then not to be
+// used) and the host raises RL_ERR_UNSUPPORTED after its next synchronisation (kernel variant 1 has no such bound).
+// ~60 instructions for one wave of the launch.
+// The range words: RANGE_SLOTS minima and RANGE_SLOTS maxima, one 128-byte line each (writers fold into slot
+// workgroup % RANGE_SLOTS: tens of thousands of atomics on ONE address resolve one after the other in the L2 and cost
+// a 4,096-lane period 0.1 ms; the reader is one wave, one slot per lane).
+constexpr int RANGE_SLOTS = 64, RANGE_STRIDE = 32;  // (words)
+constexpr int RANGE_WORDS = 2 * RANGE_SLOTS * RANGE_STRIDE;
+__device__ __forceinline__ uint32_t *range_lo_slot(uint32_t *range, int s) { return range + s * RANGE_STRIDE; }
+__device__ __forceinline__ uint32_t *range_hi_slot(uint32_t *range, int s) { return range + (RANGE_SLOTS + s) * RANGE_STRIDE; }
+__device__ __forceinline__ void range_fold(uint32_t *range, uint32_t workgroup, uint32_t lo, uint32_t hi) {
+  const int s = (int)(workgroup % RANGE_SLOTS);
+  if (lo < __hip_atomic_load(range_lo_slot(range, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(range_lo_slot(range, s), lo);
+  if (hi > __hip_atomic_load(range_hi_slot(range, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(range_hi_slot(range, s), hi);
+}
+__device__ __forceinline__ void range_reset(uint32_t *range, int tid, int nthreads) {
+  for (int s = tid; s < RANGE_SLOTS; s += nthreads) {
+    *range_lo_slot(range, s) = 0x7F7FFFFFu;
+    *range_hi_slot(range, s) = 0u;
+  }
+}
+// the whole wave: lane l reads slot l; every lane returns the bounds
+__device__ __forceinline__ void range_bounds(uint32_t *range, int lane, float &xmin, float &xmax) {
+  uint32_t lo = *range_lo_slot(range, lane % RANGE_SLOTS), hi = *range_hi_slot(range, lane % RANGE_SLOTS);
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, m, 64), oh = (uint32_t)__shfl_xor((int)hi, m, 64);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  xmax = __builtin_bit_cast(float, hi);
+  xmin = hi == 0u ? 0.0f : __builtin_bit_cast(float, lo);  // (all observations zero: pre = bias)
+}
+__device__ __forceinline__ void range_guard(float wa, float wb, float w4, float bj, int hf, float xmin, float xmax,
+                                            uint32_t *err) {
   const float aa = __builtin_fabsf(wa), ab = __builtin_fabsf(wb);
   const float own = hf == 0 ? __builtin_fabsf(w4) : 0.0f, bias = __builtin_fabsf(bj);
   float hi = (aa + ab + own) * xmax, lo = __builtin_fmaxf(__builtin_fmaxf(aa, ab), own) * xmin, nz = aa + ab + own;
@@ -309,7 +339,7 @@ __device__ __forceinline__ void range_guard(float wa, float wb, float w4, float 
   const float upper = hi0 + hi1 + bias, largest = __builtin_fmaxf(__builtin_fmaxf(lo0, lo1), bias);
   const bool zero_unit = nz0 + nz1 + bias == 0.0f;
   const bool bad = !(upper < 0x1p31f) || (!zero_unit && !(largest >= 0x1p-46f));
-  if (bad) __hip_atomic_store(range + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bad) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ uint32_t mask_pair(float lo, float hi, float after) {
   uint32_t r;

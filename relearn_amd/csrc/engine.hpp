@@ -53,6 +53,7 @@ struct EnvStateDev {
   uint32_t *reset_count;          // [n]
 };
 
+constexpr int RL_RANGE_WORDS = 2 * 64 * 32;  // = bt::RANGE_WORDS (bf16_tile.hpp)
 struct TrajDev {
   float *obs;       // [D][T+1][n]
   uint8_t *action;  // [T][n]
@@ -64,9 +65,12 @@ struct TrajDev {
   float *rtg;       // [T][n]
   float *tgt;       // [T][n] regression targets of the critic update: rtg, or the one-step TD targets (StepValueTarget)
   uint32_t n, T, D;
-  // [4] numeric range of the observation planes, for the fused kernels' guard (bf16_tile.hpp range_guard): bits of the
-  // smallest non-zero |obs|, bits of the largest |obs| (k_obs_range), the sticky range-error word, unused
+  // numeric range of the observation planes, for the fused kernels' guard (bf16_tile.hpp range_guard): 64 slots of the
+  // bits of the smallest non-zero |obs|, 64 of the bits of the largest |obs|, one 128-byte line each (RL_RANGE_WORDS)
   uint32_t *range;
+  // the guard's error word, in HOST memory mapped into the device (hipHostMalloc): a violation is one store across the
+  // bus, and the host reads the word after a synchronisation it makes anyway — no copy, no extra round trip per update
+  uint32_t *range_err;
 };
 
 // the DQN replay store: every lane is one ReplayBuffer (src/agents/buffers/replay.rs:11-27), see replay.hpp for the
@@ -344,6 +348,15 @@ struct rl_traj {
   // d.range[0..1] describe the current observation planes (false after anything rewrote them: traj_ensure_range, abi.hip);
   // `range_fixed`: the words are constants of the producer (the DQN minibatch workspace: CartPole-generated observations)
   bool range_valid = false, range_fixed = false;
+  // the rollout that wrote the planes has reset d.range[0..1]: the value forward that follows (launch_values) measures
+  // the range on the way and no pass of its own is needed
+  bool range_reset = false;
+  uint32_t *h_range_err = nullptr;  // host view of d.range_err
+  // the range guard runs in the FIRST fused launch of each kind after an entry point began (range_check at the end of
+  // every entry point re-arms it): the later launches of the same call — 79 of a critic update's 80 steps, the
+  // Fisher-vector products and line-search candidates of a TRPO update — start from parameters the same call produced in
+  // steps bounded by the learning rate / the KL constraint, and the wave that runs the guard starts its tiles ~1 us late
+  bool guard_next_policy = true, guard_next_critic = true;
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
   GenDev gen;

@@ -1,5 +1,6 @@
 // kernels.hpp — host launchers implemented in the .hip translation units.
 #pragma once
+#include <cstdlib>
 #include <functional>
 // arrays of [128 units][32 lanes] floats per (step, tile) block in the recurrent training workspace (kernels_seq.hip)
 #define RL_SEQ_ACT_ARRAYS 9
@@ -21,6 +22,8 @@ void launch_obs_range(rl_traj *traj);
 // ... once per content of the planes: whoever rewrites them (rollouts, rl_traj_write) clears `range_valid`
 inline void traj_ensure_range(rl_traj *traj) {
   if (traj->range_valid || traj->range_fixed) return;
+  static const bool off = std::getenv("RELEARN_NO_RANGE_GUARD") != nullptr;  // (A/B timing only: the guard then reads stale words)
+  if (off) return;
   launch_obs_range(traj);
   traj->range_valid = true;
 }

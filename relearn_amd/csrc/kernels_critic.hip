@@ -56,6 +56,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   Frag fw[NT][3];
   float w2v[NT];
   float lv[3] = {0.0f, 0.0f, 0.0f};
+  const bool guard = blockIdx.x == 0 && wave == 0 && tr.range != nullptr;  // the numeric range guard (bf16_tile.hpp)
+  float gxmin = 0.0f, gxmax = 0.0f;
+  if (guard) bt::range_bounds(tr.range, lane, gxmin, gxmax);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = t * 32 + n;
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     lv[2] = __builtin_fmaf(w2, hf == 0 ? w4 : bj, lv[2]);
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain takes the scale
     // back out through w2 (both exact)
-    if (blockIdx.x == 0 && wave == 0) bt::range_guard(wa, wb, w4, bj, hf, tr.range);  // (one wave sees all 128 units)
+    if (guard) bt::range_guard(wa, wb, w4, bj, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
     const float sc = bt::FWD_SCALE;
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
     w2v[t] = bt::FWD_UNSCALE * w2;
@@ -275,7 +278,10 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (nb > cus) nb = cus;
   traj->nbC = (uint32_t)nb;
   traj->last_rows = traj->nbC;
-  hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, traj->d,
+  TrajDev d = traj->d;
+  if (!traj->guard_next_critic) d.range = nullptr;  // (the range guard: first critic launch of the call only, engine.hpp)
+  traj->guard_next_critic = false;
+  hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, d,
                      critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
   return true;
 }

@@ -795,11 +795,14 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   Frag fw[NT][3];
   float w2v[A][NT];
   float lv[A][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};  // the linear half of relu, per output
+  const bool guard = blockIdx.x == 0 && wave == 0 && tr.range != nullptr;  // the numeric range guard (bf16_tile.hpp)
+  float gxmin = 0.0f, gxmax = 0.0f;
+  if (guard) bt::range_bounds(tr.range, lane, gxmin, gxmax);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = t * 32 + n;
     const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
-    if (blockIdx.x == 0 && wave == 0) bt::range_guard(wa, wb, w4, bj, hf, tr.range);  // (one wave sees all 128 units)
+    if (guard) bt::range_guard(wa, wb, w4, bj, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
     const float sc = bt::FWD_SCALE;  // relu' by conversion (bf16_tile.hpp); the |pre| chains take the scale back out
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
 #pragma unroll
@@ -1006,11 +1009,14 @@ bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total, boo
   uint64_t nb = (n_tiles + DQN_WAVES - 1) / DQN_WAVES;
   if (nb > cus) nb = cus;
   mb->nbV2 = (uint32_t)nb;  // slab rows of this launch (the slabs are sized for any grid up to 8 x CUs)
+  TrajDev d = mb->d;
+  if (!mb->guard_next_policy) d.range = nullptr;  // (the range guard: first step of an update only, engine.hpp)
+  mb->guard_next_policy = false;
   if (td_in_kernel)
-    hipLaunchKernelGGL(k_dqn_step_bf16<true>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, mb->d,
+    hipLaunchKernelGGL(k_dqn_step_bf16<true>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, d,
                        qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
   else
-    hipLaunchKernelGGL(k_dqn_step_bf16<false>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, mb->d,
+    hipLaunchKernelGGL(k_dqn_step_bf16<false>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, d,
                        qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
   RL_HIP_CHECK(hipGetLastError());
   return true;

@@ -70,13 +70,16 @@ __global__ void __launch_bounds__(WAVES * 64)
   float w2d[NT];
   float lvd[3] = {0.0f, 0.0f, 0.0f};  // the linear half of relu (bf16_tile.hpp) for the differenced logit
   float tb2d = 0.0f;
+  const bool guard = blockIdx.x == 0 && wave == 0 && tr.range != nullptr;  // the numeric range guard (bf16_tile.hpp)
+  float gxmin = 0.0f, gxmax = 0.0f;
+  if (guard) bt::range_bounds(tr.range, lane, gxmin, gxmax);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int j = t * 32 + n;
     const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain of the gradient /
     // evaluation passes takes the scale back out through w2d (both exact); the Fisher-vector pass only needs the masks
-    if (blockIdx.x == 0 && wave == 0) bt::range_guard(wa, wb, w4, bj, hf, tr.range);  // (one wave sees all 128 units)
+    if (guard) bt::range_guard(wa, wb, w4, bj, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
     const float sc = bt::FWD_SCALE;
     bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
     if (FW_LDS && wave == t) {
@@ -426,8 +429,11 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
   hipStream_t s = traj->eng->stream;
   uint32_t P = (uint32_t)policy->P;
+  TrajDev d = traj->d;
+  if (!traj->guard_next_policy) d.range = nullptr;  // (the range guard: first policy launch of the call only, engine.hpp)
+  traj->guard_next_policy = false;
 #define BLAUNCH(MM)                                                                                                  \
-  hipLaunchKernelGGL((k_policy_bf16<MM, V2_WAVES>), g, b, 0, s, traj->d, policy->d_params, d_tangent, traj->lp0,       \
+  hipLaunchKernelGGL((k_policy_bf16<MM, V2_WAVES>), g, b, 0, s, d, policy->d_params, d_tangent, traj->lp0,             \
                      traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
   if (mode == PASS_INIT) BLAUNCH(PASS_INIT);
   else if (mode == PASS_JVP) BLAUNCH(PASS_JVP);
@@ -436,7 +442,7 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
     // the evaluation pass has no backward state: with the weight fragments in LDS it fits twelve waves per CU (152
     // VGPRs) — 0.155 ms per launch at 8.4 M samples against 0.206 ms at eight (sixteen waves: 17 spills, no gain)
     constexpr int EVAL_WAVES = 16;
-    hipLaunchKernelGGL((k_policy_bf16<PASS_EVAL, EVAL_WAVES, true>), g, dim3(EVAL_WAVES * 64), 0, s, traj->d,
+    hipLaunchKernelGGL((k_policy_bf16<PASS_EVAL, EVAL_WAVES, true>), g, dim3(EVAL_WAVES * 64), 0, s, d,
                        policy->d_params, d_tangent, traj->lp0, traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi);
   }
 #undef BLAUNCH

@@ -4,6 +4,7 @@
 // global access of a wavefront is one contiguous 256-B (f32) / 64-B (u8) segment.
 #include <cstdlib>
 
+#include "bf16_tile.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
@@ -80,6 +81,9 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
   __shared__ __attribute__((aligned(16))) float pk[MLP_PK_FLOATS];  // the policy, one 8-float record per hidden unit
   const uint32_t n = tr.n, T = tr.T;
   mlp_pack_lds<D>(pk, policy, H, threadIdx.x, BLOCK);
+  // new observations: their magnitude range is measured by the value forward that follows (k_mlp_forward_rows<.., RANGE>),
+  // which starts from these words
+  if (blockIdx.x == 0) bt::range_reset(tr.range, (int)threadIdx.x, BLOCK);
   __syncthreads();
   // (Launch order = lane order.  Giving each XCD a contiguous range of lanes, so that the 32-byte pieces a wave of G = 2
   // writes into the byte-wide `action` / `flag` planes meet in one L2, was measured in round 4: WRITE_SIZE is 222 MB per
@@ -146,15 +150,38 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole(CartPoleDev c, EnvSt
 // ---------------------------------------------------------------- value forward over SoA rows
 // eval_extended_state_values (torch/agents/critics/mod.rs:116-131) on the lane layout: V for every
 // obs[.][t][lane], t = 0..T.  One row per lane, A outputs.
-template <int D, int A>
+// RANGE: the rows are a trajectory's observation planes, every one of them — the pass also folds the magnitude range of
+// what it reads (bits of the smallest non-zero |x| and of the largest |x|) into range[0..1] for the fused update kernels'
+// guard (bf16_tile.hpp; the words were reset by the rollout that wrote the planes).  A workgroup touches the shared
+// words only when it improves on what it reads there: a handful of the tens of thousands of workgroups do.
+template <int D, int A, bool RANGE = false>
 __global__ void __launch_bounds__(256) k_mlp_forward_rows(const float *__restrict__ params, int H,
                                                           const float *__restrict__ in, size_t in_plane,
-                                                          size_t rows, float *__restrict__ out, size_t out_plane) {
+                                                          size_t rows, float *__restrict__ out, size_t out_plane,
+                                                          uint32_t *__restrict__ range = nullptr) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+  if (!RANGE && r >= rows) return;
+  const bool live = r < rows;
   float x[D], z[A];
 #pragma unroll
-  for (int d = 0; d < D; ++d) x[d] = in[d * in_plane + r];
+  for (int d = 0; d < D; ++d) x[d] = live ? in[d * in_plane + r] : 0.0f;
+  if (RANGE) {
+    uint32_t lo = 0x7F7FFFFFu, hi = 0u;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const uint32_t a = __builtin_bit_cast(uint32_t, x[d]) & 0x7FFFFFFFu;
+      hi = a > hi ? a : hi;
+      lo = a != 0u && a < lo ? a : lo;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const uint32_t ol = (uint32_t)__shfl_xor((int)lo, m, 64), oh = (uint32_t)__shfl_xor((int)hi, m, 64);
+      lo = ol < lo ? ol : lo;
+      hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) bt::range_fold(range, blockIdx.x * 4 + (threadIdx.x >> 6), lo, hi);
+    if (!live) return;
+  }
   mlp_forward_lane<D, A>(params, H, x, z);
 #pragma unroll
   for (int a = 0; a < A; ++a) out[a * out_plane + r] = z[a];
@@ -334,35 +361,55 @@ static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) 
 // integer orders like the magnitude; NaN and Inf come out on top): what the fused update kernels' range guard reads
 // (bf16_tile.hpp).  One pass over the planes per period, HBM-bound (0.17 GB at the metric's size: ~40 us).
 __global__ void __launch_bounds__(256) k_obs_range(const float *__restrict__ x, size_t count, uint32_t *__restrict__ range) {
+  __shared__ uint32_t los[4], his[4];
   uint32_t lo = 0x7F7FFFFFu, hi = 0u;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-    const uint32_t a = __builtin_bit_cast(uint32_t, x[i]) & 0x7FFFFFFFu;
+  auto take = [&](float v) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, v) & 0x7FFFFFFFu;
     hi = a > hi ? a : hi;
     lo = a != 0u && a < lo ? a : lo;
+  };
+  // 16-byte loads, a grid-stride walk (the planes come from hipMalloc: 256-byte aligned); the tail element by element
+  const size_t quads = count / 4;
+  const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(x);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    take(v.x);
+    take(v.y);
+    take(v.z);
+    take(v.w);
   }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) take(x[quads * 4 + threadIdx.x]);
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
     const uint32_t ol = (uint32_t)__shfl_xor((int)lo, m, 64), oh = (uint32_t)__shfl_xor((int)hi, m, 64);
     lo = ol < lo ? ol : lo;
     hi = oh > hi ? oh : hi;
   }
+  // one pair of atomics per workgroup (thousands of same-address atomics resolve one after the other in the L2)
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(range + 0, lo);
-    atomicMax(range + 1, hi);
+    los[threadIdx.x >> 6] = lo;
+    his[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      lo = los[w] < lo ? los[w] : lo;
+      hi = his[w] > hi ? his[w] : hi;
+    }
+    bt::range_fold(range, blockIdx.x, lo, hi);
   }
 }
-__global__ void k_obs_range_reset(uint32_t *range) {
-  range[0] = 0x7F7FFFFFu;
-  range[1] = 0u;
-}
+__global__ void k_obs_range_reset(uint32_t *range) { bt::range_reset(range, (int)threadIdx.x, 64); }
 
 void launch_obs_range(rl_traj *traj) {
   ProfScope ps(traj->eng, RL_K_SMALL);
   const uint64_t D = traj->d.D > 5 ? traj->d.D : 5;
   const size_t count = (size_t)D * (traj->d.T + 1) * traj->d.n;
-  size_t blocks = (count + 256 * 16 - 1) / (256 * 16);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_obs_range_reset, dim3(1), dim3(1), 0, traj->eng->stream, traj->d.range);
+  size_t blocks = (count / 4 + 256 * 4 - 1) / (256 * 4);  // >= four 16-byte loads per thread
+  const size_t cap = 4 * (size_t)traj->eng->prop.multiProcessorCount;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_obs_range_reset, dim3(1), dim3(64), 0, traj->eng->stream, traj->d.range);
   hipLaunchKernelGGL(k_obs_range, dim3((unsigned)blocks), dim3(256), 0, traj->eng->stream, traj->d.obs, count,
                      traj->d.range);
 }
@@ -410,6 +457,7 @@ static void launch_rollout_g(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
   const uint32_t n = (uint32_t)env->cfg.n_lanes;
   hipLaunchKernelGGL((k_rollout_cartpole<D, BLOCK, G>), dim3(cdiv((size_t)n * G, BLOCK)), dim3(BLOCK), 0,
                      env->eng->stream, env->dev, env->st, traj->d, policy->d_params, (int)policy->hidden, env->t_global);
+  traj->range_reset = true;  // (the kernel has reset the range words for the value forward that follows)
 }
 
 void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
@@ -442,12 +490,18 @@ void launch_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
 void launch_values(rl_traj *traj, const rl_mlp *critic) {
   ProfScope ps(traj->eng, RL_K_VALUES);
   size_t rows = (size_t)(traj->d.T + 1) * traj->d.n;
-  if (traj->d.D == 5)
+  if (traj->d.D == 5 && traj->range_reset && !traj->range_valid && !traj->range_fixed) {
+    // the planes' magnitude range as a by-product of the pass that reads every observation anyway (no pass of its own)
+    hipLaunchKernelGGL((k_mlp_forward_rows<5, 1, true>), dim3(cdiv(rows, 256)), dim3(256), 0, traj->eng->stream,
+                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows, traj->d.range);
+    traj->range_valid = true;
+    traj->range_reset = false;
+  } else if (traj->d.D == 5)
     hipLaunchKernelGGL((k_mlp_forward_rows<5, 1>), dim3(cdiv(rows, 256)), dim3(256), 0, traj->eng->stream,
-                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows);
+                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows, (uint32_t *)nullptr);
   else
     hipLaunchKernelGGL((k_mlp_forward_rows<4, 1>), dim3(cdiv(rows, 256)), dim3(256), 0, traj->eng->stream,
-                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows);
+                       critic->d_params, (int)critic->hidden, traj->d.obs, rows, rows, traj->d.values, rows, (uint32_t *)nullptr);
 }
 
 void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
@@ -484,7 +538,7 @@ void launch_mlp_forward_host_rows(rl_mlp *mlp, const float *d_in_soa, size_t row
   hipStream_t s = mlp->eng->stream;
   int H = (int)mlp->hidden;
 #define FWD(DD, AA)                                                                                              \
-  hipLaunchKernelGGL((k_mlp_forward_rows<DD, AA>), g, b, 0, s, mlp->d_params, H, d_in_soa, rows, rows, d_out_soa, \
+  hipLaunchKernelGGL((k_mlp_forward_rows<DD, AA, false>), g, b, 0, s, mlp->d_params, H, d_in_soa, rows, rows, d_out_soa, \
                      rows)
   if (mlp->in_dim == 5 && mlp->out_dim == 2) FWD(5, 2);
   else if (mlp->in_dim == 5 && mlp->out_dim == 1) FWD(5, 1);
