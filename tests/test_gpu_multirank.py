@@ -463,3 +463,72 @@ def test_bench_as_four_processes_at_the_full_workload():
         # (over the mailboxes the critic chain's 80 exchanges run INSIDE its reduce + Adam launches)
         assert all(p["launches_per_step"] >= 1 + 11 + 2 + (80 if comm == "gloo" else 0) for p in per_rank)
         assert res["last_update"]["trpo_status"] == ra.OPT_OK
+
+
+def test_two_loopback_ranks_pipelined_periods_keep_identical_replicas():
+    """rl_actor_critic_update_begin / _finish with a collective: two ranks run three periods with the next rollout
+    enqueued under the critic chain (two trajectories per rank); both chains' all-reduces travel on their own channels,
+    every rank ends every period with the same policy and critic, and the sequence equals the same ranks running
+    rl_actor_critic_update without the split, bit for bit (same launches, same sums; only the host's enqueue order
+    differs)."""
+    os.environ["RELEARN_LOOPBACK_COMM"] = "1"
+    try:
+        def job(pipelined):
+            uid = ra.comm_unique_id()
+            out = {}
+
+            def run(rank):
+                try:
+                    eng = ra.Engine(0)
+                    eng.comm_init(rank, 2, uid)
+                    n = 512
+                    env = ra.CartPoleEnv(eng, n, max_steps=40, lane_offset=rank * n, seed_env=5, seed_actor=6)
+                    pol, cri = ra.Mlp(eng, 5, H, 2), ra.Mlp(eng, 5, H, 1)
+                    pol.init(2)
+                    cri.init(3)
+                    opt = ra.Adam(cri)
+                    trajs = [ra.Trajectory(eng, n, 32, 5), ra.Trajectory(eng, n, 32, 5)]
+                    ccfg = ra.values_opt_config_default()
+                    ccfg.opt_steps_per_update = 8
+                    res, pending = [], None
+                    for k in range(3):
+                        tr = trajs[k & 1]
+                        ra.rollout(env, pol, tr)
+                        ra.gae(tr, cri, 0.99, 0.95)
+                        if pipelined:
+                            if pending is not None:
+                                cst, losses = ra.actor_critic_update_finish(pending, want_losses=True)
+                                res[-1] += (cri.get_params(), losses)
+                            pst = ra.actor_critic_update_begin(pol, cri, opt, tr, None, ccfg)
+                            res.append((pst.as_dict(),))
+                            pending = tr
+                        else:
+                            pst, cst, losses = ra.actor_critic_update(pol, cri, opt, tr, None, ccfg, want_losses=True)
+                            res.append((pst.as_dict(), cri.get_params(), losses))
+                    if pipelined:
+                        cst, losses = ra.actor_critic_update_finish(pending, want_losses=True)
+                        res[-1] += (cri.get_params(), losses)
+                    out[rank] = (res, pol.get_params())
+                except BaseException as exc:
+                    out[rank] = exc
+                    raise
+
+            threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=200)
+            for r in range(2):
+                assert r in out and not isinstance(out[r], BaseException), out.get(r)
+            return out
+
+        plain, piped = job(False), job(True)
+    finally:
+        os.environ.pop("RELEARN_LOOPBACK_COMM", None)
+    for run in (plain, piped):  # identical replicas on both ranks, every period
+        assert np.array_equal(run[0][1], run[1][1])
+        for (s0, c0, l0), (s1, c1, l1) in zip(run[0][0], run[1][0]):
+            assert s0 == s1 and np.array_equal(c0, c1) and np.array_equal(l0, l1)
+    assert np.array_equal(plain[0][1], piped[0][1])
+    for (s0, c0, l0), (s1, c1, l1) in zip(plain[0][0], piped[0][0]):
+        assert s0 == s1 and np.array_equal(c0, c1) and np.array_equal(l0, l1)
