@@ -39,6 +39,19 @@ def lib_sha16():
     return hashlib.sha256(open(ra.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
+def build_record():
+    """which binary this line belongs to: the library's identity, and what the last build() did with it"""
+    import relearn_amd as ra
+    rec = {"lib_sha16": lib_sha16()}
+    try:
+        last = json.load(open(ra.BUILD_RECORD))
+        rec["last_build"] = last
+        rec["last_build_is_this_library"] = last.get("lib_sha16") == rec["lib_sha16"]
+    except Exception:
+        rec["last_build"] = None
+    return rec
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -593,6 +606,7 @@ def main():
             "phases": phases,
             "replicas_identical": replicas_identical,
             "allreduce_per_rank": allreduce_per_rank,
+            "build": build_record(),
             "last_update": {"trpo_status": st.status, "num_backtracks": st.num_backtracks,
                             "kl": st.constraint_val_final, "entropy": st.entropy,
                             "critic_loss_first": last["critic"].loss_first,

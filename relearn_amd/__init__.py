@@ -109,8 +109,36 @@ def build(force=False, check=False):
     when the library exists (a no-op when it is newer than every source) — what `__graft_entry__.build()` does; the
     default leaves an existing library alone, so that a process which has it loaded never relinks it under itself."""
     if force or check or not os.path.exists(LIB_PATH):
+        before = os.path.getmtime(LIB_PATH) if os.path.exists(LIB_PATH) else None
         subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
+        _write_build_record(before)
     return LIB_PATH
+
+
+BUILD_RECORD = os.path.join(_HERE, "build_record.json")
+
+
+def _write_build_record(mtime_before):
+    """what the last build() did — linked a new library, or found the shipped one newer than every source — with the
+    identity of the library; bench.py copies it into its line so that a reader knows which binary a number belongs to"""
+    import hashlib
+    import json
+    import time
+    try:
+        after = os.path.getmtime(LIB_PATH)
+        try:
+            hipcc = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, timeout=30).stdout.decode().splitlines()[0]
+        except Exception:
+            hipcc = None
+        rec = {"mode": "linked a new library" if mtime_before is None or after > mtime_before else
+                       "make: library newer than every source (nothing compiled)",
+               "lib_sha16": hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16],
+               "lib_mtime": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(after)),
+               "checked_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "hipcc": hipcc,
+               "arch": "gfx950"}
+        json.dump(rec, open(BUILD_RECORD, "w"), indent=1)
+    except Exception:
+        pass  # (a record, never a reason for a build to fail)
 
 
 _lib = None
