@@ -177,3 +177,36 @@ def test_rollout_histories_are_measured_again_every_period(engine):
     ra.gae(traj, cri, 0.99, 0.95)
     gc, _ = ra.critic_gradient(cri, traj)
     assert np.all(np.isfinite(gc))
+
+
+def test_dqn_update_checks_its_weights_against_the_fixed_observation_bounds(engine):
+    """rl_dqn_update's fused step sees CartPole-generated observations only, so its guard takes fixed bounds for them
+    (2^-64 <= |obs| <= 2^16) and checks the action-value network's weights: a network whose layer-1 rows could carry a
+    pre-activation past 2^31 is refused, the default initialisation passes, and variant 1 trains the large one."""
+    def agent(w1_scale):
+        env = ra.CartPoleEnv(engine, 256, max_steps=60, seed_env=9, seed_actor=10)
+        q = ra.Mlp(engine, 5, H, 2)
+        q.init(77)
+        p = q.get_params()
+        p[:5 * H] *= np.float32(w1_scale)
+        p[6 * H:] *= np.float32(1.0 / w1_scale)
+        q.set_params(p)
+        cfg = ra.dqn_config_default()
+        cfg.exploration_kind, cfg.exploration_start = ra.SCHEDULE_CONSTANT, 0.5
+        cfg.minibatch_steps, cfg.opt_steps_per_update, cfg.buffer_capacity = 2000, 3, 128
+        dqn = ra.Dqn(env, q, ra.Adam(q), cfg)
+        dqn.collect(60)
+        return dqn
+
+    st, losses = agent(1.0).update(want_losses=True)
+    assert st.opt_steps == 3 and np.all(np.isfinite(losses))
+    big = agent(1e5)  # 5 x ~2e4 x 2^16 = 6.6e9 >= 2^31
+    with pytest.raises(ra.RelearnError) as err:
+        big.update()
+    assert err.value.code == ra.ERR_UNSUPPORTED and "numeric range" in str(err.value)
+    engine.set_kernel_variant(1)
+    try:
+        st, losses = agent(1e5).update(want_losses=True)
+    finally:
+        engine.set_kernel_variant(0)
+    assert st.opt_steps == 3 and np.all(np.isfinite(losses))
