@@ -532,3 +532,14 @@ def test_two_loopback_ranks_pipelined_periods_keep_identical_replicas():
     assert np.array_equal(plain[0][1], piped[0][1])
     for (s0, c0, l0), (s1, c1, l1) in zip(plain[0][0], piped[0][0]):
         assert s0 == s1 and np.array_equal(c0, c1) and np.array_equal(l0, l1)
+
+
+def test_bench_pipelined_periods_report_the_same_update_as_the_plain_sequence():
+    """`bench.py --pipeline` (period k + 1's rollout enqueued under critic chain k, two trajectories) is the same
+    computation as the default sequence: after four periods the last update's statistics are identical to the digit."""
+    common = ("--envs", "4096", "--horizon", "32", "--critic-steps", "10", "--steps", "4", "--warmup", "0")
+    plain = run_bench(1, workload=common)
+    piped = run_bench(1, workload=common + ("--pipeline",))
+    assert "two trajectories" in piped["config"]["pipeline"] and plain["config"]["pipeline"] == "none"
+    assert plain["last_update"] == piped["last_update"]
+    assert plain["last_update"]["trpo_status"] == ra.OPT_OK
