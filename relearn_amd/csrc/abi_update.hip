@@ -586,7 +586,9 @@ static void actor_critic_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_o
     // chain is nearly done).  So: a few critic steps to give the device something to do, the TRPO chain's head, the
     // rest of the critic chain, and only then the TRPO chain's read-backs.
     uint64_t K0 = K < 6 ? K : 6;
-    if (const char *k0 = std::getenv("RELEARN_CRITIC_HEAD_STEPS")) {  // (A/B: K = the whole critic chain first, round 4's order)
+    // (A/B on one rank only — the ranks of a job must enqueue their collectives in one order: K = the whole critic chain
+    // first, round 4's order)
+    if (const char *k0 = e->n_ranks == 1 ? std::getenv("RELEARN_CRITIC_HEAD_STEPS") : nullptr) {
       const long long v = std::atoll(k0);
       K0 = v < 0 ? 0 : ((uint64_t)v > K ? K : (uint64_t)v);
     }

@@ -22,8 +22,6 @@ void launch_obs_range(rl_traj *traj);
 // ... once per content of the planes: whoever rewrites them (rollouts, rl_traj_write) clears `range_valid`
 inline void traj_ensure_range(rl_traj *traj) {
   if (traj->range_valid || traj->range_fixed) return;
-  static const bool off = std::getenv("RELEARN_NO_RANGE_GUARD") != nullptr;  // (A/B timing only: the guard then reads stale words)
-  if (off) return;
   launch_obs_range(traj);
   traj->range_valid = true;
 }
