@@ -351,6 +351,10 @@ def main():
         eng.sync()
 
     enter("warm-up periods (%s collective)" % comm_kind)
+    if os.environ.get("RELEARN_BENCH_TEST_STALL_RANK") == str(rank) and world > 1:
+        # test hook (tests/test_gpu_multirank.py): this rank never joins the job's first collective — what a rank that
+        # lost its GPU or its link looks like to the others; every rank's watchdog must end the job and name the phase
+        time.sleep(3600)
     periods(args.warmup)
     barrier()
     # Per-kernel HIP events (two per launch) cost ~2 ms of host time per period when they wrap all ~220 launches, so

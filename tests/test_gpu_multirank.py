@@ -543,3 +543,34 @@ def test_bench_pipelined_periods_report_the_same_update_as_the_plain_sequence():
     assert "two trajectories" in piped["config"]["pipeline"] and plain["config"]["pipeline"] == "none"
     assert plain["last_update"] == piped["last_update"]
     assert plain["last_update"]["trpo_status"] == ra.OPT_OK
+
+
+def test_a_stalled_rank_ends_the_bench_with_the_phase_it_was_stuck_in():
+    """bench.py's watchdog (multi-rank jobs): one of two ranks never joins the first collective of the warm-up; both ranks
+    must leave within the bound (RELEARN_BENCH_TIMEOUT, here 20 s after the rendezvous) with exit code 4 and a line on
+    stderr that names the phase — a job that stalls on a real node explains itself instead of holding it."""
+    import subprocess
+    import sys
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELEARN_BENCH_SINGLE_DEVICE="1", RELEARN_BENCH_COMM="gloo",
+               RELEARN_BENCH_TEST_STALL_RANK="1", RELEARN_BENCH_TIMEOUT="20")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--envs", "2048", "--horizon", "32", "--critic-steps", "5", "--no-cpu-baseline"]
+    proc = subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=200)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.communicate()
+        raise AssertionError("the stalled job did not end by itself")
+    text = err.decode()
+    assert proc.returncode != 0
+    assert "stuck in phase `warm-up periods (gloo collective)`" in text and "giving up (exit 4)" in text, text[-2000:]
+    assert not [l for l in out.decode().splitlines() if l.startswith("{")]  # no result line from a job that did not finish
