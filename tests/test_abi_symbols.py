@@ -119,3 +119,18 @@ def test_integration_doc_struct_layouts_match_the_header():
         assert rust.get(m.group(1)) == fields, (m.group(1), fields, rust.get(m.group(1)))
         checked += 1
     assert checked >= 11
+
+
+def test_headers_are_plain_c():
+    """the boundary is a C ABI: every header under include/ compiles as C99 with -pedantic (what a cgo / bindgen / ctypes
+    generator would be fed), and relearn_hip.h alone declares everything its prototypes use"""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for headers in (["relearn_hip.h"], ["rl_chacha.h", "rl_detmath.h"], ["relearn_hip.h", "rl_chacha.h", "rl_detmath.h"]):
+        src = "".join('#include "%s"\n' % h for h in headers) + "int main(void) { return 0; }\n"
+        with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I",
+                               os.path.join(root, "include"), "-fsyntax-only", f.name])
+        os.unlink(f.name)
