@@ -63,11 +63,15 @@ def parse_args():
     ap.add_argument("--critic-steps", type=int, default=80)
     ap.add_argument("--max-episode-steps", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", choices=("rccl", "ipc", "gloo"), default=os.environ.get("RELEARN_BENCH_COMM", "rccl"),
+    ap.add_argument("--comm", choices=("rccl", "ipc", "host", "gloo"), default=os.environ.get("RELEARN_BENCH_COMM", "rccl"),
                     help="data-plane collective for N > 1: RCCL on the engine stream (default); `ipc` = the library's "
                          "single-launch all-reduce over peer-mapped mailboxes (self-tested at start-up, RCCL if the test "
-                         "fails); `gloo` = the host-staged fallback over the control group (also taken when RCCL cannot "
-                         "be initialised)")
+                         "fails); `host` = the host-staged fallback over the control plane (also taken when RCCL cannot "
+                         "be initialised); `gloo` = `host` with `--control gloo`")
+    ap.add_argument("--control", choices=("tcp", "gloo"), default=os.environ.get("RELEARN_BENCH_CONTROL", "tcp"),
+                    help="control plane for N > 1 (id hand-out, barriers, max of the timing): `tcp` = the standard-library "
+                         "star on rank 0 (relearn_amd/rendezvous.py; no rank imports torch); `gloo` = a torch.distributed "
+                         "gloo group, imported only when asked for")
     ap.add_argument("--no-kernel-profile", action="store_true",
                     help="do not wrap launches in HIP events inside the timed region")
     ap.add_argument("--profile-steps", type=int, default=1,
@@ -80,6 +84,9 @@ def parse_args():
                          "_finish over a pair of trajectories).  Off by default: it buys nothing on this part — a critic "
                          "step is one 8-wave x 252-register workgroup per CU and cannot be placed on a CU that holds a "
                          "rollout wave, so the two take turns (DESIGN 7b, profiles/r05_pipeline_timeline_8192.csv)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch path rehearsal without a GPU: the ranks meet on the control plane, run one of each of its "
+                         "collectives, rank 0 prints one JSON line, nothing else runs (tests/test_bench_launch.py)")
     ap.add_argument("--cpu-sample-steps", type=int, default=262144,
                     help="total env-steps of the bounded CPU-baseline sample (split over the host cores)")
     return ap.parse_args()
@@ -87,95 +94,213 @@ def parse_args():
 
 def cpu_baseline(args):
     """The oracle's train_parallel-structured CPU path (one worker thread per host core running the scalar
-    Steps::step loop, single-threaded update), timed on this box's host cores on a bounded sample."""
+    Steps::step loop, then the update), timed on this box's host cores on a bounded sample.
+
+    The update is timed three ways, because the reference's agent runs it on one Rust thread while libtorch splits every
+    batched matmul over its intra-op pool (examples/cartpole-trpo.rs:44: num_cpus::get() workers; actor_critic.rs:176-211):
+      * on one thread, over a PREFIX of the sample that costs a few seconds (a side figure, scaled by sample count — every
+        pass of the update visits every sample once);
+      * with every full-batch pass split over 16, 64 and all the cores of this process's affinity mask, on a quarter of
+        the sample: which count is fastest depends on the cores the job really gets, so it is MEASURED here;
+      * with the fastest of those counts over the whole sample: the leg `value` is computed from."""
     import ctypes as C
 
     import oracle as O
+    t_start = time.time()
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    # the cores this job may actually use at once: a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) can be far
-    # below the visible CPU count; passes with a barrier per pass (the intra-op leg) must not be oversubscribed
-    usable = cores
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            usable = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                usable = max(1, min(cores, int(q / p_ + 0.5)))
-        except Exception:
-            pass
     H = args.hidden
     ps, cs = O.MlpShape(5, H, 2), O.MlpShape(5, H, 1)
     pp, cp = O.mlp_init(ps, 2), O.mlp_init(cs, 3)
-    # (no quota to read: a one-GPU job's share of the host is 16 cores on this pool; a pass has a barrier at its end, and
-    # a pool wider than the cores it really gets spends the update spinning — 20 s instead of 2 s with 256 threads)
-    if usable == cores:
-        usable = min(cores, 16)
-    if os.environ.get("RELEARN_BENCH_USABLE_CORES"):
-        usable = max(1, min(cores, int(os.environ["RELEARN_BENCH_USABLE_CORES"])))
-    opt = O.lib().oracle_adam_new(len(cp))
+    L = O.lib()
     st = O.PeriodStats()
-    t0 = time.time()
     per_thread = max(64, args.cpu_sample_steps // cores)
-    # (the update twice: on one thread, and with every full-batch pass split over the cores like libtorch's intra-op pool)
-    O.lib().oracle_cartpole_trpo_period_ex(0, 0, cores, per_thread, 100, args.max_episode_steps, H,
-                                           O.f32p(pp), O.f32p(cp), opt, args.critic_steps, usable, C.byref(st))
-    wall = time.time() - t0
-    O.lib().oracle_adam_free(opt)
-    steps = int(st.steps)
-    # HOT LOOP A alone, long enough to be a measurement: a short calibration run, then >= ~2.5 s of stepping on every
+    sample = L.oracle_cpu_sample_collect(0, cores, per_thread, 100, args.max_episode_steps, H, O.f32p(pp), O.f32p(cp),
+                                         C.byref(st))
+    steps, rollout_s = int(st.steps), st.rollout_seconds
+    # one thread: a prefix sized from a calibration on 1/64 of the sample so that the leg costs <= ~2 s
+    st1 = O.PeriodStats()
+    n_cal = max(1024, steps // 64)
+    cal_s = L.oracle_cpu_sample_update_one_thread(sample, n_cal, args.critic_steps, C.byref(st1))
+    n_one = int(min(steps, max(n_cal, n_cal * 2.0 / max(cal_s, 1e-6))))
+    one_s = L.oracle_cpu_sample_update_one_thread(sample, n_one, args.critic_steps, C.byref(st1))
+    one_thread_full_s = one_s * steps / n_one
+    # the passes over several thread counts (quarter sample), then the fastest count over the whole sample
+    if os.environ.get("RELEARN_BENCH_USABLE_CORES"):
+        counts = [max(1, min(cores, int(os.environ["RELEARN_BENCH_USABLE_CORES"])))]
+        how = "RELEARN_BENCH_USABLE_CORES"
+    else:
+        counts = sorted({min(cores, 16), min(cores, 64), cores})
+        how = "measured: the update's passes over a quarter of the sample with %s threads, fastest taken" % (
+            " / ".join(str(c) for c in counts))
+    probe = {}
+    for c in counts:
+        L.oracle_cpu_sample_update_intraop(sample, 2048, 2, c)  # (the OpenMP pool of this width exists before the clock)
+        probe[c] = L.oracle_cpu_sample_update_intraop(sample, max(1024, steps // 4), args.critic_steps, c)
+    usable = min(probe, key=probe.get)
+    intraop_s = L.oracle_cpu_sample_update_intraop(sample, steps, args.critic_steps, usable)
+    L.oracle_cpu_sample_free(sample)
+    # HOT LOOP A alone, long enough to be a measurement: a short calibration run, then >= 2 s of stepping on every
     # thread (thread start-up outside the clock; buffers cleared every 8,192 steps)
-    pp2 = O.mlp_init(ps, 2)
     got = C.c_uint64()
-    cal = O.lib().oracle_cartpole_rollout_only(1, cores, 20000, 8192, args.max_episode_steps, H, O.f32p(pp2), C.byref(got))
-    per_thread_ro = int(min(max(2.5 * 20000 / max(cal, 1e-6), 50000), 20_000_000))
-    for attempt in range(3):  # (the calibration run is cold: repeat with the measured rate until the leg lasts >= 2 s)
-        ro_s = O.lib().oracle_cartpole_rollout_only(2 + attempt, cores, per_thread_ro, 8192, args.max_episode_steps, H,
-                                                    O.f32p(pp2), C.byref(got))
+    cal = L.oracle_cartpole_rollout_only(1, cores, 20000, 8192, args.max_episode_steps, H, O.f32p(pp), C.byref(got))
+    per_thread_ro = int(min(max(2.3 * 20000 / max(cal, 1e-6), 50000), 20_000_000))
+    for attempt in range(2):  # (the calibration run is cold: repeat once with the measured rate if the leg lasted < 2 s)
+        ro_s = L.oracle_cartpole_rollout_only(2 + attempt, cores, per_thread_ro, 8192, args.max_episode_steps, H,
+                                              O.f32p(pp), C.byref(got))
         if ro_s >= 2.0:
             break
-        per_thread_ro = int(min(per_thread_ro * 2.6 / max(ro_s, 1e-3), 40_000_000))
+        per_thread_ro = int(min(per_thread_ro * 2.4 / max(ro_s, 1e-3), 40_000_000))
     ro_steps = int(got.value)
     return {
-        # the reference's agent update runs on one Rust thread, but its batched matmuls run on libtorch's intra-op pool:
-        # the headline CPU figure is the one with the update's passes split over the cores (the faster, fairer one)
-        "value": steps / (st.rollout_seconds + min(st.update_intraop_seconds, st.update_seconds)),
-        "value_single_threaded_update": steps / (st.rollout_seconds + st.update_seconds),
-        "update_seconds": {"one_thread": st.update_seconds, "passes_over_%d_threads" % usable: st.update_intraop_seconds},
+        "value": steps / (rollout_s + min(intraop_s, one_thread_full_s)),
+        "value_definition": "v3 (round 6): sample steps / (rollout + update), the update with its full-batch passes split "
+                            "over the MEASURED fastest thread count (round 5: a fixed 16; rounds 1-4: one thread = "
+                            "value_single_threaded_update)",
+        "value_single_threaded_update": steps / (rollout_s + one_thread_full_s),
+        "update_seconds": {"one_thread_scaled_to_the_sample": one_thread_full_s,
+                           "one_thread_measured": {"samples": n_one, "seconds": one_s},
+                           "passes_over_%d_threads" % usable: intraop_s,
+                           "quarter_sample_probe": {str(c): probe[c] for c in counts}},
         "usable_cores": usable,
+        "usable_cores_how": how,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
         "build": "gcc -O3 -ffp-contract=off -mavx2 -mfma -fopenmp (oracle/Makefile)",
-        "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes), then GAE + TRPO + %d Adam "
-                  "steps: on one thread %.2f s, with every full-batch pass split over %d threads %.2f s (`value` takes the "
-                  "faster of the two); rollout %.2f s" % (
-                      cores, per_thread, steps, int(st.episodes), args.critic_steps, st.update_seconds, usable,
-                      st.update_intraop_seconds, st.rollout_seconds),
+        "sample": "%d worker threads x >=%d scalar Steps::step steps (%d steps, %d episodes) in %.2f s, then TRPO + %d Adam "
+                  "steps with every full-batch pass split over %d threads in %.2f s (`value`); on one thread %.2f s for "
+                  "the first %d samples = %.1f s for the sample" % (
+                      cores, per_thread, steps, int(st.episodes), rollout_s, args.critic_steps, usable, intraop_s, one_s,
+                      n_one, one_thread_full_s),
         "rollout_only_steps_per_s": ro_steps / max(ro_s, 1e-9),
         "rollout_only_sample": "%d threads x %d scalar Steps::step steps in %.2f s (worker threads started before the "
                                "clock)" % (cores, per_thread_ro, ro_s),
-        "wall_s": time.time() - t0,
+        "wall_s": time.time() - t_start,
     }
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children — each with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in its environment, exactly what torch.distributed.run would give it — wait for them, pass
+    rank 0's one JSON line on, and leave non-zero if any rank did.  The process-level form of train_parallel's scoped
+    thread fan-out and join (/root/reference/src/simulation/train.rs:98-158,180).  This process never touches the GPU
+    (nothing here imports the engine), and no process is ever replaced: the ranks are fresh children."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sock:  # a free port for the ranks' control plane
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    limit = float(os.environ.get("RELEARN_BENCH_TIMEOUT", "420")) + 240.0  # the ranks' own watchdogs fire first
+
+    def die_with_parent():  # a killed launcher must not leave ranks holding GPUs
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM)  # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RELEARN_RDZV_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, preexec_fn=die_with_parent))
+    lines = [[] for _ in procs]
+
+    def pump(i):  # rank 0's stdout is the job's stdout; anything another rank prints goes to stderr
+        for raw in procs[i].stdout:
+            text = raw.decode(errors="replace")
+            lines[i].append(text)
+            (sys.stdout if i == 0 else sys.stderr).write(text)
+            (sys.stdout if i == 0 else sys.stderr).flush()
+
+    pumps = [threading.Thread(target=pump, args=(i,), daemon=True) for i in range(len(procs))]
+    for t in pumps:
+        t.start()
+    t0, first_bad, codes = time.time(), None, [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+                if codes[i] not in (None, 0) and first_bad is None:
+                    first_bad = time.time()
+                    print("bench.py: rank %d left with exit code %d" % (i, codes[i]), file=sys.stderr, flush=True)
+        # a rank that failed: the others notice through the control plane / their watchdogs; after a grace period (or at
+        # the overall limit) the ranks still running — this process's own children, by pid — are ended
+        if (first_bad is not None and time.time() - first_bad > 45.0) or time.time() - t0 > limit:
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    pr.kill()
+                    codes[i] = pr.wait()
+            if first_bad is None:
+                print("bench.py: the ranks did not finish within %.0f s" % limit, file=sys.stderr, flush=True)
+            break
+        time.sleep(0.05)
+    for t in pumps:
+        t.join(timeout=5)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        return bad[0] if bad[0] and bad[0] > 0 else 1
+    if len([l for l in lines[0] if l.startswith("{")]) != 1:
+        print("bench.py: rank 0 did not print exactly one result line", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+class GlooControl:
+    """`--control gloo`: the control plane's interface (relearn_amd/rendezvous.py) over a torch.distributed gloo group —
+    optional, imported only when asked for; the default control plane needs no torch"""
+
+    def __init__(self, rank, world):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    def all_gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def broadcast(self, obj, src=0):
+        box = [obj if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_min(self, x):
+        return min(self.all_gather(x))
+
+    def all_max(self, x):
+        return max(self.all_gather(x))
+
+    def all_reduce_sum_f32(self, array):
+        self.dist.all_reduce(self.torch.from_numpy(array))
+        return array
+
+    def close(self):
+        self.dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
+    if args.comm == "gloo":
+        args.comm, args.control = "host", "gloo"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # (before anything that could touch a GPU)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (
-                args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     # (multi-process GPU work on this driver stack needs dmabuf IPC: RCCL's peer mappings and the mailbox handles fail
     # with "hipIpcGetMemHandle: invalid argument" otherwise; must be in the environment before the HIP runtime starts)
@@ -191,6 +316,7 @@ def main():
         phase["name"], phase["since"] = name, time.time()
 
     watchdog_all = None
+    ctl = None
     if world > 1:
         import threading
 
@@ -200,17 +326,36 @@ def main():
                 time.time() - phase["since"]), file=sys.stderr, flush=True)
             os._exit(4)
 
-    dist = None
-    if world > 1:
-        # control plane only (unique-id exchange, barrier, max-reduce of the timing); the data-plane
-        # collective is RCCL called from the library on its own HIP stream
-        import torch
-        import torch.distributed as dist
-        enter("rendezvous (gloo control group)")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # control plane only (unique-id exchange, barrier, max-reduce of the timing); the data-plane collective is RCCL
+        # (or the peer mailboxes) called from the library on its own HIP stream.  Standard library by default: no rank
+        # imports torch, so no rank maps a second HIP runtime next to the one the engine runs on.
+        enter("rendezvous (%s control plane)" % args.control)
+        if args.control == "gloo":
+            ctl = GlooControl(rank, world)
+        else:
+            from relearn_amd import rendezvous
+            ctl = rendezvous.from_env()
         watchdog_all = threading.Timer(float(os.environ.get("RELEARN_BENCH_TIMEOUT", "420")), stalled)
         watchdog_all.daemon = True
         watchdog_all.start()
+
+    if args.rendezvous_only:
+        out = {"rendezvous_only": True, "n_gpus": world, "control": args.control if world > 1 else None,
+               "torch_imported": "torch" in sys.modules}
+        if ctl is not None:
+            seen = ctl.all_gather({"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
+                                   "torch_imported": "torch" in sys.modules})
+            ctl.barrier()
+            probe = np.full(5, float(rank + 1), dtype=np.float32)
+            ctl.all_reduce_sum_f32(probe)
+            out.update(ranks=seen, max_rank=ctl.all_max(rank), min_rank=ctl.all_min(rank), sum_probe=float(probe[0]),
+                       uid_len=len(ctl.broadcast(b"\x07" * 128 if rank == 0 else None, src=0)))
+            ctl.barrier()
+            ctl.close()
+            watchdog_all.cancel()
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
 
     assert args.envs % world == 0, "envs must divide evenly over GPUs"
     n_local = args.envs // world
@@ -226,16 +371,15 @@ def main():
     if world > 1:
         comm_kind = args.comm
         if comm_kind == "ipc":
-            # peer-mailbox transport: exchange the mailbox handles over the control group, map, and let every rank run
-            # the library's self-test; the job uses it only if ALL ranks pass (else RCCL, then gloo)
+            # peer-mailbox transport: exchange the mailbox handles over the control plane, map, and let every rank run
+            # the library's self-test; the job uses it only if ALL ranks pass (else RCCL, then the host-staged one)
             ok = 1
             try:
                 mine = eng.comm_ipc_handle(world)
             except ra.RelearnError as exc:
                 print("bench.py: rank %d: no mailbox (%s)" % (rank, exc), file=sys.stderr)
                 mine, ok = None, 0
-            handles = [None] * world
-            dist.all_gather_object(handles, mine)
+            handles = ctl.all_gather(mine)
             if ok and all(h is not None for h in handles):
                 try:
                     eng.comm_init_ipc(rank, world, handles)
@@ -245,10 +389,8 @@ def main():
                     ok = 0
             else:
                 ok = 0
-            agreed = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-            if int(agreed.item()) == 0:
-                dist.barrier()
+            if ctl.all_min(ok) == 0:
+                ctl.barrier()
                 eng.comm_destroy()
                 comm_kind = "rccl"
                 if rank == 0:
@@ -258,16 +400,15 @@ def main():
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             # 1. every rank checks that it can bind RCCL at all, and the job agrees on it BEFORE anyone enters the
             #    collective ncclCommInitRank (a rank that failed here would leave its peers blocked in there)
-            can = torch.tensor([1 if ra.comm_available() else 0], dtype=torch.int32)
-            dist.all_reduce(can, op=dist.ReduceOp.MIN)
-            ok, ids = int(can.item()), [None]
+            ok = ctl.all_min(1 if ra.comm_available() else 0)
+            uid = None
             if ok and rank == 0:
                 try:
-                    ids = [ra.comm_unique_id()]
+                    uid = ra.comm_unique_id()
                 except ra.RelearnError as exc:
                     print("bench.py: RCCL unavailable (%s)" % exc, file=sys.stderr)
-            dist.broadcast_object_list(ids, src=0)
-            if ids[0] is None:
+            uid = ctl.broadcast(uid, src=0)
+            if uid is None:
                 ok = 0
             if ok:
                 # 2. the collective initialisation under a watchdog: a rank stuck in RCCL's bootstrap ends the job with
@@ -279,21 +420,19 @@ def main():
                 watchdog.daemon = True
                 watchdog.start()
                 try:
-                    eng.comm_init(rank, world, ids[0])
+                    eng.comm_init(rank, world, uid)
                 except ra.RelearnError as exc:
                     print("bench.py: rank %d: RCCL communicator not created (%s)" % (rank, exc), file=sys.stderr)
                     ok = 0
                 finally:
                     watchdog.cancel()
-            agreed = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)  # every rank takes the same path
-            if int(agreed.item()) == 0:
+            if ctl.all_min(ok) == 0:  # every rank takes the same path
                 eng.comm_destroy()
-                comm_kind = "gloo"
+                comm_kind = "host"
                 if rank == 0:
-                    print("bench.py: falling back to the host-staged collective over gloo", file=sys.stderr)
-        if comm_kind == "gloo":
-            eng.comm_init_host(rank, world, lambda a: dist.all_reduce(torch.from_numpy(a)))
+                    print("bench.py: falling back to the host-staged collective over the control plane", file=sys.stderr)
+        if comm_kind == "host":
+            eng.comm_init_host(rank, world, ctl.all_reduce_sum_f32)
 
     enter("allocation")
     env = ra.CartPoleEnv(eng, n_local, max_steps=args.max_episode_steps, limit=ra.LIMIT_VISIBLE,
@@ -341,13 +480,11 @@ def main():
             last["critic"] = ra.actor_critic_update_finish(pending)
 
     def barrier():
-        # eng.sync() = hipStreamSynchronize(engine stream) + hipDeviceSynchronize(); torch.cuda.synchronize() is the
-        # same device-wide wait, spelled the way the bench contract does (torch is only imported for world > 1)
+        # eng.sync() = hipStreamSynchronize(engine stream) + hipDeviceSynchronize(): the device-wide wait the bench
+        # contract spells torch.cuda.synchronize(), from the one HIP runtime this process has
         eng.sync()
-        if dist is not None:
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            torch.cuda.synchronize(device)
+        if ctl is not None:
+            ctl.barrier()
         eng.sync()
 
     enter("warm-up periods (%s collective)" % comm_kind)
@@ -379,11 +516,8 @@ def main():
     prof = eng.profile_read(reset=True) if not args.no_kernel_profile else None
     eng.profile_enable(False)
     eng.set_serial_update(args.serial_update)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if ctl is not None:
+        elapsed = float(ctl.all_max(elapsed))
 
     total_steps = args.envs * T * args.steps
     value = total_steps / elapsed
@@ -552,26 +686,24 @@ def main():
     # replicas must still be bit-identical after the timed region: every rank applied the same all-reduced vectors
     # (whatever the transport).  A rank whose parameters differ invalidates the run.
     replicas_identical = None
-    if dist is not None:
+    if ctl is not None:
         import hashlib
         mine = hashlib.sha256(policy.get_params().tobytes() + critic.get_params().tobytes()).hexdigest()
-        digests = [None] * world
-        dist.all_gather_object(digests, mine)
+        digests = ctl.all_gather(mine)
         replicas_identical = all(d == digests[0] for d in digests)
         if not replicas_identical:
             print("bench.py: rank %d: replicas diverged under the %s collective: %s" % (rank, comm_kind, digests),
                   file=sys.stderr, flush=True)
-        dist.barrier()
+        ctl.barrier()
     # what the collective cost each rank (launches and time per period), so that a scaling run explains itself
     allreduce_per_rank = None
-    if dist is not None:
+    if ctl is not None:
         mine = None
         if prof is not None and prof.get("allreduce", (0.0, 0))[1]:
             ar_ms, ar_n = prof["allreduce"]
             mine = {"rank": rank, "launches_per_step": ar_n / prof_steps, "us_per_launch": 1e3 * ar_ms / ar_n,
                     "ms_per_step": ar_ms / prof_steps}
-        allreduce_per_rank = [None] * world
-        dist.all_gather_object(allreduce_per_rank, mine)
+        allreduce_per_rank = ctl.all_gather(mine)
     if rank == 0:
         st = last["trpo"]
         out = {
@@ -601,7 +733,8 @@ def main():
                                  max(args.steps - prof_steps - 1, 0), args.steps) if pipelined else "none"),
                 "parallelism": "env-sharded x%d + %s" % (world, {"none": "no collective (one rank)", "rccl": "RCCL all-reduce",
                                                                "ipc": "single-launch all-reduce over peer-mapped mailboxes",
-                                                               "gloo": "host-staged all-reduce over gloo (fallback)"}[comm_kind]),
+                                                               "host": "host-staged all-reduce over the %s control plane "
+                                                                       "(fallback)" % args.control}[comm_kind]),
             },
             "roofline": roofline,
             "roofline_policy": roofline_policy,
@@ -622,13 +755,13 @@ def main():
         print(json.dumps(out))
     if watchdog_all is not None:
         watchdog_all.cancel()
-    if dist is not None:
+    if ctl is not None:
         try:
-            eng.comm_destroy()  # every rank releases its communicator before the control group goes away
+            eng.comm_destroy()  # every rank releases its communicator before the control plane goes away
         except ra.RelearnError as exc:
             print("bench.py: rank %d: comm_destroy: %s" % (rank, exc), file=sys.stderr)
-        dist.barrier()
-        dist.destroy_process_group()
+        ctl.barrier()
+        ctl.close()
     if replicas_identical is False:
         sys.exit(3)
 

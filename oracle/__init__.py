@@ -462,6 +462,15 @@ def _declare(L):
     L.oracle_cartpole_trpo_period_ex.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
                                                  C.c_uint64, C.c_uint32, P(C.c_float), P(C.c_float), P(AdamState),
                                                  C.c_uint64, C.c_uint32, P(PeriodStats)]
+    L.oracle_cpu_sample_collect.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                            P(C.c_float), P(C.c_float), P(PeriodStats)]
+    L.oracle_cpu_sample_collect.restype = C.c_void_p
+    L.oracle_cpu_sample_update_one_thread.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, P(PeriodStats)]
+    L.oracle_cpu_sample_update_one_thread.restype = C.c_double
+    L.oracle_cpu_sample_update_intraop.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]
+    L.oracle_cpu_sample_update_intraop.restype = C.c_double
+    L.oracle_cpu_sample_free.argtypes = [C.c_void_p]
+    L.oracle_cpu_sample_free.restype = None
 
 
 # ---------------------------------------------------------------------------------------------

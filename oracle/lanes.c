@@ -479,14 +479,13 @@ void oracle_cartpole_trpo_period(uint64_t seed, uint64_t period_index, uint32_t 
                                  policy_params, critic_params, critic_opt, critic_steps, 0, stats);
 }
 
-void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
-                                    uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
-                                    float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
-                                    uint32_t intraop_threads, oracle_period_stats *stats) {
+/* the collection half of a period: `n_threads` workers of TakeAlignedSteps over Steps::step, packed into one batch */
+static oracle_features *collect_period_sample(uint64_t seed, uint64_t period_index, uint32_t n_threads,
+                                              uint64_t steps_per_thread, uint64_t slack_steps, uint64_t max_steps,
+                                              oracle_mlp_shape ps, const float *policy_params,
+                                              double *rollout_seconds) {
   oracle_cartpole env;
   oracle_cartpole_default(&env);
-  oracle_mlp_shape ps = {5, hidden, 2}, cs = {5, hidden, 1};
-  memset(stats, 0, sizeof(*stats));
   oracle_vecbuffer **buffers = (oracle_vecbuffer **)malloc(n_threads * sizeof(*buffers));
   oracle_prng *t_env = (oracle_prng *)malloc(n_threads * sizeof(oracle_prng));
   oracle_prng *t_agent = (oracle_prng *)malloc(n_threads * sizeof(oracle_prng));
@@ -542,10 +541,27 @@ void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32
     }
     oracle_vecbuffer_end_experience(buffers[i]);
   }
-  double t1 = now_s();
-  stats->rollout_seconds = t1 - t0;
-  /* ActorCriticAgent::batch_update_slice (torch/agents/actor_critic.rs:176-211), single thread */
+  *rollout_seconds = now_s() - t0;
   oracle_features *feat = oracle_features_from_buffers(buffers, n_threads);
+  for (uint32_t i = 0; i < n_threads; ++i) oracle_vecbuffer_free(buffers[i]);
+  free(buffers);
+  free(t_env);
+  free(t_agent);
+  return feat;
+}
+
+void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32_t n_threads, uint64_t steps_per_thread,
+                                    uint64_t slack_steps, uint64_t max_steps, uint32_t hidden, float *policy_params,
+                                    float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
+                                    uint32_t intraop_threads, oracle_period_stats *stats) {
+  oracle_cartpole env;
+  oracle_cartpole_default(&env);
+  oracle_mlp_shape ps = {5, hidden, 2}, cs = {5, hidden, 1};
+  memset(stats, 0, sizeof(*stats));
+  oracle_features *feat = collect_period_sample(seed, period_index, n_threads, steps_per_thread, slack_steps, max_steps,
+                                                ps, policy_params, &stats->rollout_seconds);
+  double t1 = now_s();
+  /* ActorCriticAgent::batch_update_slice (torch/agents/actor_critic.rs:176-211), single thread */
   stats->steps = feat->n_steps;
   stats->episodes = feat->n_episodes;
   stats->mean_episode_length = feat->n_episodes ? (double)feat->n_steps / (double)feat->n_episodes : 0.0;
@@ -576,8 +592,99 @@ void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32
   free(adv);
   free(rtg);
   oracle_features_free(feat);
-  for (uint32_t i = 0; i < n_threads; ++i) oracle_vecbuffer_free(buffers[i]);
-  free(buffers);
-  free(t_env);
-  free(t_agent);
+}
+
+/* ---- the same period with its legs callable one at a time (bench.py's cpu_baseline: the update timed on one thread
+ * over a PREFIX of the sample, and with its passes split over several thread counts, so that the count that is fastest
+ * on the box at hand is measured rather than assumed).  The update is linear in the number of samples: every pass
+ * visits every sample once.  Parameters are never changed: every leg works on private copies. */
+struct oracle_cpu_sample {
+  oracle_mlp_shape ps, cs;
+  oracle_features *feat;
+  float *adv, *rtg, *policy_params, *critic_params;
+  uint64_t critic_steps, n_evals, cg_iterations;
+};
+
+oracle_cpu_sample *oracle_cpu_sample_collect(uint64_t seed, uint32_t n_threads, uint64_t steps_per_thread,
+                                             uint64_t slack_steps, uint64_t max_steps, uint32_t hidden,
+                                             const float *policy_params, const float *critic_params,
+                                             oracle_period_stats *stats) {
+  oracle_cartpole env;
+  oracle_cartpole_default(&env);
+  oracle_cpu_sample *s = (oracle_cpu_sample *)calloc(1, sizeof(*s));
+  s->ps = (oracle_mlp_shape){5, hidden, 2};
+  s->cs = (oracle_mlp_shape){5, hidden, 1};
+  memset(stats, 0, sizeof(*stats));
+  s->feat = collect_period_sample(seed, 0, n_threads, steps_per_thread, slack_steps, max_steps, s->ps, policy_params,
+                                  &stats->rollout_seconds);
+  stats->steps = s->feat->n_steps;
+  stats->episodes = s->feat->n_episodes;
+  stats->mean_episode_length = s->feat->n_episodes ? (double)s->feat->n_steps / (double)s->feat->n_episodes : 0.0;
+  const uint64_t n = s->feat->n_steps ? s->feat->n_steps : 1, Pp = oracle_mlp_num_params(s->ps),
+                 Pc = oracle_mlp_num_params(s->cs);
+  s->adv = (float *)malloc(sizeof(float) * n);
+  s->rtg = (float *)malloc(sizeof(float) * n);
+  s->policy_params = (float *)malloc(sizeof(float) * Pp);
+  s->critic_params = (float *)malloc(sizeof(float) * Pc);
+  memcpy(s->policy_params, policy_params, sizeof(float) * Pp);
+  memcpy(s->critic_params, critic_params, sizeof(float) * Pc);
+  const float gamma = (float)fmin(0.99, env.discount_factor);
+  oracle_gae_packed(s->cs, critic_params, s->feat, gamma, 0.95f, s->adv, NULL);
+  oracle_reward_to_go_packed(s->feat, gamma, s->rtg);
+  oracle_trpo_cfg cfg;
+  oracle_trpo_cfg_default(&cfg);
+  s->cg_iterations = cfg.iterations;
+  s->n_evals = 1;
+  return s;
+}
+
+/* GAE's value pass excluded (it ran at collection); TRPO + `critic_steps` Adam steps on the first `n_prefix` samples, one
+ * thread, as ActorCriticAgent::batch_update_slice runs them.  Returns seconds; fills the TRPO statistics. */
+double oracle_cpu_sample_update_one_thread(oracle_cpu_sample *s, uint64_t n_prefix, uint64_t critic_steps,
+                                           oracle_period_stats *stats) {
+  const uint64_t n = n_prefix && n_prefix < s->feat->n_steps ? n_prefix : s->feat->n_steps;
+  const uint64_t Pp = oracle_mlp_num_params(s->ps), Pc = oracle_mlp_num_params(s->cs);
+  float *pp = (float *)malloc(sizeof(float) * Pp), *cp = (float *)malloc(sizeof(float) * Pc);
+  memcpy(pp, s->policy_params, sizeof(float) * Pp);
+  memcpy(cp, s->critic_params, sizeof(float) * Pc);
+  oracle_adam_state *opt = oracle_adam_new(Pc);
+  oracle_adam_cfg acfg;
+  oracle_adam_cfg_default(&acfg);
+  oracle_trpo_cfg cfg;
+  oracle_trpo_cfg_default(&cfg);
+  float *losses = (float *)malloc(sizeof(float) * (critic_steps ? critic_steps : 1));
+  const double t0 = now_s();
+  oracle_trpo_update_f32(s->ps, pp, s->feat->obs, s->feat->actions, s->adv, n, &cfg, &stats->trpo, NULL);
+  oracle_critic_update_f32(s->cs, cp, opt, &acfg, s->feat->obs, s->rtg, n, critic_steps, losses);
+  const double secs = now_s() - t0;
+  if (critic_steps) {
+    stats->critic_loss_first = losses[0];
+    stats->critic_loss_last = losses[critic_steps - 1];
+  }
+  s->n_evals = stats->trpo.num_backtracks >= 0 ? (uint64_t)stats->trpo.num_backtracks + 1 : cfg.max_backtracks;
+  free(losses);
+  oracle_adam_free(opt);
+  free(cp);
+  free(pp);
+  return secs;
+}
+
+/* the same pass count over the first `n_prefix` samples with every pass split over `n_threads` threads */
+double oracle_cpu_sample_update_intraop(oracle_cpu_sample *s, uint64_t n_prefix, uint64_t critic_steps,
+                                        uint32_t n_threads) {
+  oracle_features view = *s->feat;
+  if (n_prefix && n_prefix < view.n_steps) view.n_steps = n_prefix;
+  if (view.n_steps == 0) return 0.0;
+  return update_intraop_seconds(s->ps, s->cs, s->policy_params, s->critic_params, &view, s->adv, s->rtg,
+                                s->cg_iterations, s->n_evals, critic_steps, n_threads ? n_threads : 1);
+}
+
+void oracle_cpu_sample_free(oracle_cpu_sample *s) {
+  if (!s) return;
+  oracle_features_free(s->feat);
+  free(s->adv);
+  free(s->rtg);
+  free(s->policy_params);
+  free(s->critic_params);
+  free(s);
 }

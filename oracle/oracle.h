@@ -511,6 +511,19 @@ void oracle_cartpole_trpo_period_ex(uint64_t seed, uint64_t period_index, uint32
                                     float *critic_params, oracle_adam_state *critic_opt, uint64_t critic_steps,
                                     uint32_t intraop_threads, oracle_period_stats *stats);
 
+/* The period's legs one at a time (bench.py's cpu_baseline): collect once, then time the update on one thread over a
+ * prefix of the sample and with its passes split over any number of threads.  No leg changes the parameters. */
+typedef struct oracle_cpu_sample oracle_cpu_sample;
+oracle_cpu_sample *oracle_cpu_sample_collect(uint64_t seed, uint32_t n_threads, uint64_t steps_per_thread,
+                                             uint64_t slack_steps, uint64_t max_steps, uint32_t hidden,
+                                             const float *policy_params, const float *critic_params,
+                                             oracle_period_stats *stats);
+double oracle_cpu_sample_update_one_thread(oracle_cpu_sample *s, uint64_t n_prefix, uint64_t critic_steps,
+                                           oracle_period_stats *stats);
+double oracle_cpu_sample_update_intraop(oracle_cpu_sample *s, uint64_t n_prefix, uint64_t critic_steps,
+                                        uint32_t n_threads);
+void oracle_cpu_sample_free(oracle_cpu_sample *s);
+
 #ifdef __cplusplus
 }
 #endif

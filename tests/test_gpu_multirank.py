@@ -125,8 +125,19 @@ def test_two_ranks_equal_one_rank():
     assert np.all(np.isfinite(double[0]["dqn"]["losses"]))
 
 
-def run_bench(world, extra_env=None, workload=("--envs", "2048", "--horizon", "32", "--critic-steps", "5"), limit=150):
-    """bench.py exactly as the driver launches it (torch.distributed.run, one process per rank), on a small workload"""
+def poisoned_torch(tmp_path):
+    """a directory that makes `import torch` fail when it is first on PYTHONPATH"""
+    d = os.path.join(str(tmp_path), "no_torch", "torch")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "__init__.py"), "w") as f:
+        f.write("raise ImportError('torch is not available in this test')\n")
+    return os.path.dirname(d)
+
+
+def run_bench(world, extra_env=None, workload=("--envs", "2048", "--horizon", "32", "--critic-steps", "5"), limit=150,
+              launcher="self"):
+    """bench.py on a small workload, one process per rank: `launcher` "self" = `python bench.py --gpus N` (bench.py starts
+    its own ranks), "torchrun" = exactly as the driver launches it (torch.distributed.run)"""
     import json
     import subprocess
     import sys
@@ -135,11 +146,13 @@ def run_bench(world, extra_env=None, workload=("--envs", "2048", "--horizon", "3
     # period would start from policies that already differ by TRPO's amplified rounding, and drift apart from there)
     args = ["--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + list(workload)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RELEARN_RDZV_PORT"):
+        env.pop(k, None)
     import socket
     with socket.socket() as sock:  # a free rendezvous port
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    if world == 1:
+    if world == 1 or launcher == "self":
         cmd = [sys.executable, os.path.join(root, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
@@ -166,39 +179,47 @@ def run_bench(world, extra_env=None, workload=("--envs", "2048", "--horizon", "3
     return res
 
 
-def test_bench_as_two_processes_over_the_host_collective():
-    """The multi-process launch path of bench.py — RANK / LOCAL_RANK / WORLD_SIZE from torch.distributed.run, gloo control
-    group, lane sharding, barriers, max-over-ranks timing, one JSON line — rehearsed with two processes on this box's
-    one GPU.  RCCL refuses two ranks on one device, so the data-plane collective is the library's host-staged one
-    (rl_comm_init_host over the same gloo group); the RCCL call path itself is covered by the one-rank communicator test.
+def test_bench_as_two_processes_over_the_host_collective(tmp_path):
+    """The multi-process launch path of bench.py — its own spawner (RANK / LOCAL_RANK / WORLD_SIZE as
+    torch.distributed.run sets them), the standard-library control plane, lane sharding, barriers, max-over-ranks
+    timing, one JSON line — rehearsed with two processes on this box's one GPU, in an environment where torch cannot be
+    imported.  RCCL refuses two ranks on one device, so the data-plane collective is the library's host-staged one
+    (rl_comm_init_host over the control plane); the RCCL call path itself is covered by the one-rank communicator test.
     The sharded job must report the same update statistics as the one-process job (same samples, other sum order)."""
-    # page torch in first (a cold image needs a minute or two for its first import), in a child process: importing it
-    # here would map a second copy of the ROCm runtime into the test process
-    import subprocess
-    import sys
-    subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
-    one = run_bench(1)
-    two = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "gloo"})
+    no_torch = {"PYTHONPATH": poisoned_torch(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", "")}
+    one = run_bench(1, no_torch)
+    two = run_bench(2, dict(no_torch, RELEARN_BENCH_SINGLE_DEVICE="1", RELEARN_BENCH_COMM="host"))
     assert two["n_gpus"] == 2 and two["config"]["n_envs_per_gpu"] == 1024 and two["config"]["n_envs_total"] == 2048
-    assert "gloo" in two["config"]["parallelism"] and two["cpu_baseline"] is None
+    assert "host-staged" in two["config"]["parallelism"] and "tcp" in two["config"]["parallelism"]
+    assert two["cpu_baseline"] is None
     assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] * 1e-3 - 2048 * 32) < 1e-6 * 2048 * 32
     assert two["phases"]["allreduce"]["launches_per_step"] >= 5 + 11 + 2
     # the same launch with the peer-mailbox transport (both ranks map each other's mailbox on the one device)
-    ipc = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "ipc"})
+    ipc = run_bench(2, dict(no_torch, RELEARN_BENCH_SINGLE_DEVICE="1", RELEARN_BENCH_COMM="ipc"))
     assert "mailboxes" in ipc["config"]["parallelism"], ipc["_stderr"][-1500:]
     assert ipc["phases"]["allreduce"]["launches_per_step"] >= 5 + 11 + 2
     assert one["replicas_identical"] is None and two["replicas_identical"] is True and ipc["replicas_identical"] is True
     for other in (two, ipc):
         a, b = one["last_update"], other["last_update"]
         assert a["trpo_status"] == b["trpo_status"]
+        # one period of training with the f32 sums in another order: TRPO's CG amplifies rounding-level differences of
+        # the Fisher-vector products (DESIGN.md §6), so the runs stay close, not identical
         assert abs(a["entropy"] - b["entropy"]) < 5e-3
         assert abs(a["critic_loss_last"] - b["critic_loss_last"]) < 5e-2 * a["critic_loss_last"]
-    a, b = one["last_update"], two["last_update"]
-    assert a["trpo_status"] == b["trpo_status"]
-    # one period of training with the f32 sums in another order: TRPO's CG amplifies rounding-level differences of the
-    # Fisher-vector products (DESIGN.md §6), so the runs stay close, not identical
-    assert abs(a["entropy"] - b["entropy"]) < 5e-3
-    assert abs(a["critic_loss_last"] - b["critic_loss_last"]) < 5e-2 * a["critic_loss_last"]
+
+
+def test_bench_under_torch_distributed_run_and_over_the_gloo_control_plane():
+    """the driver's launch line (torch.distributed.run) lands on the same torch-free control plane; `--control gloo`
+    (torch imported on request) stays available as a fallback"""
+    import subprocess
+    import sys
+    # page torch in first (a cold image needs a minute or two for its first import), in a child process
+    subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
+    tr = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "host"}, launcher="torchrun")
+    assert tr["n_gpus"] == 2 and "tcp" in tr["config"]["parallelism"] and tr["replicas_identical"] is True
+    gl = run_bench(2, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": "gloo"}, launcher="torchrun")
+    assert gl["n_gpus"] == 2 and "gloo" in gl["config"]["parallelism"] and gl["replicas_identical"] is True
+    assert tr["last_update"] == gl["last_update"]  # the same sums in the same (rank) order, whatever carries them
 
 
 @pytest.mark.parametrize("order", ["torch_first", "engine_first"])
@@ -444,24 +465,27 @@ def test_eight_mailbox_ranks_at_the_config4_split(tmp_path, config4_single):
     _check_config4(ranks, config4_single)
 
 
-def test_bench_as_four_processes_at_the_full_workload():
-    """(c) bench.py launched as the driver launches it, FOUR processes (the pool's limit is six on one card) on this box's
-    one GPU over the host-staged collective and over the mailboxes, at the metric's workload (65,536 envs, T = 128, 80
-    critic steps): the line says n_gpus 4, the replicas are identical, and `allreduce_per_rank` is filled for every
-    rank — what the first real multi-GPU run will be read by."""
+def test_bench_as_four_processes_at_the_full_workload(tmp_path):
+    """(c) `python bench.py --gpus 4`, FOUR processes (the pool's limit is six on one card) on this box's one GPU at the
+    metric's workload (65,536 envs, T = 128, 80 critic steps), over the mailboxes: started by bench.py itself, started by
+    torch.distributed.run as the driver does, and started where `import torch` fails — and once over the host-staged
+    collective.  The line says n_gpus 4, the replicas are identical, and `allreduce_per_rank` is filled for every rank:
+    what the first real multi-GPU run will be read by."""
     import subprocess
     import sys
     subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
-    for comm in ("gloo", "ipc"):
-        res = run_bench(4, {"RELEARN_BENCH_SINGLE_DEVICE": "1", "RELEARN_BENCH_COMM": comm},
-                        workload=("--steps", "2", "--warmup", "1"), limit=280)
+    no_torch = {"PYTHONPATH": poisoned_torch(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", "")}
+    for comm, launcher, extra in (("ipc", "self", {}), ("ipc", "torchrun", {}), ("ipc", "self", no_torch),
+                                  ("host", "self", no_torch)):
+        res = run_bench(4, dict(extra, RELEARN_BENCH_SINGLE_DEVICE="1", RELEARN_BENCH_COMM=comm),
+                        workload=("--steps", "2", "--warmup", "1"), limit=280, launcher=launcher)
         assert res["n_gpus"] == 4 and res["config"]["n_envs_per_gpu"] == 16384 and res["config"]["n_envs_total"] == 65536
         assert res["replicas_identical"] is True, res["_stderr"][-1500:]
-        assert ("gloo" if comm == "gloo" else "mailboxes") in res["config"]["parallelism"], res["_stderr"][-1500:]
+        assert ("host-staged" if comm == "host" else "mailboxes") in res["config"]["parallelism"], res["_stderr"][-1500:]
         per_rank = res["allreduce_per_rank"]
         assert len(per_rank) == 4 and all(p is not None and p["rank"] == i for i, p in enumerate(per_rank))
         # (over the mailboxes the critic chain's 80 exchanges run INSIDE its reduce + Adam launches)
-        assert all(p["launches_per_step"] >= 1 + 11 + 2 + (80 if comm == "gloo" else 0) for p in per_rank)
+        assert all(p["launches_per_step"] >= 1 + 11 + 2 + (80 if comm == "host" else 0) for p in per_rank)
         assert res["last_update"]["trpo_status"] == ra.OPT_OK
 
 
@@ -548,19 +572,16 @@ def test_bench_pipelined_periods_report_the_same_update_as_the_plain_sequence():
 def test_a_stalled_rank_ends_the_bench_with_the_phase_it_was_stuck_in():
     """bench.py's watchdog (multi-rank jobs): one of two ranks never joins the first collective of the warm-up; both ranks
     must leave within the bound (RELEARN_BENCH_TIMEOUT, here 20 s after the rendezvous) with exit code 4 and a line on
-    stderr that names the phase — a job that stalls on a real node explains itself instead of holding it."""
+    stderr that names the phase, and the launcher passes that on as a non-zero exit without a result line — a job that
+    stalls on a real node explains itself instead of holding it."""
     import subprocess
     import sys
-    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run([sys.executable, "-c", "import torch"], check=True, timeout=280)
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELEARN_BENCH_SINGLE_DEVICE="1", RELEARN_BENCH_COMM="gloo",
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELEARN_BENCH_SINGLE_DEVICE="1", RELEARN_BENCH_COMM="host",
                RELEARN_BENCH_TEST_STALL_RANK="1", RELEARN_BENCH_TIMEOUT="20")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RELEARN_RDZV_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "1", "--envs", "2048", "--horizon", "32", "--critic-steps", "5", "--no-cpu-baseline"]
     proc = subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
     try:
@@ -572,5 +593,5 @@ def test_a_stalled_rank_ends_the_bench_with_the_phase_it_was_stuck_in():
         raise AssertionError("the stalled job did not end by itself")
     text = err.decode()
     assert proc.returncode != 0
-    assert "stuck in phase `warm-up periods (gloo collective)`" in text and "giving up (exit 4)" in text, text[-2000:]
+    assert "stuck in phase `warm-up periods (host collective)`" in text and "giving up (exit 4)" in text, text[-2000:]
     assert not [l for l in out.decode().splitlines() if l.startswith("{")]  # no result line from a job that did not finish
