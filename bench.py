@@ -137,10 +137,17 @@ def cpu_baseline(args):
         how = "measured: the update's passes over a quarter of the sample with %s threads, fastest taken" % (
             " / ".join(str(c) for c in counts))
     probe = {}
-    for c in counts:
+    for c in counts:  # ascending
+        if probe and min(probe.values()) * 1.25 < probe[max(probe)]:
+            # the previous, wider pool was already clearly slower than a narrower one: this job does not get more cores
+            # than that, and a pool far wider than its cores spends every one of the ~100 barriers of an update in the
+            # scheduler (256 threads on a 16-core share: 18 s for this probe, measured) — not run
+            probe[c] = None
+            continue
         L.oracle_cpu_sample_update_intraop(sample, 2048, 2, c)  # (the OpenMP pool of this width exists before the clock)
         probe[c] = L.oracle_cpu_sample_update_intraop(sample, max(1024, steps // 4), args.critic_steps, c)
-    usable = min(probe, key=probe.get)
+    ran = {c: t for c, t in probe.items() if t is not None}
+    usable = min(ran, key=ran.get)
     intraop_s = L.oracle_cpu_sample_update_intraop(sample, steps, args.critic_steps, usable)
     L.oracle_cpu_sample_free(sample)
     # HOT LOOP A alone, long enough to be a measurement: a short calibration run, then >= 2 s of stepping on every
@@ -164,7 +171,9 @@ def cpu_baseline(args):
         "update_seconds": {"one_thread_scaled_to_the_sample": one_thread_full_s,
                            "one_thread_measured": {"samples": n_one, "seconds": one_s},
                            "passes_over_%d_threads" % usable: intraop_s,
-                           "quarter_sample_probe": {str(c): probe[c] for c in counts}},
+                           "quarter_sample_probe": {str(c): (probe[c] if probe[c] is not None else
+                                                                     "not run: a narrower pool was already >= 1.25x faster "
+                                                                     "than the one before this") for c in counts}},
         "usable_cores": usable,
         "usable_cores_how": how,
         "unit": "env-steps/s",

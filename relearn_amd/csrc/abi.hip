@@ -1189,6 +1189,7 @@ int32_t rl_mlp_destroy(rl_mlp *m) {
   (void)hipStreamSynchronize(m->eng->stream);
   (void)hipStreamSynchronize(m->eng->aux_stream);  // (a critic chain left in flight by rl_actor_critic_update_begin)
   dfree(m->d_params);
+  dfree(m->d_wimg);
   if (m->exec) {
     dfree(m->exec->d_params);
     delete m->exec;
@@ -1227,6 +1228,7 @@ static void mlp_init_host(rl_mlp *m, uint64_t seed, const rl_initializer &kinit,
     }
   }
   h2d(m->eng, m->d_params, h.data(), m->P * sizeof(float));
+  wimg_invalidate(m);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
 }
 
 int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
@@ -1236,6 +1238,7 @@ int32_t rl_mlp_init(rl_mlp *m, uint64_t seed) {
       std::vector<float> hp;
       rnn_mlp_init_host(m, seed, rnn_default_inits(), hp);
       h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
+      wimg_invalidate(m);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
       return;
     }
     const rl_initializer glorot{RL_INIT_UNIFORM, RL_SCALE_FAN_AVG, 0.0};
@@ -1298,6 +1301,7 @@ int32_t rl_rnn_mlp_init_with(rl_mlp *m, uint64_t seed, const rl_initializer *inp
                                         *mlp_kernel_init, *mlp_bias_init},
                       hp);
     h2d(m->eng, m->d_params, hp.data(), m->P * sizeof(float));
+    wimg_invalidate(m);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
   });
 }
 
@@ -1314,6 +1318,7 @@ int32_t rl_params_set(rl_mlp *m, const float *host, uint64_t n) {
     RL_REQUIRE(m && host, "NULL argument");
     RL_REQUIRE(n == m->P, "parameter count mismatch");
     h2d(m->eng, m->d_params, host, n * sizeof(float));
+    wimg_invalidate(m);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
   });
 }
 
@@ -1370,8 +1375,8 @@ static void traj_field(const rl_traj *t, int32_t field, void **ptr, uint64_t *by
     case RL_TRAJ_ADVANTAGES: *ptr = t->d.adv; *bytes = T * n * 4; break;
     case RL_TRAJ_RETURNS: *ptr = t->d.rtg; *bytes = T * n * 4; break;
     case RL_TRAJ_TARGETS:
-      RL_REQUIRE(t->td != nullptr, "no value targets yet: they are written by rl_values_opt_update");
-      *ptr = t->td;
+      RL_REQUIRE(t->last_targets != nullptr, "no value targets yet: they are written by rl_values_opt_update");
+      *ptr = const_cast<float *>(t->last_targets);
       *bytes = T * n * 4;
       break;
     default: throw RlError(RL_ERR_INVALID_ARGUMENT, "unknown trajectory field");
@@ -1534,6 +1539,7 @@ int32_t rl_traj_write(rl_traj *t, int32_t field, const void *host, uint64_t byte
     RL_REQUIRE(bytes == need, "byte count mismatch for trajectory field");
     h2d(t->eng, p, host, bytes);
     if (field == RL_TRAJ_OBS) t->range_valid = t->range_reset = false;  // (the range guard reads the planes' magnitudes)
+    t->rtg_scan_valid = false;  // (whatever was written, the return plane is no longer known to match the rewards)
   });
 }
 
@@ -1621,6 +1627,7 @@ int32_t rl_rollout(rl_env *env, const rl_mlp *policy, rl_traj *traj) {
     // ahead beside it on the main stream; anything else waits for the chain like every other call.
     if (traj == env->eng->pending.traj || policy == env->eng->pending.critic) engine_settle(env->eng);
     traj->range_valid = traj->range_reset = false;  // new observations: the range guard has them measured again
+    traj->rtg_scan_valid = false;                   // new rewards: the return plane belongs to the old ones
     RL_REQUIRE(traj->d.n == env->cfg.n_lanes && traj->d.D == env->D, "trajectory shape does not match the env");
     RL_REQUIRE(policy->in_dim == env->D && policy->out_dim == env->A, "policy shape does not match the env");
     if (policy->general) {  // any hidden_sizes: one launch sequence per step, either env family (advances t_global)

@@ -309,6 +309,7 @@ int32_t rl_module_from_cbor(rl_mlp *module, const uint8_t *buf, uint64_t len) {
     }
     RL_REQUIRE((uint64_t)(end - p.data()) == module->P, "CBOR module: parameter count mismatch");
     h2d(module->eng, module->d_params, p.data(), module->P * sizeof(float));
+    wimg_invalidate(module);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
   });
 }
 

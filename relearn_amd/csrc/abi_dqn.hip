@@ -164,16 +164,14 @@ int32_t rl_dqn_create(rl_env *env, rl_mlp *qnet, rl_adam *opt, const rl_dqn_conf
     q->d_counts = dalloc<DqnCountsDev>(nb);
     RL_HIP_CHECK(hipMemsetAsync(q->d_counts, 0, nb * sizeof(DqnCountsDev), e->stream));
     q->mb = traj_alloc(e, q->max_steps_mb, 1, env->D, true);
-    {  // the fused step's range guard (bf16_tile.hpp): the minibatches hold observations this env produced — bounded by
-       // its termination thresholds and, for the velocities, by what a 500-step episode can reach; fixed bounds with room
-      const float lo = 0x1p-64f, hi = 0x1p16f;
+    {  // the fused step's range guard (bf16_tile.hpp): the words hold the magnitude range of every observation the
+       // collection kernel has put into the store so far (k_rollout_cartpole_dqn folds what it writes, one fold per wave
+       // and launch; never reset, so they bound every minibatch drawn from the store from outside).  Rounds 3-5 kept fixed bounds here, 2^-64 .. 2^16,
+       // under which a Q-network with a zero bias could never pass the guard.
       std::vector<uint32_t> words(RL_RANGE_WORDS, 0u);  // every slot of the minima / the maxima (bf16_tile.hpp)
-      for (int s = 0; s < 64; ++s) {
-        words[(size_t)s * 32] = __builtin_bit_cast(uint32_t, lo);
-        words[(size_t)(64 + s) * 32] = __builtin_bit_cast(uint32_t, hi);
-      }
+      for (int s = 0; s < 64; ++s) words[(size_t)s * 32] = 0x7F7FFFFFu;  // "nothing seen": largest finite minimum, maximum 0
       h2d(e, q->mb->d.range, words.data(), words.size() * sizeof(uint32_t));
-      q->mb->range_fixed = true;
+      q->mb->range_fixed = true;  // (maintained by the builders: no measuring pass over the workspace)
     }
     q->own_obs = q->mb->d.obs;
     q->own_target = q->mb->d.adv;
@@ -246,7 +244,7 @@ int32_t rl_dqn_collect(rl_dqn *q, uint64_t horizon, rl_dqn_collect_stats *stats)
       if (!q->d_q) q->d_q = dalloc<float>(2 * (size_t)q->rp.N);
       launch_rollout_dqn_general(q->env, q->qnet, q->mb, q->d_q, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
     } else {
-      launch_rollout_dqn(q->env, q->qnet, q->rp, (uint32_t)horizon, p_int, always, q->d_flags);
+      launch_rollout_dqn(q->env, q->qnet, q->rp, (uint32_t)horizon, p_int, always, q->d_flags, q->mb->d.range);
     }
     q->env->t_global += horizon;
     q->steps_per_lane += horizon;
@@ -461,7 +459,11 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
     // have run: the update is all or nothing, so the network and the optimiser state are saved first and put back then
     // (four device copies of <= 4 KB; the one-launch draw validates every minibatch before the first step).
     const uint64_t Pq = q->qnet->P, host_step0 = q->opt->host_step;
-    if (pipelined) {
+    // (the fused gradient kernel's range guard reports after the steps it could not vouch for have run: the same
+    // all-or-nothing rule — saved, and put back when the guard fires)
+    const bool fused_shape = e->kernel_variant == 0 && D == 5 && q->qnet->hidden == 128 && !q->qnet->general;
+    const bool snapshot = pipelined || fused_shape;
+    if (snapshot) {
       if (!q->snap) q->snap = dalloc<float>(3 * Pq + 2);
       RL_HIP_CHECK(hipMemcpyAsync(q->snap, q->qnet->d_params, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
       RL_HIP_CHECK(hipMemcpyAsync(q->snap + Pq, q->opt->d_m, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
@@ -513,10 +515,17 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
           dqn_gradient(q, q->opt, (int)k);
         }
       }
+      // the range guard's word is read here, inside the all-or-nothing scope (the stream is drained first: the word is
+      // host memory the kernels write across the bus)
+      if (fused_shape && K) {
+        sync(e);
+        range_check(q->mb);
+      }
     } catch (...) {
-      if (pipelined) {
-        (void)hipStreamSynchronize(q->draw_stream);  // the later chunks' draws still advance the agent's Prng
+      if (snapshot) {
+        if (pipelined) (void)hipStreamSynchronize(q->draw_stream);  // the later chunks' draws still advance the agent's Prng
         (void)hipMemcpyAsync(q->qnet->d_params, q->snap, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
+        wimg_invalidate(q->qnet);
         (void)hipMemcpyAsync(q->opt->d_m, q->snap + Pq, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
         (void)hipMemcpyAsync(q->opt->d_v, q->snap + 2 * Pq, Pq * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
         (void)hipMemcpyAsync(q->opt->d_step, q->snap + 3 * Pq, sizeof(uint64_t), hipMemcpyDeviceToDevice, e->stream);

@@ -30,6 +30,7 @@ static inline void engine_settle(rl_engine *e) {
 template <typename F>
 static inline int32_t guarded(rl_engine *eng, F &&f, bool settle = true) {
   try {
+    if (eng != nullptr) eng->call_epoch += 1;
     if (eng != nullptr && settle) engine_settle(eng);
     f();
     if (eng != nullptr) {

@@ -269,8 +269,10 @@ int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, f
     std::vector<float> cur(P);
     d2h(e, cur.data(), policy->d_params, P * sizeof(float));
     h2d(e, policy->d_params, params0, P * sizeof(float));
+    wimg_invalidate(policy);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
     run_policy_gradient(policy, traj);  // fills lp0 under params0
     h2d(e, policy->d_params, cur.data(), P * sizeof(float));
+    wimg_invalidate(policy);  // (the parameters changed under the module's weight image, bf16_tile.hpp)
     run_policy_eval(policy, traj, nullptr);
     float h[4];
     d2h(e, h, traj->vec + P, sizeof(h));
@@ -397,9 +399,19 @@ static void critic_enqueue_steps(rl_mlp *critic, rl_adam *opt, rl_traj *traj, ui
 
 // the losses of the steps just enqueued (synchronises the engine's current stream)
 static void critic_collect(rl_traj *traj, uint64_t opt_steps, rl_critic_stats *stats, float *losses_out) {
-  if (stats || losses_out) {
+  if (!(stats || losses_out)) {
+    // nothing to read back — but the call's contract is the same: a failed exchange or a range-guard violation of THESE
+    // launches is this call's error, not a later entry point's, and the guard is re-armed for the next call (ADVICE
+    // round 5: both used to be skipped here)
+    sync(traj->eng);
+    ipc_check(traj->eng);
+    range_check(traj);
+    return;
+  }
+  {
     std::vector<float> h(opt_steps ? opt_steps : 1);
     if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
+    else sync(traj->eng);
     ipc_check(traj->eng);
     range_check(traj);
     if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
@@ -453,7 +465,11 @@ static void values_opt_targets(rl_mlp *critic, rl_traj *traj, const rl_values_op
     traj->td = dalloc<float>((size_t)traj->d.T * traj->d.n);
   }
   traj->d.tgt = traj->td;
-  if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO) {
+  if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO && traj->rtg_scan_valid && traj->rtg_gamma == cfg->discount_factor) {
+    // the advantage pass's lane scan has already left exactly these targets in the return plane (same recursion, same
+    // operations: k_gae_scan / k_value_targets_rtg, kernels_rollout.hip) — no second scan over the rewards
+    traj->d.tgt = traj->d.rtg;
+  } else if (cfg->target == RL_VALUE_TARGET_REWARD_TO_GO) {
     launch_value_targets(traj, nullptr, cfg->discount_factor);
   } else if (rl_module_is_recurrent(critic->kind)) {
     SeqScope sc(traj, critic);
@@ -467,6 +483,7 @@ static void values_opt_targets(rl_mlp *critic, rl_traj *traj, const rl_values_op
     launch_values(traj, critic);
     launch_value_targets(traj, critic, cfg->discount_factor);
   }
+  traj->last_targets = traj->d.tgt;  // (what RL_TRAJ_TARGETS reads)
 }
 
 int32_t rl_values_opt_update(rl_mlp *critic, rl_adam *opt, rl_traj *traj, const rl_values_opt_config *cfg,

@@ -225,6 +225,78 @@ __device__ __forceinline__ void weight_frags(float wa, float wb, float w4, float
   f[2].u[3] = hf == 0 ? pk(e1, e2) : pk(g1, g2);
 }
 
+constexpr float FWD_SCALE = 0x1p96f, FWD_UNSCALE = 0x1p-96f;  // ("relu' in half an instruction per value", below)
+
+// ---- the weight image (round 6).  Every fused launch used to rebuild its weight-piece fragments from the flat parameter
+// vector in every wave: 20 strided loads and ~330 vector instructions (twelve three-piece splits and their packing) per
+// wave before the first tile — a third of a wave's instructions when a rank holds 8,192 lanes (16 tiles per wave), most
+// of them for a DQN minibatch (3 tiles per wave).  The kernels that WRITE the parameters (k_reduce_adam, k_adam_step,
+// k_ls_set_params: one lane owns one parameter) now also store that parameter's three 2^96-scaled pieces where the
+// consumers' lanes will load them, so a consumer's prologue is 12 x 16-byte loads per lane plus 5 raw floats per hidden
+// tile.  Same numbers as weight_frags(2^96 w ...): the consumers compute bit for bit what they computed before.
+//   frag part   uint4 [NT * 3][64]: entry (3 t + i, lane) = fragment i of hidden tile t for that lane, i.e. the halfword
+//               sequence h = 0..23 of weight_frags — pieces of input 2 hf (h 0..8: p0 p1 p2 three times), of input 2 hf + 1
+//               (h 9..17), then for half 0 input 4 twice (h 18..23), for half 1 input 4 once and the bias (h 18..23)
+//   raw part    float [NT][WIMG_RAW][64]: the unscaled weights of the lane's unit — inputs 2 hf, 2 hf + 1, then input 4
+//               (half 0) or the bias (half 1), then the unit's output weights W2[0][j] (and W2[1][j] for two outputs)
+// Who may trust it: the image belongs to a module and is valid for one C-ABI call at a time (rl_mlp::wimg_epoch against
+// rl_engine::call_epoch, engine.hpp): the first fused launch of a call builds it with k_wimg_build, the parameter-writing
+// kernels of the same call keep it current, and whatever else touches the parameters makes the next call rebuild it.
+constexpr int WIMG_RAW = 5;
+constexpr int WIMG_FRAG_WORDS = NT * 3 * 64 * 4;
+constexpr int WIMG_WORDS = WIMG_FRAG_WORDS + NT * WIMG_RAW * 64;
+__device__ __forceinline__ uint32_t wimg_half_index(int t, int lane, int h) {
+  return (uint32_t)(((t * 3 + (h >> 3)) * 64 + lane) * 8 + (h & 7));
+}
+__device__ __forceinline__ uint32_t wimg_raw_index(int t, int lane, int c) {
+  return (uint32_t)(WIMG_FRAG_WORDS + (t * WIMG_RAW + c) * 64 + lane);
+}
+// parameter p of a flat [W1 (H x D), b1 (H), W2 (A x H), b2 (A)] vector with H = 128, D = 5 has the new value w
+__device__ __forceinline__ void wimg_store_param(uint32_t *__restrict__ img, uint32_t p, float w, int A) {
+  constexpr int H = 128, D = 5;
+  unsigned short *h16 = reinterpret_cast<unsigned short *>(img);
+  float *f32 = reinterpret_cast<float *>(img);
+  if (p >= (uint32_t)(H * D + H + A * H)) return;  // the output biases are read from the vector itself
+  if (p >= (uint32_t)(H * D + H)) {                // W2[a][j]: both halves of unit j
+    const int q = (int)p - (H * D + H), a = q / H, j = q % H;
+    f32[wimg_raw_index(j >> 5, j & 31, 3 + a)] = w;
+    f32[wimg_raw_index(j >> 5, 32 + (j & 31), 3 + a)] = w;
+    return;
+  }
+  uint32_t p0, p1, p2;
+  split3(FWD_SCALE * w, p0, p1, p2);
+  const unsigned short q0 = (unsigned short)p0, q1 = (unsigned short)p1, q2 = (unsigned short)p2;
+  auto put = [&](int t, int lane, int h) {
+    h16[wimg_half_index(t, lane, h)] = q0;
+    h16[wimg_half_index(t, lane, h + 1)] = q1;
+    h16[wimg_half_index(t, lane, h + 2)] = q2;
+  };
+  if (p >= (uint32_t)(H * D)) {  // b1[j]: the last three slots of half 1
+    const int j = (int)p - H * D, t = j >> 5, n = j & 31;
+    put(t, 32 + n, 21);
+    f32[wimg_raw_index(t, 32 + n, 2)] = w;
+    return;
+  }
+  const int j = (int)p / D, k = (int)p % D, t = j >> 5, n = j & 31;
+  if (k < 4) {
+    const int lane = n + 32 * (k >> 1), base = 9 * (k & 1);
+    put(t, lane, base);
+    put(t, lane, base + 3);
+    put(t, lane, base + 6);
+    f32[wimg_raw_index(t, lane, k & 1)] = w;
+  } else {
+    put(t, n, 18);
+    put(t, n, 21);
+    put(t, 32 + n, 18);
+    f32[wimg_raw_index(t, n, 2)] = w;
+  }
+}
+// a consumer's prologue: this lane's fragments of hidden tile t and the raw weights of its unit
+struct WRaw {
+  float wa, wb, wc, w2[2];  // wc: input 4 (half 0) or the bias (half 1)
+};
+__device__ __forceinline__ void wimg_load(const uint32_t *__restrict__ img, int t, int lane, Frag (&f)[3], WRaw &r, int A);
+
 // A operands of the forward for one sample: its features 2 hf, 2 hf + 1, 4 and the bias input (1, or 0 for a padding
 // sample)
 __device__ __forceinline__ void input_frags(float xa, float xb, float xc, bool valid, int hf, Frag (&f)[3]) {
@@ -248,6 +320,17 @@ __device__ __forceinline__ void input_frags(float xa, float xb, float xc, bool v
   f[2].u[3] = pkh(x1, x1);
 }
 
+__device__ __forceinline__ void wimg_load(const uint32_t *__restrict__ img, int t, int lane, Frag (&f)[3], WRaw &r, int A) {
+  const uint4 *__restrict__ fi = reinterpret_cast<const uint4 *>(img);
+  const float *__restrict__ rw = reinterpret_cast<const float *>(img);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) f[i].x = fi[(t * 3 + i) * 64 + lane];
+  r.wa = rw[wimg_raw_index(t, lane, 0)];
+  r.wb = rw[wimg_raw_index(t, lane, 1)];
+  r.wc = rw[wimg_raw_index(t, lane, 2)];
+  r.w2[0] = rw[wimg_raw_index(t, lane, 3)];
+  r.w2[1] = A > 1 ? rw[wimg_raw_index(t, lane, 4)] : 0.0f;
+}
 // pre-activations of one 32-unit hidden tile for the wave's 32 samples
 __device__ __forceinline__ f32x16 layer1(const Frag (&fa)[3], const Frag (&fw)[3]) {
   f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -283,7 +366,6 @@ __device__ __forceinline__ void pack_mask_now(const float (&gm)[16], Frag (&ga)[
 // interlock): the first reader of the tile is therefore a real instruction — the clamp of element 0, which the
 // conversion's own clamp leaves unchanged — and every asm statement takes its result as an extra operand, so all of
 // them follow it in program order, behind the wait states the compiler inserted for it.
-constexpr float FWD_SCALE = 0x1p96f, FWD_UNSCALE = 0x1p-96f;
 
 // The numeric range in which the scaled forward is exact (include/relearn_hip.h, "Numeric range of the fused kernels"),
 // checked once per call from the weights the first fused launch has just loaded (hidden unit j: its weights for inputs
@@ -315,6 +397,21 @@ __device__ __forceinline__ void range_reset(uint32_t *range, int tid, int nthrea
     *range_hi_slot(range, s) = 0u;
   }
 }
+// a producer's side of the words: every lane accumulates the magnitudes it writes, the wave folds once at its end
+__device__ __forceinline__ void range_accumulate(float x, uint32_t &lo, uint32_t &hi) {
+  const uint32_t a = __builtin_bit_cast(uint32_t, x) & 0x7FFFFFFFu;
+  hi = a > hi ? a : hi;
+  lo = a != 0u && a < lo ? a : lo;
+}
+__device__ __forceinline__ void range_fold_wave(uint32_t *range, uint32_t key, uint32_t lo, uint32_t hi) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, m, 64), oh = (uint32_t)__shfl_xor((int)hi, m, 64);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if ((threadIdx.x & 63) == 0) range_fold(range, key, lo, hi);
+}
 // the whole wave: lane l reads slot l; every lane returns the bounds
 __device__ __forceinline__ void range_bounds(uint32_t *range, int lane, float &xmin, float &xmax) {
   uint32_t lo = *range_lo_slot(range, lane % RANGE_SLOTS), hi = *range_hi_slot(range, lane % RANGE_SLOTS);
@@ -341,6 +438,13 @@ __device__ __forceinline__ void range_guard(float wa, float wb, float w4, float 
   const bool bad = !(upper < 0x1p31f) || (!zero_unit && !(largest >= 0x1p-46f));
   if (bad) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the range guard's view of a unit from the image: input 4's weight lives in half 0, the bias in half 1
+__device__ __forceinline__ void range_guard_img(const WRaw &r, int hf, float xmin, float xmax, uint32_t *err) {
+  float w4, bj;
+  both_halves(r.wc, w4, bj);
+  range_guard(r.wa, r.wb, w4, bj, hf, xmin, xmax, err);
+}
+
 __device__ __forceinline__ uint32_t mask_pair(float lo, float hi, float after) {
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(lo), "v"(hi), "v"(after));
@@ -516,7 +620,9 @@ __device__ __forceinline__ void backward(const Frag (&ga)[NT][2], const Frag (&u
 // an input column sit in neighbouring lanes of one 16-lane row; add them (p0 + p1) + p2 with row shifts, then one
 // ds_add_f64 per value on the lane that holds piece 0 (every address belongs to exactly one lane: no contention, and
 // the order of the additions into an address is the program order of the flushes)
-__device__ __forceinline__ void flush(f32x16 (&dm)[NT], double *acc64, int stride, int n, int hf) {
+// `first` (wave-uniform): this is the wave's first flush — its image holds nothing yet, the values are STORED (a wave that
+// passes `true` for its first flush needs no zeroed image: every slot the epilogues read is written here)
+__device__ __forceinline__ void flush(f32x16 (&dm)[NT], double *acc64, int stride, int n, int hf, bool first = false) {
   const bool owner = (n < 15 && (n % 3) == 0) || n == 16;
   const int k = n == 16 ? 5 : n / 3;
 #pragma unroll
@@ -533,7 +639,13 @@ __device__ __forceinline__ void flush(f32x16 (&dm)[NT], double *acc64, int strid
       tot[r] = (v + v1) + v2;
       dm[t][r] = 0.0f;
     }
-    if (owner) {
+    if (owner && first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        acc64[j * stride + k] = (double)tot[r];
+      }
+    } else if (owner) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;

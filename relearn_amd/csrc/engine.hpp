@@ -176,6 +176,9 @@ struct rl_engine {
   // last child is destroyed (hosts with garbage collectors release handles in arbitrary order)
   int64_t live_handles = 0;
   bool zombie = false;
+  // counts the C-ABI calls made on this engine (guarded(), abi_internal.hpp): what a module's weight image is valid for
+  // (rl_mlp::wimg_epoch) — state derived from the parameters is never trusted across entry points
+  uint64_t call_epoch = 0;
   // 0: best available kernels (MFMA v2 where the shape allows); 1: v1 reference kernels only
   int kernel_variant = 0;
   // rl_actor_critic_update: run the policy chain and the critic chain one after the other on the main stream (what the
@@ -223,6 +226,10 @@ struct rl_mlp {
   uint32_t in_dim, hidden, out_dim;  // GRU_MLP: hidden = the MLP's hidden width
   uint64_t P;
   float *d_params = nullptr;
+  // the weight image of a 5 -> 128 -> A module for the fused update kernels (bf16_tile.hpp "the weight image"): allocated
+  // on first use, current while wimg_epoch == eng->call_epoch (wimg_ensure / wimg_if_current / wimg_invalidate, kernels.hpp)
+  mutable uint32_t *d_wimg = nullptr;
+  mutable uint64_t wimg_epoch = 0;
   int kind = RL_MODULE_MLP;
   uint32_t gru_hidden = 0;
   // RnnBaseConfig::num_layers (seq/rnn/mod.rs:20-45,223-257).  > 1: stacked layers — flat order [W_ih, W_hh, b_ih, b_hh]
@@ -357,6 +364,13 @@ struct rl_traj {
   // Fisher-vector products and line-search candidates of a TRPO update — start from parameters the same call produced in
   // steps bounded by the learning rate / the KL constraint, and the wave that runs the guard starts its tiles ~1 us late
   bool guard_next_policy = true, guard_next_critic = true;
+  // d.rtg holds the reward-to-go of the CURRENT reward / flag planes at discount factor `rtg_gamma`, written by the
+  // lane scan of k_gae_scan (launch_gae) — the same recursion, operation for operation, as the RewardToGo value targets
+  // (k_value_targets_rtg): a critic update that asks for exactly those regresses on the plane instead of scanning the
+  // rewards a second time.  Cleared by whatever rewrites the planes (rollouts, rl_traj_write, the array-fed scans).
+  bool rtg_scan_valid = false;
+  float rtg_gamma = 0.0f;
+  const float *last_targets = nullptr;  // where the last rl_values_opt_update's targets are: `td`, or the return plane
   uint32_t bwd_chunk = 0;   // samples per backward block
   SeqDev seq;
   GenDev gen;

@@ -26,6 +26,18 @@ inline void traj_ensure_range(rl_traj *traj) {
   traj->range_valid = true;
 }
 
+// The weight image of a 5 -> 128 -> A module (bf16_tile.hpp): valid for one C-ABI call at a time.
+//   wimg_ensure       a fused launcher about to read it: builds it (one small launch on the engine's current stream)
+//                     unless this call already did, returns it
+//   wimg_if_current   a launcher whose kernel writes the module's parameters one lane per parameter: the image to keep
+//                     current beside them, or NULL when this call has not built one (nothing to keep)
+//   wimg_invalidate   anything else that writes the parameters on the device inside a call
+const uint32_t *wimg_ensure(const rl_mlp *m);
+inline uint32_t *wimg_if_current(const rl_mlp *m) {
+  return m->d_wimg != nullptr && m->wimg_epoch == m->eng->call_epoch ? m->d_wimg : nullptr;
+}
+inline void wimg_invalidate(const rl_mlp *m) { m->wimg_epoch = 0; }
+
 // kernels_update.hip
 enum PolicyPassMode { PASS_INIT = 0, PASS_EVAL = 1, PASS_JVP = 2, PASS_DQN = 3, PASS_PPO = 4 };
 // PASS_INIT : lp0 <- log pi(.|s); dz <- d(-mean(ratio*A))/dz at theta0; slabB <- {sum A, sum entropy}
@@ -61,8 +73,9 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
                       const int32_t *d_skip_flag, float clip_lo = 0.0f, float clip_hi = 0.0f);
 
 // kernels_dqn.hip
+// d_range (may be NULL): the collected observations' magnitude range is folded there (the fused gradient's range guard)
 void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
-                        int always_explore, uint8_t *d_flags);
+                        int always_explore, uint8_t *d_flags, uint32_t *d_range = nullptr);
 // an action-value module of any shape (rl_mlp::general): one launch sequence per step; `ws` lends the layer kernels their
 // workspace, d_q [2][n] receives the module's outputs of every step
 void launch_rollout_dqn_general(rl_env *env, const rl_mlp *qnet, rl_traj *ws, float *d_q, const ReplayDev &rp, uint32_t T,

@@ -17,7 +17,10 @@
 // loses here: 0.259 against 0.219 ms per step; this kernel has one |pre| chain to replace, not a second layer-1 product
 // with its LDS-resident operands, and 16 more matrix instructions per tile push it against the matrix pipe.)
 // Algorithmic flops per sample: 3 x (2*5*128 + 2*128) = 4608 (forward + 2 x backward of the 5-128-1 MLP).
+#include <algorithm>
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "bf16_tile.hpp"
 #include "device_fns.hpp"
@@ -31,9 +34,22 @@ constexpr int CRITIC_WAVES = 8;  // waves per workgroup, one workgroup per CU (t
                                                // does not fit three)
 constexpr int C_FLUSH = 64;                     // f32 -> f64 flush period in tiles (2048 samples per accumulator: the accumulated error stays below a 128-sample f32 fma chain's, scripts/probe/mfma_bf16_mask.hip)
 
+// -DRL_CRITIC_TIMESTAMPS (a timing build, scripts/build_variant.sh): wave 0 of every workgroup records the constant
+// 100 MHz clock at seven points of the launch; the launcher prints the averages over the workgroups (round 6: where the
+// ~7 us a launch costs beyond its tiles go)
+#ifdef RL_CRITIC_TIMESTAMPS
+__device__ uint64_t g_critic_ts[1024 * 8];
+#define RL_TS(k)                                                                                   \
+  do {                                                                                             \
+    if (threadIdx.x == 0) g_critic_ts[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();    \
+  } while (0)
+#else
+#define RL_TS(k)
+#endif
+
 __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
-    k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
-                       double *__restrict__ slabB, float two_over_B, uint32_t P) {
+    k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, const uint32_t *__restrict__ wimg,
+                       double *__restrict__ slabA, double *__restrict__ slabB, float two_over_B, uint32_t P) {
   constexpr int D = 5, H = 128, NT = bt::NT;
   constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] (slot 6 unused); then db2, loss
 #ifndef RL_CRITIC_Y_IN_REGISTERS
@@ -49,7 +65,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   const size_t B = (size_t)tr.T * tr.n;
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   double *acc64 = Acc[wave];
-  for (int p = lane; p < IMG; p += 64) acc64[p] = 0.0;
+  RL_TS(0);
+  // (the wave's f64 image is not zeroed: its first flush stores — bt::flush — and every wave flushes at least once)
+  bool flushed = false;
 
   // weight pieces of hidden unit 32 t + n in this half's slot order; w2; the linear half of relu (v of this half's
   // inputs: 2 hf, 2 hf + 1, and 4 or the bias)
@@ -59,19 +77,18 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   const bool guard = blockIdx.x == 0 && wave == 0 && tr.range != nullptr;  // the numeric range guard (bf16_tile.hpp)
   float gxmin = 0.0f, gxmax = 0.0f;
   if (guard) bt::range_bounds(tr.range, lane, gxmin, gxmax);
+  // (the pieces come ready-made from the module's weight image, written by whoever wrote the parameters: bf16_tile.hpp)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int j = t * 32 + n;
-    const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
-    const float w2 = W2[j];
-    lv[0] = __builtin_fmaf(w2, wa, lv[0]);
-    lv[1] = __builtin_fmaf(w2, wb, lv[1]);
-    lv[2] = __builtin_fmaf(w2, hf == 0 ? w4 : bj, lv[2]);
+    bt::WRaw r;
+    bt::wimg_load(wimg, t, lane, fw[t], r, 1);
+    const float w2 = r.w2[0];
+    lv[0] = __builtin_fmaf(w2, r.wa, lv[0]);
+    lv[1] = __builtin_fmaf(w2, r.wb, lv[1]);
+    lv[2] = __builtin_fmaf(w2, r.wc, lv[2]);
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain takes the scale
     // back out through w2 (both exact)
-    if (guard) bt::range_guard(wa, wb, w4, bj, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
-    const float sc = bt::FWD_SCALE;
-    bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
+    if (guard) bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
     w2v[t] = bt::FWD_UNSCALE * w2;
   }
 #pragma unroll
@@ -87,6 +104,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
                                          // of every sum over samples here
   bt::wave_lds_fence();
 
+  RL_TS(1);  // (after the weights have arrived: the cross-lane sums above wait for them)
   Frag selb[2];  // piece-column selection (B operand of the routing product)
   bt::sel_frags(lane, selb);
   // Tiles: the full ones in the loop, a ragged last one (B not a multiple of 32) after it on the wave whose turn it
@@ -188,7 +206,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 #endif
     if (++since_flush == C_FLUSH) {
       since_flush = 0;
-      bt::flush(dm, acc64, 7, n, hf);
+      bt::flush(dm, acc64, 7, n, hf, !flushed);
+      flushed = true;
       loss64 += (double)loss32;
       db2_64 += (double)db2_32;
       loss32 = db2_32 = 0.0f;
@@ -201,6 +220,10 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     // loop unrolled three times — is SLOWER, 0.237 against 0.220 ms per step, although a timing build without the loads
     // runs in 0.197: what the loads cost is issue slots, not exposed latency.)
     TileOp op_a = load_tile(wave_id), op_b = op_a;
+#ifdef RL_CRITIC_TIMESTAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RL_TS(2);  // (the first tile's operands are here)
+#endif
     for (uint32_t g = wave_id; g < n_full; g += 2 * n_waves) {
       const uint32_t g1 = g + n_waves, g2 = g1 + n_waves;
       op_b = load_tile(g1 < n_full ? g1 : g);
@@ -211,9 +234,14 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     }
   }
   if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full));
-  bt::flush(dm, acc64, 7, n, hf);
-  loss64 += (double)loss32;
-  db2_64 += (double)db2_32;
+  RL_TS(3);
+  if (since_flush != 0 || !flushed) {  // (a wave whose tile count is a multiple of the flush period has nothing left: at
+                                       // the headline size every wave owns exactly 2 x C_FLUSH tiles, and this was a
+                                       // third flush of zeros; a wave without tiles still defines its image)
+    bt::flush(dm, acc64, 7, n, hf, !flushed);
+    loss64 += (double)loss32;
+    db2_64 += (double)db2_32;
+  }
   // loss / db2: reduce over the 32 owner lanes of the wave (f64 moved as two 32-bit halves)
   auto xlane = [](double v, int mask) {
     uint64_t bits = rl_f64_bits(v);
@@ -231,7 +259,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     acc64[H * 7] = bsum;   // db2
     acc64[H * 7 + 1] = l;  // loss partial
   }
+  RL_TS(4);
   __syncthreads();
+  RL_TS(5);
   // sum the per-wave images in wave order, turn M into gradients and write the workgroup's slab row
   for (uint32_t p = threadIdx.x; p <= P; p += CRITIC_WAVES * 64) {
     auto tot = [&](int src) {
@@ -261,6 +291,10 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     else slabB[(size_t)blockIdx.x * 4 + 0] = s;
   }
   if (threadIdx.x < 3) slabB[(size_t)blockIdx.x * 4 + 1 + threadIdx.x] = 0.0;
+#ifdef RL_CRITIC_TIMESTAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RL_TS(6);
+#endif
 }
 
 // ---------------------------------------------------------------- launcher
@@ -269,6 +303,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (traj->d.D != 5 || critic->hidden != 128 || critic->out_dim != 1) return false;
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
   traj_ensure_range(traj);
+  const uint32_t *wimg = wimg_ensure(critic);
   ProfScope ps(traj->eng, RL_K_CRITIC_FUSED);
   float two_over_B = 2.0f / (float)B_total;
   // persistent grid: one fat workgroup per CU (fewer, fatter workgroups = fewer slab rows for the reduction that follows
@@ -282,6 +317,26 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (!traj->guard_next_critic) d.range = nullptr;  // (the range guard: first critic launch of the call only, engine.hpp)
   traj->guard_next_critic = false;
   hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, d,
-                     critic->d_params, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
+                     critic->d_params, wimg, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
+#ifdef RL_CRITIC_TIMESTAMPS
+  if (std::getenv("RL_CRITIC_TS_PRINT")) {
+    static int calls = 0;
+    if (++calls % 16 == 0) {  // (every 16th launch: the host synchronises for it)
+      std::vector<uint64_t> h(1024 * 8);
+      (void)hipStreamSynchronize(traj->eng->stream);
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_critic_ts), h.size() * 8);
+      double sum[7] = {0}, first = 1e300, last = 0;
+      for (uint32_t b = 0; b < traj->nbC; ++b) {
+        for (int k = 0; k < 7; ++k) sum[k] += (double)(h[b * 8 + k] - h[b * 8]) * 0.01;
+        first = std::min(first, (double)h[b * 8] * 0.01);
+        last = std::max(last, (double)h[b * 8 + 6] * 0.01);
+      }
+      std::fprintf(stderr, "critic ts (us from a workgroup's start, mean of %u): weights %.2f  first tile %.2f  loop end %.2f  "
+                   "flushed %.2f  barrier %.2f  end %.2f | first start to last end %.2f\n", traj->nbC,
+                   sum[1] / traj->nbC, sum[2] / traj->nbC, sum[3] / traj->nbC, sum[4] / traj->nbC, sum[5] / traj->nbC,
+                   sum[6] / traj->nbC, last - first);
+    }
+  }
+#endif
   return true;
 }

@@ -65,9 +65,14 @@ template <int D, int BLOCK, int G>
 __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, EnvStateDev st, ReplayDev rp,
                                                                 const float *__restrict__ qnet, int H, uint32_t T,
                                                                 uint64_t p_int, int always_explore,
-                                                                uint8_t *__restrict__ flags_out) {
+                                                                uint8_t *__restrict__ flags_out,
+                                                                uint32_t *__restrict__ range) {
   __shared__ uint32_t words[16 * BLOCK];
   __shared__ __attribute__((aligned(16))) float pk[MLP_PK_FLOATS];  // the Q-network, one 8-float record per hidden unit
+  // the magnitude range of every observation that enters the store (steps and Interrupt successors), for the fused
+  // gradient kernel's range guard (bf16_tile.hpp): one fold per wave and launch into words that are never reset — the
+  // range of everything ever collected bounds every minibatch drawn from the store
+  uint32_t r_lo = 0x7F7FFFFFu, r_hi = 0u;
   const uint32_t n = rp.N;
   mlp_pack_lds<D>(pk, qnet, H, threadIdx.x, BLOCK);
   __syncthreads();
@@ -124,6 +129,8 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
       break;
     }
     const size_t o = (size_t)i * rp.C + slot_abs % rp.C;
+#pragma unroll
+    for (int d = 0; d < D; ++d) bt::range_accumulate(f[d], r_lo, r_hi);
     if (writer) {
       ReplayRec rec;
 #pragma unroll
@@ -134,6 +141,8 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
     }
     if (succ_rec == RL_SUCC_INTERRUPT) {
       cp_features<D>(c, s, f);
+#pragma unroll
+      for (int d = 0; d < D; ++d) bt::range_accumulate(f[d], r_lo, r_hi);
       if (writer) {
 #pragma unroll
         for (int d = 0; d < D; ++d) rp.next[o].x[d] = f[d];
@@ -142,6 +151,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_cartpole_dqn(CartPoleDev c, E
     if (writer) flags_out[(size_t)t * n + i] = (uint8_t)succ_rec;
     if (succ != RL_SUCC_CONTINUE) cp_reset(c, s, lane);
   }
+  if (range != nullptr) bt::range_fold_wave(range, blockIdx.x, r_lo, r_hi);  // (every thread of the wave is here)
   if (!writer) return;
   if (full) *rp.error = 1;
   rp.head[i] = ring.head;
@@ -662,20 +672,20 @@ static inline uint32_t cdiv_d(size_t a, size_t b) { return (uint32_t)((a + b - 1
 
 template <int G>
 static void launch_rollout_dqn_g(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
-                                 int always_explore, uint8_t *d_flags) {
+                                 int always_explore, uint8_t *d_flags, uint32_t *d_range) {
   constexpr int BLOCK = 64;
   const uint32_t n = (uint32_t)env->cfg.n_lanes;
   const dim3 grid(cdiv_d((size_t)n * G, BLOCK)), blk(BLOCK);
   if (env->D == 5)
     hipLaunchKernelGGL((k_rollout_cartpole_dqn<5, BLOCK, G>), grid, blk, 0, env->eng->stream, env->dev, env->st, rp,
-                       qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags);
+                       qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags, d_range);
   else
     hipLaunchKernelGGL((k_rollout_cartpole_dqn<4, BLOCK, G>), grid, blk, 0, env->eng->stream, env->dev, env->st, rp,
-                       qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags);
+                       qnet->d_params, (int)qnet->hidden, T, p_int, always_explore, d_flags, d_range);
 }
 
 void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, uint32_t T, uint64_t p_int,
-                        int always_explore, uint8_t *d_flags) {
+                        int always_explore, uint8_t *d_flags, uint32_t *d_range) {
   ProfScope ps(env->eng, RL_K_ROLLOUT);
   // threads per lane: as many as keep the launch within one wave per SIMD (launch_rollout, kernels_rollout.hip); a
   // collection that always explores never runs the forward and keeps one thread per lane
@@ -684,11 +694,11 @@ void launch_rollout_dqn(rl_env *env, const rl_mlp *qnet, const ReplayDev &rp, ui
   while (!always_explore && G < 16 && n * (uint64_t)(2 * G) <= simds * 64) G *= 2;
   if (env->eng->kernel_variant == 1) G = 1;
   switch (G) {
-    case 16: launch_rollout_dqn_g<16>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
-    case 8: launch_rollout_dqn_g<8>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
-    case 4: launch_rollout_dqn_g<4>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
-    case 2: launch_rollout_dqn_g<2>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
-    default: launch_rollout_dqn_g<1>(env, qnet, rp, T, p_int, always_explore, d_flags); break;
+    case 16: launch_rollout_dqn_g<16>(env, qnet, rp, T, p_int, always_explore, d_flags, d_range); break;
+    case 8: launch_rollout_dqn_g<8>(env, qnet, rp, T, p_int, always_explore, d_flags, d_range); break;
+    case 4: launch_rollout_dqn_g<4>(env, qnet, rp, T, p_int, always_explore, d_flags, d_range); break;
+    case 2: launch_rollout_dqn_g<2>(env, qnet, rp, T, p_int, always_explore, d_flags, d_range); break;
+    default: launch_rollout_dqn_g<1>(env, qnet, rp, T, p_int, always_explore, d_flags, d_range); break;
   }
   RL_HIP_CHECK(hipGetLastError());
 }
@@ -773,7 +783,8 @@ constexpr int DQN_FLUSH = 16;  // f32 -> f64 flush period in tiles
 // 139-150, 203-229) comes from a second forward with the same parameters (torch's no_grad target of dqn.rs:299-311).
 template <bool TD>
 __global__ void __launch_bounds__(DQN_WAVES * 64)
-    k_dqn_step_bf16(TrajDev tr, const float *__restrict__ params, double *__restrict__ slabA,
+    k_dqn_step_bf16(TrajDev tr, const float *__restrict__ params, const uint32_t *__restrict__ wimg,
+                    double *__restrict__ slabA,
                     double *__restrict__ slabB, float two_over_B, uint32_t P, float gamma) {
   using bt::f32x16;
   using bt::Frag;
@@ -790,7 +801,7 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   const size_t B = (size_t)tr.T * tr.n;
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   double *acc64 = Acc[wave];
-  for (int p = lane; p < IMG; p += 64) acc64[p] = 0.0;
+  bool flushed = false;  // (the wave's f64 image is not zeroed: its first flush stores, bt::flush)
 
   Frag fw[NT][3];
   float w2v[A][NT];
@@ -798,19 +809,19 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   const bool guard = blockIdx.x == 0 && wave == 0 && tr.range != nullptr;  // the numeric range guard (bf16_tile.hpp)
   float gxmin = 0.0f, gxmax = 0.0f;
   if (guard) bt::range_bounds(tr.range, lane, gxmin, gxmax);
+  // (the 2^96-scaled pieces — relu' by conversion, bf16_tile.hpp; the |pre| chains take the scale back out — come
+  // ready-made from the module's weight image, written by whoever wrote the parameters)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int j = t * 32 + n;
-    const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
-    if (guard) bt::range_guard(wa, wb, w4, bj, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
-    const float sc = bt::FWD_SCALE;  // relu' by conversion (bf16_tile.hpp); the |pre| chains take the scale back out
-    bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
+    bt::WRaw r;
+    bt::wimg_load(wimg, t, lane, fw[t], r, 2);
+    if (guard) bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-      const float w2 = W2[a * H + j];
-      lv[a][0] = __builtin_fmaf(w2, wa, lv[a][0]);
-      lv[a][1] = __builtin_fmaf(w2, wb, lv[a][1]);
-      lv[a][2] = __builtin_fmaf(w2, hf == 0 ? w4 : bj, lv[a][2]);
+      const float w2 = r.w2[a];
+      lv[a][0] = __builtin_fmaf(w2, r.wa, lv[a][0]);
+      lv[a][1] = __builtin_fmaf(w2, r.wb, lv[a][1]);
+      lv[a][2] = __builtin_fmaf(w2, r.wc, lv[a][2]);
       w2v[a][t] = bt::FWD_UNSCALE * w2;
     }
   }
@@ -870,8 +881,9 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
     return o;
   };
   auto flush_all = [&]() {
-    bt::flush(dm[0], acc64, 7, n, hf);
-    bt::flush(dm[1], acc64 + CH, 7, n, hf);
+    bt::flush(dm[0], acc64, 7, n, hf, !flushed);
+    bt::flush(dm[1], acc64 + CH, 7, n, hf, !flushed);
+    flushed = true;
     loss64 += (double)loss32;
     db64[0] += (double)db32[0];
     db64[1] += (double)db32[1];
@@ -953,7 +965,8 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
     }
     op = next;
   }
-  flush_all();
+  if (since_flush != 0 || !flushed) flush_all();  // (nothing left when the last tile ended a flush period; a wave
+                                                  // without tiles still defines its image)
   auto xlane = [](double v, int mask) {
     uint64_t bits = rl_f64_bits(v);
     uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, mask, 64);
@@ -1004,6 +1017,7 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
 bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total, bool td_in_kernel, float gamma) {
   if (mb->d.D != 5 || qnet->hidden != 128 || qnet->out_dim != 2 || qnet->general) return false;
   if ((uint64_t)(mb->d.T + 1) * mb->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
+  const uint32_t *wimg = wimg_ensure(qnet);
   ProfScope ps(mb->eng, RL_K_POLICY_FUSED);
   const uint64_t n_tiles = (mb->B + 31) / 32, cus = (uint64_t)mb->eng->prop.multiProcessorCount;
   uint64_t nb = (n_tiles + DQN_WAVES - 1) / DQN_WAVES;
@@ -1014,10 +1028,10 @@ bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total, boo
   mb->guard_next_policy = false;
   if (td_in_kernel)
     hipLaunchKernelGGL(k_dqn_step_bf16<true>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, d,
-                       qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
+                       qnet->d_params, wimg, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
   else
     hipLaunchKernelGGL(k_dqn_step_bf16<false>, dim3((uint32_t)nb), dim3(DQN_WAVES * 64), 0, mb->eng->stream, d,
-                       qnet->d_params, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
+                       qnet->d_params, wimg, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, gamma);
   RL_HIP_CHECK(hipGetLastError());
   return true;
 }

@@ -37,8 +37,8 @@ constexpr int PB_FLUSH = 16;  // f32 -> f64 flush period in tiles (32 / 64: 2 % 
 
 template <int MODE, int WAVES, bool FW_LDS = false>
 __global__ void __launch_bounds__(WAVES * 64)
-    k_policy_bf16(TrajDev tr, const float *__restrict__ params, const float *__restrict__ tangent,
-                  float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
+    k_policy_bf16(TrajDev tr, const float *__restrict__ params, const uint32_t *__restrict__ wimg,
+                  const float *__restrict__ tangent, float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
                   uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
   using bt::Frag;
   constexpr int D = 5, H = 128, NT = bt::NT, A = 2;
@@ -60,8 +60,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const size_t B = (size_t)tr.T * tr.n;
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   double *acc64 = Acc[wave];
-  if (BWD)
-    for (int p = lane; p < PIMG_M; p += 64) acc64[p] = 0.0;
+  bool flushed = false;  // (the wave's f64 image is not zeroed: its first flush stores, bt::flush)
 
   Frag fw[NT][3];
   // Only the DIFFERENCE of the two logits enters a two-way log-softmax (it is shift-invariant), so the output layer is
@@ -73,24 +72,23 @@ __global__ void __launch_bounds__(WAVES * 64)
   const bool guard = blockIdx.x == 0 && wave == 0 && tr.range != nullptr;  // the numeric range guard (bf16_tile.hpp)
   float gxmin = 0.0f, gxmax = 0.0f;
   if (guard) bt::range_bounds(tr.range, lane, gxmin, gxmax);
+  // (the pieces come ready-made from the module's weight image, written by whoever wrote the parameters: bf16_tile.hpp)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int j = t * 32 + n;
-    const float wa = W1[j * D + 2 * hf], wb = W1[j * D + 2 * hf + 1], w4 = W1[j * D + 4], bj = b1[j];
+    bt::WRaw r;
+    bt::wimg_load(wimg, t, lane, fw[t], r, 2);
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain of the gradient /
     // evaluation passes takes the scale back out through w2d (both exact); the Fisher-vector pass only needs the masks
-    if (guard) bt::range_guard(wa, wb, w4, bj, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
-    const float sc = bt::FWD_SCALE;
-    bt::weight_frags(sc * wa, sc * wb, sc * w4, sc * bj, hf, fw[t]);
+    if (guard) bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
     if (FW_LDS && wave == t) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) Fw[t * 3 + i][lane] = fw[t][i].x;
     }
-    const float wd = W2[j] - W2[H + j];
+    const float wd = r.w2[0] - r.w2[1];
     if (!JVP) {
-      lvd[0] = __builtin_fmaf(wd, wa, lvd[0]);
-      lvd[1] = __builtin_fmaf(wd, wb, lvd[1]);
-      lvd[2] = __builtin_fmaf(wd, hf == 0 ? w4 : bj, lvd[2]);
+      lvd[0] = __builtin_fmaf(wd, r.wa, lvd[0]);
+      lvd[1] = __builtin_fmaf(wd, r.wb, lvd[1]);
+      lvd[2] = __builtin_fmaf(wd, r.wc, lvd[2]);
     }
     w2d[t] = bt::FWD_UNSCALE * wd;
   }
@@ -313,7 +311,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       bt::backward(ga, ub, dm);
       if (++since_flush == PB_FLUSH) {
         since_flush = 0;
-        bt::flush(dm, acc64, IW, n, hf);
+        bt::flush(dm, acc64, IW, n, hf, !flushed);
+        flushed = true;
         fold();
       }
     } else if (++since_flush == PB_FLUSH) {
@@ -344,7 +343,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
   }
   if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full), n_full);
-  if (BWD) bt::flush(dm, acc64, IW, n, hf);
+  if (BWD && (since_flush != 0 || !flushed)) bt::flush(dm, acc64, IW, n, hf, !flushed);  // (nothing left when the last
+                                                                // tile ended a flush period; a wave without tiles
+                                                                // still defines its image)
   fold();
   auto xlane = [](double v, int mask) {
     uint64_t bits = rl_f64_bits(v);
@@ -423,6 +424,7 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   if (mode == PASS_DQN) return false;  // k_dqn_step_bf16 (kernels_dqn.hip)
   if ((uint64_t)(traj->d.T + 1) * traj->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernels
   traj_ensure_range(traj);
+  const uint32_t *wimg = wimg_ensure(policy);
   ProfScope ps(traj->eng, mode == PASS_JVP ? RL_K_POLICY_FVP : RL_K_POLICY_FUSED);
   float inv_B = 1.0f / (float)B_total;
   traj->last_rows = traj->nbV2;
@@ -433,7 +435,7 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   if (!traj->guard_next_policy) d.range = nullptr;  // (the range guard: first policy launch of the call only, engine.hpp)
   traj->guard_next_policy = false;
 #define BLAUNCH(MM)                                                                                                  \
-  hipLaunchKernelGGL((k_policy_bf16<MM, V2_WAVES>), g, b, 0, s, d, policy->d_params, d_tangent, traj->lp0,             \
+  hipLaunchKernelGGL((k_policy_bf16<MM, V2_WAVES>), g, b, 0, s, d, policy->d_params, wimg, d_tangent, traj->lp0,       \
                      traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
   if (mode == PASS_INIT) BLAUNCH(PASS_INIT);
   else if (mode == PASS_JVP) BLAUNCH(PASS_JVP);
@@ -443,7 +445,8 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
     // VGPRs) — 0.155 ms per launch at 8.4 M samples against 0.206 ms at eight (sixteen waves: 17 spills, no gain)
     constexpr int EVAL_WAVES = 16;
     hipLaunchKernelGGL((k_policy_bf16<PASS_EVAL, EVAL_WAVES, true>), g, dim3(EVAL_WAVES * 64), 0, s, d,
-                       policy->d_params, d_tangent, traj->lp0, traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi);
+                       policy->d_params, wimg, d_tangent, traj->lp0, traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo,
+                       clip_hi);
   }
 #undef BLAUNCH
   return true;

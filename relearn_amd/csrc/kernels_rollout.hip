@@ -507,6 +507,8 @@ void launch_values(rl_traj *traj, const rl_mlp *critic) {
 void launch_gae(rl_traj *traj, const rl_mlp *critic, float gamma, float lambda) {
   ProfScope ps(traj->eng, RL_K_GAE);
   uint32_t n = traj->d.n;
+  traj->rtg_scan_valid = true;  // d.rtg <- the lane scan's reward-to-go at `gamma` (engine.hpp)
+  traj->rtg_gamma = gamma;
   if (traj->d.D == 5)
     hipLaunchKernelGGL(k_gae_scan<5>, dim3(cdiv(n, 64)), dim3(64), 0, traj->eng->stream, traj->d,
                        critic ? critic->d_params : (const float *)nullptr, critic ? (int)critic->hidden : 0, gamma, lambda,

@@ -910,6 +910,7 @@ void launch_seq_value_targets(rl_traj *traj, float gamma) {
 }
 
 void launch_seq_gae(rl_traj *traj, float gamma, float lambda) {
+  traj->rtg_scan_valid = false;  // (this scan writes the return plane too; only k_gae_scan's is vouched for, engine.hpp)
   ProfScope ps(traj->eng, RL_K_GAE);
   uint32_t n = traj->d.n;
   hipLaunchKernelGGL(k_seq_gae, dim3(cdiv_s(n, 64)), dim3(64), 0, traj->eng->stream, traj->d, traj->seq.out,

@@ -14,6 +14,7 @@
 // Reference semantics followed: src/torch/agents/policies/trpo.rs:97-164,
 // src/torch/optimizers/conjugate_gradient.rs:115-403, src/torch/distributions/categorical.rs:29-77,
 // src/torch/agents/critics/opt.rs:100-126, src/torch/optimizers/coptimizer.rs:13-26.
+#include "bf16_tile.hpp"
 #include "comm_ipc.hpp"
 #include "device_fns.hpp"
 #include "kernels.hpp"
@@ -411,11 +412,24 @@ __device__ __forceinline__ bool comm_failed(const int32_t *comm_err) {
 }
 
 // param.copy_(prev_param - ratio * step) (conjugate_gradient.rs:204-213)
+// `wimg` (may be NULL): the module's weight image, kept current beside the parameters (bf16_tile.hpp)
 __global__ void __launch_bounds__(SB) k_ls_set_params(float *__restrict__ params, const float *__restrict__ prev,
                                                       const float *__restrict__ descent, uint32_t P, float ratio,
-                                                      const TrpoStateDev *st, const int32_t *comm_err) {
+                                                      const TrpoStateDev *st, const int32_t *comm_err,
+                                                      uint32_t *__restrict__ wimg, int A) {
   if (st->ls_accepted || comm_failed(comm_err)) return;
-  for (uint32_t i = threadIdx.x; i < P; i += SB) params[i] = prev[i] - ratio * descent[i];
+  for (uint32_t i = threadIdx.x; i < P; i += SB) {
+    const float w = prev[i] - ratio * descent[i];
+    params[i] = w;
+    if (wimg) bt::wimg_store_param(wimg, i, w, A);
+  }
+}
+
+// the weight image from scratch: one lane per parameter (the first fused launch of a C-ABI call, wimg_ensure)
+__global__ void __launch_bounds__(SB) k_wimg_build(const float *__restrict__ params, uint32_t P,
+                                                   uint32_t *__restrict__ wimg, int A) {
+  const uint32_t i = blockIdx.x * SB + threadIdx.x;
+  if (i < P) bt::wimg_store_param(wimg, i, params[i], A);
 }
 
 // acceptance test of one backtrack (conjugate_gradient.rs:215-223)
@@ -467,7 +481,8 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
                                                   uint32_t P, uint64_t step, float neg_step_size, float sqrt_bc2,
                                                   double beta1, double beta2, double eps, double weight_decay,
                                                   const float *__restrict__ loss_sum, double inv_B,
-                                                  float *__restrict__ loss_out, const int32_t *comm_err) {
+                                                  float *__restrict__ loss_out, const int32_t *comm_err,
+                                                  uint32_t *__restrict__ wimg, int A) {
   if (comm_failed(comm_err)) return;  // `grad` holds local sums: no step, no step count
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *step_ptr = step;
@@ -485,7 +500,9 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
     m[i] = mi;
     v[i] = vi;
     float denom = __fsqrt_rn(vi) / sqrt_bc2 + epsf;
-    params[i] = params[i] + (neg_step_size * mi) / denom;
+    const float w = params[i] + (neg_step_size * mi) / denom;
+    params[i] = w;
+    if (wimg) bt::wimg_store_param(wimg, i, w, A);  // (the module's weight image stays current, bf16_tile.hpp)
   }
 }
 
@@ -503,7 +520,8 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
                                                       uint64_t *step_ptr, uint64_t step, float neg_step_size,
                                                       float sqrt_bc2, double beta1, double beta2, double eps,
                                                       double weight_decay, double inv_B,
-                                                      float *__restrict__ loss_out, IpcPeers peers) {
+                                                      float *__restrict__ loss_out, IpcPeers peers,
+                                                      uint32_t *__restrict__ wimg, int A) {
   __shared__ double part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 64 + lane;
@@ -547,7 +565,11 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
   m[p] = mi;
   v[p] = vi;
   const float denom = __fsqrt_rn(vi) / sqrt_bc2 + epsf;
-  params[p] = p_old + (neg_step_size * mi) / denom;
+  const float w_new = p_old + (neg_step_size * mi) / denom;
+  params[p] = w_new;
+  // the next fused launch reads the weights as piece fragments: this lane owns parameter p, it also owns p's pieces in
+  // the module's weight image (bf16_tile.hpp; NULL when this call has built none)
+  if (wimg) bt::wimg_store_param(wimg, p, w_new, A);
 }
 
 // ---------------------------------------------------------------- launchers
@@ -647,7 +669,27 @@ void launch_step_size(rl_traj *traj, rl_mlp *policy, float reg, double max_kl) {
 void launch_ls_set_params(rl_traj *traj, rl_mlp *policy, double ratio) {
   ProfScope ps(traj->eng, RL_K_SMALL);
   hipLaunchKernelGGL(k_ls_set_params, dim3(1), dim3(SB), 0, traj->eng->stream, policy->d_params, traj->prev_params,
-                     traj->descent, (uint32_t)policy->P, (float)ratio, traj->trpo, comm_err_word(traj->eng));
+                     traj->descent, (uint32_t)policy->P, (float)ratio, traj->trpo, comm_err_word(traj->eng),
+                     wimg_if_current(policy), (int)policy->out_dim);
+}
+
+// ---------------------------------------------------------------- the weight image (bf16_tile.hpp)
+const uint32_t *wimg_ensure(const rl_mlp *m) {
+  rl_engine *e = m->eng;
+  if (m->d_wimg == nullptr) {
+    RL_HIP_CHECK(hipSetDevice(e->device));
+    void *p = nullptr;
+    RL_HIP_CHECK(hipMalloc(&p, (size_t)bt::WIMG_WORDS * sizeof(uint32_t)));
+    m->d_wimg = static_cast<uint32_t *>(p);
+    m->wimg_epoch = 0;
+  }
+  if (m->wimg_epoch != e->call_epoch) {
+    ProfScope ps(e, RL_K_SMALL);
+    hipLaunchKernelGGL(k_wimg_build, dim3(((uint32_t)m->P + SB - 1) / SB), dim3(SB), 0, e->stream, m->d_params,
+                       (uint32_t)m->P, m->d_wimg, (int)m->out_dim);
+    m->wimg_epoch = e->call_epoch;
+  }
+  return m->d_wimg;
 }
 
 void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, double ratio, double max_kl) {
@@ -660,6 +702,7 @@ void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept
   ProfScope ps(traj->eng, RL_K_SMALL);
   hipLaunchKernelGGL(k_ls_finalize, dim3(1), dim3(SB), 0, traj->eng->stream, policy->d_params, traj->prev_params,
                      (uint32_t)policy->P, max_kl, accept_violation, traj->trpo, comm_err_word(traj->eng));
+  wimg_invalidate(policy);  // (a rollback rewrites the parameters without the image)
 }
 
 // bias corrections of the optimiser's NEXT step (advances the host's step count)
@@ -685,12 +728,14 @@ void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t ro
     hipLaunchKernelGGL(k_reduce_adam<true>, dim3(cdiv(P + 4, 64)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
                        traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                        opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
-                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, peers);
+                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, peers, wimg_if_current(opt->mod),
+                       (int)opt->mod->out_dim);
   } else {
     hipLaunchKernelGGL(k_reduce_adam<false>, dim3(cdiv(P + 4, 64)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
                        traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                        opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
-                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, IpcPeers{});
+                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, IpcPeers{}, wimg_if_current(opt->mod),
+                       (int)opt->mod->out_dim);
   }
 }
 
@@ -702,7 +747,8 @@ void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_tot
   hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, traj->eng->stream, opt->mod->d_params, traj->vec, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, traj->vec + P, 1.0 / (double)B_total,
-                     loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr, comm_err_word(traj->eng));
+                     loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr, comm_err_word(traj->eng),
+                     wimg_if_current(opt->mod), (int)opt->mod->out_dim);
 }
 
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
@@ -713,5 +759,5 @@ void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
   hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr,
-                     (const int32_t *)nullptr);
+                     (const int32_t *)nullptr, wimg_if_current(opt->mod), (int)opt->mod->out_dim);
 }

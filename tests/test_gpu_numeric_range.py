@@ -179,34 +179,79 @@ def test_rollout_histories_are_measured_again_every_period(engine):
     assert np.all(np.isfinite(gc))
 
 
-def test_dqn_update_checks_its_weights_against_the_fixed_observation_bounds(engine):
-    """rl_dqn_update's fused step sees CartPole-generated observations only, so its guard takes fixed bounds for them
-    (2^-64 <= |obs| <= 2^16) and checks the action-value network's weights: a network whose layer-1 rows could carry a
-    pre-activation past 2^31 is refused, the default initialisation passes, and variant 1 trains the large one."""
-    def agent(w1_scale):
+def test_dqn_update_checks_its_weights_against_the_measured_observation_range(engine):
+    """rl_dqn_update's fused step: the collection kernel folds the magnitude range of every observation it puts into the
+    replay store into the workspace's range words (rounds 3-5 kept fixed bounds 2^-64 .. 2^16 there, under which a zero
+    bias could never pass: ADVICE round 5), and the guard checks the action-value network's weights against it.  The default
+    initialisation passes; a network with a ZERO bias vector — `bias_init: Some(Initializer::Zeros)`, a legal reference
+    configuration (src/torch/modules/ff/linear.rs:13-33) — passes and trains like the oracle's f32 network; a network
+    whose layer-1 rows could carry a pre-activation past 2^31 is refused with the parameters and the optimiser state put
+    back as they were (all or nothing), and variant 1 trains that one."""
+    def agent(w1_scale, zero_bias=False):
         env = ra.CartPoleEnv(engine, 256, max_steps=60, seed_env=9, seed_actor=10)
         q = ra.Mlp(engine, 5, H, 2)
         q.init(77)
         p = q.get_params()
         p[:5 * H] *= np.float32(w1_scale)
         p[6 * H:] *= np.float32(1.0 / w1_scale)
+        if zero_bias:
+            p[5 * H:6 * H] = 0.0
         q.set_params(p)
         cfg = ra.dqn_config_default()
         cfg.exploration_kind, cfg.exploration_start = ra.SCHEDULE_CONSTANT, 0.5
         cfg.minibatch_steps, cfg.opt_steps_per_update, cfg.buffer_capacity = 2000, 3, 128
         dqn = ra.Dqn(env, q, ra.Adam(q), cfg)
         dqn.collect(60)
-        return dqn
+        return dqn, q
 
-    st, losses = agent(1.0).update(want_losses=True)
+    st, losses = agent(1.0)[0].update(want_losses=True)
     assert st.opt_steps == 3 and np.all(np.isfinite(losses))
-    big = agent(1e5)  # 5 x ~2e4 x 2^16 = 6.6e9 >= 2^31
+    # zero bias: passes the guard (CartPole's observations are nowhere near 2^-46 / max|w|), and the fused step computes
+    # what variant 1's plain f32 kernels compute on the same minibatches
+    zb, qz = agent(1.0, zero_bias=True)
+    st, losses = zb.update(want_losses=True)
+    assert st.opt_steps == 3 and np.all(np.isfinite(losses)) and np.mean(qz.get_params()[5 * H:6 * H] != 0.0) > 0.5
+    engine.set_kernel_variant(1)
+    try:
+        zb1, qz1 = agent(1.0, zero_bias=True)
+        st1, losses1 = zb1.update(want_losses=True)
+    finally:
+        engine.set_kernel_variant(0)
+    # (Adam turns a rounding-level difference of a near-zero gradient entry into a step of the order of the learning rate:
+    # losses to 1e-5, parameters entry by entry for all but a few)
+    assert np.allclose(losses, losses1, rtol=1e-5)
+    assert np.mean(np.abs(qz.get_params() - qz1.get_params()) < 2e-5) > 0.97
+    # rows of ~2e8: 5 x 2e8 x max|obs| (a few units) >= 2^31
+    big, qb = agent(1e9)
+    before = qb.get_params()
     with pytest.raises(ra.RelearnError) as err:
         big.update()
     assert err.value.code == ra.ERR_UNSUPPORTED and "numeric range" in str(err.value)
+    assert np.array_equal(qb.get_params(), before)  # nothing of the refused update stays
     engine.set_kernel_variant(1)
     try:
-        st, losses = agent(1e5).update(want_losses=True)
+        st, losses = agent(1e9)[0].update(want_losses=True)
     finally:
         engine.set_kernel_variant(0)
     assert st.opt_steps == 3 and np.all(np.isfinite(losses))
+
+
+def test_critic_update_without_statistics_still_reports_the_range_error(engine):
+    """rl_critic_update / rl_values_opt_update with stats == NULL and losses == NULL used to skip the guard's error word and
+    leave the guard disarmed for every later call of that kind: the call itself must return
+    RL_ERR_UNSUPPORTED, and the next call on a history inside the range must work"""
+    import ctypes as C
+    c = OUT_OF_RANGE["overflow"]
+    pol, cri = modules(engine, c.get("w1_scale", 1.0), c.get("w2_scale", 1.0))
+    traj = load(engine, history(c["scales"]))
+    opt = ra.Adam(cri)
+    code = ra.lib().rl_critic_update(cri.h, opt.h, traj.h, C.c_uint64(2), None, None)
+    assert code == ra.ERR_UNSUPPORTED
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update = 2
+    assert ra.lib().rl_values_opt_update(cri.h, opt.h, traj.h, C.byref(ccfg), None, None) == ra.ERR_UNSUPPORTED
+    pol2, cri2 = modules(engine)
+    ok = load(engine, history([1.0] * 5, seed=1))
+    assert ra.lib().rl_critic_update(cri2.h, ra.Adam(cri2).h, ok.h, C.c_uint64(2), None, None) == ra.OK
+    # (and the guard is armed again: the out-of-range history is still refused by a call that asks for nothing)
+    assert ra.lib().rl_critic_update(cri.h, opt.h, traj.h, C.c_uint64(1), None, None) == ra.ERR_UNSUPPORTED

@@ -683,3 +683,77 @@ def test_rccl_call_path_single_rank():
     assert results[0][2] == results[1][2] and results[0][3] == results[1][3]
     assert np.array_equal(results[0][4], results[1][4]) and np.array_equal(results[0][5], results[1][5])
     assert results[0][6] == results[1][6] and results[0][7] == results[1][7]
+
+
+# ---------------------------------------------------------------- round 6: the weight image and the shared return plane
+def test_weight_image_kept_by_the_parameter_writers_equals_a_fresh_one(engine):
+    """The fused kernels read their weight pieces from the module's weight image (relearn_amd/csrc/bf16_tile.hpp): built
+    by the first fused launch of a C-ABI call, then kept current by the kernels that write the parameters (k_reduce_adam
+    for the critic, k_ls_set_params for the line search's candidates).  A K-step critic update in ONE call (steps 2..K
+    read the image k_reduce_adam left) must equal K one-step calls (every call rebuilds the image from the flat vector)
+    bit for bit; and the loss / KL the line search accepted (evaluated on an image k_ls_set_params wrote) must be the
+    numbers rl_policy_loss_kl computes for the same two parameter vectors from images built from scratch."""
+    n, T, K = 2048, 32, 6
+    env = ra.CartPoleEnv(engine, n, max_steps=60, seed_env=31, seed_actor=32)
+    pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+    pol.init(2)
+    cri.init(3)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.99, 0.95)
+    c0 = cri.get_params()
+    opt = ra.Adam(cri)
+    st, losses = ra.critic_update(cri, opt, traj, K, want_losses=True)
+    one_call = cri.get_params()
+    cri.set_params(c0)
+    opt2 = ra.Adam(cri)
+    step_losses = []
+    for _ in range(K):
+        _, l1 = ra.critic_update(cri, opt2, traj, 1, want_losses=True)
+        step_losses.append(l1[0])
+    assert np.array_equal(one_call, cri.get_params())
+    assert np.array_equal(losses, np.asarray(step_losses, dtype=np.float32))
+    p0 = pol.get_params()
+    pst = ra.trpo_update(pol, traj)
+    assert pst.status == ra.OPT_OK and pst.num_backtracks >= 0
+    loss, kl = ra.policy_loss_kl(pol, traj, p0)
+    assert np.float32(pst.loss_final) == np.float32(loss) and np.float32(pst.constraint_val_final) == np.float32(kl)
+
+
+def test_reward_to_go_targets_come_from_the_advantage_scan_only_when_they_are_the_same_numbers(engine):
+    """RewardToGo value targets (critics/mod.rs:101-105, 203-229) at the discount factor of the advantage pass are the
+    return plane rl_gae has just written — the critic update regresses on it without a second scan; at another discount
+    factor, or after the rewards were rewritten, they are scanned afresh.  Either way they equal the oracle's."""
+    n, T = 512, 40
+    env = ra.CartPoleEnv(engine, n, max_steps=25, seed_env=41, seed_actor=42)
+    pol, cri = ra.Mlp(engine, 5, H, 2), ra.Mlp(engine, 5, H, 1)
+    pol.init(2)
+    cri.init(3)
+    traj = ra.Trajectory(engine, n, T, 5)
+    ra.rollout(env, pol, traj)
+    ra.gae(traj, cri, 0.97, 0.95)
+    tr = traj.read_all()
+
+    def oracle_rtg(reward, flag, gamma):
+        out = np.zeros_like(reward)
+        nxt = np.zeros(reward.shape[1], dtype=np.float32)
+        for t in range(reward.shape[0] - 1, -1, -1):
+            ends = (flag[t] != ra.SUCC_CONTINUE) | (t == reward.shape[0] - 1)
+            g = np.where(ends, reward[t], reward[t] + (nxt * np.float32(gamma)).astype(np.float32)).astype(np.float32)
+            out[t] = g
+            nxt = g
+        return out
+
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update = 1
+    for gamma in (0.97, 0.99):  # the scan's own factor (shared plane), then another one (own scan)
+        ccfg.discount_factor = gamma
+        ra.values_opt_update(cri, ra.Adam(cri), traj, ccfg)
+        assert np.array_equal(traj.read(ra.TRAJ_TARGETS), oracle_rtg(tr["reward"], tr["flag"], gamma)), gamma
+    assert np.array_equal(traj.read(ra.TRAJ_RETURNS), oracle_rtg(tr["reward"], tr["flag"], 0.97))
+    # rewards rewritten by the host: the return plane no longer vouches for anything
+    reward2 = (tr["reward"] * np.float32(0.5)).astype(np.float32)
+    traj.write(ra.TRAJ_REWARD, reward2)
+    ccfg.discount_factor = 0.97
+    ra.values_opt_update(cri, ra.Adam(cri), traj, ccfg)
+    assert np.array_equal(traj.read(ra.TRAJ_TARGETS), oracle_rtg(reward2, tr["flag"], 0.97))
