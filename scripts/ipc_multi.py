@@ -24,8 +24,9 @@ def wait_for(paths, what, limit=180.0):
         time.sleep(0.02)
 
 
-def config4_rank(eng, rank, world, n_total, T, critic_steps, periods):
-    """the bench's period on this rank's lanes; returns what the 1-rank / N-rank comparison needs"""
+def config4_rank(eng, rank, world, n_total, T, critic_steps, periods, save_obs=False):
+    """the bench's period on this rank's lanes; returns what the 1-rank / N-rank comparison needs (`save_obs`: also the
+    observation planes of the first period — 169 MB at the full size, asked of the one-rank run only)"""
     n = n_total // world
     env = ra.CartPoleEnv(eng, n, max_steps=500, lane_offset=rank * n, seed_env=0, seed_actor=1)
     pol, cri = ra.Mlp(eng, 5, 128, 2), ra.Mlp(eng, 5, 128, 1)
@@ -35,7 +36,7 @@ def config4_rank(eng, rank, world, n_total, T, critic_steps, periods):
     traj = ra.Trajectory(eng, n, T, 5)
     ccfg = ra.values_opt_config_default()
     ccfg.opt_steps_per_update = critic_steps
-    out = {}
+    out = {"policy_init": pol.get_params()}
     eng.profile_enable(True)
     for period in range(periods):
         ra.rollout(env, pol, traj)
@@ -43,11 +44,13 @@ def config4_rank(eng, rank, world, n_total, T, critic_steps, periods):
         if period == 0:
             out["action"], out["flag"] = traj.read(ra.TRAJ_ACTION), traj.read(ra.TRAJ_FLAG)
             out["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
+            if save_obs:
+                out["obs"] = traj.read(ra.TRAJ_OBS)
         st, cs, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
         out["policy%d" % period], out["critic%d" % period] = pol.get_params(), cri.get_params()
         out["losses%d" % period] = losses
         out["trpo%d" % period] = np.array([st.loss_initial, st.entropy, st.step_size, st.cg_iterations, st.status,
-                                           st.num_backtracks])
+                                           st.num_backtracks, st.step_scale, st.loss_final, st.constraint_val_final])
     eng.sync()
     out["allreduce_launches"] = np.array([eng.profile_read()["allreduce"][1]])
     return out

@@ -85,7 +85,7 @@ pol.init(2)
 cri.init(3)
 opt = ra.Adam(cri)
 traj = ra.Trajectory(eng, n, T, 5)
-out = {}
+out = {"policy_init": pol.get_params(), "critic_init": cri.get_params()}
 eng.profile_enable(True)
 for period in range(2):
     ra.rollout(env, pol, traj)
@@ -93,6 +93,9 @@ for period in range(2):
     if period == 0:
         out["action"] = traj.read(ra.TRAJ_ACTION)
         out["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
+        # (what the oracle-based bars of tests/test_gpu_multirank.py need: the samples and the critic's targets)
+        out["obs"], out["flag"], out["reward"] = traj.read(ra.TRAJ_OBS), traj.read(ra.TRAJ_FLAG), traj.read(ra.TRAJ_REWARD)
+        out["rtg"] = traj.read(ra.TRAJ_RETURNS)
     if period == 0:
         st = ra.trpo_update(pol, traj)
         cs, losses = ra.critic_update(cri, opt, traj, 6, want_losses=True)
@@ -103,7 +106,8 @@ for period in range(2):
     out["policy%d" % period] = pol.get_params()
     out["critic%d" % period] = cri.get_params()
     out["losses%d" % period] = losses
-    out["trpo%d" % period] = np.array([st.loss_initial, st.entropy, st.step_size, st.cg_iterations, st.status])
+    out["trpo%d" % period] = np.array([st.loss_initial, st.entropy, st.step_size, st.cg_iterations, st.status,
+                                       st.loss_final, st.constraint_val_final, st.step_scale, st.num_backtracks])
 eng.sync()
 out["allreduce_launches"] = np.array([eng.profile_read()["allreduce"][1]])
 np.savez(os.path.join(d, "out%d_of_%d.npz" % (rank, world)), **out)
