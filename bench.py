@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-PMC_SUMMARY = "r05_pmc_65536_summary.json"  # profiles/: counter passes of the build named inside (scripts/pmc_summary.py)
+PMC_SUMMARY = "r06_pmc_65536_summary.json"  # profiles/: counter passes of the build named inside (scripts/pmc_summary.py)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 MFMA peak = f32 vector peak
 BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak

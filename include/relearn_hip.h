@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define RL_ABI_VERSION 5
+/* Incremented whenever an entry point is added or removed, an argument list or a struct layout changes, or a status code
+ * is renumbered: a binding checks rl_abi_version() against the value it was generated from.  6 (round 6): covers the two
+ * entry points round 5 added under the old number (rl_actor_critic_update_begin / _finish); nothing was added since. */
+#define RL_ABI_VERSION 6
 
 /* ---------------------------------------------------------------------------------------------
  * Status codes.  The non-generic ones mirror the reference's error enums:

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     missing = [s for s in decl if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(ra.ABI_SYMBOLS) == decl, set(ra.ABI_SYMBOLS) ^ set(decl)
-    assert lib.rl_abi_version() == 5
+    assert lib.rl_abi_version() == 6
 
 
 def test_every_entry_point_cites_the_reference():
