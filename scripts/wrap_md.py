@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Re-flow the project's Markdown documents to at most WIDTH columns so that their diffs are reviewable.
 
-  * prose lines longer than WIDTH are broken at spaces; continuation lines are indented under the text of the list
-    item (or under the paragraph's own indent), which Markdown joins back into the same paragraph;
+  * every paragraph and list item is re-flowed as a whole (its lines joined, then broken at spaces); continuation lines
+    are indented under the text of the list item (or under the paragraph's own indent), which Markdown reads as the same
+    paragraph;
   * a table with a row longer than WIDTH cannot be wrapped (a row is one line), so it becomes a list: one item per row
     headed by its first cell, one sub-item per further column labelled with the column's header;
   * fenced code blocks, headings and tables that fit are left alone.
@@ -31,8 +32,18 @@ def greedy(words, first, hang):
         elif width(cur) + 1 + width(w) <= WIDTH:
             cur += " " + w
         else:
+            # a continuation line must not begin with something Markdown reads as a block start (a list marker, a heading,
+            # a table row, a quote): the previous word comes down with it
+            def risky(x):
+                return x in ("-", "*", "+", ">") or re.match(r"^\d+[.)]$", x) is not None or x[:1] in ("#", "|", ">")
+
+            lead = len(first) if not out else len(hang)
+            down = w
+            while risky(down.split(" ", 1)[0]) and " " in cur[lead:]:
+                cur, last = cur.rsplit(" ", 1)
+                down = last + " " + down
             out.append(cur)
-            cur = hang + w
+            cur = hang + down
     out.append(cur)
     return out
 
@@ -128,8 +139,24 @@ def reflow(text):
                 out += rows
             i = j
             continue
-        out += wrap_line(line)
-        i += 1
+        if line.strip() == "":
+            out.append(line)
+            i += 1
+            continue
+        # a paragraph or list item: this line and the plain lines that continue it, re-flowed as one
+        j = i + 1
+        hard_break = line.endswith("  ")
+        while (not hard_break and j < len(lines) and lines[j].strip() != "" and not LIST.match(lines[j])
+               and not lines[j].lstrip().startswith(("#", "|", "```", ">"))):
+            hard_break = lines[j].endswith("  ")
+            j += 1
+        m = LIST.match(line)
+        first = m.group(0) if m else re.match(r"^\s*", line).group(0)
+        hang = " " * len(first) if m else first
+        text = " ".join([line[len(first):].strip()] + [ln.strip() for ln in lines[i + 1:j]])
+        words = [w for w in text.split(" ") if w != ""]
+        out += greedy(words, first, hang) if words else [line]
+        i = j
     return "\n".join(out)
 
 
