@@ -79,7 +79,7 @@ if k_n:
     mb = out["minibatch_steps"]
     us = 1e3 * k_ms / k_n
     flop, alg_bytes = 5376.0 * mb, 25.0 * mb
-    kernels, src = ru.pmc_kernels("r05_pmc_dqn_summary.json")
+    kernels, src = ru.pmc_kernels("r06_pmc_dqn_summary.json")
     traffic, _ = ru.traffic_of(kernels if src["applies"] else {}, {"k_dqn_step_bf16": 1.0})
     ach = flop / (us * 1e-6) / 1e12
     out["roofline"] = {

@@ -77,7 +77,7 @@ import roofline_util as ru  # noqa: E402
 plane = 4.0 * 128 * steps
 accounted = 24.0 * plane
 alg_bytes = (5 * 4 + 1 + 4 + 1) * steps
-kernels, src = ru.pmc_kernels("r05_pmc_gru_config5_summary.json")
+kernels, src = ru.pmc_kernels("r06_pmc_gru_config5_summary.json")
 traffic, found = ru.traffic_of(kernels if src["applies"] else {}, {
     "k_gru_recur_fwd": 1.0, "k_seq_head_forward<1>": 80.0 / n_grad, "k_seq_head_forward<2>": 10.0 / n_grad,
     "k_gru_head_backward<1>": 80.0 / n_grad, "k_gru_head_backward<2>": 10.0 / n_grad, "k_gru_recur_bwd": 1.0,
