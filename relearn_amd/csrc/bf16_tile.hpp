@@ -625,20 +625,41 @@ __device__ __forceinline__ void backward(const Frag (&ga)[NT][2], const Frag (&u
 __device__ __forceinline__ void flush(f32x16 (&dm)[NT], double *acc64, int stride, int n, int hf, bool first = false) {
   const bool owner = (n < 15 && (n % 3) == 0) || n == 16;
   const int k = n == 16 ? 5 : n / 3;
+  // -DRL_FLUSH_ADD_DPP (A/B build, round 6): the row shifts ride on the additions themselves (v_add_f32_dpp; the compiler
+  // keeps a v_mov_b32_dpp per shift when they are written with the builtin — 128 more vector instructions per flush, a
+  // quarter of it).  Inline asm, so the matrix instructions' results get their wait states by hand (no interlock, and the
+  // hazard recogniser does not look into asm): one statement that names all accumulator tiles and idles 20 cycles comes
+  // first, every addition after it in program order through its operand.  Measured: the flush of a wave goes from 1.94
+  // to 1.75 us (profiles/r06_critic_step_timeline.txt), the critic chain per step stays where it was at 4,096 / 8,192 /
+  // 65,536 lanes (three runs each on one box, to the microsecond) — the default keeps the compiler-scheduled form.
+#ifdef RL_FLUSH_ADD_DPP
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(dm[0]), "+v"(dm[1]), "+v"(dm[2]), "+v"(dm[3]));
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     float tot[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      // row_shl:1 / row_shl:2: lane i reads lane i + 1 / i + 2 of its 16-lane row (0 past the end of the row);
+      // tot = (v + v1) + v2 in this order (float addition commutes bit for bit: the shifted operand is source 0)
+#ifdef RL_FLUSH_ADD_DPP
+      float sum;
+      asm("v_add_f32_dpp %0, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+          : "=&v"(sum)
+          : "v"(dm[t][r]));
+      tot[r] = sum;
+#else  // (default: the shifts as v_mov_b32_dpp)
       const float v = dm[t][r];
-      // row_shl:1 / row_shl:2: lane i reads lane i + 1 / i + 2 of its 16-lane row (0 past the end of the row)
       const float v1 = __builtin_bit_cast(
           float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
       const float v2 = __builtin_bit_cast(
           float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102, 0xf, 0xf, true));
       tot[r] = (v + v1) + v2;
-      dm[t][r] = 0.0f;
+#endif
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dm[t][r] = 0.0f;
     if (owner && first) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
