@@ -43,6 +43,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NT = 4;     // 32-unit hidden tiles (H = 128)
+// How the fused kernels with two waves per SIMD deal their tiles (round 6).  The older wave of a SIMD (waves 0-3 of an
+// eight-wave workgroup) wins the issue arbitration: dealt evenly, it finished its tiles at 0.71 of the launch and the
+// younger wave ran the rest alone, with nothing to overlap its matrix instructions with.  An older wave now plays
+// SHARE_OLD virtual waves, a younger one SHARE_YOUNG; 5 : 3 lets both finish within 8 us of each other at the headline
+// size and keeps the tile counts integral at every power-of-two lane count (9:7, 12:7, 7:4, 16:9, 9:5, 11:6, 2:1, 7:3, 3:1
+// measured: none better; profiles/r06_critic_step_timeline.txt).  RL_CRITIC_SHARES=a:b overrides at run time.
+constexpr uint32_t SHARE_OLD = 5, SHARE_YOUNG = 3;
 constexpr int COLS = 19;  // piece columns of the backward: pcol(k) + p, k = input feature (5 = bias), p = piece; the three
                           // pieces of a feature stay inside one 16-lane row (column 15 is unused), so the flush adds them
                           // with row shifts

@@ -39,6 +39,7 @@ constexpr int C_FLUSH = 64;                     // f32 -> f64 flush period in ti
 // ~7 us a launch costs beyond its tiles go)
 #ifdef RL_CRITIC_TIMESTAMPS
 __device__ uint64_t g_critic_ts[1024 * 8];
+__device__ uint64_t g_critic_wave_end[1024 * 8];  // when each wave of a workgroup has finished its tiles
 #define RL_TS(k)                                                                                   \
   do {                                                                                             \
     if (threadIdx.x == 0) g_critic_ts[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();    \
@@ -49,7 +50,8 @@ __device__ uint64_t g_critic_ts[1024 * 8];
 
 __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, const uint32_t *__restrict__ wimg,
-                       double *__restrict__ slabA, double *__restrict__ slabB, float two_over_B, uint32_t P) {
+                       double *__restrict__ slabA, double *__restrict__ slabB, float two_over_B, uint32_t P,
+                       uint32_t share_old, uint32_t share_young) {
   constexpr int D = 5, H = 128, NT = bt::NT;
   constexpr int IMG = H * 7 + 2;  // per hidden unit: M[0..5] (slot 6 unused); then db2, loss
 #ifndef RL_CRITIC_Y_IN_REGISTERS
@@ -113,7 +115,17 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   // offset as the scalar operand: no vector address arithmetic per tile.
   const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
   const uint32_t n_full = B32 / 32u, tail = B32 & 31u;
-  const uint32_t wave_id = blockIdx.x * CRITIC_WAVES + (uint32_t)wave, n_waves = gridDim.x * CRITIC_WAVES;
+  // The two waves of a SIMD do not progress alike: the older one (waves 0-3 of the workgroup, launched first) wins the
+  // issue arbitration and used to finish its tiles at 0.71 of the launch, leaving the younger one alone — one wave per
+  // SIMD, nothing to overlap its matrix instructions with — for the rest (profiles/r06_critic_step_timeline.txt).  So the
+  // tiles are not dealt evenly: an older wave plays `share_old` virtual waves, a younger one `share_young`, and both
+  // finish together.  (Virtual wave ids: workgroup-major, the older waves' first.)
+  const uint32_t per_wg = (CRITIC_WAVES / 2) * (share_old + share_young);
+  const uint32_t my_share = wave < CRITIC_WAVES / 2 ? share_old : share_young;
+  const uint32_t my_first = blockIdx.x * per_wg + (wave < CRITIC_WAVES / 2 ? (uint32_t)wave * share_old
+                                                   : (CRITIC_WAVES / 2) * share_old +
+                                                         (uint32_t)(wave - CRITIC_WAVES / 2) * share_young);
+  const uint32_t n_waves = gridDim.x * per_wg;  // virtual waves of the launch
   const bt::rsrc_t obs_r = bt::make_rsrc(tr.obs, (uint32_t)D * plane32 * 4u), tgt_r = bt::make_rsrc(tr.tgt, B32 * 4u);
   const uint32_t off_a = ((uint32_t)(2 * hf) * plane32 + (uint32_t)n) * 4u, off_b = off_a + plane32 * 4u;
   const uint32_t off_c = (4u * plane32 + (uint32_t)n) * 4u, off_t = (uint32_t)n * 4u;
@@ -214,7 +226,9 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     }
   };
 
-  if (wave_id < n_full) {
+  for (uint32_t vw = 0; vw < my_share; ++vw) {
+   const uint32_t wave_id = my_first + vw;
+   if (wave_id < n_full) {
     // global loads run one tile ahead (past the wave's last tile: that tile again), into two named buffers that take
     // turns — no register moves.  (Two tiles ahead — by register moves or by rotating three named buffers through a
     // loop unrolled three times — is SLOWER, 0.237 against 0.220 ms per step, although a timing build without the loads
@@ -232,9 +246,13 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
       op_a = load_tile(g2 < n_full ? g2 : g1);
       tile(std::false_type{}, op_b);
     }
+   }
+   if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full));
   }
-  if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full));
   RL_TS(3);
+#ifdef RL_CRITIC_TIMESTAMPS
+  if (lane == 0) g_critic_wave_end[blockIdx.x * 8 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (since_flush != 0 || !flushed) {  // (a wave whose tile count is a multiple of the flush period has nothing left: at
                                        // the headline size every wave owns exactly 2 x C_FLUSH tiles, and this was a
                                        // third flush of zeros; a wave without tiles still defines its image)
@@ -313,11 +331,18 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   if (nb > cus) nb = cus;
   traj->nbC = (uint32_t)nb;
   traj->last_rows = traj->nbC;
+  // shares of the tiles for the older / the younger wave of a SIMD (the kernel says why); RL_CRITIC_SHARES=a:b overrides
+  uint32_t share_old = bt::SHARE_OLD, share_young = bt::SHARE_YOUNG;
+  if (const char *sh = std::getenv("RL_CRITIC_SHARES")) {
+    unsigned a = 0, b = 0;
+    if (std::sscanf(sh, "%u:%u", &a, &b) == 2 && a >= 1 && b >= 1 && a <= 64 && b <= 64) share_old = a, share_young = b;
+  }
   TrajDev d = traj->d;
   if (!traj->guard_next_critic) d.range = nullptr;  // (the range guard: first critic launch of the call only, engine.hpp)
   traj->guard_next_critic = false;
   hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, d,
-                     critic->d_params, wimg, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P);
+                     critic->d_params, wimg, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P, share_old,
+                     share_young);
 #ifdef RL_CRITIC_TIMESTAMPS
   if (std::getenv("RL_CRITIC_TS_PRINT")) {
     static int calls = 0;
@@ -330,6 +355,16 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
         for (int k = 0; k < 7; ++k) sum[k] += (double)(h[b * 8 + k] - h[b * 8]) * 0.01;
         first = std::min(first, (double)h[b * 8] * 0.01);
         last = std::max(last, (double)h[b * 8 + 6] * 0.01);
+      }
+      {
+        std::vector<uint64_t> we(1024 * 8);
+        (void)hipMemcpyFromSymbol(we.data(), HIP_SYMBOL(g_critic_wave_end), we.size() * 8);
+        double per[8] = {0};
+        for (uint32_t b = 0; b < traj->nbC; ++b)
+          for (int w = 0; w < 8; ++w) per[w] += (double)(we[b * 8 + w] - h[b * 8]) * 0.01;
+        std::fprintf(stderr, "critic ts: tiles of wave 0..7 done at (us, mean over workgroups):");
+        for (int w = 0; w < 8; ++w) std::fprintf(stderr, " %.1f", per[w] / traj->nbC);
+        std::fprintf(stderr, "\n");
       }
       std::fprintf(stderr, "critic ts (us from a workgroup's start, mean of %u): weights %.2f  first tile %.2f  loop end %.2f  "
                    "flushed %.2f  barrier %.2f  end %.2f | first start to last end %.2f\n", traj->nbC,

@@ -3,6 +3,8 @@
 // kernels_critic.hip, the DQN gradient (two outputs, two backward channels) is k_dqn_step_bf16 in kernels_dqn.hip.
 // (Rounds 1-2 ran these passes on the f32 MFMA with the backward on the VALU; that kernel is gone — its last user was
 // the DQN gradient.)
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "bf16_tile.hpp"
@@ -38,8 +40,9 @@ constexpr int PB_FLUSH = 16;  // f32 -> f64 flush period in tiles (32 / 64: 2 % 
 template <int MODE, int WAVES, bool FW_LDS = false>
 __global__ void __launch_bounds__(WAVES * 64)
     k_policy_bf16(TrajDev tr, const float *__restrict__ params, const uint32_t *__restrict__ wimg,
-                  const float *__restrict__ tangent, float *__restrict__ lp0, double *__restrict__ slabA, double *__restrict__ slabB, float inv_B,
-                  uint32_t P, const int32_t *__restrict__ skip, float clip_lo, float clip_hi) {
+                  const float *__restrict__ tangent, float *__restrict__ lp0, double *__restrict__ slabA,
+                  double *__restrict__ slabB, float inv_B, uint32_t P, const int32_t *__restrict__ skip, float clip_lo,
+                  float clip_hi, uint32_t share_old, uint32_t share_young) {
   using bt::Frag;
   constexpr int D = 5, H = 128, NT = bt::NT, A = 2;
   constexpr bool BWD = MODE != PASS_EVAL;
@@ -153,7 +156,14 @@ __global__ void __launch_bounds__(WAVES * 64)
   // scalar operand: no vector address arithmetic per tile (kernels_critic.hip has the same loop).
   const uint32_t B32 = (uint32_t)B, plane32 = (uint32_t)plane;
   const uint32_t n_full = B32 / 32u, tail = B32 & 31u;
-  const uint32_t wave_id = blockIdx.x * WAVES + (uint32_t)wave, n_waves = gridDim.x * WAVES;
+  // (the tiles are dealt 5 : 3 between the older and the younger wave of a SIMD: bf16_tile.hpp SHARE_OLD; the
+  // sixteen-wave evaluation pass deals evenly — its launcher passes 1 : 1)
+  if (WAVES != 8) share_old = share_young = 1u;  // (compile-time for the sixteen-wave form: its loop below folds away)
+  const uint32_t per_wg = (WAVES / 2) * (share_old + share_young);
+  const uint32_t my_share = wave < WAVES / 2 ? share_old : share_young;
+  const uint32_t my_first = blockIdx.x * per_wg + (wave < WAVES / 2 ? (uint32_t)wave * share_old
+                                                   : (WAVES / 2) * share_old + (uint32_t)(wave - WAVES / 2) * share_young);
+  const uint32_t n_waves = gridDim.x * per_wg;  // virtual waves of the launch
   const bt::rsrc_t obs_r = bt::make_rsrc(tr.obs, (uint32_t)D * plane32 * 4u), lp0_r = bt::make_rsrc(lp0, 2u * B32 * 4u);
   const bt::rsrc_t adv_r = bt::make_rsrc(tr.adv, B32 * 4u), act_r = bt::make_rsrc(tr.action, B32);
   const uint32_t off_a = ((uint32_t)(2 * hf) * plane32 + (uint32_t)n) * 4u, off_b = off_a + plane32 * 4u;
@@ -320,7 +330,9 @@ __global__ void __launch_bounds__(WAVES * 64)
       fold();
     }
   };
-  if (wave_id < n_full) {
+  for (uint32_t vw = 0; vw < my_share; ++vw) {
+   const uint32_t wave_id = my_first + vw;
+   if (wave_id < n_full) {
     // loads run one tile ahead (past the wave's last tile: that tile again), into two named buffers that take turns
     // (the Fisher-vector pass has no registers for a second buffer: one buffer and a move per operand there)
     TileOp op_a = load_tile(wave_id), op_b = op_a;
@@ -341,8 +353,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         tile(std::false_type{}, op_b, g1);
       }
     }
+   }
+   if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full), n_full);
   }
-  if (tail != 0 && n_full % n_waves == wave_id) tile(std::true_type{}, load_tile(n_full), n_full);
   if (BWD && (since_flush != 0 || !flushed)) bt::flush(dm, acc64, IW, n, hf, !flushed);  // (nothing left when the last
                                                                 // tile ended a flush period; a wave without tiles
                                                                 // still defines its image)
@@ -431,12 +444,17 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
   dim3 g(traj->nbV2), b(V2_WAVES * 64);
   hipStream_t s = traj->eng->stream;
   uint32_t P = (uint32_t)policy->P;
+  uint32_t share_old = bt::SHARE_OLD, share_young = bt::SHARE_YOUNG;  // (RL_CRITIC_SHARES=a:b: A/B runs)
+  if (const char *sh = std::getenv("RL_CRITIC_SHARES")) {
+    unsigned a = 0, b2 = 0;
+    if (std::sscanf(sh, "%u:%u", &a, &b2) == 2 && a >= 1 && b2 >= 1 && a <= 64 && b2 <= 64) share_old = a, share_young = b2;
+  }
   TrajDev d = traj->d;
   if (!traj->guard_next_policy) d.range = nullptr;  // (the range guard: first policy launch of the call only, engine.hpp)
   traj->guard_next_policy = false;
 #define BLAUNCH(MM)                                                                                                  \
   hipLaunchKernelGGL((k_policy_bf16<MM, V2_WAVES>), g, b, 0, s, d, policy->d_params, wimg, d_tangent, traj->lp0,       \
-                     traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi)
+                     traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo, clip_hi, share_old, share_young)
   if (mode == PASS_INIT) BLAUNCH(PASS_INIT);
   else if (mode == PASS_JVP) BLAUNCH(PASS_JVP);
   else if (mode == PASS_PPO) BLAUNCH(PASS_PPO);
@@ -446,7 +464,7 @@ bool launch_policy_v2(rl_traj *traj, const rl_mlp *policy, int mode, const float
     constexpr int EVAL_WAVES = 16;
     hipLaunchKernelGGL((k_policy_bf16<PASS_EVAL, EVAL_WAVES, true>), g, dim3(EVAL_WAVES * 64), 0, s, d,
                        policy->d_params, wimg, d_tangent, traj->lp0, traj->slabA, traj->slabB, inv_B, P, d_skip, clip_lo,
-                       clip_hi);
+                       clip_hi, 1u, 1u);
   }
 #undef BLAUNCH
   return true;

@@ -15,4 +15,4 @@ ra.critic_update(cri, opt, traj, 3)
 eng.sync(); eng.timer_begin()
 st = ra.critic_update(cri, opt, traj, steps)
 ms = eng.timer_end()
-print("critic step: %.3f ms  (loss %.3f -> %.3f)" % (ms / steps, st.loss_first, st.loss_last))
+print("critic step: %.3f ms = %.2f us (loss %.3f -> %.3f)" % (ms / steps, 1e3 * ms / steps, st.loss_first, st.loss_last))
