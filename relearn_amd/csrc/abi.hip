@@ -113,11 +113,14 @@ void rccl_check(int rc, const char *what) {
 // driven by its own host thread).  It exists so that the multi-rank arithmetic — lane sharding by global lane id,
 // sample-weighted means over all ranks, identical redundant updates — can be exercised on a one-GPU box; the RCCL
 // call path itself is exercised with a one-rank communicator (RELEARN_FORCE_RCCL=1).
-__global__ void k_loopback_sum(float *const *bufs, int n_ranks, size_t count) {
+// (`bad_rank` >= 0: a test of the tests — that rank's vector enters the sum multiplied by `bad_weight`, what a rank that
+// weighs its samples by a wrong B_local / B_total contributes; every rank still receives the same sums, so the job runs
+// to its end and must FAIL the sharded parity bars: tests/test_gpu_multirank.py, RELEARN_LOOPBACK_TEST_WEIGHT)
+__global__ void k_loopback_sum(float *const *bufs, int n_ranks, size_t count, int bad_rank, float bad_weight) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  float s = bufs[0][i];
-  for (int r = 1; r < n_ranks; ++r) s = s + bufs[r][i];
+  float s = bad_rank == 0 ? bad_weight * bufs[0][i] : bufs[0][i];
+  for (int r = 1; r < n_ranks; ++r) s = s + (r == bad_rank ? bad_weight * bufs[r][i] : bufs[r][i]);
   for (int r = 0; r < n_ranks; ++r) bufs[r][i] = s;
 }
 
@@ -128,6 +131,8 @@ struct LoopbackGroup {
   uint64_t generation = 0;
   std::vector<float *> bufs;
   float **d_bufs = nullptr;
+  int bad_rank = -1;        // RELEARN_LOOPBACK_TEST_WEIGHT="rank:weight" when the group was made (k_loopback_sum)
+  float bad_weight = 1.0f;  // ... applied to the gradient-sized vectors only (the set-up's rank count stays a count)
   void barrier(std::unique_lock<std::mutex> &lk) {
     const uint64_t gen = generation;
     if (++arrived == n_ranks) {
@@ -152,7 +157,7 @@ static void loopback_allreduce(rl_engine *e, float *d_buf, size_t count) {
     RL_HIP_CHECK(hipMemcpyAsync(g->d_bufs, g->bufs.data(), g->n_ranks * sizeof(float *), hipMemcpyHostToDevice,
                                 e->stream));
     hipLaunchKernelGGL(k_loopback_sum, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, g->d_bufs,
-                       g->n_ranks, count);
+                       g->n_ranks, count, count > 64 ? g->bad_rank : -1, g->bad_weight);
     RL_HIP_CHECK(hipStreamSynchronize(e->stream));
   }
   g->barrier(lk);
@@ -443,6 +448,11 @@ int32_t rl_comm_init(rl_engine *e, int32_t rank, int32_t n_ranks, const uint8_t 
         grp->bufs.assign(n_ranks, nullptr);
         RL_HIP_CHECK(hipSetDevice(e->device));
         grp->d_bufs = dalloc<float *>(n_ranks);
+        if (const char *tw = std::getenv("RELEARN_LOOPBACK_TEST_WEIGHT")) {
+          int r = -1;
+          float w = 1.0f;
+          if (std::sscanf(tw, "%d:%f", &r, &w) == 2 && r >= 0 && r < n_ranks) grp->bad_rank = r, grp->bad_weight = w;
+        }
       }
       RL_REQUIRE(grp->n_ranks == n_ranks, "loopback group: inconsistent n_ranks");
       grp->joined += 1;

@@ -374,8 +374,15 @@ static void dqn_gradient(rl_dqn *q, rl_adam *step_opt = nullptr, int loss_slot =
   rl_traj *mb = q->mb;
   uint32_t P = (uint32_t)q->qnet->P;
   uint32_t rowsA, rowsB;
-  if (q->eng->kernel_variant == 0 &&
-      launch_dqn_step_bf16(mb, q->qnet, q->last_total_steps, q->td_in_kernel, q->cfg.discount_factor)) {
+  // targets given (reward-to-go, or one-step TD built beforehand): two critic-step channels per SIMD
+  // (kernels_critic.hip, k_critic_step_mfma<2>; RL_DQN_SINGLE_WAVE=1 keeps rounds 3-5's kernel for A/B runs); targets
+  // formed inside the launch (one-step TD on the current network): k_dqn_step_bf16
+  static const bool single_wave = std::getenv("RL_DQN_SINGLE_WAVE") != nullptr;
+  if (q->eng->kernel_variant == 0 && !q->td_in_kernel && !single_wave &&
+      launch_dqn_step_pair(mb, q->qnet, q->last_total_steps)) {
+    rowsA = rowsB = mb->nbV2;
+  } else if (q->eng->kernel_variant == 0 &&
+             launch_dqn_step_bf16(mb, q->qnet, q->last_total_steps, q->td_in_kernel, q->cfg.discount_factor)) {
     rowsA = rowsB = mb->nbV2;
   } else {
     launch_policy_pass(mb, q->qnet, PASS_DQN, nullptr, q->last_total_steps, nullptr);

@@ -93,6 +93,8 @@ void launch_dqn_build_all(rl_engine *eng, const ReplayDev &rp, uint32_t n_batche
                           float *d_target, size_t step_stride, float gamma, uint8_t *d_flag);
 void launch_replay_planes(rl_engine *eng, const ReplayDev &rp, int field, void *d_out);
 bool launch_dqn_step_bf16(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total, bool td_in_kernel, float gamma);
+// kernels_critic.hip: the same gradient (targets given, not in-kernel TD) as two critic-step channels per SIMD
+bool launch_dqn_step_pair(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total);
 void launch_dqn_build_minibatch(rl_engine *eng, const ReplayDev &rp, uint32_t n_eps, const uint32_t *d_lane,
                                 const uint32_t *d_start, const uint32_t *d_len, const uint32_t *d_off,
                                 float *d_obs, size_t out_plane, uint8_t *d_action, float *d_target, float gamma,

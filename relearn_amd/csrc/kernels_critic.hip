@@ -48,6 +48,16 @@ __device__ uint64_t g_critic_wave_end[1024 * 8];  // when each wave of a workgro
 #define RL_TS(k)
 #endif
 
+// CH = 1: the critic step (above).  CH = 2 (round 6): the DQN gradient — mean((Q(s)[a] - target)^2) of the 5-128-2
+// action-value MLP, dqn.rs:316-326 — as TWO critic steps side by side: the loss reaches the hidden layer through row a_s
+// of the output weights only, so channel c (waves 0-3: c = 0, waves 4-7: c = 1) is the critic step of the one-output
+// network (W1, b1, W2[c], b2[c]) over the samples with a_s = c, every other sample contributing zero.  Both channels walk
+// the same tiles (the forward is computed twice) — and the two waves of a SIMD, one of each channel, overlap each other's
+// matrix and vector work, which the one-wave-per-SIMD kernel of rounds 3-5 (two backward channels in one wave's whole
+// register file: k_dqn_step_bf16, still the kernel of the in-kernel TD targets) could not: 19.0 -> 11 us per launch.
+// The workgroup's row combines them: dW1[j][k] = W2[0][j] M_0[j][k] + W2[1][j] M_1[j][k] (db1 likewise),
+// dW2[c][j] = sum_k W~1[j][k] M_c[j][k], db2[c] = sum of channel c's dL/dy, the loss the sum of both channels'.
+template <int CH>
 __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     k_critic_step_mfma(TrajDev tr, const float *__restrict__ params, const uint32_t *__restrict__ wimg,
                        double *__restrict__ slabA, double *__restrict__ slabB, float two_over_B, uint32_t P,
@@ -63,7 +73,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: tile indices stay scalar
   const int n = lane & 31, hf = lane >> 5;
   const float *__restrict__ W1 = params, *__restrict__ b1 = W1 + H * D, *__restrict__ W2 = b1 + H;
-  const float b2 = W2[H];
+  const int chan = CH == 2 ? (wave >= CRITIC_WAVES / 2 ? 1 : 0) : 0;  // (wave-uniform) the output this wave differentiates
+  const float b2 = W2[CH * H + chan];
   const size_t B = (size_t)tr.T * tr.n;
   const size_t plane = (size_t)(tr.T + 1) * tr.n;
   double *acc64 = Acc[wave];
@@ -83,8 +94,8 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     bt::WRaw r;
-    bt::wimg_load(wimg, t, lane, fw[t], r, 1);
-    const float w2 = r.w2[0];
+    bt::wimg_load(wimg, t, lane, fw[t], r, CH);
+    const float w2 = CH == 2 && chan == 1 ? r.w2[1] : r.w2[0];
     lv[0] = __builtin_fmaf(w2, r.wa, lv[0]);
     lv[1] = __builtin_fmaf(w2, r.wb, lv[1]);
     lv[2] = __builtin_fmaf(w2, r.wc, lv[2]);
@@ -120,13 +131,18 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   // SIMD, nothing to overlap its matrix instructions with — for the rest (profiles/r06_critic_step_timeline.txt).  So the
   // tiles are not dealt evenly: an older wave plays `share_old` virtual waves, a younger one `share_young`, and both
   // finish together.  (Virtual wave ids: workgroup-major, the older waves' first.)
-  const uint32_t per_wg = (CRITIC_WAVES / 2) * (share_old + share_young);
+  // (CH = 2: the two channels walk the same tiles — wave w and wave w + 4 are one virtual wave)
+  if (CH == 2) share_old = share_young = 1u;
+  const uint32_t per_wg = CH == 2 ? (uint32_t)(CRITIC_WAVES / 2) : (CRITIC_WAVES / 2) * (share_old + share_young);
   const uint32_t my_share = wave < CRITIC_WAVES / 2 ? share_old : share_young;
-  const uint32_t my_first = blockIdx.x * per_wg + (wave < CRITIC_WAVES / 2 ? (uint32_t)wave * share_old
-                                                   : (CRITIC_WAVES / 2) * share_old +
-                                                         (uint32_t)(wave - CRITIC_WAVES / 2) * share_young);
+  const uint32_t my_first =
+      blockIdx.x * per_wg + (CH == 2 ? (uint32_t)(wave & (CRITIC_WAVES / 2 - 1))
+                                     : wave < CRITIC_WAVES / 2 ? (uint32_t)wave * share_old
+                                                               : (CRITIC_WAVES / 2) * share_old +
+                                                                     (uint32_t)(wave - CRITIC_WAVES / 2) * share_young);
   const uint32_t n_waves = gridDim.x * per_wg;  // virtual waves of the launch
   const bt::rsrc_t obs_r = bt::make_rsrc(tr.obs, (uint32_t)D * plane32 * 4u), tgt_r = bt::make_rsrc(tr.tgt, B32 * 4u);
+  const bt::rsrc_t act_r = bt::make_rsrc(tr.action, B32);  // (CH = 2 only: the action taken selects the channel)
   const uint32_t off_a = ((uint32_t)(2 * hf) * plane32 + (uint32_t)n) * 4u, off_b = off_a + plane32 * 4u;
   const uint32_t off_c = (4u * plane32 + (uint32_t)n) * 4u, off_t = (uint32_t)n * 4u;
   int since_flush = 0;
@@ -136,6 +152,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
   // per lane: features 2 hf, 2 hf + 1 and 4 of sample n, and its target
   struct TileOp {
     float xa, xb, xc, tgt;
+    uint32_t act;
   };
   auto load_tile = [&](uint32_t g) {  // g: wave-uniform tile index (< 2^25: the launcher bounds the element count)
     TileOp o;
@@ -144,6 +161,7 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     o.xb = bt::buf_f32(obs_r, off_b, soff);
     o.xc = bt::buf_f32(obs_r, off_c, soff);
     o.tgt = bt::buf_f32(tgt_r, off_t, soff);
+    o.act = CH == 2 ? bt::buf_u8(act_r, (uint32_t)n, g * 32u) : 0u;
     return o;
   };
 
@@ -203,8 +221,10 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     const float y = 0.5f * (abs_sum + (l0 + l1)) + b2;
 #endif
     const float d = y - op.tgt;
-    const float dy = valid ? d * two_over_B : 0.0f;
-    if (valid) {  // (both halves hold sample n and count it; the reduction after the loop reads half 0 only)
+    // (CH = 2: only the samples whose action is this wave's channel count — loss, db2 and the backward alike)
+    const bool mine = CH == 2 ? valid && op.act == (uint32_t)chan : valid;
+    const float dy = mine ? d * two_over_B : 0.0f;
+    if (mine) {  // (both halves hold sample n and count it; the reduction after the loop reads half 0 only)
       loss32 = __builtin_fmaf(d, d, loss32);
       db2_32 = db2_32 + dy;
     }
@@ -288,8 +308,31 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
       for (int w = 1; w < CRITIC_WAVES; ++w) s = s + Acc[w][src];
       return s;
     };
+    auto totc = [&](int c, int src) {  // CH = 2: the four waves of channel c
+      double s = Acc[4 * c][src];
+#pragma unroll
+      for (int w = 1; w < CRITIC_WAVES / 2; ++w) s = s + Acc[4 * c + w][src];
+      return s;
+    };
     double s;
-    if (p < (uint32_t)(H * D)) {
+    if (CH == 2) {
+      if (p < (uint32_t)(H * D)) {
+        const int j = p / D, k = p % D;
+        s = totc(0, j * 7 + k) * (double)W2[j] + totc(1, j * 7 + k) * (double)W2[H + j];
+      } else if (p < (uint32_t)(H * D + H)) {
+        const int j = p - H * D;
+        s = totc(0, j * 7 + 5) * (double)W2[j] + totc(1, j * 7 + 5) * (double)W2[H + j];
+      } else if (p < (uint32_t)(H * D + H + 2 * H)) {
+        const int q = p - H * D - H, c = q / H, j = q % H;
+        s = totc(c, j * 7 + 5) * (double)b1[j];
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += totc(c, j * 7 + k) * (double)W1[j * D + k];
+      } else if (p < P) {
+        s = totc((int)(p - (H * D + H + 2 * H)), H * 7);
+      } else {
+        s = tot(H * 7 + 1);
+      }
+    } else if (p < (uint32_t)(H * D)) {
       int j = p / D, k = p % D;
       s = tot(j * 7 + k) * (double)W2[j];
     } else if (p < (uint32_t)(H * D + H)) {
@@ -340,7 +383,7 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
   TrajDev d = traj->d;
   if (!traj->guard_next_critic) d.range = nullptr;  // (the range guard: first critic launch of the call only, engine.hpp)
   traj->guard_next_critic = false;
-  hipLaunchKernelGGL(k_critic_step_mfma, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, d,
+  hipLaunchKernelGGL(k_critic_step_mfma<1>, dim3(traj->nbC), dim3(CRITIC_WAVES * 64), 0, traj->eng->stream, d,
                      critic->d_params, wimg, traj->slabA, traj->slabB, two_over_B, (uint32_t)critic->P, share_old,
                      share_young);
 #ifdef RL_CRITIC_TIMESTAMPS
@@ -373,5 +416,26 @@ bool launch_critic_step_v2(rl_traj *traj, const rl_mlp *critic, uint64_t B_total
     }
   }
 #endif
+  return true;
+}
+
+// The DQN gradient of a 5-128-2 action-value network over the minibatch workspace `mb` (targets in `adv`, actions in
+// `action`): k_critic_step_mfma<2>.  False: shape not built (the caller has other kernels).
+bool launch_dqn_step_pair(rl_traj *mb, const rl_mlp *qnet, uint64_t B_total) {
+  if (mb->d.D != 5 || qnet->hidden != 128 || qnet->out_dim != 2 || qnet->general) return false;
+  if ((uint64_t)(mb->d.T + 1) * mb->d.n * 5 >= (1ull << 30)) return false;  // 32-bit element offsets in the kernel
+  const uint32_t *wimg = wimg_ensure(qnet);
+  ProfScope ps(mb->eng, RL_K_POLICY_FUSED);
+  const uint64_t n_tiles = (mb->B + 31) / 32, cus = (uint64_t)mb->eng->prop.multiProcessorCount;
+  uint64_t nb = (n_tiles + CRITIC_WAVES / 2 - 1) / (CRITIC_WAVES / 2);  // four tile-walking wave pairs per workgroup
+  if (nb > cus) nb = cus;
+  mb->nbV2 = (uint32_t)nb;  // slab rows of this launch (the slabs are sized for any grid up to 8 x CUs)
+  TrajDev d = mb->d;
+  d.tgt = mb->d.adv;  // (the minibatch workspace keeps its targets where a trajectory keeps advantages)
+  if (!mb->guard_next_policy) d.range = nullptr;  // (the range guard: first step of an update only, engine.hpp)
+  mb->guard_next_policy = false;
+  hipLaunchKernelGGL(k_critic_step_mfma<2>, dim3((uint32_t)nb), dim3(CRITIC_WAVES * 64), 0, mb->eng->stream, d,
+                     qnet->d_params, wimg, mb->slabA, mb->slabB, 2.0f / (float)B_total, (uint32_t)qnet->P, 1u, 1u);
+  RL_HIP_CHECK(hipGetLastError());
   return true;
 }

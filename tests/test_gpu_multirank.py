@@ -187,21 +187,29 @@ def test_sharded_ranks_equal_one_rank(world):
 
 
 def test_a_wrongly_weighted_shard_fails_the_sharded_parity_bars():
-    """The negative of the test above: the library weighs a rank's sums by B_local / B_total with
-    B_total = B_local x n_ranks — equal shards are its contract.  Two ranks with 384 and 128 lanes break it: every
-    sample of the small shard counts three times as much as one of the large shard.  The trajectories are still the
-    single rank's (lane ids are global) and the replicas still identical, but the update is not the single rank's
-    update, and the bars of check_sharded_update_against_the_oracles must say so."""
+    """The negative of the test above: one rank of two contributes its gradient-sized vectors —
+    the policy gradient, the Fisher-vector products, every critic gradient — with a wrong weight, what a wrong
+    B_local / B_total on that rank would do (RELEARN_LOOPBACK_TEST_WEIGHT = "1:1.5": the in-process collective multiplies
+    rank 1's vector by 1.5 before it sums; every rank still receives the same sums, so the job runs to its end).  The
+    trajectories are still the single rank's and the replicas still identical — and the update is not the single rank's
+    update: the bars of check_sharded_update_against_the_oracles must say so.  (Two ranks of unequal lane counts, the
+    first form of this test, break the library's contract in a way that lets their line searches disagree and the job
+    deadlock.)"""
     n_total, T = 512, 48
     single = launch(1, n_total, T, with_dqn=False)
-    skewed = launch(2, n_total, T, lanes=[384, 128], with_dqn=False)
+    os.environ["RELEARN_LOOPBACK_TEST_WEIGHT"] = "1:1.5"
+    try:
+        skewed = launch(2, n_total, T, with_dqn=False)
+    finally:
+        os.environ.pop("RELEARN_LOOPBACK_TEST_WEIGHT", None)
     assert np.array_equal(skewed[0][0]["policy"], skewed[1][0]["policy"])  # (identical, and identically wrong)
+    assert np.array_equal(np.concatenate([skewed[r][0]["adv"] for r in range(2)], axis=1), single[0][0]["adv"])
     with pytest.raises(AssertionError):
         check_sharded_update_against_the_oracles([skewed[0], skewed[1]], single[0])
-    # and it is the weighting that fails it, not the harness: the scalars alone are off by more than the bar
+    # a milder error on the critic's vectors only would still be caught by the per-step losses: here they are off by
+    # far more than the 1e-5 bar from the second step on (the first loss is computed before any wrong step is taken)
     a, b = skewed[0][0], single[0][0]
-    assert abs(a["trpo"]["loss_initial"] - b["trpo"]["loss_initial"]) > 1e-6 or \
-        np.max(np.abs(a["losses"] - b["losses"]) / b["losses"]) > 1e-5
+    assert np.max(np.abs(a["losses"][1:] - b["losses"][1:]) / b["losses"][1:]) > 1e-4
 
 
 def poisoned_torch(tmp_path):
