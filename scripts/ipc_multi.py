@@ -46,6 +46,13 @@ def config4_rank(eng, rank, world, n_total, T, critic_steps, periods, save_obs=F
             out["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
             if save_obs:
                 out["obs"] = traj.read(ra.TRAJ_OBS)
+            # every kind of all-reduced vector on its own, before anything is updated (collective calls; what
+            # tests/test_gpu_multirank.py::check_probe_vectors compares)
+            g, loss, ent = ra.policy_gradient(pol, traj)
+            v = np.random.default_rng(7).standard_normal(pol.P).astype(np.float32)
+            gc, lc = ra.critic_gradient(cri, traj)
+            out.update(probe_g=g, probe_loss=np.float64(loss), probe_ent=np.float64(ent),
+                       probe_hv=ra.policy_fvp(pol, traj, v, 0.0), probe_gc=gc, probe_lc=np.float64(lc))
         st, cs, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
         out["policy%d" % period], out["critic%d" % period] = pol.get_params(), cri.get_params()
         out["losses%d" % period] = losses

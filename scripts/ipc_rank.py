@@ -96,6 +96,11 @@ for period in range(2):
         # (what the oracle-based bars of tests/test_gpu_multirank.py need: the samples and the critic's targets)
         out["obs"], out["flag"], out["reward"] = traj.read(ra.TRAJ_OBS), traj.read(ra.TRAJ_FLAG), traj.read(ra.TRAJ_REWARD)
         out["rtg"] = traj.read(ra.TRAJ_RETURNS)
+        g, loss, ent = ra.policy_gradient(pol, traj)
+        v = np.random.default_rng(7).standard_normal(pol.P).astype(np.float32)
+        gc, lc = ra.critic_gradient(cri, traj)
+        out.update(probe_g=g, probe_loss=np.float64(loss), probe_ent=np.float64(ent),
+                   probe_hv=ra.policy_fvp(pol, traj, v, 0.0), probe_gc=gc, probe_lc=np.float64(lc))
     if period == 0:
         st = ra.trpo_update(pol, traj)
         cs, losses = ra.critic_update(cri, opt, traj, 6, want_losses=True)

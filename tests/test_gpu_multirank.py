@@ -22,6 +22,26 @@ H = 128
 PS, CS = O.MlpShape(5, H, 2), O.MlpShape(5, H, 1)
 
 
+def probe_vectors(pol, cri, traj):
+    """the three kinds of vector a sharded update all-reduces, each once: the policy gradient (with its loss and entropy
+    sums), a Fisher-vector product with a fixed tangent, the critic gradient (with its loss)"""
+    g, loss, ent = ra.policy_gradient(pol, traj)
+    v = np.random.default_rng(7).standard_normal(pol.P).astype(np.float32)
+    hv = ra.policy_fvp(pol, traj, v, 0.0)
+    gc, lc = ra.critic_gradient(cri, traj)
+    return dict(g=g, loss=loss, ent=ent, hv=hv, gc=gc, lc=lc)
+
+
+def check_probe_vectors(sharded, single, tol=2e-6):
+    """same samples, other order of the f32 partial sums and one rounding more per all-reduce: the vectors agree to
+    rounding (2e-6 of their largest entry; a shard weighted 1.5 x instead of 1 moves them by per cent)"""
+    for k in ("g", "hv", "gc"):
+        a, b = np.asarray(sharded[k], dtype=np.float64), np.asarray(single[k], dtype=np.float64)
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), k
+    for k in ("loss", "ent", "lc"):
+        assert abs(sharded[k] - single[k]) <= 1e-6 * max(1.0, abs(single[k])), k
+
+
 def run_rank(rank, world, uid, lanes, T, out, barrier, critic_steps=10, with_dqn=True):
     """`lanes`: the lane count of every rank (the library's contract: equal shards — the negative test breaks it)"""
     try:
@@ -42,6 +62,8 @@ def run_rank(rank, world, uid, lanes, T, out, barrier, critic_steps=10, with_dqn
             ra.gae(traj, cri, 0.99, 0.95)
             before = traj.read_all() if period == 0 else None
             rtg = traj.read(ra.TRAJ_RETURNS) if period == 0 else None
+            if period == 0:  # every kind of all-reduced vector on its own, before anything is updated (collective calls)
+                res["probe"] = probe_vectors(pol, cri, traj)
             # period 0: the two updates in turn; period 1: side by side on two streams, each chain with its own
             # collective channel (rl_actor_critic_update) — identical replicas either way
             if period == 0:
@@ -112,6 +134,8 @@ def check_sharded_update_against_the_oracles(ranks, single, critic_steps=10):
     A shard weighted by the wrong B_local / B_total moves the scalars and the per-step losses by per cent (the negative
     test below): none of these bars lets that through."""
     s = single[0]
+    if "probe" in single and "probe" in ranks[0]:
+        check_probe_vectors(ranks[0]["probe"], single["probe"])
     tr = s["traj"]
     for f in ("action", "flag", "reward", "obs"):
         axis = 2 if f == "obs" else 1
@@ -148,7 +172,7 @@ def check_sharded_update_against_the_oracles(ranks, single, critic_steps=10):
     # — differ from each other by a factor of a few in this residual: f32 CG has lost conjugacy by then, tests/
     # test_gpu_parity.py::test_trpo_update_default_config_vs_f64_truth quotes 0.32 / 0.25 / 0.046 on one problem and 0.040 /
     # 0.026 / 0.11 on another.  The bar is 3 x the worst of the yardsticks; a wrong operator, sign or weight gives O(1).)
-    assert r_dev <= 3.0 * max(r_o32, r_o64, r_one) + 1e-6
+    assert r_dev <= max(3.0 * max(r_o32, r_o64, r_one), 0.2)  # (the sharp bars on the vectors are check_probe_vectors)
     # critic: the oracle's Adam loop on the same samples and targets
     import ctypes as C
     ac = O.AdamCfg()
@@ -379,7 +403,9 @@ def _as_launch_result(npz):
                 status=int(t[4]), loss_final=float(t[5]), constraint_val_final=float(t[6]), step_scale=float(t[7]),
                 num_backtracks=int(t[8]))
     traj = dict(obs=npz["obs"], action=npz["action"], flag=npz["flag"], reward=npz["reward"])
-    return {"policy_init": npz["policy_init"], "critic_init": npz["critic_init"],
+    probe = dict(g=npz["probe_g"], hv=npz["probe_hv"], gc=npz["probe_gc"], loss=float(npz["probe_loss"]),
+                 ent=float(npz["probe_ent"]), lc=float(npz["probe_lc"]))
+    return {"policy_init": npz["policy_init"], "critic_init": npz["critic_init"], "probe": probe,
             0: dict(traj=traj, adv=npz["adv"], rtg=npz["rtg"], policy=npz["policy0"], critic=npz["critic0"], trpo=trpo,
                     losses=npz["losses0"])}
 
@@ -544,7 +570,7 @@ def _config4_yardstick(single):
 def _check_config4(ranks, single):
     """rollouts bit-identical lane for lane; every rank's replica identical after both periods; the first period's update
     held to the bars of check_sharded_update_against_the_oracles with the one-rank device result as the f32 yardstick:
-    scalars to 1e-6, step size no farther from the f64 step size than twice the one-rank run is, backward error of the
+    scalars to 1e-6, step size no farther from the f64 step size than twice the one-rank run is (or 2 %), backward error of the
     step direction under the f64 operator no more than 3 x the worse of the one-rank run's and the f64 iteration's own,
     the loss before every critic step to 1e-5, the critic's parameters to the single-rank test's bound"""
     world = len(ranks)
@@ -563,10 +589,18 @@ def _check_config4(ranks, single):
     a, b = ranks[0]["trpo0"], single["trpo0"]
     assert abs(a[0] - b[0]) < 1e-6 and abs(a[1] - b[1]) < 1e-6 and a[3] == b[3] and a[4] == b[4]
     y = _config4_yardstick(single)
-    assert abs(float(a[2]) - y["ss64"]) <= 2.0 * y["ss_err_single"] + 1e-3 * y["ss64"], (a[2], b[2], y["ss64"])
+    # (the one-rank run is ONE f32 evaluation and may land anywhere inside the f32 scatter — 0.1 % from the f64 step size
+    # on one run where the eight ranks landed 1.0 % from it: the yardstick is twice its distance or 2 % of the step,
+    # whichever is larger; a shard of 1/8 of the samples weighted 1.5 x moves the step size by 6 %)
+    assert abs(float(a[2]) - y["ss64"]) <= max(2.0 * y["ss_err_single"], 0.02 * y["ss64"]), (a[2], b[2], y["ss64"])
     r8 = y["residual"](ranks[0]["policy0"], a)
     print("config 4 TRPO backward error |Ax - g| / |g|: 8 ranks %.4g, 1 rank %.4g, f64 CG %.4g" % (r8, y["r_single"], y["r64"]))
-    assert r8 <= 3.0 * max(y["r_single"], y["r64"]) + 1e-6
+    # (0.041 / 0.094 / 0.0089 and 0.046 / 0.010 / 0.0089 for eight ranks / one rank / the f64 iteration on two builds of
+    # the library: ten f32 CG iterations scatter by a factor of ten here.  The bar keeps out what is wrong by O(1); the
+    # sharp bars are the vectors themselves, below, and the per-step critic losses)
+    assert r8 <= max(3.0 * max(y["r_single"], y["r64"]), 0.2)
+    check_probe_vectors({k[6:]: ranks[0][k] for k in ranks[0] if k.startswith("probe_")},
+                        {k[6:]: single[k] for k in single if k.startswith("probe_")})
     assert a[8] <= 0.01 and a[7] < a[0]  # the accepted step obeys the trust region and improves the surrogate
     steps = CONFIG4["critic_steps"]
     assert np.max(np.abs(ranks[0]["losses0"] - single["losses0"]) / single["losses0"]) < 1e-5
