@@ -623,7 +623,10 @@ def test_eight_mailbox_ranks_at_the_config4_split(tmp_path, config4_single):
     script = os.path.join(root, "scripts", "ipc_multi.py")
     d = os.path.join(str(tmp_path), "config4")
     os.makedirs(d)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (eight ranks share one GPU's hardware queues here: a rank's first launch can sit behind the others' spinning waits
+    # for a firmware scheduling quantum or more — the wait bound is raised from its 30 s so that a slow start is not
+    # mistaken for a missing peer; the test's own limit stays)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELEARN_IPC_TIMEOUT_MS="150000")
     args = [str(CONFIG4[k]) for k in ("n_total", "T", "critic_steps", "periods")]
     procs = [subprocess.Popen([sys.executable, script, str(p), "4", "2", d] + args, cwd=root, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
