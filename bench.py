@@ -559,7 +559,7 @@ def main():
         out["source"]["this_lib_sha16"] = lib_sha16()
         out["source"]["applies"] = summary.get("lib_sha16") == lib_sha16()
         for kname, row in summary.get("kernels", {}).items():
-            if kname.startswith(prefix):
+            if kname.replace("void ", "").startswith(prefix):
                 out["traffic"] = row.get("hbm_bytes_per_launch")
                 out["valu_busy_frac"], out["mfma_busy_frac"] = row.get("valu_busy_frac"), row.get("mfma_busy_frac")
                 if row.get("SQ_INSTS_VALU") and row.get("SQ_BUSY_CU_CYCLES"):
@@ -581,7 +581,7 @@ def main():
         algorithmic = flop_c * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
         bf16_flop = 22 * 32768 // 32
         executed = bf16_flop * B_local * cf_n / (cf_ms * 1e-3) / 1e12 if cf_ms > 0 else 0.0
-        ctr = counters("k_critic_step_mfma")
+        ctr = counters("k_critic_step_mfma<1>")
         if fused:
             roofline = {
                 # achieved = ALGORITHMIC flop (3 x critic forward = 4,608 per sample) x samples / launch time,
@@ -628,7 +628,7 @@ def main():
             flop_p = 4 * 2 * (5 * H + H * 2)
             ach = flop_p * B_local * fv_n / (fv_ms * 1e-3) / 1e12
             exe = (38 * 32768 // 32) * B_local * fv_n / (fv_ms * 1e-3) / 1e12
-            pc = counters("void k_policy_bf16<2")
+            pc = counters("k_policy_bf16<2")
             roofline_policy = {"kernel": "k_policy_bf16<PASS_JVP>", "bound": "mfma", "achieved": ach,
                                "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
                                "frac_algorithmic": ach / BF16_PEAK_TFLOPS,

@@ -70,8 +70,9 @@ out.update({
     "kernel_ms_per_update": {k: v[0] / updates for k, v in prof.items() if v[1]},
     "kernel_launches_per_update": {k: v[1] / updates for k, v in prof.items() if v[1]},
 })
-# ---- roofline of the dominant kernel, as bench.py reports it for config 4: k_dqn_step_bf16, one launch = forward
-# + loss + backward of the 5-128-2 action-value network over a minibatch.  Algorithmic: 3 x 2 x (5*128 + 128*2) = 5,376
+# ---- roofline of the dominant kernel, as bench.py reports it for config 4: the DQN gradient — k_critic_step_mfma<2>
+# (two critic-step channels per SIMD, round 6; k_dqn_step_bf16 with RL_DQN_SINGLE_WAVE=1 or in-kernel TD targets) —, one
+# launch = forward + loss + backward of the 5-128-2 action-value network over a minibatch.  Algorithmic: 3 x 2 x (5*128 + 128*2) = 5,376
 # flop and 25 B (five f32 features, the action, the target) per sample.
 import roofline_util as ru  # noqa: E402
 k_ms, k_n = out["kernel_ms_per_update"].get("policy_fused", 0.0), out["kernel_launches_per_update"].get("policy_fused", 0)
@@ -80,16 +81,18 @@ if k_n:
     us = 1e3 * k_ms / k_n
     flop, alg_bytes = 5376.0 * mb, 25.0 * mb
     kernels, src = ru.pmc_kernels("r06_pmc_dqn_summary.json")
-    traffic, _ = ru.traffic_of(kernels if src["applies"] else {}, {"k_dqn_step_bf16": 1.0})
+    single = os.environ.get("RL_DQN_SINGLE_WAVE") is not None or os.environ.get("DQN_TD") == "1"
+    kname = "k_dqn_step_bf16" if single else "k_critic_step_mfma<2>"
+    traffic, _ = ru.traffic_of(kernels if src["applies"] else {}, {kname: 1.0})
     ach = flop / (us * 1e-6) / 1e12
     out["roofline"] = {
-        "kernel": "k_dqn_step_bf16", "bound": "mfma", "achieved": ach, "peak": ru.BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "kernel": kname, "bound": "mfma", "achieved": ach, "peak": ru.BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": ach / ru.BF16_PEAK_TFLOPS, "traffic": traffic, "algorithmic_flop_per_sample": 5376,
         "algorithmic_bytes_per_launch": alg_bytes,
         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
         "hbm_GBps": (traffic / (us * 1e-6) / 1e9) if traffic else None,
         "hbm_frac": (traffic / (us * 1e-6) / 1e9 / ru.HBM_PEAK_GBS) if traffic else None,
         "avg_launch_us": us, "samples_per_launch": mb, "launches_per_update": k_n, "source": src,
-        "note": "a minibatch is ~3 tiles per wave: the launch is latency-bound (fixed cost of a launch ~8 us), neither roof "
-                "is near; frac = algorithmic flop / time / dense bf16 peak as in bench.py"}
+        "note": "a minibatch is ~3 tiles per wave pair: the launch is latency-bound (a launch costs ~6 us beyond its tiles), "
+                "neither roof is near; frac = algorithmic flop / time / dense bf16 peak as in bench.py"}
 print(json.dumps(out))
