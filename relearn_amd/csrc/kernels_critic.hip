@@ -32,7 +32,10 @@ using bt::Frag;
 constexpr int CRITIC_WAVES = 8;  // waves per workgroup, one workgroup per CU (two waves per SIMD: the
                                                // tile state — 64 accumulators of each pass, 48 weight-piece registers —
                                                // does not fit three)
-constexpr int C_FLUSH = 64;                     // f32 -> f64 flush period in tiles (2048 samples per accumulator: the accumulated error stays below a 128-sample f32 fma chain's, scripts/probe/mfma_bf16_mask.hip)
+#ifndef RL_C_FLUSH
+#define RL_C_FLUSH 64
+#endif
+constexpr int C_FLUSH = RL_C_FLUSH;                     // f32 -> f64 flush period in tiles (2048 samples per accumulator: the accumulated error stays below a 128-sample f32 fma chain's, scripts/probe/mfma_bf16_mask.hip)
 
 // -DRL_CRITIC_TIMESTAMPS (a timing build, scripts/build_variant.sh): wave 0 of every workgroup records the constant
 // 100 MHz clock at seven points of the launch; the launcher prints the averages over the workgroups (round 6: where the

@@ -291,6 +291,48 @@ __global__ void __launch_bounds__(1024) k_reduce(const double *__restrict__ slab
   }
 }
 
+// k_reduce with narrower workgroups (round 6; k_reduce_adam_narrow below says why): CW columns per workgroup, the 64 / CW
+// lane groups of a wave on different rows
+template <int CW>
+__global__ void __launch_bounds__(1024) k_reduce_narrow(const double *__restrict__ slabA, uint32_t nbA, uint32_t P,
+                                                        const double *__restrict__ slabB, uint32_t nbB,
+                                                        float *__restrict__ vec, int useA, int useB) {
+  constexpr int GPW = 64 / CW, RG = 16 * GPW, U = 256 / RG;
+  __shared__ double part[RG][CW];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane & (CW - 1), rg = w * GPW + lane / CW;
+  const uint32_t p = blockIdx.x * CW + (uint32_t)c;
+  auto partial = [&](const double *__restrict__ slab, uint32_t nb, uint32_t stride, uint32_t col) {
+    double acc = 0.0;
+    for (uint32_t r0 = (uint32_t)rg; r0 < nb; r0 += RG * U) {
+      double x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t r = r0 + RG * u;
+        x[u] = r < nb ? slab[(size_t)r * stride + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = acc + x[u];
+    }
+    return acc;
+  };
+  double acc = 0.0;
+  if (p < P) {
+    if (useA) acc = partial(slabA, nbA, P, p);
+  } else if (p < P + 4) {
+    if (useB) acc = partial(slabB, nbB, 4, p - P);
+  }
+  part[rg][c] = acc;
+  __syncthreads();
+  if (threadIdx.x >= CW || p >= P + 4) return;
+  if (p < P ? useA != 0 : useB != 0) {
+    double t = part[0][c];
+#pragma unroll
+    for (int k = 1; k < RG; ++k) t = t + part[k][c];
+    vec[p] = (float)t;
+  }
+}
+
 // ---------------------------------------------------------------- single-workgroup bookkeeping kernels
 constexpr int SB = 256;  // P <= 1026: four entries per thread, 8 barrier rounds per block-wide sum
 
@@ -572,6 +614,78 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
   if (wimg) bt::wimg_store_param(wimg, p, w_new, A);
 }
 
+// The same launch with NARROWER workgroups (round 6): CW = 16 or 32 columns per workgroup instead of 64, the 64 / CW lane
+// groups of a wave taking different rows — four (two) times as many workgroups pull the slab, each a quarter (half) of
+// the bytes, and a lane has 4 (8) loads in flight instead of 16.  A column's partial sums are per row group r, r + RG, ...
+// (RG = 16 x 64 / CW groups) in row order, combined in group order: deterministic, another order than the wide form.
+// (No mailbox exchange here: its chunks are 64 columns.)
+template <int CW>
+__global__ void __launch_bounds__(1024) k_reduce_adam_narrow(const double *__restrict__ slabA, uint32_t nbA, uint32_t P,
+                                                             const double *__restrict__ slabB, uint32_t nbB,
+                                                             float *__restrict__ vec, float *__restrict__ params,
+                                                             float *__restrict__ m, float *__restrict__ v,
+                                                             uint64_t *step_ptr, uint64_t step, float neg_step_size,
+                                                             float sqrt_bc2, double beta1, double beta2, double eps,
+                                                             double weight_decay, double inv_B,
+                                                             float *__restrict__ loss_out, uint32_t *__restrict__ wimg,
+                                                             int A) {
+  constexpr int GPW = 64 / CW, RG = 16 * GPW;  // row groups per wave, per workgroup
+  __shared__ double part[RG][CW];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane & (CW - 1), rg = w * GPW + lane / CW;
+  const uint32_t p = blockIdx.x * CW + (uint32_t)c;
+  float p_old = 0.0f, m_old = 0.0f, v_old = 0.0f;
+  if (threadIdx.x < CW && p < P) {  // the optimiser state of this column arrives under the slab loads
+    p_old = params[p];
+    m_old = m[p];
+    v_old = v[p];
+  }
+  auto partial = [&](const double *__restrict__ slab, uint32_t nb, uint32_t stride, uint32_t col) {
+    constexpr int U = 256 / RG;  // loads in flight per lane: one memory round trip for <= 256 rows
+    double acc = 0.0;
+    for (uint32_t r0 = (uint32_t)rg; r0 < nb; r0 += RG * U) {
+      double x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t r = r0 + RG * u;
+        x[u] = r < nb ? slab[(size_t)r * stride + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = acc + x[u];
+    }
+    return acc;
+  };
+  double acc = 0.0;
+  if (p < P) acc = partial(slabA, nbA, P, p);
+  else if (p < P + 4) acc = partial(slabB, nbB, 4, p - P);
+  part[rg][c] = acc;
+  __syncthreads();
+  if (threadIdx.x >= CW || p >= P + 4) return;
+  double t = part[0][c];
+#pragma unroll
+  for (int k = 1; k < RG; ++k) t = t + part[k][c];
+  const float gsum = (float)t;
+  vec[p] = gsum;
+  if (p == 0) *step_ptr = step;
+  if (p >= P) {
+    if (p == P && loss_out) *loss_out = (float)((double)gsum * inv_B);
+    return;
+  }
+  const float b1 = (float)beta1, b2 = (float)beta2;
+  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+  const float epsf = (float)eps;
+  float g = gsum;
+  if (weight_decay != 0.0) g = g + (float)weight_decay * p_old;
+  const float mi = m_old * b1 + omb1 * g;
+  const float vi = v_old * b2 + omb2 * g * g;
+  m[p] = mi;
+  v[p] = vi;
+  const float denom = __fsqrt_rn(vi) / sqrt_bc2 + epsf;
+  const float w_new = p_old + (neg_step_size * mi) / denom;
+  params[p] = w_new;
+  if (wimg) bt::wimg_store_param(wimg, p, w_new, A);
+}
+
 // ---------------------------------------------------------------- launchers
 // the word a failed mailbox exchange sets (NULL when that transport is not in use)
 static const int32_t *comm_err_word(const rl_engine *e) { return e->ipc_active ? e->ipc_err : (const int32_t *)nullptr; }
@@ -637,10 +751,27 @@ void launch_mlp_backward(rl_traj *traj, const rl_mlp *mlp, const int32_t *d_skip
 #undef BWD
 }
 
+// columns of the reduced vector per workgroup of the slab reductions: 16 (57 - 65 workgroups pull the slab, a lane has
+// four loads in flight; round 6: 6.4 -> 4.5 us per reduce + Adam launch, scripts/critic_only.py) — or 64, the form of
+// rounds 1-5, with RL_REDUCE_WIDTH=64 (A/B runs).  The mailbox exchange keeps the wide form: its chunks are 64 columns.
+// (vectors of more than 2,048 entries — the recurrent chains, wide general MLPs — are bandwidth-, not latency-bound and
+// keep the wide form)
+static int reduce_width(uint32_t P) {
+  static const int w = [] {
+    const char *e = std::getenv("RL_REDUCE_WIDTH");
+    return e != nullptr && std::atoi(e) == 64 ? 64 : 16;
+  }();
+  return P + 4 > 2048 ? 64 : w;
+}
+
 void launch_reduce(rl_traj *traj, uint32_t P, bool useA, bool useB, uint32_t rowsA, uint32_t rowsB) {
   ProfScope ps(traj->eng, RL_K_REDUCE);
-  hipLaunchKernelGGL(k_reduce, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
-                     traj->slabB, rowsB, traj->vec, useA ? 1 : 0, useB ? 1 : 0);
+  if (reduce_width(P) == 64)
+    hipLaunchKernelGGL(k_reduce, dim3(cdiv(P + 4, 64)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA, P,
+                       traj->slabB, rowsB, traj->vec, useA ? 1 : 0, useB ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_reduce_narrow<16>, dim3(cdiv(P + 4, 16)), dim3(1024), 0, traj->eng->stream, traj->slabA, rowsA,
+                       P, traj->slabB, rowsB, traj->vec, useA ? 1 : 0, useB ? 1 : 0);
 }
 
 void launch_trpo_begin(rl_traj *traj, rl_mlp *policy, uint64_t B_total) {
@@ -729,6 +860,12 @@ void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t ro
                        traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                        opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
                        opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, peers, wimg_if_current(opt->mod),
+                       (int)opt->mod->out_dim);
+  } else if (reduce_width(P) != 64) {
+    hipLaunchKernelGGL(k_reduce_adam_narrow<16>, dim3(cdiv(P + 4, 16)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
+                       traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
+                       opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
+                       opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, wimg_if_current(opt->mod),
                        (int)opt->mod->out_dim);
   } else {
     hipLaunchKernelGGL(k_reduce_adam<false>, dim3(cdiv(P + 4, 64)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
