@@ -242,9 +242,13 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     float *__restrict__ store = act + ((size_t)t * tiles + tile) * SEQ_ARR * GH * TL;
     // (uniform block base + 32-bit lane offsets: the addresses stay out of the vector registers)
     const uint32_t row = rec_at(j, 16 * mt + 4 * g4);
+    // -DRL_GRU_TIMING_FWD_ONE_PLANE (a TIMING build, results unusable; round 6): the forward of the partition the round-5
+    // review asked for records relu(h') only — what that forward would cost
+#ifndef RL_GRU_TIMING_FWD_ONE_PLANE
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_GHN * GH * TL) + row) = acc[2][mt];
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_HPREV * GH * TL) + row) =
         (f32x4){hown[4 * mt], hown[4 * mt + 1], hown[4 * mt + 2], hown[4 * mt + 3]};
+#endif
     float wih[3][D], bih[3];
 #pragma unroll
     for (int gte = 0; gte < 3; ++gte) {
@@ -284,9 +288,13 @@ __global__ void __launch_bounds__(W16 * 64, 2)
       hP[1][img_at(m, j)] = (unsigned short)p1;
       hP[2][img_at(m, j)] = (unsigned short)p2;
     }
+#ifndef RL_GRU_TIMING_FWD_ONE_PLANE
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_R * GH * TL) + row) = rv;
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_Z * GH * TL) + row) = zv;
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_N * GH * TL) + row) = nv;
+#else
+    asm volatile("" ::"v"(rv), "v"(zv), "v"(nv));  // (the values are still computed)
+#endif
     *reinterpret_cast<f32x4 *>(store + (uint32_t)(ACT_A1 * GH * TL) + row) = av;
   };
   // the order asked of the scheduler for a phase: one matrix instruction, a few vector ones (PHASE: the two phases share
@@ -710,11 +718,18 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     const float *__restrict__ ab = act + blk * SEQ_ARR * GH * TL;
     const float *__restrict__ db = dpre + blk * DPRE_ARR * GH * TL;
     const uint32_t o = lo + REC_HALF * mt;
+    // -DRL_GRU_TIMING_BWD_TWO_PLANES (a TIMING build, results unusable; round 6): the backward of the asked partition reads
+    // h_prev and d relu(h') only (the gates it would recompute are stand-ins here: the recompute itself is NOT timed)
+#ifndef RL_GRU_TIMING_BWD_TWO_PLANES
     in.r = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_R * GH * TL) + o);
     in.z = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_Z * GH * TL) + o);
     in.n = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_N * GH * TL) + o);
     in.ghn = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_GHN * GH * TL) + o);
     in.hp = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
+#else
+    in.hp = *reinterpret_cast<const f32x4 *>(ab + (uint32_t)(ACT_HPREV * GH * TL) + o);
+    in.r = in.z = in.n = in.ghn = in.hp * 0.25f + 0.5f;
+#endif
     in.da1 = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + o);
     in.end = *reinterpret_cast<const uint32_t *>(tr.flag + ((size_t)t * N + lane0) + (uint32_t)(16 * mt + 4 * g4));
   };
