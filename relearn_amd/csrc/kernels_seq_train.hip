@@ -30,6 +30,10 @@
 // step and the gate arithmetic.
 // Reference: gru_cell (src/torch/modules/seq/rnn/gru.rs:30-39), Chain (modules/chain.rs:127-186), and what libtorch's
 // autograd does for loss.backward() on them (src/torch/optimizers/coptimizer.rs:13-26).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "bf16_tile.hpp"
 #include "seq_common.hpp"
 
@@ -669,6 +673,11 @@ __global__ void __launch_bounds__(W16 * 64, 2)
 //   d pre_z = dh (h_prev - n) z (1 - z),  d gh_n = d pre_n r
 //   d h_prev = dh z + W_hh[r]^T d pre_r + W_hh[z]^T d pre_z + W_hh[n]^T d gh_n          (K = 384 on the matrix pipe)
 // and writes the four per-step arrays the weight-gradient GEMMs read.
+// -DRL_GRU_BWD_TIMESTAMPS (a timing build): waves 0 and 4 of every tile accumulate, over the steps, the 100 MHz clock
+// spent in each phase's work and at each barrier; the launcher prints the means (round 6: where a step's 7.2 us go)
+#ifdef RL_GRU_BWD_TIMESTAMPS
+__device__ unsigned long long g_gru_bwd_ts[1024 * 2 * 6];
+#endif
 __global__ void __launch_bounds__(W16 * 64, 2)
     k_gru_recur_bwd(TrajDev tr, const float *__restrict__ params, int A, const float *__restrict__ act,
                     float *__restrict__ dpre, float *__restrict__ slab, uint32_t P,
@@ -733,6 +742,11 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     in.da1 = *reinterpret_cast<const f32x4 *>(db + (uint32_t)(DPRE_DA1 * GH * TL) + o);
     in.end = *reinterpret_cast<const uint32_t *>(tr.flag + ((size_t)t * N + lane0) + (uint32_t)(16 * mt + 4 * g4));
   };
+  // (Round 6, measured and not kept: with every load of the loop issued unconditionally by every thread the compiler's
+  // wait counts become exact — no s_waitcnt vmcnt(0) at the head of the phases any more — and the step takes the same
+  // 7.0 us: the waits move, the time does not.  What a phase waits for is the LDS: every wave's product reads the same
+  // 36 KB of gate-gradient pieces plus its 9 KB of weights, 368 KB per phase and CU = 1.4 us at 128 B per cycle, twice
+  // per step (timing build -DRL_GRU_BWD_TIMESTAMPS: products 1.2 - 2.8 us, gate gradients 1.1 - 1.8 us per phase).)
   const bool x_thread = threadIdx.x < TL * D;
   auto load_x = [&](uint32_t t) {  // feature (tid / TL) of sample (tid % TL) of step t
     return tr.obs[(size_t)(threadIdx.x / TL) * plane + (size_t)t * N + lane0 + (threadIdx.x % TL)];
@@ -813,6 +827,17 @@ __global__ void __launch_bounds__(W16 * 64, 2)
   gates(inA, T - 1, 0);
   if (T > 1) load(inA, T - 2, 0);
   __syncthreads();
+#ifdef RL_GRU_BWD_TIMESTAMPS
+  unsigned long long ts_acc[6] = {0, 0, 0, 0, 0, 0}, ts_last = __builtin_amdgcn_s_memrealtime();
+#define GRU_TS(k)                                                  \
+  do {                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); \
+    ts_acc[k] += now_ - ts_last;                                   \
+    ts_last = now_;                                                \
+  } while (0)
+#else
+#define GRU_TS(k)
+#endif
   for (uint32_t t = T; t-- > 0;) {
     if (x_thread && t > 0) xS[(t - 1) & 1][threadIdx.x % TL][threadIdx.x / TL] = xin;  // the features of step t - 1
     if (x_thread && t > 1) xin = load_x(t - 2);
@@ -821,26 +846,38 @@ __global__ void __launch_bounds__(W16 * 64, 2)
     if (wave < W16 / 2) {
       products(0);
       __builtin_amdgcn_sched_barrier(0);
+      GRU_TS(0);
       gates(inB, t, 1);
     } else {
       gates(inB, t, 1);
       __builtin_amdgcn_sched_barrier(0);
+      GRU_TS(0);
       products(0);
     }
     if (t > 0) load(inB, t - 1, 1);
+    GRU_TS(1);
     __syncthreads();  // rows 16-31 of the image of step t are complete; rows 0-15 have been read
+    GRU_TS(2);
     if (wave < W16 / 2) {
       products(1);
       __builtin_amdgcn_sched_barrier(0);
+      GRU_TS(3);
       if (t > 0) gates(inA, t - 1, 0);
     } else {
       if (t > 0) gates(inA, t - 1, 0);
       __builtin_amdgcn_sched_barrier(0);
+      GRU_TS(3);
       products(1);
     }
     if (t > 1) load(inA, t - 2, 0);
+    GRU_TS(4);
     __syncthreads();  // rows 0-15 of the image of step t - 1 are complete; rows 16-31 have been read
+    GRU_TS(5);
   }
+#ifdef RL_GRU_BWD_TIMESTAMPS
+  if (lane == 0 && (wave == 0 || wave == 4) && tile < 1024)
+    for (int k = 0; k < 6; ++k) g_gru_bwd_ts[(tile * 2 + (wave >> 2)) * 6 + k] = ts_acc[k];
+#endif
   // ---- this tile's row of partials: the n gate's rows of W_ih and b_ih (the four lane groups of a wave hold
   // different samples of the same unit)
   float *__restrict__ out = slab + (size_t)tile * P;
@@ -1312,4 +1349,23 @@ void launch_gru_train_recur_backward(rl_traj *traj, const rl_mlp *mod, const int
   // the head columns of the same rows)
   hipLaunchKernelGGL(k_gru_recur_bwd, dim3(q.tiles), dim3(W16 * 64), 0, traj->eng->stream, traj->d, mod->d_params,
                      (int)mod->out_dim, q.act, q.dpre, q.wg_slab + (size_t)q.chunks * mod->P, (uint32_t)mod->P, d_skip);
+#ifdef RL_GRU_BWD_TIMESTAMPS
+  if (std::getenv("RL_GRU_TS_PRINT")) {
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      const uint32_t tiles = q.tiles < 1024 ? q.tiles : 1024;
+      std::vector<unsigned long long> h(1024 * 2 * 6);
+      (void)hipStreamSynchronize(traj->eng->stream);
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_gru_bwd_ts), h.size() * 8);
+      for (int wv = 0; wv < 2; ++wv) {
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t tl = 0; tl < tiles; ++tl)
+          for (int k = 0; k < 6; ++k) sum[k] += (double)h[(tl * 2 + wv) * 6 + k] * 0.01 / traj->d.T;
+        std::fprintf(stderr, "gru bwd ts, wave %d (%s first; us per step, mean over %u tiles): phase 1: %.2f + %.2f, barrier "
+                     "%.2f; phase 2: %.2f + %.2f, barrier %.2f\n", 4 * wv, wv == 0 ? "products" : "gates", tiles,
+                     sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[5] / tiles);
+      }
+    }
+  }
+#endif
 }
