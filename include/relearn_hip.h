@@ -110,8 +110,8 @@ int32_t rl_engine_set_kernel_variant(rl_engine *engine, int32_t variant);
  * The library checks the condition in the first fused launch of each module of every call (the later launches of the
  * same call start from parameters that call produced itself, in steps bounded by the learning rate or the KL constraint),
  * from the weights the launch has just loaded and the magnitude range of the trajectory's observation planes (measured
- * once per rollout / rl_traj_write; the DQN minibatches use fixed bounds for CartPole-generated observations,
- * 2^-64 <= |obs| <= 2^16).  Outside the range the call returns RL_ERR_UNSUPPORTED
+ * once per rollout / rl_traj_write; for DQN the collecting rollout folds the observations it writes to the replay
+ * store into the same range words).  Outside the range the call returns RL_ERR_UNSUPPORTED
  * — never a silently wrong mask; its outputs (and, for an update, the parameters it was stepping) are then not valid.
  * Kernel variant 1 is plain f32 and takes any magnitudes.  tests/test_gpu_numeric_range.py. */
 /* HIP-event timing of everything enqueued between begin and end on the engine stream (milliseconds) */
