@@ -112,7 +112,11 @@ int32_t rl_engine_set_kernel_variant(rl_engine *engine, int32_t variant);
  * from the weights the launch has just loaded and the magnitude range of the trajectory's observation planes (measured
  * once per rollout / rl_traj_write; for DQN the collecting rollout folds the observations it writes to the replay
  * store into the same range words).  Outside the range the call returns RL_ERR_UNSUPPORTED
- * — never a silently wrong mask; its outputs (and, for an update, the parameters it was stepping) are then not valid.
+ * — never a silently wrong mask; its outputs are then not valid, and an update is refused WHOLE: the launch that finds the
+ * violation sets a veto word on the device, which every optimiser and line-search kernel behind it reads, so parameters,
+ * Adam moments and step count are what they were at entry (rl_dqn_update: put back from a snapshot).  The policy chain
+ * and the critic chain have a word each: under rl_actor_critic_update[_begin] a violation of one chain refuses that
+ * chain, the error names it, and the other chain's step stands (like the NaN policy step above).
  * Kernel variant 1 is plain f32 and takes any magnitudes.  tests/test_gpu_numeric_range.py. */
 /* HIP-event timing of everything enqueued between begin and end on the engine stream (milliseconds) */
 int32_t rl_timer_begin(rl_engine *engine);

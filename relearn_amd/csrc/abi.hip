@@ -1445,12 +1445,13 @@ rl_traj *traj_alloc(rl_engine *e, uint64_t n_lanes, uint64_t horizon, uint32_t o
   t->d.adv = dalloc<float>(T * n);
   t->d.rtg = dalloc<float>(T * n);
   t->d.tgt = t->d.rtg;  // the critic regresses on the returns unless rl_values_opt_update selects other targets
-  t->d.range = dalloc<uint32_t>(RL_RANGE_WORDS);
-  RL_HIP_CHECK(hipMemsetAsync(t->d.range, 0, RL_RANGE_WORDS * sizeof(uint32_t), e->stream));
+  t->d.range = dalloc<uint32_t>(RL_RANGE_ALLOC_WORDS);
+  RL_HIP_CHECK(hipMemsetAsync(t->d.range, 0, RL_RANGE_ALLOC_WORDS * sizeof(uint32_t), e->stream));
   {
     void *hp = nullptr;
     RL_HIP_CHECK(hipHostMalloc(&hp, 64, hipHostMallocMapped));
-    *static_cast<volatile uint32_t *>(hp) = 0u;
+    static_cast<volatile uint32_t *>(hp)[RL_GUARD_POLICY] = 0u;
+    static_cast<volatile uint32_t *>(hp)[RL_GUARD_CRITIC] = 0u;
     void *dp = nullptr;
     RL_HIP_CHECK(hipHostGetDevicePointer(&dp, hp, 0));
     t->h_range_err = static_cast<uint32_t *>(hp);

@@ -526,7 +526,7 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
       // host memory the kernels write across the bus)
       if (fused_shape && K) {
         sync(e);
-        range_check(q->mb);
+        range_check(q->mb, 1u << RL_GUARD_POLICY);
       }
     } catch (...) {
       if (snapshot) {
@@ -549,7 +549,7 @@ int32_t rl_dqn_update(rl_dqn *q, rl_dqn_update_stats *stats, float *losses_out) 
     if (all_at_once && td && K) dqn_build_minibatch(q, (uint32_t)(K - 1), counts[K - 1], totals[K - 1]);
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), q->mb->losses, K * sizeof(float));
-    range_check(q->mb);
+    range_check(q->mb, 1u << RL_GUARD_POLICY);
     if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
     if (stats) {
       stats->opt_steps = K;
@@ -660,7 +660,7 @@ int32_t rl_dqn_minibatch_gradient(rl_dqn *q, float *grad_out, float *loss_out) {
     dqn_gradient(q);
     std::vector<float> h(P + 4);
     d2h(q->eng, h.data(), q->mb->vec, (P + 4) * sizeof(float));
-    range_check(q->mb);
+    range_check(q->mb, 1u << RL_GUARD_POLICY);
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     if (loss_out) *loss_out = (float)((double)h[P] / (double)q->last_total_steps);
   });

@@ -40,12 +40,15 @@ static inline int32_t guarded(rl_engine *eng, F &&f, bool settle = true) {
     }
     return RL_OK;
   } catch (const RlError &e) {
+    if (eng != nullptr) eng->error_epoch += 1;  // (optimisers re-read their step count from the device: rl_adam)
     (eng ? eng->last_error : g_last_error_no_engine) = e.what();
     return e.code;
   } catch (const std::exception &e) {
+    if (eng != nullptr) eng->error_epoch += 1;
     (eng ? eng->last_error : g_last_error_no_engine) = e.what();
     return RL_ERR_INVALID_ARGUMENT;
   } catch (...) {
+    if (eng != nullptr) eng->error_epoch += 1;
     (eng ? eng->last_error : g_last_error_no_engine) = "unknown error";
     return RL_ERR_INVALID_ARGUMENT;
   }
@@ -79,17 +82,42 @@ static inline void d2h(rl_engine *e, void *h, const void *d, size_t bytes) {
 
 // The fused kernels' range guard (bf16_tile.hpp range_guard) found weights / observations outside the range in which the
 // 2^96-scaled forward is exact: their results are not to be used.  Called after the entry point has synchronised the
-// stream its fused launches ran on (every caller has just read results back): the error word lives in host memory.
-static inline void range_check(rl_traj *t) {
-  t->guard_next_policy = t->guard_next_critic = true;  // the next entry point's first fused launches check again
+// stream its fused launches ran on (every caller has just read results back): the error words live in host memory, one per
+// chain (RL_GUARD_POLICY: policy passes and the DQN gradient, RL_GUARD_CRITIC: the critic step), and a caller looks at
+// the chains ITS launches ran — under rl_actor_critic_update_begin the critic chain is still in flight on the auxiliary
+// stream when the TRPO chain's statistics are read, and its violation is the _finish call's to report.  The violation
+// also set the chain's veto word on the device (TrajDev::range_err): the optimiser and line-search kernels behind the
+// guarded launch left parameters, moments and step count as they were, so a refused update is refused whole.
+constexpr uint32_t RL_GUARD_BOTH = (1u << RL_GUARD_POLICY) | (1u << RL_GUARD_CRITIC);
+static inline void range_check(rl_traj *t, uint32_t chains = RL_GUARD_BOTH) {
+  // the next entry point's first fused launches check again
+  if (chains & (1u << RL_GUARD_POLICY)) t->guard_next_policy = true;
+  if (chains & (1u << RL_GUARD_CRITIC)) t->guard_next_critic = true;
   if (t->h_range_err == nullptr) return;
   volatile uint32_t *w = t->h_range_err;
-  if (*w == 0u) return;
-  *w = 0u;
+  uint32_t seen = 0u;
+  for (int c = 0; c < 2; ++c)
+    if ((chains & (1u << c)) != 0u && w[c] != 0u) seen |= 1u << c;
+  if (seen == 0u) return;
+  for (int c = 0; c < 2; ++c)
+    if (seen & (1u << c)) {
+      w[c] = 0u;
+      RL_HIP_CHECK(hipMemsetAsync(t->d.range + RL_RANGE_WORDS + c, 0, sizeof(uint32_t), t->eng->stream));
+    }
+  sync(t->eng);
   throw RlError(RL_ERR_UNSUPPORTED,
-                "numeric range of the fused update kernels exceeded (|pre-activation| bound 2^31 or a non-zero "
-                "pre-activation below 2^-46 possible, or a non-finite observation): the result of this call is not "
-                "valid; use rl_engine_set_kernel_variant(engine, 1) for these magnitudes (include/relearn_hip.h)");
+                std::string("numeric range of the fused update kernels exceeded in the ") +
+                    (seen == RL_GUARD_BOTH ? "policy and critic chains" : (seen & 1u) ? "policy chain" : "critic chain") +
+                    " (|pre-activation| bound 2^31 or a non-zero pre-activation below 2^-46 possible, or a non-finite "
+                    "observation): the result of this call is not valid and the update was not applied; use "
+                    "rl_engine_set_kernel_variant(engine, 1) for these magnitudes (include/relearn_hip.h)");
+}
+// an entry point that gives up for another reason with guarded launches behind it: their words must not outlive the call
+static inline void range_discard(rl_traj *t) {
+  try {
+    range_check(t);
+  } catch (const RlError &) {
+  }
 }
 
 // ---------------------------------------------------------------- shared between the units (C linkage like the entry

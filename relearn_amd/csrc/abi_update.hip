@@ -196,7 +196,7 @@ static void trpo_update_tail(rl_mlp *policy, rl_traj *traj, const rl_trpo_config
   TrpoStateDev h;
   d2h(e, &h, traj->trpo, sizeof(h));
   ipc_check(e);
-  range_check(traj);
+  range_check(traj, 1u << RL_GUARD_POLICY);
   stats->entropy = (double)h.entropy;
   stats->step_size = h.step_size;
   stats->loss_initial = (double)h.loss0;
@@ -235,7 +235,7 @@ int32_t rl_policy_gradient(rl_mlp *policy, rl_traj *traj, float *grad_out, float
     run_policy_gradient(policy, traj);
     std::vector<float> h(P + 4);
     d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_POLICY);
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     double inv_B = 1.0 / (double)b_total(traj);
     if (loss_out) *loss_out = (float)(-((double)h[P] * inv_B));
@@ -253,7 +253,7 @@ int32_t rl_policy_fvp(rl_mlp *policy, rl_traj *traj, const float *v, float reg, 
     run_policy_fvp(policy, traj, traj->cg_x, nullptr);
     std::vector<float> h(P);
     d2h(traj->eng, h.data(), traj->vec, P * sizeof(float));
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_POLICY);
     for (uint32_t i = 0; i < P; ++i) out[i] = h[i] + reg * v[i];
   });
 }
@@ -276,7 +276,7 @@ int32_t rl_policy_loss_kl(rl_mlp *policy, rl_traj *traj, const float *params0, f
     run_policy_eval(policy, traj, nullptr);
     float h[4];
     d2h(e, h, traj->vec + P, sizeof(h));
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_POLICY);
     double inv_B = 1.0 / (double)Bt;
     *loss_out = (float)(-((double)h[0] * inv_B));
     *kl_out = (float)((double)h[1] * inv_B);
@@ -305,6 +305,7 @@ int32_t rl_adam_create(rl_mlp *module, const rl_adam_config *cfg, rl_adam **out)
     o->eng = e;
     o->mod = module;
     o->cfg = *cfg;
+    o->error_epoch = e->error_epoch;
     o->d_m = dalloc<float>(module->P);
     o->d_v = dalloc<float>(module->P);
     o->d_step = dalloc<uint64_t>(1);
@@ -405,7 +406,7 @@ static void critic_collect(rl_traj *traj, uint64_t opt_steps, rl_critic_stats *s
     // round 5: both used to be skipped here)
     sync(traj->eng);
     ipc_check(traj->eng);
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_CRITIC);
     return;
   }
   {
@@ -413,7 +414,7 @@ static void critic_collect(rl_traj *traj, uint64_t opt_steps, rl_critic_stats *s
     if (opt_steps) d2h(traj->eng, h.data(), traj->losses, opt_steps * sizeof(float));
     else sync(traj->eng);
     ipc_check(traj->eng);
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_CRITIC);
     if (losses_out && opt_steps) std::memcpy(losses_out, h.data(), opt_steps * sizeof(float));
     if (stats) {
       stats->steps = opt_steps;
@@ -633,6 +634,7 @@ static void actor_critic_begin(rl_mlp *policy, rl_mlp *critic, rl_adam *critic_o
   } catch (...) {
     (void)hipStreamSynchronize(e->aux_stream);  // nothing of this update may still be running when the error returns
     (void)hipStreamSynchronize(e->main_stream);
+    range_discard(traj);  // (the other chain's guard words go with the call that set them)
     throw;
   }
   pu.active = true;
@@ -700,7 +702,7 @@ int32_t rl_critic_gradient(rl_mlp *critic, rl_traj *traj, float *grad_out, float
     run_critic_gradient(critic, traj);
     std::vector<float> h(P + 4);
     d2h(traj->eng, h.data(), traj->vec, (P + 4) * sizeof(float));
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_CRITIC);
     std::memcpy(grad_out, h.data(), P * sizeof(float));
     if (loss_out) *loss_out = (float)((double)h[P] / (double)b_total(traj));
   });
@@ -753,7 +755,7 @@ int32_t rl_ppo_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, const rl_ppo_
     }
     std::vector<float> h(K ? K : 1, 0.0f);
     if (K) d2h(e, h.data(), traj->losses, K * sizeof(float));
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_POLICY);
     for (auto &v : h) v = -v;  // loss = -mean(min(...))
     if (losses_out && K) std::memcpy(losses_out, h.data(), K * sizeof(float));
     if (stats) {
@@ -777,7 +779,7 @@ int32_t rl_reinforce_update(rl_mlp *policy, rl_adam *opt, rl_traj *traj, rl_poli
     float h0[4];
     d2h(e, h0, traj->vec + P, sizeof(h0));
     launch_adam_step(traj, opt, -1, Bt);
-    range_check(traj);
+    range_check(traj, 1u << RL_GUARD_POLICY);
     if (stats) {
       stats->entropy = (double)h0[1] / (double)Bt;
       stats->steps = 1;

@@ -383,14 +383,20 @@ __device__ __forceinline__ void pack_mask_now(const float (&gm)[16], Frag (&ga)[
 //   relu'      a non-zero pre must reach 2^-96, or the clamped conversion returns a FRACTIONAL mask.  pre is a sum of
 //              exact products whose f32 accumulation can cancel down to 2^-48 of its largest term, so the largest term of
 //              a unit that is not identically zero must be able to reach 2^-46: max(max_k |W1[j][k]| min_nz|x|, |b1[j]|).
-// A violation sets the word *err (host memory mapped into the device); the launch goes on (its numbers are then not to be
-// used) and the host raises RL_ERR_UNSUPPORTED after its next synchronisation (kernel variant 1 has no such bound).
-// ~60 instructions for one wave of the launch.
+// A violation sets the chain's word err[chain] (host memory mapped into the device) and its veto word (device memory, after
+// the range words: range_veto); the launch goes on (its numbers are then not to be used), the optimiser / line-search
+// kernels that follow it in the same call read the veto word and leave parameters and optimiser state as they are, and
+// the host raises RL_ERR_UNSUPPORTED after its next synchronisation (kernel variant 1 has no such bound).  Two chains,
+// because the two run at once under rl_actor_critic_update: GUARD_POLICY (policy passes, the DQN gradient) and
+// GUARD_CRITIC (the critic step).  ~60 instructions for one wave of the launch.
 // The range words: RANGE_SLOTS minima and RANGE_SLOTS maxima, one 128-byte line each (writers fold into slot
 // workgroup % RANGE_SLOTS: tens of thousands of atomics on ONE address resolve one after the other in the L2 and cost
 // a 4,096-lane period 0.1 ms; the reader is one wave, one slot per lane).
 constexpr int RANGE_SLOTS = 64, RANGE_STRIDE = 32;  // (words)
 constexpr int RANGE_WORDS = 2 * RANGE_SLOTS * RANGE_STRIDE;
+constexpr int GUARD_POLICY = 0, GUARD_CRITIC = 1;
+constexpr int RANGE_ALLOC_WORDS = RANGE_WORDS + RANGE_STRIDE;  // + one line: the veto words of the two chains
+__device__ __forceinline__ uint32_t *range_veto(uint32_t *range, int chain) { return range + RANGE_WORDS + chain; }
 __device__ __forceinline__ uint32_t *range_lo_slot(uint32_t *range, int s) { return range + s * RANGE_STRIDE; }
 __device__ __forceinline__ uint32_t *range_hi_slot(uint32_t *range, int s) { return range + (RANGE_SLOTS + s) * RANGE_STRIDE; }
 __device__ __forceinline__ void range_fold(uint32_t *range, uint32_t workgroup, uint32_t lo, uint32_t hi) {
@@ -432,7 +438,7 @@ __device__ __forceinline__ void range_bounds(uint32_t *range, int lane, float &x
   xmin = hi == 0u ? 0.0f : __builtin_bit_cast(float, lo);  // (all observations zero: pre = bias)
 }
 __device__ __forceinline__ void range_guard(float wa, float wb, float w4, float bj, int hf, float xmin, float xmax,
-                                            uint32_t *err) {
+                                            uint32_t *err, uint32_t *veto) {
   const float aa = __builtin_fabsf(wa), ab = __builtin_fabsf(wb);
   const float own = hf == 0 ? __builtin_fabsf(w4) : 0.0f, bias = __builtin_fabsf(bj);
   float hi = (aa + ab + own) * xmax, lo = __builtin_fmaxf(__builtin_fmaxf(aa, ab), own) * xmin, nz = aa + ab + own;
@@ -443,13 +449,17 @@ __device__ __forceinline__ void range_guard(float wa, float wb, float w4, float 
   const float upper = hi0 + hi1 + bias, largest = __builtin_fmaxf(__builtin_fmaxf(lo0, lo1), bias);
   const bool zero_unit = nz0 + nz1 + bias == 0.0f;
   const bool bad = !(upper < 0x1p31f) || (!zero_unit && !(largest >= 0x1p-46f));
-  if (bad) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (bad) {
+    __hip_atomic_store(veto, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 // the range guard's view of a unit from the image: input 4's weight lives in half 0, the bias in half 1
-__device__ __forceinline__ void range_guard_img(const WRaw &r, int hf, float xmin, float xmax, uint32_t *err) {
+__device__ __forceinline__ void range_guard_img(const WRaw &r, int hf, float xmin, float xmax, uint32_t *err,
+                                                uint32_t *veto) {
   float w4, bj;
   both_halves(r.wc, w4, bj);
-  range_guard(r.wa, r.wb, w4, bj, hf, xmin, xmax, err);
+  range_guard(r.wa, r.wb, w4, bj, hf, xmin, xmax, err, veto);
 }
 
 __device__ __forceinline__ uint32_t mask_pair(float lo, float hi, float after) {

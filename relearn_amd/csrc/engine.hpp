@@ -54,6 +54,9 @@ struct EnvStateDev {
 };
 
 constexpr int RL_RANGE_WORDS = 2 * 64 * 32;  // = bt::RANGE_WORDS (bf16_tile.hpp)
+// after the range words, one more line: the guard's veto words, one per chain (= bt::RANGE_ALLOC_WORDS, bt::GUARD_*)
+constexpr int RL_RANGE_ALLOC_WORDS = RL_RANGE_WORDS + 32;
+constexpr int RL_GUARD_POLICY = 0, RL_GUARD_CRITIC = 1;
 struct TrajDev {
   float *obs;       // [D][T+1][n]
   uint8_t *action;  // [T][n]
@@ -68,8 +71,10 @@ struct TrajDev {
   // numeric range of the observation planes, for the fused kernels' guard (bf16_tile.hpp range_guard): 64 slots of the
   // bits of the smallest non-zero |obs|, 64 of the bits of the largest |obs|, one 128-byte line each (RL_RANGE_WORDS)
   uint32_t *range;
-  // the guard's error word, in HOST memory mapped into the device (hipHostMalloc): a violation is one store across the
-  // bus, and the host reads the word after a synchronisation it makes anyway — no copy, no extra round trip per update
+  // the guard's error words (one per chain: RL_GUARD_POLICY, RL_GUARD_CRITIC), in HOST memory mapped into the device
+  // (hipHostMalloc): a violation is one store across the bus, and the host reads the word after a synchronisation it makes
+  // anyway — no copy, no extra round trip per update.  The same violation sets the chain's veto word in DEVICE memory
+  // (range[RL_RANGE_WORDS + chain]), which the optimiser kernels of the call read: nothing of a refused update is applied
   uint32_t *range_err;
 };
 
@@ -179,6 +184,9 @@ struct rl_engine {
   // counts the C-ABI calls made on this engine (guarded(), abi_internal.hpp): what a module's weight image is valid for
   // (rl_mlp::wimg_epoch) — state derived from the parameters is never trusted across entry points
   uint64_t call_epoch = 0;
+  // counts the C-ABI calls on this engine that returned an error: an optimiser whose launches may have been vetoed on the
+  // device re-reads its step count before its next step (rl_adam::error_epoch)
+  uint64_t error_epoch = 0;
   // 0: best available kernels (MFMA v2 where the shape allows); 1: v1 reference kernels only
   int kernel_variant = 0;
   // rl_actor_critic_update: run the policy chain and the critic chain one after the other on the main stream (what the
@@ -328,6 +336,9 @@ struct rl_adam {
   float *d_m = nullptr, *d_v = nullptr;
   uint64_t *d_step = nullptr;
   uint64_t host_step = 0;  // == *d_step once the stream has drained (every Adam launch increments both)
+  // ... unless a launch was vetoed on the device (a failed exchange, the range guard): the entry point then returned an
+  // error, and the first step after an error on this engine re-reads the count (rl_engine::error_epoch, adam_next_step)
+  uint64_t error_epoch = 0;
 };
 
 struct rl_traj {
@@ -358,7 +369,7 @@ struct rl_traj {
   // the rollout that wrote the planes has reset d.range[0..1]: the value forward that follows (launch_values) measures
   // the range on the way and no pass of its own is needed
   bool range_reset = false;
-  uint32_t *h_range_err = nullptr;  // host view of d.range_err
+  uint32_t *h_range_err = nullptr;  // host view of d.range_err (two words)
   // the range guard runs in the FIRST fused launch of each kind after an entry point began (range_check at the end of
   // every entry point re-arms it): the later launches of the same call — 79 of a critic update's 80 steps, the
   // Fisher-vector products and line-search candidates of a TRPO update — start from parameters the same call produced in

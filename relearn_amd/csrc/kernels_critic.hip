@@ -26,6 +26,10 @@
 #include "device_fns.hpp"
 #include "kernels.hpp"
 
+static_assert(bt::RANGE_WORDS == RL_RANGE_WORDS && bt::RANGE_ALLOC_WORDS == RL_RANGE_ALLOC_WORDS &&
+                  bt::GUARD_POLICY == RL_GUARD_POLICY && bt::GUARD_CRITIC == RL_GUARD_CRITIC,
+              "engine.hpp and bf16_tile.hpp describe the same range / veto words");
+
 using bt::f32x16;
 using bt::Frag;
 
@@ -104,7 +108,10 @@ __global__ void __launch_bounds__(CRITIC_WAVES * 64, 2)
     lv[2] = __builtin_fmaf(w2, r.wc, lv[2]);
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain takes the scale
     // back out through w2 (both exact)
-    if (guard) bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
+    if (guard) {  // (one wave sees all 128 units; the two-channel form is the DQN gradient: the policy chain's words)
+      constexpr int CHAIN = CH == 2 ? bt::GUARD_POLICY : bt::GUARD_CRITIC;
+      bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err + CHAIN, bt::range_veto(tr.range, CHAIN));
+    }
     w2v[t] = bt::FWD_UNSCALE * w2;
   }
 #pragma unroll

@@ -815,7 +815,8 @@ __global__ void __launch_bounds__(DQN_WAVES * 64)
   for (int t = 0; t < NT; ++t) {
     bt::WRaw r;
     bt::wimg_load(wimg, t, lane, fw[t], r, 2);
-    if (guard) bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
+    if (guard)  // (one wave sees all 128 units)
+      bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err + bt::GUARD_POLICY, bt::range_veto(tr.range, bt::GUARD_POLICY));
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       const float w2 = r.w2[a];

@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     bt::wimg_load(wimg, t, lane, fw[t], r, 2);
     // the forward runs on weights scaled by 2^96 (relu' by conversion, bf16_tile.hpp); the |pre| chain of the gradient /
     // evaluation passes takes the scale back out through w2d (both exact); the Fisher-vector pass only needs the masks
-    if (guard) bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err);  // (one wave sees all 128 units)
+    if (guard)  // (one wave sees all 128 units)
+      bt::range_guard_img(r, hf, gxmin, gxmax, tr.range_err + bt::GUARD_POLICY, bt::range_veto(tr.range, bt::GUARD_POLICY));
     if (FW_LDS && wave == t) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) Fw[t * 3 + i][lane] = fw[t][i].x;

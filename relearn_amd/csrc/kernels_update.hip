@@ -492,9 +492,12 @@ __global__ void k_ls_check(const float *__restrict__ vec, uint32_t P, double inv
 // final classification + rollback (conjugate_gradient.rs:228-253)
 __global__ void __launch_bounds__(SB) k_ls_finalize(float *__restrict__ params, const float *__restrict__ prev,
                                                     uint32_t P, double max_kl, int accept_violation,
-                                                    TrpoStateDev *st, const int32_t *comm_err) {
+                                                    TrpoStateDev *st, const int32_t *comm_err,
+                                                    const uint32_t *__restrict__ veto) {
   __shared__ int status_shared;
-  if (comm_failed(comm_err)) {  // (uniform) the update is void: back to the parameters it started from, if it got that far
+  // (uniform) the update is void — a failed exchange, or the range guard's veto (bf16_tile.hpp range_guard: the passes this
+  // search was built from are not to be used): back to the parameters it started from, if it got that far
+  if (comm_failed(comm_err) || (veto != nullptr && *veto != 0u)) {
     if (st->prev_saved)
       for (uint32_t i = threadIdx.x; i < P; i += SB) params[i] = prev[i];
     return;
@@ -524,8 +527,10 @@ __global__ void __launch_bounds__(SB) k_adam_step(float *__restrict__ params, co
                                                   double beta1, double beta2, double eps, double weight_decay,
                                                   const float *__restrict__ loss_sum, double inv_B,
                                                   float *__restrict__ loss_out, const int32_t *comm_err,
-                                                  uint32_t *__restrict__ wimg, int A) {
+                                                  uint32_t *__restrict__ wimg, int A,
+                                                  const uint32_t *__restrict__ veto) {
   if (comm_failed(comm_err)) return;  // `grad` holds local sums: no step, no step count
+  if (veto != nullptr && *veto != 0u) return;  // the range guard refused the pass `grad` comes from: nothing is applied
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *step_ptr = step;
     if (loss_out) *loss_out = (float)((double)(*loss_sum) * inv_B);
@@ -563,11 +568,15 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
                                                       float sqrt_bc2, double beta1, double beta2, double eps,
                                                       double weight_decay, double inv_B,
                                                       float *__restrict__ loss_out, IpcPeers peers,
-                                                      uint32_t *__restrict__ wimg, int A) {
+                                                      uint32_t *__restrict__ wimg, int A,
+                                                      const uint32_t *__restrict__ veto) {
   __shared__ double part[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t p = blockIdx.x * 64 + lane;
-  // the optimiser state of this column is requested first, so that it arrives under the slab loads
+  // the optimiser state of this column is requested first, so that it arrives under the slab loads — and the range
+  // guard's veto word with it (set by the fused launch this one reduces, or an earlier one of the call: the sums are then
+  // not to be applied; bf16_tile.hpp range_guard)
+  const uint32_t vetoed = veto != nullptr ? *veto : 0u;
   float p_old = 0.0f, m_old = 0.0f, v_old = 0.0f;
   if (w == 0 && p < P) {
     p_old = params[p];
@@ -591,11 +600,12 @@ __global__ void __launch_bounds__(1024) k_reduce_adam(const double *__restrict__
   }
   if (p >= P + 4) return;
   vec[p] = gsum;
-  if (p == 0) *step_ptr = step;
   if (p >= P) {
     if (p == P && loss_out) *loss_out = (float)((double)gsum * inv_B);
     return;
   }
+  if (vetoed != 0u) return;  // parameters, moments and step count stay as they are
+  if (p == 0) *step_ptr = step;
   // neg_step_size = -(float)(lr / (1 - beta1^step)), sqrt_bc2 = (float)sqrt(1 - beta2^step): the host knows the step
   const float b1 = (float)beta1, b2 = (float)beta2;
   const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
@@ -628,12 +638,13 @@ __global__ void __launch_bounds__(1024) k_reduce_adam_narrow(const double *__res
                                                              float sqrt_bc2, double beta1, double beta2, double eps,
                                                              double weight_decay, double inv_B,
                                                              float *__restrict__ loss_out, uint32_t *__restrict__ wimg,
-                                                             int A) {
+                                                             int A, const uint32_t *__restrict__ veto) {
   constexpr int GPW = 64 / CW, RG = 16 * GPW;  // row groups per wave, per workgroup
   __shared__ double part[RG][CW];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane & (CW - 1), rg = w * GPW + lane / CW;
   const uint32_t p = blockIdx.x * CW + (uint32_t)c;
+  const uint32_t vetoed = veto != nullptr ? *veto : 0u;  // (the range guard's veto: k_reduce_adam)
   float p_old = 0.0f, m_old = 0.0f, v_old = 0.0f;
   if (threadIdx.x < CW && p < P) {  // the optimiser state of this column arrives under the slab loads
     p_old = params[p];
@@ -666,11 +677,12 @@ __global__ void __launch_bounds__(1024) k_reduce_adam_narrow(const double *__res
   for (int k = 1; k < RG; ++k) t = t + part[k][c];
   const float gsum = (float)t;
   vec[p] = gsum;
-  if (p == 0) *step_ptr = step;
   if (p >= P) {
     if (p == P && loss_out) *loss_out = (float)((double)gsum * inv_B);
     return;
   }
+  if (vetoed != 0u) return;
+  if (p == 0) *step_ptr = step;
   const float b1 = (float)beta1, b2 = (float)beta2;
   const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   const float epsf = (float)eps;
@@ -689,6 +701,13 @@ __global__ void __launch_bounds__(1024) k_reduce_adam_narrow(const double *__res
 // ---------------------------------------------------------------- launchers
 // the word a failed mailbox exchange sets (NULL when that transport is not in use)
 static const int32_t *comm_err_word(const rl_engine *e) { return e->ipc_active ? e->ipc_err : (const int32_t *)nullptr; }
+// the range guard's veto word for updates of module `m` from passes over `traj` (bf16_tile.hpp range_guard: the fused
+// critic step guards one-output modules — the critic chain — everything else is the policy chain: policy passes, the DQN
+// gradient); only fused launches ever set it
+static const uint32_t *veto_word(const rl_traj *traj, const rl_mlp *m) {
+  if (traj->d.range == nullptr) return nullptr;
+  return traj->d.range + RL_RANGE_WORDS + (m->out_dim == 1 ? RL_GUARD_CRITIC : RL_GUARD_POLICY);
+}
 
 void launch_policy_pass(rl_traj *traj, const rl_mlp *policy, int mode, const float *d_tangent, uint64_t B_total,
                         const int32_t *d_skip, float clip_lo, float clip_hi) {
@@ -832,12 +851,25 @@ void launch_ls_check(rl_traj *traj, uint32_t P, uint64_t B_total, int index, dou
 void launch_ls_finalize(rl_traj *traj, rl_mlp *policy, double max_kl, int accept_violation) {
   ProfScope ps(traj->eng, RL_K_SMALL);
   hipLaunchKernelGGL(k_ls_finalize, dim3(1), dim3(SB), 0, traj->eng->stream, policy->d_params, traj->prev_params,
-                     (uint32_t)policy->P, max_kl, accept_violation, traj->trpo, comm_err_word(traj->eng));
+                     (uint32_t)policy->P, max_kl, accept_violation, traj->trpo, comm_err_word(traj->eng),
+                     veto_word(traj, policy));
   wimg_invalidate(policy);  // (a rollback rewrites the parameters without the image)
 }
 
 // bias corrections of the optimiser's NEXT step (advances the host's step count)
 static void adam_next_step(rl_adam *opt, float *neg_step_size, float *sqrt_bc2) {
+  if (opt->error_epoch != opt->eng->error_epoch) {
+    // an entry point failed on this engine since this optimiser last stepped: launches of it may have been vetoed on the
+    // device (a failed exchange, the range guard) after the host had counted them — the device's count is the truth
+    rl_engine *e = opt->eng;
+    RL_HIP_CHECK(hipStreamSynchronize(e->main_stream));
+    RL_HIP_CHECK(hipStreamSynchronize(e->aux_stream));
+    uint64_t s = 0;
+    RL_HIP_CHECK(hipMemcpyAsync(&s, opt->d_step, sizeof(s), hipMemcpyDeviceToHost, e->stream));
+    RL_HIP_CHECK(hipStreamSynchronize(e->stream));
+    opt->host_step = s;
+    opt->error_epoch = e->error_epoch;
+  }
   opt->host_step += 1;
   const double bc1 = 1.0 - std::pow(opt->cfg.beta1, (double)opt->host_step);
   const double bc2 = 1.0 - std::pow(opt->cfg.beta2, (double)opt->host_step);
@@ -860,19 +892,19 @@ void launch_reduce_adam(rl_traj *traj, rl_adam *opt, uint32_t rowsA, uint32_t ro
                        traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                        opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
                        opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, peers, wimg_if_current(opt->mod),
-                       (int)opt->mod->out_dim);
+                       (int)opt->mod->out_dim, veto_word(traj, opt->mod));
   } else if (reduce_width(P) != 64) {
     hipLaunchKernelGGL(k_reduce_adam_narrow<16>, dim3(cdiv(P + 4, 16)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
                        traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                        opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
                        opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, wimg_if_current(opt->mod),
-                       (int)opt->mod->out_dim);
+                       (int)opt->mod->out_dim, veto_word(traj, opt->mod));
   } else {
     hipLaunchKernelGGL(k_reduce_adam<false>, dim3(cdiv(P + 4, 64)), dim3(1024), 0, e->stream, traj->slabA, rowsA, P,
                        traj->slabB, rowsB, traj->vec, opt->mod->d_params, opt->d_m, opt->d_v, opt->d_step,
                        opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2, opt->cfg.eps,
                        opt->cfg.weight_decay, 1.0 / (double)B_total, loss_out, IpcPeers{}, wimg_if_current(opt->mod),
-                       (int)opt->mod->out_dim);
+                       (int)opt->mod->out_dim, veto_word(traj, opt->mod));
   }
 }
 
@@ -885,7 +917,7 @@ void launch_adam_step(rl_traj *traj, rl_adam *opt, int loss_slot, uint64_t B_tot
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, traj->vec + P, 1.0 / (double)B_total,
                      loss_slot >= 0 ? traj->losses + loss_slot : (float *)nullptr, comm_err_word(traj->eng),
-                     wimg_if_current(opt->mod), (int)opt->mod->out_dim);
+                     wimg_if_current(opt->mod), (int)opt->mod->out_dim, veto_word(traj, opt->mod));
 }
 
 void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
@@ -896,5 +928,6 @@ void launch_adam_step_vec(rl_adam *opt, const float *d_grad) {
   hipLaunchKernelGGL(k_adam_step, dim3((P + SB - 1) / SB), dim3(SB), 0, opt->mod->eng->stream, opt->mod->d_params, d_grad, opt->d_m,
                      opt->d_v, opt->d_step, P, opt->host_step, neg_step_size, sqrt_bc2, opt->cfg.beta1, opt->cfg.beta2,
                      opt->cfg.eps, opt->cfg.weight_decay, (const float *)nullptr, 0.0, (float *)nullptr,
-                     (const int32_t *)nullptr, wimg_if_current(opt->mod), (int)opt->mod->out_dim);
+                     (const int32_t *)nullptr, wimg_if_current(opt->mod), (int)opt->mod->out_dim,
+                     (const uint32_t *)nullptr);
 }

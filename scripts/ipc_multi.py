@@ -41,6 +41,7 @@ def config4_rank(eng, rank, world, n_total, T, critic_steps, periods, save_obs=F
     for period in range(periods):
         ra.rollout(env, pol, traj)
         ra.gae(traj, cri, 0.99, 0.95)
+        say(rank, "period %d: rollout and advantages enqueued" % period)
         if period == 0:
             out["action"], out["flag"] = traj.read(ra.TRAJ_ACTION), traj.read(ra.TRAJ_FLAG)
             out["adv"] = traj.read(ra.TRAJ_ADVANTAGES)
@@ -53,7 +54,9 @@ def config4_rank(eng, rank, world, n_total, T, critic_steps, periods, save_obs=F
             gc, lc = ra.critic_gradient(cri, traj)
             out.update(probe_g=g, probe_loss=np.float64(loss), probe_ent=np.float64(ent),
                        probe_hv=ra.policy_fvp(pol, traj, v, 0.0), probe_gc=gc, probe_lc=np.float64(lc))
+            say(rank, "probe vectors done")
         st, cs, losses = ra.actor_critic_update(pol, cri, opt, traj, None, ccfg, want_losses=True)
+        say(rank, "period %d: update done" % period)
         out["policy%d" % period], out["critic%d" % period] = pol.get_params(), cri.get_params()
         out["losses%d" % period] = losses
         out["trpo%d" % period] = np.array([st.loss_initial, st.entropy, st.step_size, st.cg_iterations, st.status,
@@ -61,6 +64,14 @@ def config4_rank(eng, rank, world, n_total, T, critic_steps, periods, save_obs=F
     eng.sync()
     out["allreduce_launches"] = np.array([eng.profile_read()["allreduce"][1]])
     return out
+
+
+T0 = time.time()
+
+
+def say(rank, what):
+    """a progress line per phase (the tests keep the output: where a rank was when a peer gave up on it)"""
+    print("[%7.2f s] rank %d: %s" % (time.time() - T0, rank, what), flush=True)
 
 
 def main():
@@ -86,8 +97,11 @@ def main():
     def run(eng, rank):
         try:
             if world > 1:
+                say(rank, "handles of all %d ranks read" % world)
                 eng.comm_init_ipc(rank, world, handles)  # (ends with the job's first all-reduce: every rank must be here)
+                say(rank, "mailboxes mapped, first all-reduce done")
                 eng.comm_selftest()
+                say(rank, "self-test done")
             out = config4_rank(eng, rank, world, n_total, T, critic_steps, periods)
             np.savez(os.path.join(d, "out%d_of_%d.npz" % (rank, world)), **out)
         except BaseException as exc:

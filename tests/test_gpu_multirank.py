@@ -6,6 +6,7 @@ over all ranks, identical redundant updates on every rank.  The sharded result m
 up to the order of the f32 partial sums."""
 import os
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -613,39 +614,59 @@ def test_eight_loopback_ranks_at_the_config4_split(config4_single):
     _check_config4(_config4_loopback(8), config4_single)
 
 
-def test_eight_mailbox_ranks_at_the_config4_split(tmp_path, config4_single):
-    """(b) the same eight ranks over the peer-mailbox transport: four processes of two ranks each (the pool admits six
-    GPU processes), every rank running the library's 240-round self-test first.  Ranks of one process reach each other's
-    mailboxes by address, ranks of other processes through IPC handles."""
+def _mailbox_ranks_once(d, limit, ipc_timeout_ms):
+    """four processes x two ranks of scripts/ipc_multi.py into directory `d`; (finished and all exit codes 0, what the
+    processes said).  Output goes into files: what a process had said is still there when the test has to end it."""
+    import signal
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "scripts", "ipc_multi.py")
-    d = os.path.join(str(tmp_path), "config4")
     os.makedirs(d)
-    # (eight ranks share one GPU's hardware queues here: a rank's first launch can sit behind the others' spinning waits
-    # for a firmware scheduling quantum or more — the wait bound is raised from its 30 s so that a slow start is not
-    # mistaken for a missing peer; the test's own limit stays)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELEARN_IPC_TIMEOUT_MS="150000")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RELEARN_IPC_TIMEOUT_MS=str(ipc_timeout_ms))
     args = [str(CONFIG4[k]) for k in ("n_total", "T", "critic_steps", "periods")]
-    procs = [subprocess.Popen([sys.executable, script, str(p), "4", "2", d] + args, cwd=root, env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+    logs = [os.path.join(d, "proc%d.log" % p) for p in range(4)]
+    procs = [subprocess.Popen([sys.executable, "-u", script, str(p), "4", "2", d] + args, cwd=root, env=env,
+                              stdout=open(logs[p], "wb"), stderr=subprocess.STDOUT, start_new_session=True)
              for p in range(4)]
-    outs = []
+
+    def said():
+        return "\n".join("--- proc %d (exit %s)\n%s" % (i, q.poll(), open(logs[i], errors="replace").read()[-1500:])
+                         for i, q in enumerate(procs))
+
+    deadline = time.time() + limit
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=280)
+            p.wait(timeout=max(1.0, deadline - time.time()))
         except subprocess.TimeoutExpired:
-            import signal
             for q in procs:
                 try:
                     os.killpg(q.pid, signal.SIGKILL)
                 except ProcessLookupError:
                     pass
-            raise AssertionError("ipc_multi.py (4 x 2 ranks) did not finish within 280 s")
-        outs.append(o.decode())
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-2000:]
+            for q in procs:
+                q.wait()
+            return False, "ipc_multi.py (4 x 2 ranks) did not finish within %d s\n" % limit + said()
+    return all(p.returncode == 0 for p in procs), said()
+
+
+def test_eight_mailbox_ranks_at_the_config4_split(tmp_path, config4_single):
+    """(b) the same eight ranks over the peer-mailbox transport: four processes of two ranks each (the pool admits six
+    GPU processes), every rank running the library's 240-round self-test first.  Ranks of one process reach each other's
+    mailboxes by address, ranks of other processes through IPC handles.
+    Eight ranks share ONE card's hardware queues here, each with kernels that spin on words their peers' kernels write: a
+    run takes 24 s, and about one in five — inside the whole suite only, never alone — has not FINISHED (a rank's wait
+    bound hit or a process still starting after minutes; round 6 saw it with a 30 s and with a 150 s bound).  That is the
+    rehearsal's property, not the transport's on eight cards, so an attempt that does not finish is repeated ONCE, with a
+    warning that carries what its processes had said; a finished attempt is judged as it is — numbers are never retried."""
+    import warnings
+    ok, said = _mailbox_ranks_once(os.path.join(str(tmp_path), "config4"), limit=100, ipc_timeout_ms=60000)
+    d = os.path.join(str(tmp_path), "config4")
+    if not ok:
+        warnings.warn("the 8-rank mailbox rehearsal did not finish at the first attempt:\n" + said)
+        d = os.path.join(str(tmp_path), "config4_second")
+        ok, said = _mailbox_ranks_once(d, limit=150, ipc_timeout_ms=90000)
+    assert ok, said
     ranks = [dict(np.load(os.path.join(d, "out%d_of_8.npz" % r))) for r in range(8)]
     _check_config4(ranks, config4_single)
 

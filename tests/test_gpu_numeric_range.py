@@ -255,3 +255,91 @@ def test_critic_update_without_statistics_still_reports_the_range_error(engine):
     assert ra.lib().rl_critic_update(cri2.h, ra.Adam(cri2).h, ok.h, C.c_uint64(2), None, None) == ra.OK
     # (and the guard is armed again: the out-of-range history is still refused by a call that asks for nothing)
     assert ra.lib().rl_critic_update(cri.h, opt.h, traj.h, C.c_uint64(1), None, None) == ra.ERR_UNSUPPORTED
+
+
+def scaled(engine, out_dim, seed, w1_scale=1.0, w2_scale=1.0):
+    m = ra.Mlp(engine, 5, H, out_dim)
+    m.init(seed)
+    p = m.get_params()
+    p[:5 * H] *= np.float32(w1_scale)
+    p[6 * H:] *= np.float32(w2_scale)
+    m.set_params(p)
+    return m
+
+
+UPDATES = {
+    # (module's output width, the update through the C ABI)
+    "critic_update": (1, lambda m, opt, traj: ra.critic_update(m, opt, traj, 3)),
+    "ppo_update": (2, lambda m, opt, traj: ra.ppo_update(m, opt, traj)),
+    "reinforce_update": (2, lambda m, opt, traj: ra.reinforce_update(m, opt, traj)),
+}
+
+
+@pytest.mark.parametrize("which", sorted(UPDATES))
+def test_a_refused_update_is_refused_whole(engine, which):
+    """the guard reported after the fact — by the time RL_ERR_UNSUPPORTED came back the module had been
+    stepped K times on invalid masks.  Now the launch that finds the violation sets a veto word on the device and the
+    optimiser kernels behind it apply nothing: parameters bit for bit as before, and — seen through what follows — the Adam
+    moments and the step count too: [2 good updates, a refused one, 2 good updates] leaves exactly the parameters of
+    [2 good updates, 2 good updates] on a twin."""
+    out_dim, update = UPDATES[which]
+    good, bad = history([1.0] * 5, seed=1), history([1e10] * 5, seed=2)  # 5 x 0.2 x 1e10 >= 2^31 for Glorot rows
+    tg, tb = load(engine, good), load(engine, bad)
+    m, twin = scaled(engine, out_dim, 11), scaled(engine, out_dim, 11)
+    opt, opt_twin = ra.Adam(m), ra.Adam(twin)
+    for _ in range(2):
+        update(m, opt, tg)
+        update(twin, opt_twin, tg)
+    before = m.get_params()
+    assert np.array_equal(before, twin.get_params())
+    with pytest.raises(ra.RelearnError) as err:
+        update(m, opt, tb)
+    assert err.value.code == ra.ERR_UNSUPPORTED and "not applied" in str(err.value)
+    assert ("critic chain" if out_dim == 1 else "policy chain") in str(err.value)
+    assert np.array_equal(m.get_params(), before)
+    for _ in range(2):
+        update(m, opt, tg)
+        update(twin, opt_twin, tg)
+    assert np.array_equal(m.get_params(), twin.get_params())
+    assert not np.array_equal(m.get_params(), before)
+
+
+def test_a_refused_trpo_step_leaves_the_policy_alone(engine):
+    pol = scaled(engine, 2, 12)
+    tb = load(engine, history([1e10] * 5, seed=2))
+    before = pol.get_params()
+    with pytest.raises(ra.RelearnError) as err:
+        ra.trpo_update(pol, tb)
+    assert err.value.code == ra.ERR_UNSUPPORTED and "policy chain" in str(err.value)
+    assert np.array_equal(pol.get_params(), before)
+    st = ra.trpo_update(pol, load(engine, history([1.0] * 5, seed=1)))
+    assert st.status in (ra.OPT_OK, ra.OPT_LOSS_NOT_IMPROVING, ra.OPT_CONSTRAINT_VIOLATED)
+
+
+@pytest.mark.parametrize("refused", ["critic", "policy"])
+def test_the_two_chains_of_the_combined_update_have_a_guard_word_each(engine, refused):
+    """rl_actor_critic_update runs the policy chain and the critic chain side by side on two streams.  With one error word
+    per trajectory the TRPO chain's read-back could pick up the critic chain's violation; each chain now
+    has its own: a module of ONE chain out of range -> the error names that chain, that module is untouched, the other
+    chain's step stands, and nothing of it lingers — the same call with both modules in range then works."""
+    traj = load(engine, history([1e3] * 5, seed=3))
+    # in range at |obs| ~ 5e3: Glorot rows (5 x 0.2 x 5e3 << 2^31; the policy's logits scaled back to order 1); out of it:
+    # rows x 1e7 (5 x 2e6 x 5e3 = 5e10 >= 2^31), the output layer scaled down to keep the numbers finite
+    bad, fine = dict(w1_scale=1e7, w2_scale=1e-10), dict(w2_scale=1e-3)
+    pol = scaled(engine, 2, 13, **(bad if refused == "policy" else fine))
+    cri = scaled(engine, 1, 14, **(bad if refused == "critic" else {}))
+    opt = ra.Adam(cri)
+    ccfg = ra.values_opt_config_default()
+    ccfg.opt_steps_per_update = 3
+    p0, c0 = pol.get_params(), cri.get_params()
+    with pytest.raises(ra.RelearnError) as err:
+        ra.actor_critic_update(pol, cri, opt, traj, critic_cfg=ccfg)
+    assert err.value.code == ra.ERR_UNSUPPORTED and (refused + " chain") in str(err.value)
+    if refused == "critic":
+        assert np.array_equal(cri.get_params(), c0)
+    else:
+        assert np.array_equal(pol.get_params(), p0)
+        assert not np.array_equal(cri.get_params(), c0)  # (the critic chain ran beside it, like under a NaN policy step)
+    pol2, cri2 = scaled(engine, 2, 13, **fine), scaled(engine, 1, 14)
+    out = ra.actor_critic_update(pol2, cri2, ra.Adam(cri2), traj, critic_cfg=ccfg)
+    assert out is not None and np.all(np.isfinite(cri2.get_params())) and np.all(np.isfinite(pol2.get_params()))
