@@ -659,9 +659,9 @@ def test_eight_mailbox_ranks_at_the_config4_split(tmp_path, config4_single):
     """(b) the same eight ranks over the peer-mailbox transport: four processes of two ranks each (the pool admits six
     GPU processes), every rank running the library's 240-round self-test first.  Ranks of one process reach each other's
     mailboxes by address, ranks of other processes through IPC handles.
-    Eight ranks share ONE card's hardware queues here, each with kernels that spin on words their peers' kernels write: a
-    run takes 24 s, and about one in five — inside the whole suite only, never alone — has not FINISHED (a rank's wait
-    bound hit or a process still starting after minutes; round 6 saw it with a 30 s and with a 150 s bound).  That is the
+    Eight ranks share ONE card's hardware queues here, each with kernels that spin on words their peers' kernels write: the
+    job itself takes about a second, and about one in five — inside the whole suite only, never alone — has not FINISHED
+    (a rank's wait bound hit or a process still starting after minutes; round 6 saw it with a 30 s and with a 150 s bound).  That is the
     rehearsal's property, not the transport's on eight cards, so an attempt that does not finish is repeated ONCE, with a
     warning that carries what its processes had said; a finished attempt is judged as it is — numbers are never retried."""
     import warnings
